@@ -1,0 +1,206 @@
+"""CPU oracle for the DSVGP minibatch-ELBO hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-torch (CPU) restatement of what the reference computes for one
+training step of ``directional_vi.train_gp`` -- it is the *checker* for the HIP path and
+the ``cpu_baseline`` leg of ``bench.py``.  Nothing under ``gp-derivatives-variational-inference_amd/``
+may import it; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py`` do.
+
+Parity status
+-------------
+* Rows a1/a2 (``RBFKernelDirectionalGrad.forward``) are PINNED: ``tests/golden/kernel_*.npz`` were
+  produced by importing the reference kernel file itself (``oracle/make_golden.py``) and
+  ``tests/test_oracle_golden.py`` checks :func:`kernel_matrix` / :func:`kernel_diag` against them.
+* Rows a3-a8 (ScaleKernel, constraints, jitter, Cholesky/solve composition, variational
+  distribution, Gaussian likelihood, ELBO, KL) live in the un-vendored third-party dependency
+  ``gpytorch==1.4.0`` (reference ``graphite_environment.yml:101``), which is not installable here.
+  They are restated from its published algorithm and anchored on the reference call sites cited
+  below.  The reference's own tests hold no golden values for them: **parity unpinned** for those rows.
+
+All functions work in whatever dtype their inputs have; :func:`elbo_forward` additionally
+implements the reference's mixed precision (model dtype + fp64 Cholesky / triangular solves).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+KZZ_JITTER = 1e-3      # LazyTensor.add_jitter() default, reference DGVS.py:144
+KXX_JITTER = 1e-4      # data_data_covar.add_jitter(1e-4), reference DGVS.py:197,203
+NOISE_FLOOR = 1e-4     # GaussianLikelihood noise constraint GreaterThan(1e-4) (gpytorch 1.4.0)
+CHOL_JITTER = 1e-6     # settings.cholesky_jitter.value() (float default), reference DGVS.py:74
+CHOL_TRIES = 3         # psd_safe_cholesky max_tries (gpytorch 1.4.0)
+MIN_VARIANCE = 1e-6    # MultivariateNormal.variance clamp (gpytorch settings.min_variance, float)
+
+
+# --------------------------------------------------------------------------------------
+# a1 / a2: RBFKernelDirectionalGrad
+# --------------------------------------------------------------------------------------
+def normalize_rows(v):
+    """reference RBFKernelDirectionalGrad.py:57-58 -- directions are L2-normalised per call."""
+    return v / v.norm(dim=1, keepdim=True)
+
+
+def kernel_matrix(x1, x2, v1, v2, lengthscale):
+    """Dense interleaved block kernel, reference RBFKernelDirectionalGrad.py:41-108.
+
+    Row ``i*(p+1)`` is the function value at ``x1[i]``, rows ``i*(p+1)+1+a`` the derivative along
+    the a-th (normalised) direction of point i; columns likewise for ``x2``/``v2``.
+    Written pair-wise (difference form) instead of the reference's block-assemble-then-shuffle.
+    """
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    p = v1.shape[0] // n1
+    assert v2.shape[0] // n2 == p, "v1 and v2 must contain same number of directions"
+    ell = lengthscale.reshape(()) if torch.is_tensor(lengthscale) else lengthscale
+    V1 = normalize_rows(v1).reshape(n1, p, d)
+    V2 = normalize_rows(v2).reshape(n2, p, d)
+    r = (x1[:, None, :] - x2[None, :, :]) / ell                    # :67-68
+    k = torch.exp(-0.5 * (r * r).sum(-1))                          # :71-73
+    u = torch.einsum("ijd,iad->ija", r, V1)                        # r . v1_{i,a}
+    w = torch.einsum("ijd,jbd->ijb", r, V2)                        # r . v2_{j,b}
+    G = torch.einsum("iad,jbd->iajb", V1, V2)
+    K = x1.new_zeros(n1, p + 1, n2, p + 1)
+    K[:, 0, :, 0] = k
+    K[:, 0, :, 1:] = w * k[..., None] / ell                        # :77-83
+    K[:, 1:, :, 0] = (-u * k[..., None] / ell).permute(0, 2, 1)    # :86-93
+    uw = u.permute(0, 2, 1)[:, :, :, None] * w[:, None, :, :]      # [i,a,j,b]
+    K[:, 1:, :, 1:] = (G - uw) * k[:, None, :, None] / ell ** 2    # :97-102
+    return K.reshape(n1 * (p + 1), n2 * (p + 1))                   # interleaved, :105-107
+
+
+def kernel_diag(n, p, lengthscale, dtype=torch.float64):
+    """diag=True branch, reference RBFKernelDirectionalGrad.py:110-119."""
+    ell = lengthscale.reshape(()) if torch.is_tensor(lengthscale) else torch.tensor(lengthscale, dtype=dtype)
+    dg = torch.ones(n, p + 1, dtype=ell.dtype if torch.is_tensor(ell) else dtype)
+    dg = dg * torch.cat([torch.ones(1, dtype=dg.dtype), (1.0 / ell ** 2).expand(p).to(dg.dtype)])
+    return dg.reshape(n * (p + 1))
+
+
+# --------------------------------------------------------------------------------------
+# a3-a8: one ELBO evaluation
+# --------------------------------------------------------------------------------------
+def constrained(params):
+    """softplus constraints (gpytorch Positive / GreaterThan(1e-4)); raw inits are 0."""
+    ell = F.softplus(params["raw_lengthscale"]).reshape(())
+    s = F.softplus(params["raw_outputscale"]).reshape(())
+    noise = F.softplus(params["raw_noise"]).reshape(()) + NOISE_FLOOR
+    return ell, s, noise
+
+
+def psd_safe_cholesky(K):
+    """gpytorch.utils.cholesky.psd_safe_cholesky (1.4.0): retry with jitter*10^i, i=0..2."""
+    L, info = torch.linalg.cholesky_ex(K)
+    if int(info) == 0:
+        return L
+    prev = 0.0
+    Kp = K.clone()
+    for i in range(CHOL_TRIES):
+        new = CHOL_JITTER * (10 ** i)
+        Kp.diagonal().add_(new - prev)
+        prev = new
+        L, info = torch.linalg.cholesky_ex(Kp)
+        if int(info) == 0:
+            return L
+    raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %g" % prev)
+
+
+def predictive(params, x, D, solve_dtype=torch.float64):
+    """DirectionalGradVariationalStrategy.forward, reference DGVS.py:89-208.
+
+    Returns (mu, var) with ``var = diag(Sigma)`` of q(f) (no likelihood noise)."""
+    Z, V = params["inducing_points"], params["inducing_directions"]
+    m = params["variational_mean"]
+    L_S = torch.tril(params["chol_variational_covar"])            # CholeskyVariationalDistribution mask
+    c = params["constant"].reshape(())
+    ell, s, _ = constrained(params)
+    M, d = Z.shape
+    p = V.shape[0] // M
+    B = x.shape[0]
+    assert D.shape[0] // B == p, "Need minibatch dim to be same as number of directions for kernel"
+    dt = x.dtype
+    K_ZX = s * kernel_matrix(Z, x, V, D, ell)                      # :128-132
+    K_XZ = s * kernel_matrix(x, Z, D, V, ell)                      # :133-137
+    K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
+    K_ZZ = K_ZZ + KZZ_JITTER * torch.eye(K_ZZ.shape[0], dtype=dt)  # :140-144
+    dg = s * kernel_diag(B, p, ell).to(dt)                         # :145-149 (diag only)
+    L = psd_safe_cholesky(K_ZZ.to(solve_dtype))                    # :72-75,172
+    A = torch.linalg.solve_triangular(L, K_ZX.to(solve_dtype), upper=False).to(dt)          # :181
+    A_t = torch.linalg.solve_triangular(L, K_XZ.t().to(solve_dtype), upper=False).to(dt)    # :183
+    mu = A_t.t() @ m + c                                           # :126,188
+    SA = L_S @ (L_S.t() @ A) - A                                   # (S - I) A, :192-194
+    var = dg + KXX_JITTER + (A_t * SA).sum(0)                      # diag of :202-205
+    return mu, var
+
+
+def kl_whitened(m, L_S):
+    """KL(q(u) || N(0, I)); gpytorch kl_mvn_mvn with the whitened prior of DGVS.py:77-87."""
+    Mp = m.shape[0]
+    return 0.5 * ((m * m).sum() + (L_S * L_S).sum() - Mp - torch.log(torch.diagonal(L_S) ** 2).sum())
+
+
+def elbo_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+    """loss = -mll(likelihood(model(x)), y), reference directional_vi.py:245-246.
+
+    ``y`` is the interleaved target vector of length B*(p+1) (:241).  ``global_rows`` lets a
+    data-parallel rank normalise by the global batch (defaults to the local one).
+    Note the reference feeds the *noised* marginal into the mll, so the noise enters twice.
+    """
+    mu, var = predictive(params, x, D, solve_dtype)
+    _, _, noise = constrained(params)
+    L_S = torch.tril(params["chol_variational_covar"])
+    Bp = y.shape[0] if global_rows is None else global_rows
+    varn = (var + noise).clamp_min(MIN_VARIANCE)                   # likelihood(model(x)).variance
+    if mll_type == "ELBO":                                         # GaussianLikelihood.expected_log_prob
+        ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+    elif mll_type == "PLL":                                        # GaussianLikelihood.log_marginal
+        tot = (varn + noise).clamp_min(1e-8)
+        ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
+    else:
+        raise ValueError(mll_type)
+    kl = kl_whitened(params["variational_mean"], L_S)
+    loss = -(ll.sum() / Bp - kl / num_data)
+    return loss, mu, varn
+
+
+PARAM_NAMES = ("inducing_points", "inducing_directions", "variational_mean", "chol_variational_covar",
+               "constant", "raw_outputscale", "raw_lengthscale", "raw_noise")
+
+
+def elbo_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+    """Forward + autograd backward, exactly how the reference gets its gradients (:249)."""
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    loss, mu, varn = elbo_forward(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype)
+    loss.backward()
+    grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps}
+    return loss.detach(), grads, mu.detach(), varn.detach()
+
+
+def init_params(Z, V, dtype=torch.float32, mean_init_std=0.0, generator=None):
+    """Initial parameter set of GPModel / GaussianLikelihood (reference directional_vi.py:25-56,172)."""
+    M = Z.shape[0]
+    p = V.shape[0] // M
+    Mp = M * (p + 1)
+    m = torch.zeros(Mp, dtype=dtype)
+    if mean_init_std:
+        m = m + mean_init_std * torch.randn(Mp, dtype=dtype, generator=generator)
+    return {
+        "inducing_points": Z.to(dtype).clone(),
+        "inducing_directions": V.to(dtype).clone(),
+        "variational_mean": m,
+        "chol_variational_covar": torch.eye(Mp, dtype=dtype),
+        "constant": torch.zeros(1, dtype=dtype),
+        "raw_outputscale": torch.zeros((), dtype=dtype),
+        "raw_lengthscale": torch.zeros(1, 1, dtype=dtype),
+        "raw_noise": torch.zeros(1, dtype=dtype),
+    }
+
+
+# --------------------------------------------------------------------------------------
+# synthetic data of the reference's smoke tests
+# --------------------------------------------------------------------------------------
+def testfun(x):
+    """f(x)=sin(2 pi |x|^2) with gradient, reference tests/testfun.py:4-12 (any d)."""
+    sq = (x ** 2).sum(1)
+    fx = torch.sin(2 * math.pi * sq)
+    gx = 4 * math.pi * torch.cos(2 * math.pi * sq)[:, None] * x
+    return torch.cat([fx[:, None], gx], 1)
