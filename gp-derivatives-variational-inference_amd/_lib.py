@@ -1,0 +1,80 @@
+"""ctypes binding of libdsvgp_hip.so (the C ABI declared in include/dsvgp.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing
+this module raises.  Build it with ``python gp-derivatives-variational-inference_amd/build_ext.py``
+(or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads torch's bundled HIP/rocBLAS/rocSOLVER first so one runtime is shared)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsvgp_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libdsvgp_hip.so not found at %s -- the HIP extension is required (no CPU fallback). "
+        "Run `python gp-derivatives-variational-inference_amd/build_ext.py`." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+_d = C.c_double
+_z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dsvgp.h one to one
+SIGNATURES = {
+    "dsvgp_create": (_i, [C.POINTER(_p)]),
+    "dsvgp_destroy": (_i, [_p]),
+    "dsvgp_set_stream": (_i, [_p, _p]),
+    "dsvgp_version": (C.c_char_p, []),
+    "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
+    "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
+    "dsvgp_packed_width": (_i, [_i]),
+    "dsvgp_pack_points": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "dsvgp_kernel_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _f, _p, _l, _i]),
+    "dsvgp_kernel_diag": (_i, [_p, _i, _i, _p, _p]),
+    "dsvgp_kernel_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "dsvgp_kernel_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "dsvgp_potrf": (_i, [_p, _p, _i, _l, _p]),
+    "dsvgp_add_diag": (_i, [_p, _p, _i, _l, _d]),
+    "dsvgp_trsm_workspace_bytes": (_z, [_i, _i, _i]),
+    "dsvgp_trsm": (_i, [_p, _p, _l, _i, _i, _p, _l, _i, _i, _p, _l, _p, _l, _i, _p, _i]),
+    "dsvgp_gemm": (_i, [_p, _i, _i, _i, _i, _i, _d, _p, _l, _p, _l, _d, _p, _l, _p, _l, _p, _l, _p]),
+    "dsvgp_stats_workspace_bytes": (_z, [_i, _i]),
+    "dsvgp_predictive_stats": (_i, [_p, _p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "dsvgp_likelihood_terms": (_i, [_p, _p, _p, _p, _i, _i, _p, _i, _d, _p, _p, _p, _p]),
+    "dsvgp_abar": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _p, _p, _l]),
+    "dsvgp_rowdot": (_i, [_p, _p, _l, _i, _i, _p, _p]),
+    "dsvgp_kl_terms": (_i, [_p, _p, _p, _l, _i, _d, _p, _p, _p, _l]),
+    "dsvgp_phi_symmetrize": (_i, [_p, _p, _i, _l]),
+    "dsvgp_transpose_f64": (_i, [_p, _p, _l, _i, _i, _p, _l]),
+    "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "dsvgp_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here == header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+# GEMM flags (include/dsvgp.h)
+TRANS_A, TRANS_B = 1, 2
+A_LOWER, A_UPPER, B_LOWER, B_UPPER = 4, 8, 16, 32
+OUT_LOWER, B_IS_FLOAT, CIN_IS_FLOAT = 64, 128, 256
+
+
+class DsvgpError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "matrix not positive definite", -3: "misaligned"}.get(rc)
+        if kind is None:
+            kind = "hipError %d" % (rc - 1000) if rc < 2000 else "rocblas_status %d" % (rc - 2000)
+        raise DsvgpError("%s failed: %s (code %d)" % (what, kind, rc))

@@ -1,0 +1,248 @@
+"""Tensor-level wrappers over the C ABI (include/dsvgp.h).
+
+torch is used only as the device allocator / stream provider: every function here checks device,
+dtype and contiguity, then hands raw device pointers to libdsvgp_hip.so.  There is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+f32, f64 = torch.float32, torch.float64
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req(t, dtype, name, dims=None):
+    if not t.is_cuda:
+        raise _lib.DsvgpError("%s must live on the GPU: the DSVGP hot path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if dims is not None and t.dim() != dims:
+        raise ValueError("%s must be %d-D" % (name, dims))
+    if t.dim() == 2:
+        if t.stride(1) != 1 and t.shape[1] > 1:
+            raise ValueError("%s must be row-major with unit column stride" % name)
+    elif not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _ld(t):
+    return int(t.stride(0)) if t.shape[0] > 1 else int(max(t.shape[1], t.stride(0)))
+
+
+class Context:
+    """One dsvgp_ctx per device; binds the library to torch's current HIP stream."""
+    _cache = {}
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.dsvgp_create(C.byref(h)), "dsvgp_create")
+        self.h = h
+        self._stream = None
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.DsvgpError("DSVGP HIP path needs a GPU device, got %s" % device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in cls._cache:
+            cls._cache[idx] = Context(torch.device("cuda", idx))
+        ctx = cls._cache[idx]
+        ctx.bind()
+        return ctx
+
+    def bind(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream:
+            check(lib.dsvgp_set_stream(self.h, C.c_void_p(s)), "dsvgp_set_stream")
+            self._stream = s
+
+
+def packed_width(d):
+    return int(lib.dsvgp_packed_width(int(d)))
+
+
+def hyp_forward(ctx, raw_l, raw_s, raw_n):
+    hyp = torch.empty(4, dtype=f32, device=raw_l.device)
+    check(lib.dsvgp_hyp_forward(ctx.h, _ptr(_req(raw_l.reshape(-1), f32, "raw_lengthscale")),
+                                _ptr(_req(raw_s.reshape(-1), f32, "raw_outputscale")),
+                                _ptr(_req(raw_n.reshape(-1), f32, "raw_noise")), _ptr(hyp)), "dsvgp_hyp_forward")
+    return hyp
+
+
+def hyp_backward(ctx, raw_l, raw_s, raw_n, d_hyp, d_raw_l, d_raw_s, d_raw_n):
+    check(lib.dsvgp_hyp_backward(ctx.h, _ptr(raw_l), _ptr(raw_s), _ptr(raw_n), _ptr(d_hyp), _ptr(d_raw_l),
+                                 _ptr(d_raw_s), _ptr(d_raw_n)), "dsvgp_hyp_backward")
+
+
+def pack_points(ctx, x, v, p, hyp):
+    """-> (P[n(p+1), DP], self[n(p+1)], vnorm[n p])"""
+    _req(x, f32, "x", 2)
+    n, d = x.shape
+    if p > 0:
+        _req(v, f32, "v", 2)
+        if v.shape != (n * p, d):
+            raise ValueError("directions must be [n*p, d] = [%d, %d], got %s" % (n * p, d, tuple(v.shape)))
+    if not x.is_contiguous() or (p > 0 and not v.is_contiguous()):
+        raise ValueError("x and v must be contiguous")
+    DP = packed_width(d)
+    P = torch.empty(n * (p + 1), DP, dtype=f32, device=x.device)
+    sf = torch.empty(n * (p + 1), dtype=f32, device=x.device)
+    vn = torch.empty(max(n * p, 1), dtype=f32, device=x.device)
+    check(lib.dsvgp_pack_points(ctx.h, _ptr(x), _ptr(v if p > 0 else None), n, d, p, _ptr(hyp), _ptr(P), _ptr(sf),
+                                _ptr(vn)), "dsvgp_pack_points")
+    return P, sf, vn
+
+
+def kernel_fwd(ctx, pack1, n1, pack2, n2, d, p, hyp, jitter=0.0, out=None, dtype=f32):
+    P1, s1 = pack1[0], pack1[1]
+    P2, s2 = pack2[0], pack2[1]
+    q = p + 1
+    if out is None:
+        out = torch.empty(n1 * q, n2 * q, dtype=dtype, device=P1.device)
+    _req(out, dtype, "out", 2)
+    if out.shape != (n1 * q, n2 * q):
+        raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), (n1 * q, n2 * q)))
+    check(lib.dsvgp_kernel_fwd(ctx.h, _ptr(P1), _ptr(s1), n1, _ptr(P2), _ptr(s2), n2, d, p, _ptr(hyp), float(jitter),
+                               _ptr(out), _ld(out), 1 if dtype == f64 else 0), "dsvgp_kernel_fwd")
+    return out
+
+
+def kernel_diag(ctx, n, p, hyp):
+    out = torch.empty(n * (p + 1), dtype=f32, device=hyp.device)
+    check(lib.dsvgp_kernel_diag(ctx.h, n, p, _ptr(hyp), _ptr(out)), "dsvgp_kernel_diag")
+    return out
+
+
+def kernel_bwd(ctx, G, pack1, n1, pack2, n2, d, p, hyp, symmetric, d_x1, d_v1, d_hyp, workspace=None):
+    P1, s1, vn1 = pack1
+    P2, s2 = pack2[0], pack2[1]
+    isd = G.dtype == f64
+    _req(G, f64 if isd else f32, "G", 2)
+    nbytes = int(lib.dsvgp_kernel_bwd_workspace_bytes(n1, n2, d, p))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=G.device)
+    check(lib.dsvgp_kernel_bwd(ctx.h, _ptr(G), _ld(G), 1 if isd else 0, _ptr(P1), _ptr(s1), _ptr(vn1), n1, _ptr(P2),
+                               _ptr(s2), n2, d, p, _ptr(hyp), 1 if symmetric else 0, _ptr(d_x1),
+                               _ptr(d_v1 if p > 0 else None), _ptr(d_hyp), _ptr(workspace)), "dsvgp_kernel_bwd")
+    return workspace
+
+
+def potrf_(ctx, A, info):
+    _req(A, f64, "A", 2)
+    check(lib.dsvgp_potrf(ctx.h, _ptr(A), A.shape[0], _ld(A), _ptr(info)), "dsvgp_potrf")
+
+
+def add_diag_(ctx, A, delta):
+    check(lib.dsvgp_add_diag(ctx.h, _ptr(A), A.shape[0], _ld(A), float(delta)), "dsvgp_add_diag")
+
+
+def trsm_workspace(n, nrhs, nb, device):
+    return torch.empty(int(lib.dsvgp_trsm_workspace_bytes(n, nrhs, nb)), dtype=torch.uint8, device=device)
+
+
+def trsm(ctx, L, B, trans, X64, X32, nb, workspace, reuse_inverse=False):
+    _req(L, f64, "L", 2)
+    isd = B.dtype == f64
+    _req(B, f64 if isd else f32, "B", 2)
+    _req(X64, f64, "X64", 2)
+    n, nrhs = B.shape
+    if L.shape != (n, n) or X64.shape != (n, nrhs) or (X32 is not None and X32.shape != (n, nrhs)):
+        raise ValueError("trsm shape mismatch")
+    need = int(lib.dsvgp_trsm_workspace_bytes(n, nrhs, nb))
+    if workspace.numel() < need:
+        raise ValueError("trsm workspace too small: %d < %d" % (workspace.numel(), need))
+    check(lib.dsvgp_trsm(ctx.h, _ptr(L), _ld(L), n, 1 if trans else 0, _ptr(B), _ld(B), 1 if isd else 0, nrhs,
+                         _ptr(X64), _ld(X64), _ptr(X32), _ld(X32) if X32 is not None else 0, nb, _ptr(workspace),
+                         1 if reuse_inverse else 0), "dsvgp_trsm")
+
+
+def gemm(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0, Cin=None, C32=None, kscale=None, M=None, N=None, K=None):
+    """C_out = alpha*op(A)op(B) + beta*Cin on the MFMA GEMM; compute dtype = C_out.dtype."""
+    isd = C_out.dtype == f64
+    if M is None:
+        M = A.shape[1] if flags & _lib.TRANS_A else A.shape[0]
+    if K is None:
+        K = A.shape[0] if flags & _lib.TRANS_A else A.shape[1]
+    if N is None:
+        N = B.shape[0] if flags & _lib.TRANS_B else B.shape[1]
+    kb = B.shape[1] if flags & _lib.TRANS_B else B.shape[0]
+    if kb < K or C_out.shape[0] < M or C_out.shape[1] < N:
+        raise ValueError("gemm shape mismatch")
+    _req(A, f64 if isd else f32, "A", 2)
+    if isd and B.dtype == f32:
+        flags |= _lib.B_IS_FLOAT
+    else:
+        _req(B, f64 if isd else f32, "B", 2)
+    if Cin is not None and isd and Cin.dtype == f32:
+        flags |= _lib.CIN_IS_FLOAT
+    check(lib.dsvgp_gemm(ctx.h, 1 if isd else 0, flags, M, N, K, float(alpha), _ptr(A), _ld(A), _ptr(B), _ld(B),
+                         float(beta), _ptr(Cin), _ld(Cin) if Cin is not None else 0, _ptr(C_out), _ld(C_out),
+                         _ptr(C32), _ld(C32) if C32 is not None else 0, _ptr(kscale)), "dsvgp_gemm")
+    return C_out
+
+
+def predictive_stats(ctx, A, W, p, m, constant, hyp, mu, var, workspace=None):
+    Mp, nc = A.shape
+    nbytes = int(lib.dsvgp_stats_workspace_bytes(Mp, nc))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=A.device)
+    check(lib.dsvgp_predictive_stats(ctx.h, _ptr(_req(A, f32, "A", 2)), _ld(A), _ptr(_req(W, f32, "W", 2)), _ld(W), Mp,
+                                     nc, p, _ptr(m), _ptr(constant), _ptr(hyp), _ptr(mu), _ptr(var), _ptr(workspace)),
+          "dsvgp_predictive_stats")
+    return workspace
+
+
+def likelihood_terms(ctx, mu, var, y, p, hyp, mll_type, global_rows, mu_bar, var_bar, varn, scalars):
+    check(lib.dsvgp_likelihood_terms(ctx.h, _ptr(mu), _ptr(var), _ptr(_req(y, f32, "y", 1)), mu.shape[0], p, _ptr(hyp),
+                                     int(mll_type), float(global_rows), _ptr(mu_bar), _ptr(var_bar), _ptr(varn),
+                                     _ptr(scalars)), "dsvgp_likelihood_terms")
+
+
+def abar(ctx, A, U, m, mu_bar, var_bar, out):
+    Mp, nc = A.shape
+    check(lib.dsvgp_abar(ctx.h, _ptr(A), _ld(A), _ptr(U), _ld(U), Mp, nc, _ptr(m), _ptr(mu_bar), _ptr(var_bar),
+                         _ptr(out), _ld(out)), "dsvgp_abar")
+
+
+def rowdot_accum(ctx, A, vec, out):
+    Mp, nc = A.shape
+    check(lib.dsvgp_rowdot(ctx.h, _ptr(A), _ld(A), Mp, nc, _ptr(vec), _ptr(out)), "dsvgp_rowdot")
+
+
+def kl_terms(ctx, m, LS, num_data, kl_buf, d_m, d_LS):
+    Mp = m.shape[0]
+    check(lib.dsvgp_kl_terms(ctx.h, _ptr(m), _ptr(_req(LS, f32, "L_S", 2)), _ld(LS), Mp, float(num_data), _ptr(kl_buf),
+                             _ptr(d_m), _ptr(d_LS), _ld(d_LS)), "dsvgp_kl_terms")
+
+
+def phi_symmetrize_(ctx, G):
+    check(lib.dsvgp_phi_symmetrize(ctx.h, _ptr(G), G.shape[0], _ld(G)), "dsvgp_phi_symmetrize")
+
+
+def transpose_f64(ctx, src, dst):
+    check(lib.dsvgp_transpose_f64(ctx.h, _ptr(src), _ld(src), src.shape[0], src.shape[1], _ptr(dst), _ld(dst)),
+          "dsvgp_transpose_f64")
+
+
+def gather_batch(ctx, X, Y, idx, cols, p, xb, yb):
+    check(lib.dsvgp_gather_batch(ctx.h, _ptr(_req(X, f32, "X", 2)), _ptr(_req(Y, f32, "Y", 2)),
+                                 _ptr(_req(idx, torch.int64, "idx", 1)), idx.shape[0], X.shape[1], Y.shape[1],
+                                 _ptr(_req(cols, torch.int32, "cols", 1)), p, _ptr(xb), _ptr(yb)), "dsvgp_gather_batch")
+
+
+def adam_step_(ctx, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if not t.is_contiguous() or t.dtype != f32 or not t.is_cuda:
+            raise ValueError("adam: %s must be a contiguous float32 GPU tensor" % nm)
+    check(lib.dsvgp_adam_step(ctx.h, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                              float(lr), float(beta1), float(beta2), float(eps), int(step)), "dsvgp_adam_step")

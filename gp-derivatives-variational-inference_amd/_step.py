@@ -1,0 +1,196 @@
+"""One DSVGP minibatch ELBO evaluation (forward + analytic backward) on the HIP kernels.
+
+Follows the reference step ``loss = -mll(likelihood(model(x, derivative_directions=D)), y)``
+(directionalvi/directional_vi.py:245-249) with the composition of
+DirectionalGradVariationalStrategy.forward (directionalvi/DirectionalGradVariationalStrategy.py:89-208):
+
+  forward   K_ZZ(+1e-3 I, fp32 values widened to fp64) -> rocSOLVER potrf (fp64)        :140-144,172
+            K_ZX (fp32)  ->  A = L^-1 K_ZX (fp64 panel solve on MFMA, cast to fp32)     :128-137,181-183
+            W = L_S^T A ; mu = A^T m + c ; var = s*diag + 1e-4 + colsum(W^2 - A^2)       :188-205
+            Gaussian expected-log-lik (noise counted twice) / PLL, KL / num_data         directional_vi.py:217-246
+  backward  analytic: Abar, L_S-bar, K_ZX-bar = L^-T Abar, L-bar,
+            Cholesky backward, kernel backward (dZ, dV, d ell, d s), softplus chain rule.
+
+K_XZ is not assembled (it is K_ZX^T) and the second triangular solve of the reference is not
+repeated (A_t == A); everything else keeps the reference's arithmetic precision: fp32 model, fp64
+Cholesky / triangular solves.
+"""
+import torch
+
+from . import _lib, _ops
+from ._lib import A_LOWER, A_UPPER, B_LOWER, OUT_LOWER, TRANS_A, TRANS_B
+
+KZZ_JITTER = 1e-3     # LazyTensor.add_jitter() default (DGVS.py:144)
+CHOL_JITTER = 1e-6    # settings.cholesky_jitter.value() (DGVS.py:74)
+CHOL_TRIES = 3        # psd_safe_cholesky max_tries
+
+PARAM_NAMES = ("inducing_points", "inducing_directions", "variational_mean", "chol_variational_covar",
+               "constant", "raw_outputscale", "raw_lengthscale", "raw_noise")
+
+f32, f64 = torch.float32, torch.float64
+
+
+class NotPSDError(RuntimeError):
+    """Same failure the reference surfaces from psd_safe_cholesky (gpytorch.utils.errors.NotPSDError)."""
+
+
+class ElboEngine:
+    """Owns the HBM workspaces of one (M', B', d, p) configuration on one GPU."""
+
+    def __init__(self, device, trsm_nb=512):
+        self.device = torch.device(device)
+        self.trsm_nb = int(trsm_nb)
+        self._buf = {}
+        self._key = None
+
+    # ---- workspace management ---------------------------------------------------------------
+    def _get(self, name, shape, dtype):
+        t = self._buf.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def _bytes(self, name, nbytes):
+        t = self._buf.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+            self._buf[name] = t
+        return t
+
+    # ---- shared forward pieces ----------------------------------------------------------------
+    def _factor(self, ctx, params, need_grad_packs=True):
+        """hyp, packs of (Z,V), L = chol(K_ZZ + 1e-3 I) with psd_safe_cholesky retries."""
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        Mp = M * (p + 1)
+        hyp = _ops.hyp_forward(ctx, params["raw_lengthscale"], params["raw_outputscale"], params["raw_noise"])
+        packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp)
+        L = self._get("L", (Mp, Mp), f64)
+        info = self._get("info", (1,), torch.int32)
+        _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
+        _ops.potrf_(ctx, L, info)
+        if int(info.item()) != 0:                       # rare path: psd_safe_cholesky jitter ladder
+            ok = False
+            for t in range(CHOL_TRIES):
+                _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
+                _ops.add_diag_(ctx, L, CHOL_JITTER * (10 ** t))
+                _ops.potrf_(ctx, L, info)
+                if int(info.item()) == 0:
+                    ok = True
+                    break
+            if not ok:
+                raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
+                                  % (CHOL_JITTER * 10 ** (CHOL_TRIES - 1)))
+        return hyp, packZ, L, (M, d, p, Mp)
+
+    def _interp(self, ctx, params, hyp, packZ, L, dims, x, D):
+        """K_ZX, A = L^-1 K_ZX (fp64 + fp32 copy), W = L_S^T A, mu, var."""
+        M, d, p, Mp = dims
+        B = x.shape[0]
+        Bp = B * (p + 1)
+        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp)
+        Kzx = self._get("Kzx", (Mp, Bp), f32)
+        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        A64 = self._get("A64", (Mp, Bp), f64)
+        A32 = self._get("A32", (Mp, Bp), f32)
+        ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp), self.trsm_nb))
+        _ops.trsm(ctx, L, Kzx, False, A64, A32, self.trsm_nb, ws, reuse_inverse=False)
+        LS = params["chol_variational_covar"]
+        W = self._get("W", (Mp, Bp), f32)
+        # W = tril(L_S)^T A : op(A) = L_S^T is upper triangular -> the strict upper part of the
+        # parameter is never read (CholeskyVariationalDistribution masks it with tril)
+        _ops.gemm(ctx, TRANS_A | A_UPPER, LS, A32, W)
+        mu = torch.empty(Bp, dtype=f32, device=self.device)
+        var = torch.empty(Bp, dtype=f32, device=self.device)
+        sws = self._bytes("stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, Bp))
+        _ops.predictive_stats(ctx, A32, W, p, params["variational_mean"], params["constant"].reshape(-1), hyp, mu, var,
+                              sws)
+        return packX, A64, A32, W, mu, var
+
+    # ---- public API -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict(self, params, x, D):
+        """q(f) mean / variance plus likelihood noise: what ``likelihood(model(x)).mean/.variance`` returns."""
+        ctx = _ops.Context.get(self.device)
+        hyp, packZ, L, dims = self._factor(ctx, params)
+        _, _, _, _, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D)
+        varn = (var + hyp[2]).clamp_min_(1e-6)
+        return mu, varn
+
+    @torch.no_grad()
+    def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True):
+        """Returns (loss, grads dict, mu, varn).  ``global_rows`` = B'(global) for data-parallel ranks;
+        ``include_kl=False`` leaves the (replicated) KL term out so exactly one rank adds it."""
+        ctx = _ops.Context.get(self.device)
+        hyp, packZ, L, dims = self._factor(ctx, params)
+        M, d, p, Mp = dims
+        B = x.shape[0]
+        Bp = B * (p + 1)
+        if y.shape != (Bp,):
+            raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bp)
+        rows = float(Bp if global_rows is None else global_rows)
+        packX, A64, A32, W, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D)
+        m = params["variational_mean"]
+        LS = params["chol_variational_covar"]
+        dev = self.device
+
+        mu_bar = torch.empty(Bp, dtype=f32, device=dev)
+        var_bar = torch.empty(Bp, dtype=f32, device=dev)
+        varn = torch.empty(Bp, dtype=f32, device=dev)
+        scal = torch.empty(8, dtype=f32, device=dev)
+        _ops.likelihood_terms(ctx, mu, var, y.contiguous(), p, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar,
+                              var_bar, varn, scal)
+
+        grads = {k: torch.zeros_like(params[k], memory_format=torch.contiguous_format) for k in PARAM_NAMES}
+        d_hyp = torch.zeros(4, dtype=f32, device=dev)
+
+        # ---- variational parameters ----
+        U = self._get("U", (Mp, Bp), f32)
+        _ops.gemm(ctx, A_LOWER, LS, W, U)                                   # U = L_S W
+        Abar = self._get("Abar", (Mp, Bp), f32)
+        _ops.abar(ctx, A32, U, m, mu_bar, var_bar, Abar)                    # m mu_bar^T + 2 (U - A) diag(var_bar)
+        dLS = grads["chol_variational_covar"]
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, W, dLS, alpha=2.0, kscale=var_bar)   # tril(2 A diag(vbar) W^T)
+        dm = grads["variational_mean"]
+        _ops.rowdot_accum(ctx, A32, mu_bar, dm)                             # A mu_bar
+        kl_buf = torch.zeros(Mp + 1, dtype=f32, device=dev)
+        if include_kl:
+            _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
+
+        # ---- through the triangular solve and the Cholesky factor (fp64) ----
+        Kb64 = self._get("Kb64", (Mp, Bp), f64)
+        Kb32 = self._get("Kb32", (Mp, Bp), f32)
+        ws = self._buf["trsm_ws"]
+        _ops.trsm(ctx, L, Abar, True, Kb64, Kb32, self.trsm_nb, ws, reuse_inverse=True)     # K_ZX-bar = L^-T Abar
+        Lbar = self._get("Lbar", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb64, A64, Lbar, alpha=-1.0)    # -tril(K_ZX-bar A^T)
+        G1 = self._get("G1", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, L, Lbar, G1)            # L^T L-bar
+        _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T
+        Y = self._get("Y", (Mp, Mp), f64)
+        _ops.trsm(ctx, L, G1, True, Y, None, self.trsm_nb, ws, reuse_inverse=True)          # L^-T S
+        Yt = Lbar                                                           # reuse
+        _ops.transpose_f64(ctx, Y, Yt)
+        Kzzbar = G1                                                         # reuse
+        _ops.trsm(ctx, L, Yt, True, Kzzbar, None, self.trsm_nb, ws, reuse_inverse=True)     # L^-T S L^-1 (symmetric)
+        Kzzbar.mul_(0.5)
+
+        # ---- kernel backward: K_ZX (data side carries no gradient) and symmetric K_ZZ ----
+        dZ, dV = grads["inducing_points"], grads["inducing_directions"]
+        kws = self._bytes("kbwd_ws", max(_lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p),
+                                         _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, M, d, p)))
+        _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
+        _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
+
+        # ---- scalars ----
+        d_hyp[0] += scal[4]
+        d_hyp[1] += scal[3]
+        d_hyp[2] += scal[1]
+        grads["constant"].reshape(-1).add_(scal[2])
+        _ops.hyp_backward(ctx, params["raw_lengthscale"].reshape(-1), params["raw_outputscale"].reshape(-1),
+                          params["raw_noise"].reshape(-1), d_hyp, grads["raw_lengthscale"].reshape(-1),
+                          grads["raw_outputscale"].reshape(-1), grads["raw_noise"].reshape(-1))
+        loss = -scal[0] / rows + kl_buf[0] / float(num_data)
+        return loss, grads, mu, varn

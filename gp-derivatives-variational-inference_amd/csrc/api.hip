@@ -1,0 +1,146 @@
+// Context, rocSOLVER potrf, panel triangular solve and GEMM entry points of the C ABI.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include "common.h"
+
+extern "C" const char* dsvgp_version(void) { return "dsvgp-hip 0.1 (gfx950)"; }
+
+extern "C" int dsvgp_create(dsvgp_ctx** out) {
+    if (!out) return DSVGP_EINVAL;
+    dsvgp_ctx* c = new dsvgp_ctx();
+    rocblas_handle h = nullptr;
+    rocblas_status st = rocblas_create_handle(&h);
+    if (st != rocblas_status_success) { delete c; return 2000 + (int)st; }
+    c->blas = h;
+    *out = c;
+    return 0;
+}
+extern "C" int dsvgp_destroy(dsvgp_ctx* ctx) {
+    if (!ctx) return DSVGP_EINVAL;
+    if (ctx->blas) rocblas_destroy_handle((rocblas_handle)ctx->blas);
+    delete ctx;
+    return 0;
+}
+extern "C" int dsvgp_set_stream(dsvgp_ctx* ctx, void* stream) {
+    if (!ctx) return DSVGP_EINVAL;
+    ctx->stream = (hipStream_t)stream;
+    rocblas_status st = rocblas_set_stream((rocblas_handle)ctx->blas, ctx->stream);
+    return st == rocblas_status_success ? 0 : 2000 + (int)st;
+}
+
+// Row-major lower Cholesky == column-major upper factorisation of the same buffer: dpotrf(upper)
+// reads A(i,j), i<=j in column-major = the row-major lower triangle, and writes U with
+// U_colmajor(i,j) = L_rowmajor(j,i).
+extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev) {
+    if (!ctx || !A || !info_dev || n <= 0 || lda < n) return DSVGP_EINVAL;
+    rocblas_status st = rocsolver_dpotrf((rocblas_handle)ctx->blas, rocblas_fill_upper, n, A, (rocblas_int)lda, info_dev);
+    return st == rocblas_status_success ? 0 : 2000 + (int)st;
+}
+
+extern "C" int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N, int K, double alpha, const void* A,
+                          int64_t lda, const void* B, int64_t ldb, double beta, const void* Cin, int64_t ldcin, void* C,
+                          int64_t ldc, float* C32, int64_t ldc32, const float* kscale) {
+    if (!ctx || !A || !B || !C || M < 0 || N < 0 || K < 0) return DSVGP_EINVAL;
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.A = A; g.B = B; g.Cin = Cin; g.C = C; g.C32 = C32; g.kscale = kscale;
+    g.lda = lda; g.ldb = ldb; g.ldcin = ldcin; g.ldc = ldc; g.ldc32 = ldc32;
+    g.alpha = alpha; g.beta = beta; g.flags = flags; g.batch = 1; g.splitk = 1;
+    // long-K, small-output contractions (K = minibatch rows): split K so that the grid fills 256 CUs
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    if (!Cin && !C32 && K >= 4096 && tiles < 1024) {
+        int sk = 1024 / (tiles > 0 ? tiles : 1);
+        const int maxsk = K / 512;
+        if (sk > maxsk) sk = maxsk;
+        if (sk > 1) {
+            g.splitk = sk;
+            const size_t esz = is_double ? 8 : 4;   // atomics accumulate into a zeroed output
+            hipError_t e = hipMemset2DAsync(C, esz * (size_t)ldc, 0, esz * (size_t)N, (size_t)M, ctx->stream);
+            if (e != hipSuccess) return 1000 + (int)e;
+        }
+    }
+    return launch_gemm(ctx->stream, is_double, g);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Panel triangular solve: op(L) X = B, L lower fp64.
+//   workspace = Dinv [n, n]  (inverted nb x nb diagonal blocks, indexed like L)
+//             | tmp  [n + nb, nb/2]  (trtri scratch)
+//             | T    [nb, nrhs]      (right-hand side of the current block row after the update)
+// -------------------------------------------------------------------------------------------------
+static inline int trsm_nb(int n, int nb) {
+    int b = 64;
+    while (b < nb) b *= 2;          // power of two >= 64
+    while (b / 2 >= n && b > 64) b /= 2;
+    return b;
+}
+extern "C" size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb) {
+    if (n <= 0 || nrhs < 0) return 0;
+    const int b = trsm_nb(n, nb);
+    return sizeof(double) * ((size_t)n * n + (size_t)(n + b) * (b / 2) + (size_t)b * (nrhs > 0 ? nrhs : 1)) + 256;
+}
+
+extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B, int64_t ldb,
+                          int b_is_double, int nrhs, double* X64, int64_t ldx64, float* X32, int64_t ldx32, int nb,
+                          void* workspace, int reuse_inverse) {
+    if (!ctx || !L || !B || !X64 || !workspace || n <= 0 || nrhs < 0 || ldl < n || ldb < nrhs || ldx64 < nrhs)
+        return DSVGP_EINVAL;
+    if (X32 && ldx32 < nrhs) return DSVGP_EINVAL;
+    if (!b_is_double && (const void*)B == (const void*)X64) return DSVGP_EINVAL;
+    const int b = trsm_nb(n, nb);
+    double* Dinv = (double*)workspace;
+    double* tmp = Dinv + (size_t)n * n;
+    double* T = tmp + (size_t)(n + b) * (b / 2);
+    hipStream_t st = ctx->stream;
+    if (!reuse_inverse) {
+        int rc = launch_trtri_blocks(st, L, ldl, n, b, Dinv, n, tmp);
+        if (rc) return rc;
+    }
+    if (nrhs == 0) return 0;
+    const int nblk = cdiv(n, b);
+    const size_t bsz = b_is_double ? 8 : 4;
+    for (int s = 0; s < nblk; ++s) {
+        const int I = trans ? (nblk - 1 - s) : s;
+        const int r0 = I * b, nr = (n - r0 < b) ? (n - r0) : b;
+        const void* Bi = (const char*)B + bsz * (size_t)r0 * ldb;
+        const int kdone = trans ? (n - (r0 + nr)) : r0;      // rows of X already solved that feed this block row
+        const void* rhs = Bi; int64_t ldrhs = ldb; bool rhs_float = !b_is_double;
+        if (kdone == 0 && (const void*)B == (const void*)X64) {
+            // in-place solve: the block row is both read (all of it) and written by the GEMM below
+            hipError_t e = hipMemcpy2DAsync(T, sizeof(double) * (size_t)nrhs, Bi, sizeof(double) * (size_t)ldb,
+                                            sizeof(double) * (size_t)nrhs, (size_t)nr, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return 1000 + (int)e;
+            rhs = T; ldrhs = nrhs;
+        }
+        if (kdone > 0) {
+            // T = B_I - op(L)[I, done] X[done]
+            GemmArgs g{};
+            g.batch = 1; g.splitk = 1;
+            g.M = nr; g.N = nrhs; g.K = kdone;
+            if (!trans) { g.A = L + (size_t)r0 * ldl; g.flags = 0; }
+            else        { g.A = L + (size_t)(r0 + nr) * ldl + r0; g.flags = DSVGP_GEMM_TRANS_A; }
+            g.lda = ldl;
+            g.B = trans ? (X64 + (size_t)(r0 + nr) * ldx64) : X64; g.ldb = ldx64;
+            g.Cin = Bi; g.ldcin = ldb; g.beta = 1.0; g.alpha = -1.0;
+            if (!b_is_double) g.flags |= DSVGP_GEMM_CIN_IS_FLOAT;
+            g.C = T; g.ldc = nrhs;
+            int rc = launch_gemm(st, 1, g);
+            if (rc) return rc;
+            rhs = T; ldrhs = nrhs; rhs_float = false;
+        }
+        // X_I = op(Dinv_I) rhs
+        GemmArgs f{};
+        f.batch = 1; f.splitk = 1;
+        f.M = nr; f.N = nrhs; f.K = nr;
+        f.A = Dinv + (size_t)r0 * n + r0; f.lda = n;
+        f.flags = trans ? (DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER) : DSVGP_GEMM_A_LOWER;
+        if (rhs_float) f.flags |= DSVGP_GEMM_B_IS_FLOAT;
+        f.B = rhs; f.ldb = ldrhs;
+        f.alpha = 1.0; f.beta = 0.0;
+        f.C = X64 + (size_t)r0 * ldx64; f.ldc = ldx64;
+        if (X32) { f.C32 = X32 + (size_t)r0 * ldx32; f.ldc32 = ldx32; }
+        int rc = launch_gemm(st, 1, f);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,41 @@
+// Internal declarations shared by the HIP translation units of libdsvgp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "dsvgp.h"
+
+struct dsvgp_ctx {
+    hipStream_t stream = nullptr;
+    void* blas = nullptr;  // rocblas_handle (opaque here so only potrf.hip needs the rocBLAS headers)
+};
+
+#define DSVGP_LAUNCH_CHECK()                                  \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return 1000 + (int)e__;        \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA GEMM (gemm.hip).  C = alpha*op(A)op(B) + beta*Cin on v_mfma_{f32,f64}_16x16x4.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+    int M, N, K;
+    int M_last, K_last;    // M / K of the LAST batch entry (ragged trtri pairs); 0 = same as M / K
+    const void* A; const void* B; const void* Cin; void* C; float* C32; const float* kscale;
+    int64_t lda, ldb, ldcin, ldc, ldc32;
+    int64_t sA, sB, sC;    // batch strides (elements); Cin/C32 are not batched
+    double alpha, beta;
+    int flags;
+    int batch;
+    int splitk;            // >1: epilogue is atomicAdd(alpha*acc) into a caller-initialised C
+};
+int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
+
+// trtri of the nb x nb diagonal blocks of the lower-triangular L into Dinv (same indexing as L,
+// leading dimension ldd); tmp is an n x (nb/2) double scratch.
+int launch_trtri_blocks(hipStream_t st, const double* L, int64_t ldl, int n, int nb, double* Dinv,
+                        int64_t ldd, double* tmp);

@@ -1,0 +1,370 @@
+// ELBO terms, KL, Cholesky-backward helper, minibatch gather and fused Adam (gfx950).
+// All kernels here are HBM-bound streaming passes over [M', B'] or [M', M'] operands or tiny
+// reductions; they use coalesced row-major sweeps (lane -> consecutive column).
+#include "common.h"
+
+namespace {
+
+constexpr float KXX_JITTER = 1e-4f;     // data_data_covar.add_jitter(1e-4), reference DGVS.py:197,203
+constexpr float NOISE_FLOOR = 1e-4f;    // GaussianLikelihood noise constraint GreaterThan(1e-4)
+constexpr float MIN_VARIANCE = 1e-6f;   // gpytorch settings.min_variance (float)
+
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void hyp_forward_kernel(const float* rl, const float* rs, const float* rn, float* hyp) {
+    if (threadIdx.x == 0) {
+        hyp[0] = softplusf(rl[0]);
+        hyp[1] = softplusf(rs[0]);
+        hyp[2] = softplusf(rn[0]) + NOISE_FLOOR;
+        hyp[3] = 0.f;
+    }
+}
+__global__ void hyp_backward_kernel(const float* rl, const float* rs, const float* rn, const float* dh, float* drl,
+                                    float* drs, float* drn) {
+    if (threadIdx.x == 0) {
+        drl[0] += dh[0] * sigmoidf(rl[0]);
+        drs[0] += dh[1] * sigmoidf(rs[0]);
+        drn[0] += dh[2] * sigmoidf(rn[0]);
+    }
+}
+
+// partial column statistics over a row chunk: part[chunk][0][j] = sum_i A_ij m_i ; part[chunk][1][j] = sum_i W^2 - A^2
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ W, int64_t ldw, int Mp, int ncols,
+                                                       const float* __restrict__ m, int rows_per_chunk,
+                                                       float* __restrict__ part) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * rows_per_chunk, i1 = min(Mp, i0 + rows_per_chunk);
+    if (j >= ncols) return;
+    float sm = 0.f, sq = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float a = A[(int64_t)i * lda + j], w = W[(int64_t)i * ldw + j];
+        sm = fmaf(a, m[i], sm);
+        sq += w * w - a * a;
+    }
+    part[((int64_t)blockIdx.y * 2) * ncols + j] = sm;
+    part[((int64_t)blockIdx.y * 2 + 1) * ncols + j] = sq;
+}
+__global__ void colstats_finish_kernel(const float* __restrict__ part, int nchunk, int ncols, int p,
+                                       const float* __restrict__ constant, const float* __restrict__ hyp,
+                                       float* __restrict__ mu, float* __restrict__ var) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    float sm = 0.f, sq = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+        sm += part[((int64_t)c * 2) * ncols + j];
+        sq += part[((int64_t)c * 2 + 1) * ncols + j];
+    }
+    const float ell = hyp[0], s = hyp[1];
+    const float dg = (j % (p + 1) == 0) ? s : s / (ell * ell);
+    mu[j] = sm + constant[0];                 // test_mean is the constant for ALL rows, DGVS.py:126
+    var[j] = dg + KXX_JITTER + sq;
+}
+
+// scalars out: 0 sum_ll, 1 d_noise, 2 d_constant, 3 d_outputscale(diag), 4 d_lengthscale(diag)
+__global__ __launch_bounds__(256) void likelihood_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                         const float* __restrict__ y, int ncols, int p,
+                                                         const float* __restrict__ hyp, int mll_type, float inv_rows,
+                                                         float* __restrict__ mu_bar, float* __restrict__ var_bar,
+                                                         float* __restrict__ varn_out, float* __restrict__ scal) {
+    __shared__ float red[5][4];
+    const float ell = hyp[0], s = hyp[1], noise = hyp[2];
+    const float LOG2PI = 1.8378770664093453f;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < ncols; j += gridDim.x * 256) {
+        const float mj = mu[j], r = y[j] - mj;
+        const float vraw = var[j] + noise;
+        const bool clamped = vraw < MIN_VARIANCE;
+        const float vn = clamped ? MIN_VARIANCE : vraw;        // likelihood(model(x)).variance
+        float ll, dmu, dvn, dnoise;                              // derivatives of ll (not yet of the loss)
+        if (mll_type == 0) {   // expected_log_prob: -0.5[((y-mu)^2 + vn)/noise + log noise + log 2pi]
+            ll = -0.5f * ((r * r + vn) / noise + logf(noise) + LOG2PI);
+            dmu = r / noise;
+            dvn = -0.5f / noise;
+            dnoise = 0.5f * (r * r + vn) / (noise * noise) - 0.5f / noise;
+        } else {               // log_marginal: log N(y; mu, vn + noise)
+            const float tot = fmaxf(vn + noise, 1e-8f);
+            ll = -0.5f * (r * r / tot + logf(tot) + LOG2PI);
+            dmu = r / tot;
+            dvn = 0.5f * (r * r / (tot * tot) - 1.f / tot);
+            dnoise = dvn;
+        }
+        const float dvar = clamped ? 0.f : dvn;                 // vn = var + noise (unless clamped)
+        dnoise += dvar;
+        // loss = -(sum ll)/rows + KL/num_data
+        const float mb = -dmu * inv_rows, vb = -dvar * inv_rows;
+        mu_bar[j] = mb;
+        var_bar[j] = vb;
+        varn_out[j] = vn;
+        const bool isf = (j % (p + 1)) == 0;
+        acc[0] += ll;
+        acc[1] += -dnoise * inv_rows;
+        acc[2] += mb;
+        acc[3] += vb * (isf ? 1.f : 1.f / (ell * ell));          // var = s*dg + ...
+        acc[4] += isf ? 0.f : vb * (-2.f * s / (ell * ell * ell));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        float v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[q][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&scal[threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void abar_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ U,
+                                                   int64_t ldu, int Mp, int ncols, const float* __restrict__ m,
+                                                   const float* __restrict__ mu_bar, const float* __restrict__ var_bar,
+                                                   float* __restrict__ Ab, int64_t ldab) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    const float mb = mu_bar[j], vb2 = 2.f * var_bar[j];
+    for (int i = blockIdx.y; i < Mp; i += gridDim.y)
+        Ab[(int64_t)i * ldab + j] = m[i] * mb + vb2 * (U[(int64_t)i * ldu + j] - A[(int64_t)i * lda + j]);
+}
+
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ A, int64_t lda, int Mp, int ncols,
+                                                     const float* __restrict__ vec, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < ncols; j += 256) s = fmaf(A[(int64_t)i * lda + j], vec[j], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] += red[0] + red[1] + red[2] + red[3];
+}
+
+// one block per row of L_S: KL pieces + gradient; rowsum[i] = 0.5*(m_i^2 + sum_{j<=i} L_ij^2 - 1 - log L_ii^2)
+__global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ m, const float* __restrict__ LS, int64_t ldls,
+                                                 int Mp, float inv_nd, float* __restrict__ rowsum,
+                                                 float* __restrict__ d_m, float* __restrict__ dLS, int64_t lddls) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < Mp; j += 256) {
+        float g = 0.f;
+        if (j <= i) {
+            const float l = LS[(int64_t)i * ldls + j];
+            s = fmaf(l, l, s);
+            g = (j == i) ? (l - 1.f / l) * inv_nd : l * inv_nd;
+            dLS[(int64_t)i * lddls + j] += g;
+        } else {
+            dLS[(int64_t)i * lddls + j] = 0.f;    // masked upper triangle carries no gradient
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lii = LS[(int64_t)i * ldls + i], mi = m[i];
+        rowsum[i] = 0.5f * (mi * mi + red[0] + red[1] + red[2] + red[3] - 1.f - logf(lii * lii));
+        d_m[i] += mi * inv_nd;
+    }
+}
+__global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+// G[i][j] (i<j) = G[j][i]; lower part and diagonal unchanged: Phi(G)+Phi(G)^T
+__global__ void phi_sym_kernel(double* __restrict__ G, int n, int64_t ldg) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;                       // handle upper block (bi, bj), bj >= bi, from lower block (bj, bi)
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bj * 32 + r, gj = bi * 32 + tx;   // lower block element (gi, gj)
+        tile[r][tx] = (gi < n && gj < n) ? G[(int64_t)gi * ldg + gj] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bi * 32 + r, gj = bj * 32 + tx;   // upper block element (gi, gj) <- lower (gj, gi)
+        if (gi < n && gj < n && gj > gi) G[(int64_t)gi * ldg + gj] = tile[tx][r];
+    }
+}
+
+__global__ void transpose_kernel(const double* __restrict__ in, int64_t ldi, int rows, int cols,
+                                 double* __restrict__ out, int64_t ldo) {
+    __shared__ double tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(int64_t)(r0 + r) * ldi + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < cols && r0 + tx < rows) out[(int64_t)(c0 + r) * ldo + r0 + tx] = tile[tx][r];
+}
+
+__global__ void add_diag_kernel(double* A, int n, int64_t lda, double delta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(int64_t)i * lda + i] += delta;
+}
+
+__global__ void gather_kernel(const float* __restrict__ X, const float* __restrict__ Y, const int64_t* __restrict__ idx,
+                              int nb, int d, int ycols, const int* __restrict__ cols, int p, float* __restrict__ xb,
+                              float* __restrict__ yb) {
+    const int b = blockIdx.x;
+    const int64_t src = idx[b];
+    for (int k = threadIdx.x; k < d; k += blockDim.x) xb[(int64_t)b * d + k] = X[src * d + k];
+    for (int c = threadIdx.x; c <= p; c += blockDim.x) yb[(int64_t)b * (p + 1) + c] = Y[src * ycols + cols[c]];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float g = grad[i];
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;      // torch.optim.Adam (single tensor path)
+        param[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int dsvgp_hyp_forward(dsvgp_ctx* ctx, const float* rl, const float* rs, const float* rn, float* hyp) {
+    if (!ctx || !rl || !rs || !rn || !hyp) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(hyp_forward_kernel, dim3(1), dim3(64), 0, ctx->stream, rl, rs, rn, hyp);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_hyp_backward(dsvgp_ctx* ctx, const float* rl, const float* rs, const float* rn, const float* dh,
+                                  float* drl, float* drs, float* drn) {
+    if (!ctx || !rl || !rs || !rn || !dh || !drl || !drs || !drn) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(hyp_backward_kernel, dim3(1), dim3(64), 0, ctx->stream, rl, rs, rn, dh, drl, drs, drn);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int stats_chunks(int Mp) { int c = cdiv(Mp, 128); return c > 32 ? 32 : (c < 1 ? 1 : c); }
+
+extern "C" size_t dsvgp_stats_workspace_bytes(int Mp, int ncols) {
+    if (Mp <= 0 || ncols <= 0) return 0;
+    return sizeof(float) * (size_t)2 * stats_chunks(Mp) * ncols;
+}
+extern "C" int dsvgp_predictive_stats(dsvgp_ctx* ctx, const float* A, int64_t lda, const float* W, int64_t ldw, int Mp,
+                                      int ncols, int p, const float* m, const float* constant, const float* hyp,
+                                      float* mu, float* var, void* workspace) {
+    if (!ctx || !A || !W || !m || !constant || !hyp || !mu || !var || !workspace || Mp <= 0 || ncols < 0 || p < 0)
+        return DSVGP_EINVAL;
+    if (ncols == 0) return 0;
+    const int nch = stats_chunks(Mp), rpc = cdiv(Mp, nch);
+    hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(ncols, 256), nch), dim3(256), 0, ctx->stream, A, lda, W, ldw, Mp,
+                       ncols, m, rpc, (float*)workspace);
+    DSVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colstats_finish_kernel, dim3(cdiv(ncols, 256)), dim3(256), 0, ctx->stream,
+                       (const float*)workspace, nch, ncols, p, constant, hyp, mu, var);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_likelihood_terms(dsvgp_ctx* ctx, const float* mu, const float* var, const float* y, int ncols,
+                                      int p, const float* hyp, int mll_type, double global_rows, float* mu_bar,
+                                      float* var_bar, float* varn_out, float* out_scalars) {
+    if (!ctx || !mu || !var || !y || !hyp || !mu_bar || !var_bar || !varn_out || !out_scalars || ncols < 0 ||
+        global_rows <= 0 || (mll_type != 0 && mll_type != 1))
+        return DSVGP_EINVAL;
+    hipError_t e = hipMemsetAsync(out_scalars, 0, 8 * sizeof(float), ctx->stream);
+    if (e != hipSuccess) return 1000 + (int)e;
+    if (ncols == 0) return 0;
+    int blocks = cdiv(ncols, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(likelihood_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mu, var, y, ncols, p, hyp, mll_type,
+                       (float)(1.0 / global_rows), mu_bar, var_bar, varn_out, out_scalars);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_abar(dsvgp_ctx* ctx, const float* A, int64_t lda, const float* U, int64_t ldu, int Mp, int ncols,
+                          const float* m, const float* mu_bar, const float* var_bar, float* Abar, int64_t ldab) {
+    if (!ctx || !A || !U || !m || !mu_bar || !var_bar || !Abar || Mp <= 0 || ncols < 0) return DSVGP_EINVAL;
+    if (ncols == 0) return 0;
+    int gy = Mp < 64 ? Mp : 64;
+    hipLaunchKernelGGL(abar_kernel, dim3(cdiv(ncols, 256), gy), dim3(256), 0, ctx->stream, A, lda, U, ldu, Mp, ncols, m,
+                       mu_bar, var_bar, Abar, ldab);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_rowdot(dsvgp_ctx* ctx, const float* A, int64_t lda, int Mp, int ncols, const float* vec,
+                            float* out_accum) {
+    if (!ctx || !A || !vec || !out_accum || Mp <= 0 || ncols < 0) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(Mp), dim3(256), 0, ctx->stream, A, lda, Mp, ncols, vec, out_accum);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_kl_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data,
+                              float* kl_out, float* d_m, float* d_LS, int64_t lddls) {
+    if (!ctx || !m || !LS || !kl_out || !d_m || !d_LS || Mp <= 0 || num_data <= 0) return DSVGP_EINVAL;
+    // kl_out must have room for 1 + Mp floats: [0] = KL, [1..Mp] = per-row scratch
+    hipLaunchKernelGGL(kl_kernel, dim3(Mp), dim3(256), 0, ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data),
+                       kl_out + 1, d_m, d_LS, lddls);
+    DSVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), Mp, kl_out);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_phi_symmetrize(dsvgp_ctx* ctx, double* G, int n, int64_t ldg) {
+    if (!ctx || !G || n <= 0 || ldg < n) return DSVGP_EINVAL;
+    const int nb = cdiv(n, 32);
+    hipLaunchKernelGGL(phi_sym_kernel, dim3(nb, nb), dim3(32, 8), 0, ctx->stream, G, n, ldg);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_transpose_f64(dsvgp_ctx* ctx, const double* in, int64_t ldi, int rows, int cols, double* out,
+                                   int64_t ldo) {
+    if (!ctx || !in || !out || in == out || rows <= 0 || cols <= 0 || ldi < cols || ldo < rows) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, ctx->stream, in, ldi,
+                       rows, cols, out, ldo);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_add_diag(dsvgp_ctx* ctx, double* A, int n, int64_t lda, double delta) {
+    if (!ctx || !A || n <= 0) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(add_diag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, delta);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_gather_batch(dsvgp_ctx* ctx, const float* X, const float* Y, const int64_t* idx, int nb, int d,
+                                  int ycols, const int* cols, int p, float* xb, float* yb) {
+    if (!ctx || !X || !Y || !idx || !cols || !xb || !yb || nb < 0 || d <= 0 || p < 0 || ycols <= p) return DSVGP_EINVAL;
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(64), 0, ctx->stream, X, Y, idx, nb, d, ycols, cols, p, xb, yb);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                               int64_t n, float lr, float beta1, float beta2, float eps, int step) {
+    if (!ctx || !param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return DSVGP_EINVAL;
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ctx->stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}

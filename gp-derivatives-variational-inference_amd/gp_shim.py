@@ -1,0 +1,195 @@
+"""Minimal host-side stand-ins for the GPyTorch 1.4.0 objects the reference's hot path touches.
+
+gpytorch is a third-party dependency of the reference (graphite_environment.yml:101) and is not
+available here; these classes keep the parameter names / shapes / state_dict keys and the call
+protocol (``model(x, derivative_directions=D)`` -> distribution, ``likelihood(dist)``,
+``mll(output, y)``) that ``directional_vi.train_gp`` relies on (directional_vi.py:25-65,172,216-219,245-246),
+and route the arithmetic to the HIP engine (``_step.ElboEngine``).  They contain no math of their own.
+"""
+import torch
+
+from ._step import ElboEngine, PARAM_NAMES
+
+
+class ConstantMean(torch.nn.Module):
+    """gpytorch.means.ConstantMean: parameter ``constant`` of shape [1], init 0."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_parameter("constant", torch.nn.Parameter(torch.zeros(1)))
+
+
+class ScaleKernel(torch.nn.Module):
+    """gpytorch.kernels.ScaleKernel: ``raw_outputscale`` (0-dim, softplus-constrained, init 0)."""
+
+    def __init__(self, base_kernel):
+        super().__init__()
+        self.base_kernel = base_kernel
+        self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(())))
+
+    @property
+    def outputscale(self):
+        return torch.nn.functional.softplus(self.raw_outputscale)
+
+
+class _NoiseCovar(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_parameter("raw_noise", torch.nn.Parameter(torch.zeros(1)))
+
+
+class GaussianLikelihood(torch.nn.Module):
+    """gpytorch.likelihoods.GaussianLikelihood: ``noise_covar.raw_noise`` [1], noise = softplus + 1e-4."""
+
+    def __init__(self):
+        super().__init__()
+        self.noise_covar = _NoiseCovar()
+
+    @property
+    def noise(self):
+        return torch.nn.functional.softplus(self.noise_covar.raw_noise) + 1e-4
+
+    def forward(self, dist):
+        return dist.with_likelihood(self)
+
+
+class _VariationalDistribution(torch.nn.Module):
+    pass
+
+
+class CholeskyVariationalDistribution(_VariationalDistribution):
+    """gpytorch.variational.CholeskyVariationalDistribution: mean zeros, Cholesky factor identity."""
+
+    def __init__(self, num_inducing_points, mean_init_std=1e-3):
+        super().__init__()
+        self.mean_init_std = mean_init_std
+        self.register_parameter("variational_mean", torch.nn.Parameter(torch.zeros(num_inducing_points)))
+        self.register_parameter("chol_variational_covar", torch.nn.Parameter(torch.eye(num_inducing_points)))
+
+    def initialize_variational_distribution(self):
+        """prior N(0, I): mean <- 0 + mean_init_std * randn, chol <- I (first training call in gpytorch)."""
+        with torch.no_grad():
+            self.variational_mean.zero_()
+            self.variational_mean.add_(torch.randn_like(self.variational_mean), alpha=self.mean_init_std)
+            self.chol_variational_covar.copy_(torch.eye(self.variational_mean.shape[0],
+                                                        device=self.variational_mean.device))
+
+
+class _ElboFunction(torch.autograd.Function):
+    """Fused forward+backward of one minibatch objective on the HIP engine."""
+
+    @staticmethod
+    def forward(ctx, engine, x, y, D, num_data, mll_type, dp, *params):
+        pd = dict(zip(PARAM_NAMES, [p.detach() for p in params]))
+        if dp is not None:
+            loss, grads, mu, varn = dp.loss_and_grads(engine, pd, x, y, D, num_data, mll_type)
+        else:
+            loss, grads, mu, varn = engine.loss_and_grads(pd, x, y, D, num_data, mll_type)
+        ctx.grads = [grads[k] for k in PARAM_NAMES]
+        ctx.mark_non_differentiable(mu, varn)
+        return -loss, mu, varn          # mll value = -loss
+
+    @staticmethod
+    def backward(ctx, g_elbo, _gm, _gv):
+        out = [None] * 7
+        for g in ctx.grads:
+            out.append(-g_elbo * g)
+        return tuple(out)
+
+
+class PredictiveDistribution:
+    """What ``model(x, derivative_directions=D)`` returns: a handle whose ``mean`` / ``variance``
+    (length B(p+1), interleaved) are produced on the GPU on demand."""
+
+    def __init__(self, model, x, D, likelihood=None):
+        self.model, self.x, self.D, self.likelihood = model, x, D, likelihood
+        self._mu = self._varn = self._var = None
+
+    def with_likelihood(self, likelihood):
+        out = PredictiveDistribution(self.model, self.x, self.D, likelihood)
+        return out
+
+    def _ensure(self):
+        if self._mu is None:
+            lik = self.likelihood
+            params = self.model._param_dict(lik)
+            mu, varn = self.model.engine.predict(params, self.x, self.D)
+            self._mu, self._varn = mu, varn
+            if lik is None:   # q(f) itself: remove the noise again
+                self._var = (varn - torch.nn.functional.softplus(params["raw_noise"].reshape(())) - 1e-4)
+
+    @property
+    def mean(self):
+        self._ensure()
+        return self._mu
+
+    loc = mean
+
+    @property
+    def variance(self):
+        self._ensure()
+        return self._varn if self.likelihood is not None else self._var
+
+    @property
+    def stddev(self):
+        return self.variance.sqrt()
+
+
+class _ApproximateMLL(torch.nn.Module):
+    mll_type = "ELBO"
+
+    def __init__(self, likelihood, model, num_data, beta=1.0):
+        super().__init__()
+        if beta != 1.0:
+            raise NotImplementedError("beta != 1 is not used by the reference harness")
+        self.likelihood, self.model, self.num_data = likelihood, model, num_data
+
+    def forward(self, output, target):
+        if not isinstance(output, PredictiveDistribution) or output.likelihood is None:
+            raise TypeError("mll expects likelihood(model(x, derivative_directions=D)) as in directional_vi.py:245")
+        model = output.model
+        plist = model._param_list(self.likelihood)
+        dp = getattr(model, "data_parallel", None)
+        elbo, mu, varn = _ElboFunction.apply(model.engine, output.x, target, output.D, float(self.num_data),
+                                             self.mll_type, dp, *plist)
+        output._mu, output._varn = mu, varn
+        return elbo
+
+
+class VariationalELBO(_ApproximateMLL):
+    mll_type = "ELBO"
+
+
+class PredictiveLogLikelihood(_ApproximateMLL):
+    mll_type = "PLL"
+
+
+class ApproximateGP(torch.nn.Module):
+    def __init__(self, variational_strategy):
+        super().__init__()
+        self.variational_strategy = variational_strategy
+        self._engine = None
+
+    @property
+    def engine(self):
+        dev = self.variational_strategy.inducing_points.device
+        if self._engine is None or self._engine.device != dev:
+            self._engine = ElboEngine(dev)
+        return self._engine
+
+    def variational_parameters(self):
+        for mod in self.modules():
+            if isinstance(mod, _VariationalDistribution):
+                for p in mod.parameters(recurse=False):
+                    yield p
+
+    def hyperparameters(self):
+        for mod in self.modules():
+            if not isinstance(mod, _VariationalDistribution):
+                for p in mod.parameters(recurse=False):
+                    yield p
+
+    def __call__(self, inputs, prior=False, **kwargs):
+        if inputs.dim() == 1:
+            inputs = inputs.unsqueeze(-1)
+        return self.variational_strategy(inputs, prior=prior, **kwargs)

@@ -1,0 +1,34 @@
+"""Fused Adam on the HIP kernel ``dsvgp_adam_step`` with torch.optim.Adam's update rule
+(the reference steps two ``torch.optim.Adam`` instances per iteration, directional_vi.py:193-199,251-254).
+Being a ``torch.optim.Optimizer`` it works with the reference's MultiStepLR / LambdaLR schedulers."""
+import torch
+
+from . import _ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                ctx = _ops.Context.get(p.device)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                _ops.adam_step_(ctx, p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
+                                st["step"])
+        return loss

@@ -1,0 +1,45 @@
+"""Data-parallel minibatch sharding for the DSVGP step: one process per GPU, RCCL over xGMI.
+
+The reference is single-process (no collective anywhere); this layer is new.
+The ELBO log-likelihood is a sum over minibatch rows, so rank g takes rows [g*B/G, (g+1)*B/G) of every
+global minibatch, computes partial gradients normalised by the GLOBAL row count, and ONE
+all-reduce(sum) of a flat fp32 buffer [grads..., loss] makes them identical on every rank.  K_ZZ, its
+Cholesky factor and the KL term are replicated; the KL term is added on rank 0 only so that the sum
+counts it once.  The Cholesky backward is linear in its upstream gradient, so reducing the final
+parameter gradients (not L-bar) is exact.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, group=None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.global_batch = None      # set by the training loop before every step
+
+    def shard_bounds(self, n):
+        """rows [lo, hi) of a global batch of n rows owned by this rank (ragged tails go to low ranks)."""
+        base, rem = divmod(n, self.world)
+        lo = self.rank * base + min(self.rank, rem)
+        return lo, lo + base + (1 if self.rank < rem else 0)
+
+    def loss_and_grads(self, engine, params, x, y, D, num_data, mll_type):
+        """x, y, D are this rank's shard.  Returns globally reduced (loss, grads, local mu, local varn)."""
+        p1 = y.shape[0] // max(x.shape[0], 1) if x.shape[0] else 1
+        rows = (self.global_batch if self.global_batch is not None else x.shape[0] * self.world) * p1
+        loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type, global_rows=rows,
+                                                      include_kl=(self.rank == 0))
+        names = list(grads.keys())
+        flat = torch.cat([grads[k].reshape(-1) for k in names] + [loss.reshape(1).to(grads[names[0]].dtype)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        out = {}
+        for k in names:
+            n = grads[k].numel()
+            out[k] = flat[off:off + n].view_as(grads[k])
+            off += n
+        return flat[off], out, mu, varn

@@ -1,0 +1,171 @@
+/*
+ * dsvgp.h -- C ABI of the MI355X (gfx950) DSVGP minibatch-ELBO hot path.
+ *
+ * The reference (mishapadidar/GP-Derivatives-Variational-Inference) is pure Python on top of
+ * GPyTorch; it has no FFI.  These entry points are what a native binding for the hot path
+ * would expose: every function takes plain device pointers, sizes and the context (which carries
+ * the HIP stream), returns 0 on success, a negative DSVGP_E* code for bad arguments and a positive
+ * hipError_t / rocblas_status (offset by 1000) for runtime failures.  No torch types.
+ *
+ * Conventions
+ *   - all matrices are dense ROW-MAJOR with an explicit leading dimension (elements, not bytes);
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - the library never allocates or frees caller-visible memory; workspaces are passed in and
+ *     sized by the *_workspace_bytes helpers;
+ *   - kernels are enqueued on the stream given to dsvgp_set_stream and do not synchronise
+ *     (exceptions are documented);
+ *   - "interleaved" layout: row i*(p+1) is the function value at point i, rows i*(p+1)+1+a the
+ *     derivative along point i's a-th direction (reference RBFKernelDirectionalGrad.py:105-107).
+ *   - hyp is a device float[4] = { lengthscale, outputscale, noise, unused } produced by
+ *     dsvgp_hyp_forward from the raw (softplus-constrained) parameters.
+ *
+ * Reference interface replaced by each entry point is cited as file:line under /root/reference.
+ */
+#ifndef DSVGP_H
+#define DSVGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsvgp_ctx dsvgp_ctx;
+
+enum {
+    DSVGP_OK = 0,
+    DSVGP_EINVAL = -1,     /* bad argument / unsupported shape        */
+    DSVGP_ENOTPD = -2,     /* Cholesky failed (matrix not PD)         */
+    DSVGP_EALIGN = -3      /* pointer / leading dimension misaligned  */
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+int dsvgp_create(dsvgp_ctx** ctx);                 /* creates the rocBLAS handle used by rocSOLVER potrf */
+int dsvgp_destroy(dsvgp_ctx* ctx);
+int dsvgp_set_stream(dsvgp_ctx* ctx, void* hip_stream);
+const char* dsvgp_version(void);
+
+/* ---- hyper-parameters: gpytorch Positive / GreaterThan(1e-4) softplus constraints ------------
+ * replaces ScaleKernel.outputscale, RBFKernel.lengthscale, GaussianLikelihood.noise
+ * (directionalvi/directional_vi.py:56,172).  raw = {raw_lengthscale, raw_outputscale, raw_noise}. */
+int dsvgp_hyp_forward(dsvgp_ctx* ctx, const float* raw_lengthscale, const float* raw_outputscale,
+                      const float* raw_noise, float* hyp);
+/* chain rule back to the raw parameters: d_raw += d_hyp * sigmoid(raw) */
+int dsvgp_hyp_backward(dsvgp_ctx* ctx, const float* raw_lengthscale, const float* raw_outputscale,
+                       const float* raw_noise, const float* d_hyp, float* d_raw_lengthscale,
+                       float* d_raw_outputscale, float* d_raw_noise);
+
+/* ---- kernel assembly: RBFKernelDirectionalGrad.forward (directionalvi/RBFKernelDirectionalGrad.py:41-119)
+ *
+ * dsvgp_pack_points: x[n,d], v[n*p,d] (raw directions, normalised here, :57-58) ->
+ *   P[n*(p+1), DP] packed operand rows (x/ell and unit directions, zero padded, plus the indicator
+ *   column used by the backward), self[n*(p+1)] (|x/ell|^2 and (x/ell).v), vnorm[n*p].
+ *   DP = dsvgp_packed_width(d).                                                                  */
+int dsvgp_packed_width(int d);
+int dsvgp_pack_points(dsvgp_ctx* ctx, const float* x, const float* v, int n, int d, int p,
+                      const float* hyp, float* P, float* self, float* vnorm);
+
+/* out[n1*(p+1), n2*(p+1)] = hyp.outputscale * K(x1,x2;v1,v2) (+ jitter on the global diagonal).
+ * out_is_double: 0 -> float output, 1 -> double output (fp32 values widened, as the reference's
+ * `.double()` cast, DirectionalGradVariationalStrategy.py:74,181).                               */
+int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* self1, int n1, const float* P2,
+                     const float* self2, int n2, int d, int p, const float* hyp, float jitter,
+                     void* out, int64_t ld, int out_is_double);
+/* diag=True branch (:110-119): out[n*(p+1)] = outputscale * [1, 1/ell^2, ...]                    */
+int dsvgp_kernel_diag(dsvgp_ctx* ctx, int n, int p, const float* hyp, float* out);
+
+/* backward of dsvgp_kernel_fwd w.r.t. (x1, v1, lengthscale, outputscale), given G = dLoss/dOut.
+ * symmetric != 0: x1==x2, v1==v2 and G symmetric (the K_ZZ case) -> point/direction grads doubled.
+ * Accumulates (+=) into d_x1[n1,d], d_v1[n1*p,d] and d_hyp[0..1].  g_is_double selects G's dtype. */
+size_t dsvgp_kernel_bwd_workspace_bytes(int n1, int n2, int d, int p);
+int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double, const float* P1,
+                     const float* self1, const float* vnorm1, int n1, const float* P2,
+                     const float* self2, int n2, int d, int p, const float* hyp, int symmetric,
+                     float* d_x1, float* d_v1, float* d_hyp, void* workspace);
+
+/* ---- Cholesky: psd_safe_cholesky(K_ZZ.double()) (DirectionalGradVariationalStrategy.py:72-75)
+ * In-place lower Cholesky of the row-major fp64 matrix A[n,n] (rocSOLVER dpotrf); only the lower
+ * triangle is read/written.  info_dev is a device int (0 = ok, k>0 = leading minor k not PD).   */
+int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev);
+/* A.diagonal() += delta   (the jitter retries of psd_safe_cholesky)                              */
+int dsvgp_add_diag(dsvgp_ctx* ctx, double* A, int n, int64_t lda, double delta);
+
+/* ---- panel triangular solve on MFMA: TriangularLazyTensor.inv_matmul (:181,183)
+ * Solves op(L) X = B for the lower-triangular fp64 L[n,n]; trans=0: op(L)=L, trans=1: op(L)=L^T.
+ * B[n,nrhs] is float or double (b_is_double); X64[n,nrhs] double output (may alias B when B is
+ * double); X32 optional float copy (NULL to skip).  Diagonal blocks of size nb are inverted
+ * (stored in the workspace) and every update is a v_mfma_f64_16x16x4 GEMM.                      */
+size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb);
+int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B,
+               int64_t ldb, int b_is_double, int nrhs, double* X64, int64_t ldx64, float* X32,
+               int64_t ldx32, int nb, void* workspace, int reuse_inverse);
+
+/* ---- generic MFMA GEMM used by the predictive / backward contractions
+ *   C = alpha * op(A) op(B) + beta * Cin,   compute type = double (is_double=1) or float.
+ * flags: see DSVGP_GEMM_* ; kscale (optional, length K, float) multiplies op(A)[:,k].             */
+enum {
+    DSVGP_GEMM_TRANS_A = 1,      /* A stored [K,M]                                             */
+    DSVGP_GEMM_TRANS_B = 2,      /* B stored [N,K]                                             */
+    DSVGP_GEMM_A_LOWER = 4,      /* op(A)[m,k] == 0 for k > m (masked, memory above ignored)   */
+    DSVGP_GEMM_A_UPPER = 8,      /* op(A)[m,k] == 0 for k < m                                  */
+    DSVGP_GEMM_B_LOWER = 16,     /* op(B)[k,n] == 0 for n > k                                  */
+    DSVGP_GEMM_B_UPPER = 32,     /* op(B)[k,n] == 0 for n < k                                  */
+    DSVGP_GEMM_OUT_LOWER = 64,   /* only m >= n is computed; m < n is written as 0             */
+    DSVGP_GEMM_B_IS_FLOAT = 128, /* (double compute only) B is float                           */
+    DSVGP_GEMM_CIN_IS_FLOAT = 256/* (double compute only) Cin is float                         */
+};
+int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N, int K, double alpha,
+               const void* A, int64_t lda, const void* B, int64_t ldb, double beta, const void* Cin,
+               int64_t ldcin, void* C, int64_t ldc, float* C32, int64_t ldc32, const float* kscale);
+
+/* ---- ELBO terms: GaussianLikelihood.expected_log_prob / log_marginal + VariationalELBO
+ * (directional_vi.py:217-219,245-246) on top of the predictive of
+ * DirectionalGradVariationalStrategy.py:188-205.
+ *
+ * dsvgp_predictive_stats: mu[j] = sum_i A[i,j] m[i] + c ; var[j] = s*dg_j + 1e-4 + sum_i (W^2 - A^2)
+ * with A = L^-1 K_ZX, W = L_S^T A, both [Mp, nb] float.                                          */
+size_t dsvgp_stats_workspace_bytes(int Mp, int ncols);
+int dsvgp_predictive_stats(dsvgp_ctx* ctx, const float* A, int64_t lda, const float* W, int64_t ldw,
+                           int Mp, int ncols, int p, const float* m, const float* constant,
+                           const float* hyp, float* mu, float* var, void* workspace);
+/* per-output log-likelihood terms and their gradients.  mll_type 0 = ELBO, 1 = PLL.
+ * out_scalars (device float[8]): {sum_ll, d_noise, d_constant, d_outputscale(diag part),
+ *  d_lengthscale(diag part), 0,0,0}; mu_bar/var_bar are dLoss/dmu, dLoss/dvar with
+ *  loss = -(sum_ll/global_rows - KL/num_data).  varn_out = clamp(var + noise) (likelihood variance). */
+int dsvgp_likelihood_terms(dsvgp_ctx* ctx, const float* mu, const float* var, const float* y,
+                           int ncols, int p, const float* hyp, int mll_type, double global_rows,
+                           float* mu_bar, float* var_bar, float* varn_out, float* out_scalars);
+/* Abar[i,j] = m[i]*mu_bar[j] + 2*var_bar[j]*(U[i,j] - A[i,j]),   U = L_S W                       */
+int dsvgp_abar(dsvgp_ctx* ctx, const float* A, int64_t lda, const float* U, int64_t ldu, int Mp,
+               int ncols, const float* m, const float* mu_bar, const float* var_bar, float* Abar,
+               int64_t ldab);
+/* d_m[i] += sum_j A[i,j]*mu_bar[j]                                                                */
+int dsvgp_rowdot(dsvgp_ctx* ctx, const float* A, int64_t lda, int Mp, int ncols, const float* vec,
+                 float* out_accum);
+/* KL(q(u)||N(0,I)) and its gradients (gpytorch kl_mvn_mvn with the whitened prior of
+ * DirectionalGradVariationalStrategy.py:77-87): kl_out (1+Mp floats): kl_out[0] = KL, rest scratch;
+ * d_m += m/num_data ; d_LS(lower) += (L_S - diag(1/L_S_ii))/num_data ; d_LS(upper) = 0.          */
+int dsvgp_kl_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp,
+                   double num_data, float* kl_out, float* d_m, float* d_LS, int64_t lddls);
+/* Cholesky backward helper: S = Phi(G) + Phi(G)^T from the lower triangle of G (in place).        */
+int dsvgp_phi_symmetrize(dsvgp_ctx* ctx, double* G, int n, int64_t ldg);
+/* out[cols, rows] = in[rows, cols]^T (out of place)                                              */
+int dsvgp_transpose_f64(dsvgp_ctx* ctx, const double* in, int64_t ldi, int rows, int cols, double* out,
+                        int64_t ldo);
+
+/* ---- minibatch gather: DataLoader batch + select_cols_of_y (directional_vi.py:68-90,229-241)
+ * xb[b,:] = X[idx[b],:] ; yb[b*(p+1)+c] = Y[idx[b], cols[c]]  (cols[0] == 0)                     */
+int dsvgp_gather_batch(dsvgp_ctx* ctx, const float* X, const float* Y, const int64_t* idx, int nb,
+                       int d, int ycols, const int* cols, int p, float* xb, float* yb);
+
+/* ---- fused Adam (torch.optim.Adam semantics, directional_vi.py:193-199,251-254)
+ * lr_dev / step_dev are device scalars so the update is graph-capturable.                         */
+int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_avg,
+                    float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSVGP_H */

@@ -1,0 +1,386 @@
+"""GPU parity tests, op level: every C-ABI entry point against the CPU oracle / plain torch fp64.
+
+Tolerances (stated per test) are against fp64 ground truth; the HIP kernels compute in fp32 with the
+same quadratic-expansion arithmetic as the reference (rel. error of kernel entries ~1e-6), the
+Cholesky / triangular-solve path in fp64."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dsvgp_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "kernel_*.npz")))
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _hyp(dev, ell, s=1.0, noise=0.1):
+    return torch.tensor([ell, s, noise, 0.0], dtype=torch.float32, device=dev)
+
+
+def _kernel_gpu(dsvgp, dev, x1, x2, v1, v2, ell, s=1.0, jitter=0.0, dtype=torch.float32):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(dev)
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    p = v1.shape[0] // n1
+    hyp = _hyp(dev, ell, s)
+    p1 = ops.pack_points(ctx, x1.float().to(dev).contiguous(), v1.float().to(dev).contiguous(), p, hyp)
+    p2 = ops.pack_points(ctx, x2.float().to(dev).contiguous(), v2.float().to(dev).contiguous(), p, hyp)
+    return ops.kernel_fwd(ctx, p1, n1, p2, n2, d, p, hyp, jitter=jitter, dtype=dtype), (ctx, hyp, p1, p2)
+
+
+# ------------------------------------------------------------------ kernel assembly forward
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_kernel_fwd_matches_reference_golden_vectors(dsvgp, gpu_device, path):
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(g[k])
+    K, _ = _kernel_gpu(dsvgp, gpu_device, t("x1"), t("x2"), t("v1"), t("v2"), float(g["lengthscale"]))
+    assert K.shape == g["K"].shape
+    assert relmax(K, t("K")) < 2e-5        # fp32 arithmetic vs the reference run in fp64
+
+
+@pytest.mark.parametrize("n1,n2,d,p", [(37, 53, 5, 2), (16, 16, 20, 5), (33, 70, 20, 5), (9, 130, 3, 0),
+                                       (20, 11, 10, 10), (7, 40, 45, 1), (130, 7, 2, 1)])
+def test_kernel_fwd_random_shapes(dsvgp, gpu_device, n1, n2, d, p):
+    g = torch.Generator().manual_seed(n1 * 1000 + n2)
+    x1, x2 = torch.rand(n1, d, generator=g), torch.rand(n2, d, generator=g)
+    v1 = torch.randn(max(n1 * p, 0), d, generator=g)
+    v2 = torch.randn(max(n2 * p, 0), d, generator=g)
+    ell, s = 0.9, 1.7
+    K, _ = _kernel_gpu(dsvgp, gpu_device, x1, x2, v1, v2, ell, s)
+    ref = s * O.kernel_matrix(x1.double(), x2.double(), v1.double().reshape(n1 * p, d), v2.double().reshape(n2 * p, d), ell)
+    assert relmax(K, ref) < 2e-5
+
+
+def test_kernel_fwd_symmetric_double_with_jitter_and_exact_diagonal(dsvgp, gpu_device):
+    g = torch.Generator().manual_seed(3)
+    M, d, p = 50, 20, 5
+    Z, V = torch.rand(M, d, generator=g), torch.randn(M * p, d, generator=g)
+    ell, s = 0.6931, 0.6931
+    K, _ = _kernel_gpu(dsvgp, gpu_device, Z, Z, V, V, ell, s, jitter=1e-3, dtype=torch.float64)
+    assert K.dtype == torch.float64
+    ref = s * O.kernel_matrix(Z.double(), Z.double(), V.double(), V.double(), ell) + 1e-3 * torch.eye(M * (p + 1), dtype=torch.float64)
+    assert relmax(K, ref) < 2e-5
+    Kc = K.cpu()
+    assert (Kc - Kc.t()).abs().max().item() < 2e-6
+    # r == 0 exactly on the diagonal blocks: value s + jitter, cross terms of the diagonal micro-blocks exactly 0
+    q = p + 1
+    for i in (0, 7, M - 1):
+        blk = Kc[i * q:(i + 1) * q, i * q:(i + 1) * q]
+        assert blk[0, 0].item() == pytest.approx(np.float32(s) + np.float32(1e-3), rel=1e-6)
+        assert blk[0, 1:].abs().max().item() == 0.0 and blk[1:, 0].abs().max().item() == 0.0
+    # fp64 output carries fp32 values (the reference's .double() cast)
+    assert torch.equal(Kc, Kc.float().double())
+
+
+def test_kernel_diag_and_errors(dsvgp, gpu_device):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    hyp = _hyp(gpu_device, 0.5, 2.0)
+    dg = ops.kernel_diag(ctx, 4, 2, hyp).cpu()
+    assert torch.allclose(dg, torch.tensor([2.0, 8.0, 8.0] * 4))
+    k = dsvgp._rbf_mod.RBFKernelDirectionalGrad().to(gpu_device)
+    x = torch.rand(3, 2, device=gpu_device)
+    v = torch.rand(6, 2, device=gpu_device)
+    with pytest.raises(RuntimeError):
+        k.forward(x, x + 1, diag=True, v1=v, v2=v)
+    with pytest.raises(AssertionError):
+        k.forward(x, x, v1=v, v2=v[:3])
+    Kd = k.forward(x, x, diag=True, v1=v, v2=v)
+    Kf = k.forward(x, x, v1=v, v2=v)
+    assert relmax(torch.diagonal(Kf), Kd) < 1e-5 and k.num_outputs_per_input(x, x) == 3
+
+
+# ------------------------------------------------------------------ kernel assembly backward
+@pytest.mark.parametrize("n1,n2,d,p,sym", [(11, 23, 5, 2, False), (20, 45, 20, 5, False), (18, 18, 20, 5, True),
+                                           (40, 300, 4, 1, False), (9, 9, 3, 3, True), (6, 10, 6, 0, False)])
+def test_kernel_bwd_matches_autograd(dsvgp, gpu_device, n1, n2, d, p, sym):
+    ops = dsvgp._ops
+    g = torch.Generator().manual_seed(n1 + 31 * n2 + d)
+    x1 = torch.rand(n1, d, generator=g)
+    v1 = torch.randn(n1 * p, d, generator=g)
+    if sym:
+        x2, v2 = x1, v1
+    else:
+        x2, v2 = torch.rand(n2, d, generator=g), torch.randn(n2 * p, d, generator=g)
+    ell, s = 0.8, 1.3
+    q = p + 1
+    G = torch.randn(n1 * q, n2 * q, generator=g, dtype=torch.float64)
+    if sym:
+        G = G + G.t()
+    # fp64 autograd truth
+    x1r = x1.double().requires_grad_(True)
+    v1r = v1.double().requires_grad_(True)
+    ellr = torch.tensor(ell, dtype=torch.float64, requires_grad=True)
+    sr = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+    if sym:
+        K = sr * O.kernel_matrix(x1r, x1r, v1r, v1r, ellr)
+    else:
+        K = sr * O.kernel_matrix(x1r, x2.double(), v1r, v2.double(), ellr)
+    (K * G).sum().backward()
+    # HIP
+    dev = gpu_device
+    _, (ctx, hyp, p1, p2) = _kernel_gpu(dsvgp, dev, x1, x2, v1, v2, ell, s)
+    dx = torch.zeros(n1, d, device=dev)
+    dv = torch.zeros(max(n1 * p, 1), d, device=dev)
+    dh = torch.zeros(4, device=dev)
+    for Gd in (G.to(dev), G.float().to(dev)):                 # double and float upstream gradients
+        dx.zero_(); dv.zero_(); dh.zero_()
+        ops.kernel_bwd(ctx, Gd.contiguous(), p1, n1, p2, n2, d, p, hyp, sym, dx, dv, dh)
+        assert relmax(dx, x1r.grad) < 2e-4, "d_x1"
+        if p > 0:
+            assert relmax(dv[:n1 * p], v1r.grad) < 2e-4, "d_v1"
+        assert abs(dh[0].item() - ellr.grad.item()) < 2e-4 * max(1.0, abs(ellr.grad.item())), "d_lengthscale"
+        assert abs(dh[1].item() - sr.grad.item()) < 2e-4 * max(1.0, abs(sr.grad.item())), "d_outputscale"
+
+
+# ------------------------------------------------------------------ GEMM / trsm / potrf
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_plain(dsvgp, gpu_device, dt, ta, tb):
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 150, 263, 77
+    A = torch.randn((K, M) if ta else (M, K), generator=g, dtype=torch.float64)
+    B = torch.randn((N, K) if tb else (K, N), generator=g, dtype=torch.float64)
+    Cin = torch.randn(M, N, generator=g, dtype=torch.float64)
+    ref = 0.7 * (A.t() if ta else A) @ (B.t() if tb else B) - 0.3 * Cin
+    C = torch.empty(M, N, dtype=dt, device=gpu_device)
+    flags = (L.TRANS_A if ta else 0) | (L.TRANS_B if tb else 0)
+    ops.gemm(ctx, flags, A.to(dt).to(gpu_device), B.to(dt).to(gpu_device), C, alpha=0.7, beta=-0.3,
+             Cin=Cin.to(dt).to(gpu_device))
+    assert relmax(C, ref) < (1e-12 if dt == torch.float64 else 2e-5)
+
+
+def test_gemm_mfma_layout_asymmetric_identity(dsvgp, gpu_device):
+    """A = I with an asymmetric integer B catches a transposed C write (exact arithmetic)."""
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    n = 200
+    B = (torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 7 % 11).double()
+    for dt in (torch.float32, torch.float64):
+        C = torch.empty(n, n, dtype=dt, device=gpu_device)
+        ops.gemm(ctx, 0, torch.eye(n, dtype=dt, device=gpu_device), B.to(dt).to(gpu_device), C)
+        assert torch.equal(C.cpu().double(), B)
+
+
+def test_gemm_triangular_flags_mask_garbage(dsvgp, gpu_device):
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(11)
+    n, N = 300, 170
+    Afull = torch.randn(n, n, generator=g, dtype=torch.float64)
+    B = torch.randn(n, N, generator=g, dtype=torch.float64)
+    dev = gpu_device
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        Ad, Bd = Afull.to(dt).to(dev), B.to(dt).to(dev)
+        C = torch.empty(n, N, dtype=dt, device=dev)
+        ops.gemm(ctx, L.A_LOWER, Ad, Bd, C)                              # tril(A) B
+        assert relmax(C, Afull.tril() @ B) < tol
+        ops.gemm(ctx, L.TRANS_A | L.A_UPPER, Ad, Bd, C)                  # tril(A)^T B
+        assert relmax(C, Afull.tril().t() @ B) < tol
+        ops.gemm(ctx, L.A_UPPER, Ad, Bd, C)                              # triu(A) B
+        assert relmax(C, Afull.triu() @ B) < tol
+        S = torch.empty(n, n, dtype=dt, device=dev)
+        ops.gemm(ctx, L.TRANS_A | L.A_UPPER | L.B_LOWER, Ad, Ad, S)      # tril(A)^T tril(A)
+        assert relmax(S, Afull.tril().t() @ Afull.tril()) < tol
+        C2 = torch.empty(N, n, dtype=dt, device=dev)
+        ops.gemm(ctx, L.B_LOWER, Bd.t().contiguous(), Ad, C2)           # B^T tril(A)
+        assert relmax(C2, B.t() @ Afull.tril()) < tol
+        O_ = torch.full((n, n), 7.0, dtype=dt, device=dev)
+        ops.gemm(ctx, L.TRANS_B | L.OUT_LOWER, Bd, Bd, O_, alpha=2.0)     # tril(2 B B^T), zeros above
+        assert relmax(O_, (2 * B @ B.t()).tril()) < tol
+
+
+def test_gemm_splitk_kscale_long_k(dsvgp, gpu_device):
+    """K = minibatch axis: split-K + atomics path, column scaling (A diag(v) W^T), tril output."""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(13)
+    Mp, Bp = 190, 6000
+    A = torch.randn(Mp, Bp, generator=g)
+    W = torch.randn(Mp, Bp, generator=g)
+    v = torch.rand(Bp, generator=g)
+    dev = gpu_device
+    out = torch.full((Mp, Mp), 3.0, device=dev)
+    ops.gemm(ctx, L.TRANS_B | L.OUT_LOWER, A.to(dev), W.to(dev), out, alpha=2.0, kscale=v.to(dev))
+    ref = (2 * (A.double() * v.double()) @ W.double().t()).tril()
+    assert relmax(out, ref) < 3e-5
+    out64 = torch.empty(Mp, Mp, dtype=torch.float64, device=dev)
+    ops.gemm(ctx, L.TRANS_B | L.OUT_LOWER, A.double().to(dev), W.double().to(dev), out64, alpha=-1.0)
+    assert relmax(out64, -(A.double() @ W.double().t()).tril()) < 1e-12
+
+
+def _spd(n, g, cond_jitter=1e-3):
+    Z = torch.rand(n // 3 + 1, 4, generator=g, dtype=torch.float64)
+    V = torch.randn((n // 3 + 1) * 2, 4, generator=g, dtype=torch.float64)
+    K = 0.7 * O.kernel_matrix(Z, Z, V, V, 0.7)[:n, :n]
+    return K + cond_jitter * torch.eye(n, dtype=torch.float64)
+
+
+@pytest.mark.parametrize("n", [64, 100, 333, 700])
+def test_potrf_row_major_lower(dsvgp, gpu_device, n):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    K = _spd(n, torch.Generator().manual_seed(n))
+    A = K.tril().to(gpu_device).contiguous()                    # only the lower triangle may be read
+    info = torch.full((1,), -7, dtype=torch.int32, device=gpu_device)
+    ops.potrf_(ctx, A, info)
+    assert int(info.item()) == 0
+    Lref = torch.linalg.cholesky(K)
+    assert relmax(A.tril(), Lref) < 1e-10
+    bad = torch.eye(n, dtype=torch.float64, device=gpu_device)
+    bad[n // 2, n // 2] = -1.0
+    ops.potrf_(ctx, bad, info)
+    assert int(info.item()) == n // 2 + 1                       # leading minor index, as LAPACK
+
+
+@pytest.mark.parametrize("n,nrhs,nb", [(100, 37, 64), (333, 500, 128), (700, 260, 256), (700, 260, 1024), (520, 129, 512)])
+@pytest.mark.parametrize("trans", [0, 1])
+def test_trsm_panel_vs_solve_triangular(dsvgp, gpu_device, n, nrhs, nb, trans):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(n + nrhs)
+    Lc = torch.linalg.cholesky(_spd(n, g))
+    Lg = (Lc + torch.randn(n, n, generator=g, dtype=torch.float64).triu(1)).contiguous().to(gpu_device)   # garbage above the diagonal
+    B = torch.randn(n, nrhs, generator=g, dtype=torch.float64)
+    ref = torch.linalg.solve_triangular(Lc.t() if trans else Lc, B, upper=bool(trans))
+    ws = ops.trsm_workspace(n, max(nrhs, n), nb, gpu_device)
+    X64 = torch.empty(n, nrhs, dtype=torch.float64, device=gpu_device)
+    X32 = torch.empty(n, nrhs, dtype=torch.float32, device=gpu_device)
+    ops.trsm(ctx, Lg, B.float().to(gpu_device), trans, X64, X32, nb, ws)                 # float RHS
+    ref32 = torch.linalg.solve_triangular(Lc.t() if trans else Lc, B.float().double(), upper=bool(trans))
+    assert relmax(X64, ref32) < 1e-9
+    assert relmax(X32, ref32) < 1e-6
+    Bd = B.to(gpu_device)
+    ops.trsm(ctx, Lg, Bd, trans, Bd, None, nb, ws, reuse_inverse=True)                   # double RHS, in place
+    assert relmax(Bd, ref) < 1e-9
+
+
+# ------------------------------------------------------------------ ELBO term kernels
+def test_predictive_stats_likelihood_abar_rowdot(dsvgp, gpu_device):
+    ops = dsvgp._ops
+    dev = gpu_device
+    ctx = ops.Context.get(dev)
+    g = torch.Generator().manual_seed(17)
+    Mp, B, p = 211, 173, 2
+    Bp = B * (p + 1)
+    A, W = torch.randn(Mp, Bp, generator=g) * 0.1, torch.randn(Mp, Bp, generator=g) * 0.1
+    m, c = torch.randn(Mp, generator=g), torch.tensor([0.3])
+    y = torch.randn(Bp, generator=g)
+    hyp = _hyp(dev, 0.7, 1.2, 0.05)
+    mu, var = torch.empty(Bp, device=dev), torch.empty(Bp, device=dev)
+    ops.predictive_stats(ctx, A.to(dev), W.to(dev), p, m.to(dev), c.to(dev), hyp, mu, var)
+    A6, W6 = A.double(), W.double()
+    dg = 1.2 * O.kernel_diag(B, p, torch.tensor(0.7, dtype=torch.float64))
+    mu_ref = A6.t() @ m.double() + 0.3
+    var_ref = dg + 1e-4 + (W6 * W6 - A6 * A6).sum(0)
+    assert relmax(mu, mu_ref) < 1e-5 and relmax(var, var_ref) < 1e-5
+    for mll, name in ((0, "ELBO"), (1, "PLL")):
+        mur = mu_ref.clone().requires_grad_(True)
+        varr = var_ref.clone().requires_grad_(True)
+        noise = torch.tensor(0.05, dtype=torch.float64, requires_grad=True)
+        varn = varr + noise
+        if mll == 0:
+            ll = -0.5 * (((y.double() - mur) ** 2 + varn) / noise + torch.log(noise) + np.log(2 * np.pi))
+        else:
+            tot = varn + noise
+            ll = -0.5 * ((y.double() - mur) ** 2 / tot + torch.log(tot) + np.log(2 * np.pi))
+        rows = 2.0 * Bp
+        (-(ll.sum()) / rows).backward()
+        mb, vb, vn = (torch.empty(Bp, device=dev) for _ in range(3))
+        sc = torch.empty(8, device=dev)
+        ops.likelihood_terms(ctx, mu_ref.float().to(dev), var_ref.float().to(dev), y.to(dev), p, hyp, mll, rows, mb, vb, vn, sc)
+        assert relmax(mb, mur.grad) < 1e-5 and relmax(vb, varr.grad) < 1e-5, name
+        assert relmax(vn, varn.detach()) < 1e-6
+        assert abs(sc[0].item() - ll.sum().item()) < 1e-4 * abs(ll.sum().item())
+        assert abs(sc[1].item() - noise.grad.item()) < 1e-4 * abs(noise.grad.item())
+        assert abs(sc[2].item() - mur.grad.sum().item()) < 1e-4 * max(abs(mur.grad.sum().item()), 1e-3)
+    U = torch.randn(Mp, Bp, generator=g)
+    out = torch.empty(Mp, Bp, device=dev)
+    ops.abar(ctx, A.to(dev), U.to(dev), m.to(dev), mb, vb, out)
+    ref = m.double()[:, None] * mb.cpu().double()[None] + 2 * vb.cpu().double()[None] * (U.double() - A6)
+    assert relmax(out, ref) < 1e-5
+    acc = torch.ones(Mp, device=dev)
+    ops.rowdot_accum(ctx, A.to(dev), mb, acc)
+    assert relmax(acc, 1 + A6 @ mb.cpu().double()) < 1e-5
+
+
+def test_kl_terms_phi_transpose_adddiag(dsvgp, gpu_device):
+    ops = dsvgp._ops
+    dev = gpu_device
+    ctx = ops.Context.get(dev)
+    g = torch.Generator().manual_seed(19)
+    Mp, nd = 301, 1234.0
+    m = torch.randn(Mp, generator=g)
+    LS = torch.eye(Mp) + 0.05 * torch.randn(Mp, Mp, generator=g)          # upper part is garbage that must be ignored
+    mr = m.double().requires_grad_(True)
+    Lr = LS.double().requires_grad_(True)
+    kl = O.kl_whitened(mr, torch.tril(Lr))
+    (kl / nd).backward()
+    buf = torch.zeros(Mp + 1, device=dev)
+    dm = torch.ones(Mp, device=dev)
+    dL = torch.full((Mp, Mp), 5.0, device=dev).tril()                      # pre-existing lower gradient is accumulated
+    ops.kl_terms(ctx, m.to(dev), LS.to(dev), nd, buf, dm, dL)
+    assert abs(buf[0].item() - kl.item()) < 1e-4 * abs(kl.item())
+    assert relmax(dm, 1 + mr.grad) < 1e-5
+    assert relmax(dL, 5.0 * torch.ones(Mp, Mp, dtype=torch.float64).tril() + Lr.grad) < 1e-5
+    G = torch.randn(Mp, Mp, generator=g, dtype=torch.float64)
+    Gd = G.to(dev)
+    ops.phi_symmetrize_(ctx, Gd)
+    Phi = G.tril()
+    Phi.diagonal().mul_(0.5)
+    assert relmax(Gd, Phi + Phi.t()) < 1e-15
+    R = torch.randn(130, 77, generator=g, dtype=torch.float64).to(dev)
+    Rt = torch.empty(77, 130, dtype=torch.float64, device=dev)
+    ops.transpose_f64(ctx, R, Rt)
+    assert torch.equal(Rt, R.t())
+    ops.add_diag_(ctx, Gd, 0.25)
+    assert relmax(Gd, Phi + Phi.t() + 0.25 * torch.eye(Mp, dtype=torch.float64)) < 1e-15
+
+
+def test_gather_batch_and_fused_adam(dsvgp, gpu_device):
+    ops = dsvgp._ops
+    dev = gpu_device
+    ctx = ops.Context.get(dev)
+    g = torch.Generator().manual_seed(23)
+    N, d, p = 500, 7, 3
+    X, Y = torch.rand(N, d, generator=g), torch.rand(N, d + 1, generator=g)
+    idx = torch.randperm(N, generator=g)[:64]
+    cols = [0, 2, 5, 6]
+    xb = torch.empty(64, d, device=dev)
+    yb = torch.empty(64 * (p + 1), device=dev)
+    ops.gather_batch(ctx, X.to(dev), Y.to(dev), idx.to(dev), torch.tensor(cols, dtype=torch.int32, device=dev), p, xb, yb)
+    assert torch.equal(xb.cpu(), X[idx]) and torch.equal(yb.cpu(), Y[idx][:, cols].reshape(-1))
+    # Adam: 5 steps against torch.optim.Adam
+    w0 = torch.randn(1000, generator=g)
+    wt = w0.clone().requires_grad_(True)
+    wh = torch.nn.Parameter(w0.clone().to(dev))
+    ot = torch.optim.Adam([wt], lr=0.01)
+    oh = dsvgp.FusedAdam([wh], lr=0.01)
+    for k in range(5):
+        gr = torch.randn(1000, generator=g) * (k + 1)
+        wt.grad = gr.clone()
+        wh.grad = gr.clone().to(dev)
+        ot.step()
+        oh.step()
+    assert relmax(wh.detach(), wt.detach()) < 2e-6
+
+
+def test_no_cpu_fallback(dsvgp):
+    """The product path refuses CPU tensors instead of silently computing elsewhere."""
+    with pytest.raises(Exception):
+        dsvgp._ops.Context.get(torch.device("cpu"))
+    eng = dsvgp.ElboEngine(torch.device("cpu"))
+    P = O.init_params(torch.rand(4, 2), torch.eye(2)[:1].repeat(4, 1))
+    with pytest.raises(Exception):
+        eng.predict(P, torch.rand(3, 2), torch.eye(2)[:1].repeat(3, 1))

@@ -1,0 +1,195 @@
+"""GPU parity tests, step level: the fused HIP ELBO forward/backward, prediction and the train_gp /
+eval_gp drop-in against the CPU oracle (reference-mixed precision: fp32 model, fp64 Cholesky/solves).
+
+Stated tolerance (fp32 path vs oracle): loss 2e-5 relative, predictive mean/variance 2e-4 of the max
+magnitude, gradients 2e-3 relative in max-norm per parameter (the K_ZZ path amplifies fp32 kernel
+rounding by cond(L) ~ 1e2-1e3; the oracle's own fp32-vs-fp64 spread is of the same size)."""
+import math
+
+import pytest
+import torch
+
+import dsvgp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def make_problem(N, d, M, p, B, seed=0, perturb=True):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(N, d, generator=g)
+    Y = O.testfun(X)
+    Z = X[:M].clone()
+    V = torch.eye(d)[:p].repeat(M, 1)
+    if perturb:
+        V = V + 0.1 * torch.randn(M * p, d, generator=g)
+    P = O.init_params(Z, V, torch.float32, mean_init_std=0.2 if perturb else 1e-3, generator=g)
+    Mp = M * (p + 1)
+    if perturb:
+        P["chol_variational_covar"] = torch.eye(Mp) + 0.05 * torch.randn(Mp, Mp, generator=g)   # garbage above diag is masked
+        P["constant"] = torch.tensor([0.1])
+        P["raw_outputscale"] = torch.tensor(0.2)
+        P["raw_lengthscale"] = torch.tensor([[0.3]])
+        P["raw_noise"] = torch.tensor([-0.5])
+    cols = sorted([0] + (torch.randperm(d, generator=g)[:p] + 1).tolist())
+    x = X[M:M + B].contiguous()
+    y = Y[M:M + B][:, cols].reshape(-1).contiguous()
+    D = torch.eye(d)[[c - 1 for c in cols[1:]]].repeat(B, 1)
+    return P, x, y, D, (d + 1) * N
+
+
+def run_gpu(dsvgp, dev, P, x, y, D, nd, mll="ELBO", **kw):
+    eng = dsvgp.ElboEngine(dev, **{k: v for k, v in kw.items() if k == "trsm_nb"})
+    Pg = {k: v.to(dev) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(dev), y.to(dev), D.to(dev), nd, mll,
+                                               **{k: v for k, v in kw.items() if k != "trsm_nb"})
+    torch.cuda.synchronize()
+    return loss, grads, mu, varn, eng, Pg
+
+
+CASES = [
+    # N, d, M, p, B
+    (400, 2, 20, 2, 200),      # reference tests/test_dsvgp.py sizes
+    (600, 5, 40, 2, 128),      # scaled-down C2
+    (500, 20, 30, 5, 96),      # C4 geometry (d=20, p=5), small M/B
+    (300, 4, 25, 4, 50),       # p == d (full gradient)
+    (300, 6, 70, 0, 64),       # p = 0: plain SVGP special case
+]
+
+
+@pytest.mark.parametrize("N,d,M,p,B", CASES)
+@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+def test_step_matches_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=N + d)
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd, mll)
+    loss, grads, mu, varn, _, _ = run_gpu(dsvgp, gpu_device, P, x, y, D, nd, mll)
+    assert abs(loss.item() - l_ref.item()) < 2e-5 * abs(l_ref.item()), (loss.item(), l_ref.item())
+    assert relmax(mu, mu_ref) < 2e-4 and relmax(varn, var_ref) < 2e-4
+    P64 = {k: v.double() for k, v in P.items()}
+    _, g64, _, _ = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), nd, mll)
+    for k in O.PARAM_NAMES:
+        if p == 0 and k == "inducing_directions":
+            continue
+        gr = g_ref[k]
+        if k == "chol_variational_covar":
+            assert grads[k].triu(1).abs().max().item() == 0.0
+        e_mixed, e_64 = relmax(grads[k], gr), relmax(grads[k], g64[k])
+        assert min(e_mixed, e_64) < 2e-3, (k, e_mixed, e_64)
+
+
+def test_step_at_c2_sizes_against_oracle(dsvgp, gpu_device):
+    """BASELINE config 2: d=5, M=200, p=2 (M'=600), B=512."""
+    P, x, y, D, nd = make_problem(10000, 5, 200, 2, 512, seed=42)
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd)
+    for nb in (128, 512, 1024):
+        loss, grads, mu, varn, _, _ = run_gpu(dsvgp, gpu_device, P, x, y, D, nd, trsm_nb=nb)
+        assert abs(loss.item() - l_ref.item()) < 2e-5 * abs(l_ref.item())
+        assert relmax(mu, mu_ref) < 2e-4 and relmax(varn, var_ref) < 2e-4
+        for k in O.PARAM_NAMES:
+            assert relmax(grads[k], g_ref[k]) < 5e-3, (nb, k, relmax(grads[k], g_ref[k]))
+
+
+def test_predict_matches_oracle_and_initial_variance(dsvgp, gpu_device):
+    P, x, y, D, nd = make_problem(500, 5, 40, 2, 100, seed=9)
+    mu_ref, var_ref = O.predictive(P, x, D)
+    _, _, noise = O.constrained(P)
+    eng = dsvgp.ElboEngine(gpu_device)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    mu, varn = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu, mu_ref) < 2e-4 and relmax(varn, var_ref + noise) < 2e-4
+    # q(u) = N(0, I): variance is exactly prior diag + 1e-4 + noise (size-independent identity)
+    P0, x0, _, D0, _ = make_problem(500, 5, 40, 2, 100, seed=9, perturb=False)
+    P0["variational_mean"].zero_()
+    Pg0 = {k: v.to(gpu_device) for k, v in P0.items()}
+    mu0, varn0 = eng.predict(Pg0, x0.to(gpu_device), D0.to(gpu_device))
+    ell, s, noise0 = O.constrained(P0)
+    expect = s * O.kernel_diag(100, 2, ell) + 1e-4 + noise0
+    assert relmax(varn0, expect) < 1e-5 and mu0.abs().max().item() < 1e-6
+
+
+def test_not_psd_raises_like_reference(dsvgp, gpu_device):
+    P, x, y, D, nd = make_problem(200, 3, 10, 1, 20, seed=1)
+    P["raw_outputscale"] = torch.tensor(float("nan"))
+    with pytest.raises(dsvgp.NotPSDError):
+        run_gpu(dsvgp, gpu_device, P, x, y, D, nd)
+
+
+def test_full_size_properties_c4(dsvgp, gpu_device):
+    """BASELINE config 4 geometry at full size on one GPU (d=20, M=500, p=5 -> M'=3000; B=4096 -> B'=24576):
+    size-independent identities instead of an oracle run."""
+    torch.manual_seed(0)
+    dev = gpu_device
+    N, d, M, p, B = 20000, 20, 500, 5, 4096
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=4, perturb=False)
+    loss, grads, mu, varn, eng, Pg = run_gpu(dsvgp, dev, P, x, y, D, nd)
+    assert math.isfinite(loss.item())
+    ell, s, noise = O.constrained(P)
+    # (1) L L^T == K_ZZ + 1e-3 I  and  L A == K_ZX  (residuals of the fp64 factor / panel solve)
+    L = eng._buf["L"].tril()
+    ops = dsvgp._ops
+    ctx = ops.Context.get(dev)
+    hyp = ops.hyp_forward(ctx, Pg["raw_lengthscale"], Pg["raw_outputscale"], Pg["raw_noise"])
+    pz = ops.pack_points(ctx, Pg["inducing_points"], Pg["inducing_directions"], p, hyp)
+    Kzz = ops.kernel_fwd(ctx, pz, M, pz, M, d, p, hyp, jitter=1e-3, dtype=torch.float64)
+    assert ((L @ L.t()).tril() - Kzz.tril()).abs().max().item() < 1e-10
+    assert (Kzz - Kzz.t()).abs().max().item() < 1e-5
+    Kzx = eng._buf["Kzx"].double()
+    assert ((L @ eng._buf["A64"]) - Kzx).abs().max().item() < 1e-9
+    # (2) with L_S = I: W == A, variance == prior diag + 1e-4 + noise
+    expect = (s * O.kernel_diag(B, p, ell) + 1e-4 + noise).float()
+    assert relmax(varn, expect) < 1e-5
+    # (3) K_ZX == K_XZ^T (the redundant reference assembly)
+    px = ops.pack_points(ctx, x.to(dev), D.to(dev), p, hyp)
+    Kxz = ops.kernel_fwd(ctx, px, B, pz, M, d, p, hyp)
+    assert (Kxz.t() - eng._buf["Kzx"]).abs().max().item() < 1e-5
+    # (4) linearity of the data-parallel split: two half batches, KL once, sum == full batch
+    h = B // 2
+    q = p + 1
+    l1, g1, _, _ = eng.loss_and_grads(Pg, x[:h].to(dev), y[:h * q].to(dev), D[:h * p].to(dev), nd, global_rows=B * q, include_kl=True)
+    g1 = {k: v.clone() for k, v in g1.items()}
+    l1 = l1.clone()
+    l2, g2, _, _ = eng.loss_and_grads(Pg, x[h:].to(dev), y[h * q:].to(dev), D[h * p:].to(dev), nd, global_rows=B * q, include_kl=False)
+    assert abs((l1 + l2).item() - loss.item()) < 1e-4 * abs(loss.item())
+    for k in grads:
+        assert relmax(g1[k] + g2[k], grads[k]) < 5e-3, k
+
+
+def test_train_gp_eval_gp_drop_in(dsvgp, gpu_device, capsys):
+    """reference tests/test_dsvgp.py (n=600, d=2, M=20, p=2, B=200) shortened: loss goes down,
+    predictions have the reference's shapes/ordering and a sane error."""
+    from torch.utils.data import TensorDataset
+    torch.manual_seed(0)
+    n, dim, n_test = 600, 2, 300
+    train_x, test_x = torch.rand(n, dim), torch.rand(n_test, dim)
+    train_y, test_y = O.testfun(train_x), O.testfun(test_x)
+    ds, dst = TensorDataset(train_x, train_y), TensorDataset(test_x, test_y)
+    model, likelihood = dsvgp.train_gp(ds, num_inducing=20, num_directions=2, minibatch_size=200, minibatch_dim=2,
+                                       num_epochs=150, learning_rate_hypers=0.01, learning_rate_ngd=0.1,
+                                       inducing_data_initialization=False, use_ngd=False, use_ciq=False,
+                                       lr_sched=None, num_contour_quadrature=15, tqdm=False, verbose=True, seed=0)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert len(losses) >= 5 and losses[-1] < losses[0] - 0.5
+    keys = set(model.state_dict().keys())
+    for k in ["variational_strategy.inducing_points", "variational_strategy.inducing_directions",
+              "variational_strategy._variational_distribution.variational_mean",
+              "variational_strategy._variational_distribution.chol_variational_covar",
+              "variational_strategy.updated_strategy", "variational_strategy.variational_params_initialized",
+              "mean_module.constant", "covar_module.raw_outputscale", "covar_module.base_kernel.raw_lengthscale"]:
+        assert k in keys, k
+    assert "noise_covar.raw_noise" in likelihood.state_dict()
+    means, variances = dsvgp.eval_gp(dst, model, likelihood, num_directions=2, minibatch_size=128, minibatch_dim=2)
+    assert means.shape == (n_test * 3,) and variances.shape == (n_test * 3,) and not means.is_cuda
+    assert (variances > 0).all()
+    mse = ((means[::3] - test_y[:, 0]) ** 2).mean().item()
+    assert mse < 0.25, mse          # variance of sin(2 pi r^2) on the unit square is ~0.5
+    # eval path == oracle predictive on the trained parameters
+    P = {k: v.detach().cpu() for k, v in model._param_dict(likelihood).items()}
+    D = torch.eye(dim)[:2].repeat(n_test, 1)
+    mu_ref, var_ref = O.predictive(P, test_x, D)
+    _, _, noise = O.constrained(P)
+    assert relmax(means, mu_ref) < 5e-4 and relmax(variances, var_ref + noise) < 5e-4

@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the data-parallel wrapper (row sharding, global normalisation, KL on
+one rank, single flat all-reduce) reproduces the single-process step.  The compute engine is swapped
+for the CPU oracle here -- the HIP engine itself is covered by the -m gpu tests -- so this exercises
+exactly the N>1 logic that bench.py / train_gp run over RCCL on the GPU box."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dsvgp_oracle as O
+
+
+class OracleEngine:
+    """Same call signature as dsvgp_amd.ElboEngine.loss_and_grads, computed by the oracle."""
+
+    def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True):
+        ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        loss, mu, varn = O.elbo_forward(ps, x, y, D, num_data, mll_type, global_rows)
+        if not include_kl:
+            loss = loss - O.kl_whitened(ps["variational_mean"], torch.tril(ps["chol_variational_covar"])) / num_data
+        loss.backward()
+        grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in O.PARAM_NAMES}
+        return loss.detach(), grads, mu.detach(), varn.detach()
+
+
+def _problem():
+    g = torch.Generator().manual_seed(0)
+    N, d, M, p, B = 80, 4, 7, 2, 11          # odd global batch: ragged shards
+    X = torch.rand(N, d, generator=g, dtype=torch.float64)
+    Y = O.testfun(X)
+    P = O.init_params(X[:M], torch.eye(d)[:p].repeat(M, 1), torch.float64, 0.3, g)
+    P["chol_variational_covar"] = torch.eye(M * 3, dtype=torch.float64) + 0.1 * torch.randn(M * 3, M * 3, generator=g, dtype=torch.float64).tril()
+    x = X[20:20 + B]
+    y = Y[20:20 + B][:, [0, 2, 3]].reshape(-1)
+    D = torch.eye(d, dtype=torch.float64)[[1, 2]].repeat(B, 1)
+    return P, x, y, D, (d + 1) * N, p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsvgp_amd
+    P, x, y, D, nd, p = _problem()
+    dp = dsvgp_amd.DataParallel()
+    lo, hi = dp.shard_bounds(x.shape[0])
+    dp.global_batch = x.shape[0]
+    loss, grads, mu, varn = dp.loss_and_grads(OracleEngine(), P, x[lo:hi], y[lo * (p + 1):hi * (p + 1)],
+                                              D[lo * p:hi * p], nd, "ELBO")
+    out[rank] = (loss.item(), {k: v.clone() for k, v in grads.items()}, (lo, hi), mu.shape[0])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_equals_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    P, x, y, D, nd, p = _problem()
+    l_ref, g_ref, _, _ = O.elbo_loss_and_grads(P, x, y, D, nd)
+    assert out[0][2] == (0, 6) and out[1][2] == (6, 11)            # ragged tail goes to the low rank
+    assert out[0][3] == 18 and out[1][3] == 15
+    for r in (0, 1):
+        loss, grads = out[r][0], out[r][1]
+        assert abs(loss - l_ref.item()) < 1e-12
+        for k in g_ref:
+            assert (grads[k] - g_ref[k]).abs().max().item() < 1e-12, (r, k)
