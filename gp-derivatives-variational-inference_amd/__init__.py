@@ -13,7 +13,7 @@ from . import RBFKernelDirectionalGrad as _rbf_mod
 from . import DirectionalGradVariationalStrategy as _dgvs_mod
 from . import directional_vi  # noqa: F401
 from ._step import ElboEngine, NotPSDError, PARAM_NAMES  # noqa: F401
-from .directional_vi import GPModel, eval_gp, select_cols_of_y, train_gp  # noqa: F401
+from .directional_vi import GPModel, TrainLoop, eval_gp, select_cols_of_y, setup_training, train_gp  # noqa: F401
 from .gp_shim import GaussianLikelihood, PredictiveLogLikelihood, VariationalELBO  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .parallel import DataParallel  # noqa: F401

@@ -166,6 +166,17 @@ def trsm(ctx, L, B, trans, X64, X32, nb, workspace, reuse_inverse=False):
                          1 if reuse_inverse else 0), "dsvgp_trsm")
 
 
+def trtri_blocks(ctx, L, nrhs_max, nb, workspace):
+    """Invert the nb x nb diagonal blocks of L into the trsm workspace (the first phase of dsvgp_trsm)."""
+    _req(L, f64, "L", 2)
+    n = L.shape[0]
+    need = int(lib.dsvgp_trsm_workspace_bytes(n, nrhs_max, nb))
+    if workspace.numel() < need:
+        raise ValueError("trsm workspace too small: %d < %d" % (workspace.numel(), need))
+    check(lib.dsvgp_trsm(ctx.h, _ptr(L), _ld(L), n, 0, _ptr(workspace), 0, 1, 0, _ptr(workspace), 0, None, 0, nb,
+                         _ptr(workspace), 0), "dsvgp_trsm(trtri)")
+
+
 def gemm(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0, Cin=None, C32=None, kscale=None, M=None, N=None, K=None):
     """C_out = alpha*op(A)op(B) + beta*Cin on the MFMA GEMM; compute dtype = C_out.dtype."""
     isd = C_out.dtype == f64

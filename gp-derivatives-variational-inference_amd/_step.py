@@ -41,7 +41,8 @@ class ElboEngine:
         self.device = torch.device(device)
         self.trsm_nb = int(trsm_nb)
         self._buf = {}
-        self._key = None
+        self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
+        self.events = []
 
     # ---- workspace management ---------------------------------------------------------------
     def _get(self, name, shape, dtype):
@@ -96,7 +97,14 @@ class ElboEngine:
         A64 = self._get("A64", (Mp, Bp), f64)
         A32 = self._get("A32", (Mp, Bp), f32)
         ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp), self.trsm_nb))
-        _ops.trsm(ctx, L, Kzx, False, A64, A32, self.trsm_nb, ws, reuse_inverse=False)
+        _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws)
+        if self.record_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _ops.trsm(ctx, L, Kzx, False, A64, A32, self.trsm_nb, ws, reuse_inverse=True)
+        if self.record_events:
+            e1.record()
+            self.events.append(("solve_fwd", e0, e1))
         LS = params["chol_variational_covar"]
         W = self._get("W", (Mp, Bp), f32)
         # W = tril(L_S)^T A : op(A) = L_S^T is upper triangular -> the strict upper part of the

@@ -88,38 +88,67 @@ def _dataset_tensors(dataset, device):
             Y.to(device=device, dtype=torch.float32).contiguous())
 
 
-def train_gp(train_dataset, num_inducing=128,
-             num_directions=1, minibatch_size=1, minibatch_dim=1, num_epochs=1,
-             learning_rate_hypers=0.01, learning_rate_ngd=0.1,
-             inducing_data_initialization=True,
-             use_ngd=False,
-             use_ciq=False,
-             lr_sched=None,
-             mll_type="ELBO",
-             num_contour_quadrature=15,
-             watch_model=False, gamma=0.1,
-             verbose=True,
-             fixed_inducing_locations=None,
-             **args):
-    """Train a Derivative GP with the Directional Derivative Variational Inference method
-    (argument meaning identical to the reference, directional_vi.py:106-129).
+class TrainLoop:
+    """State of one training run: resident dataset, model, the two optimizers / schedulers and the
+    per-iteration body of the reference loop (directional_vi.py:229-254).  ``train_gp`` drives it over
+    shuffled epochs; ``bench.py`` drives the same ``step`` for its timed region."""
 
-    Extra keyword arguments understood through ``**args`` (all optional, ignored by the reference):
-      ``seed`` (int): seeds the minibatch permutation and the derivative-column sampling (required to be
-      equal on all ranks under torch.distributed; broadcast from rank 0 when omitted);
-      ``max_steps`` (int): stop after this many optimisation steps.
-    """
+    def __init__(self, X, Y, model, likelihood, mll, optimizers, schedulers, minibatch_dim, dp, col_rng, perm_gen):
+        self.X, self.Y, self.model, self.likelihood, self.mll = X, Y, model, likelihood, mll
+        self.variational_optimizer, self.hyperparameter_optimizer = optimizers
+        self.variational_scheduler, self.hyperparameter_scheduler = schedulers
+        self.minibatch_dim, self.dp, self.col_rng, self.perm_gen = minibatch_dim, dp, col_rng, perm_gen
+        self.device = X.device
+        self.dim = X.shape[1]
+        self.ctx = _ops.Context.get(self.device)
+        self.E_canonical = torch.eye(self.dim, device=self.device)
+
+    def epoch_permutation(self):
+        return torch.randperm(self.X.shape[0], device=self.device, generator=self.perm_gen)   # DataLoader(shuffle=True)
+
+    def step(self, idx):
+        """One optimisation step on the GLOBAL minibatch ``idx`` (row indices into the dataset)."""
+        dim, p, dev, dp = self.dim, self.minibatch_dim, self.device, self.dp
+        if dp is not None:
+            dp.global_batch = idx.shape[0]
+            lo, hi = dp.shard_bounds(idx.shape[0])
+            idx = idx[lo:hi]
+        # select random columns of y to train on (function values always included), :68-90
+        idx_y = sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
+        cols = torch.tensor(idx_y, dtype=torch.int32, device=dev)
+        nb = idx.shape[0]
+        x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
+        y_batch = torch.empty(nb * (p + 1), dtype=torch.float32, device=dev)
+        _ops.gather_batch(self.ctx, self.X, self.Y, idx.contiguous(), cols, p, x_batch, y_batch)   # interleaved y, :241
+        derivative_directions = self.E_canonical[np.array(idx_y[1:], dtype=np.int64) - 1]
+        kwargs = {"derivative_directions": derivative_directions.repeat(nb, 1)}                  # :238
+
+        self.variational_optimizer.zero_grad()
+        self.hyperparameter_optimizer.zero_grad()
+        output = self.likelihood(self.model(x_batch, **kwargs))
+        loss = -self.mll(output, y_batch)
+        loss.backward()
+        self.variational_optimizer.step()
+        self.variational_scheduler.step()
+        self.hyperparameter_optimizer.step()
+        self.hyperparameter_scheduler.step()
+        return loss, output, y_batch
+
+
+def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_size=1, minibatch_dim=1,
+                   num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True, lr_sched=None,
+                   mll_type="ELBO", gamma=0.1, fixed_inducing_locations=None, seed=None, tensors=None):
+    """Everything ``train_gp`` does before its loop (directional_vi.py:130-219); returns a TrainLoop."""
     assert num_directions == minibatch_dim
-    if use_ngd or use_ciq:
-        raise NotImplementedError("NGD / CIQ variants are outside the MI355X DSVGP hot path (SURVEY.md 8f)")
     if not torch.cuda.is_available():
         raise RuntimeError("train_gp needs an MI355X (HIP) device: the DSVGP hot path has no CPU fallback")
     device = torch.device("cuda", torch.cuda.current_device())
-
-    dim = len(train_dataset[0][0])
-    n_samples = len(train_dataset)
+    if tensors is not None:          # already-resident (X, Y)
+        X, Y = tensors
+    else:
+        X, Y = _dataset_tensors(train_dataset, device)
+    n_samples, dim = X.shape
     num_data = (dim + 1) * n_samples                                      # :136
-    X, Y = _dataset_tensors(train_dataset, device)
 
     if inducing_data_initialization is True:
         inducing_points = X[:num_inducing].clone()                        # first M data rows, :140-145
@@ -143,20 +172,18 @@ def train_gp(train_dataset, num_inducing=128,
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dp = DataParallel()
         model.data_parallel = dp
-    seed = args.get("seed")
-    if seed is None:
+    if seed is None and dp is not None:
         seed_t = torch.randint(0, 2 ** 31 - 1, (1,), device=device)
-        if dp is not None:
-            dist.broadcast(seed_t, 0)
-        seed = int(seed_t.item()) if dp is not None else None
+        dist.broadcast(seed_t, 0)
+        seed = int(seed_t.item())
     col_rng = random.Random(seed) if seed is not None else random      # reference: global `random`
     perm_gen = torch.Generator(device=device)
     if seed is not None:
         perm_gen.manual_seed(seed)
     else:
         perm_gen.seed()
-    if dp is not None:   # identical initial q(u) on every rank
-        model.variational_strategy._maybe_init()
+    model.variational_strategy._maybe_init()                              # q(u) <- N(0,I) + 1e-3 randn (first call)
+    if dp is not None:   # identical initial state on every rank
         for t in model._param_list(likelihood):
             dist.broadcast(t.data, 0)
 
@@ -183,40 +210,45 @@ def train_gp(train_dataset, num_inducing=128,
         mll = PredictiveLogLikelihood(likelihood, model, num_data=num_data)
     else:
         raise ValueError("mll_type must be 'ELBO' or 'PLL'")
+    return TrainLoop(X, Y, model, likelihood, mll, (variational_optimizer, hyperparameter_optimizer),
+                     (variational_scheduler, hyperparameter_scheduler), minibatch_dim, dp, col_rng, perm_gen)
 
-    ctx = _ops.Context.get(device)
-    E_canonical = torch.eye(dim, device=device)
+
+def train_gp(train_dataset, num_inducing=128,
+             num_directions=1, minibatch_size=1, minibatch_dim=1, num_epochs=1,
+             learning_rate_hypers=0.01, learning_rate_ngd=0.1,
+             inducing_data_initialization=True,
+             use_ngd=False,
+             use_ciq=False,
+             lr_sched=None,
+             mll_type="ELBO",
+             num_contour_quadrature=15,
+             watch_model=False, gamma=0.1,
+             verbose=True,
+             fixed_inducing_locations=None,
+             **args):
+    """Train a Derivative GP with the Directional Derivative Variational Inference method
+    (argument meaning identical to the reference, directional_vi.py:106-129).
+
+    Extra keyword arguments understood through ``**args`` (all optional, ignored by the reference):
+      ``seed`` (int): seeds the minibatch permutation and the derivative-column sampling (must be equal
+      on all ranks under torch.distributed; broadcast from rank 0 when omitted);
+      ``max_steps`` (int): stop after this many optimisation steps.
+    """
+    assert num_directions == minibatch_dim
+    if use_ngd or use_ciq:
+        raise NotImplementedError("NGD / CIQ variants are outside the MI355X DSVGP hot path (SURVEY.md 8f)")
+    loop = setup_training(train_dataset, num_inducing, num_directions, minibatch_size, minibatch_dim, num_epochs,
+                          learning_rate_hypers, inducing_data_initialization, lr_sched, mll_type, gamma,
+                          fixed_inducing_locations, seed=args.get("seed"))
+    n_samples = loop.X.shape[0]
     max_steps = args.get("max_steps")
     total_step = 0
     loss = None
     for i in range(num_epochs):
-        perm = torch.randperm(n_samples, device=device, generator=perm_gen)     # DataLoader(shuffle=True)
+        perm = loop.epoch_permutation()
         for start in range(0, n_samples, minibatch_size):
-            idx = perm[start:start + minibatch_size]
-            nb_global = idx.shape[0]
-            if dp is not None:
-                lo, hi = dp.shard_bounds(nb_global)
-                idx = idx[lo:hi]
-                dp.global_batch = nb_global
-            # select random columns of y to train on (function values always included), :68-90
-            idx_y = sorted(col_rng.sample(range(1, dim + 1), minibatch_dim) + [0])
-            cols = torch.tensor(idx_y, dtype=torch.int32, device=device)
-            nb = idx.shape[0]
-            x_batch = torch.empty(nb, dim, dtype=torch.float32, device=device)
-            y_batch = torch.empty(nb * (minibatch_dim + 1), dtype=torch.float32, device=device)
-            _ops.gather_batch(ctx, X, Y, idx.contiguous(), cols, minibatch_dim, x_batch, y_batch)  # interleaved y, :241
-            derivative_directions = E_canonical[np.array(idx_y[1:]) - 1]
-            kwargs = {"derivative_directions": derivative_directions.repeat(nb, 1)}             # :238
-
-            variational_optimizer.zero_grad()
-            hyperparameter_optimizer.zero_grad()
-            output = likelihood(model(x_batch, **kwargs))
-            loss = -mll(output, y_batch)
-            loss.backward()
-            variational_optimizer.step()
-            variational_scheduler.step()
-            hyperparameter_optimizer.step()
-            hyperparameter_scheduler.step()
+            loss, output, y_batch = loop.step(perm[start:start + minibatch_size])
             if total_step % 50 == 0 and verbose:
                 means = output.mean[::num_directions + 1]
                 stds = output.variance.sqrt()[::num_directions + 1]
@@ -232,7 +264,7 @@ def train_gp(train_dataset, num_inducing=128,
     if verbose and loss is not None:
         print(f"Done! loss: {loss.item()}")
         print("\nDone Training!")
-    return model, likelihood
+    return loop.model, loop.likelihood
 
 
 def eval_gp(test_dataset, model, likelihood,
