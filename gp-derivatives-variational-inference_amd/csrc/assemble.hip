@@ -296,39 +296,49 @@ __global__ __launch_bounds__(256) void kernel_bwd_kernel(const GT* __restrict__ 
     }
 }
 
-// one thread per point: slabs -> d_x1, d_v1 (through the x/ell scaling and the direction normalisation)
-__global__ void kernel_bwd_points_kernel(const float* __restrict__ slab, int nsplit, const float* __restrict__ P1,
-                                         const float* __restrict__ vnorm1, int n1, int d, int p, int K4, int DP,
-                                         int NP, const float* __restrict__ hyp, float sym,
-                                         float* __restrict__ d_x1, float* __restrict__ d_v1) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n1) return;
+// one 64-thread block per point: slabs -> d_x1, d_v1 (through the x/ell scaling and the direction normalisation)
+__global__ __launch_bounds__(64) void kernel_bwd_points_kernel(const float* __restrict__ slab, int nsplit,
+                                                               const float* __restrict__ P1,
+                                                               const float* __restrict__ vnorm1, int n1, int d, int p,
+                                                               int K4, int DP, int NP, const float* __restrict__ hyp,
+                                                               float sym, float* __restrict__ d_x1,
+                                                               float* __restrict__ d_v1) {
+    extern __shared__ float dPs[];          // [q][DP] summed over the split slabs, then [q] dots
+    const int i = blockIdx.x, t = threadIdx.x;
     const int q = p + 1;
     const int64_t n1q = (int64_t)n1 * q;
     const float ell = hyp[0];
-    auto dP = [&](int a, int col) {
+    for (int e = t; e < q * DP; e += 64) {
+        const int a = e / DP, col = e - a * DP;
         float sum = 0.f;
         for (int sp = 0; sp < nsplit; ++sp) sum += slab[((int64_t)sp * n1q + (int64_t)i * q + a) * NP + col];
-        return sum;
-    };
+        dPs[e] = sum;
+    }
+    __syncthreads();
     const float* xt = P1 + (int64_t)i * q * DP;
-    const float nbar = -0.5f * dP(0, K4);
-    // x~bar = dP[0,:] + 2 nbar x~ + sum_a alphabar_a vhat_a ; alphabar_a = -dP[a,K4]
-    for (int k = 0; k < d; ++k) {
-        float xb = dP(0, k) + 2.f * nbar * xt[k];
-        for (int a = 1; a <= p; ++a) xb += -dP(a, K4) * P1[((int64_t)i * q + a) * DP + k];
+    float* dots = dPs + q * DP;
+    // vhat-bar_a = dP[a,:] + alphabar_a x~ ; dots[a] = vhat_a . vhat-bar_a ; alphabar_a = -dP[a,K4]
+    for (int a = 1 + t; a <= p; a += 64) {
+        const float* vh = P1 + ((int64_t)i * q + a) * DP;
+        const float ab = -dPs[a * DP + K4];
+        float dot = 0.f;
+        for (int k = 0; k < d; ++k) dot += vh[k] * (dPs[a * DP + k] + ab * xt[k]);
+        dots[a] = dot;
+    }
+    __syncthreads();
+    const float nbar = -0.5f * dPs[K4];
+    for (int k = t; k < d; k += 64) {
+        // x~bar = dP[0,:] + 2 nbar x~ + sum_a alphabar_a vhat_a
+        float xb = dPs[k] + 2.f * nbar * xt[k];
+        for (int a = 1; a <= p; ++a) xb += -dPs[a * DP + K4] * P1[((int64_t)i * q + a) * DP + k];
         d_x1[(int64_t)i * d + k] += sym * xb / ell;
     }
-    for (int a = 1; a <= p; ++a) {
+    for (int e = t; e < p * d; e += 64) {
+        const int a = 1 + e / d, k = e - (a - 1) * d;
         const float* vh = P1 + ((int64_t)i * q + a) * DP;
-        const float ab = -dP(a, K4);
-        float dot = 0.f;
-        for (int k = 0; k < d; ++k) dot += vh[k] * (dP(a, k) + ab * xt[k]);
+        const float vb = dPs[a * DP + k] - dPs[a * DP + K4] * xt[k];
         const float inv = 1.f / vnorm1[(int64_t)i * p + (a - 1)];
-        for (int k = 0; k < d; ++k) {
-            const float vb = dP(a, k) + ab * xt[k];
-            d_v1[((int64_t)i * p + (a - 1)) * d + k] += sym * (vb - vh[k] * dot) * inv;   // normalisation Jacobian
-        }
+        d_v1[((int64_t)i * p + (a - 1)) * d + k] += sym * (vb - vh[k] * dots[a]) * inv;   // normalisation Jacobian
     }
 }
 
@@ -454,8 +464,8 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     }
     DSVGP_LAUNCH_CHECK();
     const float sym = symmetric ? 2.f : 1.f;
-    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(cdiv(n1, 64)), dim3(64), 0, ctx->stream, slab, ns, P1, vnorm1, n1,
-                       d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1);
+    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64), sizeof(float) * (g.q * g.DP + g.q + 1), ctx->stream,
+                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1);
     DSVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(kernel_bwd_scalars_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, ns * rt, hyp, d_hyp);
     DSVGP_LAUNCH_CHECK();

@@ -32,6 +32,7 @@ struct GemmArgs {
     int flags;
     int batch;
     int splitk;            // >1: epilogue is atomicAdd(alpha*acc) into a caller-initialised C
+    int tiles_m, tiles_n, supertile;   // filled by launch_gemm
 };
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
 

@@ -6,22 +6,42 @@
 //
 // Tiling (64-wide wavefronts): 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave a
 // 4x4 grid of 16x16 MFMA tiles (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, K=4 per
-// instruction), BK=16 per LDS stage.  Operands are staged global->registers->LDS with the next
-// stage's global loads issued before the current stage's MFMAs (latency hides under the matrix
-// pipe; fp64 MFMA is 64 cycles/instruction so the loop is matrix-pipe bound by construction).
-// LDS images: a k-contiguous operand is kept [mn][k] with row stride 17, an mn-contiguous one
-// [k][mn] with row stride 144; both give conflict-free fragment reads for ds_read_b32/_b64.
+// instruction); BK = 16 (fp64) / 32 (fp32) per stage.
+// Pipeline: global -> registers (raw element type, no conversion, so the s_waitcnt lands one full
+// MFMA phase later) -> LDS (double buffered, ONE barrier per K stage) -> fragments -> MFMA.
+// LDS images: a k-contiguous operand is kept [mn][k] with odd row stride BK+1, an mn-contiguous one
+// [k][mn] with row stride 144 (= 16 mod 32); both give conflict-free ds_read_b32/_b64 fragment reads.
+// blockIdx -> tile mapping is XCD-aware: the 8 XCDs (blocks are dealt round-robin) each get a
+// contiguous chunk of the tile grid, so the A row panel of a chunk stays in that XCD's 4 MiB L2;
+// for triangular A the heaviest row panels are scheduled first.
 #include "common.h"
+
+// tuning / ablation knobs for tools/gemm_probe (defaults = the shipped configuration)
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0      // 1: no MFMA (loads + LDS only), 2: no global loads inside the K loop
+#endif
+#ifndef GEMM_BK_F32
+#define GEMM_BK_F32 16
+#endif
+#ifndef GEMM_BK_F64
+#define GEMM_BK_F64 16
+#endif
+#ifndef GEMM_XCD
+#define GEMM_XCD 1
+#endif
+#ifndef GEMM_MINWAVES
+#define GEMM_MINWAVES 2
+#endif
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int S_MN = 144;  // [k][mn] image: 144 = 128 + 16 -> the two k rows of a 32-lane half hit disjoint bank halves
-constexpr int S_K = 17;    // [mn][k] image: odd stride
+constexpr int BM = 128, BN = 128;
+constexpr int S_MN = 144;
 
 template <typename T> struct Mfma;
 template <> struct Mfma<float> {
     using acc_t = float __attribute__((ext_vector_type(4)));
+    static constexpr int BK = GEMM_BK_F32;
     static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
@@ -29,6 +49,7 @@ template <> struct Mfma<float> {
 };
 template <> struct Mfma<double> {
     using acc_t = double __attribute__((ext_vector_type(4)));
+    static constexpr int BK = GEMM_BK_F64;
     static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
@@ -36,50 +57,95 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
 
+// Per-thread element map of one 128 x BK operand stage (EPT = 128*BK/256 elements per thread):
+//   KC (k contiguous in memory):  k = t % BK,          mn = t / BK + (256/BK) * i
+//   MN (mn contiguous in memory): mn = t & 127,        k  = (t >> 7) * (BK/2) + i
 // tri: 0 none, 1 keep k <= mn, 2 keep k >= mn   (indices local to the operand)
-template <typename TIn, typename TC, bool KC>
-__device__ __forceinline__ void load_tile(TC (&r)[8], const TIn* __restrict__ p, int64_t ld, int mn0,
-                                          int MN, int k0, int K, int tri, const float* __restrict__ kscale) {
+template <typename TIn, bool KC, int BK>
+__device__ __forceinline__ void load_raw(TIn (&r)[BK / 2], const TIn* __restrict__ p, int64_t ld, int mn0,
+                                         int MN, int k0, int K, int tri) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < BK / 2; ++i) {
         int mn, k;
-        if (KC) { k = k0 + (t & 15); mn = mn0 + (t >> 4) + 16 * i; }
-        else    { mn = mn0 + (t & 127); k = k0 + (t >> 7) * 8 + i; }
+        if (KC) { k = k0 + (t % BK); mn = mn0 + t / BK + (256 / BK) * i; }
+        else    { mn = mn0 + (t & 127); k = k0 + (t >> 7) * (BK / 2) + i; }
         bool ok = (mn < MN) && (k < K);
         if (tri == 1) ok = ok && (k <= mn);
         if (tri == 2) ok = ok && (k >= mn);
-        TC v = TC(0);
-        if (ok) {
-            v = (TC)(KC ? p[(int64_t)mn * ld + k] : p[(int64_t)k * ld + mn]);
-            if (kscale) v *= (TC)kscale[k];
-        }
+        TIn v = TIn(0);
+        if (ok) v = KC ? p[(int64_t)mn * ld + k] : p[(int64_t)k * ld + mn];
         r[i] = v;
     }
 }
 
-template <typename TC, bool KC>
-__device__ __forceinline__ void store_tile(TC* __restrict__ s, const TC (&r)[8]) {
+template <typename TIn, typename TC, bool KC, int BK>
+__device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[BK / 2], TC scale) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (KC) s[((t >> 4) + 16 * i) * S_K + (t & 15)] = r[i];
-        else    s[((t >> 7) * 8 + i) * S_MN + (t & 127)] = r[i];
+    for (int i = 0; i < BK / 2; ++i) {
+        const TC v = (TC)r[i] * scale;
+        if (KC) s[(t / BK + (256 / BK) * i) * (BK + 1) + (t % BK)] = v;
+        else    s[((t >> 7) * (BK / 2) + i) * S_MN + (t & 127)] = v;
     }
 }
 
 template <typename TC, typename TB, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
     using M = Mfma<TC>;
     using acc_t = typename M::acc_t;
-    __shared__ TC As[AKC ? BM * S_K : BK * S_MN];
-    __shared__ TC Bs[BKC ? BN * S_K : BK * S_MN];
+    constexpr int BK = M::BK;
+    constexpr int SK = BK + 1;
+    constexpr int ASZ = AKC ? BM * SK : BK * S_MN;
+    constexpr int BSZ = BKC ? BN * SK : BK * S_MN;
+    __shared__ TC As[2][ASZ];
+    __shared__ TC Bs[2][BSZ];
 
-    const int bz = blockIdx.z / g.splitk, sp = blockIdx.z % g.splitk;
+    const int fl = g.flags;
+    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
+    const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
+    const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
+
+    // XCD-aware tile mapping.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), each
+    // XCD keeps 64 workgroups resident (32 CUs x 2): give every XCD an 8x8 SUPERTILE of output tiles at
+    // a time, so that the 64 co-resident workgroups of an XCD read only 8 A panels + 8 B panels per K
+    // stage out of its private 4 MiB L2 instead of 64 + 64 from HBM / Infinity Cache.
+    const int gx = g.tiles_n, gy = g.tiles_m;
+    int tm, tn, zz;
+    if (g.supertile && GEMM_XCD) {
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int within = j & 63, Sg = (j >> 6) * 8 + xcd;     // supertile unit (z folded in: XCD balance)
+        const int nsn = (gx + 7) >> 3, nsm = (gy + 7) >> 3;
+        const bool lower_only = out_lower && nsn == nsm;
+        const int nsup = lower_only ? (nsm * (nsm + 1)) / 2 : nsn * nsm;
+        if (Sg >= nsup * g.batch * g.splitk) return;
+        zz = Sg / nsup;
+        const int S = Sg - zz * nsup;
+        int sm, sn;
+        if (lower_only) {            // enumerate supertiles on / below the diagonal only
+            sm = (int)((sqrtf(8.f * (float)S + 1.f) - 1.f) * 0.5f);
+            while ((sm + 1) * (sm + 2) / 2 <= S) ++sm;
+            while (sm * (sm + 1) / 2 > S) --sm;
+            sn = S - sm * (sm + 1) / 2;
+        } else {
+            sm = S / nsn;
+            sn = S - sm * nsn;
+        }
+        if (triA == 1) sm = nsm - 1 - sm;                       // longest K ranges first
+        tm = sm * 8 + (within >> 3);
+        tn = sn * 8 + (within & 7);
+        if (tm >= gy || tn >= gx) return;
+    } else {
+        zz = blockIdx.z;
+        tm = blockIdx.x / gx;
+        tn = blockIdx.x - tm * gx;
+        if (triA == 1 || out_lower) tm = gy - 1 - tm;
+    }
+    const int bz = zz / g.splitk, sp = zz % g.splitk;
     const bool last = (bz == g.batch - 1);
     const int Mdim = (last && g.M_last) ? g.M_last : g.M;
     const int Kdim = (last && g.K_last) ? g.K_last : g.K;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= Mdim) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -87,10 +153,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const TC* A = (const TC*)g.A + (int64_t)bz * g.sA;
     const TB* B = (const TB*)g.B + (int64_t)bz * g.sB;
     TC* C = (TC*)g.C + (int64_t)bz * g.sC;
-    const int fl = g.flags;
-    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
-    const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
-    const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
 
     if (out_lower && n0 >= m0 + BM) {  // tile strictly above the diagonal: defined as zero
         if (g.splitk == 1 || sp == 0) {
@@ -126,18 +188,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     if (klo < khi) {
-        TC ra[8], rb[8];
-        load_tile<TC, TC, AKC>(ra, A, g.lda, m0, Mdim, klo, Kdim, triA, g.kscale);
-        load_tile<TB, TC, BKC>(rb, B, g.ldb, n0, g.N, klo, Kdim, triB, nullptr);
+        TC ra[BK / 2];
+        TB rb[BK / 2];
+        TC ks = TC(1);
+        const float* __restrict__ kscale = g.kscale;   // only with k-contiguous A: one k per thread
+        auto fetch = [&](int k0) {
+            load_raw<TC, AKC, BK>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
+            load_raw<TB, BKC, BK>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
+            if (AKC && kscale) { const int k = k0 + (threadIdx.x % BK); ks = (k < Kdim) ? (TC)kscale[k] : TC(0); }
+        };
+        fetch(klo);
+        store_stage<TC, TC, AKC, BK>(As[0], ra, ks);
+        store_stage<TB, TC, BKC, BK>(Bs[0], rb, TC(1));
+        __syncthreads();
+        if (klo + BK < khi) fetch(klo + BK);
+        int cur = 0;
         for (int k0 = klo; k0 < khi; k0 += BK) {
-            __syncthreads();
-            store_tile<TC, AKC>(As, ra);
-            store_tile<TC, BKC>(Bs, rb);
-            __syncthreads();
-            if (k0 + BK < khi) {
-                load_tile<TC, TC, AKC>(ra, A, g.lda, m0, Mdim, k0 + BK, Kdim, triA, g.kscale);
-                load_tile<TB, TC, BKC>(rb, B, g.ldb, n0, g.N, k0 + BK, Kdim, triB, nullptr);
-            }
+            const TC* as = As[cur];
+            const TC* bs = Bs[cur];
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 TC a[4], b[4];
@@ -145,17 +213,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int mm = wr * 64 + i * 16 + (lane & 15);
-                    a[i] = AKC ? As[mm * S_K + kq] : As[kq * S_MN + mm];
+                    a[i] = AKC ? as[mm * SK + kq] : as[kq * S_MN + mm];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nn = wc * 64 + j * 16 + (lane & 15);
-                    b[j] = BKC ? Bs[nn * S_K + kq] : Bs[kq * S_MN + nn];
+                    b[j] = BKC ? bs[nn * SK + kq] : bs[kq * S_MN + nn];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = M::mma(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (GEMM_ABLATE == 1) { asm volatile("" :: "v"(a[i]), "v"(b[j])); }
+                        else acc[i][j] = M::mma(a[i], b[j], acc[i][j]);
+                    }
+            }
+            if (k0 + BK < khi) {
+                // stage k0+BK (already in registers) goes to the other buffer: nobody reads it any more,
+                // all waves passed the previous barrier after their last reads of it
+                store_stage<TC, TC, AKC, BK>(As[cur ^ 1], ra, ks);
+                store_stage<TB, TC, BKC, BK>(Bs[cur ^ 1], rb, TC(1));
+                __syncthreads();
+                if (GEMM_ABLATE != 2 && k0 + 2 * BK < khi) fetch(k0 + 2 * BK);
+                cur ^= 1;
             }
         }
     }
@@ -190,6 +270,7 @@ template <typename TC, typename TB>
 int dispatch(hipStream_t st, const GemmArgs& g, dim3 grid) {
     const bool akc = !(g.flags & DSVGP_GEMM_TRANS_A);  // A stored [M,K]  -> k contiguous
     const bool bkc = (g.flags & DSVGP_GEMM_TRANS_B);   // B stored [N,K]  -> k contiguous
+    if (g.kscale && !akc) return DSVGP_EINVAL;
     if (akc && bkc)        hipLaunchKernelGGL((gemm_kernel<TC, TB, true, true>), grid, dim3(256), 0, st, g);
     else if (akc && !bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, true, false>), grid, dim3(256), 0, st, g);
     else if (!akc && bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, false, true>), grid, dim3(256), 0, st, g);
@@ -197,6 +278,7 @@ int dispatch(hipStream_t st, const GemmArgs& g, dim3 grid) {
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
+
 
 // ---- inversion of 64x64 diagonal blocks (base case of the blocked trtri) -----------------------
 __global__ __launch_bounds__(64) void trtri64_kernel(const double* __restrict__ L, int64_t ldl, int n,
@@ -229,13 +311,23 @@ __global__ __launch_bounds__(64) void trtri64_kernel(const double* __restrict__ 
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.batch < 1 || g.splitk < 1) return DSVGP_EINVAL;
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
+    GemmArgs a = g;
+    a.tiles_n = cdiv(g.N, BN);
+    a.tiles_m = cdiv(g.M, BM);
+    a.supertile = (a.tiles_n * a.tiles_m >= 64) ? 1 : 0;
+    dim3 grid(a.tiles_n * a.tiles_m, 1, g.batch * g.splitk);
+    if (a.supertile) {
+        const int nsn = cdiv(a.tiles_n, 8), nsm = cdiv(a.tiles_m, 8);
+        const bool lower_only = (g.flags & DSVGP_GEMM_OUT_LOWER) && nsn == nsm;
+        const int nsup = lower_only ? (nsm * (nsm + 1)) / 2 : nsn * nsm;
+        grid = dim3(cdiv((int64_t)nsup * g.batch * g.splitk, 8) * 8 * 64, 1, 1);
+    }
     if (is_double) {
-        if (g.flags & DSVGP_GEMM_B_IS_FLOAT) return dispatch<double, float>(st, g, grid);
-        return dispatch<double, double>(st, g, grid);
+        if (g.flags & DSVGP_GEMM_B_IS_FLOAT) return dispatch<double, float>(st, a, grid);
+        return dispatch<double, double>(st, a, grid);
     }
     if (g.flags & (DSVGP_GEMM_B_IS_FLOAT | DSVGP_GEMM_CIN_IS_FLOAT)) return DSVGP_EINVAL;
-    return dispatch<float, float>(st, g, grid);
+    return dispatch<float, float>(st, a, grid);
 }
 
 // Blocked inverse of the nb x nb diagonal blocks of L by recursive doubling:
