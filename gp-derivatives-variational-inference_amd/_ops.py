@@ -245,6 +245,29 @@ def transpose_f64(ctx, src, dst):
           "dsvgp_transpose_f64")
 
 
+def residual_terms(ctx, mu, y, hyp, global_rows, mu_bar, sums):
+    check(lib.dsvgp_residual_terms(ctx.h, _ptr(mu), _ptr(_req(y, f32, "y", 1)), mu.shape[0], _ptr(hyp),
+                                   float(global_rows), _ptr(mu_bar), _ptr(sums)), "dsvgp_residual_terms")
+
+
+def trace_terms(ctx, LS, T1, G, n, sums, t1_scale=1.0):
+    check(lib.dsvgp_trace_terms(ctx.h, _ptr(LS), _ld(LS), _ptr(T1), _ld(T1), _ptr(G), _ld(G), n, float(t1_scale),
+                                _ptr(sums)), "dsvgp_trace_terms")
+
+
+def elbo_fast_finalize(ctx, sums, hyp, npts, p, global_rows, scalars):
+    check(lib.dsvgp_elbo_fast_finalize(ctx.h, _ptr(sums), _ptr(hyp), npts, p, float(global_rows), _ptr(scalars)),
+          "dsvgp_elbo_fast_finalize")
+
+
+def mirror_lower_f32_(ctx, G, n):
+    check(lib.dsvgp_mirror_lower_f32(ctx.h, _ptr(_req(G, f32, "G", 2)), n, _ld(G)), "dsvgp_mirror_lower_f32")
+
+
+def add_diag_f32_(ctx, A, n, delta):
+    check(lib.dsvgp_add_diag_f32(ctx.h, _ptr(_req(A, f32, "A", 2)), n, _ld(A), float(delta)), "dsvgp_add_diag_f32")
+
+
 def gather_batch(ctx, X, Y, idx, cols, p, xb, yb):
     check(lib.dsvgp_gather_batch(ctx.h, _ptr(_req(X, f32, "X", 2)), _ptr(_req(Y, f32, "Y", 2)),
                                  _ptr(_req(idx, torch.int64, "idx", 1)), idx.shape[0], X.shape[1], Y.shape[1],

@@ -41,6 +41,8 @@ class ElboEngine:
         self.device = torch.device(device)
         self.trsm_nb = int(trsm_nb)
         self._buf = {}
+        self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
+        self._hyp_host = None
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
 
@@ -72,6 +74,7 @@ class ElboEngine:
         info = self._get("info", (1,), torch.int32)
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
         _ops.potrf_(ctx, L, info)
+        self._hyp_host = hyp.tolist()                   # host copy of (ell, s, noise): same sync as the potrf status
         if int(info.item()) != 0:                       # rare path: psd_safe_cholesky jitter ladder
             ok = False
             for t in range(CHOL_TRIES):
@@ -128,9 +131,12 @@ class ElboEngine:
         return mu, varn
 
     @torch.no_grad()
-    def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True):
+    def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True,
+                       fast=None):
         """Returns (loss, grads dict, mu, varn).  ``global_rows`` = B'(global) for data-parallel ranks;
-        ``include_kl=False`` leaves the (replicated) KL term out so exactly one rank adds it."""
+        ``include_kl=False`` leaves the (replicated) KL term out so exactly one rank adds it.
+        ``fast`` (default ``self.elbo_fast``): in ELBO mode use the Gram-matrix formulation, which does not
+        produce per-output variances (``varn`` is then an empty tensor; ``predict`` gives them on demand)."""
         ctx = _ops.Context.get(self.device)
         hyp, packZ, L, dims = self._factor(ctx, params)
         M, d, p, Mp = dims
@@ -139,41 +145,48 @@ class ElboEngine:
         if y.shape != (Bp,):
             raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bp)
         rows = float(Bp if global_rows is None else global_rows)
-        packX, A64, A32, W, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D)
+        if fast is None:
+            fast = self.elbo_fast
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
         dev = self.device
-
-        mu_bar = torch.empty(Bp, dtype=f32, device=dev)
-        var_bar = torch.empty(Bp, dtype=f32, device=dev)
-        varn = torch.empty(Bp, dtype=f32, device=dev)
-        scal = torch.empty(8, dtype=f32, device=dev)
-        _ops.likelihood_terms(ctx, mu, var, y.contiguous(), p, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar,
-                              var_bar, varn, scal)
-
         grads = {k: torch.zeros_like(params[k], memory_format=torch.contiguous_format) for k in PARAM_NAMES}
         d_hyp = torch.zeros(4, dtype=f32, device=dev)
-
-        # ---- variational parameters ----
-        U = self._get("U", (Mp, Bp), f32)
-        _ops.gemm(ctx, A_LOWER, LS, W, U)                                   # U = L_S W
-        Abar = self._get("Abar", (Mp, Bp), f32)
-        _ops.abar(ctx, A32, U, m, mu_bar, var_bar, Abar)                    # m mu_bar^T + 2 (U - A) diag(var_bar)
-        dLS = grads["chol_variational_covar"]
-        _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, W, dLS, alpha=2.0, kscale=var_bar)   # tril(2 A diag(vbar) W^T)
-        dm = grads["variational_mean"]
-        _ops.rowdot_accum(ctx, A32, mu_bar, dm)                             # A mu_bar
+        dLS, dm = grads["chol_variational_covar"], grads["variational_mean"]
+        scal = torch.empty(8, dtype=f32, device=dev)
         kl_buf = torch.zeros(Mp + 1, dtype=f32, device=dev)
-        if include_kl:
-            _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
-
-        # ---- through the triangular solve and the Cholesky factor (fp64) ----
-        Kb64 = self._get("Kb64", (Mp, Bp), f64)
-        Kb32 = self._get("Kb32", (Mp, Bp), f32)
-        ws = self._buf["trsm_ws"]
-        _ops.trsm(ctx, L, Abar, True, Kb64, Kb32, self.trsm_nb, ws, reuse_inverse=True)     # K_ZX-bar = L^-T Abar
         Lbar = self._get("Lbar", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb64, A64, Lbar, alpha=-1.0)    # -tril(K_ZX-bar A^T)
+        Kb32 = self._get("Kb32", (Mp, Bp), f32)
+        y = y.contiguous()
+
+        if mll_type == "ELBO" and fast:
+            packX, mu = self._elbo_fast(ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl,
+                                        scal, kl_buf, dm, dLS, Kb32, Lbar)
+            varn = torch.empty(0, dtype=f32, device=dev)
+        else:
+            packX, A64, A32, W, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D)
+            mu_bar = torch.empty(Bp, dtype=f32, device=dev)
+            var_bar = torch.empty(Bp, dtype=f32, device=dev)
+            varn = torch.empty(Bp, dtype=f32, device=dev)
+            _ops.likelihood_terms(ctx, mu, var, y, p, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar, var_bar,
+                                  varn, scal)
+            # ---- variational parameters ----
+            U = self._get("U", (Mp, Bp), f32)
+            _ops.gemm(ctx, A_LOWER, LS, W, U)                                   # U = L_S W
+            Abar = self._get("Abar", (Mp, Bp), f32)
+            _ops.abar(ctx, A32, U, m, mu_bar, var_bar, Abar)                    # m mu_bar^T + 2 (U - A) diag(var_bar)
+            _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, W, dLS, alpha=2.0, kscale=var_bar)   # tril(2 A diag(vbar) W^T)
+            _ops.rowdot_accum(ctx, A32, mu_bar, dm)                             # A mu_bar
+            if include_kl:
+                _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
+            # ---- through the triangular solve (fp64) ----
+            Kb64 = self._get("Kb64", (Mp, Bp), f64)
+            ws = self._buf["trsm_ws"]
+            _ops.trsm(ctx, L, Abar, True, Kb64, Kb32, self.trsm_nb, ws, reuse_inverse=True)   # K_ZX-bar = L^-T Abar
+            _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb64, A64, Lbar, alpha=-1.0)    # L-bar = -tril(K_ZX-bar A^T)
+
+        # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 ----
+        ws = self._buf["trsm_ws"]
         G1 = self._get("G1", (Mp, Mp), f64)
         _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, L, Lbar, G1)            # L^T L-bar
         _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T
@@ -202,3 +215,69 @@ class ElboEngine:
                           grads["raw_outputscale"].reshape(-1), grads["raw_noise"].reshape(-1))
         loss = -scal[0] / rows + kl_buf[0] / float(num_data)
         return loss, grads, mu, varn
+
+    def _elbo_fast(self, ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl, scal, kl_buf, dm,
+                   dLS, Kb32, Lbar):
+        """ELBO mode: dLoss/dvar_j = vbar = 1/(2 noise rows) for every output, hence
+             sum_j var_j = prior + tr(L_S^T G L_S) - tr(G),             G = A A^T          (M' x M')
+             L_S-bar     = 2 vbar tril(G L_S)
+             K_ZX-bar    = L^-T (m mu_bar^T + 2 vbar (S - I) A) = 2 vbar [Q' | a/(2 vbar)] [A ; mu_bar^T]
+             L-bar       = -tril(K_ZX-bar A^T)                  = -2 vbar tril([Q' | a/(2 vbar)] [G ; b^T])
+           with Q' = L^-T (S - I), a = L^-T m (fp64 solves on M' x M' data), b = A mu_bar.
+           Three of the six [M', B'] products of the general path (W, U, the fp64 backward solve and the fp64
+           L-bar contraction) are replaced by one fp32 Gram product and one fp32 dense product."""
+        M, d, p, Mp = dims
+        B = x.shape[0]
+        Bp = B * (p + 1)
+        dev = self.device
+        m = params["variational_mean"]
+        LS = params["chol_variational_covar"]
+        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp)
+        Kzx = self._get("Kzx", (Mp, Bp), f32)
+        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        A64 = self._get("A64", (Mp, Bp), f64)
+        A32e = self._get("A32e", (Mp + 1, Bp), f32)          # [A ; mu_bar^T]
+        A32 = A32e[:Mp]
+        ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp + 1), self.trsm_nb))
+        _ops.trtri_blocks(ctx, L, max(Bp, Mp + 1), self.trsm_nb, ws)
+        if self.record_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _ops.trsm(ctx, L, Kzx, False, A64, A32, self.trsm_nb, ws, reuse_inverse=True)       # A = L^-1 K_ZX (fp64)
+        if self.record_events:
+            e1.record()
+            self.events.append(("solve_fwd", e0, e1))
+        mu = torch.empty(Bp, dtype=f32, device=dev)
+        var0 = torch.empty(Bp, dtype=f32, device=dev)
+        sws = self._bytes("stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, Bp))
+        _ops.predictive_stats(ctx, A32, A32, p, m, params["constant"].reshape(-1), hyp, mu, var0, sws)   # mu = A^T m + c
+        mu_bar = A32e[Mp]
+        sums = torch.empty(4, dtype=f32, device=dev)
+        _ops.residual_terms(ctx, mu, y, hyp, rows, mu_bar, sums)
+        noise = self._hyp_host[2]
+        vbar2 = 1.0 / (noise * rows)                         # 2 * vbar
+        # Gram matrix and L_S gradient
+        Ge = self._get("Ge", (Mp + 1, Mp), f32)              # [G ; b^T]
+        G = Ge[:Mp]
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, A32, G)     # tril(A A^T), split-K over the minibatch axis
+        _ops.mirror_lower_f32_(ctx, G, Mp)
+        _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
+        _ops.trace_terms(ctx, LS, dLS, G, Mp, sums, 1.0 / vbar2)
+        _ops.elbo_fast_finalize(ctx, sums, hyp, B, p, rows, scal)
+        _ops.rowdot_accum(ctx, A32, mu_bar, dm)              # b = A mu_bar (data part of m-bar)
+        Ge[Mp].copy_(dm)
+        if include_kl:
+            _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
+        # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
+        S32 = self._get("S32", (Mp, Mp), f32)
+        _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
+        _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
+        Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
+        Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
+        _ops.trsm(ctx, L, S32, True, Qe64[:, :Mp], Qe32[:, :Mp], self.trsm_nb, ws, reuse_inverse=True)
+        msc = (m * (1.0 / vbar2)).reshape(Mp, 1).contiguous()
+        _ops.trsm(ctx, L, msc, True, Qe64[:, Mp:], Qe32[:, Mp:], self.trsm_nb, ws, reuse_inverse=True)
+        # K_ZX-bar (fp32, dense) and L-bar (fp64)
+        _ops.gemm(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
+        _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)
+        return packX, mu

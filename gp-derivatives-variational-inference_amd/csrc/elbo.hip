@@ -237,6 +237,81 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, co
     }
 }
 
+// ---- ELBO fast path (constant dLoss/dvar): residuals, traces, scalar assembly -----------------------
+__global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ mu, const float* __restrict__ y,
+                                                       int ncols, const float* __restrict__ hyp, float inv_rows,
+                                                       float* __restrict__ mu_bar, float* __restrict__ sums) {
+    __shared__ float red[2][4];
+    const float noise = hyp[2];
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < ncols; j += gridDim.x * 256) {
+        const float r = y[j] - mu[j];
+        const float mb = -r / noise * inv_rows;
+        mu_bar[j] = mb;
+        a0 = fmaf(r, r, a0);
+        a1 += mb;
+    }
+    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2) atomicAdd(&sums[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+// sums[2] += sum_{i>=j} LS_ij T1_ij  (= |L_S^T A|_F^2) ; sums[3] += trace(G)
+__global__ __launch_bounds__(256) void trace_kernel(const float* __restrict__ LS, int64_t ldls,
+                                                    const float* __restrict__ T1, int64_t ldt,
+                                                    const float* __restrict__ G, int64_t ldg, int n,
+                                                    float t1_scale, float* __restrict__ sums) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j <= i; j += 256) s = fmaf(LS[(int64_t)i * ldls + j], T1[(int64_t)i * ldt + j], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2], t1_scale * (red[0] + red[1] + red[2] + red[3]));
+        atomicAdd(&sums[3], G[(int64_t)i * ldg + i]);
+    }
+}
+// scal layout of likelihood_kernel: 0 sum_ll, 1 d_noise, 2 d_constant, 3 d_outputscale(diag), 4 d_lengthscale(diag)
+__global__ void elbo_fast_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ hyp, int npts,
+                                          int p, float inv_rows, float* __restrict__ scal) {
+    if (threadIdx.x != 0) return;
+    const float ell = hyp[0], s = hyp[1], noise = hyp[2];
+    const float LOG2PI = 1.8378770664093453f;
+    const float nrow = (float)npts * (float)(p + 1);
+    const float sum_r2 = sums[0], sum_mubar = sums[1];
+    const float sum_prior = (float)npts * s * (1.f + (float)p / (ell * ell)) + nrow * 1e-4f;   // s*diag + K_XX jitter
+    const float sum_var = sum_prior + sums[2] - sums[3];
+    const float vbar = 0.5f / noise * inv_rows;                                                 // dLoss/dvar_j (constant)
+    scal[0] = -0.5f * ((sum_r2 + sum_var) / noise + nrow * (1.f + logf(noise) + LOG2PI));
+    scal[1] = 0.5f * inv_rows * (-(sum_r2 + sum_var) / (noise * noise) + nrow / noise);
+    scal[2] = sum_mubar;
+    scal[3] = vbar * (float)npts * (1.f + (float)p / (ell * ell));
+    scal[4] = vbar * (float)npts * (float)p * (-2.f * s / (ell * ell * ell));
+    scal[5] = scal[6] = scal[7] = 0.f;
+}
+__global__ void mirror_lower_f32_kernel(float* __restrict__ G, int n, int64_t ldg) {
+    __shared__ float tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bj * 32 + r, gj = bi * 32 + tx;
+        tile[r][tx] = (gi < n && gj < n) ? G[(int64_t)gi * ldg + gj] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bi * 32 + r, gj = bj * 32 + tx;
+        if (gi < n && gj < n && gj > gi) G[(int64_t)gi * ldg + gj] = tile[tx][r];
+    }
+}
+__global__ void add_diag_f32_kernel(float* A, int n, int64_t lda, float delta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(int64_t)i * lda + i] += delta;
+}
+
 }  // namespace
 
 extern "C" int dsvgp_hyp_forward(dsvgp_ctx* ctx, const float* rl, const float* rs, const float* rn, float* hyp) {
@@ -365,6 +440,49 @@ extern "C" int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ctx->stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- ELBO fast path entry points ---------------------------------------------------------------------
+extern "C" int dsvgp_residual_terms(dsvgp_ctx* ctx, const float* mu, const float* y, int ncols, const float* hyp,
+                                    double global_rows, float* mu_bar, float* sums) {
+    if (!ctx || !mu || !y || !hyp || !mu_bar || !sums || ncols < 0 || global_rows <= 0) return DSVGP_EINVAL;
+    hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(float), ctx->stream);
+    if (e != hipSuccess) return 1000 + (int)e;
+    if (ncols == 0) return 0;
+    int blocks = cdiv(ncols, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(residual_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mu, y, ncols, hyp,
+                       (float)(1.0 / global_rows), mu_bar, sums);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_trace_terms(dsvgp_ctx* ctx, const float* LS, int64_t ldls, const float* T1, int64_t ldt,
+                                 const float* G, int64_t ldg, int n, float t1_scale, float* sums) {
+    if (!ctx || !LS || !T1 || !G || !sums || n <= 0) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(trace_kernel, dim3(n), dim3(256), 0, ctx->stream, LS, ldls, T1, ldt, G, ldg, n, t1_scale, sums);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_elbo_fast_finalize(dsvgp_ctx* ctx, const float* sums, const float* hyp, int npts, int p,
+                                        double global_rows, float* out_scalars) {
+    if (!ctx || !sums || !hyp || !out_scalars || npts < 0 || p < 0 || global_rows <= 0) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(elbo_fast_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, hyp, npts, p,
+                       (float)(1.0 / global_rows), out_scalars);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_mirror_lower_f32(dsvgp_ctx* ctx, float* G, int n, int64_t ldg) {
+    if (!ctx || !G || n <= 0 || ldg < n) return DSVGP_EINVAL;
+    const int nb = cdiv(n, 32);
+    hipLaunchKernelGGL(mirror_lower_f32_kernel, dim3(nb, nb), dim3(32, 8), 0, ctx->stream, G, n, ldg);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, float delta) {
+    if (!ctx || !A || n <= 0) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(add_diag_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, delta);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -106,8 +106,11 @@ class TrainLoop:
     def epoch_permutation(self):
         return torch.randperm(self.X.shape[0], device=self.device, generator=self.perm_gen)   # DataLoader(shuffle=True)
 
-    def step(self, idx):
-        """One optimisation step on the GLOBAL minibatch ``idx`` (row indices into the dataset)."""
+    def step(self, idx, need_variance=False):
+        """One optimisation step on the GLOBAL minibatch ``idx`` (row indices into the dataset).
+        ``need_variance``: the caller will read ``output.variance`` of THIS forward (the reference's
+        every-50-steps nll print, :255-260), so the per-output path is used instead of the ELBO fast path."""
+        self.model.engine.elbo_fast = not need_variance
         dim, p, dev, dp = self.dim, self.minibatch_dim, self.device, self.dp
         if dp is not None:
             dp.global_batch = idx.shape[0]
@@ -248,8 +251,9 @@ def train_gp(train_dataset, num_inducing=128,
     for i in range(num_epochs):
         perm = loop.epoch_permutation()
         for start in range(0, n_samples, minibatch_size):
-            loss, output, y_batch = loop.step(perm[start:start + minibatch_size])
-            if total_step % 50 == 0 and verbose:
+            report = (total_step % 50 == 0) and verbose
+            loss, output, y_batch = loop.step(perm[start:start + minibatch_size], need_variance=report)
+            if report:
                 means = output.mean[::num_directions + 1]
                 stds = output.variance.sqrt()[::num_directions + 1]
                 nll = -torch.distributions.Normal(means, stds).log_prob(y_batch[::num_directions + 1]).mean()

@@ -110,7 +110,7 @@ class PredictiveDistribution:
         return out
 
     def _ensure(self):
-        if self._mu is None:
+        if self._mu is None or self._varn is None:
             lik = self.likelihood
             params = self.model._param_dict(lik)
             mu, varn = self.model.engine.predict(params, self.x, self.D)
@@ -152,7 +152,8 @@ class _ApproximateMLL(torch.nn.Module):
         dp = getattr(model, "data_parallel", None)
         elbo, mu, varn = _ElboFunction.apply(model.engine, output.x, target, output.D, float(self.num_data),
                                              self.mll_type, dp, *plist)
-        output._mu, output._varn = mu, varn
+        # the ELBO fast path does not form per-output variances; they are produced on demand
+        output._mu, output._varn = mu, (varn if varn.numel() else None)
         return elbo
 
 

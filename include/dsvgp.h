@@ -154,6 +154,23 @@ int dsvgp_phi_symmetrize(dsvgp_ctx* ctx, double* G, int n, int64_t ldg);
 int dsvgp_transpose_f64(dsvgp_ctx* ctx, const double* in, int64_t ldi, int rows, int cols, double* out,
                         int64_t ldo);
 
+/* ---- ELBO-mode fast path.  With mll_type == ELBO, dLoss/dvar_j = 1/(2 noise rows) is the same for every
+ * output, so the data term only needs  sum_j (y_j - mu_j)^2  and  sum_j var_j = prior + |L_S^T A|_F^2 - |A|_F^2,
+ * i.e. the M' x M' Gram matrix G = A A^T instead of W = L_S^T A, U = L_S W and the [M', B'] fp64 products of the
+ * backward (same quantities as DirectionalGradVariationalStrategy.py:188-205 + directional_vi.py:245-246).
+ * sums (device float[4]) = { sum r^2, sum mu_bar, sum_{i>=j} L_S_ij (G L_S)_ij, trace G }.                    */
+int dsvgp_residual_terms(dsvgp_ctx* ctx, const float* mu, const float* y, int ncols, const float* hyp,
+                         double global_rows, float* mu_bar, float* sums);          /* zeroes sums first  */
+int dsvgp_trace_terms(dsvgp_ctx* ctx, const float* LS, int64_t ldls, const float* T1, int64_t ldt,
+                      const float* G, int64_t ldg, int n, float t1_scale,          /* T1 = t1_scale * given */
+                      float* sums);                                                /* adds to sums[2..3] */
+/* out_scalars: same layout as dsvgp_likelihood_terms                                                    */
+int dsvgp_elbo_fast_finalize(dsvgp_ctx* ctx, const float* sums, const float* hyp, int npts, int p,
+                             double global_rows, float* out_scalars);
+/* copy the lower triangle of the float matrix onto its upper triangle (symmetrise a tril GEMM result)   */
+int dsvgp_mirror_lower_f32(dsvgp_ctx* ctx, float* G, int n, int64_t ldg);
+int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, float delta);
+
 /* ---- minibatch gather: DataLoader batch + select_cols_of_y (directional_vi.py:68-90,229-241)
  * xb[b,:] = X[idx[b],:] ; yb[b*(p+1)+c] = Y[idx[b], cols[c]]  (cols[0] == 0)                     */
 int dsvgp_gather_batch(dsvgp_ctx* ctx, const float* X, const float* Y, const int64_t* idx, int nb,
