@@ -40,7 +40,8 @@ SIGNATURES = {
     "dsvgp_kernel_diag": (_i, [_p, _i, _i, _p, _p]),
     "dsvgp_kernel_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_kernel_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
-    "dsvgp_potrf": (_i, [_p, _p, _i, _l, _p]),
+    "dsvgp_potrf_workspace_bytes": (_z, [_i, _i]),
+    "dsvgp_potrf": (_i, [_p, _p, _i, _l, _p, _i, _p]),
     "dsvgp_add_diag": (_i, [_p, _p, _i, _l, _d]),
     "dsvgp_trsm_workspace_bytes": (_z, [_i, _i, _i]),
     "dsvgp_trsm": (_i, [_p, _p, _l, _i, _i, _p, _l, _i, _i, _p, _l, _p, _l, _i, _p, _i]),

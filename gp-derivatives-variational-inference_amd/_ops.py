@@ -137,9 +137,21 @@ def kernel_bwd(ctx, G, pack1, n1, pack2, n2, d, p, hyp, symmetric, d_x1, d_v1, d
     return workspace
 
 
-def potrf_(ctx, A, info):
+_potrf_ws = {}
+
+
+def potrf_(ctx, A, info, algo=1):
+    """In-place lower Cholesky.  algo 0 = rocSOLVER dpotrf, 1 = blocked MFMA Cholesky (default)."""
     _req(A, f64, "A", 2)
-    check(lib.dsvgp_potrf(ctx.h, _ptr(A), A.shape[0], _ld(A), _ptr(info)), "dsvgp_potrf")
+    n = A.shape[0]
+    ws = None
+    if algo == 1:
+        key = (A.device.index, n)
+        ws = _potrf_ws.get(key)
+        if ws is None:
+            ws = torch.empty(int(lib.dsvgp_potrf_workspace_bytes(n, 1)), dtype=torch.uint8, device=A.device)
+            _potrf_ws[key] = ws
+    check(lib.dsvgp_potrf(ctx.h, _ptr(A), n, _ld(A), _ptr(info), int(algo), _ptr(ws)), "dsvgp_potrf")
 
 
 def add_diag_(ctx, A, delta):

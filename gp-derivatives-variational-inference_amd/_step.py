@@ -41,6 +41,8 @@ class ElboEngine:
         self.device = torch.device(device)
         self.trsm_nb = int(trsm_nb)
         self._buf = {}
+        self.potrf_algo = 0             # 0: rocSOLVER dpotrf (measured 6.2 ms at M'=3000), 1: blocked Cholesky on the
+                                        #    MFMA GEMM (csrc/potrf.hip, 7.1 ms: serial 64-column chain)
         self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
         self._hyp_host = None
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
@@ -73,14 +75,14 @@ class ElboEngine:
         L = self._get("L", (Mp, Mp), f64)
         info = self._get("info", (1,), torch.int32)
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
-        _ops.potrf_(ctx, L, info)
+        _ops.potrf_(ctx, L, info, self.potrf_algo)
         self._hyp_host = hyp.tolist()                   # host copy of (ell, s, noise): same sync as the potrf status
         if int(info.item()) != 0:                       # rare path: psd_safe_cholesky jitter ladder
             ok = False
             for t in range(CHOL_TRIES):
                 _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
                 _ops.add_diag_(ctx, L, CHOL_JITTER * (10 ** t))
-                _ops.potrf_(ctx, L, info)
+                _ops.potrf_(ctx, L, info, self.potrf_algo)
                 if int(info.item()) == 0:
                     ok = True
                     break

@@ -29,11 +29,19 @@ extern "C" int dsvgp_set_stream(dsvgp_ctx* ctx, void* stream) {
     return st == rocblas_status_success ? 0 : 2000 + (int)st;
 }
 
-// Row-major lower Cholesky == column-major upper factorisation of the same buffer: dpotrf(upper)
-// reads A(i,j), i<=j in column-major = the row-major lower triangle, and writes U with
-// U_colmajor(i,j) = L_rowmajor(j,i).
-extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev) {
+// algo 0: rocSOLVER dpotrf.  Row-major lower Cholesky == column-major upper factorisation of the same
+// buffer: dpotrf(upper) reads A(i,j), i<=j in column-major = the row-major lower triangle, and writes U with
+// U_colmajor(i,j) = L_rowmajor(j,i).   algo 1: blocked Cholesky on the MFMA GEMM (potrf.hip).
+extern "C" size_t dsvgp_potrf_workspace_bytes(int n, int algo) {
+    return (algo == 1 && n > 0) ? potrf_blocked_workspace_bytes(n) : 0;
+}
+extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev, int algo, void* workspace) {
     if (!ctx || !A || !info_dev || n <= 0 || lda < n) return DSVGP_EINVAL;
+    if (algo == 1) {
+        if (!workspace) return DSVGP_EINVAL;
+        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace);
+    }
+    if (algo != 0) return DSVGP_EINVAL;
     rocblas_status st = rocsolver_dpotrf((rocblas_handle)ctx->blas, rocblas_fill_upper, n, A, (rocblas_int)lda, info_dev);
     return st == rocblas_status_success ? 0 : 2000 + (int)st;
 }

@@ -34,7 +34,12 @@ struct GemmArgs {
     int splitk;            // >1: epilogue is atomicAdd(alpha*acc) into a caller-initialised C
     int tiles_m, tiles_n, supertile;   // filled by launch_gemm
 };
+constexpr int DSVGP_GEMM_KEEP_UPPER = 1 << 20;   // internal flag (with OUT_LOWER): do not touch m < n
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
+
+// blocked Cholesky (potrf.hip)
+size_t potrf_blocked_workspace_bytes(int n);
+int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* dinv_ws);
 
 // trtri of the nb x nb diagonal blocks of the lower-triangular L into Dinv (same indexing as L,
 // leading dimension ldd); tmp is an n x (nb/2) double scratch.

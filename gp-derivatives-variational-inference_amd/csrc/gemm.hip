@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
     const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
     const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
     const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
+    const bool keep_upper = fl & DSVGP_GEMM_KEEP_UPPER;   // internal: leave m < n untouched instead of zeroing it
 
     // XCD-aware tile mapping.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), each
     // XCD keeps 64 workgroups resident (32 CUs x 2): give every XCD an 8x8 SUPERTILE of output tiles at
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
     TC* C = (TC*)g.C + (int64_t)bz * g.sC;
 
     if (out_lower && n0 >= m0 + BM) {  // tile strictly above the diagonal: defined as zero
-        if (g.splitk == 1 || sp == 0) {
+        if (!keep_upper && (g.splitk == 1 || sp == 0)) {
             for (int e = threadIdx.x; e < BM * BN; e += 256) {
                 int m = m0 + e / BN, n = n0 + e % BN;
                 if (m < Mdim && n < g.N) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
                     const int64_t ci = (int64_t)m * g.ldcin + n;
                     v += beta * (cin_f ? (TC)((const float*)g.Cin)[ci] : ((const TC*)g.Cin)[ci]);
                 }
-                if (out_lower && n > m) v = TC(0);
+                if (out_lower && n > m) { if (keep_upper) continue; v = TC(0); }
                 C[(int64_t)m * g.ldc + n] = v;
                 if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
             }

@@ -227,20 +227,21 @@ def _spd(n, g, cond_jitter=1e-3):
     return K + cond_jitter * torch.eye(n, dtype=torch.float64)
 
 
-@pytest.mark.parametrize("n", [64, 100, 333, 700])
-def test_potrf_row_major_lower(dsvgp, gpu_device, n):
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("n", [64, 100, 333, 700, 1500])
+def test_potrf_row_major_lower(dsvgp, gpu_device, n, algo):
     ops = dsvgp._ops
     ctx = ops.Context.get(gpu_device)
     K = _spd(n, torch.Generator().manual_seed(n))
     A = K.tril().to(gpu_device).contiguous()                    # only the lower triangle may be read
     info = torch.full((1,), -7, dtype=torch.int32, device=gpu_device)
-    ops.potrf_(ctx, A, info)
+    ops.potrf_(ctx, A, info, algo)
     assert int(info.item()) == 0
     Lref = torch.linalg.cholesky(K)
     assert relmax(A.tril(), Lref) < 1e-10
     bad = torch.eye(n, dtype=torch.float64, device=gpu_device)
     bad[n // 2, n // 2] = -1.0
-    ops.potrf_(ctx, bad, info)
+    ops.potrf_(ctx, bad, info, algo)
     assert int(info.item()) == n // 2 + 1                       # leading minor index, as LAPACK
 
 
