@@ -12,6 +12,8 @@ from . import _lib, _ops, _step, gp_shim, optim, parallel  # noqa: F401
 from . import RBFKernelDirectionalGrad as _rbf_mod
 from . import DirectionalGradVariationalStrategy as _dgvs_mod
 from . import directional_vi  # noqa: F401
+from . import GradVariationalStrategy as _gvs_mod  # noqa: F401
+from . import grad_svgp  # noqa: F401
 from ._step import ElboEngine, NotPSDError, PARAM_NAMES  # noqa: F401
 from .directional_vi import GPModel, TrainLoop, eval_gp, select_cols_of_y, setup_training, train_gp  # noqa: F401
 from .gp_shim import GaussianLikelihood, PredictiveLogLikelihood, VariationalELBO  # noqa: F401

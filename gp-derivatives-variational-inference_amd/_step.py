@@ -41,6 +41,7 @@ class ElboEngine:
         self.device = torch.device(device)
         self.trsm_nb = int(trsm_nb)
         self._buf = {}
+        self.chol_jitter = CHOL_JITTER  # base of the psd_safe_cholesky retry ladder (1e-8 for GradVariationalStrategy)
         self.potrf_algo = 0             # 0: rocSOLVER dpotrf (measured 6.2 ms at M'=3000), 1: blocked Cholesky on the
                                         #    MFMA GEMM (csrc/potrf.hip, 7.1 ms: serial 64-column chain)
         self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
@@ -81,14 +82,14 @@ class ElboEngine:
             ok = False
             for t in range(CHOL_TRIES):
                 _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
-                _ops.add_diag_(ctx, L, CHOL_JITTER * (10 ** t))
+                _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
                 _ops.potrf_(ctx, L, info, self.potrf_algo)
                 if int(info.item()) == 0:
                     ok = True
                     break
             if not ok:
                 raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
-                                  % (CHOL_JITTER * 10 ** (CHOL_TRIES - 1)))
+                                  % (self.chol_jitter * 10 ** (CHOL_TRIES - 1)))
         return hyp, packZ, L, (M, d, p, Mp)
 
     def _interp(self, ctx, params, hyp, packZ, L, dims, x, D):

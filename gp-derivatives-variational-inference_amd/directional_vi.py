@@ -93,11 +93,13 @@ class TrainLoop:
     per-iteration body of the reference loop (directional_vi.py:229-254).  ``train_gp`` drives it over
     shuffled epochs; ``bench.py`` drives the same ``step`` for its timed region."""
 
-    def __init__(self, X, Y, model, likelihood, mll, optimizers, schedulers, minibatch_dim, dp, col_rng, perm_gen):
+    def __init__(self, X, Y, model, likelihood, mll, optimizers, schedulers, minibatch_dim, dp, col_rng, perm_gen,
+                 full_gradient=False):
         self.X, self.Y, self.model, self.likelihood, self.mll = X, Y, model, likelihood, mll
         self.variational_optimizer, self.hyperparameter_optimizer = optimizers
         self.variational_scheduler, self.hyperparameter_scheduler = schedulers
         self.minibatch_dim, self.dp, self.col_rng, self.perm_gen = minibatch_dim, dp, col_rng, perm_gen
+        self.full_gradient = full_gradient      # grad_svgp: all d+1 target columns, no derivative_directions kwarg
         self.device = X.device
         self.dim = X.shape[1]
         self.ctx = _ops.Context.get(self.device)
@@ -117,14 +119,14 @@ class TrainLoop:
             lo, hi = dp.shard_bounds(idx.shape[0])
             idx = idx[lo:hi]
         # select random columns of y to train on (function values always included), :68-90
-        idx_y = sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
+        idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
         cols = torch.tensor(idx_y, dtype=torch.int32, device=dev)
         nb = idx.shape[0]
         x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
         y_batch = torch.empty(nb * (p + 1), dtype=torch.float32, device=dev)
         _ops.gather_batch(self.ctx, self.X, self.Y, idx.contiguous(), cols, p, x_batch, y_batch)   # interleaved y, :241
         derivative_directions = self.E_canonical[np.array(idx_y[1:], dtype=np.int64) - 1]
-        kwargs = {"derivative_directions": derivative_directions.repeat(nb, 1)}                  # :238
+        kwargs = {} if self.full_gradient else {"derivative_directions": derivative_directions.repeat(nb, 1)}   # :238
 
         self.variational_optimizer.zero_grad()
         self.hyperparameter_optimizer.zero_grad()

@@ -1,0 +1,170 @@
+"""Full-gradient SVGP harness -- drop-in mirror of the reference ``directionalvi/grad_svgp.py``
+(``GPModel`` :20-39, ``train_gp`` :41-178, ``eval_gp`` :180-202): same names, arguments, defaults and
+interleaved outputs of length ``N(d+1)``.  BASELINE config 3 (d=10, N=50k, M=300 -> M(d+1)=3300).
+
+Runs on the same HIP engine as ``directional_vi`` with ``p = d`` and fixed canonical directions
+(gpytorch's ``RBFKernelGrad`` == ``RBFKernelDirectionalGrad`` with ``V = I_d``, reference
+RBFKernelDirectionalGrad.py:157-161); ``num_data = n_samples`` (:119), all ``d+1`` target columns (:143),
+``Z ~ U[0,1]^{M x d}`` (:61), nll print every 25 steps (:160-164).
+"""
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .GradVariationalStrategy import GradVariationalStrategy
+from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
+from .directional_vi import TrainLoop, _dataset_tensors
+from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
+                      PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
+from .optim import FusedAdam
+from .parallel import DataParallel
+
+
+class GPModel(ApproximateGP):
+    def __init__(self, inducing_points, **kwargs):
+        torch.nn.Module.__init__(self)
+        dim = inducing_points.size(1)
+        if kwargs.get("variational_distribution") == "NGD" or kwargs.get("variational_strategy") == "CIQ":
+            raise NotImplementedError("NGD / CIQ variants are outside the MI355X hot path (SURVEY.md 8f)")
+        variational_distribution = CholeskyVariationalDistribution(inducing_points.size(0) * (dim + 1))
+        self.variational_strategy = GradVariationalStrategy(self, inducing_points, variational_distribution,
+                                                            learn_inducing_locations=True)
+        self._engine = None
+        self.data_parallel = None
+        self.mean_module = ConstantMean()
+        self.covar_module = ScaleKernel(RBFKernelDirectionalGrad())      # stands in for gpytorch RBFKernelGrad
+        self.register_buffer("_canonical_directions", torch.eye(dim).repeat(inducing_points.size(0), 1),
+                             persistent=False)
+
+    @property
+    def engine(self):
+        eng = ApproximateGP.engine.fget(self)
+        eng.chol_jitter = 1e-8          # psd_safe_cholesky default for a double matrix (GradVariationalStrategy.py:72)
+        return eng
+
+    def _param_list(self, likelihood=None):
+        vs = self.variational_strategy
+        vd = vs._variational_distribution
+        raw_noise = (likelihood.noise_covar.raw_noise if likelihood is not None
+                     else torch.zeros(1, device=vs.inducing_points.device))
+        return [vs.inducing_points, self._canonical_directions, vd.variational_mean, vd.chol_variational_covar,
+                self.mean_module.constant, self.covar_module.raw_outputscale,
+                self.covar_module.base_kernel.raw_lengthscale, raw_noise]
+
+    def _param_dict(self, likelihood=None):
+        from ._step import PARAM_NAMES
+        return {k: v.detach() for k, v in zip(PARAM_NAMES, self._param_list(likelihood))}
+
+
+def train_gp(train_dataset, dim, num_inducing=128,
+             minibatch_size=1,
+             num_epochs=1,
+             use_ngd=False,
+             use_ciq=False,
+             learning_rate_hypers=0.01,
+             learning_rate_ngd=0.1,
+             lr_sched=None,
+             mll_type="ELBO",
+             num_contour_quadrature=15,
+             watch_model=False, gamma=0.1,
+             verbose=True,
+             **args):
+    if use_ngd or use_ciq:
+        raise NotImplementedError("NGD / CIQ variants are outside the MI355X hot path (SURVEY.md 8f)")
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_gp needs an MI355X (HIP) device: this path has no CPU fallback")
+    device = torch.device("cuda", torch.cuda.current_device())
+    X, Y = _dataset_tensors(train_dataset, device)
+    n_samples = X.shape[0]
+
+    inducing_points = torch.rand(num_inducing, dim).to(device)            # :61
+    model = GPModel(inducing_points=inducing_points).to(device)
+    likelihood = GaussianLikelihood().to(device)
+    model.train()
+    likelihood.train()
+
+    dp = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dp = DataParallel()
+        model.data_parallel = dp
+    seed = args.get("seed")
+    if seed is None and dp is not None:
+        seed_t = torch.randint(0, 2 ** 31 - 1, (1,), device=device)
+        dist.broadcast(seed_t, 0)
+        seed = int(seed_t.item())
+    perm_gen = torch.Generator(device=device)
+    perm_gen.manual_seed(seed) if seed is not None else perm_gen.seed()
+    model.variational_strategy._maybe_init()
+    if dp is not None:
+        for t in model._param_list(likelihood):
+            dist.broadcast(t.data, 0)
+
+    variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
+    hyperparameter_optimizer = FusedAdam([
+        {"params": list(model.hyperparameters())},
+        {"params": list(likelihood.parameters())},
+    ], lr=learning_rate_hypers)
+    if lr_sched == "step_lr":
+        num_batches = int(np.ceil(n_samples / minibatch_size))
+        milestones = [int(num_epochs * num_batches / 3), int(2 * num_epochs * num_batches / 3)]
+        hyperparameter_scheduler = torch.optim.lr_scheduler.MultiStepLR(hyperparameter_optimizer, milestones, gamma=gamma)
+        variational_scheduler = torch.optim.lr_scheduler.MultiStepLR(variational_optimizer, milestones, gamma=gamma)
+    else:
+        if lr_sched is None:
+            lr_sched = lambda epoch: 1.0
+        hyperparameter_scheduler = torch.optim.lr_scheduler.LambdaLR(hyperparameter_optimizer, lr_lambda=lr_sched)
+        variational_scheduler = torch.optim.lr_scheduler.LambdaLR(variational_optimizer, lr_lambda=lr_sched)
+
+    if mll_type == "ELBO":
+        mll = VariationalELBO(likelihood, model, num_data=n_samples)      # :119
+    elif mll_type == "PLL":
+        mll = PredictiveLogLikelihood(likelihood, model, num_data=n_samples)
+    else:
+        raise ValueError("mll_type must be 'ELBO' or 'PLL'")
+
+    loop = TrainLoop(X, Y, model, likelihood, mll, (variational_optimizer, hyperparameter_optimizer),
+                     (variational_scheduler, hyperparameter_scheduler), dim, dp, None, perm_gen, full_gradient=True)
+    max_steps = args.get("max_steps")
+    total_step = 0
+    loss = None
+    for i in range(num_epochs):
+        perm = loop.epoch_permutation()
+        mini_steps = 0
+        for start in range(0, n_samples, minibatch_size):
+            report = (total_step % 25 == 0) and verbose
+            loss, output, y_batch = loop.step(perm[start:start + minibatch_size], need_variance=report)
+            if report:
+                means = output.mean[::dim + 1]
+                stds = output.variance.sqrt()[::dim + 1]
+                nll = -torch.distributions.Normal(means, stds).log_prob(y_batch[::dim + 1]).mean()
+                print(f"Epoch: {i}; total_step: {mini_steps}, loss: {loss.item()}, nll: {nll}")
+            mini_steps += 1
+            total_step += 1
+            sys.stdout.flush()
+            if max_steps is not None and total_step >= max_steps:
+                break
+        if max_steps is not None and total_step >= max_steps:
+            break
+    if verbose and loss is not None:
+        print(f"Done! loss: {loss.item()}")
+    print("\nDone Training!")
+    sys.stdout.flush()
+    return model, likelihood
+
+
+def eval_gp(test_dataset, model, likelihood, mll_type="ELBO", num_inducing=128, minibatch_size=1):
+    device = model.variational_strategy.inducing_points.device
+    X, _ = _dataset_tensors(test_dataset, device)
+    model.eval()
+    likelihood.eval()
+    means, variances = [], []
+    with torch.no_grad():
+        for start in range(0, X.shape[0], minibatch_size):
+            preds = likelihood(model(X[start:start + minibatch_size]))
+            means.append(preds.mean.cpu())
+            variances.append(preds.variance.cpu())
+    means = torch.cat(means) if means else torch.zeros(0)
+    variances = torch.cat(variances) if variances else torch.zeros(0)
+    return means, variances

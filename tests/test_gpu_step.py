@@ -214,3 +214,41 @@ def test_train_gp_eval_gp_drop_in(dsvgp, gpu_device, capsys):
     # trained hyper-parameters give a worse conditioned K_ZZ: the oracle's own fp32-vs-fp64 spread is ~1e-3 here
     assert min(relmax(means, mu_ref), relmax(means, mu64)) < 2e-3
     assert min(relmax(variances, var_ref + noise), relmax(variances, var64 + noise.double())) < 2e-3
+
+
+def test_grad_svgp_drop_in(dsvgp, gpu_device, capsys):
+    """full-gradient SVGP (reference grad_svgp.py / GradVariationalStrategy.py) == the DSVGP
+    kernels with p = d and canonical directions; num_data = n_samples; reference tests/test_grad_svgp.py sizes."""
+    from torch.utils.data import TensorDataset
+    torch.manual_seed(0)
+    n, dim, n_test = 600, 2, 200
+    train_x, test_x = torch.rand(n, dim), torch.rand(n_test, dim)
+    train_y, test_y = O.testfun(train_x), O.testfun(test_x)
+    G = dsvgp.grad_svgp
+    model, likelihood = G.train_gp(TensorDataset(train_x, train_y), dim, num_inducing=20, minibatch_size=200,
+                                   num_epochs=100, mll_type="PLL", tqdm=False, seed=1)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert len(losses) >= 5 and losses[-1] < losses[0]
+    assert "variational_strategy.inducing_directions" not in model.state_dict()
+    means, variances = G.eval_gp(TensorDataset(test_x, test_y), model, likelihood, minibatch_size=64)
+    assert means.shape == (n_test * 3,) and (variances > 0).all()
+    # one ELBO step of the trained model against the oracle with p = d, V = I, D = I, num_data = n
+    P = {k: v.detach().cpu() for k, v in model._param_dict(likelihood).items()}
+    x, y = train_x[:64], train_y[:64].reshape(-1)
+    D = torch.eye(dim).repeat(64, 1)
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, n)
+    eng = dsvgp.ElboEngine(gpu_device)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), n, fast=False)
+    # trained hyper-parameters (short lengthscale) -> worse conditioned K_ZZ: compare with the mixed AND the fp64
+    # oracle; their own spread is ~1e-4 on the loss here
+    P64 = {k: v.double() for k, v in P.items()}
+    l64, g64, _, _ = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), n)
+    assert min(abs(loss.item() - l_ref.item()), abs(loss.item() - l64.item())) < 2e-4 * abs(l64.item())
+    assert relmax(mu, mu_ref) < 2e-3 and relmax(varn, var_ref) < 2e-3
+    for k in ("inducing_points", "variational_mean", "chol_variational_covar", "raw_lengthscale", "raw_noise"):
+        assert min(relmax(grads[k], g_ref[k]), relmax(grads[k], g64[k])) < 1e-2, k
+    mu_e, var_e = O.predictive(P, test_x, torch.eye(dim).repeat(n_test, 1))
+    _, _, noise = O.constrained(P)
+    assert relmax(means, mu_e) < 2e-3 and relmax(variances, var_e + noise) < 2e-3
