@@ -272,14 +272,14 @@ class ElboEngine:
         if include_kl:
             _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
         # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
-        S32 = self._get("S32", (Mp, Mp), f32)
+        S32e = self._get("S32e", (Mp, Mp + 1), f32)          # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)]
+        S32 = S32e[:, :Mp]
         _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
         _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
+        S32e[:, Mp].copy_(m * (1.0 / vbar2))
         Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
         Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
-        _ops.trsm(ctx, L, S32, True, Qe64[:, :Mp], Qe32[:, :Mp], self.trsm_nb, ws, reuse_inverse=True)
-        msc = (m * (1.0 / vbar2)).reshape(Mp, 1).contiguous()
-        _ops.trsm(ctx, L, msc, True, Qe64[:, Mp:], Qe32[:, Mp:], self.trsm_nb, ws, reuse_inverse=True)
+        _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)
         # K_ZX-bar (fp32, dense) and L-bar (fp64)
         _ops.gemm(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
         _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)

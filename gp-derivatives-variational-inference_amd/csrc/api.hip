@@ -54,31 +54,7 @@ extern "C" int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N
     g.M = M; g.N = N; g.K = K; g.A = A; g.B = B; g.Cin = Cin; g.C = C; g.C32 = C32; g.kscale = kscale;
     g.lda = lda; g.ldb = ldb; g.ldcin = ldcin; g.ldc = ldc; g.ldc32 = ldc32;
     g.alpha = alpha; g.beta = beta; g.flags = flags; g.batch = 1; g.splitk = 1;
-    // Few output tiles but a long K (the minibatch axis, or M' x M' x M' products): split K so that the
-    // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
-    const int tm = cdiv(M, 128), tn = cdiv(N, 128);
-    const int active = (flags & DSVGP_GEMM_OUT_LOWER) ? (tm * (tm + 1)) / 2 : tm * tn;
-    if (!Cin && !C32 && K >= 1024 && active > 0 && active < 1024) {
-        int sk = cdiv(2048, active);
-        const int maxsk = K / 512;
-        if (sk > maxsk) sk = maxsk;
-        if (sk > 1) {
-            g.splitk = sk;
-            const size_t esz = is_double ? 8 : 4;   // atomics accumulate into a zeroed output
-            hipError_t e = hipMemset2DAsync(C, esz * (size_t)ldc, 0, esz * (size_t)N, (size_t)M, ctx->stream);
-            if (e != hipSuccess) return 1000 + (int)e;
-        }
-    }
-    if ((flags & DSVGP_GEMM_OUT_LOWER) && g.splitk == 1) {
-        // supertiles strictly above the diagonal are never visited: define them as zero up front
-        const size_t esz = is_double ? 8 : 4;
-        hipError_t e = hipMemset2DAsync(C, esz * (size_t)ldc, 0, esz * (size_t)N, (size_t)M, ctx->stream);
-        if (e != hipSuccess) return 1000 + (int)e;
-        if (C32) {
-            e = hipMemset2DAsync(C32, 4 * (size_t)ldc32, 0, 4 * (size_t)N, (size_t)M, ctx->stream);
-            if (e != hipSuccess) return 1000 + (int)e;
-        }
-    }
+    // split-K / tril zero-fill policy lives in launch_gemm
     return launch_gemm(ctx->stream, is_double, g);
 }
 

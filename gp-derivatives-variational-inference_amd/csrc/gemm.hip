@@ -315,13 +315,40 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     GemmArgs a = g;
     a.tiles_n = cdiv(g.N, BN);
     a.tiles_m = cdiv(g.M, BM);
+    const size_t esz = is_double ? 8 : 4;
+    const bool out_lower = g.flags & DSVGP_GEMM_OUT_LOWER, keep_upper = g.flags & DSVGP_GEMM_KEEP_UPPER;
+    // Few output tiles but a long K (the minibatch axis, or M' x M' x M' products): split K so that the
+    // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
+    const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
+    if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 1024) {
+        const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 : a.tiles_m * a.tiles_n;
+        int sk = (active > 0 && active < 1024) ? cdiv(2048, active) : 1;
+        if (sk > a.K / 512) sk = a.K / 512;
+        if (sk > 1) {
+            a.splitk = sk;
+            if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; }      // atomics accumulate onto the existing C
+            else {
+                hipError_t e = hipMemset2DAsync(a.C, esz * (size_t)a.ldc, 0, esz * (size_t)a.N, (size_t)a.M, st);
+                if (e != hipSuccess) return 1000 + (int)e;
+            }
+        }
+    }
+    if (out_lower && !keep_upper && a.splitk == 1 && a.batch == 1 && g.Cin != g.C) {
+        // supertiles strictly above the diagonal are never visited: define them as zero up front
+        hipError_t e = hipMemset2DAsync(a.C, esz * (size_t)a.ldc, 0, esz * (size_t)a.N, (size_t)a.M, st);
+        if (e != hipSuccess) return 1000 + (int)e;
+        if (a.C32) {
+            e = hipMemset2DAsync(a.C32, 4 * (size_t)a.ldc32, 0, 4 * (size_t)a.N, (size_t)a.M, st);
+            if (e != hipSuccess) return 1000 + (int)e;
+        }
+    }
     a.supertile = (a.tiles_n * a.tiles_m >= 64) ? 1 : 0;
-    dim3 grid(a.tiles_n * a.tiles_m, 1, g.batch * g.splitk);
+    dim3 grid(a.tiles_n * a.tiles_m, 1, a.batch * a.splitk);
     if (a.supertile) {
         const int nsn = cdiv(a.tiles_n, 8), nsm = cdiv(a.tiles_m, 8);
         const bool lower_only = (g.flags & DSVGP_GEMM_OUT_LOWER) && nsn == nsm;
         const int nsup = lower_only ? (nsm * (nsm + 1)) / 2 : nsn * nsm;
-        grid = dim3(cdiv((int64_t)nsup * g.batch * g.splitk, 8) * 8 * 64, 1, 1);
+        grid = dim3(cdiv((int64_t)nsup * a.batch * a.splitk, 8) * 8 * 64, 1, 1);
     }
     if (is_double) {
         if (g.flags & DSVGP_GEMM_B_IS_FLOAT) return dispatch<double, float>(st, a, grid);
