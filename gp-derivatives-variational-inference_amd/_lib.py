@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (loads torch's bundled HIP/rocBLAS/rocSOLVER first so one runtime is shared)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsvgp_hip.so")
+# DSVGP_LIB_PATH lets tools/ time experimental builds of the SAME library (kernel ablations); it is not a fallback
+LIB_PATH = os.environ.get("DSVGP_LIB_PATH") or os.path.join(_HERE, "libdsvgp_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

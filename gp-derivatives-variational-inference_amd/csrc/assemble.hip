@@ -16,6 +16,10 @@
 // of K_ZZ.  The backward recomputes T, forms Tbar per micro-block and contracts Tbar . P2 on MFMA.
 #include "common.h"
 
+#ifndef ASM_ABLATE
+#define ASM_ABLATE 0      // tools only: 1 = no global stores, 2 = stores of a constant (no MFMA / epilogue math)
+#endif
+
 namespace {
 
 constexpr int TMAX = 96;   // tile rows/cols of the interleaved matrix handled per workgroup
@@ -68,8 +72,9 @@ __global__ void pack_points_kernel(const float* __restrict__ x, const float* __r
 __device__ __forceinline__ void stage_pack(float* Ps, float* selfs, const float* __restrict__ P,
                                            const float* __restrict__ self, int row0, int nvalid, int limit,
                                            int rows_pad, int DP, int ncol, int LDP) {
+    const float inv_ncol = 1.f / (float)ncol;
     for (int e = threadIdx.x; e < rows_pad * ncol; e += blockDim.x) {
-        const int r = e / ncol, k = e - r * ncol;
+        const int r = fdiv_small(e, inv_ncol), k = e - r * ncol;
         const int gr = row0 + r;
         Ps[r * LDP + k] = (r < nvalid && gr < limit && k < DP) ? P[(int64_t)gr * DP + k] : 0.f;
     }
@@ -95,51 +100,95 @@ __device__ __forceinline__ void mfma_T(float* Ts, const float* P1s, const float*
 }
 
 // ---- forward ------------------------------------------------------------------------------------
+// Workgroup tile: (Rr points x Rc points) = (Tr x Tc) outputs with Tr <= 48, Tc <= 96: ~37 KB of LDS, so four
+// workgroups (16 waves) share a CU and hide each other's staging / LDS latency.
 template <typename OutT>
 __global__ __launch_bounds__(256) void kernel_fwd_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
                                                          int n1q, const float* __restrict__ P2,
-                                                         const float* __restrict__ self2, int n2q, int q, int R,
-                                                         int K4, int DP, const float* __restrict__ hyp, float jitter,
-                                                         OutT* __restrict__ out, int64_t ld) {
+                                                         const float* __restrict__ self2, int n2q, int q, int Rr,
+                                                         int Rc, int K4, int DP, const float* __restrict__ hyp,
+                                                         float jitter, OutT* __restrict__ out, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LDP = K4 + 1;
+    const int Tr = Rr * q, Tc = Rc * q;         // valid tile extent
+    const int Trp = (Tr + 15) & ~15, Tcp = (Tc + 15) & ~15;
     float* P1s = smem;
-    float* P2s = P1s + TMAX * LDP;
-    float* Ts = P2s + TMAX * LDP;
-    float* s1 = Ts + TMAX * LDT;
-    float* s2 = s1 + TMAX;
-
-    const int T = R * q;                       // valid tile extent (rows and cols)
-    const int Tp = (T + 15) & ~15;
-    const int row0 = blockIdx.y * T, col0 = blockIdx.x * T;
-    stage_pack(P1s, s1, P1, self1, row0, T, n1q, Tp, DP, K4, LDP);
-    stage_pack(P2s, s2, P2, self2, col0, T, n2q, Tp, DP, K4, LDP);
+    float* P2s = P1s + Trp * LDP;
+    float* Ts = P2s + Tcp * LDP;
+    float* s1 = Ts + Trp * LDT;
+    float* s2 = s1 + Trp;
+    float* KK = s2 + Tcp;                       // Rr * Rc pair values
+    const int row0 = blockIdx.y * Tr, col0 = blockIdx.x * Tc;
+    const int rows = min(Tr, n1q - row0), cols = min(Tc, n2q - col0);
+    if (ASM_ABLATE == 2) {
+        for (int e = threadIdx.x; e < Tr * Tc; e += 256) {
+            const int r = e / Tc, c = e - r * Tc;
+            if (r < rows && c < cols) out[(int64_t)(row0 + r) * ld + col0 + c] = (OutT)1.f;
+        }
+        return;
+    }
+    stage_pack(P1s, s1, P1, self1, row0, Tr, n1q, Trp, DP, K4, LDP);
+    stage_pack(P2s, s2, P2, self2, col0, Tc, n2q, Tcp, DP, K4, LDP);
     __syncthreads();
-    mfma_T(Ts, P1s, P2s, Tp / 16, Tp / 16, K4, LDP);
+    if (ASM_ABLATE == 3) { if (P1s[threadIdx.x] == 123.456f) out[0] = (OutT)1.f; return; }
+    mfma_T(Ts, P1s, P2s, Trp / 16, Tcp / 16, K4, LDP);
     __syncthreads();
+    if (ASM_ABLATE == 4) { if (Ts[threadIdx.x] == 123.456f) out[0] = (OutT)1.f; return; }
 
     const float ell = hyp[0], s = hyp[1];
     const float il = 1.f / ell, il2 = il * il;
-    const float invT = 1.f / (float)T, invq = 1.f / (float)q;
-    const int rows = min(T, n1q - row0), cols = min(T, n2q - col0);
-    for (int e = threadIdx.x; e < T * T; e += 256) {
-        const int r = fdiv_small(e, invT), c = e - r * T;
-        if (r >= rows || c >= cols) continue;
-        const int ri = fdiv_small(r, invq), rj = fdiv_small(c, invq);
-        const int r0 = ri * q, c0 = rj * q;
-        const int a = r - r0, b = c - c0;
-        const float t00 = Ts[r0 * LDT + c0];
-        const float nn = fmaxf(s1[r0] + s2[c0] - 2.f * t00, 0.f);   // covar_dist clamps at 0
-        const float k = s * expf(-0.5f * nn);                        // postprocess_rbf, ScaleKernel
-        const float u = a ? (s1[r] - Ts[r * LDT + c0]) : 0.f;
-        const float w = b ? (Ts[r0 * LDT + c] - s2[c]) : 0.f;
-        float val;
-        if (a == 0) val = b ? (w * il) : 1.f;
-        else        val = b ? ((Ts[r * LDT + c] - u * w) * il2) : (-u * il);
-        val *= k;
-        const int64_t gr = row0 + r, gc = col0 + c;
-        if (gr == gc) val += jitter;
-        out[gr * ld + gc] = (OutT)val;
+    const float invq = 1.f / (float)q, invRc = 1.f / (float)Rc;
+    // pass A: one exp per PAIR of points (not per output): KK[ri][rj] = s exp(-|r|^2 / 2)
+    if (q > 1) {
+        for (int pid = threadIdx.x; pid < Rr * Rc; pid += 256) {
+            const int pi = fdiv_small(pid, invRc), pj = pid - pi * Rc;
+            const float nn = fmaxf(s1[pi * q] + s2[pj * q] - 2.f * Ts[pi * q * LDT + pj * q], 0.f);   // covar_dist clamps at 0
+            KK[pid] = s * expf(-0.5f * nn);                                                          // postprocess_rbf, ScaleKernel
+        }
+        __syncthreads();
+    }
+    // pass B: thread <-> fixed column c (consecutive lanes -> consecutive columns: coalesced stores), rows strided
+    // by the number of row groups; everything that depends only on the column (point j, direction b, s2, the
+    // addresses of T[.,c0] / T[.,c], the global column) is loop invariant, the row decomposition (point i,
+    // direction a) advances by counters: ~20 instructions and 5 LDS reads per output.
+    const int ngrp = 256 / Tc;                       // row groups that fit the workgroup (>= 2 for Tc <= 96)
+    const int c = threadIdx.x % Tc, rg = threadIdx.x / Tc;
+    if (rg < ngrp && c < cols) {
+        const int rj = fdiv_small(c, invq);
+        const int c0 = rj * q, b = c - c0;
+        const float s2c = s2[c];
+        OutT* optr = out + (int64_t)(row0 + rg) * ld + col0 + c;
+        const int64_t ostep = (int64_t)ngrp * ld;
+        const int64_t gc = col0 + c;
+        if (q > 1) {
+            int ri = fdiv_small(rg, invq);
+            int a = rg - ri * q;
+            const int da = ngrp % q, di = ngrp / q;
+#pragma unroll 4
+            for (int r = rg; r < rows; r += ngrp) {
+                const int r0 = r - a;
+                const float k = KK[ri * Rc + rj];
+                const float t = Ts[r * LDT + c];
+                const float u = s1[r] - Ts[r * LDT + c0];           // r.v1_a   (a > 0)
+                const float w = Ts[r0 * LDT + c] - s2c;             // r.v2_b   (b > 0)
+                const float f0 = b ? (w * il) : 1.f;
+                const float f1 = b ? ((t - u * w) * il2) : (-u * il);
+                float val = (a ? f1 : f0) * k;
+                if (row0 + r == gc) val += jitter;
+                if (ASM_ABLATE == 1) { if (val == 123.456f) *optr = (OutT)val; }
+                else *optr = (OutT)val;
+                optr += ostep;
+                a += da; ri += di;
+                if (a >= q) { a -= q; ++ri; }
+            }
+        } else {
+            for (int r = rg; r < rows; r += ngrp) {
+                float val = s * expf(-0.5f * fmaxf(s1[r] + s2c - 2.f * Ts[r * LDT + c], 0.f));
+                if (row0 + r == gc) val += jitter;
+                *optr = (OutT)val;
+                optr += ostep;
+            }
+        }
     }
 }
 
@@ -405,16 +454,18 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
     if (n1 == 0 || n2 == 0) return 0;
     const int n1q = n1 * g.q, n2q = n2 * g.q;
     if (ld < n2q) return DSVGP_EINVAL;
-    const size_t lds = sizeof(float) * (2 * TMAX * (g.K4 + 1) + TMAX * LDT + 2 * TMAX);
-    dim3 grid(cdiv(n2q, g.T), cdiv(n1q, g.T));
+    const int Rc = g.R, Rr = g.R >= 2 ? g.R / 2 : g.R;
+    const int Tr = Rr * g.q, Tc = Rc * g.q, Trp = (Tr + 15) & ~15, Tcp = (Tc + 15) & ~15;
+    const size_t lds = sizeof(float) * ((size_t)(Trp + Tcp) * (g.K4 + 1) + (size_t)Trp * LDT + Trp + Tcp + (size_t)Rr * Rc);
+    dim3 grid(cdiv(n2q, Tc), cdiv(n1q, Tr));
     (void)hipFuncSetAttribute((const void*)kernel_fwd_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)kernel_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (out_is_double)
         hipLaunchKernelGGL(kernel_fwd_kernel<double>, grid, dim3(256), lds, ctx->stream, P1, self1, n1q, P2, self2,
-                           n2q, g.q, g.R, g.K4, g.DP, hyp, jitter, (double*)out, ld);
+                           n2q, g.q, Rr, Rc, g.K4, g.DP, hyp, jitter, (double*)out, ld);
     else
         hipLaunchKernelGGL(kernel_fwd_kernel<float>, grid, dim3(256), lds, ctx->stream, P1, self1, n1q, P2, self2,
-                           n2q, g.q, g.R, g.K4, g.DP, hyp, jitter, (float*)out, ld);
+                           n2q, g.q, Rr, Rc, g.K4, g.DP, hyp, jitter, (float*)out, ld);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
