@@ -46,6 +46,7 @@ class ElboEngine:
                                         #    MFMA GEMM (csrc/potrf.hip, 7.1 ms: serial 64-column chain)
         self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
         self._hyp_host = None
+        self._eval_cache = None
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
 
@@ -92,7 +93,7 @@ class ElboEngine:
                                   % (self.chol_jitter * 10 ** (CHOL_TRIES - 1)))
         return hyp, packZ, L, (M, d, p, Mp)
 
-    def _interp(self, ctx, params, hyp, packZ, L, dims, x, D):
+    def _interp(self, ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=False):
         """K_ZX, A = L^-1 K_ZX (fp64 + fp32 copy), W = L_S^T A, mu, var."""
         M, d, p, Mp = dims
         B = x.shape[0]
@@ -102,8 +103,11 @@ class ElboEngine:
         _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
         A64 = self._get("A64", (Mp, Bp), f64)
         A32 = self._get("A32", (Mp, Bp), f32)
-        ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp), self.trsm_nb))
-        _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws)
+        need = _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp), self.trsm_nb)
+        old = self._buf.get("trsm_ws")
+        ws = self._bytes("trsm_ws", need)
+        if not (reuse_inverse and ws is old):           # a re-allocated workspace has no inverse in it
+            _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws)
         if self.record_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -125,11 +129,19 @@ class ElboEngine:
 
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
-    def predict(self, params, x, D):
-        """q(f) mean / variance plus likelihood noise: what ``likelihood(model(x)).mean/.variance`` returns."""
+    def predict(self, params, x, D, cache=False):
+        """q(f) mean / variance plus likelihood noise: what ``likelihood(model(x)).mean/.variance`` returns.
+        ``cache=True`` (eval mode) keeps the Cholesky factor and its inverted blocks across calls while the
+        parameters are unchanged, like the reference's ``@cached`` ``_cholesky_factor`` (DGVS.py:72)."""
         ctx = _ops.Context.get(self.device)
-        hyp, packZ, L, dims = self._factor(ctx, params)
-        _, _, _, _, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D)
+        key = tuple((t.data_ptr(), t._version) for t in (params[k] for k in PARAM_NAMES)) if cache else None
+        hit = cache and self._eval_cache is not None and self._eval_cache[0] == key
+        if hit:
+            _, hyp, packZ, L, dims = self._eval_cache
+        else:
+            hyp, packZ, L, dims = self._factor(ctx, params)
+            self._eval_cache = (key, hyp, packZ, L, dims) if cache else None
+        _, _, _, _, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=hit)
         varn = (var + hyp[2]).clamp_min_(1e-6)
         return mu, varn
 
@@ -141,6 +153,7 @@ class ElboEngine:
         ``fast`` (default ``self.elbo_fast``): in ELBO mode use the Gram-matrix formulation, which does not
         produce per-output variances (``varn`` is then an empty tensor; ``predict`` gives them on demand)."""
         ctx = _ops.Context.get(self.device)
+        self._eval_cache = None
         hyp, packZ, L, dims = self._factor(ctx, params)
         M, d, p, Mp = dims
         B = x.shape[0]

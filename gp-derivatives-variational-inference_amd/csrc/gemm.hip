@@ -35,7 +35,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
+constexpr int BM = 128;     // BN (128 or 64) is a template parameter: 64 doubles the tile count of M' x M' products
 constexpr int S_MN = 144;
 
 template <typename T> struct Mfma;
@@ -57,19 +57,19 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
 
-// Per-thread element map of one 128 x BK operand stage (EPT = 128*BK/256 elements per thread):
+// Per-thread element map of one NT x BK operand stage (NT*BK/256 elements per thread):
 //   KC (k contiguous in memory):  k = t % BK,          mn = t / BK + (256/BK) * i
-//   MN (mn contiguous in memory): mn = t & 127,        k  = (t >> 7) * (BK/2) + i
+//   MN (mn contiguous in memory): mn = t % NT,         k  = t / NT + (256/NT) * i
 // tri: 0 none, 1 keep k <= mn, 2 keep k >= mn   (indices local to the operand)
-template <typename TIn, bool KC, int BK>
-__device__ __forceinline__ void load_raw(TIn (&r)[BK / 2], const TIn* __restrict__ p, int64_t ld, int mn0,
+template <typename TIn, bool KC, int BK, int NT>
+__device__ __forceinline__ void load_raw(TIn (&r)[NT * BK / 256], const TIn* __restrict__ p, int64_t ld, int mn0,
                                          int MN, int k0, int K, int tri) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < BK / 2; ++i) {
+    for (int i = 0; i < NT * BK / 256; ++i) {
         int mn, k;
         if (KC) { k = k0 + (t % BK); mn = mn0 + t / BK + (256 / BK) * i; }
-        else    { mn = mn0 + (t & 127); k = k0 + (t >> 7) * (BK / 2) + i; }
+        else    { mn = mn0 + (t % NT); k = k0 + t / NT + (256 / NT) * i; }
         bool ok = (mn < MN) && (k < K);
         if (tri == 1) ok = ok && (k <= mn);
         if (tri == 2) ok = ok && (k >= mn);
@@ -79,19 +79,20 @@ __device__ __forceinline__ void load_raw(TIn (&r)[BK / 2], const TIn* __restrict
     }
 }
 
-template <typename TIn, typename TC, bool KC, int BK>
-__device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[BK / 2], TC scale) {
+template <typename TIn, typename TC, bool KC, int BK, int NT>
+__device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[NT * BK / 256], TC scale) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < BK / 2; ++i) {
+    for (int i = 0; i < NT * BK / 256; ++i) {
         const TC v = (TC)r[i] * scale;
         if (KC) s[(t / BK + (256 / BK) * i) * (BK + 1) + (t % BK)] = v;
-        else    s[((t >> 7) * (BK / 2) + i) * S_MN + (t & 127)] = v;
+        else    s[(t / NT + (256 / NT) * i) * S_MN + (t % NT)] = v;
     }
 }
 
-template <typename TC, typename TB, bool AKC, bool BKC>
+template <typename TC, typename TB, bool AKC, bool BKC, int BN>
 __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
+    constexpr int NJ = BN / 32;             // 16-wide MFMA column tiles per wave
     using M = Mfma<TC>;
     using acc_t = typename M::acc_t;
     constexpr int BK = M::BK;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
     const bool last = (bz == g.batch - 1);
     const int Mdim = (last && g.M_last) ? g.M_last : g.M;
     const int Kdim = (last && g.K_last) ? g.K_last : g.K;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;   // BN = template tile width
     if (m0 >= Mdim) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -182,25 +183,25 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
         klo = lo;
     }
 
-    acc_t acc[4][4];
+    acc_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     if (klo < khi) {
-        TC ra[BK / 2];
-        TB rb[BK / 2];
+        TC ra[BM * BK / 256];
+        TB rb[BN * BK / 256];
         TC ks = TC(1);
         const float* __restrict__ kscale = g.kscale;   // only with k-contiguous A: one k per thread
         auto fetch = [&](int k0) {
-            load_raw<TC, AKC, BK>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
-            load_raw<TB, BKC, BK>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
+            load_raw<TC, AKC, BK, BM>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
+            load_raw<TB, BKC, BK, BN>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
             if (AKC && kscale) { const int k = k0 + (threadIdx.x % BK); ks = (k < Kdim) ? (TC)kscale[k] : TC(0); }
         };
         fetch(klo);
-        store_stage<TC, TC, AKC, BK>(As[0], ra, ks);
-        store_stage<TB, TC, BKC, BK>(Bs[0], rb, TC(1));
+        store_stage<TC, TC, AKC, BK, BM>(As[0], ra, ks);
+        store_stage<TB, TC, BKC, BK, BN>(Bs[0], rb, TC(1));
         __syncthreads();
         if (klo + BK < khi) fetch(klo + BK);
         int cur = 0;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
             const TC* bs = Bs[cur];
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
-                TC a[4], b[4];
+                TC a[4], b[NJ];
                 const int kq = kk * 4 + (lane >> 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -217,14 +218,14 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
                     a[i] = AKC ? as[mm * SK + kq] : as[kq * S_MN + mm];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nn = wc * 64 + j * 16 + (lane & 15);
+                for (int j = 0; j < NJ; ++j) {
+                    const int nn = wc * (BN / 2) + j * 16 + (lane & 15);
                     b[j] = BKC ? bs[nn * SK + kq] : bs[kq * S_MN + nn];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         if (GEMM_ABLATE == 1) { asm volatile("" :: "v"(a[i]), "v"(b[j])); }
                         else acc[i][j] = M::mma(a[i], b[j], acc[i][j]);
                     }
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
             if (k0 + BK < khi) {
                 // stage k0+BK (already in registers) goes to the other buffer: nobody reads it any more,
                 // all waves passed the previous barrier after their last reads of it
-                store_stage<TC, TC, AKC, BK>(As[cur ^ 1], ra, ks);
-                store_stage<TB, TC, BKC, BK>(Bs[cur ^ 1], rb, TC(1));
+                store_stage<TC, TC, AKC, BK, BM>(As[cur ^ 1], ra, ks);
+                store_stage<TB, TC, BKC, BK, BN>(Bs[cur ^ 1], rb, TC(1));
                 __syncthreads();
                 if (GEMM_ABLATE != 2 && k0 + 2 * BK < khi) fetch(k0 + 2 * BK);
                 cur ^= 1;
@@ -246,11 +247,11 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 64 + i * 16 + M::row(lane, r);
-                const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+                const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
                 if (m >= Mdim || n >= g.N) continue;
                 TC v = alpha * acc[i][j][r];
                 if (g.splitk > 1) {
@@ -267,19 +268,22 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
             }
 }
 
-template <typename TC, typename TB>
-int dispatch(hipStream_t st, const GemmArgs& g, dim3 grid) {
+template <typename TC, typename TB, int BN>
+int dispatch_bn(hipStream_t st, const GemmArgs& g, dim3 grid) {
     const bool akc = !(g.flags & DSVGP_GEMM_TRANS_A);  // A stored [M,K]  -> k contiguous
     const bool bkc = (g.flags & DSVGP_GEMM_TRANS_B);   // B stored [N,K]  -> k contiguous
     if (g.kscale && !akc) return DSVGP_EINVAL;
-    if (akc && bkc)        hipLaunchKernelGGL((gemm_kernel<TC, TB, true, true>), grid, dim3(256), 0, st, g);
-    else if (akc && !bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, true, false>), grid, dim3(256), 0, st, g);
-    else if (!akc && bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, false, true>), grid, dim3(256), 0, st, g);
-    else                   hipLaunchKernelGGL((gemm_kernel<TC, TB, false, false>), grid, dim3(256), 0, st, g);
+    if (akc && bkc)        hipLaunchKernelGGL((gemm_kernel<TC, TB, true, true, BN>), grid, dim3(256), 0, st, g);
+    else if (akc && !bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, true, false, BN>), grid, dim3(256), 0, st, g);
+    else if (!akc && bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, false, true, BN>), grid, dim3(256), 0, st, g);
+    else                   hipLaunchKernelGGL((gemm_kernel<TC, TB, false, false, BN>), grid, dim3(256), 0, st, g);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
-
+template <typename TC, typename TB>
+int dispatch(hipStream_t st, const GemmArgs& g, dim3 grid) {
+    return g.bn == 64 ? dispatch_bn<TC, TB, 64>(st, g, grid) : dispatch_bn<TC, TB, 128>(st, g, grid);
+}
 
 // ---- inversion of 64x64 diagonal blocks (base case of the blocked trtri) -----------------------
 __global__ __launch_bounds__(64) void trtri64_kernel(const double* __restrict__ L, int64_t ldl, int n,
@@ -313,15 +317,18 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.batch < 1 || g.splitk < 1) return DSVGP_EINVAL;
     GemmArgs a = g;
-    a.tiles_n = cdiv(g.N, BN);
     a.tiles_m = cdiv(g.M, BM);
+    // tile width: 128 x 64 tiles were measured SLOWER than 128 x 128 + split-K for the M' x M' products
+    // (chol. backward 2.9 vs 2.3 ms, Gram 4.1 vs 3.8 ms per step at M'=3000), so 128 is used throughout
+    a.bn = g.bn == 64 ? 64 : 128;
+    a.tiles_n = cdiv(g.N, a.bn);
     const size_t esz = is_double ? 8 : 4;
     const bool out_lower = g.flags & DSVGP_GEMM_OUT_LOWER, keep_upper = g.flags & DSVGP_GEMM_KEEP_UPPER;
     // Few output tiles but a long K (the minibatch axis, or M' x M' x M' products): split K so that the
     // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
     if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 1024) {
-        const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 : a.tiles_m * a.tiles_n;
+        const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (128 / a.bn) : a.tiles_m * a.tiles_n;
         int sk = (active > 0 && active < 1024) ? cdiv(2048, active) : 1;
         if (sk > a.K / 512) sk = a.K / 512;
         if (sk > 1) {

@@ -113,7 +113,7 @@ class PredictiveDistribution:
         if self._mu is None or self._varn is None:
             lik = self.likelihood
             params = self.model._param_dict(lik)
-            mu, varn = self.model.engine.predict(params, self.x, self.D)
+            mu, varn = self.model.engine.predict(params, self.x, self.D, cache=not self.model.training)
             self._mu, self._varn = mu, varn
             if lik is None:   # q(f) itself: remove the noise again
                 self._var = (varn - torch.nn.functional.softplus(params["raw_noise"].reshape(())) - 1e-4)
