@@ -4,8 +4,8 @@
 // DirectionalGradVariationalStrategy.py:181,183 and their autograd backward), the variational
 // products W = L_S^T A, U = L_S W (:192-205) and the M' x M' Gram-type contractions of the backward.
 //
-// Tiling (64-wide wavefronts): 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave a
-// 4x4 grid of 16x16 MFMA tiles (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, K=4 per
+// Tiling (64-wide wavefronts): 128x128 output tile per 512-thread workgroup, 4x2 waves, each wave a
+// 2x4 grid of 16x16 MFMA tiles (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, K=4 per
 // instruction); BK = 16 (fp64) / 32 (fp32) per stage.
 // Pipeline: global -> registers (raw element type, no conversion, so the s_waitcnt lands one full
 // MFMA phase later) -> LDS (double buffered, ONE barrier per K stage) -> fragments -> MFMA.
@@ -29,8 +29,8 @@
 #ifndef GEMM_XCD
 #define GEMM_XCD 1
 #endif
-#ifndef GEMM_MINWAVES
-#define GEMM_MINWAVES 2
+#ifndef GEMM_THREADS
+#define GEMM_THREADS 512    // 256: 4 waves of 64 x BN/2 outputs; 512: 8 waves of 32 x BN/2 (half the accumulators per wave)
 #endif
 
 namespace {
@@ -61,15 +61,15 @@ template <> struct Mfma<double> {
 //   KC (k contiguous in memory):  k = t % BK,          mn = t / BK + (256/BK) * i
 //   MN (mn contiguous in memory): mn = t % NT,         k  = t / NT + (256/NT) * i
 // tri: 0 none, 1 keep k <= mn, 2 keep k >= mn   (indices local to the operand)
-template <typename TIn, bool KC, int BK, int NT>
-__device__ __forceinline__ void load_raw(TIn (&r)[NT * BK / 256], const TIn* __restrict__ p, int64_t ld, int mn0,
+template <typename TIn, bool KC, int BK, int NT, int NTH>
+__device__ __forceinline__ void load_raw(TIn (&r)[NT * BK / NTH], const TIn* __restrict__ p, int64_t ld, int mn0,
                                          int MN, int k0, int K, int tri) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NT * BK / 256; ++i) {
+    for (int i = 0; i < NT * BK / NTH; ++i) {
         int mn, k;
-        if (KC) { k = k0 + (t % BK); mn = mn0 + t / BK + (256 / BK) * i; }
-        else    { mn = mn0 + (t % NT); k = k0 + t / NT + (256 / NT) * i; }
+        if (KC) { k = k0 + (t % BK); mn = mn0 + t / BK + (NTH / BK) * i; }
+        else    { mn = mn0 + (t % NT); k = k0 + t / NT + (NTH / NT) * i; }
         bool ok = (mn < MN) && (k < K);
         if (tri == 1) ok = ok && (k <= mn);
         if (tri == 2) ok = ok && (k >= mn);
@@ -79,20 +79,22 @@ __device__ __forceinline__ void load_raw(TIn (&r)[NT * BK / 256], const TIn* __r
     }
 }
 
-template <typename TIn, typename TC, bool KC, int BK, int NT>
-__device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[NT * BK / 256], TC scale) {
+template <typename TIn, typename TC, bool KC, int BK, int NT, int NTH>
+__device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[NT * BK / NTH], TC scale) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NT * BK / 256; ++i) {
+    for (int i = 0; i < NT * BK / NTH; ++i) {
         const TC v = (TC)r[i] * scale;
-        if (KC) s[(t / BK + (256 / BK) * i) * (BK + 1) + (t % BK)] = v;
-        else    s[(t / NT + (256 / NT) * i) * S_MN + (t % NT)] = v;
+        if (KC) s[(t / BK + (NTH / BK) * i) * (BK + 1) + (t % BK)] = v;
+        else    s[(t / NT + (NTH / NT) * i) * S_MN + (t % NT)] = v;
     }
 }
 
-template <typename TC, typename TB, bool AKC, bool BKC, int BN>
-__global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
+template <typename TC, typename TB, bool AKC, bool BKC, int BN, int NTH>
+__global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
     constexpr int NJ = BN / 32;             // 16-wide MFMA column tiles per wave
+    constexpr int RW = 128 / (NTH / 128);   // rows per wave: 64 (4 waves) or 32 (8 waves)
+    constexpr int MI = RW / 16;             // 16-high MFMA row tiles per wave
     using M = Mfma<TC>;
     using acc_t = typename M::acc_t;
     constexpr int BK = M::BK;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
 
     if (out_lower && n0 >= m0 + BM) {  // tile strictly above the diagonal: defined as zero
         if (!keep_upper && (g.splitk == 1 || sp == 0)) {
-            for (int e = threadIdx.x; e < BM * BN; e += 256) {
+            for (int e = threadIdx.x; e < BM * BN; e += NTH) {
                 int m = m0 + e / BN, n = n0 + e % BN;
                 if (m < Mdim && n < g.N) {
                     if (g.splitk == 1) C[(int64_t)m * g.ldc + n] = TC(0);
@@ -183,25 +185,25 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
         klo = lo;
     }
 
-    acc_t acc[4][NJ];
+    acc_t acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     if (klo < khi) {
-        TC ra[BM * BK / 256];
-        TB rb[BN * BK / 256];
+        TC ra[BM * BK / NTH];
+        TB rb[BN * BK / NTH];
         TC ks = TC(1);
         const float* __restrict__ kscale = g.kscale;   // only with k-contiguous A: one k per thread
         auto fetch = [&](int k0) {
-            load_raw<TC, AKC, BK, BM>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
-            load_raw<TB, BKC, BK, BN>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
+            load_raw<TC, AKC, BK, BM, NTH>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
+            load_raw<TB, BKC, BK, BN, NTH>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
             if (AKC && kscale) { const int k = k0 + (threadIdx.x % BK); ks = (k < Kdim) ? (TC)kscale[k] : TC(0); }
         };
         fetch(klo);
-        store_stage<TC, TC, AKC, BK, BM>(As[0], ra, ks);
-        store_stage<TB, TC, BKC, BK, BN>(Bs[0], rb, TC(1));
+        store_stage<TC, TC, AKC, BK, BM, NTH>(As[0], ra, ks);
+        store_stage<TB, TC, BKC, BK, BN, NTH>(Bs[0], rb, TC(1));
         __syncthreads();
         if (klo + BK < khi) fetch(klo + BK);
         int cur = 0;
@@ -210,11 +212,11 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
             const TC* bs = Bs[cur];
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
-                TC a[4], b[NJ];
+                TC a[MI], b[NJ];
                 const int kq = kk * 4 + (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int mm = wr * 64 + i * 16 + (lane & 15);
+                for (int i = 0; i < MI; ++i) {
+                    const int mm = wr * RW + i * 16 + (lane & 15);
                     a[i] = AKC ? as[mm * SK + kq] : as[kq * S_MN + mm];
                 }
 #pragma unroll
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
                     b[j] = BKC ? bs[nn * SK + kq] : bs[kq * S_MN + nn];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         if (GEMM_ABLATE == 1) { asm volatile("" :: "v"(a[i]), "v"(b[j])); }
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
             if (k0 + BK < khi) {
                 // stage k0+BK (already in registers) goes to the other buffer: nobody reads it any more,
                 // all waves passed the previous barrier after their last reads of it
-                store_stage<TC, TC, AKC, BK, BM>(As[cur ^ 1], ra, ks);
-                store_stage<TB, TC, BKC, BK, BN>(Bs[cur ^ 1], rb, TC(1));
+                store_stage<TC, TC, AKC, BK, BM, NTH>(As[cur ^ 1], ra, ks);
+                store_stage<TB, TC, BKC, BK, BN, NTH>(Bs[cur ^ 1], rb, TC(1));
                 __syncthreads();
                 if (GEMM_ABLATE != 2 && k0 + 2 * BK < khi) fetch(k0 + 2 * BK);
                 cur ^= 1;
@@ -245,12 +247,12 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
     const TC alpha = (TC)g.alpha, beta = (TC)g.beta;
     const bool cin_f = fl & DSVGP_GEMM_CIN_IS_FLOAT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + i * 16 + M::row(lane, r);
+                const int m = m0 + wr * RW + i * 16 + M::row(lane, r);
                 const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
                 if (m >= Mdim || n >= g.N) continue;
                 TC v = alpha * acc[i][j][r];
@@ -268,17 +270,24 @@ __global__ __launch_bounds__(256, GEMM_MINWAVES) void gemm_kernel(GemmArgs g) {
             }
 }
 
+// 8 waves (512 threads, 32 x BN/2 outputs per wave, <= 128 VGPRs, 4 waves/SIMD) measured 5-7 % faster than
+// 4 waves (64 x BN/2 per wave) everywhere except the fp64 kernel with two k-contiguous operands, which spills.
+template <typename TC, typename TB, bool AKC, bool BKC, int BN>
+int launch_one(hipStream_t st, const GemmArgs& g, dim3 grid) {
+    constexpr int NTH = (sizeof(TC) == 8 && AKC && BKC) ? 256 : GEMM_THREADS;
+    hipLaunchKernelGGL((gemm_kernel<TC, TB, AKC, BKC, BN, NTH>), grid, dim3(NTH), 0, st, g);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
 template <typename TC, typename TB, int BN>
 int dispatch_bn(hipStream_t st, const GemmArgs& g, dim3 grid) {
     const bool akc = !(g.flags & DSVGP_GEMM_TRANS_A);  // A stored [M,K]  -> k contiguous
     const bool bkc = (g.flags & DSVGP_GEMM_TRANS_B);   // B stored [N,K]  -> k contiguous
     if (g.kscale && !akc) return DSVGP_EINVAL;
-    if (akc && bkc)        hipLaunchKernelGGL((gemm_kernel<TC, TB, true, true, BN>), grid, dim3(256), 0, st, g);
-    else if (akc && !bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, true, false, BN>), grid, dim3(256), 0, st, g);
-    else if (!akc && bkc)  hipLaunchKernelGGL((gemm_kernel<TC, TB, false, true, BN>), grid, dim3(256), 0, st, g);
-    else                   hipLaunchKernelGGL((gemm_kernel<TC, TB, false, false, BN>), grid, dim3(256), 0, st, g);
-    DSVGP_LAUNCH_CHECK();
-    return 0;
+    if (akc && bkc)  return launch_one<TC, TB, true, true, BN>(st, g, grid);
+    if (akc && !bkc) return launch_one<TC, TB, true, false, BN>(st, g, grid);
+    if (!akc && bkc) return launch_one<TC, TB, false, true, BN>(st, g, grid);
+    return launch_one<TC, TB, false, false, BN>(st, g, grid);
 }
 template <typename TC, typename TB>
 int dispatch(hipStream_t st, const GemmArgs& g, dim3 grid) {
