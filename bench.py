@@ -135,12 +135,12 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 corrections applied by tools/summarize_pmc.py); only valid for the 1-GPU C4 shape
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if world == 1 and args.config == "c4" and args.trsm_nb >= Mp and os.path.exists(pmc):
-            for k in json.load(open(pmc))["kernels"]:
-                if k["kernel"].startswith("gemm_kernel<double, float, true, false>") and k["grid_threads"] == 1179648:
-                    traffic = k["hbm_bytes_per_launch"]
-        roof = dict(bound="mfma", kernel="gemm_kernel<double,float,true,false> (panel solve L^-1 K_ZX, v_mfma_f64_16x16x4)",
+            cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm_kernel<double, float, true, false")]
+            if cands:   # the forward solve is the largest launch of that instantiation
+                traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+        roof = dict(bound="mfma", kernel="gemm_kernel<double,float,true,false,128,512> (panel solve L^-1 K_ZX, v_mfma_f64_16x16x4)",
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                     traffic=traffic, launches=len(durs), avg_ms=avg * 1e3, flops_per_launch=flops)
 
