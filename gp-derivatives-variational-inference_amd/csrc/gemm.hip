@@ -97,7 +97,8 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
     constexpr int MI = RW / 16;             // 16-high MFMA row tiles per wave
     using M = Mfma<TC>;
     using acc_t = typename M::acc_t;
-    constexpr int BK = M::BK;
+    // two k-contiguous fp32 operands: 32-deep stages so that every row segment is a full 128-B line
+    constexpr int BK = (sizeof(TC) == 4 && AKC && BKC) ? 32 : M::BK;
     constexpr int SK = BK + 1;
     constexpr int ASZ = AKC ? BM * SK : BK * S_MN;
     constexpr int BSZ = BKC ? BN * SK : BK * S_MN;

@@ -252,3 +252,30 @@ def test_grad_svgp_drop_in(dsvgp, gpu_device, capsys):
     mu_e, var_e = O.predictive(P, test_x, torch.eye(dim).repeat(n_test, 1))
     _, _, noise = O.constrained(P)
     assert relmax(means, mu_e) < 2e-3 and relmax(variances, var_e + noise) < 2e-3
+
+
+def test_c4_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device):
+    """BASELINE config 4 at FULL size (M'=3000, B'=24576): loss, predictive head and all gradients against the
+    oracle run committed as tests/golden/c4_step.npz (oracle/make_c4_fixture.py; inputs regenerated from the seed)."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_c4_fixture import make_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4_step.npz"))
+    P, x, y, D, nd = make_inputs()
+    for fast in (True, False):
+        loss, grads, mu, varn, _, _ = run_gpu(dsvgp, gpu_device, P, x, y, D, nd, trsm_nb=4096, fast=fast)
+        assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"])), (fast, loss.item(), float(g["loss"]))
+        assert relmax(mu[:256], torch.from_numpy(g["mu_head"])) < 2e-4
+        if not fast:
+            assert relmax(varn[:256], torch.from_numpy(g["varn_head"])) < 2e-4
+        for k in O.PARAM_NAMES:
+            if k == "chol_variational_covar":
+                gl = grads[k]
+                assert abs(gl.double().norm().item() - float(g["g_LS_norm"])) < 2e-3 * float(g["g_LS_norm"])
+                assert relmax(gl[:96, :96], torch.from_numpy(g["g_LS_block"])) < 5e-3
+                assert relmax(torch.diagonal(gl), torch.from_numpy(g["g_LS_diag"])) < 5e-3
+                assert relmax(gl[-8:, :], torch.from_numpy(g["g_LS_lastrows"])) < 5e-3
+            else:
+                assert relmax(grads[k], torch.from_numpy(g["g_" + k])) < 5e-3, (fast, k, relmax(grads[k], torch.from_numpy(g["g_" + k])))
