@@ -42,8 +42,8 @@ class ElboEngine:
         self.trsm_nb = int(trsm_nb)
         self._buf = {}
         self.chol_jitter = CHOL_JITTER  # base of the psd_safe_cholesky retry ladder (1e-8 for GradVariationalStrategy)
-        self.potrf_algo = 0             # 0: rocSOLVER dpotrf (measured 6.2 ms at M'=3000), 1: blocked Cholesky on the
-                                        #    MFMA GEMM (csrc/potrf.hip, 7.1 ms: serial 64-column chain)
+        self.potrf_algo = 1             # 1: blocked Cholesky on the MFMA GEMM (csrc/potrf.hip, 5.7 ms at M'=3000),
+                                        # 0: rocSOLVER dpotrf (8.1 ms)
         self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
         self._hyp_host = None
         self._eval_cache = None

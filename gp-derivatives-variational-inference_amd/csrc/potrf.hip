@@ -11,70 +11,94 @@ namespace {
 
 constexpr int NBC = 64;
 
-// Thread (tx = tid & 63, ty = tid >> 6) keeps A[4r + ty][tx] and X[4r + ty][tx], r = 0..15, in registers.
-// Per column j ONE barrier: the owners publish column j of A and row j of X (both "current") through
-// double-buffered LDS vectors, then every thread forms 1/sqrt(a_jj) (v_rsq_f64 + 2 Newton steps; no
-// fp64 divide or sqrt on the serial chain) and applies the right-looking update to A and the forward
-// elimination of [L | I] to X.
+// Thread (tx = tid & 63, ty = tid >> 6) keeps ONE register column w[r] <-> row NW*r + ty of column tx: it is
+// column tx of A while j < tx (right-looking updates), is published and written back as column tx of L at
+// j == tx, and from then on holds column tx of X = L^-1 (forward elimination of [L | I]) -- a lane never needs
+// both at once.  Per column j ONE barrier: the owners publish column j of A and row j of X through
+// double-buffered LDS vectors, every thread forms 1/sqrt(a_jj) (v_rsq_f64 + 2 Newton steps; no fp64 divide
+// or sqrt on the serial chain) and updates its registers.  NW waves (NW*64 threads) share the 64 x 64 block.
+#ifndef POTRF_NW
+#define POTRF_NW 16
+#endif
+#ifndef POTRF_NEWTON
+#define POTRF_NEWTON 2
+#endif
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
-    y = y + y * (0.5 * fma(-d * y, y, 1.0));
-    y = y + y * (0.5 * fma(-d * y, y, 1.0));
+#pragma unroll
+    for (int it = 0; it < POTRF_NEWTON; ++it) y = y + y * (0.5 * fma(-d * y, y, 1.0));
     return y;
 }
 
-__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int r0, int nr,
-                                                        double* __restrict__ Dinv, int* __restrict__ info) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int r0, int nr,
+                                                            double* __restrict__ Dinv, int* __restrict__ info) {
+    constexpr int RPT = NBC / NW;            // rows per thread
     __shared__ double colbuf[2][NBC];
     __shared__ double rowbuf[2][NBC];
+    __shared__ double Ls[NBC][NBC + 1];      // finished columns of L (no global store on the serial chain)
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    double a[16], x[16];
+#ifdef POTRF_DEBUG
+    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+#endif
+    double w[RPT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = 4 * r + ty;
+    for (int r = 0; r < RPT; ++r) {
+        const int i = NW * r + ty;
         double v = (i == tx) ? 1.0 : 0.0;                       // identity padding of a ragged last block
         if (i < nr && tx < nr && tx <= i) v = A[(int64_t)(r0 + i) * lda + r0 + tx];
-        a[r] = v;
-        x[r] = (i == tx) ? 1.0 : 0.0;
+        w[r] = v;
     }
     for (int j = 0; j < NBC; ++j) {
         double* cb = colbuf[j & 1];
         double* rb = rowbuf[j & 1];
         if (tx == j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cb[4 * r + ty] = a[r];
+            for (int r = 0; r < RPT; ++r) cb[NW * r + ty] = w[r];
         }
-        if (ty == (j & 3)) {
+        if (ty == j % NW) {                                      // owner of row j publishes X[j][tx] (1 on the diagonal)
+            double v = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r == (j >> 2)) rb[tx] = x[r];
+            for (int r = 0; r < RPT; ++r) v = (r == j / NW) ? w[r] : v;
+            rb[tx] = (tx == j) ? 1.0 : v;
         }
         __syncthreads();
+        double cbv[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) cbv[r] = cb[NW * r + ty];
         const double dj = cb[j];
+        const double rbv = rb[tx], cbt = cb[tx];
         if (tid == 0 && !(dj > 0.0) && j < nr && *info == 0) *info = r0 + j + 1;   // LAPACK: leading minor not PD
         const double rinv = rsqrt_nr(dj);                       // 1 / L_jj
-        const double xj = rb[tx] * rinv;                        // final X[j][tx]
-        const double ck = cb[tx] * rinv;                        // L[tx][j]
+        const bool right = tx > j, own = tx == j;
+        const double f = right ? cbt * rinv : rbv * rinv;       // L[tx][j]  or  final X[j][tx]
+        const int ilo = right ? tx : j + 1;                     // first row that takes the rank-1 update
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (4 * r + 3 < j) continue;                        // wave-uniform: rows above j are final
-            const int i = 4 * r + ty;
-            const double lij = cb[i] * rinv;                    // L[i][j]  (i == j: sqrt(a_jj))
-            if (i > j) {
-                x[r] -= lij * xj;
-                if (tx > j && i >= tx) a[r] -= lij * ck;
-            } else if (i == j) {
-                x[r] = xj;
-            }
-            if (tx == j && i >= j) a[r] = lij;
+        for (int r = 0; r < RPT; ++r) {
+            const int i = NW * r + ty;
+            const double lij = cbv[r] * rinv;                   // L[i][j]  (i == j: sqrt(a_jj))
+            if (own) Ls[i][j] = lij;                            // column j of L is final
+            const double base = own ? 0.0 : w[r];               // the X column starts from the identity
+            double v = (i >= ilo) ? fma(-lij, f, base) : base;
+            v = (!right && i == j) ? f : v;                     // row j of X
+            w[r] = v;
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = 4 * r + ty;
-        if (i < nr && tx <= i) A[(int64_t)(r0 + i) * lda + r0 + tx] = a[r];
-        Dinv[i * NBC + tx] = x[r];
+    for (int r = 0; r < RPT; ++r) Dinv[(NW * r + ty) * NBC + tx] = w[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = NW * r + ty;
+        if (i < nr && tx <= i) A[(int64_t)(r0 + i) * lda + r0 + tx] = Ls[i][tx];
     }
+#ifdef POTRF_DEBUG
+    if (tid == 0) {   // tools only: shader cycles and 100 MHz real-time ticks of this workgroup, in the unused upper corner
+        const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+        Dinv[62] = (double)(t1c - t0c);
+        Dinv[63] = (double)(t1r - t0r);
+    }
+#endif
 }
 
 }  // namespace
@@ -88,7 +112,7 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
     for (int k = 0; k < nblk; ++k) {
         const int r0 = k * NBC, nr = (n - r0 < NBC) ? (n - r0) : NBC, r1 = r0 + nr;
         double* Dk = dinv_ws + (size_t)k * NBC * NBC;
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A, lda, r0, nr, Dk, info);
+        hipLaunchKernelGGL(potf2_inv_kernel<POTRF_NW>, dim3(1), dim3(POTRF_NW * 64), 0, st, A, lda, r0, nr, Dk, info);
         DSVGP_LAUNCH_CHECK();
         if (r1 >= n) break;
         // panel: L[r1:, r0:r1] = A[r1:, r0:r1] * inv(L_kk)^T      (in place: one n-tile per row panel)
