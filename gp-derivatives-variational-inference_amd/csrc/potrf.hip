@@ -101,6 +101,64 @@ __global__ __launch_bounds__(NW * 64) void potf2_inv_kernel(double* __restrict__
 #endif
 }
 
+// Single-stage fp64 MFMA kernel for the K <= 64 products of the factorisation (panel solve against the
+// inverted diagonal block, rank-64 trailing update): C[64x64 tile] = alpha * A[64 x K] * B[64 x K]^T + beta * C.
+// Both operands are k-contiguous and fit LDS whole, so a tile costs ONE global round trip instead of the
+// K/16 dependent stages of the general GEMM (which is latency-bound at K = 64: 21 / 53 us per launch).
+// lower_only: tiles with tn > tm exit, elements with n > m are not stored.  In place (C == A) is safe: every
+// workgroup stages its whole A tile before it writes.
+__global__ __launch_bounds__(256) void smallk_gemm_kernel(const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ B, int64_t ldb,
+                                                          double* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                          double alpha, double beta, int lower_only, int b_upper) {
+    __shared__ double As[64][65];
+    __shared__ double Bs[64][65];
+    const int tm = blockIdx.y, tn = blockIdx.x;
+    if (lower_only && tn > tm) return;
+    const int m0 = tm * 64, n0 = tn * 64, tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, k = e & 63;
+        As[r][k] = (m0 + r < M && k < K) ? A[(int64_t)(m0 + r) * lda + k] : 0.0;
+        double bv = 0.0;
+        if (n0 + r < N && k < K && !(b_upper && k > n0 + r)) bv = B[(int64_t)(n0 + r) * ldb + k];   // op(B)[k][n] = B[n][k]
+        Bs[r][k] = bv;
+    }
+    __syncthreads();
+    using acc_t = double __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;   // wave -> 32 x 32 outputs
+    acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+#pragma unroll 4
+    for (int kk = 0; kk < 64; kk += 4) {
+        const int kq = kk + (lane >> 4);
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = As[wr * 32 + i * 16 + (lane & 15)][kq];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Bs[wc * 32 + j * 16 + (lane & 15)][kq];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * r;      // f64 C/D layout
+                const int n = n0 + wc * 32 + j * 16 + (lane & 15);
+                if (m >= M || n >= N || (lower_only && n > m)) continue;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * C[(int64_t)m * ldc + n];
+                C[(int64_t)m * ldc + n] = v;
+            }
+}
+
 }  // namespace
 
 size_t potrf_blocked_workspace_bytes(int n) { return sizeof(double) * (size_t)cdiv(n, NBC) * NBC * NBC; }
@@ -115,29 +173,16 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
         hipLaunchKernelGGL(potf2_inv_kernel<POTRF_NW>, dim3(1), dim3(POTRF_NW * 64), 0, st, A, lda, r0, nr, Dk, info);
         DSVGP_LAUNCH_CHECK();
         if (r1 >= n) break;
-        // panel: L[r1:, r0:r1] = A[r1:, r0:r1] * inv(L_kk)^T      (in place: one n-tile per row panel)
-        GemmArgs g{};
-        g.batch = 1; g.splitk = 1;
-        g.M = n - r1; g.N = nr; g.K = nr;
-        g.A = A + (size_t)r1 * lda + r0; g.lda = lda;
-        g.B = Dk; g.ldb = NBC;
-        g.flags = DSVGP_GEMM_TRANS_B | DSVGP_GEMM_B_UPPER;     // op(B)[k][n] = Dinv[n][k], zero for k > n
-        g.alpha = 1.0; g.beta = 0.0;
-        g.C = A + (size_t)r1 * lda + r0; g.ldc = lda;
-        int rc = launch_gemm(st, 1, g);
-        if (rc) return rc;
+        // panel: L[r1:, r0:r1] = A[r1:, r0:r1] * inv(L_kk)^T      (in place; op(B)[k][n] = Dinv[n][k], zero for k > n)
+        const int Mr = n - r1;
+        hipLaunchKernelGGL(smallk_gemm_kernel, dim3(1, cdiv(Mr, 64)), dim3(256), 0, st, A + (size_t)r1 * lda + r0, lda,
+                           (const double*)Dk, (int64_t)NBC, A + (size_t)r1 * lda + r0, lda, Mr, nr, nr, 1.0, 0.0, 0, 1);
+        DSVGP_LAUNCH_CHECK();
         // trailing update: A[r1:, r1:] -= L_panel L_panel^T        (lower tiles only, in place)
-        GemmArgs f{};
-        f.batch = 1; f.splitk = 1;
-        f.M = n - r1; f.N = n - r1; f.K = nr;
-        f.A = A + (size_t)r1 * lda + r0; f.lda = lda;
-        f.B = f.A; f.ldb = lda;
-        f.flags = DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_KEEP_UPPER;
-        f.alpha = -1.0; f.beta = 1.0;
-        f.Cin = A + (size_t)r1 * lda + r1; f.ldcin = lda;
-        f.C = A + (size_t)r1 * lda + r1; f.ldc = lda;
-        rc = launch_gemm(st, 1, f);
-        if (rc) return rc;
+        hipLaunchKernelGGL(smallk_gemm_kernel, dim3(cdiv(Mr, 64), cdiv(Mr, 64)), dim3(256), 0, st,
+                           A + (size_t)r1 * lda + r0, lda, A + (size_t)r1 * lda + r0, lda, A + (size_t)r1 * lda + r1, lda,
+                           Mr, Mr, nr, -1.0, 1.0, 1, 0);
+        DSVGP_LAUNCH_CHECK();
     }
     return 0;
 }
