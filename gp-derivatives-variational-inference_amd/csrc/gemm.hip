@@ -33,6 +33,13 @@
 #define GEMM_THREADS 512    // 256: 4 waves of 64 x BN/2 outputs; 512: 8 waves of 32 x BN/2 (half the accumulators per wave)
 #endif
 
+#ifdef GEMM_CLOCK   // tools only: in-kernel clock of one mid-grid workgroup (shader cycles vs 100 MHz real time)
+__device__ unsigned long long dsvgp_gemm_clock_dbg[2];
+extern "C" int dsvgp_debug_gemm_clock(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dsvgp_gemm_clock_dbg), 16);
+}
+#endif
+
 namespace {
 
 constexpr int BM = 128;     // BN (128 or 64) is a template parameter: 64 doubles the tile count of M' x M' products
@@ -77,6 +84,30 @@ __device__ __forceinline__ void load_raw(TIn (&r)[NT * BK / NTH], const TIn* __r
         if (ok) v = KC ? p[(int64_t)mn * ld + k] : p[(int64_t)k * ld + mn];
         r[i] = v;
     }
+}
+
+// Interior stages (tile fully inside the matrix, stage fully inside K and off the diagonal of a triangular
+// operand): no predicates, one 32-bit per-thread offset per element added to a wave-uniform stage pointer.
+template <bool KC, int BK, int NT, int NTH>
+__device__ __forceinline__ void make_offsets(int (&off)[NT * BK / NTH], int64_t ld) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NT * BK / NTH; ++i) {
+        if (KC) off[i] = (t / BK + (NTH / BK) * i) * (int)ld + (t % BK);
+        else    off[i] = (t / NT + (NTH / NT) * i) * (int)ld + (t % NT);
+    }
+}
+template <typename TIn, int E>
+__device__ __forceinline__ void load_fast(TIn (&r)[E], const TIn* __restrict__ ps, const int (&off)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = ps[off[i]];
+}
+// tri: 0 none, 1 keep k <= mn, 2 keep k >= mn : is the stage [k0, k0+BK) x [mn0, mn0+NT) free of masked elements?
+__device__ __forceinline__ bool stage_interior(int mn0, int NT, int MN, int k0, int BK, int K, int tri) {
+    bool ok = (mn0 + NT <= MN) && (k0 + BK <= K);
+    if (tri == 1) ok = ok && (k0 + BK - 1 <= mn0);
+    if (tri == 2) ok = ok && (k0 >= mn0 + NT - 1);
+    return ok;
 }
 
 template <typename TIn, typename TC, bool KC, int BK, int NT, int NTH>
@@ -186,6 +217,9 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
         klo = lo;
     }
 
+#ifdef GEMM_CLOCK
+    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+#endif
     acc_t acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -197,9 +231,22 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
         TB rb[BN * BK / NTH];
         TC ks = TC(1);
         const float* __restrict__ kscale = g.kscale;   // only with k-contiguous A: one k per thread
+        int offa[BM * BK / NTH], offb[BN * BK / NTH];
+        make_offsets<AKC, BK, BM, NTH>(offa, g.lda);
+        make_offsets<BKC, BK, BN, NTH>(offb, g.ldb);
+        // the second (predicate-free) load path costs registers: the fp64 kernels with a k-contiguous A and the
+        // kernels with two k-contiguous operands spill with it and run slower, so they keep the single path
+        constexpr bool USE_FAST = !(sizeof(TC) == 8 && AKC) && !(AKC && BKC);
+        const bool small_ld = USE_FAST && (g.lda < (1 << 23)) && (g.ldb < (1 << 23));     // 32-bit offsets are safe
         auto fetch = [&](int k0) {
-            load_raw<TC, AKC, BK, BM, NTH>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
-            load_raw<TB, BKC, BK, BN, NTH>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
+            if (small_ld && stage_interior(m0, BM, Mdim, k0, BK, Kdim, triA))
+                load_fast<TC, BM * BK / NTH>(ra, AKC ? A + (int64_t)m0 * g.lda + k0 : A + (int64_t)k0 * g.lda + m0, offa);
+            else
+                load_raw<TC, AKC, BK, BM, NTH>(ra, A, g.lda, m0, Mdim, k0, Kdim, triA);
+            if (small_ld && stage_interior(n0, BN, g.N, k0, BK, Kdim, triB))
+                load_fast<TB, BN * BK / NTH>(rb, BKC ? B + (int64_t)n0 * g.ldb + k0 : B + (int64_t)k0 * g.ldb + n0, offb);
+            else
+                load_raw<TB, BKC, BK, BN, NTH>(rb, B, g.ldb, n0, g.N, k0, Kdim, triB);
             if (AKC && kscale) { const int k = k0 + (threadIdx.x % BK); ks = (k < Kdim) ? (TC)kscale[k] : TC(0); }
         };
         fetch(klo);
@@ -245,6 +292,12 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
         }
     }
 
+#ifdef GEMM_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
+        dsvgp_gemm_clock_dbg[0] = __builtin_amdgcn_s_memtime() - t0c;
+        dsvgp_gemm_clock_dbg[1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
+#endif
     const TC alpha = (TC)g.alpha, beta = (TC)g.beta;
     const bool cin_f = fl & DSVGP_GEMM_CIN_IS_FLOAT;
 #pragma unroll

@@ -5,6 +5,9 @@
 #include <cstdlib>
 #include <vector>
 #include "dsvgp.h"
+#ifdef GEMM_CLOCK
+extern "C" int dsvgp_debug_gemm_clock(unsigned long long* out);
+#endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d line %d\n", (int)e, __LINE__); exit(1); } } while (0)
 
@@ -48,7 +51,14 @@ int main(int argc, char** argv) {
             }
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) printf("%s %8.3f ms  %7.2f TFLOP/s\n", c.name, ms / n, c.flops / (ms / n) / 1e9);
+            if (rep) {
+                printf("%s %8.3f ms  %7.2f TFLOP/s", c.name, ms / n, c.flops / (ms / n) / 1e9);
+#ifdef GEMM_CLOCK
+                unsigned long long d[2]; dsvgp_debug_gemm_clock(d);
+                printf("   in-kernel clock %.2f GHz (mid-grid WG: %.0f us)", (double)d[0] / (double)d[1] * 0.1, (double)d[1] / 100.0);
+#endif
+                printf("\n");
+            }
         }
     }
     return 0;
