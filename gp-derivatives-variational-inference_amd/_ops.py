@@ -280,6 +280,11 @@ def add_diag_f32_(ctx, A, n, delta):
     check(lib.dsvgp_add_diag_f32(ctx.h, _ptr(_req(A, f32, "A", 2)), n, _ld(A), float(delta)), "dsvgp_add_diag_f32")
 
 
+def transpose_f32(ctx, src, dst):
+    check(lib.dsvgp_transpose_f32(ctx.h, _ptr(src), _ld(src), src.shape[0], src.shape[1], _ptr(dst), _ld(dst)),
+          "dsvgp_transpose_f32")
+
+
 def gather_batch(ctx, X, Y, idx, cols, p, xb, yb):
     check(lib.dsvgp_gather_batch(ctx.h, _ptr(_req(X, f32, "X", 2)), _ptr(_req(Y, f32, "Y", 2)),
                                  _ptr(_req(idx, torch.int64, "idx", 1)), idx.shape[0], X.shape[1], Y.shape[1],

@@ -294,6 +294,8 @@ class ElboEngine:
         Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
         _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)
         # K_ZX-bar (fp32, dense) and L-bar (fp64)
-        _ops.gemm(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
+        QeT32 = self._get("QeT32", (Mp + 1, Mp), f32)          # the fp32 GEMM streams an mn-contiguous A operand ~5 % faster
+        _ops.transpose_f32(ctx, Qe32, QeT32)
+        _ops.gemm(ctx, TRANS_A, QeT32, A32e, Kb32, alpha=vbar2)
         _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)
         return packX, mu

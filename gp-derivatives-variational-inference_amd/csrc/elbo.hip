@@ -198,9 +198,10 @@ __global__ void phi_sym_kernel(double* __restrict__ G, int n, int64_t ldg) {
     }
 }
 
-__global__ void transpose_kernel(const double* __restrict__ in, int64_t ldi, int rows, int cols,
-                                 double* __restrict__ out, int64_t ldo) {
-    __shared__ double tile[32][33];
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ in, int64_t ldi, int rows, int cols,
+                                 T* __restrict__ out, int64_t ldo) {
+    __shared__ T tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x, ty = threadIdx.y;
     for (int r = ty; r < 32; r += 8)
         if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(int64_t)(r0 + r) * ldi + c0 + tx];
@@ -409,8 +410,17 @@ extern "C" int dsvgp_phi_symmetrize(dsvgp_ctx* ctx, double* G, int n, int64_t ld
 extern "C" int dsvgp_transpose_f64(dsvgp_ctx* ctx, const double* in, int64_t ldi, int rows, int cols, double* out,
                                    int64_t ldo) {
     if (!ctx || !in || !out || in == out || rows <= 0 || cols <= 0 || ldi < cols || ldo < rows) return DSVGP_EINVAL;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, ctx->stream, in, ldi,
-                       rows, cols, out, ldo);
+    hipLaunchKernelGGL(transpose_kernel<double>, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, ctx->stream, in,
+                       ldi, rows, cols, out, ldo);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_transpose_f32(dsvgp_ctx* ctx, const float* in, int64_t ldi, int rows, int cols, float* out,
+                                   int64_t ldo) {
+    if (!ctx || !in || !out || in == out || rows <= 0 || cols <= 0 || ldi < cols || ldo < rows) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel<float>, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, ctx->stream, in,
+                       ldi, rows, cols, out, ldo);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -156,6 +156,8 @@ int dsvgp_phi_symmetrize(dsvgp_ctx* ctx, double* G, int n, int64_t ldg);
 /* out[cols, rows] = in[rows, cols]^T (out of place)                                              */
 int dsvgp_transpose_f64(dsvgp_ctx* ctx, const double* in, int64_t ldi, int rows, int cols, double* out,
                         int64_t ldo);
+int dsvgp_transpose_f32(dsvgp_ctx* ctx, const float* in, int64_t ldi, int rows, int cols, float* out,
+                        int64_t ldo);
 
 /* ---- ELBO-mode fast path.  With mll_type == ELBO, dLoss/dvar_j = 1/(2 noise rows) is the same for every
  * output, so the data term only needs  sum_j (y_j - mu_j)^2  and  sum_j var_j = prior + |L_S^T A|_F^2 - |A|_F^2,

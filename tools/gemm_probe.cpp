@@ -40,6 +40,9 @@ int main(int argc, char** argv) {
         {"f32 U = L_S W                         ", 0, DSVGP_GEMM_A_LOWER, Mp, Bp, Mp, LS32, Mp, A32, Bp, W32, Bp, nullptr, tri},
         {"f32 dense                             ", 0, 0, Mp, Bp, Mp, LS32, Mp, A32, Bp, W32, Bp, nullptr, full},
         {"f32 dLS    tril(A diag(v) W^T) K=B'   ", 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, A32, Bp, K32, Bp, S32, Mp, vs, tri},
+        {"f32 Gram   tril(A A^T) k-contig ops   ", 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, A32, Bp, A32, Bp, S32, Mp, nullptr, tri},
+        {"f32 Gram   tril(At^T At) transposed    ", 0, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, A32, Mp, A32, Mp, S32, Mp, nullptr, tri},
+        {"f32 dense  transposed A (Kb-like)      ", 0, DSVGP_GEMM_TRANS_A, Mp, Bp, Mp, LS32, Mp, A32, Bp, W32, Bp, nullptr, full},
     };
     for (auto& c : cases) {
         for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
