@@ -25,12 +25,22 @@ class GradVariationalStrategy(torch.nn.Module):
             self.register_buffer("inducing_points", inducing_points)
         self._variational_distribution = variational_distribution
         self.register_buffer("variational_params_initialized", torch.tensor(0))
+        self._init_known = False
         self.register_buffer("updated_strategy", torch.tensor(True))
 
     def _maybe_init(self):
+        # the flag lives in a device buffer (state_dict compatibility); reading it is a device sync, so its value is
+        # mirrored on the host once known (a loaded checkpoint invalidates the mirror)
+        if self._init_known:
+            return
         if not self.variational_params_initialized.item():
             self._variational_distribution.initialize_variational_distribution()
             self.variational_params_initialized.fill_(1)
+        self._init_known = True
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._init_known = False
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, inducing_points=None, inducing_values=None, variational_inducing_covar=None, **kwargs):
         dim = self.inducing_points.size(1)

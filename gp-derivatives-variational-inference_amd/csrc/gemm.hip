@@ -26,6 +26,12 @@
 #ifndef GEMM_BK_F64
 #define GEMM_BK_F64 16
 #endif
+#ifndef GEMM_SK_OVH
+#define GEMM_SK_OVH 256.0     // per-workgroup fixed cost in units of K steps (split-K policy)
+#endif
+#ifndef GEMM_COMPACT_LOWER
+#define GEMM_COMPACT_LOWER 1
+#endif
 #ifndef GEMM_XCD
 #define GEMM_XCD 1
 #endif
@@ -148,7 +154,36 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
     // stage out of its private 4 MiB L2 instead of 64 + 64 from HBM / Infinity Cache.
     const int gx = g.tiles_n, gy = g.tiles_m;
     int tm, tn, zz;
-    if (g.supertile && GEMM_XCD) {
+    if (g.supertile == 2 && GEMM_XCD) {
+        // OUT_LOWER on a square tile grid: only the T(T+1)/2 tiles on / below the diagonal exist.  They are
+        // enumerated supertile-major (so 64 consecutive entries still share ~8 + 8 operand panels) and dealt
+        // to the XCDs in chunks of 64 ACTIVE tiles: every XCD gets the same number of workgroups (a diagonal
+        // supertile holds 36 tiles, a full one 64; dealing whole supertiles left the XCDs 20-35 % unbalanced).
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int lin = (((j >> 6) * 8 + xcd) << 6) + (j & 63);
+        const int nact = gy * (gy + 1) / 2;
+        if (lin >= nact * g.batch * g.splitk) return;
+        zz = lin / nact;
+        int t = lin - zz * nact, sm = 0, rows;
+        for (;; ++sm) {
+            rows = min(8, gy - sm * 8);
+            const int rowtot = sm * rows * 8 + rows * (rows + 1) / 2;
+            if (t < rowtot) break;
+            t -= rowtot;
+        }
+        if (t < sm * rows * 8) {
+            const int sn = t / (rows * 8), li = t - sn * rows * 8;
+            tm = sm * 8 + (li >> 3);
+            tn = sn * 8 + (li & 7);
+        } else {
+            const int li = t - sm * rows * 8;
+            int r = (int)((sqrtf(8.f * (float)li + 1.f) - 1.f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= li) ++r;
+            while (r * (r + 1) / 2 > li) --r;
+            tm = sm * 8 + r;
+            tn = sm * 8 + li - r * (r + 1) / 2;
+        }
+    } else if (g.supertile && GEMM_XCD) {
         const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
         const int within = j & 63, Sg = (j >> 6) * 8 + xcd;     // supertile unit (z folded in: XCD balance)
         const int nsn = (gx + 7) >> 3, nsm = (gy + 7) >> 3;
@@ -392,8 +427,16 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
     if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 1024) {
         const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (128 / a.bn) : a.tiles_m * a.tiles_n;
-        int sk = (active > 0 && active < 1024) ? cdiv(2048, active) : 1;
-        if (sk > a.K / 512) sk = a.K / 512;
+        // split factor: minimise (rounds of the 512 resident-workgroup slots) x (K slice + fixed per-workgroup cost)
+        int sk = 1;
+        if (active > 0 && active < 1024) {
+            const int maxsk = a.K / 512 < 32 ? a.K / 512 : 32;
+            double best = 1e300;
+            for (int c = 1; c <= maxsk; ++c) {
+                const double t = (double)cdiv((int64_t)active * c, 512) * ((double)a.K / c + GEMM_SK_OVH);
+                if (t < best * 0.999) { best = t; sk = c; }
+            }
+        }
         if (sk > 1) {
             a.splitk = sk;
             if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; }      // atomics accumulate onto the existing C
@@ -414,7 +457,11 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     }
     a.supertile = (a.tiles_n * a.tiles_m >= 64) ? 1 : 0;
     dim3 grid(a.tiles_n * a.tiles_m, 1, a.batch * a.splitk);
-    if (a.supertile) {
+    if (a.supertile && out_lower && a.tiles_n == a.tiles_m && GEMM_COMPACT_LOWER) {
+        a.supertile = 2;
+        const int64_t nact = (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 * a.batch * a.splitk;
+        grid = dim3(cdiv(cdiv(nact, 64), 8) * 8 * 64, 1, 1);
+    } else if (a.supertile) {
         const int nsn = cdiv(a.tiles_n, 8), nsm = cdiv(a.tiles_m, 8);
         const bool lower_only = (g.flags & DSVGP_GEMM_OUT_LOWER) && nsn == nsm;
         const int nsup = lower_only ? (nsm * (nsm + 1)) / 2 : nsn * nsm;

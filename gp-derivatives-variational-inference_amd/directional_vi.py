@@ -120,13 +120,21 @@ class TrainLoop:
             idx = idx[lo:hi]
         # select random columns of y to train on (function values always included), :68-90
         idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
-        cols = torch.tensor(idx_y, dtype=torch.int32, device=dev)
+        # host -> device without a stream sync: pinned staging ring + non_blocking copy (a pageable torch.tensor(...,
+        # device=) blocks the host until the stream has drained, i.e. until the previous step has finished)
+        slot = self._cols_slot = (getattr(self, "_cols_slot", -1) + 1) % 8
+        if not hasattr(self, "_cols_pinned") or self._cols_pinned.shape[1] != len(idx_y):
+            self._cols_pinned = torch.empty(8, len(idx_y), dtype=torch.int32).pin_memory()
+        self._cols_pinned[slot].copy_(torch.tensor(idx_y, dtype=torch.int32))
+        cols = self._cols_pinned[slot].to(dev, non_blocking=True)
         nb = idx.shape[0]
         x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
         y_batch = torch.empty(nb * (p + 1), dtype=torch.float32, device=dev)
         _ops.gather_batch(self.ctx, self.X, self.Y, idx.contiguous(), cols, p, x_batch, y_batch)   # interleaved y, :241
-        derivative_directions = self.E_canonical[np.array(idx_y[1:], dtype=np.int64) - 1]
-        kwargs = {} if self.full_gradient else {"derivative_directions": derivative_directions.repeat(nb, 1)}   # :238
+        kwargs = {}
+        if not self.full_gradient:
+            derivative_directions = self.E_canonical.index_select(0, cols[1:].long() - 1)
+            kwargs["derivative_directions"] = derivative_directions.repeat(nb, 1)   # :238
 
         self.variational_optimizer.zero_grad()
         self.hyperparameter_optimizer.zero_grad()
