@@ -31,7 +31,7 @@ extern "C" int dsvgp_set_stream(dsvgp_ctx* ctx, void* stream) {
 
 // algo 0: rocSOLVER dpotrf.  Row-major lower Cholesky == column-major upper factorisation of the same
 // buffer: dpotrf(upper) reads A(i,j), i<=j in column-major = the row-major lower triangle, and writes U with
-// U_colmajor(i,j) = L_rowmajor(j,i).   algo 1: blocked Cholesky on the MFMA GEMM (potrf.hip).
+// U_colmajor(i,j) = L_rowmajor(j,i).   algo 1: blocked Cholesky, one fused MFMA launch per block column (potrf.hip).
 extern "C" size_t dsvgp_potrf_workspace_bytes(int n, int algo) {
     return (algo == 1 && n > 0) ? potrf_blocked_workspace_bytes(n) : 0;
 }

@@ -1,25 +1,15 @@
-// Blocked right-looking Cholesky of the fp64 K_ZZ on the MFMA GEMM (algo 1 of dsvgp_potrf).
+// Blocked right-looking Cholesky of the fp64 K_ZZ (algo 1 of dsvgp_potrf), one fused MFMA launch per 64-column block.
 // reference: psd_safe_cholesky(K_ZZ.double()) -> torch.cholesky (DirectionalGradVariationalStrategy.py:72-75).
 //
-// rocSOLVER's dpotrf spends ~6 ms at M' = 3000 in serial single-workgroup panel kernels.  Here each
-// 64 x 64 diagonal block is factored AND inverted by one workgroup out of LDS (potf2_inv_kernel), the
-// panel below it is one triangular MFMA GEMM  L_panel = A_panel * inv(L_kk)^T  and the trailing update
-// one MFMA GEMM  A_22 -= L_panel L_panel^T  (lower tiles only); 3 launches per block column.
+// rocSOLVER's dpotrf takes 8.1 ms at M' = 3000 (serial single-workgroup panel kernels + many small launches); a first
+// blocked version here (diagonal-block kernel + panel GEMM + trailing GEMM per block column, 141 launches) took 4.5 ms.
+// This version: 48 launches, 1.35 ms (tools/potrf_probe.py, tools/potrf_trace.sh, tools/potrf_clock.sh).
 #include "common.h"
 
 namespace {
 
 constexpr int NBC = 64;
 
-// Thread (tx = tid & 63, ty = tid >> 6) keeps ONE register column w[r] <-> row NW*r + ty of column tx: it is
-// column tx of A while j < tx (right-looking updates), is published and written back as column tx of L at
-// j == tx, and from then on holds column tx of X = L^-1 (forward elimination of [L | I]) -- a lane never needs
-// both at once.  Per column j ONE barrier: the owners publish column j of A and row j of X through
-// double-buffered LDS vectors, every thread forms 1/sqrt(a_jj) (v_rsq_f64 + 2 Newton steps; no fp64 divide
-// or sqrt on the serial chain) and updates its registers.  NW waves (NW*64 threads) share the 64 x 64 block.
-#ifndef POTRF_NW
-#define POTRF_NW 16
-#endif
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
 #endif
@@ -30,159 +20,426 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return y;
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int r0, int nr,
-                                                            double* __restrict__ Dinv, int* __restrict__ info) {
-    constexpr int RPT = NBC / NW;            // rows per thread
-    __shared__ double colbuf[2][NBC];
-    __shared__ double rowbuf[2][NBC];
-    __shared__ double Ls[NBC][NBC + 1];      // finished columns of L (no global store on the serial chain)
-    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+// -------------------------------------------------------------------------------------------------
+// ONE launch per block column.
+//   With X_k = inv(L_kk) and W_k = X_k^T X_k = inv(A_kk) the rank-64 update of step k needs no solved panel:
+//       A_ij -= L_ik L_jk^T = (A_ik W_k) A_jk^T                  (i >= j > k)
+//   so kernel k does, per 64 x 64 trailing tile, T = A_ik W_k and A_ij -= T A_jk^T out of LDS (column k of A is
+//   read-only in that launch: no in-place hazard), and the workgroup of tile (k+1, k+1) goes on to factor its
+//   updated tile: L_{k+1,k+1}, X_{k+1}, W_{k+1}.  The solved panels L_ik = A_ik X_k^T are formed afterwards by ONE
+//   batched launch.  Critical path per block column: load + 2 products + the in-LDS factorisation.
+//
+//   In-LDS factorisation of a 64 x 64 tile by 256 threads: 4 x 4 grid of 16 x 16 sub-blocks; the diagonal
+//   sub-block is factored AND inverted by ONE wave out of registers (lane = row i, column group g; columns /
+//   rows exchanged through 16-entry LDS vectors, pivot by v_readlane: no workgroup barrier on the 16-column
+//   chain), the sub-panel, the trailing sub-blocks and the running inverse [L | I] -> [I | X] are 16x16x16
+//   fp64 MFMA products.
+// -------------------------------------------------------------------------------------------------
+using acc4 = double __attribute__((ext_vector_type(4)));
 #ifdef POTRF_DEBUG
-    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+__device__ unsigned long long chol_dbg[16];
+#define CHOL_STAMP(slot) do { if (tid == 0 && b == 0 && k == 20) chol_dbg[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHOL_STAMP(slot) do { } while (0)
 #endif
-    double w[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int i = NW * r + ty;
-        double v = (i == tx) ? 1.0 : 0.0;                       // identity padding of a ragged last block
-        if (i < nr && tx < nr && tx <= i) v = A[(int64_t)(r0 + i) * lda + r0 + tx];
-        w[r] = v;
-    }
-    for (int j = 0; j < NBC; ++j) {
-        double* cb = colbuf[j & 1];
-        double* rb = rowbuf[j & 1];
-        if (tx == j) {
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) cb[NW * r + ty] = w[r];
-        }
-        if (ty == j % NW) {                                      // owner of row j publishes X[j][tx] (1 on the diagonal)
-            double v = 0.0;
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) v = (r == j / NW) ? w[r] : v;
-            rb[tx] = (tx == j) ? 1.0 : v;
-        }
-        __syncthreads();
-        double cbv[RPT];
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) cbv[r] = cb[NW * r + ty];
-        const double dj = cb[j];
-        const double rbv = rb[tx], cbt = cb[tx];
-        if (tid == 0 && !(dj > 0.0) && j < nr && *info == 0) *info = r0 + j + 1;   // LAPACK: leading minor not PD
-        const double rinv = rsqrt_nr(dj);                       // 1 / L_jj
-        const bool right = tx > j, own = tx == j;
-        const double f = right ? cbt * rinv : rbv * rinv;       // L[tx][j]  or  final X[j][tx]
-        const int ilo = right ? tx : j + 1;                     // first row that takes the rank-1 update
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int i = NW * r + ty;
-            const double lij = cbv[r] * rinv;                   // L[i][j]  (i == j: sqrt(a_jj))
-            if (own) Ls[i][j] = lij;                            // column j of L is final
-            const double base = own ? 0.0 : w[r];               // the X column starts from the identity
-            double v = (i >= ilo) ? fma(-lij, f, base) : base;
-            v = (!right && i == j) ? f : v;                     // row j of X
-            w[r] = v;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) Dinv[(NW * r + ty) * NBC + tx] = w[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int i = NW * r + ty;
-        if (i < nr && tx <= i) A[(int64_t)(r0 + i) * lda + r0 + tx] = Ls[i][tx];
-    }
-#ifdef POTRF_DEBUG
-    if (tid == 0) {   // tools only: shader cycles and 100 MHz real-time ticks of this workgroup, in the unused upper corner
-        const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
-        Dinv[62] = (double)(t1c - t0c);
-        Dinv[63] = (double)(t1r - t0r);
-    }
-#endif
+constexpr int LDT = 66;                       // LDS row stride of a 64 x 64 tile (doubles)
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
 }
 
-// Single-stage fp64 MFMA kernel for the K <= 64 products of the factorisation (panel solve against the
-// inverted diagonal block, rank-64 trailing update): C[64x64 tile] = alpha * A[64 x K] * B[64 x K]^T + beta * C.
-// Both operands are k-contiguous and fit LDS whole, so a tile costs ONE global round trip instead of the
-// K/16 dependent stages of the general GEMM (which is latency-bound at K = 64: 21 / 53 us per launch).
-// lower_only: tiles with tn > tm exit, elements with n > m are not stored.  In place (C == A) is safe: every
-// workgroup stages its whole A tile before it writes.
-__global__ __launch_bounds__(256) void smallk_gemm_kernel(const double* __restrict__ A, int64_t lda,
-                                                          const double* __restrict__ B, int64_t ldb,
-                                                          double* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                          double alpha, double beta, int lower_only, int b_upper) {
-    __shared__ double As[64][65];
-    __shared__ double Bs[64][65];
-    const int tm = blockIdx.y, tn = blockIdx.x;
-    if (lower_only && tn > tm) return;
-    const int m0 = tm * 64, n0 = tn * 64, tid = threadIdx.x;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, k = e & 63;
-        As[r][k] = (m0 + r < M && k < K) ? A[(int64_t)(m0 + r) * lda + k] : 0.0;
-        double bv = 0.0;
-        if (n0 + r < N && k < K && !(b_upper && k > n0 + r)) bv = B[(int64_t)(n0 + r) * ldb + k];   // op(B)[k][n] = B[n][k]
-        Bs[r][k] = bv;
-    }
-    __syncthreads();
-    using acc_t = double __attribute__((ext_vector_type(4)));
-    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;   // wave -> 32 x 32 outputs
-    acc_t acc[2][2];
+// 64 x 64 x 64 product by 4 waves (wave -> 32 x 32 outputs):  acc[i][j] = sum_q Aop[m][q] * Bop(q, n)
+//   B_NK: Bop(q, n) = Bs[n][q]   (B given as [n][k]);  else Bop(q, n) = Bs[q][n]
+template <bool B_NK>
+__device__ __forceinline__ void tile_product(const double (*As)[LDT], const double (*Bs)[LDT], int lane, int wr, int wc,
+                                             acc4 (&acc)[2][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-#pragma unroll 4
-    for (int kk = 0; kk < 64; kk += 4) {
-        const int kq = kk + (lane >> 4);
-        double a[2], b[2];
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+    // all operands of the wave (2 x 16 + 2 x 16 doubles per lane) first, then 64 back-to-back MFMAs: the loops are
+    // fully unrolled (a rolled loop moves the accumulators AGPR <-> VGPR and drains the MFMA pipe every trip)
+    double a[2][16], b[2][16];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = As[wr * 32 + i * 16 + (lane & 15)][kq];
+    for (int ks = 0; ks < 16; ++ks) {
+        const int kq = 4 * ks + (lane >> 4);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = Bs[wc * 32 + j * 16 + (lane & 15)][kq];
+        for (int i = 0; i < 2; ++i) a[i][ks] = As[wr * 32 + i * 16 + (lane & 15)][kq];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = wc * 32 + j * 16 + (lane & 15);
+            b[j][ks] = B_NK ? Bs[n][kq] : Bs[kq][n];
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+}
+
+// one wave: Cholesky factor L_d (in place, upper part zeroed) and inverse Xd = L_d^-1 of the 16 x 16 block at F[o.., o..].
+// Lane (i = lane & 15, g = lane >> 4) holds a[t] = D[i][4g+t] and y[t] = Y[i][4g+t] (Y: forward elimination of the
+// identity, row i scaled by 1/L_ii at the end).  The single wave is instruction-issue bound, so per-element predicates
+// are replaced by zeros in the exchanged vectors: column j is published with rows < j zeroed, hence
+//   li = L[i][j] = 0 for i < j  and  lc = L[c][j] = 0 for c < j,   a[i][c] -= li * lc   needs no mask
+// (rows <= j only collect junk above the diagonal, which is never read), likewise Y[i][:] -= ls * Y[j][:] / L_jj with
+// ls = li for i > j, 0 otherwise.
+__device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*Xd)[17], double* colbuf, double* rowbuf,
+                                              int lane, int* info, int gidx0, int nvalid) {
+    const int i = lane & 15, g = lane >> 4;
+    double a[4], y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        a[t] = F[o + i][o + 4 * g + t];
+        y[t] = (i == 4 * g + t) ? 1.0 : 0.0;
     }
+    double ri = 1.0;                 // 1 / L_ii of this lane's row
+    int bad = -1;                    // first non-positive pivot (wave-uniform)
+    // lanes that do not own the published column / row write to a dummy slot (no exec-mask branches)
+    double* const cdst = colbuf + i;
+    double* const cdummy = colbuf + 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int gj = j >> 2, tj = j & 3;
+        const double d = readlane_f64(a[tj], j + 16 * gj);          // pivot a_jj
+        *((g == gj) ? cdst : cdummy) = (i >= j) ? a[tj] : 0.0;
+        {
+            double* rdst = (i == j) ? (rowbuf + 4 * g) : (rowbuf + 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) rdst[t] = y[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double ci = colbuf[i];
+        double cc[4], rr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { cc[t] = colbuf[4 * g + t]; rr[t] = rowbuf[4 * g + t]; }
+        __builtin_amdgcn_wave_barrier();
+        bad = (bad < 0 && !(d > 0.0)) ? j : bad;
+        const double rinv = rsqrt_nr(d);
+        const double li = ci * rinv;                                // L[i][j]  (0 above the diagonal, sqrt(a_jj) on it)
+        const double ls = (i == j) ? 0.0 : li;
+        ri = (i == j) ? rinv : ri;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = fma(-li, cc[t] * rinv, a[t]);
+            y[t] = fma(-ls, rr[t] * rinv, y[t]);
+        }
+        if (g == gj) a[tj] = li;
+    }
+    if (lane == 0 && bad >= 0 && o + bad < nvalid && *info == 0) *info = gidx0 + o + bad + 1;   // LAPACK convention
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = 4 * g + t;
+        F[o + i][o + c] = (c > i) ? 0.0 : a[t];
+        Xd[i][c] = (c > i) ? 0.0 : y[t] * ri;
+    }
+}
+
+// 16 x 16 x 16 product on one wave:  P[m][n] = sum_q Aop(m, q) Bop(q, n);  operands through pointers + strides
+//   Aop(m, q) = Ab[m * lda_ + q];   Bop(q, n) = B_NK ? Bb[n * ldb_ + q] : Bb[q * ldb_ + n]
+template <bool B_NK>
+__device__ __forceinline__ acc4 prod16(const double* Ab, int lda_, const double* Bb, int ldb_, int lane) {
+    acc4 acc{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+        const int kq = kk + (lane >> 4), r = lane & 15;
+        const double a = Ab[r * lda_ + kq];
+        const double b = B_NK ? Bb[r * ldb_ + kq] : Bb[kq * ldb_ + r];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// Factor F (64 x 64, lower, in LDS) -> L in place; Y <- X = L^-1.  256 threads.  While wave 0 runs the serial 16-column
+// chain of the next diagonal sub-block, waves 1..3 do everything that is already final: the other trailing sub-blocks,
+// the global stores of row-block kb of X and column-block kb of L, and the running sum W = X^T X = sum_kb X_kb^T X_kb
+// (lower blocks, mirrored on store) -- so the critical path is 4 x (factor16 + one panel product + one update product).
+__device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT], double (*Xd)[17], double* colbuf,
+                                             double* rowbuf, int tid, int* info, int gidx0, int nvalid,
+                                             double* __restrict__ Ag, int64_t lda, double* __restrict__ Xg,
+                                             double* __restrict__ Wg) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int mrow = (lane >> 4), ncol = lane & 15;
+    for (int e = tid; e < 64 * 64; e += 256) Y[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+    acc4 wacc[4];                        // waves 1..3: lower blocks idx = (wave - 1) + 3 s of W
+#pragma unroll
+    for (int sI = 0; sI < 4; ++sI) wacc[sI] = acc4{0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll 1      // one copy of the 16-column chain: trips 2..4 hit the instruction cache
+    for (int kb = 0; kb < 4; ++kb) {
+        const int o = kb * 16;
+#ifdef POTRF_DEBUG
+        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[8] = __builtin_amdgcn_s_memtime();
+#endif
+        if (wave == 0) factor16_wave(F, o, Xd, colbuf, rowbuf, lane, info, gidx0, nvalid);
+#ifdef POTRF_DEBUG
+        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[9] = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+        // (b) 4 tasks, one per wave: panel blocks ib > kb, row-block kb of X (cb < kb), and X_{kb,kb} = Xd
+        {
+            const int t = wave;
+            if (t < 3 - kb) {                    // L_{ib,kb} = F_{ib,kb} Xd^T
+                const int ib = kb + 1 + t;
+                acc4 r = prod16<true>(&F[ib * 16][o], LDT, &Xd[0][0], 17, lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) F[ib * 16 + mrow + 4 * q][o + ncol] = r[q];
+            } else if (t < 3) {                  // X_{kb,cb} = Xd Y_{kb,cb},  cb = t - (3 - kb)  in [0, kb)
+                const int cb = t - (3 - kb);
+                acc4 r = prod16<false>(&Xd[0][0], 17, &Y[o][cb * 16], LDT, lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Y[o + mrow + 4 * q][cb * 16 + ncol] = r[q];
+            } else {                             // X_{kb,kb} = Xd
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Y[o + mrow + 4 * q][o + ncol] = Xd[mrow + 4 * q][ncol];
+            }
+        }
+        __syncthreads();
+#ifdef POTRF_DEBUG
+        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[10] = __builtin_amdgcn_s_memtime();
+#endif
+        // (c) trailing sub-blocks:  F_{ib,jb} -= L_{ib,kb} L_{jb,kb}^T (kb < jb <= ib),  Y_{ib,cb} -= L_{ib,kb} X_{kb,cb} (cb <= kb).
+        // Look-ahead: wave 0 updates only the NEXT diagonal sub-block (from the panel block it produced itself) and goes
+        // straight on to factor it; waves 1..3 touch neither that sub-block nor Xd / colbuf / rowbuf; the barrier after
+        // the next factor16 closes the phase.
+        if (wave == 0) {
+            if (kb < 3) {
+                const int ib = kb + 1;
+                acc4 r = prod16<true>(&F[ib * 16][o], LDT, &F[ib * 16][o], LDT, lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) F[ib * 16 + mrow + 4 * q][ib * 16 + ncol] -= r[q];
+            }
+        } else {
+            int task = 0;
+            for (int ib = kb + 1; ib < 4; ++ib) {
+                for (int jb = kb + 1; jb <= ib; ++jb) {
+                    if (ib == kb + 1 && jb == kb + 1) continue;          // wave 0
+                    if (1 + (task++ % 3) != wave) continue;
+                    acc4 r = prod16<true>(&F[ib * 16][o], LDT, &F[jb * 16][o], LDT, lane);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) F[ib * 16 + mrow + 4 * q][jb * 16 + ncol] -= r[q];
+                }
+                for (int cb = 0; cb <= kb; ++cb) {
+                    if (1 + (task++ % 3) != wave) continue;
+                    acc4 r = prod16<false>(&F[ib * 16][o], LDT, &Y[o][cb * 16], LDT, lane);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Y[ib * 16 + mrow + 4 * q][cb * 16 + ncol] -= r[q];
+                }
+            }
+            // final data of this sub-block step: rows o..o+15 of X, columns o..o+15 of L -> global
+            const int t3 = tid - 64;
+            for (int e = t3; e < 16 * 64; e += 192) {
+                const int r = o + (e >> 6), c = e & 63;
+                Xg[r * 64 + c] = Y[r][c];
+            }
+            for (int e = t3; e < (64 - o) * 16; e += 192) {
+                const int r = o + (e >> 4), c = o + (e & 15);
+                if (r < nvalid && c <= r) Ag[(int64_t)r * lda + c] = F[r][c];
+            }
+            // W += X_kb^T X_kb on the lower blocks (mb >= nb) owned by this wave; X_{kb,cb} = 0 for cb > kb
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const int idx = (wave - 1) + 3 * sI;
+                const int mb = (idx >= 6) ? 3 : ((idx >= 3) ? 2 : ((idx >= 1) ? 1 : 0)), nb = idx - mb * (mb + 1) / 2;
+                if (idx < 10 && mb <= kb) {
+#pragma unroll
+                    for (int kq0 = 0; kq0 < 16; kq0 += 4) {
+                        const int kq = o + kq0 + (lane >> 4);
+                        wacc[sI] = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kq][mb * 16 + ncol], Y[kq][nb * 16 + ncol], wacc[sI], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#ifdef POTRF_DEBUG
+        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[11] = __builtin_amdgcn_s_memtime();
+#endif
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            const int idx = (wave - 1) + 3 * sI;
+            const int mb = (idx >= 6) ? 3 : ((idx >= 3) ? 2 : ((idx >= 1) ? 1 : 0)), nb = idx - mb * (mb + 1) / 2;
+            if (idx < 10) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mb * 16 + mrow + 4 * q, nn = nb * 16 + ncol;
+                    Wg[m * 64 + nn] = wacc[sI][q];
+                    Wg[nn * 64 + m] = wacc[sI][q];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
+                                                        double* __restrict__ Xws, double* __restrict__ Wws,
+                                                        int* __restrict__ info) {
+    __shared__ double S[4][64][LDT];
+    __shared__ double Xd[16][17];
+    __shared__ double colbuf[32], rowbuf[32];      // [16..31]: dummy slots of the non-owner lanes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int b = blockIdx.x;
+    int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int tj = b - ti * (ti + 1) / 2;
+    const int i0 = (k + 1 + ti) * 64, j0 = (k + 1 + tj) * 64;
+    double (*F)[LDT] = S[3];
+    CHOL_STAMP(0);
+    if (k >= 0) {
+        const int k0 = k * 64;
+        const double* Wk = Wws + (size_t)k * 4096;
+        double cv[2][2][4];    // C tile, requested behind the operand loads (clamped addresses: no predicated load -> wait -> store chains)
+        {   // all 48 + 16 loads of a thread in flight at once (a rolled loop pays the global latency 16 times)
+            double ra[16], rb[16], rw[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+                ra[u] = A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
+                rb[u] = A[(int64_t)min(j0 + r, n - 1) * lda + k0 + c];
+                rw[u] = Wk[r * 64 + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = min(i0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, n - 1);
+                        const int nn = min(j0 + wc * 32 + j * 16 + (lane & 15), n - 1);
+                        cv[i][j][q] = A[(int64_t)m * lda + nn];
+                    }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+                S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
+                S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
+                S[2][r][c] = rw[u];
+            }
+        }
+        __syncthreads();
+        CHOL_STAMP(1);
+        acc4 acc[2][2];
+        tile_product<true>(S[0], S[2], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
+        __syncthreads();
+        tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T A_jk^T
+        const bool diag = ti == tj;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * 32 + j * 16 + (lane & 15);
+                    const int m = i0 + ml, nn = j0 + nl;
+                    const bool in = m < n && nn < n && !(diag && nl > ml);
+                    const double v = cv[i][j][q] - acc[i][j][q];
+                    if (b == 0) F[ml][nl] = in ? v : ((ml == nl) ? 1.0 : 0.0);   // identity padding of a ragged last block
+                    else if (in) A[(int64_t)m * lda + nn] = v;
+                }
+        if (b != 0) return;
+    } else {
+        double ra[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            ra[u] = A[(int64_t)min(r, n - 1) * lda + min(c, n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            F[r][c] = (r < n && c <= r) ? ra[u] : ((r == c) ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    CHOL_STAMP(2);
+    // ---- factor the diagonal tile kk = k + 1 ----
+    const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
+    double (*Y)[LDT] = S[1];
+    factor64_lds(F, Y, Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
+                 Wws + (size_t)kk * 4096);
+    CHOL_STAMP(3);
+}
+
+// all solved panels in one launch:  L_ik = A_ik X_k^T  (i > k), in place, one 64 x 64 tile per workgroup
+__global__ __launch_bounds__(256) void chol_panels_kernel(double* __restrict__ A, int64_t lda, int n,
+                                                          const double* __restrict__ Xws) {
+    __shared__ double S[2][64][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int b = blockIdx.x;
+    int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int k = b - ti * (ti + 1) / 2, i0 = (ti + 1) * 64, k0 = k * 64;     // strict lower: block row ti + 1, column k
+    const double* Xk = Xws + (size_t)k * 4096;
+    {
+        double ra[16], rx[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            ra[u] = A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
+            rx[u] = Xk[r * 64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            S[0][(tid >> 6) + 4 * u][tid & 63] = (i0 + (tid >> 6) + 4 * u < n) ? ra[u] : 0.0;
+            S[1][(tid >> 6) + 4 * u][tid & 63] = rx[u];
+        }
+    }
+    __syncthreads();
+    acc4 acc[2][2];
+    tile_product<true>(S[0], S[1], lane, wr, wc, acc);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * r;      // f64 C/D layout
-                const int n = n0 + wc * 32 + j * 16 + (lane & 15);
-                if (m >= M || n >= N || (lower_only && n > m)) continue;
-                double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * C[(int64_t)m * ldc + n];
-                C[(int64_t)m * ldc + n] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int m = i0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, c = k0 + wc * 32 + j * 16 + (lane & 15);
+                if (m < n) A[(int64_t)m * lda + c] = acc[i][j][q];
             }
 }
 
 }  // namespace
 
-size_t potrf_blocked_workspace_bytes(int n) { return sizeof(double) * (size_t)cdiv(n, NBC) * NBC * NBC; }
+size_t potrf_blocked_workspace_bytes(int n) { return 2 * sizeof(double) * (size_t)cdiv(n, NBC) * NBC * NBC; }
 
-int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* dinv_ws) {
+// one fused launch per block column + one batched panel launch (see chol_step_kernel)
+int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws) {
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
     if (e != hipSuccess) return 1000 + (int)e;
     const int nblk = cdiv(n, NBC);
-    for (int k = 0; k < nblk; ++k) {
-        const int r0 = k * NBC, nr = (n - r0 < NBC) ? (n - r0) : NBC, r1 = r0 + nr;
-        double* Dk = dinv_ws + (size_t)k * NBC * NBC;
-        hipLaunchKernelGGL(potf2_inv_kernel<POTRF_NW>, dim3(1), dim3(POTRF_NW * 64), 0, st, A, lda, r0, nr, Dk, info);
+    double* Xws = ws;
+    double* Wws = ws + (size_t)nblk * NBC * NBC;
+    for (int k = -1; k < nblk - 1; ++k) {
+        const int nt = nblk - (k + 1);
+        const int grid = (k < 0) ? 1 : nt * (nt + 1) / 2;
+        hipLaunchKernelGGL(chol_step_kernel, dim3(grid), dim3(256), 0, st, A, lda, n, k, Xws, Wws, info);
         DSVGP_LAUNCH_CHECK();
-        if (r1 >= n) break;
-        // panel: L[r1:, r0:r1] = A[r1:, r0:r1] * inv(L_kk)^T      (in place; op(B)[k][n] = Dinv[n][k], zero for k > n)
-        const int Mr = n - r1;
-        hipLaunchKernelGGL(smallk_gemm_kernel, dim3(1, cdiv(Mr, 64)), dim3(256), 0, st, A + (size_t)r1 * lda + r0, lda,
-                           (const double*)Dk, (int64_t)NBC, A + (size_t)r1 * lda + r0, lda, Mr, nr, nr, 1.0, 0.0, 0, 1);
-        DSVGP_LAUNCH_CHECK();
-        // trailing update: A[r1:, r1:] -= L_panel L_panel^T        (lower tiles only, in place)
-        hipLaunchKernelGGL(smallk_gemm_kernel, dim3(cdiv(Mr, 64), cdiv(Mr, 64)), dim3(256), 0, st,
-                           A + (size_t)r1 * lda + r0, lda, A + (size_t)r1 * lda + r0, lda, A + (size_t)r1 * lda + r1, lda,
-                           Mr, Mr, nr, -1.0, 1.0, 1, 0);
+    }
+    if (nblk > 1) {
+        hipLaunchKernelGGL(chol_panels_kernel, dim3(nblk * (nblk - 1) / 2), dim3(256), 0, st, A, lda, n, (const double*)Xws);
         DSVGP_LAUNCH_CHECK();
     }
     return 0;
 }
+
+#ifdef POTRF_DEBUG
+extern "C" int dsvgp_debug_potrf_clock(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 16);
+}
+#endif

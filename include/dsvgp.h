@@ -87,8 +87,9 @@ int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double
 /* ---- Cholesky: psd_safe_cholesky(K_ZZ.double()) (DirectionalGradVariationalStrategy.py:72-75)
  * In-place lower Cholesky of the row-major fp64 matrix A[n,n] (rocSOLVER dpotrf); only the lower
  * triangle is read/written.  info_dev is a device int (0 = ok, k>0 = leading minor k not PD).   */
-/* algo 0: rocSOLVER dpotrf (no workspace).  algo 1: blocked right-looking Cholesky on the fp64 MFMA GEMM
- * (64 x 64 diagonal blocks factored + inverted out of LDS); workspace of dsvgp_potrf_workspace_bytes.     */
+/* algo 0: rocSOLVER dpotrf (no workspace).  algo 1: blocked right-looking Cholesky, one fused fp64 MFMA launch per
+ * 64-column block (trailing update + factorisation / inversion of the next diagonal block out of LDS) and one
+ * batched panel launch; workspace of dsvgp_potrf_workspace_bytes.                                           */
 size_t dsvgp_potrf_workspace_bytes(int n, int algo);
 int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev, int algo, void* workspace);
 /* A.diagonal() += delta   (the jitter retries of psd_safe_cholesky)                              */

@@ -14,3 +14,16 @@ for algo in (0, 1):
     L = A.tril().cpu()
     print("algo", algo, "max|L-Lref|/max|Lref| = %.3e" % ((L - Lref).abs().max() / Lref.abs().max()).item(),
           "resid |LL^T-K|/|K| = %.3e" % ((L @ L.t() - K).abs().max() / K.abs().max()).item())
+
+# the DSVGP K_ZZ itself (C4 geometry, fp64 assembly + 1e-3 jitter)
+M, d, p = 500, 20, 5
+hyp = torch.tensor([0.69, 0.69, 0.1, 0.0], device=dev)
+Z, V = torch.rand(M, d, device=dev), torch.eye(d, device=dev)[:p].repeat(M, 1)
+pz = ops.pack_points(ctx, Z, V, p, hyp)
+Kz = ops.kernel_fwd(ctx, pz, M, pz, M, d, p, hyp, jitter=1e-3, dtype=torch.float64)
+Kc = Kz.cpu(); Lref = torch.linalg.cholesky(Kc)
+for algo in (0, 1):
+    A = Kz.clone(); ops.potrf_(ctx, A, info, algo); torch.cuda.synchronize()
+    L = A.tril().cpu()
+    print("K_ZZ algo", algo, "info", int(info.item()), "max|L-Lref|/max|Lref| = %.3e" % ((L - Lref).abs().max() / Lref.abs().max()).item(),
+          "resid |LL^T-K|/|K| = %.3e" % ((L @ L.t() - Kc).abs().max() / Kc.abs().max()).item())

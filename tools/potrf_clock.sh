@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools only: build potrf.hip with -DPOTRF_DEBUG and print in-kernel cycles / clock of the 64x64 factor kernel
+# tools only: build potrf.hip with -DPOTRF_DEBUG and print in-kernel cycle stamps of the diagonal workgroup of the
+# fused Cholesky step kernel (block column 20 of a 3000 x 3000 matrix)
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}; C=$R/gp-derivatives-variational-inference_amd/csrc; B=/tmp/potrf_dbg; mkdir -p $B
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed -I$R/include -I$C"
@@ -7,7 +8,7 @@ for f in gemm elbo assemble api; do hipcc $FL -c $C/$f.hip -o $B/$f.o & done; wa
 hipcc $FL -DPOTRF_DEBUG ${POTRF_DEFS} -c $C/potrf.hip -o $B/potrf.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libdsvgp_hip.so $B/potrf.o $B/assemble.o $B/gemm.o $B/elbo.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
 DSVGP_LIB_PATH=$B/libdsvgp_hip.so python - <<'PY'
-import os, sys
+import os, sys, ctypes
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, dsvgp_amd
 ops = dsvgp_amd._ops
@@ -19,8 +20,13 @@ K = (Q @ Q.t() / n + torch.eye(n, dtype=torch.float64)).to(dev)
 info = torch.zeros(1, dtype=torch.int32, device=dev)
 for rep in range(3):
     A = K.clone(); ops.potrf_(ctx, A, info, 1); torch.cuda.synchronize()
-ws = ops._potrf_ws[(0, n)].view(torch.float64).view(-1, 64, 64)
-cyc, rt = ws[:, 0, 62].cpu(), ws[:, 0, 63].cpu()
-print("potf2_inv_kernel: cycles/block median %.0f, realtime %.1f us, clock %.2f GHz, cycles/column %.0f" % (
-    cyc.median().item(), rt.median().item() / 100, (cyc / rt * 0.1).median().item(), cyc.median().item() / 64))
+lib = ctypes.CDLL(os.environ["DSVGP_LIB_PATH"])
+buf = (ctypes.c_ulonglong * 16)()
+lib.dsvgp_debug_potrf_clock(buf)
+t = list(buf)
+names = {1: "loads done", 2: "2 products + F formed", 3: "factor64 + W + stores"}
+print("diag workgroup, block column 20 (shader cycles since kernel entry):")
+for s in (1, 2, 3):
+    print("  %-24s %8d  (+%d)" % (names[s], t[s] - t[0], t[s] - t[s - 1]))
+print("  inside factor64, kb = 0:  factor16 (1 wave) %d, phase (b) %d, phase (c) %d" % (t[9] - t[8], t[10] - t[9], t[11] - t[10]))
 PY

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time dsvgp_potrf algo 0 (rocSOLVER) vs 1 (blocked MFMA) on a C4-sized K_ZZ (M'=3000)."""
+"""Time dsvgp_potrf algo 0 (rocSOLVER) vs 1 (blocked, one fused MFMA launch per block column) on a C4-sized K_ZZ
+(M'=3000)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
