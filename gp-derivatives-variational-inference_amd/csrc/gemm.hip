@@ -27,10 +27,13 @@
 #define GEMM_BK_F64 16
 #endif
 #ifndef GEMM_SK_OVH
-#define GEMM_SK_OVH 256.0     // per-workgroup fixed cost in units of K steps (split-K policy)
+#define GEMM_SK_OVH 64.0      // per-workgroup fixed cost in units of K steps (split-K policy; probed 64 / 128 / 256 / 1024)
 #endif
-#ifndef GEMM_COMPACT_LOWER
-#define GEMM_COMPACT_LOWER 1
+#ifndef GEMM_SK_BINS
+#define GEMM_SK_BINS 256
+#endif
+#ifndef GEMM_MIN_CHUNK
+#define GEMM_MIN_CHUNK 16     // smallest XCD dealing unit (workgroups)
 #endif
 #ifndef GEMM_XCD
 #define GEMM_XCD 1
@@ -154,58 +157,59 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
     // stage out of its private 4 MiB L2 instead of 64 + 64 from HBM / Infinity Cache.
     const int gx = g.tiles_n, gy = g.tiles_m;
     int tm, tn, zz;
-    if (g.supertile == 2 && GEMM_XCD) {
-        // OUT_LOWER on a square tile grid: only the T(T+1)/2 tiles on / below the diagonal exist.  They are
-        // enumerated supertile-major (so 64 consecutive entries still share ~8 + 8 operand panels) and dealt
-        // to the XCDs in chunks of 64 ACTIVE tiles: every XCD gets the same number of workgroups (a diagonal
-        // supertile holds 36 tiles, a full one 64; dealing whole supertiles left the XCDs 20-35 % unbalanced).
+    if (g.supertile && GEMM_XCD) {
+        // The ACTIVE tiles (all of them, or for OUT_LOWER on a square grid the T(T+1)/2 on / below the diagonal) x
+        // batch x split-K slices are enumerated supertile-major -- 64 consecutive entries share ~8 + 8 operand panels --
+        // and dealt to the XCDs in chunks of g.chunk entries, so every XCD gets the same number of workgroups
+        // (dealing whole 8 x 8 supertiles left the XCDs 20-35 % unbalanced whenever their number x z was not a
+        // multiple of 8 or diagonal supertiles held 36 instead of 64 tiles).
+        const int CS = g.chunk;
         const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-        const int lin = (((j >> 6) * 8 + xcd) << 6) + (j & 63);
-        const int nact = gy * (gy + 1) / 2;
-        if (lin >= nact * g.batch * g.splitk) return;
-        zz = lin / nact;
-        int t = lin - zz * nact, sm = 0, rows;
-        for (;; ++sm) {
-            rows = min(8, gy - sm * 8);
-            const int rowtot = sm * rows * 8 + rows * (rows + 1) / 2;
-            if (t < rowtot) break;
-            t -= rowtot;
-        }
-        if (t < sm * rows * 8) {
-            const int sn = t / (rows * 8), li = t - sn * rows * 8;
-            tm = sm * 8 + (li >> 3);
-            tn = sn * 8 + (li & 7);
+        const int lin = ((j / CS) * 8 + xcd) * CS + (j % CS);
+        const bool lower = g.supertile == 2;
+        const int ntiles = lower ? gy * (gy + 1) / 2 : gx * gy;
+        if (lin >= ntiles * g.batch * g.splitk) return;
+        zz = lin / ntiles;
+        int t = lin - zz * ntiles;
+        if (lower) {
+            int sm = 0, rows;
+            for (;; ++sm) {
+                rows = min(8, gy - sm * 8);
+                const int rowtot = sm * rows * 8 + rows * (rows + 1) / 2;
+                if (t < rowtot) break;
+                t -= rowtot;
+            }
+            if (t < sm * rows * 8) {
+                const int sn = t / (rows * 8), li = t - sn * rows * 8;
+                tm = sm * 8 + (li >> 3);
+                tn = sn * 8 + (li & 7);
+            } else {
+                const int li = t - sm * rows * 8;
+                int r = (int)((sqrtf(8.f * (float)li + 1.f) - 1.f) * 0.5f);
+                while ((r + 1) * (r + 2) / 2 <= li) ++r;
+                while (r * (r + 1) / 2 > li) --r;
+                tm = sm * 8 + r;
+                tn = sm * 8 + li - r * (r + 1) / 2;
+            }
         } else {
-            const int li = t - sm * rows * 8;
-            int r = (int)((sqrtf(8.f * (float)li + 1.f) - 1.f) * 0.5f);
-            while ((r + 1) * (r + 2) / 2 <= li) ++r;
-            while (r * (r + 1) / 2 > li) --r;
+            const int nsm = (gy + 7) >> 3, nsn = (gx + 7) >> 3, rows_last = gy - 8 * (nsm - 1);
+            int sm, rows;
+            if (triA == 1) {                 // lower-triangular A: the longest K ranges (bottom supertile rows) first
+                const int first = rows_last * gx;
+                if (t < first) { sm = nsm - 1; rows = rows_last; }
+                else { t -= first; const int q = t / (8 * gx); sm = nsm - 2 - q; t -= q * 8 * gx; rows = 8; }
+            } else {
+                sm = min(t / (8 * gx), nsm - 1);
+                t -= sm * 8 * gx;
+                rows = (sm == nsm - 1) ? rows_last : 8;
+            }
+            const int sn = min(t / (rows * 8), nsn - 1);
+            t -= sn * rows * 8;
+            const int cols = min(8, gx - sn * 8);
+            const int r = t / cols;
             tm = sm * 8 + r;
-            tn = sm * 8 + li - r * (r + 1) / 2;
+            tn = sn * 8 + t - r * cols;
         }
-    } else if (g.supertile && GEMM_XCD) {
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-        const int within = j & 63, Sg = (j >> 6) * 8 + xcd;     // supertile unit (z folded in: XCD balance)
-        const int nsn = (gx + 7) >> 3, nsm = (gy + 7) >> 3;
-        const bool lower_only = out_lower && nsn == nsm;
-        const int nsup = lower_only ? (nsm * (nsm + 1)) / 2 : nsn * nsm;
-        if (Sg >= nsup * g.batch * g.splitk) return;
-        zz = Sg / nsup;
-        const int S = Sg - zz * nsup;
-        int sm, sn;
-        if (lower_only) {            // enumerate supertiles on / below the diagonal only
-            sm = (int)((sqrtf(8.f * (float)S + 1.f) - 1.f) * 0.5f);
-            while ((sm + 1) * (sm + 2) / 2 <= S) ++sm;
-            while (sm * (sm + 1) / 2 > S) --sm;
-            sn = S - sm * (sm + 1) / 2;
-        } else {
-            sm = S / nsn;
-            sn = S - sm * nsn;
-        }
-        if (triA == 1) sm = nsm - 1 - sm;                       // longest K ranges first
-        tm = sm * 8 + (within >> 3);
-        tn = sn * 8 + (within & 7);
-        if (tm >= gy || tn >= gx) return;
     } else {
         zz = blockIdx.z;
         tm = blockIdx.x / gx;
@@ -427,13 +431,14 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
     if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 1024) {
         const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (128 / a.bn) : a.tiles_m * a.tiles_n;
-        // split factor: minimise (rounds of the 512 resident-workgroup slots) x (K slice + fixed per-workgroup cost)
+        // split factor: minimise (rounds over the 256 CUs -- two resident workgroups share a CU's matrix pipe, so the
+        // CU, not the slot, is the unit of throughput) x (K slice + fixed per-workgroup cost)
         int sk = 1;
         if (active > 0 && active < 1024) {
             const int maxsk = a.K / 512 < 32 ? a.K / 512 : 32;
             double best = 1e300;
             for (int c = 1; c <= maxsk; ++c) {
-                const double t = (double)cdiv((int64_t)active * c, 512) * ((double)a.K / c + GEMM_SK_OVH);
+                const double t = (double)cdiv((int64_t)active * c, GEMM_SK_BINS) * ((double)a.K / c + GEMM_SK_OVH);
                 if (t < best * 0.999) { best = t; sk = c; }
             }
         }
@@ -457,15 +462,18 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     }
     a.supertile = (a.tiles_n * a.tiles_m >= 64) ? 1 : 0;
     dim3 grid(a.tiles_n * a.tiles_m, 1, a.batch * a.splitk);
-    if (a.supertile && out_lower && a.tiles_n == a.tiles_m && GEMM_COMPACT_LOWER) {
-        a.supertile = 2;
-        const int64_t nact = (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 * a.batch * a.splitk;
-        grid = dim3(cdiv(cdiv(nact, 64), 8) * 8 * 64, 1, 1);
-    } else if (a.supertile) {
-        const int nsn = cdiv(a.tiles_n, 8), nsm = cdiv(a.tiles_m, 8);
-        const bool lower_only = (g.flags & DSVGP_GEMM_OUT_LOWER) && nsn == nsm;
-        const int nsup = lower_only ? (nsm * (nsm + 1)) / 2 : nsn * nsm;
-        grid = dim3(cdiv((int64_t)nsup * a.batch * a.splitk, 8) * 8 * 64, 1, 1);
+    if (a.supertile) {
+        const bool lower = out_lower && a.tiles_n == a.tiles_m;
+        a.supertile = lower ? 2 : 1;
+        const int64_t total = (lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n) * a.batch * a.splitk;
+        // chunk dealt to an XCD at a time: 64 (a full set of resident workgroups) unless that leaves the XCDs > 4 % apart
+        int cs = 64;
+        for (; cs > GEMM_MIN_CHUNK; cs >>= 1) {
+            const int64_t nch = cdiv(total, (int64_t)cs);
+            if ((double)(cdiv(nch, 8) * 8) / (double)nch <= 1.04) break;
+        }
+        a.chunk = cs;
+        grid = dim3(cdiv(cdiv(total, (int64_t)cs), 8) * 8 * cs, 1, 1);
     }
     if (is_double) {
         if (g.flags & DSVGP_GEMM_B_IS_FLOAT) return dispatch<double, float>(st, a, grid);

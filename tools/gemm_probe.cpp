@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     fill(LS32, (size_t)Mp * Mp, false); fill(vs, Bp, false); fill(X64, (size_t)Mp * Bp, true);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Case { const char* name; int dbl, flags, M, N, K; const void *A; long lda; const void* B; long ldb; void* C; long ldc; const float* ks; double flops; };
-    const double tri = (double)Mp * Mp * Bp, full = 2.0 * Mp * Mp * Bp;
+    const double tri = (double)Mp * Mp * Bp, full = 2.0 * Mp * Mp * Bp, cube = (double)Mp * Mp * Mp;
     Case cases[] = {
         {"f64 solve  Dinv(lower) x K_ZX(f32)   ", 1, DSVGP_GEMM_A_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Bp, Mp, L64, Mp, K32, Bp, X64, Bp, nullptr, tri},
         {"f64 solveT Dinv^T(upper) x Abar(f32)  ", 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_IS_FLOAT, Mp, Bp, Mp, L64, Mp, K32, Bp, X64, Bp, nullptr, tri},
@@ -43,6 +43,12 @@ int main(int argc, char** argv) {
         {"f32 Gram   tril(A A^T) k-contig ops   ", 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, A32, Bp, A32, Bp, S32, Mp, nullptr, tri},
         {"f32 Gram   tril(At^T At) transposed    ", 0, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, A32, Mp, A32, Mp, S32, Mp, nullptr, tri},
         {"f32 dense  transposed A (Kb-like)      ", 0, DSVGP_GEMM_TRANS_A, Mp, Bp, Mp, LS32, Mp, A32, Bp, W32, Bp, nullptr, full},
+        // M' x M' x M' class (Cholesky backward, Q', L-bar of the ELBO fast path, S, dL_S)
+        {"f64 MxM solveT Dinv^T(upper) x G      ", 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER, Mp, Mp, Mp, L64, Mp, S64, Mp, X64, Mp, nullptr, cube},
+        {"f64 MxM solveT, f32 rhs (Q')          ", 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp, L64, Mp, LS32, Mp, X64, Mp, nullptr, cube},
+        {"f64 MxM tril(Q G) (L-bar fast, f32 B) ", 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp, L64, Mp, LS32, Mp, S64, Mp, nullptr, cube},
+        {"f32 MxM S = L_S L_S^T                 ", 0, DSVGP_GEMM_A_LOWER | DSVGP_GEMM_TRANS_B | DSVGP_GEMM_B_UPPER, Mp, Mp, Mp, LS32, Mp, LS32, Mp, S32, Mp, nullptr, cube * 2 / 3},
+        {"f32 MxM tril(G tril(L_S))             ", 0, DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, LS32, Mp, LS32, Mp, S32, Mp, nullptr, cube * 2 / 3},
     };
     for (auto& c : cases) {
         for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
