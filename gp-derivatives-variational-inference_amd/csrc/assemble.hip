@@ -24,7 +24,7 @@ namespace {
 
 constexpr int TMAX = 96;   // tile rows/cols of the interleaved matrix handled per workgroup
 constexpr int LDT = 100;   // LDS row stride of the T / G tiles (100 % 32 == 4 -> acc writes conflict-free per half)
-constexpr int MAXACC = 9;  // backward: max 16x16 output tiles per wave (6 x ceil(DP/16) / 4)
+
 
 using f4 = float __attribute__((ext_vector_type(4)));
 
@@ -200,117 +200,277 @@ __global__ void kernel_diag_kernel(int n, int p, const float* __restrict__ hyp, 
 }
 
 // ---- backward -------------------------------------------------------------------------------------
-// grid = (nsplit, row tiles).  Workgroup (sx, by) sweeps column tiles sx, sx+nsplit, ... of row tile by.
-template <typename GT>
-__global__ __launch_bounds__(256) void kernel_bwd_kernel(const GT* __restrict__ G, int64_t ldg,
-                                                         const float* __restrict__ P1, const float* __restrict__ self1,
-                                                         int n1q, const float* __restrict__ P2,
-                                                         const float* __restrict__ self2, int n2q, int q, int R,
-                                                         int K4, int DP, int NP, const float* __restrict__ hyp,
-                                                         float* __restrict__ slab, float* __restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LDP = NP + 1;
-    float* P1s = smem;
-    float* P2s = P1s + TMAX * LDP;
-    float* Ts = P2s + TMAX * LDP;
-    float* Gs = Ts + TMAX * LDT;
-    float* s1 = Gs + TMAX * LDT;
-    float* s2 = s1 + TMAX;
-    float* red = s2 + TMAX;  // 2*4 floats
+// grid = (nsplit, row tiles).  Workgroup (sx, by) owns Rr points (Tr = Rr q <= 48 rows for q <= 48) of side 1 and
+// sweeps column tiles sx, sx+nsplit, ... (Rc points, Tc = Rc q <= 96 columns).  Per tile:
+//   1. the upstream tile Gbar and the P2 packs arrive through registers (loads for tile t+1 are in flight while
+//      tile t is transformed), T = P1 P2^T is recomputed on MFMA;
+//   2. ROW pass, one thread per (tile row, point column): reads its 1 x q strip of Gbar / T, writes Tbar_a0 and
+//      Tbar_ab in place, the strip's share of <Gbar, dK/dk> and u_a to small side arrays;
+//   3. COLUMN pass, one thread per (point row, tile column): Tbar_0b (column sums over a) and Tbar_00;
+//   4. dP1[Tr, NP] += Tbar[Tr, Tc] . P2ext[Tc, NP] on MFMA, accumulators stay in registers over the sweep.
+// Both passes are q-fold parallel within a micro-block with in-thread reductions only (the earlier
+// one-thread-per-point-pair transform was LDS-latency bound at 4 waves per CU).
+#ifndef BWD_ABLATE
+#define BWD_ABLATE 0      // tools only: bit 0 = no row/column passes, bit 1 = no dP1 MFMA, bit 2 = no T MFMA, bit 3 = no Gbar loads
+#endif
+#ifndef BWD_NT_
+#define BWD_NT_ 384
+#endif
+#ifndef BWD_WGS_
+#define BWD_WGS_ 512
+#endif
+constexpr int BWD_NT = BWD_NT_;                 // 6 waves: 2 row + 2 column tasks per thread on a 48 x 96 tile
+constexpr int BWD_NW = BWD_NT / 64;
+constexpr int BWD_MAXACC = (36 + BWD_NW - 1) / BWD_NW;   // 16x16 dP1 tiles per wave, worst case 6 x 6
+constexpr int BWD_GCH = (48 * (TMAX / 4) + BWD_NT - 1) / BWD_NT;       // 4-wide Gbar chunks per thread (Tr <= 48)
+constexpr int BWD_GCH_MAX = (TMAX * (TMAX / 4) + BWD_NT - 1) / BWD_NT; // ... when one point fills the tile (q > 48)
+constexpr int BWD_TARGET_WGS = BWD_WGS_;         // 2 resident workgroups per CU
 
-    const int T = R * q, Tp = (T + 15) & ~15;
-    const int ntr = Tp / 16, nnp = NP / 16;
-    const int row0 = blockIdx.y * T;
-    const int ncoltiles = (n2q + T - 1) / T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <typename GT> struct GVec;
+template <> struct GVec<float> { using type = float __attribute__((ext_vector_type(4))); };
+template <> struct GVec<double> { using type = double __attribute__((ext_vector_type(4))); };
+
+template <typename GT>
+__device__ __forceinline__ f4 load_g4(const GT* __restrict__ G, int64_t ldg, int64_t gr, int64_t gc, int r, int c,
+                                      int Tr, int Tc, int n1q, int n2q, bool vec) {
+    f4 o = {0.f, 0.f, 0.f, 0.f};
+    if (r >= Tr || gr >= n1q || c >= Tc) return o;
+    const GT* src = G + gr * ldg + gc;
+    if (vec && c + 3 < Tc && gc + 3 < n2q) {
+        const typename GVec<GT>::type v = *reinterpret_cast<const typename GVec<GT>::type*>(src);
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (c + t < Tc && gc + t < n2q) o[t] = (float)src[t];
+    }
+    return o;
+}
+
+template <typename GT, int Q, int NCH>
+__global__ __launch_bounds__(BWD_NT) void kernel_bwd_kernel(const GT* __restrict__ G, int64_t ldg,
+                                                            const float* __restrict__ P1, const float* __restrict__ self1,
+                                                            int n1q, const float* __restrict__ P2,
+                                                            const float* __restrict__ self2, int n2q, int q_rt, int Rr,
+                                                            int Rc, int K4, int DP, int NP, int gvec,
+                                                            const float* __restrict__ hyp, float* __restrict__ slab,
+                                                            float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = BWD_NT, NW = BWD_NW;
+    const int q = Q > 0 ? Q : q_rt, p = q - 1;
+    const int LDP1 = K4 + 1, LDP = NP + 1;
+    const int Tr = Rr * q, Tc = Rc * q;
+    const int Trp = (Tr + 15) & ~15, Tcp = (Tc + 15) & ~15;
+    float* P1s = smem;                      // [Trp][LDP1]
+    float* P2s = P1s + Trp * LDP1;          // [Tcp][LDP]   B operand of both MFMA products
+    float* Ts = P2s + Tcp * LDP;            // [Trp][LDT]
+    float* Gs = Ts + Trp * LDT;             // [Trp][LDT]   Gbar, then Tbar in place
+    float* s1 = Gs + Trp * LDT;             // [Trp]
+    float* s2 = s1 + Trp;                   // [Tcp]
+    float* KK = s2 + Tcp;                   // [Rr][Rc]     k per point pair
+    float* Us = KK + Rr * Rc;               // [Tr][Rc]     u_a = r . v1_a
+    float* Ps = Us + Tr * Rc;               // [Tr][Rc]     per-strip share of kbar
+    float* red = Ps + Tr * Rc;              // [2 NW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntr = Trp / 16, ntc = Tcp / 16, nnp = NP / 16;
+    const int row0 = blockIdx.y * Tr;
+    const int ncoltiles = (n2q + Tc - 1) / Tc;
     const float ell = hyp[0], s = hyp[1];
     const float il = 1.f / ell, il2 = il * il;
-    const int p = q - 1;
-    const float invR = 1.f / (float)R;
+    const float invq = 1.f / (float)q, invRc = 1.f / (float)Rc, invTc = 1.f / (float)Tc;
+    const int gch_row = Tcp / 4;            // 4-wide Gbar chunks per tile row
+    const int pch_row = DP / 4;             // 4-wide chunks per packed row
+    const bool vec = gvec != 0;
+    const bool ppre = Tcp * pch_row <= 2 * NT;      // P2 packs ride in registers too when two chunks per thread cover them
 
-    stage_pack(P1s, s1, P1, self1, row0, T, n1q, Tp, DP, K4, LDP);
+    stage_pack(P1s, s1, P1, self1, row0, Tr, n1q, Trp, DP, K4, LDP1);
+    for (int e = tid; e < Tcp * LDP; e += NT) P2s[e] = 0.f;       // columns [DP, NP) and pad rows stay zero
+    for (int e = tid; e < Trp * LDT; e += NT) Gs[e] = 0.f;
 
-    f4 acc[MAXACC];
+    f4 greg[NCH], preg[2];
+    float s2reg = 0.f;
+    auto prefetch = [&](int ct) {
+        const int col0 = ct * Tc;
 #pragma unroll
-    for (int i = 0; i < MAXACC; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    float sK_sum = 0.f, l_sum = 0.f;
+        for (int i = 0; i < NCH; ++i) {
+            const int e = tid + i * NT;
+            const int r = e / gch_row, c = (e - r * gch_row) * 4;
+            if (BWD_ABLATE & 8) greg[i] = f4{1.f, 1.f, 1.f, 1.f};
+            else greg[i] = load_g4(G, ldg, (int64_t)row0 + r, (int64_t)col0 + c, r, c, Tr, Tc, n1q, n2q, vec);
+        }
+        if (ppre) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * NT;
+                const int r = e / pch_row, k = (e - r * pch_row) * 4;
+                const int gr = col0 + r;
+                preg[i] = (r < Tc && gr < n2q) ? *reinterpret_cast<const f4*>(P2 + (int64_t)gr * DP + k) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        s2reg = (tid < Tc && col0 + tid < n2q) ? self2[col0 + tid] : 0.f;
+    };
 
-    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
-        const int col0 = ct * T;
-        __syncthreads();  // previous iteration's MFMA reads of P2s / Gs are done
-        stage_pack(P2s, s2, P2, self2, col0, T, n2q, Tp, DP, NP, LDP);
-        for (int e = threadIdx.x; e < Tp * Tp; e += 256) {
-            const int r = e / Tp, c = e - r * Tp;
-            const int64_t gr = row0 + r, gc = col0 + c;
-            Gs[r * LDT + c] = (r < T && c < T && gr < n1q && gc < n2q) ? (float)G[gr * ldg + gc] : 0.f;
+    f4 acc[BWD_MAXACC];
+#pragma unroll
+    for (int i = 0; i < BWD_MAXACC; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float sK_sum = 0.f, l_acc = 0.f;
+
+    int ct = blockIdx.x;
+    if (ct < ncoltiles) prefetch(ct);
+    for (; ct < ncoltiles; ct += gridDim.x) {
+        __syncthreads();  // previous iteration's MFMA reads of P2s / Gs are done (first: P1s / zero fill visible)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int e = tid + i * NT;
+            const int r = e / gch_row, c = (e - r * gch_row) * 4;
+            if (r < Trp) *reinterpret_cast<f4*>(Gs + r * LDT + c) = greg[i];
+        }
+        if (ppre) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * NT;
+                const int r = e / pch_row, k = (e - r * pch_row) * 4;
+                if (r < Tcp) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = preg[i][t];
+                }
+            }
+        } else {
+            const int col0 = ct * Tc;
+            for (int e = tid; e < Tcp * DP; e += NT) {
+                const int r = e / DP, k = e - r * DP;
+                P2s[r * LDP + k] = (r < Tc && col0 + r < n2q) ? P2[(int64_t)(col0 + r) * DP + k] : 0.f;
+            }
+        }
+        if (tid < Tcp) s2[tid] = s2reg;
+        if (ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);
+        __syncthreads();
+
+        // T = P1s P2s^T
+        for (int id = wave; id < ntr * ntc && !(BWD_ABLATE & 4); id += NW) {
+            const int tr = id / ntc, tc = id - tr * ntc;
+            f4 t4 = {0.f, 0.f, 0.f, 0.f};
+            const float* pa = P1s + (tr * 16 + (lane & 15)) * LDP1 + (lane >> 4);
+            const float* pb = P2s + (tc * 16 + (lane & 15)) * LDP + (lane >> 4);
+            for (int kk = 0; kk < K4; kk += 4) t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], pb[kk], t4, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ts[(tr * 16 + (lane >> 4) * 4 + r) * LDT + tc * 16 + (lane & 15)] = t4[r];
         }
         __syncthreads();
-        mfma_T(Ts, P1s, P2s, ntr, ntr, K4, LDP);
-        __syncthreads();
 
-        // one thread per (point i, point j) pair: Gbar micro-block -> Tbar micro-block, in place in Gs
-        for (int pid = threadIdx.x; pid < R * R; pid += 256) {
-            const int pi = fdiv_small(pid, invR), pj = pid - pi * R;
+        // ROW pass: task = (tile row r = (point pi, slot a), point column pj)
+        for (int task = tid; task < Tr * Rc && !(BWD_ABLATE & 1); task += NT) {
+            const int r = fdiv_small(task, invRc), pj = task - r * Rc;
+            const int pi = fdiv_small(r, invq), a = r - pi * q;
             const int r0 = pi * q, c0 = pj * q;
-            float* g0 = Gs + r0 * LDT + c0;
-            const float* t0 = Ts + r0 * LDT + c0;
-            const float nn = fmaxf(s1[r0] + s2[c0] - 2.f * t0[0], 0.f);
+            float* gr_ = Gs + r * LDT + c0;
+            const float* tr_ = Ts + r * LDT + c0;
+            const float* t0_ = Ts + r0 * LDT + c0;
+            const float* s2_ = s2 + c0;
+            const float nn = fmaxf(s1[r0] + s2_[0] - 2.f * t0_[0], 0.f);
             const float k = s * expf(-0.5f * nn);
-            const float g00 = g0[0];
-            float kbar = g00, e1 = 0.f, e2 = 0.f, dotw = 0.f, dotu = 0.f;
-            for (int b = 1; b <= p; ++b) {
-                const float w = t0[b] - s2[c0 + b];
-                const float g = g0[b];
-                kbar += g * w * il;
-                e1 += g * w * k * il;
-            }
-            for (int a = 1; a <= p; ++a) {
-                const float u = s1[r0 + a] - t0[a * LDT];
-                const float ga = g0[a * LDT];
-                kbar -= ga * u * il;
-                e1 -= ga * u * k * il;
-                float accu = -ga * il;
-                for (int b = 1; b <= p; ++b) {
-                    const float w = t0[b] - s2[c0 + b];
-                    const float gab = g0[a * LDT + b];
-                    const float h = (t0[a * LDT + b] - u * w) * il2;
-                    kbar += gab * h;
-                    e2 += gab * h * k;
-                    accu -= gab * w * il2;
-                    g0[a * LDT + b] = k * gab * il2;          // Tbar_ab
+            if constexpr (Q > 0) {
+                // all LDS reads first (Gs / Ts may alias for the compiler), then the in-place stores
+                float gv[Q], tv[Q], t0v[Q], s2v[Q];
+#pragma unroll
+                for (int b = 0; b < Q; ++b) { gv[b] = gr_[b]; tv[b] = tr_[b]; t0v[b] = t0_[b]; s2v[b] = s2_[b]; }
+                const float g0 = gv[0];
+                if (a == 0) {
+                    float first = 0.f;
+#pragma unroll
+                    for (int b = 1; b < Q; ++b) first = __builtin_fmaf(gv[b], t0v[b] - s2v[b], first);
+                    first *= il;
+                    Ps[task] = g0 + first;
+                    KK[pi * Rc + pj] = k;
+                    l_acc = __builtin_fmaf(k, first, l_acc);                  // first-order entries of <Gbar, K>
+                } else {
+                    const float u = s1[r] - tv[0];
+                    float hs = 0.f, gw = 0.f;
+                    const float kil2 = k * il2;
+#pragma unroll
+                    for (int b = 1; b < Q; ++b) {
+                        const float w = t0v[b] - s2v[b];
+                        hs = __builtin_fmaf(gv[b], tv[b] - u * w, hs);
+                        gw = __builtin_fmaf(gv[b], w, gw);
+                        gr_[b] = kil2 * gv[b];                                // Tbar_ab
+                    }
+                    hs *= il2;
+                    const float ubar = k * (-g0 * il - gw * il2);
+                    gr_[0] = -ubar;                                           // Tbar_a0
+                    Us[task] = u;
+                    Ps[task] = hs - g0 * u * il;
+                    l_acc += k * (2.f * hs - g0 * u * il) + ubar * u;
                 }
-                const float ubar = k * accu;
-                g0[a * LDT] = -ubar;                            // Tbar_a0
-                dotu += ubar * u;
-            }
-            for (int b = 1; b <= p; ++b) {
-                const float w = t0[b] - s2[c0 + b];
-                float wbar = g0[b] * il * k;
-                for (int a = 1; a <= p; ++a) {
-                    const float u = s1[r0 + a] - t0[a * LDT];
-                    wbar -= g0[a * LDT + b] * u;                // Tbar_ab * u_a
+            } else {
+                const float g0 = gr_[0];
+                if (a == 0) {
+                    float first = 0.f;
+                    for (int b = 1; b <= p; ++b) first = __builtin_fmaf(gr_[b], t0_[b] - s2_[b], first);
+                    first *= il;
+                    Ps[task] = g0 + first;
+                    KK[pi * Rc + pj] = k;
+                    l_acc = __builtin_fmaf(k, first, l_acc);
+                } else {
+                    const float u = s1[r] - tr_[0];
+                    float hs = 0.f, gw = 0.f;
+                    const float kil2 = k * il2;
+                    for (int b = 1; b <= p; ++b) {
+                        const float w = t0_[b] - s2_[b];
+                        const float g = gr_[b];
+                        hs = __builtin_fmaf(g, tr_[b] - u * w, hs);
+                        gw = __builtin_fmaf(g, w, gw);
+                        gr_[b] = kil2 * g;
+                    }
+                    hs *= il2;
+                    const float ubar = k * (-g0 * il - gw * il2);
+                    gr_[0] = -ubar;
+                    Us[task] = u;
+                    Ps[task] = hs - g0 * u * il;
+                    l_acc += k * (2.f * hs - g0 * u * il) + ubar * u;
                 }
-                g0[b] = wbar;                                   // Tbar_0b
-                dotw += wbar * w;
             }
-            const float nbar = -0.5f * k * kbar;
-            g0[0] = k * kbar;                                   // Tbar_00 = -2 nbar
-            sK_sum += g00 * k + e1 + e2;
-            l_sum -= (e1 + 2.f * e2 + 2.f * nbar * nn + dotw + dotu) * il;
         }
         __syncthreads();
 
-        // dP1[Tp, NP] += Tbar[Tp, Tp] . P2ext[Tp, NP]   (A from Gs, B from P2s)
+        // COLUMN pass: task = (point row pi, tile column c = (point pj, slot b))
+        for (int task = tid; task < Rr * Tc && !(BWD_ABLATE & 1); task += NT) {
+            const int pi = fdiv_small(task, invTc), c = task - pi * Tc;
+            const int pj = fdiv_small(c, invq), b = c - pj * q;
+            const int r0 = pi * q;
+            const float k = KK[pi * Rc + pj];
+            float* g0c = Gs + r0 * LDT + c;
+            if (b == 0) {
+                float kbar = 0.f;
 #pragma unroll
-        for (int si = 0; si < MAXACC; ++si) {
-            const int id = wave + 4 * si;
-            if (id < ntr * nnp) {
+                for (int a = 0; a <= p; ++a) kbar += Ps[(r0 + a) * Rc + pj];
+                const float t00 = k * kbar;                                   // Tbar_00 = <Gbar, K> of the micro-block
+                const float nn = fmaxf(s1[r0] + s2[c] - 2.f * Ts[r0 * LDT + c], 0.f);
+                *g0c = t00;
+                sK_sum += t00;
+                l_acc = __builtin_fmaf(-t00, nn, l_acc);
+            } else {
+                const float w = Ts[r0 * LDT + c] - s2[c];
+                float wbar = k * il * *g0c;
+#pragma unroll
+                for (int a = 1; a <= p; ++a) wbar = __builtin_fmaf(-g0c[a * LDT], Us[(r0 + a) * Rc + pj], wbar);
+                *g0c = wbar;                                                  // Tbar_0b
+                l_acc = __builtin_fmaf(wbar, w, l_acc);
+            }
+        }
+        __syncthreads();
+
+        // dP1[Trp, NP] += Tbar[Trp, Tcp] . P2ext[Tcp, NP]   (A from Gs, B from P2s)
+#pragma unroll
+        for (int si = 0; si < BWD_MAXACC; ++si) {
+            const int id = wave + NW * si;
+            if (id < ntr * nnp && !(BWD_ABLATE & 2)) {
                 const int tr = id / nnp, tn = id - tr * nnp;
                 const float* pa = Gs + (tr * 16 + (lane & 15)) * LDT + (lane >> 4);
                 const float* pb = P2s + (lane >> 4) * LDP + tn * 16 + (lane & 15);
-                f4 c = acc[si];
-                for (int kk = 0; kk < Tp; kk += 4) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], pb[kk * LDP], c, 0, 0, 0);
-                acc[si] = c;
+                f4 c4 = acc[si];
+                for (int kk = 0; kk < Tcp; kk += 4) c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], pb[kk * LDP], c4, 0, 0, 0);
+                acc[si] = c4;
             }
         }
     }
@@ -318,19 +478,20 @@ __global__ __launch_bounds__(256) void kernel_bwd_kernel(const GT* __restrict__ 
     // partial slab: slab[split][row][NP]
     float* myslab = slab + ((int64_t)blockIdx.x * n1q) * NP;
 #pragma unroll
-    for (int si = 0; si < MAXACC; ++si) {
-        const int id = wave + 4 * si;
+    for (int si = 0; si < BWD_MAXACC; ++si) {
+        const int id = wave + NW * si;
         if (id < ntr * nnp) {
             const int tr = id / nnp, tn = id - tr * nnp;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = tr * 16 + (lane >> 4) * 4 + r;
                 const int64_t gr = row0 + rr;
-                if (rr < T && gr < n1q) myslab[gr * NP + tn * 16 + (lane & 15)] = acc[si][r];
+                if (rr < Tr && gr < n1q) myslab[gr * NP + tn * 16 + (lane & 15)] = acc[si][r];
             }
         }
     }
     // block reduce the two scalars
+    float l_sum = -il * l_acc;
     for (int off = 32; off > 0; off >>= 1) {
         sK_sum += __shfl_down(sK_sum, off);
         l_sum += __shfl_down(l_sum, off);
@@ -338,10 +499,12 @@ __global__ __launch_bounds__(256) void kernel_bwd_kernel(const GT* __restrict__ 
     __syncthreads();
     if (lane == 0) { red[wave * 2] = sK_sum; red[wave * 2 + 1] = l_sum; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int w = 0; w < NW; ++w) { a0 += red[2 * w]; a1 += red[2 * w + 1]; }
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-        partials[bid * 2] = red[0] + red[2] + red[4] + red[6];
-        partials[bid * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+        partials[bid * 2] = a0;
+        partials[bid * 2 + 1] = a1;
     }
 }
 
@@ -408,24 +571,45 @@ __global__ void kernel_bwd_scalars_kernel(const float* __restrict__ partials, in
     }
 }
 
-struct Geom { int q, R, T, K4, DP, NP; };
+struct Geom { int q, R, T, K4, DP, NP, Rr, Tr; };
 inline int make_geom(int d, int p, Geom& g) {
     g.q = p + 1;
     if (d < 1 || p < 0 || g.q > TMAX) return DSVGP_EINVAL;
     g.R = TMAX / g.q;
     g.T = g.R * g.q;
+    g.Rr = g.R >= 2 ? g.R / 2 : g.R;       // row tiles hold half as many points as column tiles
+    g.Tr = g.Rr * g.q;
     g.K4 = (d + 3) & ~3;
     g.DP = g.K4 + 4;
     g.NP = (g.DP + 15) & ~15;
-    if (6 * (g.NP / 16) > 4 * MAXACC) return DSVGP_EINVAL;   // d <= 88
+    if (g.NP > 96) return DSVGP_EINVAL;   // d <= 88
     return 0;
 }
 inline int bwd_nsplit(int n1, int n2, const Geom& g) {
-    const int rt = cdiv((int64_t)n1 * g.q, g.T), ctiles = cdiv((int64_t)n2 * g.q, g.T);
-    int ns = 1024 / rt;
+    const int rt = cdiv((int64_t)n1 * g.q, g.Tr), ctiles = cdiv((int64_t)n2 * g.q, g.T);
+    int ns = BWD_TARGET_WGS / rt;
     if (ns < 1) ns = 1;
     if (ns > ctiles) ns = ctiles;
     return ns;
+}
+
+template <typename GT, int Q, int NCH>
+inline void launch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int64_t ldg, const float* P1,
+                       const float* self1, int n1q, const float* P2, const float* self2, int n2q, const Geom& g,
+                       int gvec, const float* hyp, float* slab, float* partials) {
+    (void)hipFuncSetAttribute((const void*)kernel_bwd_kernel<GT, Q, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((kernel_bwd_kernel<GT, Q, NCH>), grid, dim3(BWD_NT), lds, st, G, ldg, P1, self1, n1q, P2, self2,
+                       n2q, g.q, g.Rr, g.R, g.K4, g.DP, g.NP, gvec, hyp, slab, partials);
+}
+template <typename GT>
+inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int64_t ldg, const float* P1,
+                         const float* self1, int n1q, const float* P2, const float* self2, int n2q, const Geom& g,
+                         int gvec, const float* hyp, float* slab, float* partials) {
+    const int Trp = (g.Tr + 15) & ~15;
+    if (Trp > 48) launch_bwd<GT, 0, BWD_GCH_MAX>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
+    else if (g.q == 6) launch_bwd<GT, 6, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
+    else if (g.q == 3) launch_bwd<GT, 3, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
+    else launch_bwd<GT, 0, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
 }
 
 }  // namespace
@@ -483,7 +667,7 @@ extern "C" size_t dsvgp_kernel_bwd_workspace_bytes(int n1, int n2, int d, int p)
     Geom g;
     if (make_geom(d, p, g) || n1 <= 0 || n2 <= 0) return 0;
     const int ns = bwd_nsplit(n1, n2, g);
-    const int rt = cdiv((int64_t)n1 * g.q, g.T);
+    const int rt = cdiv((int64_t)n1 * g.q, g.Tr);
     return sizeof(float) * ((size_t)ns * n1 * g.q * g.NP + (size_t)2 * ns * rt + 64);
 }
 
@@ -499,20 +683,19 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     const int n1q = n1 * g.q, n2q = n2 * g.q;
     if (ldg < n2q) return DSVGP_EINVAL;
     const int ns = bwd_nsplit(n1, n2, g);
-    const int rt = cdiv(n1q, g.T);
+    const int rt = cdiv(n1q, g.Tr);
     float* slab = (float*)workspace;
     float* partials = slab + (size_t)ns * n1q * g.NP;
-    const size_t lds = sizeof(float) * (2 * TMAX * (g.NP + 1) + 2 * TMAX * LDT + 2 * TMAX + 8);
+    const int Trp = (g.Tr + 15) & ~15, Tcp = (g.T + 15) & ~15;
+    const size_t lds = sizeof(float) * ((size_t)Trp * (g.K4 + 1) + (size_t)Tcp * (g.NP + 1) + 2 * (size_t)Trp * LDT + Trp + Tcp +
+                                        (size_t)g.Rr * g.R + 2 * (size_t)g.Tr * g.R + 2 * BWD_NW);
+    // 4-wide loads of the upstream tile need 4-element aligned tile origins and rows
+    const int gvec = (g.T % 4 == 0) && (ldg % 4 == 0) && ((uintptr_t)G % 32 == 0);
     dim3 grid(ns, rt);
-    if (g_is_double) {
-        (void)hipFuncSetAttribute((const void*)kernel_bwd_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel_bwd_kernel<double>, grid, dim3(256), lds, ctx->stream, (const double*)G, ldg, P1, self1,
-                           n1q, P2, self2, n2q, g.q, g.R, g.K4, g.DP, g.NP, hyp, slab, partials);
-    } else {
-        (void)hipFuncSetAttribute((const void*)kernel_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel_bwd_kernel<float>, grid, dim3(256), lds, ctx->stream, (const float*)G, ldg, P1, self1,
-                           n1q, P2, self2, n2q, g.q, g.R, g.K4, g.DP, g.NP, hyp, slab, partials);
-    }
+    if (g_is_double)
+        dispatch_bwd<double>(ctx->stream, grid, lds, (const double*)G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
+    else
+        dispatch_bwd<float>(ctx->stream, grid, lds, (const float*)G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
     DSVGP_LAUNCH_CHECK();
     const float sym = symmetric ? 2.f : 1.f;
     hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64), sizeof(float) * (g.q * g.DP + g.q + 1), ctx->stream,

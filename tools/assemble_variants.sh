@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/assemble_variants.sh "name:-DFLAG=.." ...   (builds variants of assemble.hip on the GPU box and times them)
+# usage: [PROBE=assemble_bwd_probe.py PROBE_LINES=2] tools/assemble_variants.sh "name:-DFLAG=.." ...   (builds variants of assemble.hip on the GPU box and times them)
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 C=$R/gp-derivatives-variational-inference_amd/csrc
@@ -11,5 +11,5 @@ for spec in "$@"; do
   mkdir -p $B/$name
   hipcc $FL $defs -c $C/assemble.hip -o $B/$name/assemble.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o $B/$name/libdsvgp_hip.so $B/$name/assemble.o $B/gemm.o $B/elbo.o $B/potrf.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
-  DSVGP_LIB_PATH=$B/$name/libdsvgp_hip.so python $R/tools/assemble_probe.py 2>&1 | tail -1
+  DSVGP_LIB_PATH=$B/$name/libdsvgp_hip.so python $R/tools/${PROBE:-assemble_probe.py} 2>&1 | tail -${PROBE_LINES:-1}
 done
