@@ -48,8 +48,10 @@ class RBFKernelDirectionalGrad(torch.nn.Module):
         ctx = _ops.Context.get(x1.device)
         hyp = self._hyp(x1.device)
         if not diag:
-            p1 = _ops.pack_points(ctx, x1.float().contiguous(), v1.float().contiguous(), n_dir1, hyp)
-            p2 = _ops.pack_points(ctx, x2.float().contiguous(), v2.float().contiguous(), n_dir2, hyp)
+            x1c = x1.float().contiguous()
+            center = _ops.column_mean(ctx, x1c)         # covar_dist's `adjustment = x1.mean(-2)` [gpytorch 1.4.0]
+            p1 = _ops.pack_points(ctx, x1c, v1.float().contiguous(), n_dir1, hyp, center)
+            p2 = _ops.pack_points(ctx, x2.float().contiguous(), v2.float().contiguous(), n_dir2, hyp, center)
             return _ops.kernel_fwd(ctx, p1, n1, p2, n2, d, n_dir1, hyp)
         if not (n1 == n2 and torch.eq(x1, x2).all() and n_dir1 == n_dir2 and torch.eq(v1, v2).all()):
             raise RuntimeError("diag=True only works when x1 == x2 and v1 == v2")

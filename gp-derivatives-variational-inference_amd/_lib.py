@@ -36,7 +36,8 @@ SIGNATURES = {
     "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_packed_width": (_i, [_i]),
-    "dsvgp_pack_points": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "dsvgp_column_mean": (_i, [_p, _p, _i, _i, _p]),
+    "dsvgp_pack_points": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dsvgp_kernel_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _f, _p, _l, _i]),
     "dsvgp_kernel_diag": (_i, [_p, _i, _i, _p, _p]),
     "dsvgp_kernel_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),

@@ -84,10 +84,25 @@ def hyp_backward(ctx, raw_l, raw_s, raw_n, d_hyp, d_raw_l, d_raw_s, d_raw_n):
                                  _ptr(d_raw_s), _ptr(d_raw_n)), "dsvgp_hyp_backward")
 
 
-def pack_points(ctx, x, v, p, hyp):
-    """-> (P[n(p+1), DP], self[n(p+1)], vnorm[n p])"""
+def column_mean(ctx, x):
+    """Column means of x[n, d]: the common shift ``center`` of the two point sets of one kernel call."""
+    _req(x, f32, "x", 2)
+    if not x.is_contiguous():
+        raise ValueError("x must be contiguous")
+    out = torch.empty(x.shape[1], dtype=f32, device=x.device)
+    check(lib.dsvgp_column_mean(ctx.h, _ptr(x), x.shape[0], x.shape[1], _ptr(out)), "dsvgp_column_mean")
+    return out
+
+
+def pack_points(ctx, x, v, p, hyp, center=None):
+    """-> (P[n(p+1), DP], self[n(p+1)], vnorm[n p]).  ``center`` [d]: shift subtracted from x (same for both
+    operands of a kernel call)."""
     _req(x, f32, "x", 2)
     n, d = x.shape
+    if center is not None:
+        _req(center, f32, "center", 1)
+        if center.shape != (d,):
+            raise ValueError("center must have shape [%d]" % d)
     if p > 0:
         _req(v, f32, "v", 2)
         if v.shape != (n * p, d):
@@ -98,8 +113,8 @@ def pack_points(ctx, x, v, p, hyp):
     P = torch.empty(n * (p + 1), DP, dtype=f32, device=x.device)
     sf = torch.empty(n * (p + 1), dtype=f32, device=x.device)
     vn = torch.empty(max(n * p, 1), dtype=f32, device=x.device)
-    check(lib.dsvgp_pack_points(ctx.h, _ptr(x), _ptr(v if p > 0 else None), n, d, p, _ptr(hyp), _ptr(P), _ptr(sf),
-                                _ptr(vn)), "dsvgp_pack_points")
+    check(lib.dsvgp_pack_points(ctx.h, _ptr(x), _ptr(v if p > 0 else None), n, d, p, _ptr(hyp), _ptr(center), _ptr(P),
+                                _ptr(sf), _ptr(vn)), "dsvgp_pack_points")
     return P, sf, vn
 
 

@@ -73,7 +73,9 @@ class ElboEngine:
         p = V.shape[0] // M if M else 0
         Mp = M * (p + 1)
         hyp = _ops.hyp_forward(ctx, params["raw_lengthscale"], params["raw_outputscale"], params["raw_noise"])
-        packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp)
+        # common shift of Z and x (gpytorch covar_dist centres on x1.mean): keeps the fp32 quadratic expansion accurate
+        self.center = _ops.column_mean(ctx, Z.contiguous())
+        packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp, self.center)
         L = self._get("L", (Mp, Mp), f64)
         info = self._get("info", (1,), torch.int32)
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
@@ -98,7 +100,7 @@ class ElboEngine:
         M, d, p, Mp = dims
         B = x.shape[0]
         Bp = B * (p + 1)
-        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp)
+        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
         Kzx = self._get("Kzx", (Mp, Bp), f32)
         _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
         A64 = self._get("A64", (Mp, Bp), f64)
@@ -248,7 +250,7 @@ class ElboEngine:
         dev = self.device
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
-        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp)
+        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
         Kzx = self._get("Kzx", (Mp, Bp), f32)
         _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
         A64 = self._get("A64", (Mp, Bp), f64)

@@ -1,7 +1,9 @@
 // Block-kernel assembly for RBFKernelDirectionalGrad (reference
 // directionalvi/RBFKernelDirectionalGrad.py:41-119) and its backward, gfx950.
 //
-// Formulation.  For every point pack the (p+1) rows  [x/ell ; v_1 ; ... ; v_p]  (unit directions)
+// Formulation.  For every point pack the (p+1) rows  [(x-c)/ell ; v_1 ; ... ; v_p]  (unit directions; c = a
+// common shift of both point sets, the column mean of side 1 like gpytorch's covar_dist adjustment, which
+// keeps the quadratic expansion below well conditioned -- the kernel only sees differences)
 // into P[n(p+1), DP].  Then T = P1 P2^T is ALREADY laid out like the interleaved kernel matrix and
 // holds every inner product the four block types need:
 //     T[i0,j0] = x1~.x2~      T[i0,jb] = x1~.v2_b      T[ia,j0] = v1_a.x2~      T[ia,jb] = v1_a.v2_b
@@ -31,8 +33,26 @@ using f4 = float __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int fdiv_small(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
 
 // ---- pack -------------------------------------------------------------------------------------
+// column means of x[n, d] (one block, one column per thread slot): the common shift of both point sets
+__global__ void column_mean_kernel(const float* __restrict__ x, int n, int d, float* __restrict__ out) {
+    __shared__ double part[256];
+    for (int k = 0; k < d; ++k) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) acc += x[(int64_t)i * d + k];
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = (float)(part[0] / (double)n);
+        __syncthreads();
+    }
+}
+
 __global__ void pack_points_kernel(const float* __restrict__ x, const float* __restrict__ v, int n, int d,
-                                   int p, const float* __restrict__ hyp, float* __restrict__ P,
+                                   int p, const float* __restrict__ hyp, const float* __restrict__ center,
+                                   float* __restrict__ P,
                                    float* __restrict__ self, float* __restrict__ vnorm, int K4, int DP) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     const int q = p + 1;
@@ -44,7 +64,7 @@ __global__ void pack_points_kernel(const float* __restrict__ x, const float* __r
     if (a == 0) {
         float acc = 0.f;
         for (int k = 0; k < d; ++k) {
-            const float xt = xi[k] / ell;          // x.div(lengthscale), :67-68
+            const float xt = (xi[k] - (center ? center[k] : 0.f)) / ell;   // x.div(lengthscale), :67-68
             Pr[k] = xt;
             acc = __builtin_fmaf(xt, xt, acc);
         }
@@ -60,7 +80,7 @@ __global__ void pack_points_kernel(const float* __restrict__ x, const float* __r
         for (int k = 0; k < d; ++k) {
             const float vh = vi[k] / nrm;
             Pr[k] = vh;
-            acc = __builtin_fmaf(vh, xi[k] / ell, acc);
+            acc = __builtin_fmaf(vh, (xi[k] - (center ? center[k] : 0.f)) / ell, acc);
         }
         for (int k = d; k < DP; ++k) Pr[k] = 0.f;
         self[row] = acc;
@@ -508,6 +528,273 @@ __global__ __launch_bounds__(BWD_NT) void kernel_bwd_kernel(const GT* __restrict
     }
 }
 
+// ---- backward, register-resident variant for small compile-time q ------------------------------------------
+// ONE WAVE per workgroup (no barriers): the wave owns R = 48/Q points of side 1 (T = R Q <= 48 rows) and sweeps
+// 48-column tiles.  Lane <-> point pair(s): the Q x Q micro-block of Gbar comes straight from HBM into registers,
+// T' = P1' P2'^T comes from MFMA through LDS, the whole micro-block transform runs in registers and Tbar goes back
+// to LDS in place as the A operand of dP1 += Tbar P2ext.  Two extra packed columns fold the self terms into T':
+//   P1'[r, K4+1] = [a == 0],  P2'[c, K4+1] = -self2[c]      =>  T'[r0, cb] = x1~.v2_b - beta_b = w_b
+//   P1'[r, K4+2] = -self1[r] [a > 0],  P2'[c, K4+2] = [b == 0]  =>  T'[ra, c0] = v1_a.x2~ - alpha_a = -u_a
+// so the transform reads nothing but its own 36 T' values.  ~21 KB of LDS per wave: 7 waves per CU hide each
+// other's LDS / HBM latency.
+constexpr int PAIR_LDT = 52;     // LDS row stride of the 48 x 48 T' / Tbar tile (even: 8-byte strips)
+#ifndef PAIR_WGS_
+#define PAIR_WGS_ (256 * 7)
+#endif
+#ifndef PAIR_ABLATE
+#define PAIR_ABLATE 0      // tools only: bit 0 = no transform, bit 1 = no dP1 MFMA, bit 2 = no T' MFMA, bit 3 = no Gbar loads
+#endif
+constexpr int PAIR_WGS = PAIR_WGS_;
+
+template <typename GT, int Q>
+__global__ __launch_bounds__(64) void kernel_bwd_pair_kernel(const GT* __restrict__ G, int64_t ldg,
+                                                             const float* __restrict__ P1, const float* __restrict__ self1,
+                                                             int n1q, const float* __restrict__ P2,
+                                                             const float* __restrict__ self2, int n2q, int K4, int DP,
+                                                             int NP, int gvec, const float* __restrict__ hyp,
+                                                             float* __restrict__ slab, float* __restrict__ partials) {
+    constexpr int R = 48 / Q, T = R * Q;
+    constexpr int NPAIR = R * R, PPL = (NPAIR + 63) / 64;      // point pairs per lane
+    constexpr int LDT2 = PAIR_LDT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP1 = K4 + 5, LDP = NP + 1;
+    float* P1s = smem;                  // [48][LDP1]  extended side-1 packs (fixed over the sweep)
+    float* P2s = P1s + 48 * LDP1;       // [48][LDP]   extended side-2 packs of the current tile
+    float* TT = P2s + 48 * LDP;         // [48][LDT2]  T', then Tbar in place
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * T;
+    const int ncoltiles = (n2q + T - 1) / T;
+    const int nnp = NP / 16;            // 1 or 2
+    const int KS = K4 / 4 + 1;
+    const int pch = DP / 4;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+    const bool vec = gvec != 0;
+
+    for (int e = lane; e < 48 * LDP1; e += 64) P1s[e] = 0.f;
+    for (int e = lane; e < 48 * LDP; e += 64) P2s[e] = 0.f;
+    __syncthreads();
+    for (int e = lane; e < T * K4; e += 64) {
+        const int r = e / K4, k = e - r * K4;
+        if (row0 + r < n1q) P1s[r * LDP1 + k] = P1[(int64_t)(row0 + r) * DP + k];
+    }
+    if (lane < T && row0 + lane < n1q) {
+        const int a = lane % Q;
+        P1s[lane * LDP1 + K4 + 1] = a == 0 ? 1.f : 0.f;
+        P1s[lane * LDP1 + K4 + 2] = a == 0 ? 0.f : -self1[row0 + lane];
+    }
+
+    // lane-invariant pair geometry
+    int pr0[PPL], pc0[PPL];
+    float s1r0[PPL];
+    bool prow[PPL];
+#pragma unroll
+    for (int pp = 0; pp < PPL; ++pp) {
+        const int pid = lane + 64 * pp;
+        const int pi = pid / R, pj = pid - pi * R;
+        pr0[pp] = pi * Q; pc0[pp] = pj * Q;
+        prow[pp] = pid < NPAIR && row0 + pr0[pp] < n1q;
+        s1r0[pp] = prow[pp] ? self1[row0 + pr0[pp]] : 0.f;
+    }
+
+    f4 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc[i][0] = f4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f4{0.f, 0.f, 0.f, 0.f}; }
+    float sK_sum = 0.f, l_acc = 0.f;
+
+    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
+        const int col0 = ct * T;
+        // upstream micro-blocks straight into registers (consumed after the T' product)
+        float g[PPL][Q][Q];
+        float s2c0[PPL];
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            const bool ok = prow[pp] && col0 + pc0[pp] < n2q && !(PAIR_ABLATE & 8);
+            const GT* src = G + (int64_t)(row0 + pr0[pp]) * ldg + col0 + pc0[pp];
+            s2c0[pp] = ok ? self2[col0 + pc0[pp]] : 0.f;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                if constexpr (Q % 2 == 0) {
+                    if (ok && vec) {
+                        using V2 = GT __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) {
+                            const V2 v = *reinterpret_cast<const V2*>(src + a * ldg + b);
+                            g[pp][a][b] = (float)v[0]; g[pp][a][b + 1] = (float)v[1];
+                        }
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < Q; ++b) g[pp][a][b] = ok ? (float)src[a * ldg + b] : 0.f;
+            }
+        }
+        __syncthreads();   // (single wave: orders the previous tile's MFMA reads of P2s / TT before the new stores)
+        for (int e = lane; e < T * pch; e += 64) {
+            const int r = e / pch, k = (e - r * pch) * 4;
+            const int gr = col0 + r;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < n2q) v = *reinterpret_cast<const f4*>(P2 + (int64_t)gr * DP + k);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = v[t];
+        }
+        __syncthreads();   // the extension columns go on top of the packed zeros
+        if (lane < T) {
+            const int gr = col0 + lane;
+            const bool ok = gr < n2q;
+            P2s[lane * LDP + K4 + 1] = ok ? -self2[gr] : 0.f;
+            P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
+        }
+        __syncthreads();
+
+        // T' = P1' P2'^T : 3 x 3 tiles of 16 x 16, K = K4 + 4
+        if (!(PAIR_ABLATE & 4)) {
+            f4 t[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+            const float* pa = P1s + m16 * LDP1 + kg;
+            const float* pb = P2s + m16 * LDP + kg;
+            for (int ks = 0; ks < KS; ++ks) {
+                float av[3], bv[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { av[i] = pa[i * 16 * LDP1 + ks * 4]; bv[i] = pb[i * 16 * LDP + ks * 4]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
+        }
+        __syncthreads();
+
+        // micro-block transform in registers
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            if (lane + 64 * pp < NPAIR && !(PAIR_ABLATE & 1)) {
+                float* blk = TT + pr0[pp] * LDT2 + pc0[pp];
+                float tq[Q][Q];
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    if constexpr (Q % 2 == 0) {
+                        using F2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) {
+                            const F2 v = *reinterpret_cast<const F2*>(blk + a * LDT2 + b);
+                            tq[a][b] = v[0]; tq[a][b + 1] = v[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) tq[a][b] = blk[a * LDT2 + b];
+                    }
+                }
+                const float nn = fmaxf(s1r0[pp] - s2c0[pp] - 2.f * tq[0][0], 0.f);
+                const float k = s * expf(-0.5f * nn);
+                const float kil = k * il, kil2 = k * il2;
+                float first = 0.f, second = 0.f, hsum = 0.f, dots = 0.f;
+                float gu[Q];
+#pragma unroll
+                for (int b = 0; b < Q; ++b) gu[b] = 0.f;
+                float out[Q][Q];
+#pragma unroll
+                for (int b = 1; b < Q; ++b) first = __builtin_fmaf(g[pp][0][b], tq[0][b], first);        // sum g0b w_b
+#pragma unroll
+                for (int a = 1; a < Q; ++a) {
+                    const float u = -tq[a][0];
+                    const float ga0 = g[pp][a][0];
+                    float gw = 0.f, gt = 0.f;
+#pragma unroll
+                    for (int b = 1; b < Q; ++b) {
+                        const float gab = g[pp][a][b];
+                        gw = __builtin_fmaf(gab, tq[0][b], gw);
+                        gt = __builtin_fmaf(gab, tq[a][b], gt);
+                        gu[b] = __builtin_fmaf(gab, u, gu[b]);
+                        out[a][b] = kil2 * gab;                                                        // Tbar_ab
+                    }
+                    second = __builtin_fmaf(ga0, u, second);
+                    hsum += gt - u * gw;
+                    const float ubar = -(kil * ga0 + kil2 * gw);
+                    out[a][0] = -ubar;                                                                 // Tbar_a0
+                    dots = __builtin_fmaf(ubar, u, dots);
+                }
+                out[0][0] = 0.f;
+#pragma unroll
+                for (int b = 1; b < Q; ++b) {
+                    const float wbar = kil * g[pp][0][b] - kil2 * gu[b];
+                    out[0][b] = wbar;                                                                  // Tbar_0b
+                    dots = __builtin_fmaf(wbar, tq[0][b], dots);
+                }
+                const float e1 = il * (first - second), e2 = il2 * hsum;
+                const float t00 = k * (g[pp][0][0] + e1 + e2);                                         // Tbar_00
+                out[0][0] = t00;
+                sK_sum += t00;
+                l_acc += k * (e1 + 2.f * e2) - t00 * nn + dots;
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    if constexpr (Q % 2 == 0) {
+                        using F2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) *reinterpret_cast<F2*>(blk + a * LDT2 + b) = F2{out[a][b], out[a][b + 1]};
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) blk[a * LDT2 + b] = out[a][b];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // dP1[48, NP] += Tbar[48, 48] . P2ext[48, NP]
+        if (!(PAIR_ABLATE & 2)) {
+            const float* pa = TT + m16 * LDT2 + kg;
+            const float* pb = P2s + kg * LDP + m16;
+#pragma unroll
+            for (int kk = 0; kk < 48; kk += 4) {
+                float av[3], bv[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) av[i] = pa[i * 16 * LDT2 + kk];
+                bv[0] = pb[kk * LDP];
+                bv[1] = nnp > 1 ? pb[kk * LDP + 16] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[0], acc[i][0], 0, 0, 0);
+                    if (nnp > 1) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[1], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* myslab = slab + ((int64_t)blockIdx.x * n1q) * NP;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < nnp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = i * 16 + kg * 4 + r;
+                    const int64_t gr = row0 + rr;
+                    if (rr < T && gr < n1q) myslab[gr * NP + j * 16 + m16] = acc[i][j][r];
+                }
+            }
+    float l_sum = -il * l_acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        sK_sum += __shfl_down(sK_sum, off);
+        l_sum += __shfl_down(l_sum, off);
+    }
+    if (lane == 0) {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        partials[bid * 2] = sK_sum;
+        partials[bid * 2 + 1] = l_sum;
+    }
+}
+
 // one 64-thread block per point: slabs -> d_x1, d_v1 (through the x/ell scaling and the direction normalisation)
 __global__ __launch_bounds__(64) void kernel_bwd_points_kernel(const float* __restrict__ slab, int nsplit,
                                                                const float* __restrict__ P1,
@@ -585,9 +872,17 @@ inline int make_geom(int d, int p, Geom& g) {
     if (g.NP > 96) return DSVGP_EINVAL;   // d <= 88
     return 0;
 }
+inline bool bwd_use_pair(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 32; }
+// row-tile height / column-tile width / workgroup budget of the backward variant that will run
+inline void bwd_tiles(const Geom& g, int& tr, int& tc, int& wgs) {
+    if (bwd_use_pair(g)) { tr = tc = (48 / g.q) * g.q; wgs = PAIR_WGS; }
+    else { tr = g.Tr; tc = g.T; wgs = BWD_TARGET_WGS; }
+}
 inline int bwd_nsplit(int n1, int n2, const Geom& g) {
-    const int rt = cdiv((int64_t)n1 * g.q, g.Tr), ctiles = cdiv((int64_t)n2 * g.q, g.T);
-    int ns = BWD_TARGET_WGS / rt;
+    int tr, tc, wgs;
+    bwd_tiles(g, tr, tc, wgs);
+    const int rt = cdiv((int64_t)n1 * g.q, tr), ctiles = cdiv((int64_t)n2 * g.q, tc);
+    int ns = wgs / rt;
     if (ns < 1) ns = 1;
     if (ns > ctiles) ns = ctiles;
     return ns;
@@ -607,8 +902,7 @@ inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int
                          int gvec, const float* hyp, float* slab, float* partials) {
     const int Trp = (g.Tr + 15) & ~15;
     if (Trp > 48) launch_bwd<GT, 0, BWD_GCH_MAX>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
-    else if (g.q == 6) launch_bwd<GT, 6, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
-    else if (g.q == 3) launch_bwd<GT, 3, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
+    else if (g.q == 4) launch_bwd<GT, 4, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
     else launch_bwd<GT, 0, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
 }
 
@@ -616,15 +910,22 @@ inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int
 
 extern "C" int dsvgp_packed_width(int d) { return ((d + 3) & ~3) + 4; }
 
+extern "C" int dsvgp_column_mean(dsvgp_ctx* ctx, const float* x, int n, int d, float* out) {
+    if (!ctx || !x || !out || n < 1 || d < 1) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(column_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, x, n, d, out);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dsvgp_pack_points(dsvgp_ctx* ctx, const float* x, const float* v, int n, int d, int p,
-                                 const float* hyp, float* P, float* self, float* vnorm) {
+                                 const float* hyp, const float* center, float* P, float* self, float* vnorm) {
     if (!ctx || !x || !hyp || !P || !self || n < 0 || (p > 0 && (!v || !vnorm))) return DSVGP_EINVAL;
     Geom g;
     if (int rc = make_geom(d, p, g)) return rc;
     if (n == 0) return 0;
     const int rows = n * g.q;
-    hipLaunchKernelGGL(pack_points_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, ctx->stream, x, v, n, d, p, hyp, P,
-                       self, vnorm, g.K4, g.DP);
+    hipLaunchKernelGGL(pack_points_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, ctx->stream, x, v, n, d, p, hyp, center,
+                       P, self, vnorm, g.K4, g.DP);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -667,7 +968,9 @@ extern "C" size_t dsvgp_kernel_bwd_workspace_bytes(int n1, int n2, int d, int p)
     Geom g;
     if (make_geom(d, p, g) || n1 <= 0 || n2 <= 0) return 0;
     const int ns = bwd_nsplit(n1, n2, g);
-    const int rt = cdiv((int64_t)n1 * g.q, g.Tr);
+    int tr, tc, wgs;
+    bwd_tiles(g, tr, tc, wgs);
+    const int rt = cdiv((int64_t)n1 * g.q, tr);
     return sizeof(float) * ((size_t)ns * n1 * g.q * g.NP + (size_t)2 * ns * rt + 64);
 }
 
@@ -683,9 +986,24 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     const int n1q = n1 * g.q, n2q = n2 * g.q;
     if (ldg < n2q) return DSVGP_EINVAL;
     const int ns = bwd_nsplit(n1, n2, g);
-    const int rt = cdiv(n1q, g.Tr);
+    int tr_, tc_, wgs_;
+    bwd_tiles(g, tr_, tc_, wgs_);
+    const int rt = cdiv(n1q, tr_);
     float* slab = (float*)workspace;
     float* partials = slab + (size_t)ns * n1q * g.NP;
+    if (bwd_use_pair(g)) {
+        const size_t lds = sizeof(float) * (48 * (size_t)(g.K4 + 5) + 48 * (size_t)(g.NP + 1) + 48 * (size_t)PAIR_LDT);
+        const int esz = g_is_double ? 8 : 4;
+        const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);    // 2-wide loads of the micro-block rows
+        dim3 grid(ns, rt);
+#define DSVGP_PAIR_LAUNCH(GT_, Q_)                                                                                      \
+        hipLaunchKernelGGL((kernel_bwd_pair_kernel<GT_, Q_>), grid, dim3(64), lds, ctx->stream, (const GT_*)G, ldg, P1, self1, \
+                           n1q, P2, self2, n2q, g.K4, g.DP, g.NP, gvec, hyp, slab, partials)
+        if (g_is_double) { if (g.q == 6) DSVGP_PAIR_LAUNCH(double, 6); else DSVGP_PAIR_LAUNCH(double, 3); }
+        else { if (g.q == 6) DSVGP_PAIR_LAUNCH(float, 6); else DSVGP_PAIR_LAUNCH(float, 3); }
+#undef DSVGP_PAIR_LAUNCH
+        DSVGP_LAUNCH_CHECK();
+    } else {
     const int Trp = (g.Tr + 15) & ~15, Tcp = (g.T + 15) & ~15;
     const size_t lds = sizeof(float) * ((size_t)Trp * (g.K4 + 1) + (size_t)Tcp * (g.NP + 1) + 2 * (size_t)Trp * LDT + Trp + Tcp +
                                         (size_t)g.Rr * g.R + 2 * (size_t)g.Tr * g.R + 2 * BWD_NW);
@@ -697,6 +1015,7 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     else
         dispatch_bwd<float>(ctx->stream, grid, lds, (const float*)G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
     DSVGP_LAUNCH_CHECK();
+    }
     const float sym = symmetric ? 2.f : 1.f;
     hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64), sizeof(float) * (g.q * g.DP + g.q + 1), ctx->stream,
                        slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1);

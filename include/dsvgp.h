@@ -61,10 +61,16 @@ int dsvgp_hyp_backward(dsvgp_ctx* ctx, const float* raw_lengthscale, const float
  * dsvgp_pack_points: x[n,d], v[n*p,d] (raw directions, normalised here, :57-58) ->
  *   P[n*(p+1), DP] packed operand rows (x/ell and unit directions, zero padded, plus the indicator
  *   column used by the backward), self[n*(p+1)] (|x/ell|^2 and (x/ell).v), vnorm[n*p].
- *   DP = dsvgp_packed_width(d).                                                                  */
+ *   DP = dsvgp_packed_width(d).  center[d] (may be NULL = 0): common shift subtracted from x before
+ *   the 1/ell scaling; both operands of one kernel call must be packed with the SAME center.  The
+ *   kernel is shift invariant; centering (gpytorch 1.4.0 Kernel.covar_dist: `adjustment =
+ *   x1.mean(-2)`, reached from RBFKernelDirectionalGrad.py:71) keeps |x~|^2 small so that the fp32
+ *   quadratic expansion |x~1|^2 + |x~2|^2 - 2 x~1.x~2 loses ~4x fewer digits.
+ * dsvgp_column_mean: out[d] = mean over the n rows of x[n,d] (the center above).                 */
 int dsvgp_packed_width(int d);
+int dsvgp_column_mean(dsvgp_ctx* ctx, const float* x, int n, int d, float* out);
 int dsvgp_pack_points(dsvgp_ctx* ctx, const float* x, const float* v, int n, int d, int p,
-                      const float* hyp, float* P, float* self, float* vnorm);
+                      const float* hyp, const float* center, float* P, float* self, float* vnorm);
 
 /* out[n1*(p+1), n2*(p+1)] = hyp.outputscale * K(x1,x2;v1,v2) (+ jitter on the global diagonal).
  * out_is_double: 0 -> float output, 1 -> double output (fp32 values widened, as the reference's

@@ -32,8 +32,10 @@ def _kernel_gpu(dsvgp, dev, x1, x2, v1, v2, ell, s=1.0, jitter=0.0, dtype=torch.
     n2 = x2.shape[0]
     p = v1.shape[0] // n1
     hyp = _hyp(dev, ell, s)
-    p1 = ops.pack_points(ctx, x1.float().to(dev).contiguous(), v1.float().to(dev).contiguous(), p, hyp)
-    p2 = ops.pack_points(ctx, x2.float().to(dev).contiguous(), v2.float().to(dev).contiguous(), p, hyp)
+    x1d = x1.float().to(dev).contiguous()
+    center = ops.column_mean(ctx, x1d)
+    p1 = ops.pack_points(ctx, x1d, v1.float().to(dev).contiguous(), p, hyp, center)
+    p2 = ops.pack_points(ctx, x2.float().to(dev).contiguous(), v2.float().to(dev).contiguous(), p, hyp, center)
     return ops.kernel_fwd(ctx, p1, n1, p2, n2, d, p, hyp, jitter=jitter, dtype=dtype), (ctx, hyp, p1, p2)
 
 

@@ -145,7 +145,7 @@ def test_full_size_properties_c4(dsvgp, gpu_device):
     ops = dsvgp._ops
     ctx = ops.Context.get(dev)
     hyp = ops.hyp_forward(ctx, Pg["raw_lengthscale"], Pg["raw_outputscale"], Pg["raw_noise"])
-    pz = ops.pack_points(ctx, Pg["inducing_points"], Pg["inducing_directions"], p, hyp)
+    pz = ops.pack_points(ctx, Pg["inducing_points"], Pg["inducing_directions"], p, hyp, eng.center)
     Kzz = ops.kernel_fwd(ctx, pz, M, pz, M, d, p, hyp, jitter=1e-3, dtype=torch.float64)
     assert ((L @ L.t()).tril() - Kzz.tril()).abs().max().item() < 1e-10
     assert (Kzz - Kzz.t()).abs().max().item() < 1e-5
@@ -155,7 +155,7 @@ def test_full_size_properties_c4(dsvgp, gpu_device):
     expect = (s * O.kernel_diag(B, p, ell) + 1e-4 + noise).float()
     assert relmax(varn, expect) < 1e-5
     # (3) K_ZX == K_XZ^T (the redundant reference assembly)
-    px = ops.pack_points(ctx, x.to(dev), D.to(dev), p, hyp)
+    px = ops.pack_points(ctx, x.to(dev), D.to(dev), p, hyp, eng.center)
     Kxz = ops.kernel_fwd(ctx, px, B, pz, M, d, p, hyp)
     assert (Kxz.t() - eng._buf["Kzx"]).abs().max().item() < 1e-5
     # (4) linearity of the data-parallel split: two half batches, KL once, sum == full batch
