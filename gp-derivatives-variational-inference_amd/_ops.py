@@ -167,6 +167,7 @@ def potrf_(ctx, A, info, algo=1):
             ws = torch.empty(int(lib.dsvgp_potrf_workspace_bytes(n, 1)), dtype=torch.uint8, device=A.device)
             _potrf_ws[key] = ws
     check(lib.dsvgp_potrf(ctx.h, _ptr(A), n, _ld(A), _ptr(info), int(algo), _ptr(ws)), "dsvgp_potrf")
+    return ws
 
 
 def add_diag_(ctx, A, delta):
@@ -193,15 +194,15 @@ def trsm(ctx, L, B, trans, X64, X32, nb, workspace, reuse_inverse=False):
                          1 if reuse_inverse else 0), "dsvgp_trsm")
 
 
-def trtri_blocks(ctx, L, nrhs_max, nb, workspace):
-    """Invert the nb x nb diagonal blocks of L into the trsm workspace (the first phase of dsvgp_trsm)."""
+def trtri_blocks(ctx, L, nrhs_max, nb, workspace, potrf_ws=None):
+    """Invert the nb x nb diagonal blocks of L into the trsm workspace (the first phase of dsvgp_trsm).
+    ``potrf_ws``: what ``potrf_(algo=1)`` returned for THIS L (its inverted 64 x 64 diagonal blocks are reused)."""
     _req(L, f64, "L", 2)
     n = L.shape[0]
     need = int(lib.dsvgp_trsm_workspace_bytes(n, nrhs_max, nb))
     if workspace.numel() < need:
         raise ValueError("trsm workspace too small: %d < %d" % (workspace.numel(), need))
-    check(lib.dsvgp_trsm(ctx.h, _ptr(L), _ld(L), n, 0, _ptr(workspace), 0, 1, 0, _ptr(workspace), 0, None, 0, nb,
-                         _ptr(workspace), 0), "dsvgp_trsm(trtri)")
+    check(lib.dsvgp_trtri(ctx.h, _ptr(L), _ld(L), n, nb, _ptr(potrf_ws), _ptr(workspace)), "dsvgp_trtri")
 
 
 def gemm(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0, Cin=None, C32=None, kscale=None, M=None, N=None, K=None):

@@ -34,6 +34,10 @@ class NotPSDError(RuntimeError):
     """Same failure the reference surfaces from psd_safe_cholesky (gpytorch.utils.errors.NotPSDError)."""
 
 
+class _Refactored(Exception):
+    """The deferred potrf status turned out non-zero: the jitter ladder must run and the step be redone."""
+
+
 class ElboEngine:
     """Owns the HBM workspaces of one (M', B', d, p) configuration on one GPU."""
 
@@ -46,6 +50,8 @@ class ElboEngine:
                                         # 0: rocSOLVER dpotrf (8.1 ms)
         self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
         self._hyp_host = None
+        self._pending = None            # (hyp, packZ, L, dims, info) of a factorisation whose status is not read yet
+        self._potrf_ws = None
         self._eval_cache = None
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
@@ -66,8 +72,11 @@ class ElboEngine:
         return t
 
     # ---- shared forward pieces ----------------------------------------------------------------
-    def _factor(self, ctx, params, need_grad_packs=True):
-        """hyp, packs of (Z,V), L = chol(K_ZZ + 1e-3 I) with psd_safe_cholesky retries."""
+    def _factor(self, ctx, params, sync=True):
+        """hyp, packs of (Z,V), L = chol(K_ZZ + 1e-3 I) with psd_safe_cholesky retries.
+        ``sync=False`` only enqueues the first factorisation; the status word (and the host copy of the
+        hyper-parameters) is read later by ``_finish_factor`` once more GPU work has been queued behind it, so the
+        host round trip does not drain the device."""
         Z, V = params["inducing_points"], params["inducing_directions"]
         M, d = Z.shape
         p = V.shape[0] // M if M else 0
@@ -79,21 +88,32 @@ class ElboEngine:
         L = self._get("L", (Mp, Mp), f64)
         info = self._get("info", (1,), torch.int32)
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
-        _ops.potrf_(ctx, L, info, self.potrf_algo)
-        self._hyp_host = hyp.tolist()                   # host copy of (ell, s, noise): same sync as the potrf status
-        if int(info.item()) != 0:                       # rare path: psd_safe_cholesky jitter ladder
-            ok = False
-            for t in range(CHOL_TRIES):
-                _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
-                _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
-                _ops.potrf_(ctx, L, info, self.potrf_algo)
-                if int(info.item()) == 0:
-                    ok = True
-                    break
-            if not ok:
-                raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
-                                  % (self.chol_jitter * 10 ** (CHOL_TRIES - 1)))
+        self._potrf_ws = _ops.potrf_(ctx, L, info, self.potrf_algo)
+        self._pending = (hyp, packZ, L, (M, d, p, Mp), info)
+        if sync:
+            self._finish_factor(ctx, ladder=True)
         return hyp, packZ, L, (M, d, p, Mp)
+
+    def _finish_factor(self, ctx, ladder=False):
+        """Read the potrf status (host sync).  Non-zero: run psd_safe_cholesky's jitter ladder here (``ladder``) or
+        tell the caller to start over synchronously (``_Refactored``)."""
+        if self._pending is None:
+            return
+        hyp, packZ, L, (M, d, p, Mp), info = self._pending
+        self._pending = None
+        self._hyp_host = hyp.tolist()                   # host copy of (ell, s, noise): same sync as the potrf status
+        if int(info.item()) == 0:
+            return
+        if not ladder:
+            raise _Refactored()
+        for t in range(CHOL_TRIES):                     # rare path: psd_safe_cholesky jitter ladder
+            _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
+            _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
+            self._potrf_ws = _ops.potrf_(ctx, L, info, self.potrf_algo)
+            if int(info.item()) == 0:
+                return
+        raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
+                          % (self.chol_jitter * 10 ** (CHOL_TRIES - 1)))
 
     def _interp(self, ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=False):
         """K_ZX, A = L^-1 K_ZX (fp64 + fp32 copy), W = L_S^T A, mu, var."""
@@ -109,7 +129,7 @@ class ElboEngine:
         old = self._buf.get("trsm_ws")
         ws = self._bytes("trsm_ws", need)
         if not (reuse_inverse and ws is old):           # a re-allocated workspace has no inverse in it
-            _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws)
+            _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws, self._potrf_ws)
         if self.record_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -156,15 +176,22 @@ class ElboEngine:
         produce per-output variances (``varn`` is then an empty tensor; ``predict`` gives them on demand)."""
         ctx = _ops.Context.get(self.device)
         self._eval_cache = None
-        hyp, packZ, L, dims = self._factor(ctx, params)
+        if fast is None:
+            fast = self.elbo_fast
+        try:        # first attempt: potrf status read only after the forward solve has been queued
+            return self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
+        except _Refactored:
+            return self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, True)
+
+    def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
+        use_fast = mll_type == "ELBO" and fast
+        hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast)
         M, d, p, Mp = dims
         B = x.shape[0]
         Bp = B * (p + 1)
         if y.shape != (Bp,):
             raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bp)
         rows = float(Bp if global_rows is None else global_rows)
-        if fast is None:
-            fast = self.elbo_fast
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
         dev = self.device
@@ -177,7 +204,7 @@ class ElboEngine:
         Kb32 = self._get("Kb32", (Mp, Bp), f32)
         y = y.contiguous()
 
-        if mll_type == "ELBO" and fast:
+        if use_fast:
             packX, mu = self._elbo_fast(ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl,
                                         scal, kl_buf, dm, dLS, Kb32, Lbar)
             varn = torch.empty(0, dtype=f32, device=dev)
@@ -206,15 +233,21 @@ class ElboEngine:
         # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 ----
         ws = self._buf["trsm_ws"]
         G1 = self._get("G1", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, L, Lbar, G1)            # L^T L-bar
-        _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar): Phi reads nothing else
+        _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T (mirror of the lower part)
         Y = self._get("Y", (Mp, Mp), f64)
         _ops.trsm(ctx, L, G1, True, Y, None, self.trsm_nb, ws, reuse_inverse=True)          # L^-T S
         Yt = Lbar                                                           # reuse
         _ops.transpose_f64(ctx, Y, Yt)
         Kzzbar = G1                                                         # reuse
-        _ops.trsm(ctx, L, Yt, True, Kzzbar, None, self.trsm_nb, ws, reuse_inverse=True)     # L^-T S L^-1 (symmetric)
-        Kzzbar.mul_(0.5)
+        if self.trsm_nb >= Mp:
+            # explicit inverse in the workspace: only the lower half of the symmetric result is computed, then mirrored
+            Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
+            _ops.gemm(ctx, TRANS_A | A_UPPER | OUT_LOWER, Linv, Yt, Kzzbar, alpha=0.5)      # 1/2 tril(L^-T S L^-1)
+            _ops.phi_symmetrize_(ctx, Kzzbar)
+        else:
+            _ops.trsm(ctx, L, Yt, True, Kzzbar, None, self.trsm_nb, ws, reuse_inverse=True) # L^-T S L^-1 (symmetric)
+            Kzzbar.mul_(0.5)
 
         # ---- kernel backward: K_ZX (data side carries no gradient) and symmetric K_ZZ ----
         dZ, dV = grads["inducing_points"], grads["inducing_directions"]
@@ -257,7 +290,7 @@ class ElboEngine:
         A32e = self._get("A32e", (Mp + 1, Bp), f32)          # [A ; mu_bar^T]
         A32 = A32e[:Mp]
         ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp + 1), self.trsm_nb))
-        _ops.trtri_blocks(ctx, L, max(Bp, Mp + 1), self.trsm_nb, ws)
+        _ops.trtri_blocks(ctx, L, max(Bp, Mp + 1), self.trsm_nb, ws, self._potrf_ws)
         if self.record_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -272,13 +305,14 @@ class ElboEngine:
         mu_bar = A32e[Mp]
         sums = torch.empty(4, dtype=f32, device=dev)
         _ops.residual_terms(ctx, mu, y, hyp, rows, mu_bar, sums)
-        noise = self._hyp_host[2]
-        vbar2 = 1.0 / (noise * rows)                         # 2 * vbar
         # Gram matrix and L_S gradient
         Ge = self._get("Ge", (Mp + 1, Mp), f32)              # [G ; b^T]
         G = Ge[:Mp]
         _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, A32, G)     # tril(A A^T), split-K over the minibatch axis
         _ops.mirror_lower_f32_(ctx, G, Mp)
+        self._finish_factor(ctx)                             # host sync, hidden behind the queued solve + Gram product
+        noise = self._hyp_host[2]
+        vbar2 = 1.0 / (noise * rows)                         # 2 * vbar
         _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
         _ops.trace_terms(ctx, LS, dLS, G, Mp, sums, 1.0 / vbar2)
         _ops.elbo_fast_finalize(ctx, sums, hyp, B, p, rows, scal)

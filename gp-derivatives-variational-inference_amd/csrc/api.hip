@@ -78,6 +78,20 @@ extern "C" size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb) {
     return sizeof(double) * ((size_t)2 * n * n + (size_t)(n + b) * (b / 2) + (size_t)b * (nrhs > 0 ? nrhs : 1)) + 256;
 }
 
+// First phase of dsvgp_trsm on its own: Dinv / DinvT of `workspace` from L.  potrf_workspace (may be NULL): the
+// workspace dsvgp_potrf(algo 1) factored THIS L with -- its inverted 64 x 64 diagonal blocks seed the recursion.
+extern "C" int dsvgp_trtri(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int nb, const void* potrf_workspace,
+                           void* workspace) {
+    if (!ctx || !L || !workspace || n <= 0 || ldl < n) return DSVGP_EINVAL;
+    const int b = trsm_nb(n, nb);
+    double* Dinv = (double*)workspace;
+    double* DinvT = Dinv + (size_t)n * n;
+    double* tmp = DinvT + (size_t)n * n;
+    int rc = launch_trtri_blocks(ctx->stream, L, ldl, n, b, Dinv, n, tmp, (const double*)potrf_workspace);
+    if (rc) return rc;
+    return dsvgp_transpose_f64(ctx, Dinv, n, n, n, DinvT, n);
+}
+
 extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B, int64_t ldb,
                           int b_is_double, int nrhs, double* X64, int64_t ldx64, float* X32, int64_t ldx32, int nb,
                           void* workspace, int reuse_inverse) {
@@ -92,7 +106,7 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
     double* T = tmp + (size_t)(n + b) * (b / 2);
     hipStream_t st = ctx->stream;
     if (!reuse_inverse) {
-        int rc = launch_trtri_blocks(st, L, ldl, n, b, Dinv, n, tmp);
+        int rc = launch_trtri_blocks(st, L, ldl, n, b, Dinv, n, tmp, nullptr);
         if (rc) return rc;
         rc = dsvgp_transpose_f64(ctx, Dinv, n, n, n, DinvT, n);
         if (rc) return rc;

@@ -42,6 +42,7 @@ size_t potrf_blocked_workspace_bytes(int n);
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* dinv_ws);
 
 // trtri of the nb x nb diagonal blocks of the lower-triangular L into Dinv (same indexing as L,
-// leading dimension ldd); tmp is an n x (nb/2) double scratch.
+// leading dimension ldd); tmp is an n x (nb/2) double scratch.  X64 (may be null): the inverted 64 x 64 diagonal
+// blocks the blocked Cholesky left in its workspace ([k][64][64]).
 int launch_trtri_blocks(hipStream_t st, const double* L, int64_t ldl, int n, int nb, double* Dinv,
-                        int64_t ldd, double* tmp);
+                        int64_t ldd, double* tmp, const double* X64);

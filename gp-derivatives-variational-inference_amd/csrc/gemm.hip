@@ -413,6 +413,18 @@ __global__ __launch_bounds__(64) void trtri64_kernel(const double* __restrict__ 
     }
 }
 
+// the blocked Cholesky already inverted every 64 x 64 diagonal block (X_k in its workspace, [k][64][64]): scatter
+// them onto the diagonal of Dinv instead of inverting again
+__global__ __launch_bounds__(256) void trtri64_copy_kernel(const double* __restrict__ X, int n, double* __restrict__ Dinv,
+                                                          int64_t ldd) {
+    const int r0 = blockIdx.x * 64;
+    const double* Xk = X + (size_t)blockIdx.x * 4096;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (r0 + r < n && r0 + c < n) Dinv[(int64_t)(r0 + r) * ldd + r0 + c] = (c <= r) ? Xk[e] : 0.0;
+    }
+}
+
 }  // namespace
 
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
@@ -429,13 +441,13 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     // Few output tiles but a long K (the minibatch axis, or M' x M' x M' products): split K so that the
     // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
-    if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 1024) {
+    if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 512) {
         const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (128 / a.bn) : a.tiles_m * a.tiles_n;
         // split factor: minimise (rounds over the 256 CUs -- two resident workgroups share a CU's matrix pipe, so the
         // CU, not the slot, is the unit of throughput) x (K slice + fixed per-workgroup cost)
         int sk = 1;
         if (active > 0 && active < 1024) {
-            const int maxsk = a.K / 512 < 32 ? a.K / 512 : 32;
+            const int maxsk = a.K / 256 < 32 ? a.K / 256 : 32;
             double best = 1e300;
             for (int c = 1; c <= maxsk; ++c) {
                 const double t = (double)cdiv((int64_t)active * c, GEMM_SK_BINS) * ((double)a.K / c + GEMM_SK_OVH);
@@ -486,9 +498,10 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
 // Blocked inverse of the nb x nb diagonal blocks of L by recursive doubling:
 //   inv([[A,0],[C,D]]) = [[A^-1,0],[-D^-1 C A^-1, D^-1]],  two batched MFMA GEMMs per level.
 int launch_trtri_blocks(hipStream_t st, const double* L, int64_t ldl, int n, int nb, double* Dinv,
-                        int64_t ldd, double* tmp) {
+                        int64_t ldd, double* tmp, const double* X64) {
     if (nb < 64 || (nb & (nb - 1))) return DSVGP_EINVAL;
-    hipLaunchKernelGGL(trtri64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, L, ldl, n, Dinv, ldd);
+    if (X64) hipLaunchKernelGGL(trtri64_copy_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, X64, n, Dinv, ldd);
+    else hipLaunchKernelGGL(trtri64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, L, ldl, n, Dinv, ldd);
     DSVGP_LAUNCH_CHECK();
     const int64_t ldt = nb / 2;
     for (int h = 64; h < nb; h *= 2) {
@@ -499,21 +512,24 @@ int launch_trtri_blocks(hipStream_t st, const double* L, int64_t ldl, int n, int
         GemmArgs g{};
         g.batch = npairs; g.splitk = 1;
         // Tmp = C * A^-1        (A^-1 lower-triangular as the right operand)
-        g.M = h; g.M_last = last_rows < h ? last_rows : h; g.N = h; g.K = h; g.K_last = h;
+        const int mlast = last_rows < h ? last_rows : h;
+        g.M = h; g.M_last = mlast; g.N = h; g.K = h; g.K_last = h;
         g.A = L + (int64_t)h * ldl;            g.lda = ldl; g.sA = (int64_t)2 * h * (ldl + 1);
         g.B = Dinv;                            g.ldb = ldd; g.sB = (int64_t)2 * h * (ldd + 1);
         g.C = tmp + (int64_t)h * ldt;          g.ldc = ldt; g.sC = (int64_t)2 * h * ldt;
         g.alpha = 1.0; g.beta = 0.0; g.flags = DSVGP_GEMM_B_LOWER;
+        if (npairs == 1) { g.M = mlast; g.M_last = 0; g.K_last = 0; }    // a single pair: true extents, so split-K can kick in
         int rc = launch_gemm(st, 1, g);
         if (rc) return rc;
         // bottom-left = -D^-1 * Tmp   (D^-1 lower-triangular as the left operand)
         GemmArgs f{};
         f.batch = npairs; f.splitk = 1;
-        f.M = h; f.M_last = g.M_last; f.N = h; f.K = h; f.K_last = g.M_last;
+        f.M = h; f.M_last = mlast; f.N = h; f.K = h; f.K_last = mlast;
         f.A = Dinv + (int64_t)h * (ldd + 1);   f.lda = ldd; f.sA = (int64_t)2 * h * (ldd + 1);
         f.B = tmp + (int64_t)h * ldt;          f.ldb = ldt; f.sB = (int64_t)2 * h * ldt;
         f.C = Dinv + (int64_t)h * ldd;         f.ldc = ldd; f.sC = (int64_t)2 * h * (ldd + 1);
         f.alpha = -1.0; f.beta = 0.0; f.flags = DSVGP_GEMM_A_LOWER;
+        if (npairs == 1) { f.M = mlast; f.K = mlast; f.M_last = 0; f.K_last = 0; }
         rc = launch_gemm(st, 1, f);
         if (rc) return rc;
     }

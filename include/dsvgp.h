@@ -110,6 +110,10 @@ size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb);
 int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B,
                int64_t ldb, int b_is_double, int nrhs, double* X64, int64_t ldx64, float* X32,
                int64_t ldx32, int nb, void* workspace, int reuse_inverse);
+/* The inversion phase of dsvgp_trsm alone (later solves pass reuse_inverse=1).  potrf_workspace: NULL, or
+ * the workspace dsvgp_potrf(algo 1) factored THIS L with (its inverted 64x64 diagonal blocks are reused). */
+int dsvgp_trtri(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int nb, const void* potrf_workspace,
+                void* workspace);
 
 /* ---- generic MFMA GEMM used by the predictive / backward contractions
  *   C = alpha * op(A) op(B) + beta * Cin,   compute type = double (is_double=1) or float.
