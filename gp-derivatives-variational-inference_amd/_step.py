@@ -52,6 +52,9 @@ class ElboEngine:
         self._hyp_host = None
         self._pending = None            # (hyp, packZ, L, dims, info) of a factorisation whose status is not read yet
         self._potrf_ws = None
+        self._side = None               # second HIP stream (work overlapped with the Cholesky chain)
+        self._side_done = None
+        self.overlap = True
         self._eval_cache = None
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
@@ -72,8 +75,11 @@ class ElboEngine:
         return t
 
     # ---- shared forward pieces ----------------------------------------------------------------
-    def _factor(self, ctx, params, sync=True):
+    def _factor(self, ctx, params, sync=True, side_job=None):
         """hyp, packs of (Z,V), L = chol(K_ZZ + 1e-3 I) with psd_safe_cholesky retries.
+        ``side_job(ctx, hyp)``: work that needs only the hyper-parameters / the centre (K_ZX assembly, S = L_S L_S^T):
+        queued on a second HIP stream so that it fills the CUs the latency-bound Cholesky chain leaves idle; the
+        caller waits on ``self._side_done`` before consuming its results.
         ``sync=False`` only enqueues the first factorisation; the status word (and the host copy of the
         hyper-parameters) is read later by ``_finish_factor`` once more GPU work has been queued behind it, so the
         host round trip does not drain the device."""
@@ -85,6 +91,20 @@ class ElboEngine:
         # common shift of Z and x (gpytorch covar_dist centres on x1.mean): keeps the fp32 quadratic expansion accurate
         self.center = _ops.column_mean(ctx, Z.contiguous())
         packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp, self.center)
+        self._pending_packZ = packZ
+        if side_job is not None:
+            main = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                ctx.bind()
+                side_job(ctx, hyp)
+                self._side_done = torch.cuda.Event()
+                self._side_done.record(self._side)
+            ctx.bind()                                  # back on the caller's stream
         L = self._get("L", (Mp, Mp), f64)
         info = self._get("info", (1,), torch.int32)
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
@@ -185,13 +205,20 @@ class ElboEngine:
 
     def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         use_fast = mll_type == "ELBO" and fast
-        hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast)
-        M, d, p, Mp = dims
+        Mz = params["inducing_points"].shape[0]
+        p = params["inducing_directions"].shape[0] // Mz if Mz else 0
         B = x.shape[0]
         Bp = B * (p + 1)
         if y.shape != (Bp,):
             raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bp)
         rows = float(Bp if global_rows is None else global_rows)
+        side = {}
+        side_job = None
+        if use_fast and self.overlap:
+            def side_job(c, hyp_):
+                side.update(self._fast_prologue(c, params, hyp_, x, D, rows))
+        hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast, side_job=side_job)
+        M, d, p, Mp = dims
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
         dev = self.device
@@ -205,8 +232,12 @@ class ElboEngine:
         y = y.contiguous()
 
         if use_fast:
+            if not side:        # no overlap: the prologue runs in line
+                side.update(self._fast_prologue(ctx, params, hyp, x, D, rows))
+            else:
+                torch.cuda.current_stream(self.device).wait_event(self._side_done)
             packX, mu = self._elbo_fast(ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl,
-                                        scal, kl_buf, dm, dLS, Kb32, Lbar)
+                                        scal, kl_buf, dm, dLS, Kb32, Lbar, side)
             varn = torch.empty(0, dtype=f32, device=dev)
         else:
             packX, A64, A32, W, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D)
@@ -267,8 +298,29 @@ class ElboEngine:
         loss = -scal[0] / rows + kl_buf[0] / float(num_data)
         return loss, grads, mu, varn
 
+    def _fast_prologue(self, ctx, params, hyp, x, D, rows):
+        """The part of the ELBO fast path that does not depend on L: K_ZX assembly and [S - I | m / (2 vbar)]."""
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        Mp = M * (p + 1)
+        B = x.shape[0]
+        Bp = B * (p + 1)
+        m = params["variational_mean"]
+        LS = params["chol_variational_covar"]
+        packZ = self._pending_packZ
+        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        Kzx = self._get("Kzx", (Mp, Bp), f32)
+        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        S32e = self._get("S32e", (Mp, Mp + 1), f32)          # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)]
+        S32 = S32e[:, :Mp]
+        _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
+        _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
+        S32e[:, Mp].copy_(m * (hyp[2] * rows))               # m / (2 vbar), 2 vbar = 1 / (noise rows)
+        return dict(packX=packX, Kzx=Kzx, S32e=S32e)
+
     def _elbo_fast(self, ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl, scal, kl_buf, dm,
-                   dLS, Kb32, Lbar):
+                   dLS, Kb32, Lbar, pro):
         """ELBO mode: dLoss/dvar_j = vbar = 1/(2 noise rows) for every output, hence
              sum_j var_j = prior + tr(L_S^T G L_S) - tr(G),             G = A A^T          (M' x M')
              L_S-bar     = 2 vbar tril(G L_S)
@@ -283,9 +335,9 @@ class ElboEngine:
         dev = self.device
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
-        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
-        Kzx = self._get("Kzx", (Mp, Bp), f32)
-        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        packX, Kzx, S32e = pro["packX"], pro["Kzx"], pro["S32e"]
+        for t in packX:
+            t.record_stream(torch.cuda.current_stream(dev))
         A64 = self._get("A64", (Mp, Bp), f64)
         A32e = self._get("A32e", (Mp + 1, Bp), f32)          # [A ; mu_bar^T]
         A32 = A32e[:Mp]
@@ -321,11 +373,6 @@ class ElboEngine:
         if include_kl:
             _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
         # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
-        S32e = self._get("S32e", (Mp, Mp + 1), f32)          # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)]
-        S32 = S32e[:, :Mp]
-        _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
-        _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
-        S32e[:, Mp].copy_(m * (1.0 / vbar2))
         Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
         Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
         _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)

@@ -21,7 +21,7 @@
 #define GEMM_ABLATE 0      // 1: no MFMA (loads + LDS only), 2: no global loads inside the K loop
 #endif
 #ifndef GEMM_BK_F32
-#define GEMM_BK_F32 16
+#define GEMM_BK_F32 32      // 32-deep fp32 stages: twice the MFMA work behind every fetch (dense 101.8 -> 108.9 TF; 16 for the ablation probes)
 #endif
 #ifndef GEMM_BK_F64
 #define GEMM_BK_F64 16
@@ -37,6 +37,12 @@
 #endif
 #ifndef GEMM_XCD
 #define GEMM_XCD 1
+#endif
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 0         // 1: next stage's LDS stores + the following global fetch are issued BEFORE the MFMA block
+#endif
+#ifndef GEMM_FRAGPF
+#define GEMM_FRAGPF 0       // 1: fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk
 #endif
 #ifndef GEMM_THREADS
 #define GEMM_THREADS 512    // 256: 4 waves of 64 x BN/2 outputs; 512: 8 waves of 32 x BN/2 (half the accumulators per wave)
@@ -297,9 +303,15 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
         for (int k0 = klo; k0 < khi; k0 += BK) {
             const TC* as = As[cur];
             const TC* bs = Bs[cur];
-#pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                TC a[MI], b[NJ];
+            if (GEMM_PIPE && k0 + BK < khi) {
+                // stage k0+BK (in registers since one MFMA block ago) goes to the other buffer now -- all waves passed
+                // the barrier after their last reads of it -- and the loads of stage k0+2BK are issued, so that
+                // nothing but the barrier separates this stage's MFMA block from the next one
+                store_stage<TC, TC, AKC, BK, BM, NTH>(As[cur ^ 1], ra, ks);
+                store_stage<TB, TC, BKC, BK, BN, NTH>(Bs[cur ^ 1], rb, TC(1));
+                if (GEMM_ABLATE != 2 && k0 + 2 * BK < khi) fetch(k0 + 2 * BK);
+            }
+            auto frag = [&](int kk, TC (&a)[MI], TC (&b)[NJ]) {
                 const int kq = kk * 4 + (lane >> 4);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
@@ -311,21 +323,31 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
                     const int nn = wc * (BN / 2) + j * 16 + (lane & 15);
                     b[j] = BKC ? bs[nn * SK + kq] : bs[kq * S_MN + nn];
                 }
+            };
+            TC a[2][MI], b[2][NJ];
+            if (GEMM_FRAGPF) frag(0, a[0], b[0]);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                const int cb = GEMM_FRAGPF ? (kk & 1) : 0;
+                if (GEMM_FRAGPF) { if (kk + 1 < BK / 4) frag(kk + 1, a[cb ^ 1], b[cb ^ 1]); }
+                else frag(kk, a[0], b[0]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        if (GEMM_ABLATE == 1) { asm volatile("" :: "v"(a[i]), "v"(b[j])); }
-                        else acc[i][j] = M::mma(a[i], b[j], acc[i][j]);
+                        if (GEMM_ABLATE == 1) { asm volatile("" :: "v"(a[cb][i]), "v"(b[cb][j])); }
+                        else acc[i][j] = M::mma(a[cb][i], b[cb][j], acc[i][j]);
                     }
             }
             if (k0 + BK < khi) {
-                // stage k0+BK (already in registers) goes to the other buffer: nobody reads it any more,
-                // all waves passed the previous barrier after their last reads of it
-                store_stage<TC, TC, AKC, BK, BM, NTH>(As[cur ^ 1], ra, ks);
-                store_stage<TB, TC, BKC, BK, BN, NTH>(Bs[cur ^ 1], rb, TC(1));
+                if (!GEMM_PIPE) {
+                    // stage k0+BK (already in registers) goes to the other buffer: nobody reads it any more,
+                    // all waves passed the previous barrier after their last reads of it
+                    store_stage<TC, TC, AKC, BK, BM, NTH>(As[cur ^ 1], ra, ks);
+                    store_stage<TB, TC, BKC, BK, BN, NTH>(Bs[cur ^ 1], rb, TC(1));
+                }
                 __syncthreads();
-                if (GEMM_ABLATE != 2 && k0 + 2 * BK < khi) fetch(k0 + 2 * BK);
+                if (!GEMM_PIPE && GEMM_ABLATE != 2 && k0 + 2 * BK < khi) fetch(k0 + 2 * BK);
                 cur ^= 1;
             }
         }

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Kernel timeline of the LAST bench step in a rocprofv3 --kernel-trace database (start offset, duration, stream)."""
+import sqlite3, sys
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select name,start,end,stream_id,grid_x,workgroup_x from kernels order by start").fetchall()
+idx = [i for i, r in enumerate(rows) if 'hyp_forward' in r[0]]
+a, b = idx[-2], idx[-1]
+t0 = rows[a][1]
+skip = tuple(sys.argv[2:])
+prev_end = t0
+for r in rows[a:b]:
+    nm = r[0].replace('(anonymous namespace)::', '').replace('void ', '')[:64]
+    if any(k in nm for k in skip):
+        continue
+    print("%9.1f us  dur %8.1f  gap %7.1f  s%-3s grid %-8d %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3, r[3], r[4], nm))
+    prev_end = max(prev_end, r[2])
+print("step span %.1f us" % ((rows[b][1] - t0) / 1e3))
