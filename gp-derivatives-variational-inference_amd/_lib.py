@@ -35,6 +35,7 @@ SIGNATURES = {
     "dsvgp_version": (C.c_char_p, []),
     "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
+    "dsvgp_step_epilogue": (_i, [_p, _p, _p, _d, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_packed_width": (_i, [_i]),
     "dsvgp_column_mean": (_i, [_p, _p, _i, _i, _p]),
     "dsvgp_pack_points": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -94,6 +94,12 @@ def column_mean(ctx, x):
     return out
 
 
+def step_epilogue(ctx, scal, kl0, rows, num_data, raw_l, raw_s, raw_n, d_hyp, d_raw_l, d_raw_s, d_raw_n, d_const, loss):
+    check(lib.dsvgp_step_epilogue(ctx.h, _ptr(scal), _ptr(kl0), float(rows), float(num_data), _ptr(raw_l), _ptr(raw_s),
+                                  _ptr(raw_n), _ptr(d_hyp), _ptr(d_raw_l), _ptr(d_raw_s), _ptr(d_raw_n), _ptr(d_const),
+                                  _ptr(loss)), "dsvgp_step_epilogue")
+
+
 def pack_points(ctx, x, v, p, hyp, center=None):
     """-> (P[n(p+1), DP], self[n(p+1)], vnorm[n p]).  ``center`` [d]: shift subtracted from x (same for both
     operands of a kernel call)."""
@@ -182,15 +188,17 @@ def trsm(ctx, L, B, trans, X64, X32, nb, workspace, reuse_inverse=False):
     _req(L, f64, "L", 2)
     isd = B.dtype == f64
     _req(B, f64 if isd else f32, "B", 2)
-    _req(X64, f64, "X64", 2)
+    if X64 is not None:
+        _req(X64, f64, "X64", 2)
     n, nrhs = B.shape
-    if L.shape != (n, n) or X64.shape != (n, nrhs) or (X32 is not None and X32.shape != (n, nrhs)):
+    if L.shape != (n, n) or (X64 is not None and X64.shape != (n, nrhs)) or (X32 is not None and X32.shape != (n, nrhs)):
         raise ValueError("trsm shape mismatch")
     need = int(lib.dsvgp_trsm_workspace_bytes(n, nrhs, nb))
     if workspace.numel() < need:
         raise ValueError("trsm workspace too small: %d < %d" % (workspace.numel(), need))
     check(lib.dsvgp_trsm(ctx.h, _ptr(L), _ld(L), n, 1 if trans else 0, _ptr(B), _ld(B), 1 if isd else 0, nrhs,
-                         _ptr(X64), _ld(X64), _ptr(X32), _ld(X32) if X32 is not None else 0, nb, _ptr(workspace),
+                         _ptr(X64), _ld(X64) if X64 is not None else 0, _ptr(X32), _ld(X32) if X32 is not None else 0, nb,
+                         _ptr(workspace),
                          1 if reuse_inverse else 0), "dsvgp_trsm")
 
 

@@ -222,8 +222,17 @@ class ElboEngine:
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
         dev = self.device
-        grads = {k: torch.zeros_like(params[k], memory_format=torch.contiguous_format) for k in PARAM_NAMES}
-        d_hyp = torch.zeros(4, dtype=f32, device=dev)
+        # all gradients + the loss live in ONE flat buffer: one fill, and the data-parallel all-reduce needs no packing
+        sizes = [params[k].numel() for k in PARAM_NAMES]
+        total = sum((nk + 15) // 16 * 16 for nk in sizes)           # every segment starts 64-byte aligned
+        flat = torch.zeros(total + 1 + 4, dtype=f32, device=dev)
+        grads, off = {}, 0
+        for k, nk in zip(PARAM_NAMES, sizes):
+            grads[k] = flat[off:off + nk].view(params[k].shape)
+            off += (nk + 15) // 16 * 16
+        self.flat = flat[:off + 1]                      # [grads (padded)..., loss]
+        loss_out = flat[off:off + 1]
+        d_hyp = flat[off + 1:off + 5]
         dLS, dm = grads["chol_variational_covar"], grads["variational_mean"]
         scal = torch.empty(8, dtype=f32, device=dev)
         kl_buf = torch.zeros(Mp + 1, dtype=f32, device=dev)
@@ -287,15 +296,12 @@ class ElboEngine:
         _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
         _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
 
-        # ---- scalars ----
-        d_hyp[0] += scal[4]
-        d_hyp[1] += scal[3]
-        d_hyp[2] += scal[1]
-        grads["constant"].reshape(-1).add_(scal[2])
-        _ops.hyp_backward(ctx, params["raw_lengthscale"].reshape(-1), params["raw_outputscale"].reshape(-1),
-                          params["raw_noise"].reshape(-1), d_hyp, grads["raw_lengthscale"].reshape(-1),
-                          grads["raw_outputscale"].reshape(-1), grads["raw_noise"].reshape(-1))
-        loss = -scal[0] / rows + kl_buf[0] / float(num_data)
+        # ---- scalars: d_hyp += data-term scalars, softplus chain rule, d constant, loss (one launch) ----
+        _ops.step_epilogue(ctx, scal, kl_buf, rows, num_data, params["raw_lengthscale"].reshape(-1),
+                           params["raw_outputscale"].reshape(-1), params["raw_noise"].reshape(-1), d_hyp,
+                           grads["raw_lengthscale"].reshape(-1), grads["raw_outputscale"].reshape(-1),
+                           grads["raw_noise"].reshape(-1), grads["constant"].reshape(-1), loss_out)
+        loss = loss_out[0]
         return loss, grads, mu, varn
 
     def _fast_prologue(self, ctx, params, hyp, x, D, rows):
@@ -338,7 +344,8 @@ class ElboEngine:
         packX, Kzx, S32e = pro["packX"], pro["Kzx"], pro["S32e"]
         for t in packX:
             t.record_stream(torch.cuda.current_stream(dev))
-        A64 = self._get("A64", (Mp, Bp), f64)
+        # the fast path consumes only the fp32 copy of A: with the explicit inverse the fp64 result is never stored
+        A64 = None if self.trsm_nb >= Mp else self._get("A64", (Mp, Bp), f64)
         A32e = self._get("A32e", (Mp + 1, Bp), f32)          # [A ; mu_bar^T]
         A32 = A32e[:Mp]
         ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp + 1), self.trsm_nb))

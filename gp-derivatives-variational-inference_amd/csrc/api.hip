@@ -95,11 +95,14 @@ extern "C" int dsvgp_trtri(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, 
 extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B, int64_t ldb,
                           int b_is_double, int nrhs, double* X64, int64_t ldx64, float* X32, int64_t ldx32, int nb,
                           void* workspace, int reuse_inverse) {
-    if (!ctx || !L || !B || !X64 || !workspace || n <= 0 || nrhs < 0 || ldl < n || ldb < nrhs || ldx64 < nrhs)
+    if (!ctx || !L || !B || !workspace || n <= 0 || nrhs < 0 || ldl < n || ldb < nrhs || (X64 && ldx64 < nrhs))
         return DSVGP_EINVAL;
     if (X32 && ldx32 < nrhs) return DSVGP_EINVAL;
-    if (!b_is_double && (const void*)B == (const void*)X64) return DSVGP_EINVAL;
+    if (X64 && !b_is_double && (const void*)B == (const void*)X64) return DSVGP_EINVAL;
     const int b = trsm_nb(n, nb);
+    // X64 == NULL (only the fp32 copy is wanted) is possible when the whole solve is ONE product with the explicit
+    // inverse (nb >= n): with several block rows the fp64 result of earlier rows feeds the later ones
+    if (!X64 && (!X32 || b < n)) return DSVGP_EINVAL;
     double* Dinv = (double*)workspace;
     double* DinvT = Dinv + (size_t)n * n;
     double* tmp = DinvT + (size_t)n * n;
@@ -154,7 +157,7 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
         if (rhs_float) f.flags |= DSVGP_GEMM_B_IS_FLOAT;
         f.B = rhs; f.ldb = ldrhs;
         f.alpha = 1.0; f.beta = 0.0;
-        f.C = X64 + (size_t)r0 * ldx64; f.ldc = ldx64;
+        f.C = X64 ? X64 + (size_t)r0 * ldx64 : nullptr; f.ldc = ldx64;
         if (X32) { f.C32 = X32 + (size_t)r0 * ldx32; f.ldc32 = ldx32; }
         int rc = launch_gemm(st, 1, f);
         if (rc) return rc;

@@ -29,6 +29,22 @@ __global__ void hyp_backward_kernel(const float* rl, const float* rs, const floa
     }
 }
 
+// everything the step does with its scalar accumulators in ONE launch: fold the data-term scalars into d_hyp,
+// softplus chain rule to the raw parameters, d constant, and loss = -ll / rows + KL / num_data
+__global__ void step_epilogue_kernel(const float* scal, const float* kl0, float inv_rows, float inv_num_data,
+                                     const float* rl, const float* rs, const float* rn, float* dh, float* drl,
+                                     float* drs, float* drn, float* dconst, float* loss) {
+    if (threadIdx.x == 0) {
+        const float d0 = dh[0] + scal[4], d1 = dh[1] + scal[3], d2 = dh[2] + scal[1];
+        dh[0] = d0; dh[1] = d1; dh[2] = d2;
+        drl[0] += d0 * sigmoidf(rl[0]);
+        drs[0] += d1 * sigmoidf(rs[0]);
+        drn[0] += d2 * sigmoidf(rn[0]);
+        dconst[0] += scal[2];
+        loss[0] = -scal[0] * inv_rows + kl0[0] * inv_num_data;
+    }
+}
+
 // partial column statistics over a row chunk: part[chunk][0][j] = sum_i A_ij m_i ; part[chunk][1][j] = sum_i W^2 - A^2
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw, int Mp, int ncols,
@@ -325,6 +341,18 @@ extern "C" int dsvgp_hyp_backward(dsvgp_ctx* ctx, const float* rl, const float* 
                                   float* drl, float* drs, float* drn) {
     if (!ctx || !rl || !rs || !rn || !dh || !drl || !drs || !drn) return DSVGP_EINVAL;
     hipLaunchKernelGGL(hyp_backward_kernel, dim3(1), dim3(64), 0, ctx->stream, rl, rs, rn, dh, drl, drs, drn);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_step_epilogue(dsvgp_ctx* ctx, const float* scal, const float* kl0, double rows, double num_data,
+                                   const float* rl, const float* rs, const float* rn, float* dh, float* drl,
+                                   float* drs, float* drn, float* dconst, float* loss) {
+    if (!ctx || !scal || !kl0 || !rl || !rs || !rn || !dh || !drl || !drs || !drn || !dconst || !loss || rows <= 0 ||
+        num_data <= 0)
+        return DSVGP_EINVAL;
+    hipLaunchKernelGGL(step_epilogue_kernel, dim3(1), dim3(64), 0, ctx->stream, scal, kl0, (float)(1.0 / rows),
+                       (float)(1.0 / num_data), rl, rs, rn, dh, drl, drs, drn, dconst, loss);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
             for (int e = threadIdx.x; e < BM * BN; e += NTH) {
                 int m = m0 + e / BN, n = n0 + e % BN;
                 if (m < Mdim && n < g.N) {
-                    if (g.splitk == 1) C[(int64_t)m * g.ldc + n] = TC(0);
+                    if (g.splitk == 1 && g.C) C[(int64_t)m * g.ldc + n] = TC(0);
                     if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = 0.f;
                 }
             }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
                     v += beta * (cin_f ? (TC)((const float*)g.Cin)[ci] : ((const TC*)g.Cin)[ci]);
                 }
                 if (out_lower && n > m) { if (keep_upper) continue; v = TC(0); }
-                C[(int64_t)m * g.ldc + n] = v;
+                if (g.C) C[(int64_t)m * g.ldc + n] = v;                 // C == nullptr: only the fp32 copy is wanted
                 if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
             }
 }
@@ -463,6 +463,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     // Few output tiles but a long K (the minibatch axis, or M' x M' x M' products): split K so that the
     // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
+    if (!g.C && !g.C32) return DSVGP_EINVAL;
     if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 512) {
         const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (128 / a.bn) : a.tiles_m * a.tiles_n;
         // split factor: minimise (rounds over the 256 CUs -- two resident workgroups share a CU's matrix pipe, so the
@@ -487,7 +488,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     }
     if (out_lower && !keep_upper && a.splitk == 1 && a.batch == 1 && g.Cin != g.C) {
         // supertiles strictly above the diagonal are never visited: define them as zero up front
-        hipError_t e = hipMemset2DAsync(a.C, esz * (size_t)a.ldc, 0, esz * (size_t)a.N, (size_t)a.M, st);
+        hipError_t e = a.C ? hipMemset2DAsync(a.C, esz * (size_t)a.ldc, 0, esz * (size_t)a.N, (size_t)a.M, st) : hipSuccess;
         if (e != hipSuccess) return 1000 + (int)e;
         if (a.C32) {
             e = hipMemset2DAsync(a.C32, 4 * (size_t)a.ldc32, 0, 4 * (size_t)a.N, (size_t)a.M, st);

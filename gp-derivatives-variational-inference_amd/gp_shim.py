@@ -91,10 +91,12 @@ class _ElboFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_elbo, _gm, _gv):
-        out = [None] * 7
-        for g in ctx.grads:
-            out.append(-g_elbo * g)
-        return tuple(out)
+        # d loss / d param = -(d loss / d mll) * grads; the engine's buffers are consumed in place (multi-tensor
+        # scale by the device scalar: no per-parameter temporaries, the 36 MB L_S gradient is not copied)
+        grads = ctx.grads
+        ctx.grads = None
+        torch._foreach_mul_(grads, -g_elbo.detach().to(grads[0].dtype))
+        return tuple([None] * 7 + list(grads))
 
 
 class PredictiveDistribution:

@@ -33,9 +33,16 @@ class DataParallel:
         rows = (self.global_batch if self.global_batch is not None else x.shape[0] * self.world) * p1
         loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type, global_rows=rows,
                                                       include_kl=(self.rank == 0))
+        flat = getattr(engine, "flat", None)
         names = list(grads.keys())
-        flat = torch.cat([grads[k].reshape(-1) for k in names] + [loss.reshape(1).to(grads[names[0]].dtype)])
+        if flat is None or flat.data_ptr() != grads[names[0]].data_ptr():                 # engines without a flat buffer
+            flat = torch.cat([grads[k].reshape(-1) for k in names] + [loss.reshape(1).to(grads[names[0]].dtype)])
+            views = None
+        else:
+            views = grads                       # the engine's gradients ARE views of [grads..., loss]
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if views is not None:
+            return flat[-1], views, mu, varn
         off = 0
         out = {}
         for k in names:

@@ -55,6 +55,13 @@ int dsvgp_hyp_forward(dsvgp_ctx* ctx, const float* raw_lengthscale, const float*
 int dsvgp_hyp_backward(dsvgp_ctx* ctx, const float* raw_lengthscale, const float* raw_outputscale,
                        const float* raw_noise, const float* d_hyp, float* d_raw_lengthscale,
                        float* d_raw_outputscale, float* d_raw_noise);
+/* The scalar tail of one step in a single launch: d_hyp += data-term scalars (scal[4], scal[3], scal[1] of
+ * dsvgp_likelihood_terms / dsvgp_elbo_fast_finalize), the softplus chain rule of dsvgp_hyp_backward, d constant +=
+ * scal[2], and loss = -scal[0] / rows + kl0[0] / num_data  (VariationalELBO, directional_vi.py:217,245-246).  */
+int dsvgp_step_epilogue(dsvgp_ctx* ctx, const float* scal, const float* kl0, double rows, double num_data,
+                        const float* raw_lengthscale, const float* raw_outputscale, const float* raw_noise,
+                        float* d_hyp, float* d_raw_lengthscale, float* d_raw_outputscale, float* d_raw_noise,
+                        float* d_constant, float* loss);
 
 /* ---- kernel assembly: RBFKernelDirectionalGrad.forward (directionalvi/RBFKernelDirectionalGrad.py:41-119)
  *
@@ -104,7 +111,8 @@ int dsvgp_add_diag(dsvgp_ctx* ctx, double* A, int n, int64_t lda, double delta);
 /* ---- panel triangular solve on MFMA: TriangularLazyTensor.inv_matmul (:181,183)
  * Solves op(L) X = B for the lower-triangular fp64 L[n,n]; trans=0: op(L)=L, trans=1: op(L)=L^T.
  * B[n,nrhs] is float or double (b_is_double); X64[n,nrhs] double output (may alias B when B is
- * double); X32 optional float copy (NULL to skip).  Diagonal blocks of size nb are inverted
+ * double); X32 optional float copy (NULL to skip); X64 may be NULL when X32 is given and nb >= n
+ * (single product with the explicit inverse).  Diagonal blocks of size nb are inverted
  * (stored in the workspace) and every update is a v_mfma_f64_16x16x4 GEMM.                      */
 size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb);
 int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B,
