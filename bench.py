@@ -140,7 +140,7 @@ def main():
             cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm_kernel<double, float, false, false")]
             if cands:   # the forward solve is the largest launch of that instantiation
                 traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
-        roof = dict(bound="mfma", kernel="gemm_kernel<double,float,false,false,128,512> (panel solve L^-1 K_ZX through the transposed inverse, v_mfma_f64_16x16x4)",
+        roof = dict(bound="mfma", kernel="gemm_kernel<double,float,false,false,128,512> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                     traffic=traffic, launches=len(durs), avg_ms=avg * 1e3, flops_per_launch=flops)
 
