@@ -14,10 +14,11 @@ from . import DirectionalGradVariationalStrategy as _dgvs_mod
 from . import directional_vi  # noqa: F401
 from . import GradVariationalStrategy as _gvs_mod  # noqa: F401
 from . import grad_svgp  # noqa: F401
-from ._step import ElboEngine, NotPSDError, PARAM_NAMES  # noqa: F401
+from ._step import ElboEngine, NotPSDError, NGD_PARAM_NAMES, PARAM_NAMES  # noqa: F401
 from .directional_vi import GPModel, TrainLoop, eval_gp, select_cols_of_y, setup_training, train_gp  # noqa: F401
-from .gp_shim import GaussianLikelihood, PredictiveLogLikelihood, VariationalELBO  # noqa: F401
-from .optim import FusedAdam  # noqa: F401
+from .gp_shim import (GaussianLikelihood, NaturalVariationalDistribution, PredictiveLogLikelihood,  # noqa: F401
+                      VariationalELBO)
+from .optim import NGD, FusedAdam  # noqa: F401
 from .parallel import DataParallel  # noqa: F401
 
 __version__ = "0.1.0"

@@ -27,6 +27,12 @@ CHOL_TRIES = 3        # psd_safe_cholesky max_tries
 PARAM_NAMES = ("inducing_points", "inducing_directions", "variational_mean", "chol_variational_covar",
                "constant", "raw_outputscale", "raw_lengthscale", "raw_noise")
 
+# q(u) as a NaturalVariationalDistribution (reference directional_vi.py:35-37, use_ngd / use_ciq): same slots, the
+# gradients returned for (natural_vec, natural_mat) are those w.r.t. the expectation parameters (natural gradient)
+NGD_PARAM_NAMES = ("inducing_points", "inducing_directions", "natural_vec", "natural_mat",
+                   "constant", "raw_outputscale", "raw_lengthscale", "raw_noise")
+_NGD_RENAME = {"variational_mean": "natural_vec", "chol_variational_covar": "natural_mat"}
+
 f32, f64 = torch.float32, torch.float64
 
 
@@ -176,13 +182,20 @@ class ElboEngine:
         ``cache=True`` (eval mode) keeps the Cholesky factor and its inverted blocks across calls while the
         parameters are unchanged, like the reference's ``@cached`` ``_cholesky_factor`` (DGVS.py:72)."""
         ctx = _ops.Context.get(self.device)
-        key = tuple((t.data_ptr(), t._version) for t in (params[k] for k in PARAM_NAMES)) if cache else None
+        key = tuple((t.data_ptr(), t._version) for t in params.values()) if cache else None
         hit = cache and self._eval_cache is not None and self._eval_cache[0] == key
+        if "natural_vec" in params:
+            if hit:
+                params = self._eval_cache[5]
+            else:
+                m32, LS32, _, _ = self._natural_to_mu_chol(ctx, params["natural_vec"], params["natural_mat"])
+                params = {k: v for k, v in params.items() if not k.startswith("natural_")}
+                params["variational_mean"], params["chol_variational_covar"] = m32, LS32
         if hit:
-            _, hyp, packZ, L, dims = self._eval_cache
+            _, hyp, packZ, L, dims, _ = self._eval_cache
         else:
             hyp, packZ, L, dims = self._factor(ctx, params)
-            self._eval_cache = (key, hyp, packZ, L, dims) if cache else None
+            self._eval_cache = (key, hyp, packZ, L, dims, params) if cache else None
         _, _, _, _, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=hit)
         varn = (var + hyp[2]).clamp_min_(1e-6)
         return mu, varn
@@ -198,10 +211,93 @@ class ElboEngine:
         self._eval_cache = None
         if fast is None:
             fast = self.elbo_fast
+        nat = None
+        if "natural_vec" in params:
+            # NaturalVariationalDistribution.forward: (theta_1, theta_2) -> (mu, chol S); the step itself is unchanged
+            m32, LS32, LS64, wsS = self._natural_to_mu_chol(ctx, params["natural_vec"], params["natural_mat"])
+            nat = (m32, LS64, wsS)
+            params = {k: v for k, v in params.items() if not k.startswith("natural_")}
+            params["variational_mean"], params["chol_variational_covar"] = m32, LS32
         try:        # first attempt: potrf status read only after the forward solve has been queued
-            return self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
+            out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
         except _Refactored:
-            return self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, True)
+            out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, True)
+        if nat is not None:
+            loss, grads, mu, varn = out
+            self._natural_grads(ctx, grads, *nat)
+            out = (loss, {_NGD_RENAME.get(k, k): v for k, v in grads.items()}, mu, varn)
+        return out
+
+    # ---- q(u) in natural parameters (gpytorch 1.4.0 NaturalVariationalDistribution / _NaturalToMuVarSqrt) ----
+    def _natural_to_mu_chol(self, ctx, nat_vec, nat_mat):
+        """P = -2 theta_2 = L_P L_P^T (fp64), S = L_P^-T L_P^-1, mu = S theta_1, L_S = chol(S).
+        Returns (mu fp32, L_S fp32, L_S fp64, trsm workspace holding the inverted blocks of L_S)."""
+        Mp = nat_vec.shape[0]
+        nb = self.trsm_nb
+        P = self._get("ngd_P", (Mp, Mp), f64)
+        P.copy_(nat_mat)
+        P.mul_(-2.0)
+        info = self._get("ngd_info", (2,), torch.int32)
+        wsP = self._bytes("ngd_wsP", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
+        wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
+        pws = _ops.potrf_(ctx, P, info[0:1], self.potrf_algo)
+        _ops.trtri_blocks(ctx, P, Mp, nb, wsP, pws)
+        eye = self._buf.get("ngd_eye")
+        if eye is None or eye.shape[0] != Mp:
+            eye = self._buf["ngd_eye"] = torch.eye(Mp, dtype=f64, device=self.device)
+        X = self._get("ngd_X", (Mp, Mp), f64)
+        _ops.trsm(ctx, P, eye, False, X, None, nb, wsP, reuse_inverse=True)            # X = L_P^-1 (lower)
+        LS64 = self._get("ngd_LS64", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, X, X, LS64)                         # S = X^T X
+        m64 = self._get("ngd_m64", (Mp, 1), f64)
+        t64 = self._get("ngd_t64", (Mp, 1), f64)
+        t64.copy_(nat_vec.reshape(Mp, 1))
+        _ops.gemm(ctx, 0, LS64, t64, m64)                                               # mu = S theta_1
+        pws = _ops.potrf_(ctx, LS64, info[1:2], self.potrf_algo)                        # L_S (lower triangle)
+        _ops.trtri_blocks(ctx, LS64, Mp, nb, wsS, pws)
+        bad = info.tolist()
+        if bad[0] or bad[1]:
+            raise NotPSDError("natural_mat does not define a positive definite precision (potrf info %s)" % bad)
+        m32 = m64.reshape(Mp).to(f32)
+        LS32 = torch.tril(LS64).to(f32)
+        return m32, LS32, LS64, wsS
+
+    def _natural_grads(self, ctx, grads, m32, LS64, wsS):
+        """(dm, dL_S) -> gradients w.r.t. the expectation parameters eta_1 = mu, eta_2 = S + mu mu^T
+        (``_NaturalToMuVarSqrt.backward``): dS through the Cholesky factor, d eta_2 = dS, d eta_1 = dm - 2 dS mu.
+        In place in the slots of (dm, dL_S)."""
+        Mp = m32.shape[0]
+        dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
+        Lbar = self._get("Lbar", (Mp, Mp), f64)
+        Lbar.copy_(dLS)
+        dS = self._chol_backward(ctx, LS64, Lbar, wsS, Mp)
+        dLS.copy_(dS)
+        m64 = self._get("ngd_m64", (Mp, 1), f64)
+        t64 = self._get("ngd_t64", (Mp, 1), f64)
+        m64.copy_(m32.reshape(Mp, 1))
+        _ops.gemm(ctx, 0, dS, m64, t64)
+        dm.add_(t64.reshape(Mp).to(f32), alpha=-2.0)
+
+    def _chol_backward(self, ctx, L, Lbar, ws, Mp):
+        """K-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 (symmetric, fp64) for the lower factor L whose inverted
+        blocks are in ``ws``; L-bar (lower) is destroyed."""
+        G1 = self._get("G1", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar): Phi reads nothing else
+        _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T (mirror of the lower part)
+        Y = self._get("Y", (Mp, Mp), f64)
+        _ops.trsm(ctx, L, G1, True, Y, None, self.trsm_nb, ws, reuse_inverse=True)          # L^-T S
+        Yt = Lbar                                                           # reuse
+        _ops.transpose_f64(ctx, Y, Yt)
+        Kbar = G1                                                           # reuse
+        if self.trsm_nb >= Mp:
+            # explicit inverse in the workspace: only the lower half of the symmetric result is computed, then mirrored
+            Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
+            _ops.gemm(ctx, TRANS_A | A_UPPER | OUT_LOWER, Linv, Yt, Kbar, alpha=0.5)        # 1/2 tril(L^-T S L^-1)
+            _ops.phi_symmetrize_(ctx, Kbar)
+        else:
+            _ops.trsm(ctx, L, Yt, True, Kbar, None, self.trsm_nb, ws, reuse_inverse=True)   # L^-T S L^-1 (symmetric)
+            Kbar.mul_(0.5)
+        return Kbar
 
     def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         use_fast = mll_type == "ELBO" and fast
@@ -271,23 +367,7 @@ class ElboEngine:
             _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb64, A64, Lbar, alpha=-1.0)    # L-bar = -tril(K_ZX-bar A^T)
 
         # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 ----
-        ws = self._buf["trsm_ws"]
-        G1 = self._get("G1", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar): Phi reads nothing else
-        _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T (mirror of the lower part)
-        Y = self._get("Y", (Mp, Mp), f64)
-        _ops.trsm(ctx, L, G1, True, Y, None, self.trsm_nb, ws, reuse_inverse=True)          # L^-T S
-        Yt = Lbar                                                           # reuse
-        _ops.transpose_f64(ctx, Y, Yt)
-        Kzzbar = G1                                                         # reuse
-        if self.trsm_nb >= Mp:
-            # explicit inverse in the workspace: only the lower half of the symmetric result is computed, then mirrored
-            Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
-            _ops.gemm(ctx, TRANS_A | A_UPPER | OUT_LOWER, Linv, Yt, Kzzbar, alpha=0.5)      # 1/2 tril(L^-T S L^-1)
-            _ops.phi_symmetrize_(ctx, Kzzbar)
-        else:
-            _ops.trsm(ctx, L, Yt, True, Kzzbar, None, self.trsm_nb, ws, reuse_inverse=True) # L^-T S L^-1 (symmetric)
-            Kzzbar.mul_(0.5)
+        Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp)
 
         # ---- kernel backward: K_ZX (data side carries no gradient) and symmetric K_ZZ ----
         dZ, dV = grads["inducing_points"], grads["inducing_directions"]

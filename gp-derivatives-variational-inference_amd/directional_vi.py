@@ -11,7 +11,8 @@ What is different underneath (MI355X-first):
     per-iteration LR schedulers as the reference (:251-254);
   * under ``torch.distributed`` (one process per GPU) every global minibatch is sharded by rows and
     gradients are reduced with one RCCL all-reduce (``parallel.DataParallel``).
-NGD / CIQ variants (``use_ngd`` / ``use_ciq``) are outside this hot path and raise.
+``use_ngd=True`` swaps q(u) for a NaturalVariationalDistribution stepped by ``optim.NGD`` (reference :35-37,186-187) on the
+same engine; ``use_ciq`` is not built yet and raises.
 """
 import random
 import sys
@@ -24,8 +25,8 @@ from . import _ops
 from .DirectionalGradVariationalStrategy import DirectionalGradVariationalStrategy
 from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
-                      PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
-from .optim import FusedAdam
+                      NaturalVariationalDistribution, PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
+from .optim import NGD, FusedAdam
 from .parallel import DataParallel
 
 
@@ -35,9 +36,12 @@ class GPModel(ApproximateGP):
         self.num_inducing = len(inducing_points)
         self.num_directions = int(len(inducing_directions) / self.num_inducing)  # num directions per point
         num_directional_derivs = self.num_directions * self.num_inducing
-        if kwargs.get("variational_distribution") == "NGD" or kwargs.get("variational_strategy") == "CIQ":
-            raise NotImplementedError("NGD / CIQ variants are outside the MI355X DSVGP hot path (SURVEY.md 8f)")
-        variational_distribution = CholeskyVariationalDistribution(self.num_inducing + num_directional_derivs)
+        if kwargs.get("variational_strategy") == "CIQ":
+            raise NotImplementedError("the CIQ strategy is not built yet (SURVEY.md 8f rank 3)")
+        if kwargs.get("variational_distribution") == "NGD":                       # :35-37
+            variational_distribution = NaturalVariationalDistribution(self.num_inducing + num_directional_derivs)
+        else:
+            variational_distribution = CholeskyVariationalDistribution(self.num_inducing + num_directional_derivs)
         variational_strategy = DirectionalGradVariationalStrategy(
             self, inducing_points, inducing_directions, variational_distribution,
             learn_inducing_locations=learn_inducing_locations)
@@ -53,13 +57,19 @@ class GPModel(ApproximateGP):
         vd = vs._variational_distribution
         raw_noise = (likelihood.noise_covar.raw_noise if likelihood is not None
                      else torch.zeros(1, device=vs.inducing_points.device))
-        return [vs.inducing_points, vs.inducing_directions, vd.variational_mean, vd.chol_variational_covar,
-                self.mean_module.constant, self.covar_module.raw_outputscale,
-                self.covar_module.base_kernel.raw_lengthscale, raw_noise]
+        q = ([vd.natural_vec, vd.natural_mat] if isinstance(vd, NaturalVariationalDistribution)
+             else [vd.variational_mean, vd.chol_variational_covar])
+        return [vs.inducing_points, vs.inducing_directions] + q + [
+            self.mean_module.constant, self.covar_module.raw_outputscale,
+            self.covar_module.base_kernel.raw_lengthscale, raw_noise]
+
+    def _param_names(self):
+        from ._step import NGD_PARAM_NAMES, PARAM_NAMES
+        ngd = isinstance(self.variational_strategy._variational_distribution, NaturalVariationalDistribution)
+        return NGD_PARAM_NAMES if ngd else PARAM_NAMES
 
     def _param_dict(self, likelihood=None):
-        from ._step import PARAM_NAMES
-        return {k: v.detach() for k, v in zip(PARAM_NAMES, self._param_list(likelihood))}
+        return {k: v.detach() for k, v in zip(self._param_names(), self._param_list(likelihood))}
 
 
 def select_cols_of_y(y_batch, minibatch_dim, dim):
@@ -150,7 +160,8 @@ class TrainLoop:
 
 def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_size=1, minibatch_dim=1,
                    num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True, lr_sched=None,
-                   mll_type="ELBO", gamma=0.1, fixed_inducing_locations=None, seed=None, tensors=None):
+                   mll_type="ELBO", gamma=0.1, fixed_inducing_locations=None, seed=None, tensors=None,
+                   use_ngd=False, learning_rate_ngd=0.1):
     """Everything ``train_gp`` does before its loop (directional_vi.py:130-219); returns a TrainLoop."""
     assert num_directions == minibatch_dim
     if not torch.cuda.is_available():
@@ -174,7 +185,11 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         inducing_points = fixed_inducing_locations.to(device)
         learn_inducing_locations = False
 
-    model = GPModel(inducing_points, inducing_directions, dim, learn_inducing_locations=learn_inducing_locations)
+    if use_ngd:                                                           # :166-167
+        model = GPModel(inducing_points, inducing_directions, dim, variational_distribution="NGD",
+                        learn_inducing_locations=learn_inducing_locations)
+    else:
+        model = GPModel(inducing_points, inducing_directions, dim, learn_inducing_locations=learn_inducing_locations)
     likelihood = GaussianLikelihood()
     model = model.to(device)
     likelihood = likelihood.to(device)
@@ -200,7 +215,10 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         for t in model._param_list(likelihood):
             dist.broadcast(t.data, 0)
 
-    variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
+    if use_ngd:                                                           # :186-187
+        variational_optimizer = NGD(list(model.variational_parameters()), num_data=num_data, lr=learning_rate_ngd)
+    else:
+        variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
     hyperparameter_optimizer = FusedAdam([
         {"params": list(model.hyperparameters())},
         {"params": list(likelihood.parameters())},
@@ -249,11 +267,12 @@ def train_gp(train_dataset, num_inducing=128,
       ``max_steps`` (int): stop after this many optimisation steps.
     """
     assert num_directions == minibatch_dim
-    if use_ngd or use_ciq:
-        raise NotImplementedError("NGD / CIQ variants are outside the MI355X DSVGP hot path (SURVEY.md 8f)")
+    if use_ciq:
+        raise NotImplementedError("use_ciq (contour-integral-quadrature whitening) is not built yet (SURVEY.md 8f rank 3)")
     loop = setup_training(train_dataset, num_inducing, num_directions, minibatch_size, minibatch_dim, num_epochs,
                           learning_rate_hypers, inducing_data_initialization, lr_sched, mll_type, gamma,
-                          fixed_inducing_locations, seed=args.get("seed"))
+                          fixed_inducing_locations, seed=args.get("seed"), use_ngd=use_ngd,
+                          learning_rate_ngd=learning_rate_ngd)
     n_samples = loop.X.shape[0]
     max_steps = args.get("max_steps")
     total_step = 0

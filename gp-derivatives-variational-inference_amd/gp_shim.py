@@ -8,7 +8,7 @@ and route the arithmetic to the HIP engine (``_step.ElboEngine``).  They contain
 """
 import torch
 
-from ._step import ElboEngine, PARAM_NAMES
+from ._step import ElboEngine, NGD_PARAM_NAMES, PARAM_NAMES
 
 
 class ConstantMean(torch.nn.Module):
@@ -75,17 +75,37 @@ class CholeskyVariationalDistribution(_VariationalDistribution):
                                                         device=self.variational_mean.device))
 
 
+class NaturalVariationalDistribution(_VariationalDistribution):
+    """gpytorch.variational.NaturalVariationalDistribution (1.4.0): q(u) = N(m, S) held in natural parameters
+    ``natural_vec`` = S^-1 m (init 0) and ``natural_mat`` = -S^-1 / 2 (init -I/2).  The gradients the engine returns
+    for them are taken w.r.t. the expectation parameters, so ``optim.NGD`` performs natural gradient descent
+    (reference directional_vi.py:35-37,186-187)."""
+
+    def __init__(self, num_inducing_points, mean_init_std=1e-3):
+        super().__init__()
+        self.mean_init_std = mean_init_std
+        self.register_parameter("natural_vec", torch.nn.Parameter(torch.zeros(num_inducing_points)))
+        self.register_parameter("natural_mat", torch.nn.Parameter(torch.eye(num_inducing_points).mul_(-0.5)))
+
+    def initialize_variational_distribution(self):
+        """prior N(0, I): natural_vec <- P 0 + mean_init_std * randn, natural_mat <- -P / 2 with P = I."""
+        with torch.no_grad():
+            self.natural_vec.zero_()
+            self.natural_vec.add_(torch.randn_like(self.natural_vec), alpha=self.mean_init_std)
+            self.natural_mat.copy_(torch.eye(self.natural_vec.shape[0], device=self.natural_vec.device).mul_(-0.5))
+
+
 class _ElboFunction(torch.autograd.Function):
     """Fused forward+backward of one minibatch objective on the HIP engine."""
 
     @staticmethod
-    def forward(ctx, engine, x, y, D, num_data, mll_type, dp, *params):
-        pd = dict(zip(PARAM_NAMES, [p.detach() for p in params]))
+    def forward(ctx, engine, x, y, D, num_data, mll_type, dp, names, *params):
+        pd = dict(zip(names, [p.detach() for p in params]))
         if dp is not None:
             loss, grads, mu, varn = dp.loss_and_grads(engine, pd, x, y, D, num_data, mll_type)
         else:
             loss, grads, mu, varn = engine.loss_and_grads(pd, x, y, D, num_data, mll_type)
-        ctx.grads = [grads[k] for k in PARAM_NAMES]
+        ctx.grads = [grads[k] for k in names]
         ctx.mark_non_differentiable(mu, varn)
         return -loss, mu, varn          # mll value = -loss
 
@@ -96,7 +116,7 @@ class _ElboFunction(torch.autograd.Function):
         grads = ctx.grads
         ctx.grads = None
         torch._foreach_mul_(grads, -g_elbo.detach().to(grads[0].dtype))
-        return tuple([None] * 7 + list(grads))
+        return tuple([None] * 8 + list(grads))
 
 
 class PredictiveDistribution:
@@ -153,7 +173,7 @@ class _ApproximateMLL(torch.nn.Module):
         plist = model._param_list(self.likelihood)
         dp = getattr(model, "data_parallel", None)
         elbo, mu, varn = _ElboFunction.apply(model.engine, output.x, target, output.D, float(self.num_data),
-                                             self.mll_type, dp, *plist)
+                                             self.mll_type, dp, model._param_names(), *plist)
         # the ELBO fast path does not form per-output variances; they are produced on demand
         output._mu, output._varn = mu, (varn if varn.numel() else None)
         return elbo

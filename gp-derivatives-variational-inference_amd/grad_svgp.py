@@ -53,9 +53,12 @@ class GPModel(ApproximateGP):
                 self.mean_module.constant, self.covar_module.raw_outputscale,
                 self.covar_module.base_kernel.raw_lengthscale, raw_noise]
 
-    def _param_dict(self, likelihood=None):
+    def _param_names(self):
         from ._step import PARAM_NAMES
-        return {k: v.detach() for k, v in zip(PARAM_NAMES, self._param_list(likelihood))}
+        return PARAM_NAMES
+
+    def _param_dict(self, likelihood=None):
+        return {k: v.detach() for k, v in zip(self._param_names(), self._param_list(likelihood))}
 
 
 def train_gp(train_dataset, dim, num_inducing=128,

@@ -6,6 +6,25 @@ import torch
 from . import _ops
 
 
+class NGD(torch.optim.Optimizer):
+    """gpytorch.optim.NGD (1.4.0): ``theta <- theta - lr * num_data * grad`` on the natural parameters of a
+    NaturalVariationalDistribution, whose ``.grad`` holds the expectation-parameter gradients
+    (reference directional_vi.py:186-187)."""
+
+    def __init__(self, params, num_data, lr=0.1):
+        self.num_data = num_data
+        super().__init__(params, defaults=dict(lr=lr))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                p.add_(p.grad, alpha=(-group["lr"] * self.num_data))
+        return None
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))

@@ -196,6 +196,70 @@ def init_params(Z, V, dtype=torch.float32, mean_init_std=0.0, generator=None):
 
 
 # --------------------------------------------------------------------------------------
+# SURVEY 8f rank 3, first half: NaturalVariationalDistribution + gpytorch.optim.NGD
+# (reference directional_vi.py:35-37,164-167,186-191: ``use_ngd=True`` keeps the Cholesky-whitened
+# strategy and swaps q(u)'s parameterisation and its optimizer).  gpytorch 1.4.0, un-vendored: restated from
+# its published algorithm (Salimbeni et al. 2018, natural gradients in practice) -- parity unpinned.
+# --------------------------------------------------------------------------------------
+NGD_PARAM_NAMES = ("inducing_points", "inducing_directions", "natural_vec", "natural_mat",
+                   "constant", "raw_outputscale", "raw_lengthscale", "raw_noise")
+
+
+def natural_to_mu_chol(natural_vec, natural_mat):
+    """gpytorch ``_NaturalToMuVarSqrt.forward``: precision P = -2 theta_2 = L_P L_P^T, S = P^-1 = L_P^-T L_P^-1,
+    mu = S theta_1, and the Cholesky factor of S that CholLazyTensor wraps."""
+    P = -2.0 * natural_mat
+    L_P = torch.linalg.cholesky(0.5 * (P + P.t()))
+    X = torch.linalg.solve_triangular(L_P, torch.eye(P.shape[0], dtype=P.dtype), upper=False)
+    S = X.t() @ X
+    mu = S @ natural_vec
+    return mu, torch.linalg.cholesky(0.5 * (S + S.t()))
+
+
+def init_natural_params(Z, V, dtype=torch.float32, mean_init_std=0.0, generator=None):
+    """NaturalVariationalDistribution.initialize_variational_distribution(N(0, I)): theta_1 = noise, theta_2 = -I/2."""
+    P = init_params(Z, V, dtype, 0.0, generator)
+    Mp = P.pop("variational_mean").shape[0]
+    P.pop("chol_variational_covar")
+    nv = torch.zeros(Mp, dtype=dtype)
+    if mean_init_std:
+        nv = nv + mean_init_std * torch.randn(Mp, dtype=dtype, generator=generator)
+    P["natural_vec"] = nv
+    P["natural_mat"] = -0.5 * torch.eye(Mp, dtype=dtype)
+    return P
+
+
+def ngd_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+    """One step's loss and the gradients gpytorch hands to its optimizers when q(u) is a
+    NaturalVariationalDistribution: ordinary gradients for the hyper-parameters, and for (theta_1, theta_2) the
+    gradients with respect to the EXPECTATION parameters eta_1 = mu, eta_2 = S + mu mu^T
+    (``_NaturalToMuVarSqrt.backward``) -- stepping theta along them is natural gradient descent."""
+    mu0, LS0 = natural_to_mu_chol(params["natural_vec"].detach().double(), params["natural_mat"].detach().double())
+    dt = params["natural_vec"].dtype
+    eta1 = mu0.clone().requires_grad_(True)
+    eta2 = (LS0 @ LS0.t() + torch.outer(mu0, mu0)).requires_grad_(True)
+    S = eta2 - torch.outer(eta1, eta1)
+    L_S = torch.linalg.cholesky(0.5 * (S + S.t()))
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if not k.startswith("natural_")}
+    ps["variational_mean"] = eta1.to(dt)
+    ps["chol_variational_covar"] = L_S.to(dt)
+    loss, mu, varn = elbo_forward(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype)
+    loss.backward()
+    grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps
+             if k not in ("variational_mean", "chol_variational_covar")}
+    grads["natural_vec"] = eta1.grad.to(dt)
+    g2 = eta2.grad
+    grads["natural_mat"] = (0.5 * (g2 + g2.t())).to(dt)
+    return loss.detach(), grads, mu.detach(), varn.detach()
+
+
+def ngd_step(params, grads, num_data, lr=0.1):
+    """gpytorch.optim.NGD.step: theta <- theta - lr * num_data * grad (in place)."""
+    for k in ("natural_vec", "natural_mat"):
+        params[k].add_(grads[k], alpha=-lr * num_data)
+
+
+# --------------------------------------------------------------------------------------
 # synthetic data of the reference's smoke tests
 # --------------------------------------------------------------------------------------
 def testfun(x):
