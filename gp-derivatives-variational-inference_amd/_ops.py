@@ -321,3 +321,56 @@ def adam_step_(ctx, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, ste
             raise ValueError("adam: %s must be a contiguous float32 GPU tensor" % nm)
     check(lib.dsvgp_adam_step(ctx.h, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
                               float(lr), float(beta1), float(beta2), float(eps), int(step)), "dsvgp_adam_step")
+
+
+# ---- contour-integral-quadrature whitening (csrc/ciq.hip) ------------------------------------------------------
+def ciq_lanczos(ctx, K, v0, iters):
+    """alpha[iters], beta[iters] of `iters` Lanczos steps with the symmetric fp32 K started at v0."""
+    _req(K, f32, "K", 2)
+    n = K.shape[0]
+    alpha = torch.zeros(iters, dtype=f32, device=K.device)
+    beta = torch.zeros(iters, dtype=f32, device=K.device)
+    ws = torch.empty(3 * n + 8, dtype=f32, device=K.device)
+    check(lib.dsvgp_ciq_lanczos(ctx.h, _ptr(K), _ld(K), _ptr(_req(v0, f32, "v0", 1)), n, int(iters), _ptr(alpha),
+                                _ptr(beta), _ptr(ws)), "dsvgp_ciq_lanczos")
+    return alpha, beta
+
+
+def ciq_solve(ctx, K, R, sigma, omega, X, out, workspace, tol=1e-4, max_iter=1000, check_every=10):
+    """X[Q,t,n] = (K + sigma_q)^-1 R rows, out[t,n] = sum_q omega_q X[q]; returns the iteration count."""
+    _req(K, f32, "K", 2)
+    _req(R, f32, "R", 2)
+    t, n = R.shape
+    Q = sigma.shape[0]
+    if K.shape != (n, n) or X.shape != (Q, t, n) or out.shape != (t, n) or not X.is_contiguous():
+        raise ValueError("ciq_solve shape mismatch")
+    need = int(lib.dsvgp_ciq_workspace_bytes(Q, t, n))
+    if workspace.numel() * workspace.element_size() < need:
+        raise ValueError("ciq workspace too small")
+    its = C.c_int(0)
+    check(lib.dsvgp_ciq_solve(ctx.h, _ptr(K), _ld(K), _ptr(R), _ld(R), t, n, _ptr(_req(sigma, f32, "sigma", 1)),
+                              _ptr(_req(omega, f32, "omega", 1)), Q, float(tol), int(max_iter), int(check_every), _ptr(X),
+                              _ptr(out), _ld(out), _ptr(workspace), C.byref(its)), "dsvgp_ciq_solve")
+    return its.value
+
+
+def ciq_rowstats(ctx, T, ST, p, m, constant, hyp):
+    t, n = T.shape
+    dev = T.device
+    imean, mu, var, live = (torch.empty(t, dtype=f32, device=dev) for _ in range(4))
+    check(lib.dsvgp_ciq_rowstats(ctx.h, _ptr(T), _ptr(ST), t, n, p, _ptr(m), _ptr(constant), _ptr(hyp), _ptr(imean),
+                                 _ptr(mu), _ptr(var), _ptr(live)), "dsvgp_ciq_rowstats")
+    return imean, mu, var, live
+
+
+def ciq_tbar(ctx, T, ST, m, mu_bar, var_bar, live, imean, Tbar, VT):
+    t, n = T.shape
+    cvec = torch.empty(t, dtype=f32, device=T.device)
+    check(lib.dsvgp_ciq_tbar(ctx.h, _ptr(T), _ptr(ST), t, n, _ptr(m), _ptr(mu_bar), _ptr(var_bar), _ptr(live),
+                             _ptr(imean), _ptr(Tbar), _ptr(VT), _ptr(cvec)), "dsvgp_ciq_tbar")
+    return cvec
+
+
+def sym_average_f32(ctx, A, out):
+    check(lib.dsvgp_sym_average_f32(ctx.h, _ptr(_req(A, f32, "A", 2)), A.shape[0], _ld(A), _ptr(out), _ld(out)),
+          "dsvgp_sym_average_f32")

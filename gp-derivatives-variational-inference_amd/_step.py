@@ -61,6 +61,13 @@ class ElboEngine:
         self._side = None               # second HIP stream (work overlapped with the Cholesky chain)
         self._side_done = None
         self.overlap = True
+        # whitening: "cholesky" (DirectionalGradVariationalStrategy) or "ciq" (CiqDirectionalGradVariationalStrategy:
+        # K_ZZ^{-1/2} by contour-integral quadrature + msMINRES; needs natural parameters)
+        self.whitening = "cholesky"
+        self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
+        self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
+        self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
+        self.ciq_stats = {}                 # lmin / lmax / iterations of the last CIQ forward + backward
         self._eval_cache = None
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
@@ -182,6 +189,9 @@ class ElboEngine:
         ``cache=True`` (eval mode) keeps the Cholesky factor and its inverted blocks across calls while the
         parameters are unchanged, like the reference's ``@cached`` ``_cholesky_factor`` (DGVS.py:72)."""
         ctx = _ops.Context.get(self.device)
+        if self.whitening == "ciq":
+            _, _, mu, varn = self._ciq_step(ctx, params, x, None, D, 1.0, "ELBO", None, False, False)
+            return mu, varn
         key = tuple((t.data_ptr(), t._version) for t in params.values()) if cache else None
         hit = cache and self._eval_cache is not None and self._eval_cache[0] == key
         if "natural_vec" in params:
@@ -211,6 +221,8 @@ class ElboEngine:
         self._eval_cache = None
         if fast is None:
             fast = self.elbo_fast
+        if self.whitening == "ciq":
+            return self._ciq_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, True)
         nat = None
         if "natural_vec" in params:
             # NaturalVariationalDistribution.forward: (theta_1, theta_2) -> (mu, chol S); the step itself is unchanged
@@ -228,18 +240,31 @@ class ElboEngine:
             out = (loss, {_NGD_RENAME.get(k, k): v for k, v in grads.items()}, mu, varn)
         return out
 
+    def _alloc_grads(self, params, names):
+        """All gradients + the loss in ONE flat buffer (one fill; the data-parallel all-reduce needs no packing).
+        Returns (dict of views, loss slot, d_hyp[4])."""
+        sizes = [params[k].numel() for k in names]
+        total = sum((nk + 15) // 16 * 16 for nk in sizes)           # every segment starts 64-byte aligned
+        flat = torch.zeros(total + 1 + 4, dtype=f32, device=self.device)
+        grads, off = {}, 0
+        for k, nk in zip(names, sizes):
+            grads[k] = flat[off:off + nk].view(params[k].shape)
+            off += (nk + 15) // 16 * 16
+        self.flat = flat[:off + 1]                      # [grads (padded)..., loss]
+        return grads, flat[off:off + 1], flat[off + 1:off + 5]
+
     # ---- q(u) in natural parameters (gpytorch 1.4.0 NaturalVariationalDistribution / _NaturalToMuVarSqrt) ----
-    def _natural_to_mu_chol(self, ctx, nat_vec, nat_mat):
-        """P = -2 theta_2 = L_P L_P^T (fp64), S = L_P^-T L_P^-1, mu = S theta_1, L_S = chol(S).
-        Returns (mu fp32, L_S fp32, L_S fp64, trsm workspace holding the inverted blocks of L_S)."""
+    def _natural_moments(self, ctx, nat_vec, nat_mat):
+        """P = -2 theta_2 = L_P L_P^T (fp64), S = L_P^-T L_P^-1, mu = S theta_1.  Returns (S fp64 [M',M'], mu fp64 [M',1],
+        device status word of the factorisation)."""
         Mp = nat_vec.shape[0]
         nb = self.trsm_nb
         P = self._get("ngd_P", (Mp, Mp), f64)
         P.copy_(nat_mat)
         P.mul_(-2.0)
         info = self._get("ngd_info", (2,), torch.int32)
+        info.zero_()
         wsP = self._bytes("ngd_wsP", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
-        wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
         pws = _ops.potrf_(ctx, P, info[0:1], self.potrf_algo)
         _ops.trtri_blocks(ctx, P, Mp, nb, wsP, pws)
         eye = self._buf.get("ngd_eye")
@@ -247,12 +272,21 @@ class ElboEngine:
             eye = self._buf["ngd_eye"] = torch.eye(Mp, dtype=f64, device=self.device)
         X = self._get("ngd_X", (Mp, Mp), f64)
         _ops.trsm(ctx, P, eye, False, X, None, nb, wsP, reuse_inverse=True)            # X = L_P^-1 (lower)
-        LS64 = self._get("ngd_LS64", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, X, X, LS64)                         # S = X^T X
+        S64 = self._get("ngd_LS64", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, X, X, S64)                          # S = X^T X
         m64 = self._get("ngd_m64", (Mp, 1), f64)
         t64 = self._get("ngd_t64", (Mp, 1), f64)
         t64.copy_(nat_vec.reshape(Mp, 1))
-        _ops.gemm(ctx, 0, LS64, t64, m64)                                               # mu = S theta_1
+        _ops.gemm(ctx, 0, S64, t64, m64)                                                # mu = S theta_1
+        return S64, m64, info
+
+    def _natural_to_mu_chol(self, ctx, nat_vec, nat_mat):
+        """NaturalVariationalDistribution.forward: (theta_1, theta_2) -> mu and L_S = chol(S).
+        Returns (mu fp32, L_S fp32, L_S fp64, trsm workspace holding the inverted blocks of L_S)."""
+        Mp = nat_vec.shape[0]
+        nb = self.trsm_nb
+        LS64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)
+        wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
         pws = _ops.potrf_(ctx, LS64, info[1:2], self.potrf_algo)                        # L_S (lower triangle)
         _ops.trtri_blocks(ctx, LS64, Mp, nb, wsS, pws)
         bad = info.tolist()
@@ -277,6 +311,124 @@ class ElboEngine:
         m64.copy_(m32.reshape(Mp, 1))
         _ops.gemm(ctx, 0, dS, m64, t64)
         dm.add_(t64.reshape(Mp).to(f32), alpha=-2.0)
+
+    # ---- CIQ whitening (CiqDirectionalGradVariationalStrategy.forward with a NaturalVariationalDistribution) ----
+    def _ciq_quadrature(self, ctx, K32, v0):
+        """Eigenvalue bounds from 20 Lanczos steps (device) and the elliptic-function quadrature (host, scipy) exactly
+        as gpytorch's contour_integral_quad: K^-1/2 ~ sum_q omega_q (K + sigma_q I)^-1."""
+        import math
+        import numpy as np
+        import scipy.special
+        n = K32.shape[0]
+        iters = min(20, n)
+        alpha, beta = _ops.ciq_lanczos(ctx, K32, v0.contiguous(), iters)
+        a, b = alpha.double().cpu(), beta.double().cpu()              # host sync (40 floats)
+        Tm = torch.diag(a)
+        if iters > 1:
+            Tm = Tm + torch.diag(b[:iters - 1], 1) + torch.diag(b[:iters - 1], -1)
+        eigs = torch.linalg.eigvalsh(Tm)
+        if not torch.isfinite(eigs).all() or eigs.min() <= 0:
+            eigs = torch.diagonal(K32).double().cpu()
+        lmin, lmax = float(eigs.min()), float(eigs.max())
+        Q = int(self.ciq_num_quadrature)
+        k2 = lmin / lmax
+        Kp = scipy.special.ellipk(1.0 - k2)
+        u = (np.arange(1, Q + 1) - 0.5) * Kp / Q
+        sn, cn, dn, _ = scipy.special.ellipj(u, 1.0 - k2)
+        sigma = lmin * (sn / cn) ** 2
+        omega = 2.0 * Kp * math.sqrt(lmin) / (math.pi * Q) * dn / cn ** 2
+        self.ciq_stats.update(lmin=lmin, lmax=lmax)
+        dev = self.device
+        return (torch.tensor(sigma, dtype=f32, device=dev), torch.tensor(omega, dtype=f32, device=dev),
+                [float(w) for w in omega])
+
+    def _ciq_step(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, want_grads):
+        """One step with K_ZZ^{-1/2} whitening by CIQ (reference CiqDirectionalGradVariationalStrategy.py:197-295) and the
+        NGD interpolation terms (:19-123).  Everything Krylov lives in the row layout [B', M'] (csrc/ciq.hip).
+        The KL term is NOT part of the returned loss (the reference's forward leaves it at zero, :74) but its gradient
+        reaches (natural_vec, natural_mat) (:107,117)."""
+        if "natural_vec" not in params:
+            raise NotImplementedError("the CIQ strategy is built for a NaturalVariationalDistribution (what "
+                                      "train_gp(use_ciq=True) constructs, reference directional_vi.py:164-166)")
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        Mp = M * (p + 1)
+        B = x.shape[0]
+        Bp = B * (p + 1)
+        dev = self.device
+        rows = float(Bp if global_rows is None else global_rows)
+        nat_vec, nat_mat = params["natural_vec"], params["natural_mat"]
+        hyp = _ops.hyp_forward(ctx, params["raw_lengthscale"], params["raw_outputscale"], params["raw_noise"])
+        self.center = _ops.column_mean(ctx, Z.contiguous())
+        packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp, self.center)
+        packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        K32 = self._get("ciq_K", (Mp, Mp), f32)
+        _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=K32)         # :230-234
+        Rrow = self._get("ciq_R", (Bp, Mp), f32)                                                 # K_XZ = K_ZX^T, one RHS per row
+        _ops.kernel_fwd(ctx, packX, B, packZ, M, d, p, hyp, out=Rrow)
+        sigma, omega, omega_host = self._ciq_quadrature(ctx, K32, Rrow[0])
+        Q = sigma.shape[0]
+        X = self._get("ciq_X", (Q, Bp, Mp), f32)
+        Trow = self._get("ciq_T", (Bp, Mp), f32)
+        ws = self._bytes("ciq_ws", _lib.lib.dsvgp_ciq_workspace_bytes(Q, Bp, Mp))
+        its = _ops.ciq_solve(ctx, K32, Rrow, sigma, omega, X, Trow, ws, self.ciq_tolerance, self.ciq_max_iter)   # :255-256
+        self.ciq_stats.update(iterations=its)
+        # natural parameters -> S, m (the reference's preconditioned CG on the precision, :51-61, as a direct fp64 solve)
+        S64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)
+        if int(info[0].item()) != 0:
+            raise NotPSDError("natural_mat does not define a positive definite precision")
+        S32 = self._get("ciq_S32", (Mp, Mp), f32)
+        S32.copy_(S64)
+        m32 = m64.reshape(Mp).to(f32)
+        STrow = self._get("ciq_ST", (Bp, Mp), f32)
+        _ops.gemm(ctx, 0, Trow, S32, STrow)                                                      # (S T)^T = T^T S
+        imean, mu, var, live = _ops.ciq_rowstats(ctx, Trow, STrow, p, m32, params["constant"].reshape(-1), hyp)   # :65-69,265-266
+        mu_bar = torch.empty(Bp, dtype=f32, device=dev)
+        var_bar = torch.empty(Bp, dtype=f32, device=dev)
+        varn = torch.empty(Bp, dtype=f32, device=dev)
+        scal = torch.empty(8, dtype=f32, device=dev)
+        if not want_grads:
+            noise = hyp[2]
+            return None, None, mu, (var + noise).clamp_min_(1e-6)
+        _ops.likelihood_terms(ctx, mu, var, y.contiguous(), p, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar, var_bar,
+                              varn, scal)
+        grads, loss_out, d_hyp = self._alloc_grads(params, NGD_PARAM_NAMES)
+        Tbar = self._get("ciq_Tbar", (Bp, Mp), f32)
+        VT = self._get("ciq_VT", (Bp, Mp), f32)
+        cvec = _ops.ciq_tbar(ctx, Trow, STrow, m32, mu_bar, var_bar, live, imean, Tbar, VT)       # :94-96
+        kl_bar = (1.0 / float(num_data)) if include_kl else 0.0
+        d1 = grads["natural_vec"].reshape(1, Mp)
+        _ops.gemm(ctx, 0, cvec.reshape(1, Bp), Trow, d1)                                          # :102-106
+        d1.add_(nat_vec.reshape(1, Mp), alpha=kl_bar)                                             # :107
+        d2 = grads["natural_mat"]
+        _ops.gemm(ctx, TRANS_A, VT, Trow, d2)                                                     # :115-116
+        d2.add_(nat_mat, alpha=kl_bar)                                                            # kl/2 (I - prec), prec = -2 theta_2
+        d2.diagonal().add_(0.5 * kl_bar)
+        # backward of sqrt_inv_matmul: dR = K^-1/2 Tbar, dK = -sym sum_q omega_q Y_q^T X_q (same quadrature)
+        Y = self._get("ciq_Y", (Q, Bp, Mp), f32)
+        Rbar = self._get("ciq_Rbar", (Bp, Mp), f32)
+        its_b = _ops.ciq_solve(ctx, K32, Tbar, sigma, omega, Y, Rbar, ws, self.ciq_tolerance, self.ciq_max_iter)
+        self.ciq_stats.update(iterations_backward=its_b)
+        dK = self._get("ciq_dK", (Mp, Mp), f32)
+        dK.zero_()
+        for q in range(Q):
+            _ops.gemm(ctx, TRANS_A, Y[q], X[q], dK, alpha=-omega_host[q], beta=1.0, Cin=dK)
+        Kzzbar = self._get("ciq_Kzzbar", (Mp, Mp), f32)
+        _ops.sym_average_f32(ctx, dK, Kzzbar)
+        Kb32 = self._get("Kb32", (Mp, Bp), f32)
+        _ops.transpose_f32(ctx, Rbar, Kb32)
+        dZ, dV = grads["inducing_points"], grads["inducing_directions"]
+        kws = self._bytes("kbwd_ws", max(_lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p),
+                                         _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, M, d, p)))
+        _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
+        _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
+        kl0 = torch.zeros(1, dtype=f32, device=dev)                                               # :74
+        _ops.step_epilogue(ctx, scal, kl0, rows, num_data, params["raw_lengthscale"].reshape(-1),
+                           params["raw_outputscale"].reshape(-1), params["raw_noise"].reshape(-1), d_hyp,
+                           grads["raw_lengthscale"].reshape(-1), grads["raw_outputscale"].reshape(-1),
+                           grads["raw_noise"].reshape(-1), grads["constant"].reshape(-1), loss_out)
+        return loss_out[0], grads, mu, varn
 
     def _chol_backward(self, ctx, L, Lbar, ws, Mp):
         """K-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 (symmetric, fp64) for the lower factor L whose inverted
@@ -318,17 +470,7 @@ class ElboEngine:
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
         dev = self.device
-        # all gradients + the loss live in ONE flat buffer: one fill, and the data-parallel all-reduce needs no packing
-        sizes = [params[k].numel() for k in PARAM_NAMES]
-        total = sum((nk + 15) // 16 * 16 for nk in sizes)           # every segment starts 64-byte aligned
-        flat = torch.zeros(total + 1 + 4, dtype=f32, device=dev)
-        grads, off = {}, 0
-        for k, nk in zip(PARAM_NAMES, sizes):
-            grads[k] = flat[off:off + nk].view(params[k].shape)
-            off += (nk + 15) // 16 * 16
-        self.flat = flat[:off + 1]                      # [grads (padded)..., loss]
-        loss_out = flat[off:off + 1]
-        d_hyp = flat[off + 1:off + 5]
+        grads, loss_out, d_hyp = self._alloc_grads(params, PARAM_NAMES)
         dLS, dm = grads["chol_variational_covar"], grads["variational_mean"]
         scal = torch.empty(8, dtype=f32, device=dev)
         kl_buf = torch.zeros(Mp + 1, dtype=f32, device=dev)

@@ -12,7 +12,8 @@ What is different underneath (MI355X-first):
   * under ``torch.distributed`` (one process per GPU) every global minibatch is sharded by rows and
     gradients are reduced with one RCCL all-reduce (``parallel.DataParallel``).
 ``use_ngd=True`` swaps q(u) for a NaturalVariationalDistribution stepped by ``optim.NGD`` (reference :35-37,186-187) on the
-same engine; ``use_ciq`` is not built yet and raises.
+same engine; ``use_ciq=True`` additionally whitens with K_ZZ^{-1/2} by contour-integral quadrature + msMINRES
+(``CiqDirectionalGradVariationalStrategy``, ``csrc/ciq.hip``).
 """
 import random
 import sys
@@ -22,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import _ops
+from .CiqDirectionalGradVariationalStrategy import CiqDirectionalGradVariationalStrategy
 from .DirectionalGradVariationalStrategy import DirectionalGradVariationalStrategy
 from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
@@ -36,20 +38,36 @@ class GPModel(ApproximateGP):
         self.num_inducing = len(inducing_points)
         self.num_directions = int(len(inducing_directions) / self.num_inducing)  # num directions per point
         num_directional_derivs = self.num_directions * self.num_inducing
-        if kwargs.get("variational_strategy") == "CIQ":
-            raise NotImplementedError("the CIQ strategy is not built yet (SURVEY.md 8f rank 3)")
         if kwargs.get("variational_distribution") == "NGD":                       # :35-37
             variational_distribution = NaturalVariationalDistribution(self.num_inducing + num_directional_derivs)
         else:
             variational_distribution = CholeskyVariationalDistribution(self.num_inducing + num_directional_derivs)
-        variational_strategy = DirectionalGradVariationalStrategy(
-            self, inducing_points, inducing_directions, variational_distribution,
-            learn_inducing_locations=learn_inducing_locations)
+        self._ciq = kwargs.get("variational_strategy") == "CIQ"
+        if self._ciq:                                                             # :46-48
+            variational_strategy = CiqDirectionalGradVariationalStrategy(
+                self, inducing_points, inducing_directions, variational_distribution,
+                learn_inducing_locations=learn_inducing_locations)
+        else:
+            variational_strategy = DirectionalGradVariationalStrategy(
+                self, inducing_points, inducing_directions, variational_distribution,
+                learn_inducing_locations=learn_inducing_locations)
         self.variational_strategy = variational_strategy
         self._engine = None
         self.data_parallel = None
         self.mean_module = ConstantMean()
         self.covar_module = ScaleKernel(RBFKernelDirectionalGrad())
+        if self._ciq:
+            # stable initialization of lengthscale for CIQ (:58-60): lengthscale = 1 / num_inducing through the
+            # inverse of the softplus constraint
+            ell = torch.tensor(1.0 / self.num_inducing)
+            with torch.no_grad():
+                self.covar_module.base_kernel.raw_lengthscale.fill_(float(torch.log(torch.expm1(ell))))
+
+    @property
+    def engine(self):
+        eng = ApproximateGP.engine.fget(self)
+        eng.whitening = "ciq" if self._ciq else "cholesky"
+        return eng
 
     # --- parameter plumbing for the HIP engine (order = _step.PARAM_NAMES) ---
     def _param_list(self, likelihood=None):
@@ -161,7 +179,7 @@ class TrainLoop:
 def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_size=1, minibatch_dim=1,
                    num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True, lr_sched=None,
                    mll_type="ELBO", gamma=0.1, fixed_inducing_locations=None, seed=None, tensors=None,
-                   use_ngd=False, learning_rate_ngd=0.1):
+                   use_ngd=False, learning_rate_ngd=0.1, use_ciq=False, num_contour_quadrature=15):
     """Everything ``train_gp`` does before its loop (directional_vi.py:130-219); returns a TrainLoop."""
     assert num_directions == minibatch_dim
     if not torch.cuda.is_available():
@@ -185,7 +203,10 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         inducing_points = fixed_inducing_locations.to(device)
         learn_inducing_locations = False
 
-    if use_ngd:                                                           # :166-167
+    if use_ciq:                                                           # :164-165
+        model = GPModel(inducing_points, inducing_directions, dim, variational_distribution="NGD",
+                        variational_strategy="CIQ", learn_inducing_locations=learn_inducing_locations)
+    elif use_ngd:                                                         # :166-167
         model = GPModel(inducing_points, inducing_directions, dim, variational_distribution="NGD",
                         learn_inducing_locations=learn_inducing_locations)
     else:
@@ -210,12 +231,14 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         perm_gen.manual_seed(seed)
     else:
         perm_gen.seed()
+    if use_ciq:
+        model.engine.ciq_num_quadrature = int(num_contour_quadrature)    # gpytorch.settings.num_contour_quadrature, :165
     model.variational_strategy._maybe_init()                              # q(u) <- N(0,I) + 1e-3 randn (first call)
     if dp is not None:   # identical initial state on every rank
         for t in model._param_list(likelihood):
             dist.broadcast(t.data, 0)
 
-    if use_ngd:                                                           # :186-187
+    if use_ngd or use_ciq:                                                # :186-187
         variational_optimizer = NGD(list(model.variational_parameters()), num_data=num_data, lr=learning_rate_ngd)
     else:
         variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
@@ -267,12 +290,11 @@ def train_gp(train_dataset, num_inducing=128,
       ``max_steps`` (int): stop after this many optimisation steps.
     """
     assert num_directions == minibatch_dim
-    if use_ciq:
-        raise NotImplementedError("use_ciq (contour-integral-quadrature whitening) is not built yet (SURVEY.md 8f rank 3)")
     loop = setup_training(train_dataset, num_inducing, num_directions, minibatch_size, minibatch_dim, num_epochs,
                           learning_rate_hypers, inducing_data_initialization, lr_sched, mll_type, gamma,
                           fixed_inducing_locations, seed=args.get("seed"), use_ngd=use_ngd,
-                          learning_rate_ngd=learning_rate_ngd)
+                          learning_rate_ngd=learning_rate_ngd, use_ciq=use_ciq,
+                          num_contour_quadrature=num_contour_quadrature)
     n_samples = loop.X.shape[0]
     max_steps = args.get("max_steps")
     total_step = 0

@@ -206,6 +206,29 @@ int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_
                     float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step);
 
+/* ---- contour-integral-quadrature whitening: lazify(K_ZZ).sqrt_inv_matmul(K_ZX)
+ * (directionalvi/CiqDirectionalGradVariationalStrategy.py:255-256; quadrature + msMINRES of gpytorch 1.4.0
+ * utils/contour_integral_quad.py, utils/minres.py).  Layout: one right-hand side per ROW, R[t, n], K[n, n] symmetric.
+ * dsvgp_ciq_lanczos: `iters` Lanczos steps from v0 -> alpha[iters], beta[iters] (host takes the Ritz values of the
+ *   tridiagonal as eigenvalue bounds, max_lanczos_iter = 20).  workspace: 3 n + 2 floats.
+ * dsvgp_ciq_solve: X[Q, t, n] = (K + sigma_q I)^-1 R for all shifts from one Lanczos process per row, and
+ *   out[t, n] = sum_q omega_q X[q]; stops when the mean of |update| / |solution| over (shift, row) < tol, tested every
+ *   `check_every` iterations (gpytorch: tol 1e-4, every 10, at most 1000).  workspace: dsvgp_ciq_workspace_bytes.
+ * dsvgp_ciq_rowstats / dsvgp_ciq_tbar: the mean / variance interpolation terms of _NgdInterpTerms (:65-69,265-266)
+ *   and the gradient factors of its backward (:94-118) for rows of T = (K^-1/2 K_ZX)^T and ST = T S.
+ * dsvgp_sym_average_f32: out = (A + A^T) / 2.                                                                  */
+size_t dsvgp_ciq_workspace_bytes(int Q, int t, int n);
+int dsvgp_ciq_lanczos(dsvgp_ctx* ctx, const float* K, int64_t ldk, const float* v0, int n, int iters, float* alpha,
+                      float* beta, void* workspace);
+int dsvgp_ciq_solve(dsvgp_ctx* ctx, const float* K, int64_t ldk, const float* R, int64_t ldr, int t, int n,
+                    const float* sigma, const float* omega, int Q, float tol, int max_iter, int check_every, float* X,
+                    float* out, int64_t ldo, void* workspace, int* iters_out);
+int dsvgp_ciq_rowstats(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, int p, const float* m,
+                       const float* constant, const float* hyp, float* imean, float* mu, float* var, float* live);
+int dsvgp_ciq_tbar(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, const float* m, const float* mu_bar,
+                   const float* var_bar, const float* live, const float* imean, float* Tbar, float* VT, float* cvec);
+int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, float* out, int64_t ldo);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,6 +260,236 @@ def ngd_step(params, grads, num_data, lr=0.1):
 
 
 # --------------------------------------------------------------------------------------
+# SURVEY 8f rank 3, second half: CIQ whitening (reference CiqDirectionalGradVariationalStrategy.py:197-295,
+# ``use_ciq=True``): interp_term = K_ZZ^{-1/2} K_ZX by contour-integral quadrature + msMINRES, and the NGD
+# interpolation terms of ``_NgdInterpTerms`` (:19-123).  The quadrature / msMINRES / custom backward live in
+# gpytorch 1.4.0 (``utils/contour_integral_quad.py``, ``utils/minres.py``, ``functions/_sqrt_inv_matmul.py``),
+# un-vendored: restated from the published algorithm (Pleiss et al. 2020; Hale, Higham & Trefethen 2008,
+# method 3; Paige & Saunders MINRES with shifts) -- parity unpinned.
+# --------------------------------------------------------------------------------------
+NUM_CONTOUR_QUADRATURE = 15   # train_gp(num_contour_quadrature=15), reference directional_vi.py:101,165
+MINRES_TOLERANCE = 1e-4       # gpytorch settings.minres_tolerance
+MAX_MINRES_ITER = 1000        # gpytorch settings.max_cg_iterations
+MAX_LANCZOS_ITER = 20         # contour_integral_quad(max_lanczos_iter=20)
+
+
+def lanczos_eig_bounds(K, v0, iters=MAX_LANCZOS_ITER):
+    """Extreme Ritz values of ``iters`` Lanczos steps started at v0 (what contour_integral_quad's
+    linear_cg(n_tridiag=1) tridiagonal yields); falls back to diag(K) when they are not positive."""
+    n = K.shape[0]
+    iters = min(iters, n)
+    q_prev = torch.zeros_like(v0)
+    q = v0 / v0.norm()
+    beta = 0.0
+    alphas, betas = [], []
+    for k in range(iters):
+        w = K @ q - beta * q_prev
+        alpha = torch.dot(q, w)
+        w = w - alpha * q
+        alphas.append(alpha)
+        beta = w.norm()
+        if k + 1 < iters:
+            if float(beta) < 1e-12 * float(abs(alpha)):
+                break
+            betas.append(beta)
+            q_prev, q = q, w / beta
+    a = torch.stack(alphas)
+    T = torch.diag(a)
+    if len(alphas) > 1:
+        b = torch.stack(betas[:len(alphas) - 1])
+        T = T + torch.diag(b, 1) + torch.diag(b, -1)
+    eigs = torch.linalg.eigvalsh(T)
+    if eigs.min() <= 0:
+        eigs = torch.diagonal(K)
+    return float(eigs.min()), float(eigs.max())
+
+
+def ciq_quadrature(lmin, lmax, Q=NUM_CONTOUR_QUADRATURE):
+    """K^{-1/2} ~= sum_q omega_q (K + sigma_q I)^-1 on [lmin, lmax] (HHT method 3 through Jacobi elliptic functions,
+    as contour_integral_quad does with scipy): sigma_q = lmin sn^2/cn^2, omega_q = 2 K' sqrt(lmin) dn / (pi Q cn^2)."""
+    import numpy as np
+    import scipy.special
+    k2 = lmin / lmax
+    Kp = scipy.special.ellipk(1.0 - k2)
+    u = (np.arange(1, Q + 1) - 0.5) * Kp / Q
+    sn, cn, dn, _ = scipy.special.ellipj(u, 1.0 - k2)
+    sigma = lmin * (sn / cn) ** 2
+    omega = 2.0 * Kp * math.sqrt(lmin) / (math.pi * Q) * dn / cn ** 2
+    return torch.tensor(sigma, dtype=torch.float64), torch.tensor(omega, dtype=torch.float64)
+
+
+def msminres(K, R, sigma, tol=MINRES_TOLERANCE, max_iter=MAX_MINRES_ITER):
+    """Shifted MINRES: X[q] = (K + sigma_q I)^-1 R for all shifts from ONE Lanczos process per right-hand side
+    (gpytorch.utils.minres).  Columns are normalised first; convergence = mean over (shift, column) of
+    |last update| / |solution| < tol, tested every 10 iterations."""
+    n, t = R.shape
+    Q = sigma.shape[0]
+    dt = R.dtype
+    sig = sigma.to(dt).reshape(Q, 1)
+    rnorm = R.norm(dim=0)
+    rnorm = torch.where(rnorm < 1e-10, torch.ones_like(rnorm), rnorm)
+    q_prev = torch.zeros_like(R)
+    q = R / rnorm
+    beta = torch.ones(t, dtype=dt)              # beta_1 of the normalised system
+    cs = -torch.ones(Q, t, dtype=dt)
+    sn = torch.zeros(Q, t, dtype=dt)
+    dbar = torch.zeros(Q, t, dtype=dt)
+    eps = torch.zeros(Q, t, dtype=dt)
+    phibar = torch.ones(Q, t, dtype=dt)
+    w1 = torch.zeros(Q, n, t, dtype=dt)
+    w2 = torch.zeros(Q, n, t, dtype=dt)
+    X = torch.zeros(Q, n, t, dtype=dt)
+    beta_prev = torch.zeros(t, dtype=dt)
+    its = 0
+    for it in range(max_iter):
+        its = it + 1
+        v = K @ q - beta_prev * q_prev
+        alpha = (q * v).sum(0)
+        v = v - alpha * q
+        beta_next = v.norm(dim=0)
+        # Paige-Saunders recurrences, one set per shift
+        alfa = alpha.unsqueeze(0) + sig
+        oldeps = eps
+        delta = cs * dbar + sn * alfa
+        gbar = sn * dbar - cs * alfa
+        eps = sn * beta_next
+        dbar = -cs * beta_next
+        gamma = torch.sqrt(gbar * gbar + beta_next * beta_next).clamp_min(1e-30)
+        cs = gbar / gamma
+        sn = beta_next / gamma
+        phi = cs * phibar
+        phibar = sn * phibar
+        w = (q.unsqueeze(0) - oldeps.unsqueeze(1) * w1 - delta.unsqueeze(1) * w2) / gamma.unsqueeze(1)
+        upd = phi.unsqueeze(1) * w
+        X = X + upd
+        w1, w2 = w2, w
+        if (it + 1) % 10 == 0 or it + 1 == max_iter:
+            conv = (upd.norm(dim=1) / X.norm(dim=1).clamp_min(1e-30)).mean()
+            if float(conv) < tol:
+                break
+        safe = beta_next.clamp_min(1e-30)
+        q_prev, q = q, v / safe
+        beta_prev = beta_next
+    return X * rnorm, its
+
+
+class _SqrtInvMatmul(torch.autograd.Function):
+    """T = K^{-1/2} R by CIQ; backward re-uses the quadrature: dR = K^{-1/2} G, dK = -sym sum_q omega_q Y_q X_q^T with
+    X_q = (K + sigma_q)^-1 R, Y_q = (K + sigma_q)^-1 G (gpytorch functions/_sqrt_inv_matmul.py)."""
+
+    @staticmethod
+    def forward(ctx, K, R, Q, stats):
+        with torch.no_grad():
+            lmin, lmax = lanczos_eig_bounds(K, R[:, 0])
+            sigma, omega = ciq_quadrature(lmin, lmax, Q)
+            X, its = msminres(K, R, sigma)
+            T = (omega.to(R.dtype).reshape(-1, 1, 1) * X).sum(0)
+        ctx.save_for_backward(K, X)
+        ctx.quad = (sigma, omega)
+        if stats is not None:
+            stats.update(lmin=lmin, lmax=lmax, iterations=its, sigma=sigma, omega=omega)
+        return T
+
+    @staticmethod
+    def backward(ctx, G):
+        K, X = ctx.saved_tensors
+        sigma, omega = ctx.quad
+        with torch.no_grad():
+            Y, _ = msminres(K, G.contiguous(), sigma)
+            om = omega.to(G.dtype).reshape(-1, 1, 1)
+            dR = (om * Y).sum(0)
+            dK = -torch.einsum("qik,qjk->ij", om * Y, X)
+            dK = 0.5 * (dK + dK.t())
+        return dK, dR, None, None
+
+
+def sqrt_inv_matmul(K, R, Q=NUM_CONTOUR_QUADRATURE, stats=None):
+    return _SqrtInvMatmul.apply(K, R, Q, stats)
+
+
+def sqrt_inv_matmul_exact(K, R):
+    """K^{-1/2} R through the symmetric eigendecomposition (differentiable): what CIQ approximates."""
+    lam, U = torch.linalg.eigh(0.5 * (K + K.t()))
+    return U @ ((U.t() @ R) / lam.sqrt().unsqueeze(1))
+
+
+class _NgdInterpTermsFn(torch.autograd.Function):
+    """reference CiqDirectionalGradVariationalStrategy.py:19-123: mean / variance interpolation terms from the
+    natural parameters; the gradients returned for (natural_vec, natural_mat) are those w.r.t. the expectation
+    parameters.  The reference's preconditioned linear_cg on the precision is restated as a direct solve."""
+
+    @staticmethod
+    def forward(ctx, interp_term, natural_vec, natural_mat):
+        prec = natural_mat * -2.0                                             # :41
+        sol = torch.linalg.solve(prec, torch.cat([natural_vec.unsqueeze(-1), interp_term], dim=-1))   # :51-59
+        expec_vec, s_times = sol[:, 0], sol[:, 1:]                            # :60-61
+        interp_mean = s_times.t() @ natural_vec                               # :65
+        interp_var = (s_times * interp_term).sum(0)                           # :69
+        kl_div = torch.zeros((), dtype=interp_term.dtype)                     # :74 (not computed in the forward pass)
+        ctx.save_for_backward(interp_term, s_times, interp_mean, natural_vec, expec_vec, prec)
+        return interp_mean, interp_var, kl_div
+
+    @staticmethod
+    def backward(ctx, g_mean, g_var, g_kl):
+        interp_term, s_times, interp_mean, natural_vec, expec_vec, prec = ctx.saved_tensors
+        gm, gv = g_mean.unsqueeze(0), g_var.unsqueeze(0)
+        d_interp = 2.0 * gv * s_times + gm * expec_vec.unsqueeze(1)                                  # :94-96
+        d_vec = (-2.0 * (gv * interp_mean.unsqueeze(0) * interp_term).sum(1) + (gm * interp_term).sum(1)
+                 + g_kl * natural_vec)                                                                # :102-108
+        eye = torch.eye(expec_vec.shape[0], dtype=expec_vec.dtype)
+        d_mat = (gv * interp_term) @ interp_term.t() + g_kl * 0.5 * (eye - prec)                      # :115-118
+        return d_interp, d_vec, d_mat
+
+
+def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=None):
+    """CiqDirectionalGradVariationalStrategy.forward with a NaturalVariationalDistribution (:197-268).
+    Returns (mu, var, kl) with kl == 0 as in the reference's forward (:74)."""
+    Z, V = params["inducing_points"], params["inducing_directions"]
+    c = params["constant"].reshape(())
+    ell, s, _ = constrained(params)
+    M, d = Z.shape
+    p = V.shape[0] // M
+    B = x.shape[0]
+    assert D.shape[0] // B == p, "Need minibatch dim to be same as number of directions for kernel"
+    dt = x.dtype
+    K_ZX = s * kernel_matrix(Z, x, V, D, ell)                                  # :218-222
+    K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
+    K_ZZ = K_ZZ + KZZ_JITTER * torch.eye(K_ZZ.shape[0], dtype=dt)              # :230-234
+    dg = s * kernel_diag(B, p, ell).to(dt)                                     # :235-239, diag only (:265)
+    T = sqrt_inv_matmul_exact(K_ZZ, K_ZX) if exact else sqrt_inv_matmul(K_ZZ, K_ZX, Q, stats)     # :255-256
+    interp_mean, interp_var, kl = _NgdInterpTermsFn.apply(T, params["natural_vec"], params["natural_mat"])  # :261-263
+    var = (dg - (T * T).sum(0) + interp_var).clamp_min(MIN_VARIANCE)           # :265-266
+    return interp_mean + c, var, kl                                            # :126 (constant mean on all rows), :293
+
+
+def ciq_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=NUM_CONTOUR_QUADRATURE, exact=False,
+                stats=None):
+    mu, var, kl = ciq_predictive(params, x, D, Q, exact, stats)
+    _, _, noise = constrained(params)
+    Bp = y.shape[0] if global_rows is None else global_rows
+    varn = (var + noise).clamp_min(MIN_VARIANCE)
+    if mll_type == "ELBO":
+        ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+    elif mll_type == "PLL":
+        tot = (varn + noise).clamp_min(1e-8)
+        ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
+    else:
+        raise ValueError(mll_type)
+    loss = -(ll.sum() / Bp - kl / num_data)
+    return loss, mu, varn
+
+
+def ciq_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=NUM_CONTOUR_QUADRATURE,
+                       exact=False, stats=None):
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    loss, mu, varn = ciq_forward(ps, x, y, D, num_data, mll_type, global_rows, Q, exact, stats)
+    loss.backward()
+    grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps}
+    grads["natural_mat"] = 0.5 * (grads["natural_mat"] + grads["natural_mat"].t())
+    return loss.detach(), grads, mu.detach(), varn.detach()
+
+
+# --------------------------------------------------------------------------------------
 # synthetic data of the reference's smoke tests
 # --------------------------------------------------------------------------------------
 def testfun(x):

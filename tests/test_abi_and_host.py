@@ -72,8 +72,15 @@ def test_reference_api_surface(dsvgp):
     assert sd["covar_module.base_kernel.raw_lengthscale"].shape == (1, 1) and sd["covar_module.raw_outputscale"].shape == ()
     assert sd["mean_module.constant"].shape == (1,) and bool(sd["variational_strategy.updated_strategy"])
     assert len(list(m.variational_parameters())) == 2 and len(list(m.hyperparameters())) == 5
-    with pytest.raises(NotImplementedError):
-        dsvgp.GPModel(Z, V, 3, variational_strategy="CIQ")
+    # NGD / CIQ construction (reference directional_vi.py:35-37,46-48,58-60)
+    mc = dsvgp.GPModel(Z, V, 3, variational_distribution="NGD", variational_strategy="CIQ")
+    sdc = mc.state_dict()
+    assert sdc["variational_strategy._variational_distribution.natural_vec"].shape == (18,)
+    assert torch.equal(sdc["variational_strategy._variational_distribution.natural_mat"], -0.5 * torch.eye(18))
+    assert "variational_strategy.updated_strategy" not in sdc
+    ell = torch.nn.functional.softplus(sdc["covar_module.base_kernel.raw_lengthscale"])
+    assert abs(ell.item() - 1.0 / 6) < 1e-6                                # lengthscale = 1 / num_inducing
+    assert type(mc.variational_strategy).__name__ == "CiqDirectionalGradVariationalStrategy"
     with pytest.raises(AssertionError):
         m(torch.rand(4, 3), derivative_directions=torch.rand(4, 3))       # p mismatch, reference DGVS.py:106
 
