@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     "c4": dict(name="DSVGP d=20 N=1M M=500 p=5 B=4096", d=20, N=1_000_000, M=500, p=5, B=4096),
     "c2": dict(name="DSVGP d=5 N=10k M=200 p=2 B=512", d=5, N=10_000, M=200, p=2, B=512),
+    # BASELINE config 5: CIQ whitening + NGD (no dataset / batch size given there; N and B chosen like C4's per-GPU shard)
+    "c5": dict(name="CIQ-DSVGP d=50 N=100k M=1024 p=5 B=512", d=50, N=100_000, M=1024, p=5, B=512, ciq=True),
 }
 PEAK_F64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (spec)
 
@@ -92,7 +94,7 @@ def main():
     X, Y = synthetic_data(N, d, device)
     loop = dsvgp_amd.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
                                     num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True,
-                                    seed=0, tensors=(X, Y))
+                                    seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
     eng = loop.model.engine
     eng.trsm_nb = args.trsm_nb
     perm = loop.epoch_permutation()
@@ -154,7 +156,9 @@ def main():
                        "parallelism": "dp%d rows" % world, "trsm_nb": args.trsm_nb, "final_loss": final_loss},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if cfg.get("ciq"):
+            out["config"]["ciq"] = dict(eng.ciq_stats)
+        if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq"):
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
