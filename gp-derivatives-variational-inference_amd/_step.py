@@ -64,6 +64,9 @@ class ElboEngine:
         # whitening: "cholesky" (DirectionalGradVariationalStrategy) or "ciq" (CiqDirectionalGradVariationalStrategy:
         # K_ZZ^{-1/2} by contour-integral quadrature + msMINRES; needs natural parameters)
         self.whitening = "cholesky"
+        # "all": every data point carries p directional derivatives (DSVGP); "values": derivative-free data, only
+        # function values on the data side (reference DFreeDirectionalGradVariationalStrategy.py:113-136)
+        self.data_outputs = "all"
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
@@ -148,14 +151,38 @@ class ElboEngine:
         raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
                           % (self.chol_jitter * 10 ** (CHOL_TRIES - 1)))
 
+    def _pd(self, p):
+        """directional derivatives per DATA point"""
+        return 0 if self.data_outputs == "values" else p
+
+    def _assemble_kzx(self, ctx, packZ, M, packX, B, d, p, hyp, Mp):
+        """K_ZX [M', B(pd+1)].  Derivative-free data: the value columns (every (p+1)-th) of the full block matrix."""
+        if self.data_outputs == "values" and p > 0:
+            full = self._get("Kzx_full", (Mp, B * (p + 1)), f32)
+            _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=full)
+            Kzx = self._get("Kzx", (Mp, B), f32)
+            Kzx.copy_(full[:, ::p + 1])
+            return Kzx
+        Kzx = self._get("Kzx", (Mp, B * (p + 1)), f32)
+        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        return Kzx
+
+    def _kernel_bwd_zx(self, ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws):
+        if self.data_outputs == "values" and p > 0:
+            full = self._get("Kzx_full", (Kb32.shape[0], B * (p + 1)), f32)
+            full.zero_()
+            full[:, ::p + 1] = Kb32                      # derivative columns carry no gradient
+            Kb32 = full
+        _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
+
     def _interp(self, ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=False):
         """K_ZX, A = L^-1 K_ZX (fp64 + fp32 copy), W = L_S^T A, mu, var."""
         M, d, p, Mp = dims
         B = x.shape[0]
-        Bp = B * (p + 1)
+        pd = self._pd(p)
+        Bp = B * (pd + 1)
         packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
-        Kzx = self._get("Kzx", (Mp, Bp), f32)
-        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        Kzx = self._assemble_kzx(ctx, packZ, M, packX, B, d, p, hyp, Mp)
         A64 = self._get("A64", (Mp, Bp), f64)
         A32 = self._get("A32", (Mp, Bp), f32)
         need = _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp), self.trsm_nb)
@@ -178,7 +205,7 @@ class ElboEngine:
         mu = torch.empty(Bp, dtype=f32, device=self.device)
         var = torch.empty(Bp, dtype=f32, device=self.device)
         sws = self._bytes("stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, Bp))
-        _ops.predictive_stats(ctx, A32, W, p, params["variational_mean"], params["constant"].reshape(-1), hyp, mu, var,
+        _ops.predictive_stats(ctx, A32, W, pd, params["variational_mean"], params["constant"].reshape(-1), hyp, mu, var,
                               sws)
         return packX, A64, A32, W, mu, var
 
@@ -347,6 +374,8 @@ class ElboEngine:
         NGD interpolation terms (:19-123).  Everything Krylov lives in the row layout [B', M'] (csrc/ciq.hip).
         The KL term is NOT part of the returned loss (the reference's forward leaves it at zero, :74) but its gradient
         reaches (natural_vec, natural_mat) (:107,117)."""
+        if self.data_outputs != "all":
+            raise NotImplementedError("derivative-free data is built for the Cholesky-whitened strategy only")
         if "natural_vec" not in params:
             raise NotImplementedError("the CIQ strategy is built for a NaturalVariationalDistribution (what "
                                       "train_gp(use_ciq=True) constructs, reference directional_vi.py:164-166)")
@@ -456,7 +485,8 @@ class ElboEngine:
         Mz = params["inducing_points"].shape[0]
         p = params["inducing_directions"].shape[0] // Mz if Mz else 0
         B = x.shape[0]
-        Bp = B * (p + 1)
+        pd = self._pd(p)
+        Bp = B * (pd + 1)
         if y.shape != (Bp,):
             raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bp)
         rows = float(Bp if global_rows is None else global_rows)
@@ -491,7 +521,7 @@ class ElboEngine:
             mu_bar = torch.empty(Bp, dtype=f32, device=dev)
             var_bar = torch.empty(Bp, dtype=f32, device=dev)
             varn = torch.empty(Bp, dtype=f32, device=dev)
-            _ops.likelihood_terms(ctx, mu, var, y, p, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar, var_bar,
+            _ops.likelihood_terms(ctx, mu, var, y, pd, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar, var_bar,
                                   varn, scal)
             # ---- variational parameters ----
             U = self._get("U", (Mp, Bp), f32)
@@ -515,7 +545,7 @@ class ElboEngine:
         dZ, dV = grads["inducing_points"], grads["inducing_directions"]
         kws = self._bytes("kbwd_ws", max(_lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p),
                                          _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, M, d, p)))
-        _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
+        self._kernel_bwd_zx(ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws)
         _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
 
         # ---- scalars: d_hyp += data-term scalars, softplus chain rule, d constant, loss (one launch) ----
@@ -533,13 +563,11 @@ class ElboEngine:
         p = V.shape[0] // M if M else 0
         Mp = M * (p + 1)
         B = x.shape[0]
-        Bp = B * (p + 1)
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
         packZ = self._pending_packZ
         packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
-        Kzx = self._get("Kzx", (Mp, Bp), f32)
-        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        Kzx = self._assemble_kzx(ctx, packZ, M, packX, B, d, p, hyp, Mp)
         S32e = self._get("S32e", (Mp, Mp + 1), f32)          # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)]
         S32 = S32e[:, :Mp]
         _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
@@ -559,7 +587,8 @@ class ElboEngine:
            L-bar contraction) are replaced by one fp32 Gram product and one fp32 dense product."""
         M, d, p, Mp = dims
         B = x.shape[0]
-        Bp = B * (p + 1)
+        pd = self._pd(p)
+        Bp = B * (pd + 1)
         dev = self.device
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
@@ -582,7 +611,7 @@ class ElboEngine:
         mu = torch.empty(Bp, dtype=f32, device=dev)
         var0 = torch.empty(Bp, dtype=f32, device=dev)
         sws = self._bytes("stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, Bp))
-        _ops.predictive_stats(ctx, A32, A32, p, m, params["constant"].reshape(-1), hyp, mu, var0, sws)   # mu = A^T m + c
+        _ops.predictive_stats(ctx, A32, A32, pd, m, params["constant"].reshape(-1), hyp, mu, var0, sws)  # mu = A^T m + c
         mu_bar = A32e[Mp]
         sums = torch.empty(4, dtype=f32, device=dev)
         _ops.residual_terms(ctx, mu, y, hyp, rows, mu_bar, sums)
@@ -596,7 +625,7 @@ class ElboEngine:
         vbar2 = 1.0 / (noise * rows)                         # 2 * vbar
         _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
         _ops.trace_terms(ctx, LS, dLS, G, Mp, sums, 1.0 / vbar2)
-        _ops.elbo_fast_finalize(ctx, sums, hyp, B, p, rows, scal)
+        _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
         _ops.rowdot_accum(ctx, A32, mu_bar, dm)              # b = A mu_bar (data part of m-bar)
         Ge[Mp].copy_(dm)
         if include_kl:

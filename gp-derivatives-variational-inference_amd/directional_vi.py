@@ -48,7 +48,8 @@ class GPModel(ApproximateGP):
                 self, inducing_points, inducing_directions, variational_distribution,
                 learn_inducing_locations=learn_inducing_locations)
         else:
-            variational_strategy = DirectionalGradVariationalStrategy(
+            strategy_class = getattr(self, "_strategy_class", None) or DirectionalGradVariationalStrategy
+            variational_strategy = strategy_class(
                 self, inducing_points, inducing_directions, variational_distribution,
                 learn_inducing_locations=learn_inducing_locations)
         self.variational_strategy = variational_strategy
@@ -67,6 +68,7 @@ class GPModel(ApproximateGP):
     def engine(self):
         eng = ApproximateGP.engine.fget(self)
         eng.whitening = "ciq" if self._ciq else "cholesky"
+        eng.data_outputs = "all"
         return eng
 
     # --- parameter plumbing for the HIP engine (order = _step.PARAM_NAMES) ---
@@ -122,12 +124,13 @@ class TrainLoop:
     shuffled epochs; ``bench.py`` drives the same ``step`` for its timed region."""
 
     def __init__(self, X, Y, model, likelihood, mll, optimizers, schedulers, minibatch_dim, dp, col_rng, perm_gen,
-                 full_gradient=False):
+                 full_gradient=False, dfree=False):
         self.X, self.Y, self.model, self.likelihood, self.mll = X, Y, model, likelihood, mll
         self.variational_optimizer, self.hyperparameter_optimizer = optimizers
         self.variational_scheduler, self.hyperparameter_scheduler = schedulers
         self.minibatch_dim, self.dp, self.col_rng, self.perm_gen = minibatch_dim, dp, col_rng, perm_gen
         self.full_gradient = full_gradient      # grad_svgp: all d+1 target columns, no derivative_directions kwarg
+        self.dfree = dfree                      # dfree_directional_vi: function values only, first p canonical directions
         self.device = X.device
         self.dim = X.shape[1]
         self.ctx = _ops.Context.get(self.device)
@@ -147,7 +150,10 @@ class TrainLoop:
             lo, hi = dp.shard_bounds(idx.shape[0])
             idx = idx[lo:hi]
         # select random columns of y to train on (function values always included), :68-90
-        idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
+        if self.dfree:
+            idx_y = [0]
+        else:
+            idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
         # host -> device without a stream sync: pinned staging ring + non_blocking copy (a pageable torch.tensor(...,
         # device=) blocks the host until the stream has drained, i.e. until the previous step has finished)
         slot = self._cols_slot = (getattr(self, "_cols_slot", -1) + 1) % 8
@@ -156,11 +162,14 @@ class TrainLoop:
         self._cols_pinned[slot].copy_(torch.tensor(idx_y, dtype=torch.int32))
         cols = self._cols_pinned[slot].to(dev, non_blocking=True)
         nb = idx.shape[0]
+        py = len(idx_y) - 1                     # derivative columns of y per point
         x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
-        y_batch = torch.empty(nb * (p + 1), dtype=torch.float32, device=dev)
-        _ops.gather_batch(self.ctx, self.X, self.Y, idx.contiguous(), cols, p, x_batch, y_batch)   # interleaved y, :241
+        y_batch = torch.empty(nb * (py + 1), dtype=torch.float32, device=dev)
+        _ops.gather_batch(self.ctx, self.X, self.Y, idx.contiguous(), cols, py, x_batch, y_batch)  # interleaved y, :241
         kwargs = {}
-        if not self.full_gradient:
+        if self.dfree:                          # dfree_directional_vi.py:224-227
+            kwargs["derivative_directions"] = self.E_canonical[:p].repeat(nb, 1)
+        elif not self.full_gradient:
             derivative_directions = self.E_canonical.index_select(0, cols[1:].long() - 1)
             kwargs["derivative_directions"] = derivative_directions.repeat(nb, 1)   # :238
 
@@ -179,7 +188,8 @@ class TrainLoop:
 def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_size=1, minibatch_dim=1,
                    num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True, lr_sched=None,
                    mll_type="ELBO", gamma=0.1, fixed_inducing_locations=None, seed=None, tensors=None,
-                   use_ngd=False, learning_rate_ngd=0.1, use_ciq=False, num_contour_quadrature=15):
+                   use_ngd=False, learning_rate_ngd=0.1, use_ciq=False, num_contour_quadrature=15, model_class=None,
+                   dfree=False):
     """Everything ``train_gp`` does before its loop (directional_vi.py:130-219); returns a TrainLoop."""
     assert num_directions == minibatch_dim
     if not torch.cuda.is_available():
@@ -189,6 +199,9 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         X, Y = tensors
     else:
         X, Y = _dataset_tensors(train_dataset, device)
+    if Y.dim() == 1:                 # derivative-free data: scalar targets
+        Y = Y.reshape(-1, 1).contiguous()
+    model_class = model_class or GPModel
     n_samples, dim = X.shape
     num_data = (dim + 1) * n_samples                                      # :136
 
@@ -204,13 +217,14 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         learn_inducing_locations = False
 
     if use_ciq:                                                           # :164-165
-        model = GPModel(inducing_points, inducing_directions, dim, variational_distribution="NGD",
-                        variational_strategy="CIQ", learn_inducing_locations=learn_inducing_locations)
+        model = model_class(inducing_points, inducing_directions, dim, variational_distribution="NGD",
+                            variational_strategy="CIQ", learn_inducing_locations=learn_inducing_locations)
     elif use_ngd:                                                         # :166-167
-        model = GPModel(inducing_points, inducing_directions, dim, variational_distribution="NGD",
-                        learn_inducing_locations=learn_inducing_locations)
+        model = model_class(inducing_points, inducing_directions, dim, variational_distribution="NGD",
+                            learn_inducing_locations=learn_inducing_locations)
     else:
-        model = GPModel(inducing_points, inducing_directions, dim, learn_inducing_locations=learn_inducing_locations)
+        model = model_class(inducing_points, inducing_directions, dim,
+                            learn_inducing_locations=learn_inducing_locations)
     likelihood = GaussianLikelihood()
     model = model.to(device)
     likelihood = likelihood.to(device)
@@ -265,7 +279,7 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
     else:
         raise ValueError("mll_type must be 'ELBO' or 'PLL'")
     return TrainLoop(X, Y, model, likelihood, mll, (variational_optimizer, hyperparameter_optimizer),
-                     (variational_scheduler, hyperparameter_scheduler), minibatch_dim, dp, col_rng, perm_gen)
+                     (variational_scheduler, hyperparameter_scheduler), minibatch_dim, dp, col_rng, perm_gen, dfree=dfree)
 
 
 def train_gp(train_dataset, num_inducing=128,

@@ -104,10 +104,13 @@ def psd_safe_cholesky(K):
     raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %g" % prev)
 
 
-def predictive(params, x, D, solve_dtype=torch.float64):
+def predictive(params, x, D, solve_dtype=torch.float64, data_outputs="all"):
     """DirectionalGradVariationalStrategy.forward, reference DGVS.py:89-208.
 
-    Returns (mu, var) with ``var = diag(Sigma)`` of q(f) (no likelihood noise)."""
+    Returns (mu, var) with ``var = diag(Sigma)`` of q(f) (no likelihood noise).
+    ``data_outputs="values"``: the derivative-free-data variant (reference DFreeDirectionalGradVariationalStrategy.py:
+    113-136): the inducing side keeps its p directional derivatives, the data side only function values, i.e. every
+    (p+1)-th column / row of the same kernel blocks."""
     Z, V = params["inducing_points"], params["inducing_directions"]
     m = params["variational_mean"]
     L_S = torch.tril(params["chol_variational_covar"])            # CholeskyVariationalDistribution mask
@@ -123,6 +126,8 @@ def predictive(params, x, D, solve_dtype=torch.float64):
     K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
     K_ZZ = K_ZZ + KZZ_JITTER * torch.eye(K_ZZ.shape[0], dtype=dt)  # :140-144
     dg = s * kernel_diag(B, p, ell).to(dt)                         # :145-149 (diag only)
+    if data_outputs == "values":                                   # DFree :119,124,136
+        K_ZX, K_XZ, dg = K_ZX[:, ::p + 1], K_XZ[::p + 1, :], dg[::p + 1]
     L = psd_safe_cholesky(K_ZZ.to(solve_dtype))                    # :72-75,172
     A = torch.linalg.solve_triangular(L, K_ZX.to(solve_dtype), upper=False).to(dt)          # :181
     A_t = torch.linalg.solve_triangular(L, K_XZ.t().to(solve_dtype), upper=False).to(dt)    # :183
@@ -138,14 +143,15 @@ def kl_whitened(m, L_S):
     return 0.5 * ((m * m).sum() + (L_S * L_S).sum() - Mp - torch.log(torch.diagonal(L_S) ** 2).sum())
 
 
-def elbo_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+def elbo_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64,
+                 data_outputs="all"):
     """loss = -mll(likelihood(model(x)), y), reference directional_vi.py:245-246.
 
     ``y`` is the interleaved target vector of length B*(p+1) (:241).  ``global_rows`` lets a
     data-parallel rank normalise by the global batch (defaults to the local one).
     Note the reference feeds the *noised* marginal into the mll, so the noise enters twice.
     """
-    mu, var = predictive(params, x, D, solve_dtype)
+    mu, var = predictive(params, x, D, solve_dtype, data_outputs)
     _, _, noise = constrained(params)
     L_S = torch.tril(params["chol_variational_covar"])
     Bp = y.shape[0] if global_rows is None else global_rows
@@ -166,10 +172,11 @@ PARAM_NAMES = ("inducing_points", "inducing_directions", "variational_mean", "ch
                "constant", "raw_outputscale", "raw_lengthscale", "raw_noise")
 
 
-def elbo_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+def elbo_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64,
+                        data_outputs="all"):
     """Forward + autograd backward, exactly how the reference gets its gradients (:249)."""
     ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    loss, mu, varn = elbo_forward(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype)
+    loss, mu, varn = elbo_forward(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype, data_outputs)
     loss.backward()
     grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps}
     return loss.detach(), grads, mu.detach(), varn.detach()

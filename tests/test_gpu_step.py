@@ -280,3 +280,52 @@ def test_c4_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device):
                 assert relmax(gl[-8:, :], torch.from_numpy(g["g_LS_lastrows"])) < 5e-3
             else:
                 assert relmax(grads[k], torch.from_numpy(g["g_" + k])) < 5e-3, (fast, k, relmax(grads[k], torch.from_numpy(g["g_" + k])))
+
+
+# ------------------------------------------------------------------ derivative-free data
+@pytest.mark.parametrize("mll", ["ELBO", "ELBO-general", "PLL"])
+def test_dfree_step_matches_oracle(dsvgp, gpu_device, mll):
+    """reference DFreeDirectionalGradVariationalStrategy.py:113-136: inducing derivatives, value-only data."""
+    fast = mll == "ELBO"
+    mll = mll.split("-")[0]
+    N, d, M, p, B = 400, 3, 16, 2, 96
+    P, x, _, D, nd = make_problem(N, d, M, p, B, seed=11)
+    y = O.testfun(x)[:, 0].contiguous()
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd, mll, data_outputs="values")
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.data_outputs = "values"
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll, fast=fast)
+    assert mu.shape == (B,) and abs(loss.item() - l_ref.item()) < 2e-5 * abs(l_ref.item())
+    assert relmax(mu, mu_ref) < 2e-4
+    if not fast:
+        assert relmax(varn, var_ref) < 2e-4
+    for k in O.PARAM_NAMES:
+        assert relmax(grads[k], g_ref[k]) < 2e-3, k
+    mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu2, mu_ref) < 2e-4 and relmax(varn2, var_ref) < 2e-4
+    with pytest.raises(ValueError):          # interleaved (p+1)-wide targets are the DSVGP layout, not this one
+        eng.loss_and_grads(Pg, x.to(gpu_device), torch.zeros(B * (p + 1), device=gpu_device), D.to(gpu_device), nd)
+
+
+def test_dfree_train_gp_drop_in(dsvgp, gpu_device, capsys):
+    """reference tests/test_dfree_dsvgp.py: n=600, d=2, 20 inducing points with 2 directions, scalar targets."""
+    from torch.utils.data import TensorDataset
+    torch.manual_seed(0)
+    n, dim, p = 600, 2, 2
+    train_x, test_x = torch.rand(n, dim), torch.rand(200, dim)
+    train_y, test_y = O.testfun(train_x)[:, 0].contiguous(), O.testfun(test_x)[:, 0].contiguous()
+    F = dsvgp.dfree_directional_vi
+    model, likelihood = F.train_gp(TensorDataset(train_x, train_y), num_inducing=20, num_directions=p,
+                                   minibatch_size=200, minibatch_dim=p, num_epochs=120, learning_rate_hypers=0.01,
+                                   inducing_data_initialization=False, tqdm=False, seed=5)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert len(losses) >= 5 and losses[-1] < losses[0]
+    means, variances = F.eval_gp(TensorDataset(test_x, test_y), model, likelihood, num_directions=p, minibatch_size=100,
+                                 minibatch_dim=p)
+    assert means.shape == (200,) and (variances > 0).all()
+    mse_model = ((means - test_y) ** 2).mean().item()
+    mse_const = ((test_y.mean() - test_y) ** 2).mean().item()
+    assert mse_model < 0.5 * mse_const                    # learned something about f from values alone
+    assert type(model.variational_strategy).__module__.endswith("DFreeDirectionalGradVariationalStrategy")
