@@ -67,6 +67,10 @@ class ElboEngine:
         # "all": every data point carries p directional derivatives (DSVGP); "values": derivative-free data, only
         # function values on the data side (reference DFreeDirectionalGradVariationalStrategy.py:113-136)
         self.data_outputs = "all"
+        # True: ONE set of p inducing directions shared by all inducing points, q(u) over M + p values, zero middle term
+        # (reference SharedDirectionalGradVariationalStrategy.py:95-107,210-212)
+        self.shared_directions = False
+        self._no_middle = False
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
@@ -198,10 +202,13 @@ class ElboEngine:
             e1.record()
             self.events.append(("solve_fwd", e0, e1))
         LS = params["chol_variational_covar"]
-        W = self._get("W", (Mp, Bp), f32)
-        # W = tril(L_S)^T A : op(A) = L_S^T is upper triangular -> the strict upper part of the
-        # parameter is never read (CholeskyVariationalDistribution masks it with tril)
-        _ops.gemm(ctx, TRANS_A | A_UPPER, LS, A32, W)
+        if self._no_middle:
+            W = A32                         # zero middle term: colsum(W^2 - A^2) vanishes
+        else:
+            W = self._get("W", (Mp, Bp), f32)
+            # W = tril(L_S)^T A : op(A) = L_S^T is upper triangular -> the strict upper part of the
+            # parameter is never read (CholeskyVariationalDistribution masks it with tril)
+            _ops.gemm(ctx, TRANS_A | A_UPPER, LS, A32, W)
         mu = torch.empty(Bp, dtype=f32, device=self.device)
         var = torch.empty(Bp, dtype=f32, device=self.device)
         sws = self._bytes("stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, Bp))
@@ -219,6 +226,16 @@ class ElboEngine:
         if self.whitening == "ciq":
             _, _, mu, varn = self._ciq_step(ctx, params, x, None, D, 1.0, "ELBO", None, False, False)
             return mu, varn
+        if self.shared_directions:
+            params, _ = self._shared_expand(params)
+            self._no_middle = True
+            try:
+                return self._predict_chol(ctx, params, x, D, cache)
+            finally:
+                self._no_middle = False
+        return self._predict_chol(ctx, params, x, D, cache)
+
+    def _predict_chol(self, ctx, params, x, D, cache):
         key = tuple((t.data_ptr(), t._version) for t in params.values()) if cache else None
         hit = cache and self._eval_cache is not None and self._eval_cache[0] == key
         if "natural_vec" in params:
@@ -250,6 +267,8 @@ class ElboEngine:
             fast = self.elbo_fast
         if self.whitening == "ciq":
             return self._ciq_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, True)
+        if self.shared_directions:
+            return self._shared_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl)
         nat = None
         if "natural_vec" in params:
             # NaturalVariationalDistribution.forward: (theta_1, theta_2) -> (mu, chol S); the step itself is unchanged
@@ -338,6 +357,49 @@ class ElboEngine:
         m64.copy_(m32.reshape(Mp, 1))
         _ops.gemm(ctx, 0, dS, m64, t64)
         dm.add_(t64.reshape(Mp).to(f32), alpha=-2.0)
+
+    # ---- shared inducing directions (SharedDirectionalGradVariationalStrategy) ----
+    def _shared_expand(self, params):
+        """(:95-107): tile the p shared directions over the M points, interleave the M + p variational values; the
+        covariance of q(u) does not reach the predictive (zero middle term, :210-212), so a unit factor stands in."""
+        Z, Vs, ms = params["inducing_points"], params["inducing_directions"], params["variational_mean"]
+        M, p = Z.shape[0], Vs.shape[0]
+        if ms.shape[0] != M + p:
+            raise ValueError("shared directions: q(u) has M + p = %d values, got %d" % (M + p, ms.shape[0]))
+        idx = torch.cat([torch.arange(M, device=self.device).reshape(M, 1),
+                         torch.arange(M, M + p, device=self.device).reshape(1, p).expand(M, p)], dim=1).reshape(-1)
+        full = dict(params)
+        full["inducing_directions"] = Vs.repeat(M, 1).contiguous()
+        full["variational_mean"] = ms[idx].contiguous()
+        full["chol_variational_covar"] = torch.zeros(1, 1, dtype=f32, device=self.device)      # never read
+        return full, idx
+
+    def _shared_step(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl):
+        full, idx = self._shared_expand(params)
+        M, p = params["inducing_points"].shape[0], params["inducing_directions"].shape[0]
+        self._no_middle = True
+        try:
+            try:
+                out = self._loss_and_grads(ctx, full, x, y, D, num_data, mll_type, global_rows, False, False, False)
+            except _Refactored:
+                out = self._loss_and_grads(ctx, full, x, y, D, num_data, mll_type, global_rows, False, False, True)
+        finally:
+            self._no_middle = False
+        loss, g, mu, varn = out
+        ms, LS = params["variational_mean"], params["chol_variational_covar"]
+        grads = {k: g[k] for k in PARAM_NAMES if k not in ("inducing_directions", "variational_mean",
+                                                            "chol_variational_covar")}
+        grads["inducing_directions"] = g["inducing_directions"].reshape(M, p, -1).sum(0)
+        dm = torch.zeros_like(ms)
+        dm.index_add_(0, idx, g["variational_mean"])
+        dLS = torch.zeros_like(LS, memory_format=torch.contiguous_format)
+        if include_kl:                                             # KL of the (M + p)-dimensional q(u)
+            kl_buf = torch.zeros(M + p + 1, dtype=f32, device=self.device)
+            _ops.kl_terms(ctx, ms, LS, num_data, kl_buf, dm, dLS)
+            loss = loss + kl_buf[0] / float(num_data)
+        grads["variational_mean"], grads["chol_variational_covar"] = dm, dLS
+        self.flat = None                                           # gradients are not views of one buffer here
+        return loss, {k: grads[k] for k in PARAM_NAMES}, mu, varn
 
     # ---- CIQ whitening (CiqDirectionalGradVariationalStrategy.forward with a NaturalVariationalDistribution) ----
     def _ciq_quadrature(self, ctx, K32, v0):
@@ -524,11 +586,14 @@ class ElboEngine:
             _ops.likelihood_terms(ctx, mu, var, y, pd, hyp, 0 if mll_type == "ELBO" else 1, rows, mu_bar, var_bar,
                                   varn, scal)
             # ---- variational parameters ----
-            U = self._get("U", (Mp, Bp), f32)
-            _ops.gemm(ctx, A_LOWER, LS, W, U)                                   # U = L_S W
             Abar = self._get("Abar", (Mp, Bp), f32)
-            _ops.abar(ctx, A32, U, m, mu_bar, var_bar, Abar)                    # m mu_bar^T + 2 (U - A) diag(var_bar)
-            _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, W, dLS, alpha=2.0, kscale=var_bar)   # tril(2 A diag(vbar) W^T)
+            if self._no_middle:
+                _ops.abar(ctx, A32, A32, m, mu_bar, var_bar, Abar)              # m mu_bar^T (U == A: no variance path)
+            else:
+                U = self._get("U", (Mp, Bp), f32)
+                _ops.gemm(ctx, A_LOWER, LS, W, U)                               # U = L_S W
+                _ops.abar(ctx, A32, U, m, mu_bar, var_bar, Abar)                # m mu_bar^T + 2 (U - A) diag(var_bar)
+                _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, W, dLS, alpha=2.0, kscale=var_bar)   # tril(2 A diag(vbar) W^T)
             _ops.rowdot_accum(ctx, A32, mu_bar, dm)                             # A mu_bar
             if include_kl:
                 _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)

@@ -69,6 +69,7 @@ class GPModel(ApproximateGP):
         eng = ApproximateGP.engine.fget(self)
         eng.whitening = "ciq" if self._ciq else "cholesky"
         eng.data_outputs = "all"
+        eng.shared_directions = False
         return eng
 
     # --- parameter plumbing for the HIP engine (order = _step.PARAM_NAMES) ---
@@ -189,7 +190,7 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
                    num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True, lr_sched=None,
                    mll_type="ELBO", gamma=0.1, fixed_inducing_locations=None, seed=None, tensors=None,
                    use_ngd=False, learning_rate_ngd=0.1, use_ciq=False, num_contour_quadrature=15, model_class=None,
-                   dfree=False):
+                   dfree=False, shared=False):
     """Everything ``train_gp`` does before its loop (directional_vi.py:130-219); returns a TrainLoop."""
     assert num_directions == minibatch_dim
     if not torch.cuda.is_available():
@@ -210,6 +211,8 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
     else:
         inducing_points = torch.rand(num_inducing, dim).to(device)        # :149
     inducing_directions = torch.eye(dim)[:num_directions].repeat(num_inducing, 1).to(device)
+    if shared and inducing_data_initialization is not True:          # shared_directional_vi.py:150-155: not tiled
+        inducing_directions = torch.eye(dim)[:num_directions].to(device)
 
     learn_inducing_locations = True
     if fixed_inducing_locations is not None:
@@ -308,7 +311,8 @@ def train_gp(train_dataset, num_inducing=128,
                           learning_rate_hypers, inducing_data_initialization, lr_sched, mll_type, gamma,
                           fixed_inducing_locations, seed=args.get("seed"), use_ngd=use_ngd,
                           learning_rate_ngd=learning_rate_ngd, use_ciq=use_ciq,
-                          num_contour_quadrature=num_contour_quadrature)
+                          num_contour_quadrature=num_contour_quadrature, model_class=args.get("_model_class"),
+                          shared=bool(args.get("_shared")))
     n_samples = loop.X.shape[0]
     max_steps = args.get("max_steps")
     total_step = 0

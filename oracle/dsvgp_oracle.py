@@ -203,6 +203,59 @@ def init_params(Z, V, dtype=torch.float32, mean_init_std=0.0, generator=None):
 
 
 # --------------------------------------------------------------------------------------
+# shared inducing directions (reference SharedDirectionalGradVariationalStrategy.py:89-212,
+# shared_directional_vi.py:25-63): ONE set of p directions for all inducing points, q(u) over M function values +
+# p shared derivative values, and -- as the reference computes it -- a ZERO middle term (:210-212), so the predictive
+# covariance is K_XX + 1e-4 I and q(u)'s covariance enters the objective through the KL term only.
+# --------------------------------------------------------------------------------------
+def shared_expand(V_s, m_s, M):
+    """(:95-107) tile the p shared directions over the M inducing points and interleave the values:
+    row i(p+1) <- m_s[i], rows i(p+1)+1.. <- the p shared derivative values m_s[M:]."""
+    p = V_s.shape[0]
+    V = V_s.repeat(M, 1)
+    iv = torch.cat([m_s[:M].reshape(M, 1), m_s[M:].reshape(1, p).expand(M, p)], dim=1).reshape(-1)
+    return V, iv
+
+
+def shared_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+    Z, V_s = params["inducing_points"], params["inducing_directions"]
+    m_s = params["variational_mean"]
+    L_S = torch.tril(params["chol_variational_covar"])
+    c = params["constant"].reshape(())
+    ell, s, noise = constrained(params)
+    M = Z.shape[0]
+    p = V_s.shape[0]
+    B = x.shape[0]
+    assert D.shape[0] // B == p, "Need minibatch dim to be same as number of directions for kernel"
+    dt = x.dtype
+    V, iv = shared_expand(V_s, m_s, M)
+    K_ZX = s * kernel_matrix(Z, x, V, D, ell)                                   # :147-151 (K_XZ is its transpose)
+    K_ZZ = s * kernel_matrix(Z, Z, V, V, ell) + KZZ_JITTER * torch.eye(M * (p + 1), dtype=dt)   # :158-162
+    dg = s * kernel_diag(B, p, ell).to(dt)
+    L = psd_safe_cholesky(K_ZZ.to(solve_dtype))
+    A = torch.linalg.solve_triangular(L, K_ZX.to(solve_dtype), upper=False).to(dt)              # :194-196
+    mu = A.t() @ iv + c                                                         # :201
+    var = dg + KXX_JITTER                                                       # :210-226 with the zero middle term
+    Bp = y.shape[0] if global_rows is None else global_rows
+    varn = (var + noise).clamp_min(MIN_VARIANCE)
+    if mll_type == "ELBO":
+        ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+    else:
+        tot = (varn + noise).clamp_min(1e-8)
+        ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
+    kl = kl_whitened(m_s, L_S)                                                  # q(u) over M + p values
+    return -(ll.sum() / Bp - kl / num_data), mu, varn
+
+
+def shared_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    loss, mu, varn = shared_forward(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype)
+    loss.backward()
+    grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps}
+    return loss.detach(), grads, mu.detach(), varn.detach()
+
+
+# --------------------------------------------------------------------------------------
 # SURVEY 8f rank 3, first half: NaturalVariationalDistribution + gpytorch.optim.NGD
 # (reference directional_vi.py:35-37,164-167,186-191: ``use_ngd=True`` keeps the Cholesky-whitened
 # strategy and swaps q(u)'s parameterisation and its optimizer).  gpytorch 1.4.0, un-vendored: restated from
