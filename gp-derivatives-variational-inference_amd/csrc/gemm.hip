@@ -44,6 +44,9 @@
 #ifndef GEMM_FRAGPF
 #define GEMM_FRAGPF 0       // 1: fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk
 #endif
+#ifndef GEMM_MINW
+#define GEMM_MINW 0         // tools: override the min-waves-per-SIMD launch bound (0 = NTH / 128)
+#endif
 #ifndef GEMM_THREADS
 #define GEMM_THREADS 512    // 256: 4 waves of 64 x BN/2 outputs; 512: 8 waves of 32 x BN/2 (half the accumulators per wave)
 #endif
@@ -137,7 +140,7 @@ __device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[N
 }
 
 template <typename TC, typename TB, bool AKC, bool BKC, int BN, int NTH>
-__global__ __launch_bounds__(NTH, NTH / 128) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTH, GEMM_MINW ? GEMM_MINW : NTH / 128) void gemm_kernel(GemmArgs g) {
     constexpr int NJ = BN / 32;             // 16-wide MFMA column tiles per wave
     constexpr int RW = 128 / (NTH / 128);   // rows per wave: 64 (4 waves) or 32 (8 waves)
     constexpr int MI = RW / 16;             // 16-high MFMA row tiles per wave
