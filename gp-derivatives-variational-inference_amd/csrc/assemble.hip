@@ -212,6 +212,162 @@ __global__ __launch_bounds__(256) void kernel_fwd_kernel(const float* __restrict
     }
 }
 
+// ---- forward, register-resident variant for small compile-time q ---------------------------------------------
+// Same organisation as kernel_bwd_pair_kernel below: ONE WAVE per workgroup (no barriers), 48 x 48 tiles, the wave owns
+// R = 48/Q points of side 1 and sweeps column tiles.  T' = P1' P2'^T (self terms folded in as two extra packed columns:
+// T'[r0, cb] = w_b, T'[ra, c0] = -u_a) goes MFMA -> LDS -> registers, every lane turns the Q x Q values of its point
+// pair(s) into the kernel micro-block with one exp and writes it straight to HBM in the interleaved layout.
+// ~15 KB of LDS per wave: 8 waves per CU overlap each other's staging, MFMA and store phases.
+constexpr int FWD_PAIR_LDT = 52;
+#ifndef FWD_PAIR_WGS_
+#define FWD_PAIR_WGS_ (256 * 16)      // probed 4 / 6 / 8 / 12 / 16 / 32 per CU: 207 / 170 / 137 / 133 / 121 / 135 us for K_ZX at C4
+#endif
+
+template <typename OutT, int Q>
+__global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
+                                                             int n1q, const float* __restrict__ P2,
+                                                             const float* __restrict__ self2, int n2q, int K4, int DP,
+                                                             int ovec, const float* __restrict__ hyp, float jitter,
+                                                             OutT* __restrict__ out, int64_t ld) {
+    constexpr int R = 48 / Q, T = R * Q;
+    constexpr int NPAIR = R * R, PPL = (NPAIR + 63) / 64;
+    constexpr int LDT2 = FWD_PAIR_LDT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP = K4 + 5;
+    float* P1s = smem;                  // [48][LDP]
+    float* P2s = P1s + 48 * LDP;        // [48][LDP]
+    float* TT = P2s + 48 * LDP;         // [48][LDT2]
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * T;
+    const int ncoltiles = (n2q + T - 1) / T;
+    const int KS = K4 / 4 + 1;
+    const int pch = DP / 4;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+
+    for (int e = lane; e < 48 * LDP; e += 64) { P1s[e] = 0.f; P2s[e] = 0.f; }
+    __syncthreads();
+    for (int e = lane; e < T * K4; e += 64) {
+        const int r = e / K4, k = e - r * K4;
+        if (row0 + r < n1q) P1s[r * LDP + k] = P1[(int64_t)(row0 + r) * DP + k];
+    }
+    if (lane < T && row0 + lane < n1q) {
+        const int a = lane % Q;
+        P1s[lane * LDP + K4 + 1] = a == 0 ? 1.f : 0.f;
+        P1s[lane * LDP + K4 + 2] = a == 0 ? 0.f : -self1[row0 + lane];
+    }
+    int pr0[PPL], pc0[PPL];
+    float s1r0[PPL];
+    bool prow[PPL];
+#pragma unroll
+    for (int pp = 0; pp < PPL; ++pp) {
+        const int pid = lane + 64 * pp;
+        const int pi = pid / R, pj = pid - pi * R;
+        pr0[pp] = pi * Q; pc0[pp] = pj * Q;
+        prow[pp] = pid < NPAIR && row0 + pr0[pp] < n1q;
+        s1r0[pp] = prow[pp] ? self1[row0 + pr0[pp]] : 0.f;
+    }
+
+    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
+        const int col0 = ct * T;
+        float s2c0[PPL];
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) s2c0[pp] = (prow[pp] && col0 + pc0[pp] < n2q) ? self2[col0 + pc0[pp]] : 0.f;
+        __syncthreads();   // single wave: orders the previous tile's LDS reads before the new stores
+        for (int e = lane; e < T * pch; e += 64) {
+            const int r = e / pch, k = (e - r * pch) * 4;
+            const int gr = col0 + r;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < n2q) v = *reinterpret_cast<const f4*>(P2 + (int64_t)gr * DP + k);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = v[t];
+        }
+        __syncthreads();
+        if (lane < T) {
+            const int gr = col0 + lane;
+            const bool ok = gr < n2q;
+            P2s[lane * LDP + K4 + 1] = ok ? -self2[gr] : 0.f;
+            P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        {
+            f4 t[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+            const float* pa = P1s + m16 * LDP + kg;
+            const float* pb = P2s + m16 * LDP + kg;
+            for (int ks = 0; ks < KS; ++ks) {
+                float av[3], bv[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { av[i] = pa[i * 16 * LDP + ks * 4]; bv[i] = pb[i * 16 * LDP + ks * 4]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            if (prow[pp] && col0 + pc0[pp] < n2q) {
+                const float* blk = TT + pr0[pp] * LDT2 + pc0[pp];
+                float tq[Q][Q];
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    if constexpr (Q % 2 == 0) {
+                        using F2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) {
+                            const F2 v = *reinterpret_cast<const F2*>(blk + a * LDT2 + b);
+                            tq[a][b] = v[0]; tq[a][b + 1] = v[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) tq[a][b] = blk[a * LDT2 + b];
+                    }
+                }
+                const float nn = fmaxf(s1r0[pp] - s2c0[pp] - 2.f * tq[0][0], 0.f);     // covar_dist clamps at 0
+                const float k = s * expf(-0.5f * nn);                                  // postprocess_rbf, ScaleKernel
+                const float kil = k * il, kil2 = k * il2;
+                const int64_t gr0 = (int64_t)row0 + pr0[pp], gc0 = (int64_t)col0 + pc0[pp];
+                OutT* o = out + gr0 * ld + gc0;
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    float v[Q];
+                    if (a == 0) {
+                        v[0] = k;
+#pragma unroll
+                        for (int b = 1; b < Q; ++b) v[b] = tq[0][b] * kil;                          // w_b k / ell
+                    } else {
+                        v[0] = tq[a][0] * kil;                                                      // -u_a k / ell
+#pragma unroll
+                        for (int b = 1; b < Q; ++b) v[b] = (tq[a][b] + tq[a][0] * tq[0][b]) * kil2;  // (G_ab - u_a w_b) k / ell^2
+                    }
+                    if (jitter != 0.f && gr0 == gc0) v[a] += jitter;      // diagonal micro-block: global row == global column
+                    if constexpr (Q % 2 == 0) {
+                        if (ovec) {
+                            using O2 = OutT __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int b = 0; b < Q; b += 2) *reinterpret_cast<O2*>(o + a * ld + b) = O2{(OutT)v[b], (OutT)v[b + 1]};
+                            continue;
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < Q; ++b) o[a * ld + b] = (OutT)v[b];
+                }
+            }
+        }
+    }
+}
+
 __global__ void kernel_diag_kernel(int n, int p, const float* __restrict__ hyp, float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * (p + 1)) return;
@@ -939,6 +1095,25 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
     if (n1 == 0 || n2 == 0) return 0;
     const int n1q = n1 * g.q, n2q = n2 * g.q;
     if (ld < n2q) return DSVGP_EINVAL;
+    if ((g.q == 6 || g.q == 3) && g.NP <= 32) {
+        const int T = (48 / g.q) * g.q;
+        const int rt = cdiv(n1q, T), ctiles = cdiv(n2q, T);
+        int ns = FWD_PAIR_WGS_ / rt;
+        if (ns < 1) ns = 1;
+        if (ns > ctiles) ns = ctiles;
+        const size_t lds = sizeof(float) * (2 * 48 * (size_t)(g.K4 + 5) + 48 * (size_t)FWD_PAIR_LDT);
+        const int esz = out_is_double ? 8 : 4;
+        const int ovec = (ld % 2 == 0) && ((uintptr_t)out % (2 * esz) == 0);      // 2-wide stores of the micro-block rows
+        dim3 grid(ns, rt);
+#define DSVGP_FWD_PAIR(OT_, Q_)                                                                                      \
+        hipLaunchKernelGGL((kernel_fwd_pair_kernel<OT_, Q_>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, \
+                           n2q, g.K4, g.DP, ovec, hyp, jitter, (OT_*)out, ld)
+        if (out_is_double) { if (g.q == 6) DSVGP_FWD_PAIR(double, 6); else DSVGP_FWD_PAIR(double, 3); }
+        else { if (g.q == 6) DSVGP_FWD_PAIR(float, 6); else DSVGP_FWD_PAIR(float, 3); }
+#undef DSVGP_FWD_PAIR
+        DSVGP_LAUNCH_CHECK();
+        return 0;
+    }
     const int Rc = g.R, Rr = g.R >= 2 ? g.R / 2 : g.R;
     const int Tr = Rr * g.q, Tc = Rc * g.q, Trp = (Tr + 15) & ~15, Tcp = (Tc + 15) & ~15;
     const size_t lds = sizeof(float) * ((size_t)(Trp + Tcp) * (g.K4 + 1) + (size_t)Trp * LDT + Trp + Tcp + (size_t)Rr * Rc);

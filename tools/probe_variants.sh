@@ -6,12 +6,12 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 C=$R/gp-derivatives-variational-inference_amd/csrc
 B=/tmp/probe_build; mkdir -p $B
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -I$R/include -I$C"
-for f in assemble elbo potrf api; do hipcc $FL -c $C/$f.hip -o $B/$f.o & done; wait
+for f in assemble elbo potrf ciq api; do hipcc $FL -c $C/$f.hip -o $B/$f.o & done; wait
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}; defs=${defs//,/ }
   mkdir -p $B/$name
   hipcc $FL $defs -c $C/gemm.hip -o $B/$name/gemm.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $B/$name/libdsvgp_hip.so $B/$name/gemm.o $B/assemble.o $B/elbo.o $B/potrf.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $B/$name/libdsvgp_hip.so $B/$name/gemm.o $B/assemble.o $B/elbo.o $B/potrf.o $B/ciq.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
   hipcc -O2 $defs $R/tools/gemm_probe.cpp -I$R/include -L$B/$name -ldsvgp_hip -Wl,-rpath,$B/$name -o $B/$name/probe
   echo "=== variant $name  ($defs)"
   $B/$name/probe ${PROBE_ARGS}
