@@ -83,11 +83,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
+    # rehearsal on a one-GPU box: DSVGP_REHEARSE_GLOO=1 runs all ranks on cuda:0 over gloo (exercises the sharded path,
+    # not a measurement); the driver's multi-GPU runs use one GPU per rank over RCCL
+    rehearse = os.environ.get("DSVGP_REHEARSE_GLOO") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import dsvgp_amd
     d, N, M, p, B = cfg["d"], cfg["N"], cfg["M"], cfg["p"], cfg["B"]
