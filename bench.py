@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     "c4": dict(name="DSVGP d=20 N=1M M=500 p=5 B=4096", d=20, N=1_000_000, M=500, p=5, B=4096),
     "c2": dict(name="DSVGP d=5 N=10k M=200 p=2 B=512", d=5, N=10_000, M=200, p=2, B=512),
+    # diagnostics: the per-rank shard of C4 at 8 GPUs (B = 4096 / 8) run alone -- what one rank computes per step
+    "c4shard8": dict(name="DSVGP d=20 N=1M M=500 p=5 B=512 (one rank's share of C4 at 8 GPUs)", d=20, N=1_000_000, M=500,
+                     p=5, B=512),
     # BASELINE config 5: CIQ whitening + NGD (no dataset / batch size given there; N and B chosen like C4's per-GPU shard)
     "c5": dict(name="CIQ-DSVGP d=50 N=100k M=1024 p=5 B=512", d=50, N=100_000, M=1024, p=5, B=512, ciq=True),
 }
