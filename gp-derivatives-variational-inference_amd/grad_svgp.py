@@ -17,8 +17,8 @@ from .GradVariationalStrategy import GradVariationalStrategy
 from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .directional_vi import TrainLoop, _dataset_tensors
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
-                      PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
-from .optim import FusedAdam
+                      NaturalVariationalDistribution, PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
+from .optim import NGD, FusedAdam
 from .parallel import DataParallel
 
 
@@ -26,9 +26,12 @@ class GPModel(ApproximateGP):
     def __init__(self, inducing_points, **kwargs):
         torch.nn.Module.__init__(self)
         dim = inducing_points.size(1)
-        if kwargs.get("variational_distribution") == "NGD" or kwargs.get("variational_strategy") == "CIQ":
-            raise NotImplementedError("NGD / CIQ variants are outside the MI355X hot path (SURVEY.md 8f)")
-        variational_distribution = CholeskyVariationalDistribution(inducing_points.size(0) * (dim + 1))
+        if kwargs.get("variational_strategy") == "CIQ":
+            raise NotImplementedError("grad_svgp with gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27) is not built")
+        if kwargs.get("variational_distribution") == "NGD":                               # grad_svgp.py:21-22
+            variational_distribution = NaturalVariationalDistribution(inducing_points.size(0) * (dim + 1))
+        else:
+            variational_distribution = CholeskyVariationalDistribution(inducing_points.size(0) * (dim + 1))
         self.variational_strategy = GradVariationalStrategy(self, inducing_points, variational_distribution,
                                                             learn_inducing_locations=True)
         self._engine = None
@@ -49,13 +52,16 @@ class GPModel(ApproximateGP):
         vd = vs._variational_distribution
         raw_noise = (likelihood.noise_covar.raw_noise if likelihood is not None
                      else torch.zeros(1, device=vs.inducing_points.device))
-        return [vs.inducing_points, self._canonical_directions, vd.variational_mean, vd.chol_variational_covar,
-                self.mean_module.constant, self.covar_module.raw_outputscale,
-                self.covar_module.base_kernel.raw_lengthscale, raw_noise]
+        q = ([vd.natural_vec, vd.natural_mat] if isinstance(vd, NaturalVariationalDistribution)
+             else [vd.variational_mean, vd.chol_variational_covar])
+        return [vs.inducing_points, self._canonical_directions] + q + [
+            self.mean_module.constant, self.covar_module.raw_outputscale,
+            self.covar_module.base_kernel.raw_lengthscale, raw_noise]
 
     def _param_names(self):
-        from ._step import PARAM_NAMES
-        return PARAM_NAMES
+        from ._step import NGD_PARAM_NAMES, PARAM_NAMES
+        ngd = isinstance(self.variational_strategy._variational_distribution, NaturalVariationalDistribution)
+        return NGD_PARAM_NAMES if ngd else PARAM_NAMES
 
     def _param_dict(self, likelihood=None):
         return {k: v.detach() for k, v in zip(self._param_names(), self._param_list(likelihood))}
@@ -74,8 +80,8 @@ def train_gp(train_dataset, dim, num_inducing=128,
              watch_model=False, gamma=0.1,
              verbose=True,
              **args):
-    if use_ngd or use_ciq:
-        raise NotImplementedError("NGD / CIQ variants are outside the MI355X hot path (SURVEY.md 8f)")
+    if use_ciq:
+        raise NotImplementedError("grad_svgp with gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27) is not built")
     if not torch.cuda.is_available():
         raise RuntimeError("train_gp needs an MI355X (HIP) device: this path has no CPU fallback")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -83,7 +89,10 @@ def train_gp(train_dataset, dim, num_inducing=128,
     n_samples = X.shape[0]
 
     inducing_points = torch.rand(num_inducing, dim).to(device)            # :61
-    model = GPModel(inducing_points=inducing_points).to(device)
+    if use_ngd:                                                           # grad_svgp.py:66-67
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(device)
+    else:
+        model = GPModel(inducing_points=inducing_points).to(device)
     likelihood = GaussianLikelihood().to(device)
     model.train()
     likelihood.train()
@@ -104,7 +113,10 @@ def train_gp(train_dataset, dim, num_inducing=128,
         for t in model._param_list(likelihood):
             dist.broadcast(t.data, 0)
 
-    variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
+    if use_ngd:                                                           # grad_svgp.py:87-88
+        variational_optimizer = NGD(list(model.variational_parameters()), num_data=n_samples, lr=learning_rate_ngd)
+    else:
+        variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
     hyperparameter_optimizer = FusedAdam([
         {"params": list(model.hyperparameters())},
         {"params": list(likelihood.parameters())},

@@ -143,3 +143,22 @@ def test_train_gp_use_ngd_drop_in(dsvgp, gpu_device, capsys):
     assert abs(loss.item() - l_ref.item()) < 2e-4 * abs(l_ref.item())
     assert relmax(grads["natural_vec"], g_ref["natural_vec"]) < 1e-2
     assert relmax(grads["natural_mat"], g_ref["natural_mat"]) < 1e-2
+
+
+@pytest.mark.gpu
+def test_grad_svgp_use_ngd(dsvgp, gpu_device, capsys):
+    """reference grad_svgp.py:21-22,66-67,87-88: the full-gradient SVGP with natural-gradient q(u) updates."""
+    from torch.utils.data import TensorDataset
+    torch.manual_seed(0)
+    n, dim = 400, 2
+    train_x = torch.rand(n, dim)
+    train_y = O.testfun(train_x)
+    G = dsvgp.grad_svgp
+    model, likelihood = G.train_gp(TensorDataset(train_x, train_y), dim, num_inducing=16, minibatch_size=100,
+                                   num_epochs=40, use_ngd=True, learning_rate_ngd=0.1, tqdm=False, seed=1)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert len(losses) >= 3 and losses[-1] < losses[0]
+    assert "variational_strategy._variational_distribution.natural_mat" in model.state_dict()
+    means, variances = G.eval_gp(TensorDataset(train_x[:40], train_y[:40]), model, likelihood, minibatch_size=20)
+    assert means.shape == (120,) and (variances > 0).all()
