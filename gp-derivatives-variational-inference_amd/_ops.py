@@ -176,6 +176,21 @@ def potrf_(ctx, A, info, algo=1):
     return ws
 
 
+def potrf_inverse_(ctx, A, info, nb, workspace):
+    """In-place lower Cholesky (blocked MFMA algorithm) AND the explicit inverse into the trsm workspace, in the same
+    launches.  Only for nb >= n; later ``trsm(..., reuse_inverse=True)`` calls use the inverse."""
+    _req(A, f64, "A", 2)
+    n = A.shape[0]
+    key = (A.device.index, n)
+    ws = _potrf_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.dsvgp_potrf_workspace_bytes(n, 1)), dtype=torch.uint8, device=A.device)
+        _potrf_ws[key] = ws
+    check(lib.dsvgp_potrf_inverse(ctx.h, _ptr(A), n, _ld(A), _ptr(info), _ptr(ws), int(nb), _ptr(workspace)),
+          "dsvgp_potrf_inverse")
+    return ws
+
+
 def add_diag_(ctx, A, delta):
     check(lib.dsvgp_add_diag(ctx.h, _ptr(A), A.shape[0], _ld(A), float(delta)), "dsvgp_add_diag")
 

@@ -58,6 +58,7 @@ class ElboEngine:
         self._hyp_host = None
         self._pending = None            # (hyp, packZ, L, dims, info) of a factorisation whose status is not read yet
         self._potrf_ws = None
+        self._inverse_ws = None         # the trsm workspace that holds the inverse of the current factor
         self._side = None               # second HIP stream (work overlapped with the Cholesky chain)
         self._side_done = None
         self.overlap = True
@@ -71,6 +72,7 @@ class ElboEngine:
         # (reference SharedDirectionalGradVariationalStrategy.py:95-107,210-212)
         self.shared_directions = False
         self._no_middle = False
+        self.fused_inverse = True       # L^-1 by forward elimination inside the Cholesky launches (csrc/potrf.hip)
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
@@ -95,7 +97,7 @@ class ElboEngine:
         return t
 
     # ---- shared forward pieces ----------------------------------------------------------------
-    def _factor(self, ctx, params, sync=True, side_job=None):
+    def _factor(self, ctx, params, sync=True, side_job=None, nrhs=0):
         """hyp, packs of (Z,V), L = chol(K_ZZ + 1e-3 I) with psd_safe_cholesky retries.
         ``side_job(ctx, hyp)``: work that needs only the hyper-parameters / the centre (K_ZX assembly, S = L_S L_S^T):
         queued on a second HIP stream so that it fills the CUs the latency-bound Cholesky chain leaves idle; the
@@ -128,11 +130,24 @@ class ElboEngine:
         L = self._get("L", (Mp, Mp), f64)
         info = self._get("info", (1,), torch.int32)
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
-        self._potrf_ws = _ops.potrf_(ctx, L, info, self.potrf_algo)
+        nrhs = max(int(nrhs), Mp + 1)
+        ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, nrhs, self.trsm_nb))
+        self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs)       # L and the inverted blocks of L
+        self._inverse_ws = ws
         self._pending = (hyp, packZ, L, (M, d, p, Mp), info)
         if sync:
             self._finish_factor(ctx, ladder=True)
         return hyp, packZ, L, (M, d, p, Mp)
+
+    def _potrf_and_inverse(self, ctx, L, info, ws, nrhs):
+        """L <- chol(L) and the inverted blocks of L into the trsm workspace ``ws``: ONE fused chain of launches when the
+        explicit-inverse regime applies (blocked algorithm, nb >= n), else potrf followed by the trtri recursion."""
+        n = L.shape[0]
+        if self.potrf_algo == 1 and self.trsm_nb >= n and self.fused_inverse:
+            return _ops.potrf_inverse_(ctx, L, info, self.trsm_nb, ws)
+        pws = _ops.potrf_(ctx, L, info, self.potrf_algo)
+        _ops.trtri_blocks(ctx, L, nrhs, self.trsm_nb, ws, pws)
+        return pws
 
     def _finish_factor(self, ctx, ladder=False):
         """Read the potrf status (host sync).  Non-zero: run psd_safe_cholesky's jitter ladder here (``ladder``) or
@@ -149,7 +164,7 @@ class ElboEngine:
         for t in range(CHOL_TRIES):                     # rare path: psd_safe_cholesky jitter ladder
             _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
             _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
-            self._potrf_ws = _ops.potrf_(ctx, L, info, self.potrf_algo)
+            self._potrf_ws = self._potrf_and_inverse(ctx, L, info, self._inverse_ws, Mp + 1)
             if int(info.item()) == 0:
                 return
         raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
@@ -192,8 +207,9 @@ class ElboEngine:
         need = _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp), self.trsm_nb)
         old = self._buf.get("trsm_ws")
         ws = self._bytes("trsm_ws", need)
-        if not (reuse_inverse and ws is old):           # a re-allocated workspace has no inverse in it
+        if not ((reuse_inverse and ws is old) or ws is self._inverse_ws):   # a re-allocated workspace has no inverse in it
             _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws, self._potrf_ws)
+            self._inverse_ws = ws
         if self.record_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -248,7 +264,9 @@ class ElboEngine:
         if hit:
             _, hyp, packZ, L, dims, _ = self._eval_cache
         else:
-            hyp, packZ, L, dims = self._factor(ctx, params)
+            Mz = params["inducing_points"].shape[0]
+            pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
+            hyp, packZ, L, dims = self._factor(ctx, params, nrhs=x.shape[0] * (self._pd(pz) + 1))
             self._eval_cache = (key, hyp, packZ, L, dims, params) if cache else None
         _, _, _, _, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=hit)
         varn = (var + hyp[2]).clamp_min_(1e-6)
@@ -311,8 +329,7 @@ class ElboEngine:
         info = self._get("ngd_info", (2,), torch.int32)
         info.zero_()
         wsP = self._bytes("ngd_wsP", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
-        pws = _ops.potrf_(ctx, P, info[0:1], self.potrf_algo)
-        _ops.trtri_blocks(ctx, P, Mp, nb, wsP, pws)
+        self._potrf_and_inverse(ctx, P, info[0:1], wsP, Mp)
         eye = self._buf.get("ngd_eye")
         if eye is None or eye.shape[0] != Mp:
             eye = self._buf["ngd_eye"] = torch.eye(Mp, dtype=f64, device=self.device)
@@ -333,8 +350,7 @@ class ElboEngine:
         nb = self.trsm_nb
         LS64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)
         wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
-        pws = _ops.potrf_(ctx, LS64, info[1:2], self.potrf_algo)                        # L_S (lower triangle)
-        _ops.trtri_blocks(ctx, LS64, Mp, nb, wsS, pws)
+        self._potrf_and_inverse(ctx, LS64, info[1:2], wsS, Mp)                          # L_S (lower triangle) and L_S^-1
         bad = info.tolist()
         if bad[0] or bad[1]:
             raise NotPSDError("natural_mat does not define a positive definite precision (potrf info %s)" % bad)
@@ -557,7 +573,7 @@ class ElboEngine:
         if use_fast and self.overlap:
             def side_job(c, hyp_):
                 side.update(self._fast_prologue(c, params, hyp_, x, D, rows))
-        hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast, side_job=side_job)
+        hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast, side_job=side_job, nrhs=Bp)
         M, d, p, Mp = dims
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
@@ -665,7 +681,9 @@ class ElboEngine:
         A32e = self._get("A32e", (Mp + 1, Bp), f32)          # [A ; mu_bar^T]
         A32 = A32e[:Mp]
         ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, max(Bp, Mp + 1), self.trsm_nb))
-        _ops.trtri_blocks(ctx, L, max(Bp, Mp + 1), self.trsm_nb, ws, self._potrf_ws)
+        if ws is not self._inverse_ws:                       # (re-allocated: the factorisation's inverse is not in it)
+            _ops.trtri_blocks(ctx, L, max(Bp, Mp + 1), self.trsm_nb, ws, self._potrf_ws)
+            self._inverse_ws = ws
         if self.record_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -39,7 +39,7 @@ extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* i
     if (!ctx || !A || !info_dev || n <= 0 || lda < n) return DSVGP_EINVAL;
     if (algo == 1) {
         if (!workspace) return DSVGP_EINVAL;
-        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace);
+        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace, nullptr, 0);
     }
     if (algo != 0) return DSVGP_EINVAL;
     rocblas_status st = rocsolver_dpotrf((rocblas_handle)ctx->blas, rocblas_fill_upper, n, A, (rocblas_int)lda, info_dev);
@@ -76,6 +76,20 @@ extern "C" size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb) {
     if (n <= 0 || nrhs < 0) return 0;
     const int b = trsm_nb(n, nb);
     return sizeof(double) * ((size_t)2 * n * n + (size_t)(n + b) * (b / 2) + (size_t)b * (nrhs > 0 ? nrhs : 1)) + 256;
+}
+
+// Factorisation AND explicit inverse in the same launches (blocked Cholesky with the fused forward elimination of the
+// identity, potrf.hip): L in place, L^-1 / its transpose into the Dinv / DinvT slots of the trsm `workspace`, which
+// later solves use with reuse_inverse = 1.  Needs the single-block regime nb >= n.
+extern "C" int dsvgp_potrf_inverse(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev, void* potrf_workspace,
+                                   int nb, void* workspace) {
+    if (!ctx || !A || !info_dev || !potrf_workspace || !workspace || n <= 0 || lda < n) return DSVGP_EINVAL;
+    if (trsm_nb(n, nb) < n) return DSVGP_EINVAL;
+    double* Dinv = (double*)workspace;
+    double* DinvT = Dinv + (size_t)n * n;
+    int rc = launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n);
+    if (rc) return rc;
+    return dsvgp_transpose_f64(ctx, Dinv, n, n, n, DinvT, n);
 }
 
 // First phase of dsvgp_trsm on its own: Dinv / DinvT of `workspace` from L.  potrf_workspace (may be NULL): the

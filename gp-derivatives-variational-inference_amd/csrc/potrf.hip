@@ -277,14 +277,92 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
     }
 }
 
+// Fused inverse (Rw != nullptr): the same launches also run the forward elimination of the identity, block row by
+// block row, so that Y = L^-1 is complete when the factorisation is (no separate trtri recursion):
+//   R-tiles  (i > k, j <= k):  R_ij -= (A_ik W_k) R_kj,  R_kk = I     (the W_k form of  R_i -= L_ik Y_k,  Y_k = X_k R_k)
+//   Y-tiles  (j <= k):         Y_kj  = X_k R_kj                        (row block k of L^-1 is final)
+// Row k of R was completed by launch k-1 and is read-only here; these tiles ride on the CUs the latency-bound
+// factorisation chain leaves idle.
+__device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n,
+                                                  int k, int e, const double* __restrict__ Xws,
+                                                  const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
+                                                  double* __restrict__ Y, int64_t ldy, int nblk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int nt = nblk - (k + 1), nR = nt * (k + 1);
+    const int k0 = k * 64;
+    const bool ytile = e >= nR;
+    const int j = ytile ? (e - nR) : (e % (k + 1));
+    const int i0 = ytile ? k0 : (k + 1 + e / (k + 1)) * 64;
+    const int j0 = j * 64;
+    const double* Lk = ytile ? (Xws + (size_t)k * 4096) : (Wws + (size_t)k * 4096);
+    {
+        double ra[16], rb[16], rc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            ra[u] = ytile ? 0.0 : A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
+            rb[u] = Lk[r * 64 + c];
+            rc[u] = (j == k) ? ((r == c) ? 1.0 : 0.0) : Rw[(int64_t)(k0 + r) * ldr + j0 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
+            S[2][r][c] = rb[u];
+            S[1][r][c] = rc[u];
+        }
+    }
+    __syncthreads();
+    acc4 acc[2][2];
+    if (!ytile) {
+        tile_product<true>(S[0], S[2], lane, wr, wc, acc);          // T = A_ik W_k
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + jj * 16 + (lane & 15)] = acc[i][jj][q];
+        __syncthreads();
+        tile_product<false>(S[0], S[1], lane, wr, wc, acc);         // T R_kj
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * 32 + jj * 16 + (lane & 15);
+                    double* dst = Rw + (int64_t)(i0 + ml) * ldr + j0 + nl;
+                    *dst = ((j == k) ? 0.0 : *dst) - acc[i][jj][q];
+                }
+    } else {
+        tile_product<false>(S[2], S[1], lane, wr, wc, acc);         // X_k R_kj
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = k0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, c = j0 + wc * 32 + jj * 16 + (lane & 15);
+                    if (m < n && c < n) Y[(int64_t)m * ldy + c] = acc[i][jj][q];
+                }
+    }
+}
+
 __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
                                                         double* __restrict__ Xws, double* __restrict__ Wws,
-                                                        int* __restrict__ info) {
+                                                        int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
+                                                        double* __restrict__ Yinv, int64_t ldy, int nA) {
     __shared__ double S[4][64][LDT];
     __shared__ double Xd[16][17];
     __shared__ double colbuf[32], rowbuf[32];      // [16..31]: dummy slots of the non-owner lanes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int b = blockIdx.x;
+    if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
+        chol_inverse_tile(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64);
+        return;
+    }
     int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while (ti * (ti + 1) / 2 > b) --ti;
@@ -375,6 +453,16 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
     CHOL_STAMP(3);
 }
 
+// the last block row of L^-1 (its X is produced by the last step launch): Y_kj = X_k R_kj, j <= k = nblk - 1
+__global__ __launch_bounds__(256) void chol_yrow_kernel(const double* __restrict__ A, int64_t lda, int n, int k,
+                                                        const double* __restrict__ Xws, const double* __restrict__ Wws,
+                                                        double* __restrict__ Rw, int64_t ldr, double* __restrict__ Yinv,
+                                                        int64_t ldy) {
+    __shared__ double S[3][64][LDT];
+    const int nblk = (n + 63) / 64;
+    chol_inverse_tile(S, A, lda, n, k, (nblk - (k + 1)) * (k + 1) + blockIdx.x, Xws, Wws, Rw, ldr, Yinv, ldy, nblk);
+}
+
 // all solved panels in one launch:  L_ik = A_ik X_k^T  (i > k), in place, one 64 x 64 tile per workgroup
 __global__ __launch_bounds__(256) void chol_panels_kernel(double* __restrict__ A, int64_t lda, int n,
                                                           const double* __restrict__ Xws) {
@@ -416,19 +504,33 @@ __global__ __launch_bounds__(256) void chol_panels_kernel(double* __restrict__ A
 
 }  // namespace
 
-size_t potrf_blocked_workspace_bytes(int n) { return 2 * sizeof(double) * (size_t)cdiv(n, NBC) * NBC * NBC; }
+size_t potrf_blocked_workspace_bytes(int n) {
+    const size_t nblk = (size_t)cdiv(n, NBC);
+    // X_k, W_k blocks + the working matrix R of the fused inverse (padded to whole blocks)
+    return sizeof(double) * (2 * nblk * NBC * NBC + nblk * NBC * nblk * NBC);
+}
 
-// one fused launch per block column + one batched panel launch (see chol_step_kernel)
-int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws) {
+// one fused launch per block column + one batched panel launch (see chol_step_kernel).  Yinv != nullptr: also L^-1
+// (lower triangle, leading dimension ldy) by the fused forward elimination.
+int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy) {
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
     if (e != hipSuccess) return 1000 + (int)e;
     const int nblk = cdiv(n, NBC);
     double* Xws = ws;
     double* Wws = ws + (size_t)nblk * NBC * NBC;
+    double* Rw = Yinv ? Wws + (size_t)nblk * NBC * NBC : nullptr;
+    const int64_t ldr = (int64_t)nblk * NBC;
     for (int k = -1; k < nblk - 1; ++k) {
         const int nt = nblk - (k + 1);
-        const int grid = (k < 0) ? 1 : nt * (nt + 1) / 2;
-        hipLaunchKernelGGL(chol_step_kernel, dim3(grid), dim3(256), 0, st, A, lda, n, k, Xws, Wws, info);
+        const int nA = (k < 0) ? 1 : nt * (nt + 1) / 2;
+        const int nI = (k >= 0 && Yinv) ? nt * (k + 1) + (k + 1) : 0;
+        hipLaunchKernelGGL(chol_step_kernel, dim3(nA + nI), dim3(256), 0, st, A, lda, n, k, Xws, Wws, info, Rw, ldr, Yinv, ldy,
+                           nA);
+        DSVGP_LAUNCH_CHECK();
+    }
+    if (Yinv) {
+        hipLaunchKernelGGL(chol_yrow_kernel, dim3(nblk), dim3(256), 0, st, (const double*)A, lda, n, nblk - 1,
+                           (const double*)Xws, (const double*)Wws, Rw, ldr, Yinv, ldy);
         DSVGP_LAUNCH_CHECK();
     }
     if (nblk > 1) {

@@ -122,6 +122,12 @@ int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, c
  * the workspace dsvgp_potrf(algo 1) factored THIS L with (its inverted 64x64 diagonal blocks are reused). */
 int dsvgp_trtri(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int nb, const void* potrf_workspace,
                 void* workspace);
+/* dsvgp_potrf(algo 1) and the inversion phase in the SAME launches (blocked Cholesky with a fused forward elimination of
+ * the identity): A <- L in place, L^-1 and its transpose into `workspace` (the dsvgp_trsm workspace; later solves pass
+ * reuse_inverse=1).  Only for the single-product regime nb >= n; potrf_workspace sized by
+ * dsvgp_potrf_workspace_bytes(n, 1).                                                                              */
+int dsvgp_potrf_inverse(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* info_dev, void* potrf_workspace, int nb,
+                        void* workspace);
 
 /* ---- generic MFMA GEMM used by the predictive / backward contractions
  *   C = alpha * op(A) op(B) + beta * Cin,   compute type = double (is_double=1) or float.

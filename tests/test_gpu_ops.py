@@ -247,6 +247,37 @@ def test_potrf_row_major_lower(dsvgp, gpu_device, n, algo):
     assert int(info.item()) == n // 2 + 1                       # leading minor index, as LAPACK
 
 
+@pytest.mark.parametrize("n", [40, 64, 100, 333, 704, 1500])
+def test_potrf_inverse_fused(dsvgp, gpu_device, n):
+    """Blocked Cholesky with the fused forward elimination: L and L^-1 from the same launches (ragged last block, one
+    block, several blocks); later solves reuse the inverse."""
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(n)
+    K = _spd(n, g)
+    A = K.clone().to(gpu_device)
+    info = torch.zeros(1, dtype=torch.int32, device=gpu_device)
+    nb = 4096
+    ws = ops.trsm_workspace(n, n, nb, gpu_device)
+    ops.potrf_inverse_(ctx, A, info, nb, ws)
+    assert int(info.item()) == 0
+    L = torch.tril(A).cpu()
+    assert (L @ L.t() - K).abs().max() < 1e-10 * K.abs().max()
+    Linv = torch.tril(ws[:n * n * 8].view(torch.float64).view(n, n)).cpu()
+    assert (Linv @ L - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-9
+    B = torch.randn(n, 17, generator=g, dtype=torch.float64)
+    X = torch.empty(n, 17, dtype=torch.float64, device=gpu_device)
+    for trans in (0, 1):
+        ops.trsm(ctx, A, B.to(gpu_device), trans, X, None, nb, ws, reuse_inverse=True)
+        ref = torch.linalg.solve_triangular(L.t() if trans else L, B, upper=bool(trans))
+        assert relmax(X, ref) < 1e-9
+    bad = K.clone()
+    bad[n // 2, n // 2] = -1.0
+    bad = bad.to(gpu_device)
+    ops.potrf_inverse_(ctx, bad, info, nb, ws)
+    assert int(info.item()) == n // 2 + 1
+
+
 @pytest.mark.parametrize("n,nrhs,nb", [(100, 37, 64), (333, 500, 128), (700, 260, 256), (700, 260, 1024), (520, 129, 512)])
 @pytest.mark.parametrize("trans", [0, 1])
 def test_trsm_panel_vs_solve_triangular(dsvgp, gpu_device, n, nrhs, nb, trans):
