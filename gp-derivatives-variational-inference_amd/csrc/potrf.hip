@@ -295,8 +295,10 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     const int i0 = ytile ? k0 : (k + 1 + e / (k + 1)) * 64;
     const int j0 = j * 64;
     const double* Lk = ytile ? (Xws + (size_t)k * 4096) : (Wws + (size_t)k * 4096);
+    // two LDS tiles only (two workgroups per CU): R_kj waits in registers until T = A_ik W_k has been formed
+    double rc[16];
     {
-        double ra[16], rb[16], rc[16];
+        double ra[16], rb[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int r = (tid >> 6) + 4 * u, c = tid & 63;
@@ -307,15 +309,14 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int r = (tid >> 6) + 4 * u, c = tid & 63;
-            S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
-            S[2][r][c] = rb[u];
-            S[1][r][c] = rc[u];
+            S[0][r][c] = ytile ? rb[u] : ((i0 + r < n) ? ra[u] : 0.0);      // Y-tile: X_k is the left operand already
+            S[1][r][c] = ytile ? rc[u] : rb[u];
         }
     }
     __syncthreads();
     acc4 acc[2][2];
     if (!ytile) {
-        tile_product<true>(S[0], S[2], lane, wr, wc, acc);          // T = A_ik W_k
+        tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -324,6 +325,8 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + jj * 16 + (lane & 15)] = acc[i][jj][q];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) S[1][(tid >> 6) + 4 * u][tid & 63] = rc[u];
         __syncthreads();
         tile_product<false>(S[0], S[1], lane, wr, wc, acc);         // T R_kj
 #pragma unroll
@@ -337,7 +340,7 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                     *dst = ((j == k) ? 0.0 : *dst) - acc[i][jj][q];
                 }
     } else {
-        tile_product<false>(S[2], S[1], lane, wr, wc, acc);         // X_k R_kj
+        tile_product<false>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -350,11 +353,14 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     }
 }
 
-__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
-                                                        double* __restrict__ Xws, double* __restrict__ Wws,
-                                                        int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
-                                                        double* __restrict__ Yinv, int64_t ldy, int nA) {
-    __shared__ double S[4][64][LDT];
+__global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
+                                                           double* __restrict__ Xws, double* __restrict__ Wws,
+                                                           int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
+                                                           double* __restrict__ Yinv, int64_t ldy, int nA) {
+    // TWO 64 x 64 LDS tiles (70 KB with the factorisation scratch): two workgroups share a CU, which halves the rounds
+    // the ~1100 update / inverse tiles of a mid-chain launch need.  The second right operand of every tile waits in
+    // registers while the first product runs.
+    __shared__ double S[2][64][LDT];
     __shared__ double Xd[16][17];
     __shared__ double colbuf[32], rowbuf[32];      // [16..31]: dummy slots of the non-owner lanes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -368,14 +374,15 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
     while (ti * (ti + 1) / 2 > b) --ti;
     const int tj = b - ti * (ti + 1) / 2;
     const int i0 = (k + 1 + ti) * 64, j0 = (k + 1 + tj) * 64;
-    double (*F)[LDT] = S[3];
+    double (*F)[LDT] = S[0];
     CHOL_STAMP(0);
     if (k >= 0) {
         const int k0 = k * 64;
         const double* Wk = Wws + (size_t)k * 4096;
         double cv[2][2][4];    // C tile, requested behind the operand loads (clamped addresses: no predicated load -> wait -> store chains)
+        double rb[16];         // A_jk, parked until T = A_ik W_k is in LDS
         {   // all 48 + 16 loads of a thread in flight at once (a rolled loop pays the global latency 16 times)
-            double ra[16], rb[16], rw[16];
+            double ra[16], rw[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int r = (tid >> 6) + 4 * u, c = tid & 63;
@@ -397,14 +404,13 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
             for (int u = 0; u < 16; ++u) {
                 const int r = (tid >> 6) + 4 * u, c = tid & 63;
                 S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
-                S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
-                S[2][r][c] = rw[u];
+                S[1][r][c] = rw[u];
             }
         }
         __syncthreads();
         CHOL_STAMP(1);
         acc4 acc[2][2];
-        tile_product<true>(S[0], S[2], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
+        tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -413,9 +419,15 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
+        }
         __syncthreads();
         tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T A_jk^T
         const bool diag = ti == tj;
+        if (b == 0) __syncthreads();                                // F aliases the T tile: every wave is done reading it
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(256) void chol_yrow_kernel(const double* __restrict
                                                         const double* __restrict__ Xws, const double* __restrict__ Wws,
                                                         double* __restrict__ Rw, int64_t ldr, double* __restrict__ Yinv,
                                                         int64_t ldy) {
-    __shared__ double S[3][64][LDT];
+    __shared__ double S[2][64][LDT];
     const int nblk = (n + 63) / 64;
     chol_inverse_tile(S, A, lda, n, k, (nblk - (k + 1)) * (k + 1) + blockIdx.x, Xws, Wws, Rw, ldr, Yinv, ldy, nblk);
 }
