@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trsm-nb", type=int, default=int(os.environ.get("DSVGP_TRSM_NB", "4096")))
+    ap.add_argument("--no-overlap", action="store_true", help="diagnostics: no side stream under the Cholesky chain")
+    ap.add_argument("--no-fused-inverse", action="store_true", help="diagnostics: potrf + trtri recursion instead")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -108,6 +110,8 @@ def main():
                                     seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
     eng = loop.model.engine
     eng.trsm_nb = args.trsm_nb
+    eng.overlap = not args.no_overlap
+    eng.fused_inverse = not args.no_fused_inverse
     perm = loop.epoch_permutation()
     nbatches = N // B
 
