@@ -54,10 +54,15 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     const int i0 = blockIdx.y * rows_per_chunk, i1 = min(Mp, i0 + rows_per_chunk);
     if (j >= ncols) return;
     float sm = 0.f, sq = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const float a = A[(int64_t)i * lda + j], w = W[(int64_t)i * ldw + j];
-        sm = fmaf(a, m[i], sm);
-        sq += w * w - a * a;
+    if (W == A) {                 // ELBO fast path / zero middle term: only mu is wanted, A is streamed once
+#pragma unroll 4
+        for (int i = i0; i < i1; ++i) sm = fmaf(A[(int64_t)i * lda + j], m[i], sm);
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const float a = A[(int64_t)i * lda + j], w = W[(int64_t)i * ldw + j];
+            sm = fmaf(a, m[i], sm);
+            sq += w * w - a * a;
+        }
     }
     part[((int64_t)blockIdx.y * 2) * ncols + j] = sm;
     part[((int64_t)blockIdx.y * 2 + 1) * ncols + j] = sq;
@@ -150,7 +155,16 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ A
     __shared__ float red[4];
     const int i = blockIdx.x;
     float s = 0.f;
-    for (int j = threadIdx.x; j < ncols; j += 256) s = fmaf(A[(int64_t)i * lda + j], vec[j], s);
+    const float* row = A + (int64_t)i * lda;
+    if ((lda & 3) == 0 && (ncols & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)vec & 15) == 0) {
+        using f4 = float __attribute__((ext_vector_type(4)));       // 16-byte loads: the row is streamed once
+        for (int j = threadIdx.x * 4; j < ncols; j += 1024) {
+            const f4 a = *reinterpret_cast<const f4*>(row + j), v = *reinterpret_cast<const f4*>(vec + j);
+            s = fmaf(a[0], v[0], fmaf(a[1], v[1], fmaf(a[2], v[2], fmaf(a[3], v[3], s))));
+        }
+    } else {
+        for (int j = threadIdx.x; j < ncols; j += 256) s = fmaf(row[j], vec[j], s);
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -458,6 +458,13 @@ __global__ __launch_bounds__(256) void trtri64_copy_kernel(const double* __restr
 
 }  // namespace
 
+// zero an M x N block with leading dimension ld: one linear memset when the rows are contiguous (the pitched 2-D memset
+// kernel of the runtime moves < 1 TB/s: 96 us for a 3000 x 3000 fp64 output)
+static hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st) {
+    if (ld == N) return hipMemsetAsync(C, 0, esz * (size_t)M * (size_t)N, st);
+    return hipMemset2DAsync(C, esz * (size_t)ld, 0, esz * (size_t)N, (size_t)M, st);
+}
+
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.batch < 1 || g.splitk < 1) return DSVGP_EINVAL;
@@ -493,17 +500,17 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
             a.splitk = sk;
             if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; }      // atomics accumulate onto the existing C
             else {
-                hipError_t e = hipMemset2DAsync(a.C, esz * (size_t)a.ldc, 0, esz * (size_t)a.N, (size_t)a.M, st);
+                hipError_t e = zero_block(a.C, esz, a.ldc, a.M, a.N, st);
                 if (e != hipSuccess) return 1000 + (int)e;
             }
         }
     }
     if (out_lower && !keep_upper && a.splitk == 1 && a.batch == 1 && g.Cin != g.C) {
         // supertiles strictly above the diagonal are never visited: define them as zero up front
-        hipError_t e = a.C ? hipMemset2DAsync(a.C, esz * (size_t)a.ldc, 0, esz * (size_t)a.N, (size_t)a.M, st) : hipSuccess;
+        hipError_t e = a.C ? zero_block(a.C, esz, a.ldc, a.M, a.N, st) : hipSuccess;
         if (e != hipSuccess) return 1000 + (int)e;
         if (a.C32) {
-            e = hipMemset2DAsync(a.C32, 4 * (size_t)a.ldc32, 0, 4 * (size_t)a.N, (size_t)a.M, st);
+            e = zero_block(a.C32, 4, a.ldc32, a.M, a.N, st);
             if (e != hipSuccess) return 1000 + (int)e;
         }
     }
