@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--trsm-nb", type=int, default=int(os.environ.get("DSVGP_TRSM_NB", "4096")))
     ap.add_argument("--no-overlap", action="store_true", help="diagnostics: no side stream under the Cholesky chain")
     ap.add_argument("--no-fused-inverse", action="store_true", help="diagnostics: potrf + trtri recursion instead")
+    ap.add_argument("--no-lib-gemm", action="store_true", help="diagnostics: the dense K_ZX-bar product on gemm.hip")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -112,6 +113,7 @@ def main():
     eng.trsm_nb = args.trsm_nb
     eng.overlap = not args.no_overlap
     eng.fused_inverse = not args.no_fused_inverse
+    eng.lib_dense_gemm = not args.no_lib_gemm
     perm = loop.epoch_permutation()
     nbatches = N // B
 

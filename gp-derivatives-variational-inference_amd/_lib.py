@@ -36,6 +36,7 @@ SIGNATURES = {
     "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_step_epilogue": (_i, [_p, _p, _p, _d, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "dsvgp_gemm_lib_f32": (_i, [_p, _i, _i, _i, _i, _f, _p, _l, _p, _l, _f, _p, _l]),
     "dsvgp_ciq_workspace_bytes": (_z, [_i, _i, _i]),
     "dsvgp_ciq_lanczos": (_i, [_p, _p, _l, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_solve": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _f, _i, _i, _p, _p, _l, _p, _p]),

@@ -338,6 +338,19 @@ def adam_step_(ctx, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, ste
                               float(lr), float(beta1), float(beta2), float(eps), int(step)), "dsvgp_adam_step")
 
 
+def gemm_lib_f32(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0):
+    """C_out = alpha op(A) op(B) + beta C_out, plain dense fp32, through rocBLAS (no structure flags)."""
+    _req(A, f32, "A", 2); _req(B, f32, "B", 2); _req(C_out, f32, "C", 2)
+    M = A.shape[1] if flags & _lib.TRANS_A else A.shape[0]
+    K = A.shape[0] if flags & _lib.TRANS_A else A.shape[1]
+    N = B.shape[0] if flags & _lib.TRANS_B else B.shape[1]
+    kb = B.shape[1] if flags & _lib.TRANS_B else B.shape[0]
+    if kb != K or C_out.shape != (M, N):
+        raise ValueError("gemm_lib_f32 shape mismatch")
+    check(lib.dsvgp_gemm_lib_f32(ctx.h, int(flags), M, N, K, float(alpha), _ptr(A), _ld(A), _ptr(B), _ld(B), float(beta),
+                                 _ptr(C_out), _ld(C_out)), "dsvgp_gemm_lib_f32")
+
+
 # ---- contour-integral-quadrature whitening (csrc/ciq.hip) ------------------------------------------------------
 def ciq_lanczos(ctx, K, v0, iters):
     """alpha[iters], beta[iters] of `iters` Lanczos steps with the symmetric fp32 K started at v0."""

@@ -73,6 +73,7 @@ class ElboEngine:
         self.shared_directions = False
         self._no_middle = False
         self.fused_inverse = True       # L^-1 by forward elimination inside the Cholesky launches (csrc/potrf.hip)
+        self.lib_dense_gemm = True      # plain dense K_ZX-bar product through rocBLAS (129 vs 108 TF); False: gemm.hip
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
@@ -718,8 +719,12 @@ class ElboEngine:
         Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
         _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)
         # K_ZX-bar (fp32, dense) and L-bar (fp64)
-        QeT32 = self._get("QeT32", (Mp + 1, Mp), f32)          # the fp32 GEMM streams an mn-contiguous A operand ~5 % faster
-        _ops.transpose_f32(ctx, Qe32, QeT32)
-        _ops.gemm(ctx, TRANS_A, QeT32, A32e, Kb32, alpha=vbar2)
+        if self.lib_dense_gemm:
+            # the one product of the step without structure or fused epilogue: the library's tuned dense kernel
+            _ops.gemm_lib_f32(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
+        else:
+            QeT32 = self._get("QeT32", (Mp + 1, Mp), f32)      # the fp32 GEMM streams an mn-contiguous A operand ~5 % faster
+            _ops.transpose_f32(ctx, Qe32, QeT32)
+            _ops.gemm(ctx, TRANS_A, QeT32, A32e, Kb32, alpha=vbar2)
         _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)
         return packX, mu

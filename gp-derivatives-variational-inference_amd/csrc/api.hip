@@ -58,6 +58,22 @@ extern "C" int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N
     return launch_gemm(ctx->stream, is_double, g);
 }
 
+// Plain dense fp32 product through rocBLAS (row-major C = alpha op(A) op(B) + beta C): the library's tuned Tensile kernel
+// (MT128x128x64, 16x16x1 MFMA blocks, 129 TF at the C4 shape) for products with NO structure or fused epilogue -- in the
+// step that is K_ZX-bar = [Q' | a] [A ; mu_bar^T].  Everything triangular / fused / fp64 stays on gemm.hip.
+extern "C" int dsvgp_gemm_lib_f32(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                                  const float* B, int64_t ldb, float beta, float* C, int64_t ldc) {
+    if (!ctx || !A || !B || !C || M <= 0 || N <= 0 || K <= 0) return DSVGP_EINVAL;
+    if (flags & ~(DSVGP_GEMM_TRANS_A | DSVGP_GEMM_TRANS_B)) return DSVGP_EINVAL;
+    // row-major C[M,N] = op(A) op(B)  <=>  column-major C^T[N,M] = op(B)^T op(A)^T; a row-major matrix read column-major
+    // IS its transpose, so an untransposed row-major operand enters as "no transpose" and a stored-transposed one as "T"
+    const rocblas_operation ob = (flags & DSVGP_GEMM_TRANS_B) ? rocblas_operation_transpose : rocblas_operation_none;
+    const rocblas_operation oa = (flags & DSVGP_GEMM_TRANS_A) ? rocblas_operation_transpose : rocblas_operation_none;
+    rocblas_status st = rocblas_sgemm((rocblas_handle)ctx->blas, ob, oa, N, M, K, &alpha, B, (rocblas_int)ldb, A,
+                                      (rocblas_int)lda, &beta, C, (rocblas_int)ldc);
+    return st == rocblas_status_success ? 0 : 2000 + (int)st;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Panel triangular solve: op(L) X = B, L lower fp64.
 //   workspace = Dinv [n, n]  (inverted nb x nb diagonal blocks, indexed like L)

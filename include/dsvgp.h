@@ -212,6 +212,11 @@ int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_
                     float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step);
 
+/* Plain dense fp32 GEMM through rocBLAS (row-major, flags: DSVGP_GEMM_TRANS_A / _TRANS_B only): for products without
+ * structure or fused epilogue (the dense K_ZX-bar product of the ELBO fast path); everything else is dsvgp_gemm.      */
+int dsvgp_gemm_lib_f32(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                       const float* B, int64_t ldb, float beta, float* C, int64_t ldc);
+
 /* ---- contour-integral-quadrature whitening: lazify(K_ZZ).sqrt_inv_matmul(K_ZX)
  * (directionalvi/CiqDirectionalGradVariationalStrategy.py:255-256; quadrature + msMINRES of gpytorch 1.4.0
  * utils/contour_integral_quad.py, utils/minres.py).  Layout: one right-hand side per ROW, R[t, n], K[n, n] symmetric.

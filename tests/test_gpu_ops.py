@@ -247,6 +247,22 @@ def test_potrf_row_major_lower(dsvgp, gpu_device, n, algo):
     assert int(info.item()) == n // 2 + 1                       # leading minor index, as LAPACK
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_lib_f32_row_major_convention(dsvgp, gpu_device, ta, tb):
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(5 + ta + 2 * tb)
+    M, N, K = 70, 131, 53
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    C = torch.randn(M, N, generator=g)
+    ref = 0.7 * (A.t() if ta else A).double() @ (B.t() if tb else B).double() + 0.3 * C.double()
+    Cg = C.to(gpu_device)
+    ops.gemm_lib_f32(ctx, (L.TRANS_A if ta else 0) | (L.TRANS_B if tb else 0), A.to(gpu_device), B.to(gpu_device), Cg,
+                     alpha=0.7, beta=0.3)
+    assert relmax(Cg, ref) < 1e-5
+
+
 @pytest.mark.parametrize("n", [40, 64, 100, 333, 704, 1500])
 def test_potrf_inverse_fused(dsvgp, gpu_device, n):
     """Blocked Cholesky with the fused forward elimination: L and L^-1 from the same launches (ragged last block, one
