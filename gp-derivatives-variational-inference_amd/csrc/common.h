@@ -32,7 +32,7 @@ struct GemmArgs {
     int flags;
     int batch;
     int splitk;            // >1: epilogue is atomicAdd(alpha*acc) into a caller-initialised C
-    int tiles_m, tiles_n, supertile, bn, chunk;   // filled by launch_gemm (bn = output tile width, 128 or 64)
+    int tiles_m, tiles_n, supertile, bn, chunk, bm;   // filled by launch_gemm (bn / bm = output tile width / height, 128 or 64)
 };
 constexpr int DSVGP_GEMM_KEEP_UPPER = 1 << 20;   // internal flag (with OUT_LOWER): do not touch m < n
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);

@@ -63,7 +63,10 @@ extern "C" int dsvgp_debug_gemm_clock(unsigned long long* out) {
 
 namespace {
 
-constexpr int BM = 128;     // BN (128 or 64) is a template parameter: 64 doubles the tile count of M' x M' products
+constexpr int BM_MAX = 128;  // BN (128 or 64) and BM (128 or 64) are template parameters
+#ifndef GEMM_BM64
+#define GEMM_BM64 0         // tools: 1 = 64-row tiles on 4-wave workgroups for products without OUT_LOWER
+#endif
 constexpr int S_MN = 144;
 
 template <typename T> struct Mfma;
@@ -138,22 +141,23 @@ __device__ __forceinline__ void store_stage(TC* __restrict__ s, const TIn (&r)[N
     for (int i = 0; i < NT * BK / NTH; ++i) {
         const TC v = (TC)r[i] * scale;
         if (KC) s[(t / BK + (NTH / BK) * i) * (BK + 1) + (t % BK)] = v;
-        else    s[(t / NT + (NTH / NT) * i) * S_MN + (t % NT)] = v;
+        else    s[(t / NT + (NTH / NT) * i) * (NT + 16) + (t % NT)] = v;
     }
 }
 
-template <typename TC, typename TB, bool AKC, bool BKC, int BN, int NTH>
+template <typename TC, typename TB, bool AKC, bool BKC, int BN, int NTH, int BM = BM_MAX>
 __global__ __launch_bounds__(NTH, GEMM_MINW ? GEMM_MINW : NTH / 128) void gemm_kernel(GemmArgs g) {
     constexpr int NJ = BN / 32;             // 16-wide MFMA column tiles per wave
-    constexpr int RW = 128 / (NTH / 128);   // rows per wave: 64 (4 waves) or 32 (8 waves)
+    constexpr int RW = BM / (NTH / 128);    // rows per wave: 64 (4 waves) or 32 (8 waves; 4 waves on a 64-row tile)
     constexpr int MI = RW / 16;             // 16-high MFMA row tiles per wave
     using M = Mfma<TC>;
     using acc_t = typename M::acc_t;
     // two k-contiguous fp32 operands: 32-deep stages so that every row segment is a full 128-B line
     constexpr int BK = (sizeof(TC) == 4 && AKC && BKC) ? 32 : M::BK;
     constexpr int SK = BK + 1;
-    constexpr int ASZ = AKC ? BM * SK : BK * S_MN;
-    constexpr int BSZ = BKC ? BN * SK : BK * S_MN;
+    constexpr int SA = BM + 16, SB = BN + 16;   // row strides of the mn-contiguous LDS images (= 16 mod 32)
+    constexpr int ASZ = AKC ? BM * SK : BK * SA;
+    constexpr int BSZ = BKC ? BN * SK : BK * SB;
     __shared__ TC As[2][ASZ];
     __shared__ TC Bs[2][BSZ];
 
@@ -322,12 +326,12 @@ __global__ __launch_bounds__(NTH, GEMM_MINW ? GEMM_MINW : NTH / 128) void gemm_k
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int mm = wr * RW + i * 16 + (lane & 15);
-                    a[i] = AKC ? as[mm * SK + kq] : as[kq * S_MN + mm];
+                    a[i] = AKC ? as[mm * SK + kq] : as[kq * SA + mm];
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int nn = wc * (BN / 2) + j * 16 + (lane & 15);
-                    b[j] = BKC ? bs[nn * SK + kq] : bs[kq * S_MN + nn];
+                    b[j] = BKC ? bs[nn * SK + kq] : bs[kq * SB + nn];
                 }
             };
             TC a[2][MI], b[2][NJ];
@@ -399,6 +403,13 @@ __global__ __launch_bounds__(NTH, GEMM_MINW ? GEMM_MINW : NTH / 128) void gemm_k
 template <typename TC, typename TB, bool AKC, bool BKC, int BN>
 int launch_one(hipStream_t st, const GemmArgs& g, dim3 grid) {
     constexpr int NTH = (sizeof(TC) == 8 && AKC && BKC) ? 256 : GEMM_THREADS;
+#if GEMM_BM64
+    if (g.bm == 64) {
+        hipLaunchKernelGGL((gemm_kernel<TC, TB, AKC, BKC, BN, 256, 64>), grid, dim3(256), 0, st, g);
+        DSVGP_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL((gemm_kernel<TC, TB, AKC, BKC, BN, NTH>), grid, dim3(NTH), 0, st, g);
     DSVGP_LAUNCH_CHECK();
     return 0;
@@ -469,6 +480,9 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.batch < 1 || g.splitk < 1) return DSVGP_EINVAL;
     GemmArgs a = g;
+    const bool out_lower_ = g.flags & DSVGP_GEMM_OUT_LOWER;
+    a.bm = (GEMM_BM64 && !out_lower_ && g.batch == 1) ? 64 : 128;
+    const int BM = a.bm;
     a.tiles_m = cdiv(g.M, BM);
     // tile width: 128 x 64 tiles were measured SLOWER than 128 x 128 + split-K for the M' x M' products
     // (chol. backward 2.9 vs 2.3 ms, Gram 4.1 vs 3.8 ms per step at M'=3000), so 128 is used throughout
