@@ -31,6 +31,10 @@ CONFIGS = {
     # diagnostics: the per-rank shard of C4 at 8 GPUs (B = 4096 / 8) run alone -- what one rank computes per step
     "c4shard8": dict(name="DSVGP d=20 N=1M M=500 p=5 B=512 (one rank's share of C4 at 8 GPUs)", d=20, N=1_000_000, M=500,
                      p=5, B=512),
+    "c4shard4": dict(name="DSVGP d=20 N=1M M=500 p=5 B=1024 (one rank's share of C4 at 4 GPUs)", d=20, N=1_000_000, M=500,
+                     p=5, B=1024),
+    "c4shard2": dict(name="DSVGP d=20 N=1M M=500 p=5 B=2048 (one rank's share of C4 at 2 GPUs)", d=20, N=1_000_000, M=500,
+                     p=5, B=2048),
     # BASELINE config 5: CIQ whitening + NGD (no dataset / batch size given there; N and B chosen like C4's per-GPU shard)
     "c5": dict(name="CIQ-DSVGP d=50 N=100k M=1024 p=5 B=512", d=50, N=100_000, M=1024, p=5, B=512, ciq=True),
 }
