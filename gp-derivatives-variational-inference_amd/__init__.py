@@ -16,6 +16,7 @@ from . import GradVariationalStrategy as _gvs_mod  # noqa: F401
 from . import grad_svgp  # noqa: F401
 from . import dfree_directional_vi  # noqa: F401
 from . import shared_directional_vi  # noqa: F401
+from . import traditional_vi  # noqa: F401
 from ._step import ElboEngine, NotPSDError, NGD_PARAM_NAMES, PARAM_NAMES  # noqa: F401
 from .directional_vi import GPModel, TrainLoop, eval_gp, select_cols_of_y, setup_training, train_gp  # noqa: F401
 from .gp_shim import (GaussianLikelihood, NaturalVariationalDistribution, PredictiveLogLikelihood,  # noqa: F401

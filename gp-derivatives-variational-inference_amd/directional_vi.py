@@ -151,7 +151,7 @@ class TrainLoop:
             lo, hi = dp.shard_bounds(idx.shape[0])
             idx = idx[lo:hi]
         # select random columns of y to train on (function values always included), :68-90
-        if self.dfree:
+        if self.dfree or getattr(self, "plain", False):      # scalar targets: dfree_directional_vi / traditional_vi
             idx_y = [0]
         else:
             idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])

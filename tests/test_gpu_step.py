@@ -376,3 +376,44 @@ def test_shared_train_gp_drop_in(dsvgp, gpu_device, capsys):
     with pytest.raises(AssertionError):       # the reference tiles the directions in this branch and its forward assertion fails
         S.train_gp(TensorDataset(train_x, train_y), num_inducing=20, num_directions=p, minibatch_size=200,
                    minibatch_dim=p, num_epochs=1, inducing_data_initialization=True, tqdm=False, verbose=False)
+
+
+# ------------------------------------------------------------------ plain SVGP harness (BASELINE config 0)
+def test_traditional_vi_drop_in(dsvgp, gpu_device, capsys):
+    """reference tests/test_traditional_vi.py: SVGP on a 1-D sine, 50 inducing points (the p = 0 path of the engine)."""
+    import math as _m
+    from torch.utils.data import TensorDataset
+    torch.manual_seed(0)
+    n = 500
+    train_x = torch.rand(n, 1)
+    train_y = torch.sin(2 * _m.pi * train_x[:, 0]) + 0.05 * torch.randn(n)
+    test_x = torch.linspace(0.02, 0.98, 120).reshape(-1, 1)
+    test_y = torch.sin(2 * _m.pi * test_x[:, 0])
+    T = dsvgp.traditional_vi
+    model, likelihood = T.train_gp(TensorDataset(train_x, train_y), 1, num_inducing=50, minibatch_size=100, num_epochs=150,
+                                   learning_rate_hypers=0.02, tqdm=False, seed=4)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert "Using ELBO" in out and len(losses) >= 5 and losses[-1] < losses[0]
+    sd = model.state_dict()
+    assert sd["variational_strategy.inducing_points"].shape == (50, 1)
+    assert sd["variational_strategy._variational_distribution.chol_variational_covar"].shape == (50, 50)
+    means, variances = T.eval_gp(TensorDataset(test_x, test_y), model, likelihood, minibatch_size=60)
+    assert means.shape == (120,) and (variances > 0).all()
+    assert ((means - test_y) ** 2).mean().item() < 0.05
+    # one step of the trained model against the oracle with no directions at all
+    P = {k: v.detach().cpu() for k, v in model._param_dict(likelihood).items()}
+    x, y = train_x[:64], train_y[:64].contiguous()
+    D = torch.empty(0, 1)
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, n)
+    eng = dsvgp.ElboEngine(gpu_device)
+    loss, grads, mu, varn = eng.loss_and_grads({k: v.to(gpu_device) for k, v in P.items()}, x.to(gpu_device),
+                                               y.to(gpu_device), D.to(gpu_device), n, fast=False)
+    assert abs(loss.item() - l_ref.item()) < 1e-4 * abs(l_ref.item())
+    assert relmax(mu, mu_ref) < 1e-3 and relmax(varn, var_ref) < 1e-3
+    # natural-gradient variant of the same harness
+    model2, lik2 = T.train_gp(TensorDataset(train_x, train_y), 1, num_inducing=30, minibatch_size=100, num_epochs=40,
+                              use_ngd=True, learning_rate_ngd=0.1, tqdm=False, seed=4, verbose=False)
+    m2, v2 = T.eval_gp(TensorDataset(test_x, test_y), model2, lik2, minibatch_size=60)
+    assert torch.isfinite(m2).all() and (v2 > 0).all()
+    assert "variational_strategy._variational_distribution.natural_vec" in model2.state_dict()
