@@ -47,9 +47,12 @@ class _Refactored(Exception):
 class ElboEngine:
     """Owns the HBM workspaces of one (M', B', d, p) configuration on one GPU."""
 
-    def __init__(self, device, trsm_nb=512):
+    def __init__(self, device, trsm_nb=None):
         self.device = torch.device(device)
-        self.trsm_nb = int(trsm_nb)
+        # block size of the panel triangular solve.  None = automatic: the explicit-inverse regime (one triangular MFMA
+        # product per solve, inverse fused into the Cholesky launches) whenever M' <= 8192, 512-wide panels beyond
+        self._trsm_nb = None if trsm_nb is None else int(trsm_nb)
+        self._auto_nb = 512
         self._buf = {}
         self.chol_jitter = CHOL_JITTER  # base of the psd_safe_cholesky retry ladder (1e-8 for GradVariationalStrategy)
         self.potrf_algo = 1             # 1: blocked Cholesky on the MFMA GEMM (csrc/potrf.hip, 5.7 ms at M'=3000),
@@ -82,6 +85,18 @@ class ElboEngine:
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
 
+    @property
+    def trsm_nb(self):
+        return self._trsm_nb if self._trsm_nb is not None else self._auto_nb
+
+    @trsm_nb.setter
+    def trsm_nb(self, value):
+        self._trsm_nb = None if value is None else int(value)
+
+    def _problem_size(self, Mp):
+        """resolve the automatic solve regime for an M' x M' inducing system"""
+        self._auto_nb = (1 << max(6, (int(Mp) - 1).bit_length())) if Mp <= 8192 else 512
+
     # ---- workspace management ---------------------------------------------------------------
     def _get(self, name, shape, dtype):
         t = self._buf.get(name)
@@ -110,6 +125,7 @@ class ElboEngine:
         M, d = Z.shape
         p = V.shape[0] // M if M else 0
         Mp = M * (p + 1)
+        self._problem_size(Mp)
         hyp = _ops.hyp_forward(ctx, params["raw_lengthscale"], params["raw_outputscale"], params["raw_noise"])
         # common shift of Z and x (gpytorch covar_dist centres on x1.mean): keeps the fp32 quadratic expansion accurate
         self.center = _ops.column_mean(ctx, Z.contiguous())
@@ -323,6 +339,7 @@ class ElboEngine:
         """P = -2 theta_2 = L_P L_P^T (fp64), S = L_P^-T L_P^-1, mu = S theta_1.  Returns (S fp64 [M',M'], mu fp64 [M',1],
         device status word of the factorisation)."""
         Mp = nat_vec.shape[0]
+        self._problem_size(Mp)
         nb = self.trsm_nb
         P = self._get("ngd_P", (Mp, Mp), f64)
         P.copy_(nat_mat)
