@@ -53,6 +53,9 @@ class ElboEngine:
         # product per solve, inverse fused into the Cholesky launches) whenever M' <= 8192, 512-wide panels beyond
         self._trsm_nb = None if trsm_nb is None else int(trsm_nb)
         self._auto_nb = 512
+        self.early_reduce = None      # data-parallel hook: callable(flat_early) -> handle with .wait()
+        self._early_handle = None
+        self._allow_early = False
         self._buf = {}
         self.chol_jitter = CHOL_JITTER  # base of the psd_safe_cholesky retry ladder (1e-8 for GradVariationalStrategy)
         self.potrf_algo = 1             # 1: blocked Cholesky on the MFMA GEMM (csrc/potrf.hip, 5.7 ms at M'=3000),
@@ -300,6 +303,8 @@ class ElboEngine:
         self._eval_cache = None
         if fast is None:
             fast = self.elbo_fast
+        self._allow_early = False
+        self._early_handle = None
         if self.whitening == "ciq":
             return self._ciq_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, True)
         if self.shared_directions:
@@ -311,6 +316,7 @@ class ElboEngine:
             nat = (m32, LS64, wsS)
             params = {k: v for k, v in params.items() if not k.startswith("natural_")}
             params["variational_mean"], params["chol_variational_covar"] = m32, LS32
+        self._allow_early = nat is None     # (natural / shared parameterisations post-process m-bar and L_S-bar)
         try:        # first attempt: potrf status read only after the forward solve has been queued
             out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
         except _Refactored:
@@ -322,17 +328,29 @@ class ElboEngine:
         return out
 
     def _alloc_grads(self, params, names):
-        """All gradients + the loss in ONE flat buffer (one fill; the data-parallel all-reduce needs no packing).
+        """All gradients + the loss in ONE flat buffer (one fill; the data-parallel all-reduce needs no packing), the
+        variational parameters (names[2:4], 99.8 % of the bytes) first: they are final half-way through the backward, so
+        the data-parallel layer reduces ``flat_early`` while the rest of the step runs and ``flat_late`` at the end.
         Returns (dict of views, loss slot, d_hyp[4])."""
-        sizes = [params[k].numel() for k in names]
-        total = sum((nk + 15) // 16 * 16 for nk in sizes)           # every segment starts 64-byte aligned
+        order = list(names[2:4]) + list(names[:2]) + list(names[4:])
+        pad = lambda nk: (nk + 15) // 16 * 16                       # every segment starts 64-byte aligned
+        total = sum(pad(params[k].numel()) for k in order)
         flat = torch.zeros(total + 1 + 4, dtype=f32, device=self.device)
-        grads, off = {}, 0
-        for k, nk in zip(names, sizes):
-            grads[k] = flat[off:off + nk].view(params[k].shape)
-            off += (nk + 15) // 16 * 16
+        views, off = {}, 0
+        for k in order:
+            nk = params[k].numel()
+            views[k] = flat[off:off + nk].view(params[k].shape)
+            off += pad(nk)
+        early = sum(pad(params[k].numel()) for k in order[:2])
         self.flat = flat[:off + 1]                      # [grads (padded)..., loss]
-        return grads, flat[off:off + 1], flat[off + 1:off + 5]
+        self.flat_early, self.flat_late = flat[:early], flat[early:off + 1]
+        self._early_handle = None
+        return {k: views[k] for k in names}, flat[off:off + 1], flat[off + 1:off + 5]
+
+    def _variational_grads_final(self):
+        """called once m-bar and L_S-bar are complete: hand them to the data-parallel layer (asynchronous all-reduce)"""
+        if self.early_reduce is not None and self._allow_early:
+            self._early_handle = self.early_reduce(self.flat_early)
 
     # ---- q(u) in natural parameters (gpytorch 1.4.0 NaturalVariationalDistribution / _NaturalToMuVarSqrt) ----
     def _natural_moments(self, ctx, nat_vec, nat_mat):
@@ -631,6 +649,7 @@ class ElboEngine:
             _ops.rowdot_accum(ctx, A32, mu_bar, dm)                             # A mu_bar
             if include_kl:
                 _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
+            self._variational_grads_final()
             # ---- through the triangular solve (fp64) ----
             Kb64 = self._get("Kb64", (Mp, Bp), f64)
             ws = self._buf["trsm_ws"]
@@ -731,6 +750,7 @@ class ElboEngine:
         Ge[Mp].copy_(dm)
         if include_kl:
             _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
+        self._variational_grads_final()
         # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
         Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
         Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)

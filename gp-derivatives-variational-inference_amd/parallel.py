@@ -2,8 +2,10 @@
 
 The reference is single-process (no collective anywhere); this layer is new.
 The ELBO log-likelihood is a sum over minibatch rows, so rank g takes rows [g*B/G, (g+1)*B/G) of every
-global minibatch, computes partial gradients normalised by the GLOBAL row count, and ONE
-all-reduce(sum) of a flat fp32 buffer [grads..., loss] makes them identical on every rank.  K_ZZ, its
+global minibatch, computes partial gradients normalised by the GLOBAL row count, and an all-reduce(sum)
+of a flat fp32 buffer [grads..., loss] makes them identical on every rank -- issued in two pieces: the
+variational-parameter gradients (36 MB at M'=3000) as soon as they are final, overlapped with the rest of
+the backward, and the small remainder at the end of the step.  K_ZZ, its
 Cholesky factor and the KL term are replicated; the KL term is added on rank 0 only so that the sum
 counts it once.  The Cholesky backward is linear in its upstream gradient, so reducing the final
 parameter gradients (not L-bar) is exact.
@@ -31,16 +33,31 @@ class DataParallel:
         """x, y, D are this rank's shard.  Returns globally reduced (loss, grads, local mu, local varn)."""
         p1 = y.shape[0] // max(x.shape[0], 1) if x.shape[0] else 1
         rows = (self.global_batch if self.global_batch is not None else x.shape[0] * self.world) * p1
-        loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type, global_rows=rows,
-                                                      include_kl=(self.rank == 0))
+        # engines with a flat gradient buffer call this back as soon as m-bar and L_S-bar (99.8 % of the bytes) are final:
+        # their all-reduce then runs on the collective's own stream under the rest of the backward
+        if hasattr(engine, "early_reduce"):
+            engine.early_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        try:
+            loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type, global_rows=rows,
+                                                          include_kl=(self.rank == 0))
+        finally:
+            if hasattr(engine, "early_reduce"):
+                engine.early_reduce = None
         flat = getattr(engine, "flat", None)
         names = list(grads.keys())
-        if flat is None or flat.data_ptr() != grads[names[0]].data_ptr():                 # engines without a flat buffer
+        lo = min(grads[k].data_ptr() for k in names)
+        if flat is None or flat.data_ptr() != lo:                                         # engines without a flat buffer
             flat = torch.cat([grads[k].reshape(-1) for k in names] + [loss.reshape(1).to(grads[names[0]].dtype)])
             views = None
         else:
             views = grads                       # the engine's gradients ARE views of [grads..., loss]
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        early = getattr(engine, "_early_handle", None) if views is not None else None
+        if early is not None:
+            dist.all_reduce(engine.flat_late, op=dist.ReduceOp.SUM, group=self.group)     # [Z-bar, V-bar, scalars, loss]
+            early.wait()
+            engine._early_handle = None
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         if views is not None:
             return flat[-1], views, mu, varn
         off = 0

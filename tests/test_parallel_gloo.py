@@ -26,6 +26,30 @@ class OracleEngine:
         return loss.detach(), grads, mu.detach(), varn.detach()
 
 
+def _flat_engine(dsvgp_amd):
+    """The product engine's own gradient layout and early-reduce protocol (ElboEngine._alloc_grads /
+    _variational_grads_final), with the numbers supplied by the oracle: the m-bar / L_S-bar segment is handed to the
+    data-parallel layer BEFORE the remaining gradients are written, as in the HIP step."""
+
+    class FlatOracleEngine(dsvgp_amd.ElboEngine):
+        def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True):
+            loss, g, mu, varn = OracleEngine().loss_and_grads(params, x, y, D, num_data, mll_type, global_rows, include_kl)
+            p32 = {k: v.float() for k, v in params.items()}
+            grads, loss_out, _ = self._alloc_grads(p32, O.PARAM_NAMES)
+            for k in ("variational_mean", "chol_variational_covar"):
+                grads[k].copy_(g[k])
+            self._allow_early = True
+            self._variational_grads_final()
+            self.fired = self._early_handle is not None
+            for k in O.PARAM_NAMES:
+                if k not in ("variational_mean", "chol_variational_covar"):
+                    grads[k].copy_(g[k])
+            loss_out.copy_(loss.reshape(1))
+            return loss_out[0], grads, mu, varn
+
+    return FlatOracleEngine(torch.device("cpu"))
+
+
 def _problem():
     g = torch.Generator().manual_seed(0)
     N, d, M, p, B = 80, 4, 7, 2, 11          # odd global batch: ragged shards
@@ -49,6 +73,14 @@ def _worker(rank, world, port, out):
     dp.global_batch = x.shape[0]
     loss, grads, mu, varn = dp.loss_and_grads(OracleEngine(), P, x[lo:hi], y[lo * (p + 1):hi * (p + 1)],
                                               D[lo * p:hi * p], nd, "ELBO")
+    # the same step through the product engine's flat buffer: early (overlapped) + late all-reduce
+    eng = _flat_engine(dsvgp_amd)
+    loss2, grads2, _, _ = dp.loss_and_grads(eng, P, x[lo:hi], y[lo * (p + 1):hi * (p + 1)], D[lo * p:hi * p], nd, "ELBO")
+    assert eng.fired and eng.early_reduce is None and eng._early_handle is None
+    assert grads2["variational_mean"].data_ptr() == eng.flat.data_ptr()       # variational segment leads the buffer
+    assert eng.flat_early.numel() + eng.flat_late.numel() == eng.flat.numel()
+    err = max((grads2[k].double() - grads[k]).abs().max().item() / (1e-30 + grads[k].abs().max().item()) for k in grads)
+    assert err < 1e-6 and abs(loss2.item() - loss.item()) < 1e-5 * abs(loss.item()), (err, loss2.item(), loss.item())
     out[rank] = (loss.item(), {k: v.clone() for k, v in grads.items()}, (lo, hi), mu.shape[0])
     dist.destroy_process_group()
 
