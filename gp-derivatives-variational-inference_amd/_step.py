@@ -271,7 +271,51 @@ class ElboEngine:
                 self._no_middle = False
         return self._predict_chol(ctx, params, x, D, cache)
 
-    def _predict_chol(self, ctx, params, x, D, cache):
+    @torch.no_grad()
+    def predict_joint(self, params, x, D, cache=False):
+        """Mean [B'] and the FULL predictive covariance [B', B'] (fp32, likelihood noise on the diagonal): the
+        MultivariateNormal behind ``likelihood(model(x, derivative_directions=D))`` (reference DGVS.py:199-208), which the
+        BO drivers sample jointly (experiments/GNN_bo/gcn_turbo.py:238-239).
+        Sigma = s K_XX + 1e-4 I + W^T W - A^T A + noise I: one symmetric kernel assembly and two MFMA Gram products."""
+        ctx = _ops.Context.get(self.device)
+        if self.whitening == "ciq":
+            raise NotImplementedError("joint predictive covariance is built for the Cholesky-whitened strategies only")
+        if self.shared_directions:
+            params, _ = self._shared_expand(params)
+            self._no_middle = True
+            try:
+                return self._predict_chol(ctx, params, x, D, cache, joint=True)
+            finally:
+                self._no_middle = False
+        return self._predict_chol(ctx, params, x, D, cache, joint=True)
+
+    @torch.no_grad()
+    def covariance_root(self, Sigma):
+        """Lower Cholesky factor (fp64) of a predictive covariance, with the psd_safe_cholesky jitter ladder."""
+        ctx = _ops.Context.get(self.device)
+        n = Sigma.shape[0]
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        jit = 0.0
+        for t in range(-1, 3):
+            R = Sigma.to(f64)
+            if t >= 0:
+                jit = self.chol_jitter * 10.0 ** t
+                _ops.add_diag_(ctx, R, jit)
+            info.zero_()
+            _ops.potrf_(ctx, R, info, self.potrf_algo)
+            if int(info.item()) == 0:
+                return R
+        raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %g" % jit)
+
+    @torch.no_grad()
+    def draw(self, mu, root, eps):
+        """mu + tril(root) eps_i for every row eps_i of eps [n, B']: one triangular fp64 MFMA product.  Returns [n, B'] fp32."""
+        ctx = _ops.Context.get(self.device)
+        out = torch.empty(mu.shape[0], eps.shape[0], dtype=f64, device=self.device)
+        _ops.gemm(ctx, A_LOWER, root, eps.t().contiguous(), out)
+        return out.t().to(f32) + mu
+
+    def _predict_chol(self, ctx, params, x, D, cache, joint=False):
         key = tuple((t.data_ptr(), t._version) for t in params.values()) if cache else None
         hit = cache and self._eval_cache is not None and self._eval_cache[0] == key
         if "natural_vec" in params:
@@ -288,7 +332,18 @@ class ElboEngine:
             pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
             hyp, packZ, L, dims = self._factor(ctx, params, nrhs=x.shape[0] * (self._pd(pz) + 1))
             self._eval_cache = (key, hyp, packZ, L, dims, params) if cache else None
-        _, _, _, _, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=hit)
+        packX, _, A32, W, mu, var = self._interp(ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=hit)
+        if joint:
+            M, d, p, Mp = dims
+            B = x.shape[0]
+            Sigma = _ops.kernel_fwd(ctx, packX, B, packX, B, d, p, hyp)            # s K(X, X; D, D), all (p+1)^2 blocks
+            if self.data_outputs == "values" and p > 0:
+                Sigma = Sigma[::p + 1, ::p + 1].contiguous()
+            if not self._no_middle:
+                _ops.gemm(ctx, TRANS_A, W, W, Sigma, beta=1.0, Cin=Sigma)          # + W^T W
+                _ops.gemm(ctx, TRANS_A, A32, A32, Sigma, alpha=-1.0, beta=1.0, Cin=Sigma)   # - A^T A
+            Sigma.diagonal().add_(hyp[2] + 1e-4)                                   # add_jitter(1e-4) + likelihood noise
+            return mu, Sigma
         varn = (var + hyp[2]).clamp_min_(1e-6)
         return mu, varn
 

@@ -156,6 +156,47 @@ class PredictiveDistribution:
     def stddev(self):
         return self.variance.sqrt()
 
+    def confidence_region(self):
+        """(mean - 2 std, mean + 2 std), gpytorch MultivariateNormal.confidence_region"""
+        std2 = self.stddev.mul(2)
+        return self.mean - std2, self.mean + std2
+
+    # ---- joint distribution over the B(p+1) outputs of the batch (BO drivers: ``preds.sample(torch.Size([n]))``,
+    #      reference experiments/GNN_bo/gcn_turbo.py:238-239, experiments/rover/test_turbo.py:138) ----
+    def _ensure_joint(self):
+        if getattr(self, "_Sigma", None) is None:
+            lik = self.likelihood
+            params = self.model._param_dict(lik)
+            mu, Sigma = self.model.engine.predict_joint(params, self.x, self.D, cache=not self.model.training)
+            if lik is None:   # q(f) itself: remove the noise again
+                Sigma.diagonal().sub_(torch.nn.functional.softplus(params["raw_noise"].reshape(())) + 1e-4)
+            self._mu, self._Sigma, self._root = mu, Sigma, None
+
+    @property
+    def covariance_matrix(self):
+        self._ensure_joint()
+        return self._Sigma
+
+    def rsample(self, sample_shape=torch.Size(), base_samples=None):
+        """mean + chol(Sigma) eps: exact Cholesky root on the GPU (fp64 blocked MFMA factorisation) where gpytorch switches
+        to a Lanczos root above ``max_cholesky_size``.  Shape ``sample_shape + [B(p+1)]``."""
+        self._ensure_joint()
+        eng = self.model.engine
+        if self._root is None:
+            self._root = eng.covariance_root(self._Sigma)
+        n_out = self._mu.shape[0]
+        sample_shape = torch.Size(sample_shape)
+        n = int(sample_shape.numel()) if len(sample_shape) else 1
+        if base_samples is None:
+            eps = torch.randn(n, n_out, dtype=torch.float32, device=self._mu.device)
+        else:
+            eps = base_samples.reshape(n, n_out).to(torch.float32)
+        return eng.draw(self._mu, self._root, eps).reshape(tuple(sample_shape) + (n_out,))
+
+    def sample(self, sample_shape=torch.Size(), base_samples=None):
+        with torch.no_grad():
+            return self.rsample(sample_shape, base_samples)
+
 
 class _ApproximateMLL(torch.nn.Module):
     mll_type = "ELBO"

@@ -137,6 +137,33 @@ def predictive(params, x, D, solve_dtype=torch.float64, data_outputs="all"):
     return mu, var
 
 
+def predictive_joint(params, x, D, solve_dtype=torch.float64, data_outputs="all"):
+    """Mean and FULL covariance of q(f) at the batch (no likelihood noise): the MultivariateNormal that
+    ``model(x, derivative_directions=D)`` returns in eval mode, reference DGVS.py:199-208
+    (``data_data_covar.add_jitter(1e-4) + A_t^T (S - I) A``); ``likelihood(.)`` adds ``noise * I``.  The BO drivers draw
+    joint samples from it (experiments/GNN_bo/gcn_turbo.py:238-239)."""
+    Z, V = params["inducing_points"], params["inducing_directions"]
+    m = params["variational_mean"]
+    L_S = torch.tril(params["chol_variational_covar"])
+    c = params["constant"].reshape(())
+    ell, s, _ = constrained(params)
+    M = Z.shape[0]
+    p = V.shape[0] // M
+    dt = x.dtype
+    K_ZX = s * kernel_matrix(Z, x, V, D, ell)
+    K_XX = s * kernel_matrix(x, x, D, D, ell)
+    K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
+    K_ZZ = K_ZZ + KZZ_JITTER * torch.eye(K_ZZ.shape[0], dtype=dt)
+    if data_outputs == "values":
+        K_ZX, K_XX = K_ZX[:, ::p + 1], K_XX[::p + 1, ::p + 1]
+    L = psd_safe_cholesky(K_ZZ.to(solve_dtype))
+    A = torch.linalg.solve_triangular(L, K_ZX.to(solve_dtype), upper=False).to(dt)
+    mu = A.t() @ m + c
+    W = L_S.t() @ A
+    Sigma = K_XX + KXX_JITTER * torch.eye(K_XX.shape[0], dtype=dt) + W.t() @ W - A.t() @ A
+    return mu, Sigma
+
+
 def kl_whitened(m, L_S):
     """KL(q(u) || N(0, I)); gpytorch kl_mvn_mvn with the whitened prior of DGVS.py:77-87."""
     Mp = m.shape[0]

@@ -417,3 +417,64 @@ def test_traditional_vi_drop_in(dsvgp, gpu_device, capsys):
     m2, v2 = T.eval_gp(TensorDataset(test_x, test_y), model2, lik2, minibatch_size=60)
     assert torch.isfinite(m2).all() and (v2 > 0).all()
     assert "variational_strategy._variational_distribution.natural_vec" in model2.state_dict()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["all", "values"])
+def test_joint_predictive_covariance_matches_oracle(dsvgp, gpu_device, mode):
+    """Full covariance of likelihood(model(x)) (reference DGVS.py:199-208): HIP assembly + Gram products vs the oracle."""
+    P, x, y, D, nd = make_problem(500, 5, 40, 2, 60, seed=4)
+    mu_ref, Sig_ref = O.predictive_joint({k: v.double() for k, v in P.items()}, x.double(), D.double(), data_outputs=mode)
+    _, _, noise = O.constrained(P)
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.data_outputs = mode
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    mu, Sigma = eng.predict_joint(Pg, x.to(gpu_device), D.to(gpu_device))
+    n = 60 * (3 if mode == "all" else 1)
+    assert Sigma.shape == (n, n) and Sigma.dtype == torch.float32
+    Sig_ref = Sig_ref + noise.double() * torch.eye(n, dtype=torch.float64)
+    assert relmax(mu, mu_ref) < 5e-4 and relmax(Sigma, Sig_ref) < 5e-4
+    assert (Sigma - Sigma.t()).abs().max().item() < 1e-5 * Sigma.abs().max().item()
+    # its diagonal is what predict() returns
+    _, varn = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(Sigma.diagonal(), varn) < 1e-4
+    # Cholesky root reproduces Sigma; sampling through it is mean + root eps
+    R = torch.tril(eng.covariance_root(Sigma))
+    assert relmax(R @ R.t(), Sig_ref) < 5e-4
+    eps = torch.randn(7, n, device=gpu_device)
+    draws = eng.draw(mu, eng.covariance_root(Sigma), eps)
+    assert relmax(draws, mu.double().cpu() + eps.double().cpu() @ R.cpu().t()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_distribution_sample_protocol_of_bo_drivers(dsvgp, gpu_device):
+    """``likelihood(model(x, derivative_directions=D)).sample(torch.Size([n]))[:, ::p+1]`` as the reference's BO drivers
+    call it (experiments/GNN_bo/gcn_turbo.py:238-239): shapes, moments of the draws, base_samples determinism."""
+    torch.manual_seed(0)
+    dim, p, M, nx = 3, 2, 12, 20
+    Z = torch.rand(M, dim)
+    model = dsvgp.GPModel(Z, torch.eye(dim)[:p].repeat(M, 1), dim).to(gpu_device)
+    likelihood = dsvgp.gp_shim.GaussianLikelihood().to(gpu_device)
+    model.eval()
+    likelihood.eval()
+    x = torch.rand(nx, dim, device=gpu_device)
+    D = torch.eye(dim)[:p].repeat(nx, 1).to(gpu_device)
+    with torch.no_grad():
+        preds = likelihood(model(x, derivative_directions=D))
+        S = preds.sample(torch.Size([4000]))
+        assert S.shape == (4000, nx * (p + 1)) and S[:, ::model.num_directions + 1].shape == (4000, nx)
+        assert preds.sample().shape == (nx * (p + 1),)
+        Sigma = preds.covariance_matrix
+        assert relmax(Sigma.diagonal(), preds.variance) < 1e-4
+        emp = torch.cov(S.t().double())
+        assert (emp.cpu() - Sigma.double().cpu()).abs().max().item() < 0.12 * Sigma.abs().max().item()
+        assert (S.mean(0) - preds.mean).abs().max().item() < 0.1 * Sigma.diagonal().max().sqrt().item()
+        eps = torch.randn(5, nx * (p + 1), device=gpu_device)
+        a, b = preds.rsample(torch.Size([5]), base_samples=eps), preds.rsample(torch.Size([5]), base_samples=eps)
+        assert torch.equal(a, b)
+        lo, hi = preds.confidence_region()
+        assert torch.allclose(hi - lo, 4 * preds.stddev)
+        # q(f) without the likelihood: noise removed from the diagonal only
+        Sf = model(x, derivative_directions=D).covariance_matrix
+        noise = likelihood.noise.reshape(())
+        assert relmax(Sigma - Sf, noise * torch.eye(nx * (p + 1), device=gpu_device)) < 1e-3
