@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--trsm-nb", type=int, default=int(os.environ.get("DSVGP_TRSM_NB", "4096")))
     ap.add_argument("--no-overlap", action="store_true", help="diagnostics: no side stream under the Cholesky chain")
     ap.add_argument("--no-fused-inverse", action="store_true", help="diagnostics: potrf + trtri recursion instead")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="diagnostics (N = 1): rank 0's work of a W-rank job, collectives skipped")
+    ap.add_argument("--no-global-gram", action="store_true",
+                    help="diagnostics (N > 1): all-reduce the variational gradients instead of [G ; b^T], replicated Cholesky backward")
     ap.add_argument("--no-lib-gemm", action="store_true", help="diagnostics: the dense K_ZX-bar product on gemm.hip")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -118,6 +122,19 @@ def main():
     eng.overlap = not args.no_overlap
     eng.fused_inverse = not args.no_fused_inverse
     eng.lib_dense_gemm = not args.no_lib_gemm
+    eng.global_gram = not args.no_global_gram
+    if args.emulate_world > 1 and world == 1:
+        # diagnostics on a one-GPU box: run rank 0's share of the work of a W-rank job with the collectives skipped
+        # (use with --config c4shardW; not a measurement of the job, only of one rank's kernels)
+        class _NoComm:
+            rank, world = 0, args.emulate_world
+
+            def all_reduce_async(self, t):
+                class _H:
+                    def wait(self):
+                        pass
+                return _H()
+        eng.collective = _NoComm()
     perm = loop.epoch_permutation()
     nbatches = N // B
 

@@ -53,9 +53,14 @@ class ElboEngine:
         # product per solve, inverse fused into the Cholesky launches) whenever M' <= 8192, 512-wide panels beyond
         self._trsm_nb = None if trsm_nb is None else int(trsm_nb)
         self._auto_nb = 512
-        self.early_reduce = None      # data-parallel hook: callable(flat_early) -> handle with .wait()
+        # data-parallel hook (parallel.DataParallel while a sharded step runs): .rank, .world and
+        # .all_reduce_async(tensor) -> handle with .wait()
+        self.collective = None
+        self.global_gram = True       # ELBO fast path on > 1 rank: reduce [G ; b^T] early, split the Cholesky backward by columns
         self._early_handle = None
         self._allow_early = False
+        self._global_gram = False
+        self.variational_grads_global = False     # the last step returned m-bar / L_S-bar already summed over the ranks
         self._buf = {}
         self.chol_jitter = CHOL_JITTER  # base of the psd_safe_cholesky retry ladder (1e-8 for GradVariationalStrategy)
         self.potrf_algo = 1             # 1: blocked Cholesky on the MFMA GEMM (csrc/potrf.hip, 5.7 ms at M'=3000),
@@ -360,6 +365,7 @@ class ElboEngine:
             fast = self.elbo_fast
         self._allow_early = False
         self._early_handle = None
+        self.variational_grads_global = False
         if self.whitening == "ciq":
             return self._ciq_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, True)
         if self.shared_directions:
@@ -404,8 +410,8 @@ class ElboEngine:
 
     def _variational_grads_final(self):
         """called once m-bar and L_S-bar are complete: hand them to the data-parallel layer (asynchronous all-reduce)"""
-        if self.early_reduce is not None and self._allow_early:
-            self._early_handle = self.early_reduce(self.flat_early)
+        if self.collective is not None and self._allow_early and self.collective.world > 1:
+            self._early_handle = self.collective.all_reduce_async(self.flat_early)
 
     # ---- q(u) in natural parameters (gpytorch 1.4.0 NaturalVariationalDistribution / _NaturalToMuVarSqrt) ----
     def _natural_moments(self, ctx, nat_vec, nat_mat):
@@ -649,6 +655,22 @@ class ElboEngine:
             Kbar.mul_(0.5)
         return Kbar
 
+    def _chol_backward_cols(self, ctx, L, Lbar, ws, Mp, c0, c1):
+        """Columns [c0, c1) of K-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 from the explicit inverse in ``ws``
+        (one rank's share of the Cholesky backward under the global-Gram schedule): 2 M'^2 w flops instead of 3 M'^3."""
+        G1 = self._get("G1", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar)
+        _ops.phi_symmetrize_(ctx, G1)                                       # S = Phi(.) + Phi(.)^T
+        Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
+        w = c1 - c0
+        T = self._get("cbT", (Mp, w), f64)
+        # S L^-1[:, c0:c1]: rows < c0 of that column block of the lower-triangular inverse are zero, the rest is lower
+        # triangular in its own coordinates (nothing above the diagonal of the workspace is read)
+        _ops.gemm(ctx, B_LOWER, G1[:, c0:], Linv[c0:, c0:c1], T)
+        Kc = self._get("cbK", (Mp, w), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER, Linv, T, Kc, alpha=0.5)
+        return Kc
+
     def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         use_fast = mll_type == "ELBO" and fast
         Mz = params["inducing_points"].shape[0]
@@ -677,6 +699,9 @@ class ElboEngine:
         Kb32 = self._get("Kb32", (Mp, Bp), f32)
         y = y.contiguous()
 
+        coll = self.collective
+        self._global_gram = bool(use_fast and self.global_gram and self._allow_early and coll is not None
+                                 and coll.world > 1 and self.trsm_nb >= Mp and M >= coll.world)
         if use_fast:
             if not side:        # no overlap: the prologue runs in line
                 side.update(self._fast_prologue(ctx, params, hyp, x, D, rows))
@@ -711,15 +736,25 @@ class ElboEngine:
             _ops.trsm(ctx, L, Abar, True, Kb64, Kb32, self.trsm_nb, ws, reuse_inverse=True)   # K_ZX-bar = L^-T Abar
             _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb64, A64, Lbar, alpha=-1.0)    # L-bar = -tril(K_ZX-bar A^T)
 
-        # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 ----
-        Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp)
-
-        # ---- kernel backward: K_ZX (data side carries no gradient) and symmetric K_ZZ ----
         dZ, dV = grads["inducing_points"], grads["inducing_directions"]
         kws = self._bytes("kbwd_ws", max(_lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p),
                                          _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, M, d, p)))
-        self._kernel_bwd_zx(ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws)
-        _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
+        self._kernel_bwd_zx(ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws)     # data side: no gradient
+        if self._global_gram:
+            # L-bar is the same on every rank: each takes the inducing points [m0, m1) = columns [m0 q, m1 q) of the
+            # symmetric K_ZZ-bar, whose contributions sum in the final all-reduce of (Z-bar, V-bar, hyper-parameters)
+            q = p + 1
+            base, rem = divmod(M, coll.world)
+            m0 = coll.rank * base + min(coll.rank, rem)
+            m1 = m0 + base + (1 if coll.rank < rem else 0)
+            Kcols = self._chol_backward_cols(ctx, L, Lbar, self._buf["trsm_ws"], Mp, m0 * q, m1 * q)
+            sub = (packZ[0][m0 * q:m1 * q], packZ[1][m0 * q:m1 * q])
+            _ops.kernel_bwd(ctx, Kcols, packZ, M, sub, m1 - m0, d, p, hyp, True, dZ, dV, d_hyp, kws)
+            self.variational_grads_global = True
+        else:
+            # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1, symmetric kernel backward ----
+            Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp)
+            _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
 
         # ---- scalars: d_hyp += data-term scalars, softplus chain rule, d constant, loss (one launch) ----
         _ops.step_epilogue(ctx, scal, kl_buf, rows, num_data, params["raw_lengthscale"].reshape(-1),
@@ -794,29 +829,63 @@ class ElboEngine:
         Ge = self._get("Ge", (Mp + 1, Mp), f32)              # [G ; b^T]
         G = Ge[:Mp]
         _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, A32, G)     # tril(A A^T), split-K over the minibatch axis
-        _ops.mirror_lower_f32_(ctx, G, Mp)
-        self._finish_factor(ctx)                             # host sync, hidden behind the queued solve + Gram product
+        coll = self.collective if self._global_gram else None
+        handle = None
+        if coll is not None:
+            # data parallel, "global Gram" schedule: everything downstream of [G ; b^T] is linear in it, so the ranks sum
+            # THAT (36 MB, under the Q' solve and the K_ZX-bar product) instead of the L_S gradient at the end: L_S-bar and
+            # m-bar then come out global on every rank, and the replicated Cholesky backward can be split by column blocks
+            bt = Ge[Mp]
+            bt.zero_()
+            _ops.rowdot_accum(ctx, A32, mu_bar, bt)          # b = A mu_bar (this rank's rows)
+            self._finish_factor(ctx)
+            handle = coll.all_reduce_async(Ge)
+        else:
+            _ops.mirror_lower_f32_(ctx, G, Mp)
+            self._finish_factor(ctx)                         # host sync, hidden behind the queued solve + Gram product
         noise = self._hyp_host[2]
         vbar2 = 1.0 / (noise * rows)                         # 2 * vbar
-        _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
-        _ops.trace_terms(ctx, LS, dLS, G, Mp, sums, 1.0 / vbar2)
-        _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
-        _ops.rowdot_accum(ctx, A32, mu_bar, dm)              # b = A mu_bar (data part of m-bar)
-        Ge[Mp].copy_(dm)
-        if include_kl:
-            _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)
-        self._variational_grads_final()
-        # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
-        Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
-        Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
-        _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)
-        # K_ZX-bar (fp32, dense) and L-bar (fp64)
-        if self.lib_dense_gemm:
-            # the one product of the step without structure or fused epilogue: the library's tuned dense kernel
-            _ops.gemm_lib_f32(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
+
+        def variational_part():
+            _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
+            _ops.trace_terms(ctx, LS, dLS, G, Mp, sums, 1.0 / vbar2)
+            if coll is not None and not include_kl:
+                sums[2:4].zero_()                            # the trace terms of the GLOBAL G are counted on one rank only
+            _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
+            if coll is None:
+                _ops.rowdot_accum(ctx, A32, mu_bar, dm)      # b = A mu_bar (data part of m-bar)
+                Ge[Mp].copy_(dm)
+            else:
+                dm.copy_(Ge[Mp])                             # global b
+            if include_kl or coll is not None:               # (global schedule: m-bar / L_S-bar are not reduced again, so
+                _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)            # every rank adds the KL gradient itself)
+                if not include_kl:
+                    kl_buf[0:1].zero_()                      # ... and one rank the KL value
+            if coll is None:
+                self._variational_grads_final()
+
+        def solve_part():
+            # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
+            Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
+            Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
+            _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)
+            # K_ZX-bar (fp32, dense)
+            if self.lib_dense_gemm:
+                # the one product of the step without structure or fused epilogue: the library's tuned dense kernel
+                _ops.gemm_lib_f32(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
+            else:
+                QeT32 = self._get("QeT32", (Mp + 1, Mp), f32)  # the fp32 GEMM streams an mn-contiguous A operand ~5 % faster
+                _ops.transpose_f32(ctx, Qe32, QeT32)
+                _ops.gemm(ctx, TRANS_A, QeT32, A32e, Kb32, alpha=vbar2)
+            return Qe64
+
+        if coll is None:
+            variational_part()
+            Qe64 = solve_part()
         else:
-            QeT32 = self._get("QeT32", (Mp + 1, Mp), f32)      # the fp32 GEMM streams an mn-contiguous A operand ~5 % faster
-            _ops.transpose_f32(ctx, Qe32, QeT32)
-            _ops.gemm(ctx, TRANS_A, QeT32, A32e, Kb32, alpha=vbar2)
-        _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)
+            Qe64 = solve_part()
+            handle.wait()
+            _ops.mirror_lower_f32_(ctx, G, Mp)
+            variational_part()
+        _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)                 # L-bar (fp64)
         return packX, mu

@@ -183,6 +183,10 @@ class TrainLoop:
         self.variational_scheduler.step()
         self.hyperparameter_optimizer.step()
         self.hyperparameter_scheduler.step()
+        if dp is not None and self.model.engine.variational_grads_global:
+            self._dp_steps = getattr(self, "_dp_steps", 0) + 1
+            if self._dp_steps % dp.resync_every == 0:
+                dp.resync(self.model, (self.variational_optimizer, self.hyperparameter_optimizer))
         return loss, output, y_batch
 
 

@@ -22,6 +22,7 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.global_batch = None      # set by the training loop before every step
+        self.resync_every = 256       # steps between broadcasts of the variational parameters (see ``resync``)
 
     def shard_bounds(self, n):
         """rows [lo, hi) of a global batch of n rows owned by this rank (ragged tails go to low ranks)."""
@@ -29,20 +30,41 @@ class DataParallel:
         lo = self.rank * base + min(self.rank, rem)
         return lo, lo + base + (1 if self.rank < rem else 0)
 
+    def resync(self, model, optimizers):
+        """Under the global-Gram schedule every rank forms L_S-bar itself from the same reduced [G ; b^T]; the split-K
+        atomics of that product sum in a run-dependent order, so the replicas' L_S (and its Adam moments) can differ in the
+        last bit.  Every ``resync_every`` steps rank 0's copies are broadcast (3 x 36 MB at M'=3000, amortised to nothing);
+        Z, V and the hyper-parameters only ever see all-reduced gradients and stay bit-identical by construction."""
+        vs = model.variational_strategy
+        ts = [p.data for p in vs._variational_distribution.parameters()]
+        for opt in optimizers:
+            for p in vs._variational_distribution.parameters():
+                st = opt.state.get(p)
+                if st:
+                    ts += [v for v in st.values() if torch.is_tensor(v)]
+        for t in ts:
+            dist.broadcast(t, 0, group=self.group)
+
+    def all_reduce_async(self, t):
+        """sum over the ranks, asynchronously on the collective's own stream; ``.wait()`` orders the current stream after it"""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def loss_and_grads(self, engine, params, x, y, D, num_data, mll_type):
         """x, y, D are this rank's shard.  Returns globally reduced (loss, grads, local mu, local varn)."""
         p1 = y.shape[0] // max(x.shape[0], 1) if x.shape[0] else 1
         rows = (self.global_batch if self.global_batch is not None else x.shape[0] * self.world) * p1
-        # engines with a flat gradient buffer call this back as soon as m-bar and L_S-bar (99.8 % of the bytes) are final:
-        # their all-reduce then runs on the collective's own stream under the rest of the backward
-        if hasattr(engine, "early_reduce"):
-            engine.early_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # engines with a flat gradient buffer use this object as their collective while the step runs (``all_reduce_async``):
+        # either [G ; b^T] is summed early and m-bar / L_S-bar come back global, or they are reduced as soon as they are
+        # final, under the rest of the backward; what is left for the end of the step is the small ``flat_late`` segment
+        hooked = hasattr(engine, "collective")
+        if hooked:
+            engine.collective = self
         try:
             loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type, global_rows=rows,
                                                           include_kl=(self.rank == 0))
         finally:
-            if hasattr(engine, "early_reduce"):
-                engine.early_reduce = None
+            if hooked:
+                engine.collective = None
         flat = getattr(engine, "flat", None)
         names = list(grads.keys())
         lo = min(grads[k].data_ptr() for k in names)
@@ -52,8 +74,10 @@ class DataParallel:
         else:
             views = grads                       # the engine's gradients ARE views of [grads..., loss]
         early = getattr(engine, "_early_handle", None) if views is not None else None
-        if early is not None:
+        if views is not None and getattr(engine, "variational_grads_global", False):
             dist.all_reduce(engine.flat_late, op=dist.ReduceOp.SUM, group=self.group)     # [Z-bar, V-bar, scalars, loss]
+        elif early is not None:
+            dist.all_reduce(engine.flat_late, op=dist.ReduceOp.SUM, group=self.group)
             early.wait()
             engine._early_handle = None
         else:

@@ -1,0 +1,79 @@
+"""GPU, 3 ranks on ONE card over gloo (a rehearsal of the N > 1 path: the driver's multi-GPU runs put one rank per GPU
+over RCCL): the HIP engine under ``DataParallel`` -- row shards, the early all-reduce of [G ; b^T] with the column-split
+Cholesky backward ("global Gram" schedule), and the early all-reduce of the variational gradients (general schedule) --
+reproduces the single-process step."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_step import make_problem
+    return make_problem(600, 5, 40, 2, 97, seed=5)      # 97 rows over 3 ranks: ragged shards; 40 inducing points: 14/13/13
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsvgp_amd
+    dev = torch.device("cuda", 0)
+    P, x, y, D, nd = _problem()
+    p = 2
+    dp = dsvgp_amd.DataParallel()
+    lo, hi = dp.shard_bounds(x.shape[0])
+    dp.global_batch = x.shape[0]
+    Pg = {k: v.to(dev) for k, v in P.items()}
+    xs, ys, Ds = x[lo:hi].to(dev), y[lo * (p + 1):hi * (p + 1)].to(dev), D[lo * p:hi * p].to(dev)
+    res = {}
+    for mode, mll in (("global", "ELBO"), ("early", "ELBO"), ("early", "PLL")):
+        eng = dsvgp_amd.ElboEngine(dev)
+        eng.global_gram = mode == "global"
+        loss, grads, mu, varn = dp.loss_and_grads(eng, Pg, xs, ys, Ds, nd, mll)
+        torch.cuda.synchronize()
+        assert eng.variational_grads_global == (mode == "global"), (mode, mll)
+        assert eng.collective is None and eng._early_handle is None
+        res[mode + mll] = (loss.item(), {k: v.cpu().clone() for k, v in grads.items()})
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(3, port, out), nprocs=3, join=True)
+    P, x, y, D, nd = _problem()
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    for mll in ("ELBO", "PLL"):
+        eng = dsvgp.ElboEngine(gpu_device)
+        l1, g1, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
+        for mode in (("global", "early") if mll == "ELBO" else ("early",)):
+            for r in range(3):
+                loss, grads = out[r][mode + mll]
+                assert abs(loss - l1.item()) < 2e-5 * abs(l1.item()), (mode, mll, r, loss, l1.item())
+                for k in g1:
+                    ref = g1[k].double().cpu()
+                    err = (grads[k].double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+                    assert err < 2e-4, (mode, mll, r, k, err)
+            # identical on every rank (what the replicated Adam step relies on)
+            for k in g1:
+                assert torch.equal(out[0][mode + mll][1][k], out[1][mode + mll][1][k]) or \
+                    (out[0][mode + mll][1][k] - out[1][mode + mll][1][k]).abs().max().item() < 1e-6 * max(
+                        g1[k].abs().max().item(), 1e-30), (mode, mll, k)

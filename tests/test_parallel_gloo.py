@@ -76,7 +76,7 @@ def _worker(rank, world, port, out):
     # the same step through the product engine's flat buffer: early (overlapped) + late all-reduce
     eng = _flat_engine(dsvgp_amd)
     loss2, grads2, _, _ = dp.loss_and_grads(eng, P, x[lo:hi], y[lo * (p + 1):hi * (p + 1)], D[lo * p:hi * p], nd, "ELBO")
-    assert eng.fired and eng.early_reduce is None and eng._early_handle is None
+    assert eng.fired and eng.collective is None and eng._early_handle is None
     assert grads2["variational_mean"].data_ptr() == eng.flat.data_ptr()       # variational segment leads the buffer
     assert eng.flat_early.numel() + eng.flat_late.numel() == eng.flat.numel()
     err = max((grads2[k].double() - grads[k]).abs().max().item() / (1e-30 + grads[k].abs().max().item()) for k in grads)
