@@ -68,6 +68,7 @@ class ElboEngine:
         self.elbo_fast = True           # ELBO mode: Gram-matrix formulation (see _elbo_fast)
         self._hyp_host = None
         self._pending = None            # (hyp, packZ, L, dims, info) of a factorisation whose status is not read yet
+        self._host_status = self._host_info = self._status_ready = None
         self._potrf_ws = None
         self._inverse_ws = None         # the trsm workspace that holds the inverse of the current factor
         self._side = None               # second HIP stream (work overlapped with the Cholesky chain)
@@ -160,6 +161,15 @@ class ElboEngine:
         self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs)       # L and the inverted blocks of L
         self._inverse_ws = ws
         self._pending = (hyp, packZ, L, (M, d, p, Mp), info)
+        # status word + hyper-parameters go to pinned host memory right behind the factorisation: the later read waits for
+        # THIS point of the stream only, not for the solve / Gram product queued after it (no idle device around the read)
+        if self._host_status is None:
+            self._host_status = torch.empty(16, dtype=f32).pin_memory()
+            self._host_info = torch.empty(1, dtype=torch.int32).pin_memory()
+        self._host_status[:hyp.numel()].copy_(hyp.reshape(-1), non_blocking=True)
+        self._host_info.copy_(info, non_blocking=True)
+        self._status_ready = torch.cuda.Event()
+        self._status_ready.record(torch.cuda.current_stream(self.device))
         if sync:
             self._finish_factor(ctx, ladder=True)
         return hyp, packZ, L, (M, d, p, Mp)
@@ -181,8 +191,9 @@ class ElboEngine:
             return
         hyp, packZ, L, (M, d, p, Mp), info = self._pending
         self._pending = None
-        self._hyp_host = hyp.tolist()                   # host copy of (ell, s, noise): same sync as the potrf status
-        if int(info.item()) == 0:
+        self._status_ready.synchronize()
+        self._hyp_host = self._host_status[:hyp.numel()].tolist()      # host copy of (ell, s, noise)
+        if int(self._host_info[0]) == 0:
             return
         if not ladder:
             raise _Refactored()
