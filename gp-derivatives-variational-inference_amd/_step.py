@@ -839,16 +839,14 @@ class ElboEngine:
         # Gram matrix and L_S gradient
         Ge = self._get("Ge", (Mp + 1, Mp), f32)              # [G ; b^T]
         G = Ge[:Mp]
-        _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32, A32, G)     # tril(A A^T), split-K over the minibatch axis
+        # tril([A ; mu_bar^T] A^T) = [tril(G) ; b^T], split-K over the minibatch axis: b = A mu_bar rides along as row M'
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32e, A32, Ge)
         coll = self.collective if self._global_gram else None
         handle = None
         if coll is not None:
             # data parallel, "global Gram" schedule: everything downstream of [G ; b^T] is linear in it, so the ranks sum
             # THAT (36 MB, under the Q' solve and the K_ZX-bar product) instead of the L_S gradient at the end: L_S-bar and
             # m-bar then come out global on every rank, and the replicated Cholesky backward can be split by column blocks
-            bt = Ge[Mp]
-            bt.zero_()
-            _ops.rowdot_accum(ctx, A32, mu_bar, bt)          # b = A mu_bar (this rank's rows)
             self._finish_factor(ctx)
             handle = coll.all_reduce_async(Ge)
         else:
@@ -863,11 +861,7 @@ class ElboEngine:
             if coll is not None and not include_kl:
                 sums[2:4].zero_()                            # the trace terms of the GLOBAL G are counted on one rank only
             _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
-            if coll is None:
-                _ops.rowdot_accum(ctx, A32, mu_bar, dm)      # b = A mu_bar (data part of m-bar)
-                Ge[Mp].copy_(dm)
-            else:
-                dm.copy_(Ge[Mp])                             # global b
+            dm.copy_(Ge[Mp])                                 # b = A mu_bar, the data part of m-bar (global under coll)
             if include_kl or coll is not None:               # (global schedule: m-bar / L_S-bar are not reduced again, so
                 _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)            # every rank adds the KL gradient itself)
                 if not include_kl:
