@@ -74,6 +74,7 @@ SIGNATURES = {
     "dsvgp_add_diag_f32": (_i, [_p, _p, _i, _l, _f]),
     "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
     "dsvgp_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
+    "dsvgp_adam_step_multi": (_i, [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

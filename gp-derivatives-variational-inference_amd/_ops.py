@@ -330,6 +330,25 @@ def gather_batch(ctx, X, Y, idx, cols, p, xb, yb):
                                  _ptr(_req(cols, torch.int32, "cols", 1)), p, _ptr(xb), _ptr(yb)), "dsvgp_gather_batch")
 
 
+ADAM_MAX_TENSORS = 16
+
+
+def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
+    """torch.optim.Adam update of several tensors that share (lr, betas, eps, step) in one launch."""
+    import ctypes
+    n = len(params)
+    if n > ADAM_MAX_TENSORS:
+        raise ValueError("at most %d tensors per launch" % ADAM_MAX_TENSORS)
+    for group in (params, grads, exp_avgs, exp_avg_sqs):
+        for t in group:
+            if t.dtype != f32 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("adam: tensors must be contiguous float32 GPU tensors")
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (ctypes.c_int64 * n)(*[t.numel() for t in params])
+    check(lib.dsvgp_adam_step_multi(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, float(lr),
+                                    float(beta1), float(beta2), float(eps), int(step)), "dsvgp_adam_step_multi")
+
+
 def adam_step_(ctx, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if not t.is_contiguous() or t.dtype != f32 or not t.is_cuda:

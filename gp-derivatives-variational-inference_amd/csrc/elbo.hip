@@ -268,6 +268,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, co
     }
 }
 
+// all tensors of one optimizer in ONE launch: workgroup b belongs to the tensor whose [first, first + blocks) holds b
+struct AdamTable {
+    float* param[DSVGP_ADAM_MAX_TENSORS];
+    const float* grad[DSVGP_ADAM_MAX_TENSORS];
+    float* m[DSVGP_ADAM_MAX_TENSORS];
+    float* v[DSVGP_ADAM_MAX_TENSORS];
+    int64_t n[DSVGP_ADAM_MAX_TENSORS];
+    int first[DSVGP_ADAM_MAX_TENSORS + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, float lr, float b1, float b2, float eps,
+                                                         float bc1, float bc2_sqrt) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first[k + 1]) ++k;
+    const int nb = t.first[k + 1] - t.first[k];
+    float* __restrict__ param = t.param[k];
+    const float* __restrict__ grad = t.grad[k];
+    float* __restrict__ m = t.m[k];
+    float* __restrict__ v = t.v[k];
+    const int64_t n = t.n[k];
+    for (int64_t i = (int64_t)(blockIdx.x - t.first[k]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        const float g = grad[i];
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
 // ---- ELBO fast path (constant dLoss/dvar): residuals, traces, scalar assembly -----------------------
 __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ mu, const float* __restrict__ y,
                                                        int ncols, const float* __restrict__ hyp, float inv_rows,
@@ -498,6 +529,32 @@ extern "C" int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ctx->stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
+                                     float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
+                                     float beta1, float beta2, float eps, int step) {
+    if (!ctx || count < 0 || count > DSVGP_ADAM_MAX_TENSORS || step < 1) return DSVGP_EINVAL;
+    if (count && (!params || !grads || !exp_avgs || !exp_avg_sqs || !sizes)) return DSVGP_EINVAL;
+    AdamTable t{};
+    int nblocks = 0;
+    for (int k = 0; k < count; ++k) {
+        if (sizes[k] < 0 || (sizes[k] > 0 && (!params[k] || !grads[k] || !exp_avgs[k] || !exp_avg_sqs[k]))) return DSVGP_EINVAL;
+        if (sizes[k] == 0) continue;
+        const int c = t.count++;
+        t.param[c] = params[k]; t.grad[c] = grads[k]; t.m[c] = exp_avgs[k]; t.v[c] = exp_avg_sqs[k]; t.n[c] = sizes[k];
+        int b = cdiv(sizes[k], 256);
+        if (b > 2048) b = 2048;
+        t.first[c] = nblocks;
+        nblocks += b;
+    }
+    if (!t.count) return 0;
+    t.first[t.count] = nblocks;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, t, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2));
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -130,6 +130,7 @@ class TrainLoop:
         self.variational_optimizer, self.hyperparameter_optimizer = optimizers
         self.variational_scheduler, self.hyperparameter_scheduler = schedulers
         self.minibatch_dim, self.dp, self.col_rng, self.perm_gen = minibatch_dim, dp, col_rng, perm_gen
+        self.autograd_protocol = False          # True: loss = -mll(output, y); loss.backward() through torch.autograd
         self.full_gradient = full_gradient      # grad_svgp: all d+1 target columns, no derivative_directions kwarg
         self.dfree = dfree                      # dfree_directional_vi: function values only, first p canonical directions
         self.device = X.device
@@ -177,8 +178,11 @@ class TrainLoop:
         self.variational_optimizer.zero_grad()
         self.hyperparameter_optimizer.zero_grad()
         output = self.likelihood(self.model(x_batch, **kwargs))
-        loss = -self.mll(output, y_batch)
-        loss.backward()
+        if self.autograd_protocol:
+            loss = -self.mll(output, y_batch)           # the reference's three lines, through torch.autograd
+            loss.backward()
+        else:
+            loss = self.mll.backward_step(output, y_batch)      # same numbers, gradients assigned directly
         self.variational_optimizer.step()
         self.variational_scheduler.step()
         self.hyperparameter_optimizer.step()

@@ -37,6 +37,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            batch = {}                                   # tensors that share the step count go out in one launch
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -46,8 +47,14 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                ctx = _ops.Context.get(p.device)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _ops.adam_step_(ctx, p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                                st["step"])
+                batch.setdefault((st["step"], p.device), []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+            for (step, dev), items in batch.items():
+                ctx = _ops.Context.get(dev)
+                for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
+                    ps, gs, ms, vs = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
+                    if len(ps) == 1:
+                        _ops.adam_step_(ctx, ps[0], gs[0], ms[0], vs[0], group["lr"], b1, b2, group["eps"], step)
+                    else:
+                        _ops.adam_step_multi_(ctx, ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], step)
         return loss

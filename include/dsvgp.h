@@ -212,6 +212,13 @@ int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_
                     float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step);
 
+/* the same update for up to DSVGP_ADAM_MAX_TENSORS tensors that share (lr, betas, eps, step) in ONE launch: the parameter
+ * groups of one torch.optim.Adam (directional_vi.py:193-199); the arrays are HOST arrays of device pointers / element counts */
+#define DSVGP_ADAM_MAX_TENSORS 16
+int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
+                          float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
+                          float beta1, float beta2, float eps, int step);
+
 /* Plain dense fp32 GEMM through rocBLAS (row-major, flags: DSVGP_GEMM_TRANS_A / _TRANS_B only): for products without
  * structure or fused epilogue (the dense K_ZX-bar product of the ELBO fast path); everything else is dsvgp_gemm.      */
 int dsvgp_gemm_lib_f32(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alpha, const float* A, int64_t lda,

@@ -424,6 +424,29 @@ def test_gather_batch_and_fused_adam(dsvgp, gpu_device):
         ot.step()
         oh.step()
     assert relmax(wh.detach(), wt.detach()) < 2e-6
+    # several tensors of one optimizer in ONE launch (dsvgp_adam_step_multi): ragged sizes, a [1,1] and a 0-d parameter,
+    # one parameter without gradient, more tensors than one launch takes -- bit-identical to the per-tensor launches
+    shapes = [(300, 7), (5,), (1, 1), (), (70000,), (3, 3)] + [(11,)] * 14
+    init = [torch.randn(*sh, generator=g) if len(sh) else torch.randn((), generator=g) for sh in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pt = [t.clone().requires_grad_(True) for t in init]
+    oa, ot = dsvgp.FusedAdam(pa, lr=0.02), torch.optim.Adam(pt, lr=0.02)
+    ob = [dsvgp.FusedAdam([q], lr=0.02) for q in pb]
+    for k in range(4):
+        for i, (a, b, t) in enumerate(zip(pa, pb, pt)):
+            if i == 1 and k < 2:
+                a.grad = b.grad = t.grad = None          # joins later: its step count differs from the others'
+                continue
+            gr = torch.randn(t.shape, generator=g)
+            a.grad, b.grad, t.grad = gr.to(dev), gr.to(dev), gr.clone()
+        oa.step()
+        ot.step()
+        for o in ob:
+            o.step()
+    for a, b, t in zip(pa, pb, pt):
+        assert torch.equal(a.detach(), b.detach())
+        assert relmax(a.detach().reshape(-1), t.detach().reshape(-1)) < 5e-6
 
 
 def test_no_cpu_fallback(dsvgp):

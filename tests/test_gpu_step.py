@@ -478,3 +478,30 @@ def test_distribution_sample_protocol_of_bo_drivers(dsvgp, gpu_device):
         Sf = model(x, derivative_directions=D).covariance_matrix
         noise = likelihood.noise.reshape(())
         assert relmax(Sigma - Sf, noise * torch.eye(nx * (p + 1), device=gpu_device)) < 1e-3
+
+
+def test_direct_gradient_step_equals_autograd_protocol(dsvgp, gpu_device):
+    """TrainLoop's default step (mll.backward_step: engine gradients become .grad) against the reference's three lines
+    ``loss = -mll(output, y); loss.backward()`` through torch.autograd: same losses and parameters (up to the run-to-run
+    summation order of the split-K atomics)."""
+    torch.manual_seed(0)
+    n, dim = 400, 3
+    X = torch.rand(n, dim, device=gpu_device)
+    Y = O.testfun(X.cpu()).to(gpu_device)
+    states = []
+    for protocol in (False, True):
+        torch.manual_seed(1)                      # the 1e-3 randn initialisation of the variational mean
+        loop = dsvgp.setup_training(None, num_inducing=16, num_directions=2, minibatch_size=100, minibatch_dim=2,
+                                    num_epochs=1, learning_rate_hypers=0.01, seed=3, tensors=(X, Y))
+        loop.autograd_protocol = protocol
+        loop.col_rng.seed(5)
+        losses = []
+        perm = loop.epoch_permutation()
+        for k in range(4):
+            loss, _, _ = loop.step(perm[k * 100:(k + 1) * 100])
+            losses.append(loss.item())
+        states.append((losses, {k: v.detach().clone() for k, v in loop.model._param_dict(loop.likelihood).items()}))
+    for a, b in zip(*[st[0] for st in states]):
+        assert abs(a - b) < 1e-5 * abs(a), (a, b)
+    for k in states[0][1]:
+        assert (states[0][1][k] - states[1][1][k]).abs().max().item() < 2e-4, k      # 4 Adam steps of 1e-2
