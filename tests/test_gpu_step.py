@@ -505,3 +505,28 @@ def test_direct_gradient_step_equals_autograd_protocol(dsvgp, gpu_device):
         assert abs(a - b) < 1e-5 * abs(a), (a, b)
     for k in states[0][1]:
         assert (states[0][1][k] - states[1][1][k]).abs().max().item() < 2e-4, k      # 4 Adam steps of 1e-2
+
+
+def test_panel_regime_beyond_the_explicit_inverse_limit(dsvgp, gpu_device):
+    """M' = 9000 > 8192: the engine switches by itself to 512-wide panels (potrf + inverted diagonal blocks + panel solves,
+    general ELBO schedule on fp64 A).  Its step must agree with the explicit-inverse regime forced on the same inputs --
+    two independent code paths through the factorisation, the solves and the Cholesky backward."""
+    N, d, M, p, B = 4000, 20, 1500, 5, 256
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=12)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    xg, yg, Dg = x.to(gpu_device), y.to(gpu_device), D.to(gpu_device)
+    out = {}
+    for name, nb in (("panel", None), ("explicit", 16384)):
+        eng = dsvgp.ElboEngine(gpu_device, trsm_nb=nb)
+        loss, grads, mu, _ = eng.loss_and_grads(Pg, xg, yg, Dg, nd)
+        torch.cuda.synchronize()
+        assert eng.trsm_nb == (512 if nb is None else nb)
+        out[name] = (loss.item(), {k: v.clone() for k, v in grads.items()}, mu.clone())
+        del eng
+        torch.cuda.empty_cache()
+    la, ga, ma = out["panel"]
+    lb, gb, mb = out["explicit"]
+    assert math.isfinite(la) and abs(la - lb) < 2e-5 * abs(lb), (la, lb)
+    assert relmax(ma, mb) < 2e-4
+    for k in ga:
+        assert relmax(ga[k], gb[k]) < 5e-3, (k, relmax(ga[k], gb[k]))
