@@ -67,8 +67,10 @@ class DataParallel:
                 engine.collective = None
         flat = getattr(engine, "flat", None)
         names = list(grads.keys())
-        lo = min(grads[k].data_ptr() for k in names)
-        if flat is None or flat.data_ptr() != lo:                                         # engines without a flat buffer
+        ptrs = [grads[k].data_ptr() for k in names if grads[k].numel()]    # (an empty gradient, p = 0, has no address)
+        if flat is None or not ptrs or flat.data_ptr() != min(ptrs):                      # engines without a flat buffer
+            if getattr(engine, "variational_grads_global", False):
+                raise RuntimeError("engine returned globally reduced gradients outside its flat buffer")
             flat = torch.cat([grads[k].reshape(-1) for k in names] + [loss.reshape(1).to(grads[names[0]].dtype)])
             views = None
         else:

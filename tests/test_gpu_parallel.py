@@ -22,6 +22,29 @@ def _problem():
     return make_problem(600, 5, 40, 2, 97, seed=5)      # 97 rows over 3 ranks: ragged shards; 40 inducing points: 14/13/13
 
 
+def _variant_problems():
+    """(name, engine flags, params, x, y, D, num_data, p_data): the parameterisations of the SURVEY 8f variants"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dsvgp_oracle as O
+    from test_gpu_step import make_problem
+    out = []
+    P, x, _, D, nd = make_problem(400, 3, 16, 2, 50, seed=11)                      # derivative-free data
+    out.append(("dfree", dict(data_outputs="values"), P, x, O.testfun(x)[:, 0].contiguous(), D, nd, 0))
+    P, x, y, D, nd = make_problem(400, 4, 14, 2, 50, seed=21)                      # shared inducing directions
+    g = torch.Generator().manual_seed(4)
+    P["inducing_directions"] = torch.eye(4)[:2] + 0.2 * torch.randn(2, 4, generator=g)
+    P["variational_mean"] = 0.3 * torch.randn(16, generator=g)
+    P["chol_variational_covar"] = torch.eye(16) + 0.05 * torch.randn(16, 16, generator=g)
+    out.append(("shared", dict(shared_directions=True), P, x, y, D, nd, 2))
+    from test_ngd import make_ngd_problem
+    P, x, y, D, nd = make_ngd_problem(400, 2, 20, 2, 50, seed=402)                 # natural parameters (NGD)
+    out.append(("ngd", {}, P, x, y, D, nd, 2))
+    P, x, y, D, nd = make_problem(300, 6, 30, 0, 50, seed=3)                       # p = 0: plain SVGP
+    out.append(("plain", {}, P, x, y, D, nd, 0))
+    return out
+
+
 def _worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
@@ -46,12 +69,25 @@ def _worker(rank, world, port, out):
         assert eng.variational_grads_global == (mode == "global"), (mode, mll)
         assert eng.collective is None and eng._early_handle is None
         res[mode + mll] = (loss.item(), {k: v.cpu().clone() for k, v in grads.items()})
+    for name, flags, P, x, y, D, nd, pdata in _variant_problems():
+        lo, hi = dp.shard_bounds(x.shape[0])
+        dp.global_batch = x.shape[0]
+        pz = D.shape[0] // x.shape[0]
+        eng = dsvgp_amd.ElboEngine(dev)
+        for k, v in flags.items():
+            setattr(eng, k, v)
+        Pg = {k: v.to(dev) for k, v in P.items()}
+        loss, grads, _, _ = dp.loss_and_grads(eng, Pg, x[lo:hi].to(dev), y[lo * (pdata + 1):hi * (pdata + 1)].to(dev),
+                                              D[lo * pz:hi * pz].to(dev), nd, "ELBO")
+        torch.cuda.synchronize()
+        res[name] = (loss.item(), {k: v.cpu().clone() for k, v in grads.items()})
     out[rank] = res
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device):
+@pytest.fixture(scope="module")
+def dp_results(gpu_device):
+    """ONE 3-rank run (3 GPU processes + this one) for all the tests of this module"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -59,6 +95,12 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(3, port, out), nprocs=3, join=True)
+    return {r: out[r] for r in range(3)}
+
+
+@pytest.mark.timeout(600)
+def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device, dp_results):
+    out = dp_results
     P, x, y, D, nd = _problem()
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
     for mll in ("ELBO", "PLL"):
@@ -77,3 +119,26 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device):
                 assert torch.equal(out[0][mode + mll][1][k], out[1][mode + mll][1][k]) or \
                     (out[0][mode + mll][1][k] - out[1][mode + mll][1][k]).abs().max().item() < 1e-6 * max(
                         g1[k].abs().max().item(), 1e-30), (mode, mll, k)
+
+
+@pytest.mark.timeout(600)
+def test_variants_under_data_parallel(dsvgp, gpu_device, dp_results):
+    """derivative-free data, shared directions, natural parameters and p = 0 through DataParallel on 3 ranks (one card, gloo)
+    against the single-process step of the same engine configuration."""
+    out = dp_results
+    for name, flags, P, x, y, D, nd, pdata in _variant_problems():
+        eng = dsvgp.ElboEngine(gpu_device)
+        for k, v in flags.items():
+            setattr(eng, k, v)
+        Pg = {k: v.to(gpu_device) for k, v in P.items()}
+        l1, g1, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO")
+        for r in range(3):
+            loss, grads = out[r][name]
+            assert abs(loss - l1.item()) < 3e-5 * abs(l1.item()), (name, r, loss, l1.item())
+            assert set(grads) == set(g1)
+            for k in g1:
+                ref = g1[k].double().cpu()
+                if ref.numel() == 0 or ref.abs().max().item() == 0:
+                    continue
+                err = (grads[k].double() - ref).abs().max().item() / ref.abs().max().item()
+                assert err < 5e-4, (name, r, k, err)
