@@ -42,6 +42,8 @@ def _variant_problems():
     out.append(("ngd", {}, P, x, y, D, nd, 2))
     P, x, y, D, nd = make_problem(300, 6, 30, 0, 50, seed=3)                       # p = 0: plain SVGP
     out.append(("plain", {}, P, x, y, D, nd, 0))
+    P, x, y, D, nd = make_ngd_problem(400, 2, 20, 2, 60, seed=402)                 # CIQ whitening (iterative: looser)
+    out.append(("ciq", dict(whitening="ciq"), P, x, y, D, nd, 2))
     return out
 
 
@@ -134,11 +136,12 @@ def test_variants_under_data_parallel(dsvgp, gpu_device, dp_results):
         l1, g1, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO")
         for r in range(3):
             loss, grads = out[r][name]
-            assert abs(loss - l1.item()) < 3e-5 * abs(l1.item()), (name, r, loss, l1.item())
+            ltol, gtol = (2e-3, 3e-2) if name == "ciq" else (3e-5, 5e-4)
+            assert abs(loss - l1.item()) < ltol * abs(l1.item()), (name, r, loss, l1.item())
             assert set(grads) == set(g1)
             for k in g1:
                 ref = g1[k].double().cpu()
                 if ref.numel() == 0 or ref.abs().max().item() == 0:
                     continue
                 err = (grads[k].double() - ref).abs().max().item() / ref.abs().max().item()
-                assert err < 5e-4, (name, r, k, err)
+                assert err < gtol, (name, r, k, err)
