@@ -145,3 +145,77 @@ def test_variants_under_data_parallel(dsvgp, gpu_device, dp_results):
                     continue
                 err = (grads[k].double() - ref).abs().max().item() / ref.abs().max().item()
                 assert err < gtol, (name, r, k, err)
+
+
+# ------------------------------------------------------------------ the drop-in harnesses under torch.distributed
+def _harness_cases(dsvgp_amd):
+    """(name, train_gp callable(dataset, **kw), dataset builder) for every train_gp mirror"""
+    import dsvgp_oracle as O
+    from torch.utils.data import TensorDataset
+    g = torch.Generator().manual_seed(7)
+    X = torch.rand(360, 3, generator=g)
+    Y = O.testfun(X)
+    full, vals = TensorDataset(X, Y), TensorDataset(X, Y[:, 0].contiguous())
+    kw = dict(minibatch_size=90, num_epochs=1, verbose=False, seed=11, max_steps=3, tqdm=False)
+    return [
+        ("directional_vi", lambda: dsvgp_amd.directional_vi.train_gp(full, num_inducing=12, num_directions=2, minibatch_dim=2,
+                                                                     inducing_data_initialization=False, **kw)),
+        ("directional_vi_ngd", lambda: dsvgp_amd.directional_vi.train_gp(full, num_inducing=12, num_directions=2,
+                                                                         minibatch_dim=2, use_ngd=True,
+                                                                         inducing_data_initialization=False, **kw)),
+        ("grad_svgp", lambda: dsvgp_amd.grad_svgp.train_gp(full, 3, num_inducing=12, **kw)),
+        ("dfree", lambda: dsvgp_amd.dfree_directional_vi.train_gp(full, num_inducing=12, num_directions=2, minibatch_dim=2,
+                                                                  inducing_data_initialization=False, **kw)),
+        ("shared", lambda: dsvgp_amd.shared_directional_vi.train_gp(full, num_inducing=12, num_directions=2, minibatch_dim=2,
+                                                                    inducing_data_initialization=False, **kw)),
+        ("traditional", lambda: dsvgp_amd.traditional_vi.train_gp(vals, 3, num_inducing=12, **kw)),
+    ]
+
+
+def _state(model, likelihood):
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    sd.update({"lik." + k: v.detach().cpu().clone() for k, v in likelihood.state_dict().items()})
+    return sd
+
+
+def _harness_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsvgp_amd
+    torch.cuda.set_device(0)
+    res = {}
+    for name, run in _harness_cases(dsvgp_amd):
+        torch.manual_seed(100)                       # the random initialisations (Z ~ U, 1e-3 randn mean) are rank-0's anyway
+        model, likelihood = run()
+        torch.cuda.synchronize()
+        res[name] = _state(model, likelihood)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_every_train_gp_mirror_runs_data_parallel(dsvgp, gpu_device):
+    """``train_gp`` of every mirrored module on 2 ranks (gloo, one card): parameters identical across ranks after 3 steps and
+    equal to the single-process run from the same seeds (global minibatch unchanged: rows are sharded, not re-sampled)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_harness_worker, args=(2, port, out), nprocs=2, join=True)
+    for name, run in _harness_cases(dsvgp):
+        torch.manual_seed(100)
+        model, likelihood = run()
+        ref = _state(model, likelihood)
+        a, b = out[0][name], out[1][name]
+        assert set(a) == set(ref)
+        for k in ref:
+            scale = max(ref[k].abs().max().item(), 1e-3) if ref[k].numel() else 1.0
+            if ref[k].numel() == 0:
+                continue
+            assert (a[k] - b[k]).abs().max().item() <= 1e-6 * scale, (name, k, "ranks differ")
+            assert (a[k] - ref[k]).abs().max().item() < 2e-3 * scale + 2e-4, (name, k, (a[k] - ref[k]).abs().max().item())
