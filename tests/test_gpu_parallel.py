@@ -219,3 +219,60 @@ def test_every_train_gp_mirror_runs_data_parallel(dsvgp, gpu_device):
                 continue
             assert (a[k] - b[k]).abs().max().item() <= 1e-6 * scale, (name, k, "ranks differ")
             assert (a[k] - ref[k]).abs().max().item() < 2e-3 * scale + 2e-4, (name, k, (a[k] - ref[k]).abs().max().item())
+
+
+# ------------------------------------------------------------------ the same code path on a real RCCL communicator
+def _rccl_worker(rank, world, port, out):
+    """A DataParallel over a ONE-rank RCCL group made to take the N > 1 schedules (the collectives become identities on
+    RCCL's own stream: what is exercised is the asynchronous all-reduce / wait protocol of the nccl backend, which the gloo
+    rehearsals cannot show)."""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import dsvgp_amd
+    P, x, y, D, nd = _problem()
+    Pg = {k: v.to(dev) for k, v in P.items()}
+    xg, yg, Dg = x.to(dev), y.to(dev), D.to(dev)
+    l0, g0, _, _ = dsvgp_amd.ElboEngine(dev).loss_and_grads(Pg, xg, yg, Dg, nd)
+    res = {}
+    for gg in (True, False):
+        dp = dsvgp_amd.DataParallel()
+        dp.world, dp.rank = 2, 0                       # schedules of a 2-rank job; this rank holds every row
+        dp.shard_bounds = lambda n: (0, n)
+        dp.global_batch = x.shape[0]
+        eng = dsvgp_amd.ElboEngine(dev)
+        eng.global_gram = gg
+        loss, grads, _, _ = dp.loss_and_grads(eng, Pg, xg, yg, Dg, nd, "ELBO")
+        torch.cuda.synchronize()
+        assert eng.variational_grads_global == gg
+        # m-bar / L_S-bar / loss are complete on this rank; Z-bar etc. lack the K_ZZ-bar columns of the absent rank when gg
+        res[gg] = (abs(loss.item() - l0.item()) / abs(l0.item()),
+                   (grads["chol_variational_covar"] - g0["chol_variational_covar"]).abs().max().item()
+                   / g0["chol_variational_covar"].abs().max().item(),
+                   (grads["variational_mean"] - g0["variational_mean"]).abs().max().item()
+                   / g0["variational_mean"].abs().max().item(),
+                   (grads["inducing_points"] - g0["inducing_points"]).abs().max().item()
+                   / g0["inducing_points"].abs().max().item())
+    out[0] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_multi_rank_schedules_on_an_rccl_communicator(dsvgp, gpu_device):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    res = out[0]
+    for gg in (True, False):
+        dl, dLS, dm, dZ = res[gg]
+        assert dl < 1e-5 and dLS < 1e-4 and dm < 1e-4, (gg, res[gg])
+    assert res[False][3] < 1e-4            # general schedule: everything is local, so Z-bar is complete too
