@@ -530,3 +530,50 @@ def test_panel_regime_beyond_the_explicit_inverse_limit(dsvgp, gpu_device):
     assert relmax(ma, mb) < 2e-4
     for k in ga:
         assert relmax(ga[k], gb[k]) < 5e-3, (k, relmax(ga[k], gb[k]))
+
+
+@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+def test_ten_step_trajectory_matches_oracle_training(dsvgp, gpu_device, mll):
+    """Ten optimisation steps (engine gradients + the two fused Adam optimisers, fresh minibatch every step) against the same
+    loop on the CPU oracle with torch.optim.Adam: the parameter trajectories stay together (losses to 1e-4, parameters to 2e-3
+    of their range after 10 steps of lr = 0.01)."""
+    N, d, M, p, B = 600, 4, 24, 2, 64
+    P, _, _, _, nd = make_problem(N, d, M, p, B, seed=31)
+    g = torch.Generator().manual_seed(31)
+    X = torch.rand(N, d, generator=g)
+    Y = O.testfun(X)
+    names = list(O.PARAM_NAMES)
+    var_names = ("variational_mean", "chol_variational_covar")
+    Pc = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    Pd = {k: torch.nn.Parameter(v.clone().to(gpu_device)) for k, v in P.items()}
+    oc = [torch.optim.Adam([Pc[k] for k in var_names], lr=0.01),
+          torch.optim.Adam([Pc[k] for k in names if k not in var_names], lr=0.01)]
+    od = [dsvgp.FusedAdam([Pd[k] for k in var_names], lr=0.01),
+          dsvgp.FusedAdam([Pd[k] for k in names if k not in var_names], lr=0.01)]
+    eng = dsvgp.ElboEngine(gpu_device)
+    for step in range(10):
+        idx = torch.randperm(N, generator=g)[:B]
+        cols = sorted([0] + (torch.randperm(d, generator=g)[:p] + 1).tolist())
+        x, y = X[idx].contiguous(), Y[idx][:, cols].reshape(-1).contiguous()
+        D = torch.eye(d)[[c - 1 for c in cols[1:]]].repeat(B, 1)
+        l_ref, g_ref, _, _ = O.elbo_loss_and_grads({k: v.detach() for k, v in Pc.items()}, x, y, D, nd, mll)
+        for k in names:
+            Pc[k].grad = g_ref[k].clone()
+        for o in oc:
+            o.step()
+        loss, grads, _, _ = eng.loss_and_grads({k: v.detach() for k, v in Pd.items()}, x.to(gpu_device), y.to(gpu_device),
+                                               D.to(gpu_device), nd, mll)
+        assert abs(loss.item() - l_ref.item()) < 1e-4 * abs(l_ref.item()), (step, loss.item(), l_ref.item())
+        for k in names:
+            Pd[k].grad = grads[k]
+        for o in od:
+            o.step()
+    for k in names:
+        ref = Pc[k].detach()
+        if k == "chol_variational_covar":
+            ref = torch.tril(ref)                                    # the strict upper part never receives a gradient
+            got = torch.tril(Pd[k].detach().cpu())
+        else:
+            got = Pd[k].detach().cpu()
+        scale = max(ref.abs().max().item(), 1e-2)
+        assert (got - ref).abs().max().item() < 2e-3 * scale, (k, (got - ref).abs().max().item(), scale)
