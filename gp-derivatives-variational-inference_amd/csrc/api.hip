@@ -39,7 +39,7 @@ extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* i
     if (!ctx || !A || !info_dev || n <= 0 || lda < n) return DSVGP_EINVAL;
     if (algo == 1) {
         if (!workspace) return DSVGP_EINVAL;
-        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace, nullptr, 0);
+        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace, nullptr, 0, nullptr);
     }
     if (algo != 0) return DSVGP_EINVAL;
     rocblas_status st = rocsolver_dpotrf((rocblas_handle)ctx->blas, rocblas_fill_upper, n, A, (rocblas_int)lda, info_dev);
@@ -103,9 +103,8 @@ extern "C" int dsvgp_potrf_inverse(dsvgp_ctx* ctx, double* A, int n, int64_t lda
     if (trsm_nb(n, nb) < n) return DSVGP_EINVAL;
     double* Dinv = (double*)workspace;
     double* DinvT = Dinv + (size_t)n * n;
-    int rc = launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n);
-    if (rc) return rc;
-    return dsvgp_transpose_f64(ctx, Dinv, n, n, n, DinvT, n);
+    // both images of L^-1 come out of the factorisation launches (the inverse tiles are written straight and transposed)
+    return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n, DinvT);
 }
 
 // First phase of dsvgp_trsm on its own: Dinv / DinvT of `workspace` from L.  potrf_workspace (may be NULL): the

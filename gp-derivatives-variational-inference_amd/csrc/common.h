@@ -39,7 +39,8 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
 
 // blocked Cholesky (potrf.hip)
 size_t potrf_blocked_workspace_bytes(int n);
-int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy);
+int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
+                         double* YinvT);
 
 // trtri of the nb x nb diagonal blocks of the lower-triangular L into Dinv (same indexing as L,
 // leading dimension ldd); tmp is an n x (nb/2) double scratch.  X64 (may be null): the inverted 64 x 64 diagonal

@@ -286,7 +286,8 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n,
                                                   int k, int e, const double* __restrict__ Xws,
                                                   const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
-                                                  double* __restrict__ Y, int64_t ldy, int nblk) {
+                                                  double* __restrict__ Y, int64_t ldy, int nblk,
+                                                  double* __restrict__ YT) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int nt = nblk - (k + 1), nR = nt * (k + 1);
     const int k0 = k * 64;
@@ -341,22 +342,43 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                 }
     } else {
         tile_product<false>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
+        if (YT == nullptr) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = k0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, c = j0 + wc * 32 + jj * 16 + (lane & 15);
-                    if (m < n && c < n) Y[(int64_t)m * ldy + c] = acc[i][jj][q];
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = k0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, c = j0 + wc * 32 + jj * 16 + (lane & 15);
+                        if (m < n && c < n) Y[(int64_t)m * ldy + c] = acc[i][jj][q];
+                    }
+        } else {
+            // the tile also goes out transposed (L^-T for the forward solves, which stream an mn-contiguous left operand):
+            // through LDS, so that both images are written in full rows -- no separate transpose pass over L^-1
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + jj * 16 + (lane & 15)] = acc[i][jj][q];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+                if (k0 + r < n && j0 + c < n) Y[(int64_t)(k0 + r) * ldy + j0 + c] = S[0][r][c];
+                if (j0 + r < n && k0 + c < n) YT[(int64_t)(j0 + r) * ldy + k0 + c] = S[0][c][r];
+            }
+        }
     }
 }
 
 __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
                                                            double* __restrict__ Xws, double* __restrict__ Wws,
                                                            int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
-                                                           double* __restrict__ Yinv, int64_t ldy, int nA) {
+                                                           double* __restrict__ Yinv, int64_t ldy, int nA,
+                                                           double* __restrict__ YinvT) {
     // TWO 64 x 64 LDS tiles (70 KB with the factorisation scratch): two workgroups share a CU, which halves the rounds
     // the ~1100 update / inverse tiles of a mid-chain launch need.  The second right operand of every tile waits in
     // registers while the first product runs.
@@ -366,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int b = blockIdx.x;
     if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
-        chol_inverse_tile(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64);
+        chol_inverse_tile(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT);
         return;
     }
     int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
@@ -469,10 +491,10 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 __global__ __launch_bounds__(256) void chol_yrow_kernel(const double* __restrict__ A, int64_t lda, int n, int k,
                                                         const double* __restrict__ Xws, const double* __restrict__ Wws,
                                                         double* __restrict__ Rw, int64_t ldr, double* __restrict__ Yinv,
-                                                        int64_t ldy) {
+                                                        int64_t ldy, double* __restrict__ YinvT) {
     __shared__ double S[2][64][LDT];
     const int nblk = (n + 63) / 64;
-    chol_inverse_tile(S, A, lda, n, k, (nblk - (k + 1)) * (k + 1) + blockIdx.x, Xws, Wws, Rw, ldr, Yinv, ldy, nblk);
+    chol_inverse_tile(S, A, lda, n, k, (nblk - (k + 1)) * (k + 1) + blockIdx.x, Xws, Wws, Rw, ldr, Yinv, ldy, nblk, YinvT);
 }
 
 // all solved panels in one launch:  L_ik = A_ik X_k^T  (i > k), in place, one 64 x 64 tile per workgroup
@@ -523,8 +545,10 @@ size_t potrf_blocked_workspace_bytes(int n) {
 }
 
 // one fused launch per block column + one batched panel launch (see chol_step_kernel).  Yinv != nullptr: also L^-1
-// (lower triangle, leading dimension ldy) by the fused forward elimination.
-int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy) {
+// (lower triangle, leading dimension ldy) by the fused forward elimination, and (YinvT != nullptr) its transpose with the
+// same leading dimension.
+int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
+                         double* YinvT) {
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
     if (e != hipSuccess) return 1000 + (int)e;
     const int nblk = cdiv(n, NBC);
@@ -537,12 +561,12 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
         const int nA = (k < 0) ? 1 : nt * (nt + 1) / 2;
         const int nI = (k >= 0 && Yinv) ? nt * (k + 1) + (k + 1) : 0;
         hipLaunchKernelGGL(chol_step_kernel, dim3(nA + nI), dim3(256), 0, st, A, lda, n, k, Xws, Wws, info, Rw, ldr, Yinv, ldy,
-                           nA);
+                           nA, YinvT);
         DSVGP_LAUNCH_CHECK();
     }
     if (Yinv) {
         hipLaunchKernelGGL(chol_yrow_kernel, dim3(nblk), dim3(256), 0, st, (const double*)A, lda, n, nblk - 1,
-                           (const double*)Xws, (const double*)Wws, Rw, ldr, Yinv, ldy);
+                           (const double*)Xws, (const double*)Wws, Rw, ldr, Yinv, ldy, YinvT);
         DSVGP_LAUNCH_CHECK();
     }
     if (nblk > 1) {

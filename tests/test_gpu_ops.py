@@ -274,19 +274,23 @@ def test_potrf_inverse_fused(dsvgp, gpu_device, n):
     A = K.clone().to(gpu_device)
     info = torch.zeros(1, dtype=torch.int32, device=gpu_device)
     nb = 4096
-    ws = ops.trsm_workspace(n, n, nb, gpu_device)
+    ws = ops.trsm_workspace(n, max(n, 600), nb, gpu_device)
     ops.potrf_inverse_(ctx, A, info, nb, ws)
     assert int(info.item()) == 0
     L = torch.tril(A).cpu()
     assert (L @ L.t() - K).abs().max() < 1e-10 * K.abs().max()
     Linv = torch.tril(ws[:n * n * 8].view(torch.float64).view(n, n)).cpu()
     assert (Linv @ L - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-9
-    B = torch.randn(n, 17, generator=g, dtype=torch.float64)
-    X = torch.empty(n, 17, dtype=torch.float64, device=gpu_device)
-    for trans in (0, 1):
-        ops.trsm(ctx, A, B.to(gpu_device), trans, X, None, nb, ws, reuse_inverse=True)
-        ref = torch.linalg.solve_triangular(L.t() if trans else L, B, upper=bool(trans))
-        assert relmax(X, ref) < 1e-9
+    # the transposed image comes out of the same launches (second slot of the workspace), bit-identical
+    LinvT = torch.triu(ws[n * n * 8:2 * n * n * 8].view(torch.float64).view(n, n)).cpu()
+    assert torch.equal(LinvT, Linv.t())
+    for nrhs in (17, 600):                   # >= 512 right-hand sides: the forward solve streams the transposed image
+        B = torch.randn(n, nrhs, generator=g, dtype=torch.float64)
+        X = torch.empty(n, nrhs, dtype=torch.float64, device=gpu_device)
+        for trans in (0, 1):
+            ops.trsm(ctx, A, B.to(gpu_device), trans, X, None, nb, ws, reuse_inverse=True)
+            ref = torch.linalg.solve_triangular(L.t() if trans else L, B, upper=bool(trans))
+            assert relmax(X, ref) < 1e-9
     bad = K.clone()
     bad[n // 2, n // 2] = -1.0
     bad = bad.to(gpu_device)
