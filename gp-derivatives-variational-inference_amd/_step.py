@@ -651,17 +651,20 @@ class ElboEngine:
         G1 = self._get("G1", (Mp, Mp), f64)
         _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar): Phi reads nothing else
         _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T (mirror of the lower part)
-        Y = self._get("Y", (Mp, Mp), f64)
-        _ops.trsm(ctx, L, G1, True, Y, None, self.trsm_nb, ws, reuse_inverse=True)          # L^-T S
-        Yt = Lbar                                                           # reuse
-        _ops.transpose_f64(ctx, Y, Yt)
-        Kbar = G1                                                           # reuse
+        Kbar = G1                                                           # reuse (after the first product has read it)
         if self.trsm_nb >= Mp:
-            # explicit inverse in the workspace: only the lower half of the symmetric result is computed, then mirrored
+            # explicit inverse in the workspace: Yt = S L^-1 directly (S symmetric, read through its transpose: the
+            # mn-contiguous operand path), then only the lower half of the symmetric result, mirrored
             Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
+            Yt = Lbar                                                       # reuse
+            _ops.gemm(ctx, TRANS_A | B_LOWER, G1, Linv, Yt)                 # S L^-1 = (L^-T S)^T
             _ops.gemm(ctx, TRANS_A | A_UPPER | OUT_LOWER, Linv, Yt, Kbar, alpha=0.5)        # 1/2 tril(L^-T S L^-1)
             _ops.phi_symmetrize_(ctx, Kbar)
         else:
+            Y = self._get("Y", (Mp, Mp), f64)
+            _ops.trsm(ctx, L, G1, True, Y, None, self.trsm_nb, ws, reuse_inverse=True)      # L^-T S
+            Yt = Lbar                                                       # reuse
+            _ops.transpose_f64(ctx, Y, Yt)
             _ops.trsm(ctx, L, Yt, True, Kbar, None, self.trsm_nb, ws, reuse_inverse=True)   # L^-T S L^-1 (symmetric)
             Kbar.mul_(0.5)
         return Kbar
@@ -677,7 +680,7 @@ class ElboEngine:
         T = self._get("cbT", (Mp, w), f64)
         # S L^-1[:, c0:c1]: rows < c0 of that column block of the lower-triangular inverse are zero, the rest is lower
         # triangular in its own coordinates (nothing above the diagonal of the workspace is read)
-        _ops.gemm(ctx, B_LOWER, G1[:, c0:], Linv[c0:, c0:c1], T)
+        _ops.gemm(ctx, TRANS_A | B_LOWER, G1[c0:, :], Linv[c0:, c0:c1], T)       # (S symmetric: read through its transpose)
         Kc = self._get("cbK", (Mp, w), f64)
         _ops.gemm(ctx, TRANS_A | A_UPPER, Linv, T, Kc, alpha=0.5)
         return Kc
