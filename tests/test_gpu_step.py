@@ -58,6 +58,8 @@ CASES = [
     (500, 20, 30, 5, 96),      # C4 geometry (d=20, p=5), small M/B
     (300, 4, 25, 4, 50),       # p == d (full gradient)
     (300, 6, 70, 0, 64),       # p = 0: plain SVGP special case
+    (400, 50, 20, 5, 40),      # C5 geometry (d = 50): packed rows wider than the register-resident pair kernels take
+    (300, 7, 18, 3, 33),       # q = 4, odd sizes: the generic tiled kernels
 ]
 
 
