@@ -61,6 +61,10 @@ class Context:
         return ctx
 
     def bind(self):
+        # the library launches on this context's stream without a device guard of its own: make its device current
+        # (one process per GPU is the intended use; torch.cuda.set_device(local_rank) has normally done this already)
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
         s = torch.cuda.current_stream(self.device).cuda_stream
         if s != self._stream:
             check(lib.dsvgp_set_stream(self.h, C.c_void_p(s)), "dsvgp_set_stream")
