@@ -67,6 +67,10 @@ constexpr int BM_MAX = 128;  // BN (128 or 64) and BM (128 or 64) are template p
 #ifndef GEMM_BM64
 #define GEMM_BM64 0         // tools: 1 = 64-row tiles on 4-wave workgroups for products without OUT_LOWER
 #endif
+#ifndef GEMM_SMALL
+#define GEMM_SMALL 1        // 64 x 64 tiles on 4-wave workgroups (+ finer split-K) for products too small to fill the chip with
+                            // 128 x 128 tiles (M' of a few hundred: the reference's own test sizes)
+#endif
 constexpr int S_MN = 144;
 
 template <typename T> struct Mfma;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(NTH, GEMM_MINW ? GEMM_MINW : NTH / 128) void gemm_k
 template <typename TC, typename TB, bool AKC, bool BKC, int BN>
 int launch_one(hipStream_t st, const GemmArgs& g, dim3 grid) {
     constexpr int NTH = (sizeof(TC) == 8 && AKC && BKC) ? 256 : GEMM_THREADS;
-#if GEMM_BM64
+#if GEMM_BM64 || GEMM_SMALL
     if (g.bm == 64) {
         hipLaunchKernelGGL((gemm_kernel<TC, TB, AKC, BKC, BN, 256, 64>), grid, dim3(256), 0, st, g);
         DSVGP_LAUNCH_CHECK();
@@ -482,11 +486,24 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     GemmArgs a = g;
     const bool out_lower_ = g.flags & DSVGP_GEMM_OUT_LOWER;
     a.bm = (GEMM_BM64 && !out_lower_ && g.batch == 1) ? 64 : 128;
-    const int BM = a.bm;
-    a.tiles_m = cdiv(g.M, BM);
     // tile width: 128 x 64 tiles were measured SLOWER than 128 x 128 + split-K for the M' x M' products
     // (chol. backward 2.9 vs 2.3 ms, Gram 4.1 vs 3.8 ms per step at M'=3000), so 128 is used throughout
     a.bn = g.bn == 64 ? 64 : 128;
+    int sk_div = 256, sk_min_k = 512;       // split-K granularity: slices of >= 256 k, only for K >= 512
+#if GEMM_SMALL
+    {   // too few 128 x 128 tiles to occupy the 256 CUs even with the coarse split: quarter tiles, slices of >= 128 k
+        const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch;
+        const int64_t coarse = t128 * (g.K >= 512 ? (g.K / 256 < 32 ? g.K / 256 : 32) : 1);
+        if (g.splitk == 1 && g.bn != 64 && (out_lower_ ? coarse / 2 : coarse) < 384) {
+            a.bm = 64;
+            a.bn = 64;
+            sk_div = 128;
+            sk_min_k = 256;
+        }
+    }
+#endif
+    const int BM = a.bm;
+    a.tiles_m = cdiv(g.M, BM);
     a.tiles_n = cdiv(g.N, a.bn);
     const size_t esz = is_double ? 8 : 4;
     const bool out_lower = g.flags & DSVGP_GEMM_OUT_LOWER, keep_upper = g.flags & DSVGP_GEMM_KEEP_UPPER;
@@ -494,13 +511,13 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
     if (!g.C && !g.C32) return DSVGP_EINVAL;
-    if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= 512) {
-        const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (128 / a.bn) : a.tiles_m * a.tiles_n;
+    if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= sk_min_k) {
+        const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (a.bm / a.bn) : a.tiles_m * a.tiles_n;
         // split factor: minimise (rounds over the 256 CUs -- two resident workgroups share a CU's matrix pipe, so the
         // CU, not the slot, is the unit of throughput) x (K slice + fixed per-workgroup cost)
         int sk = 1;
         if (active > 0 && active < 1024) {
-            const int maxsk = a.K / 256 < 32 ? a.K / 256 : 32;
+            const int maxsk = a.K / sk_div < 32 ? a.K / sk_div : 32;
             double best = 1e300;
             for (int c = 1; c <= maxsk; ++c) {
                 // fp64 products count rounds over the 512 resident slots (one fp64 workgroup alone leaves its CU's matrix
