@@ -67,6 +67,9 @@ constexpr int BM_MAX = 128;  // BN (128 or 64) and BM (128 or 64) are template p
 #ifndef GEMM_BM64
 #define GEMM_BM64 0         // tools: 1 = 64-row tiles on 4-wave workgroups for products without OUT_LOWER
 #endif
+#ifndef GEMM_SMALL_LIMIT
+#define GEMM_SMALL_LIMIT 384   // (128 x 128 tiles) x (coarse split-K slices) below which a product counts as small
+#endif
 #ifndef GEMM_SMALL
 #define GEMM_SMALL 1        // 64 x 64 tiles on 4-wave workgroups (+ finer split-K) for products too small to fill the chip with
                             // 128 x 128 tiles (M' of a few hundred: the reference's own test sizes)
@@ -494,7 +497,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     {   // too few 128 x 128 tiles to occupy the 256 CUs even with the coarse split: quarter tiles, slices of >= 128 k
         const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch;
         const int64_t coarse = t128 * (g.K >= 512 ? (g.K / 256 < 32 ? g.K / 256 : 32) : 1);
-        if (g.splitk == 1 && g.bn != 64 && (out_lower_ ? coarse / 2 : coarse) < 384) {
+        if (g.splitk == 1 && g.bn != 64 && (out_lower_ ? coarse / 2 : coarse) < GEMM_SMALL_LIMIT) {
             a.bm = 64;
             a.bn = 64;
             sk_div = 128;
