@@ -119,7 +119,8 @@ def main():
                                     seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
     eng = loop.model.engine
     eng.trsm_nb = args.trsm_nb
-    eng.overlap = not args.no_overlap
+    if args.no_overlap:
+        eng.overlap = False        # (default None: automatic by problem size)
     eng.fused_inverse = not args.no_fused_inverse
     eng.lib_dense_gemm = not args.no_lib_gemm
     eng.global_gram = not args.no_global_gram

@@ -73,7 +73,9 @@ class ElboEngine:
         self._inverse_ws = None         # the trsm workspace that holds the inverse of the current factor
         self._side = None               # second HIP stream (work overlapped with the Cholesky chain)
         self._side_done = None
-        self.overlap = True
+        # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
+        # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
+        self.overlap = None
         # whitening: "cholesky" (DirectionalGradVariationalStrategy) or "ciq" (CiqDirectionalGradVariationalStrategy:
         # K_ZZ^{-1/2} by contour-integral quadrature + msMINRES; needs natural parameters)
         self.whitening = "cholesky"
@@ -697,7 +699,8 @@ class ElboEngine:
         rows = float(Bp if global_rows is None else global_rows)
         side = {}
         side_job = None
-        if use_fast and self.overlap:
+        overlap = self.overlap if self.overlap is not None else Mz * (p + 1) >= 2048
+        if use_fast and overlap:
             def side_job(c, hyp_):
                 side.update(self._fast_prologue(c, params, hyp_, x, D, rows))
         hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast, side_job=side_job, nrhs=Bp)
