@@ -178,10 +178,10 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if world == 1 and args.config == "c4" and args.trsm_nb >= Mp and os.path.exists(pmc):
-            cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm_kernel<double, float, false, false")]
+            cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm64_kernel<float>")]
             if cands:   # the forward solve is the largest launch of that instantiation
                 traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
-        roof = dict(bound="mfma", kernel="gemm_kernel<double,float,false,false,128,512> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
+        roof = dict(bound="mfma", kernel="gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                     traffic=traffic, launches=len(durs), avg_ms=avg * 1e3, flops_per_launch=flops)
 

@@ -483,9 +483,26 @@ static hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipS
     return hipMemset2DAsync(C, esz * (size_t)ld, 0, esz * (size_t)N, (size_t)M, st);
 }
 
+#ifndef GEMM64
+#define GEMM64 1            // 1: fp64 products with two mn-contiguous operands and >= GEMM64_MIN_TILES 64 x 64 tiles go to gemm64.hip
+#endif
+#ifndef GEMM64_MIN_TILES
+#define GEMM64_MIN_TILES 8192      // (the [M', B'] solves; the M' x M' x M' class keeps 128 x 128 tiles + split-K)
+#endif
+#ifndef GEMM64_MIN_K
+#define GEMM64_MIN_K 256
+#endif
+
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.batch < 1 || g.splitk < 1) return DSVGP_EINVAL;
+#if GEMM64
+    if (is_double && (g.C || g.C32) && (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) >= GEMM64_MIN_TILES && g.K >= GEMM64_MIN_K) {
+        const int rc = launch_gemm64(st, g);
+        if (rc == 1) return 0;
+        if (rc > 1) return rc;
+    }
+#endif
     GemmArgs a = g;
     const bool out_lower_ = g.flags & DSVGP_GEMM_OUT_LOWER;
     a.bm = (GEMM_BM64 && !out_lower_ && g.batch == 1) ? 64 : 128;

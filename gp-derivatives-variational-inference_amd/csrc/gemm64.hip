@@ -1,0 +1,185 @@
+// Lean fp64 MFMA GEMM for operands that are both mn-contiguous (A stored [K, M], B stored [K, N]):
+//   C = alpha op(A) op(B),  64 x 64 tiles, 4 waves of 32 x 32, 16-deep stages through ONE LDS buffer (20 KB),
+// written for register economy (<= 80 VGPRs: 6 workgroups = 24 waves per CU) instead of per-wave tile size: the
+// latency of a stage is hidden by the other workgroups of the CU, not by software pipelining inside one.
+// Same conventions as gemm.hip (triangular operands trim the K range and mask the diagonal stages, OUT_LOWER skips /
+// zeroes the tiles above the diagonal, optional fp32 copy of the result).  No split-K, no Cin: the caller falls back to
+// gemm.hip for everything else.
+#include "common.h"
+
+namespace {
+
+using acc4 = double __attribute__((ext_vector_type(4)));
+constexpr int T = 64, BK = 16, LDS_STRIDE = T + 16;       // row stride = 16 (mod 32) doubles: conflict-free b64 fragment reads
+
+struct G64 {
+    const double* A; const void* B; double* C; float* C32;
+    int64_t lda, ldb, ldc, ldc32;
+    int M, N, K, tiles_m, tiles_n, flags;
+    double alpha;
+};
+
+#ifndef G64_MINW
+#define G64_MINW 6
+#endif
+#ifndef G64_PRIO
+#define G64_PRIO 0
+#endif
+
+template <typename TB>
+__global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
+    __shared__ double As[BK * LDS_STRIDE];
+    __shared__ double Bs[BK * LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int fl = g.flags;
+    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
+    const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
+    const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
+    // XCD-aware order: consecutive blocks of one XCD (b, b + 8, ...) walk an 8-wide band of tile columns row by row
+    int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
+    if (t >= g.tiles_m * g.tiles_n) return;
+    int tm, tn;
+    {
+        const int band = t / (8 * g.tiles_m), r = t - band * 8 * g.tiles_m;
+        const int wcols = min(8, g.tiles_n - band * 8);
+        tm = r / wcols;
+        tn = band * 8 + r - tm * wcols;
+        if (triA == 1) tm = g.tiles_m - 1 - tm;              // longest K ranges first
+    }
+    const int m0 = tm * T, n0 = tn * T;
+    if (out_lower && n0 >= m0 + T) {                         // strictly above the diagonal: defined as zero
+        for (int e = tid; e < T * T; e += 256) {
+            const int m = m0 + e / T, n = n0 + e % T;
+            if (m < g.M && n < g.N) {
+                if (g.C) g.C[(int64_t)m * g.ldc + n] = 0.0;
+                if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = 0.f;
+            }
+        }
+        return;
+    }
+    int klo = 0, khi = g.K;
+    if (triA == 1) khi = min(khi, m0 + T);
+    if (triA == 2) klo = max(klo, (m0 / BK) * BK);
+    if (triB == 2) klo = max(klo, (n0 / BK) * BK);
+    if (triB == 1) khi = min(khi, n0 + T);
+
+    // staging: thread -> (k = tid / 16, 4 consecutive columns at 4 (tid % 16)) of the 16 x 64 stage of each operand
+    const int sk = tid >> 4, sc = (tid & 15) * 4;
+    const double* __restrict__ Ap = g.A + m0 + sc;
+    const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc;
+    const bool a_in = m0 + T <= g.M, b_in = n0 + T <= g.N;
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const int k = k0 + sk;
+        const bool kin = k < g.K;
+        // interior of the tile / of the triangle: unmasked vector loads; otherwise element-wise with the masks
+        const bool a_fast = a_in && kin && (triA == 0 || (triA == 1 ? k0 + BK - 1 <= m0 : k0 >= m0 + T - 1));
+        const bool b_fast = b_in && kin && (triB == 0 || (triB == 1 ? k0 + BK - 1 <= n0 : k0 >= n0 + T - 1));
+        if (a_fast) {
+            const double2 v0 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda);
+            const double2 v1 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda + 2);
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + sc + e;
+                bool ok = kin && m < g.M;
+                if (triA == 1) ok = ok && k <= m;
+                if (triA == 2) ok = ok && k >= m;
+                ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
+            }
+        }
+        if (b_fast) {
+            if (sizeof(TB) == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(Bp + (int64_t)k * g.ldb);
+                rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+            } else {
+                const double2 v0 = *reinterpret_cast<const double2*>(Bp + (int64_t)k * g.ldb);
+                const double2 v1 = *reinterpret_cast<const double2*>(Bp + (int64_t)k * g.ldb + 2);
+                rb[0] = v0.x; rb[1] = v0.y; rb[2] = v1.x; rb[3] = v1.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + sc + e;
+                bool ok = kin && n < g.N;
+                if (triB == 1) ok = ok && k <= n;
+                if (triB == 2) ok = ok && k >= n;
+                rb[e] = ok ? (double)Bp[(int64_t)k * g.ldb + e] : 0.0;
+            }
+        }
+    };
+    acc4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+
+    if (klo < khi) {
+        fetch(klo);
+        for (int k0 = klo; k0 < khi; k0 += BK) {
+            double* as = As + sk * LDS_STRIDE + sc;
+            double* bs = Bs + sk * LDS_STRIDE + sc;
+            *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
+            *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
+            *reinterpret_cast<double2*>(bs) = double2{rb[0], rb[1]};
+            *reinterpret_cast<double2*>(bs + 2) = double2{rb[2], rb[3]};
+            __syncthreads();
+            if (k0 + BK < khi) fetch(k0 + BK);               // in flight under the 16 MFMAs of this stage
+            if (G64_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                const int kq = kk * 4 + (lane >> 4);
+                double a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = As[kq * LDS_STRIDE + wr * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = Bs[kq * LDS_STRIDE + wc * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (G64_PRIO) __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * r;     // f64 C/D layout: row = (lane >> 4) + 4 reg
+                const int n = n0 + wc * 32 + j * 16 + (lane & 15);
+                if (m >= g.M || n >= g.N) continue;
+                double v = g.alpha * acc[i][j][r];
+                if (out_lower && n > m) v = 0.0;
+                if (g.C) g.C[(int64_t)m * g.ldc + n] = v;
+                if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
+            }
+}
+
+}  // namespace
+
+// returns 1 if the product was taken, 0 if the caller must use gemm.hip, > 1 on a launch error
+int launch_gemm64(hipStream_t st, const GemmArgs& g) {
+    const int fl = g.flags;
+    if (!(fl & DSVGP_GEMM_TRANS_A) || (fl & DSVGP_GEMM_TRANS_B)) return 0;        // both operands mn-contiguous only
+    if (g.batch != 1 || g.splitk != 1 || g.Cin || g.kscale || (fl & DSVGP_GEMM_KEEP_UPPER)) return 0;
+    const bool bf = fl & DSVGP_GEMM_B_IS_FLOAT;
+    // 16-byte vector loads: even leading dimensions (multiples of 4 for a float B) and aligned bases
+    if (g.lda % 2 || ((uintptr_t)g.A % 16) || (bf ? (g.ldb % 4 || (uintptr_t)g.B % 16) : (g.ldb % 2 || (uintptr_t)g.B % 16))) return 0;
+    G64 a{};
+    a.A = (const double*)g.A; a.B = g.B; a.C = (double*)g.C; a.C32 = g.C32;
+    a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.ldc; a.ldc32 = g.ldc32;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.flags = fl; a.alpha = g.alpha;
+    a.tiles_m = cdiv(g.M, T); a.tiles_n = cdiv(g.N, T);
+    const int total = a.tiles_m * a.tiles_n;
+    const dim3 grid(cdiv(total, 8) * 8);
+    if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : 1000 + (int)e;
+}

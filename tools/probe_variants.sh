@@ -11,7 +11,8 @@ for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}; defs=${defs//,/ }
   mkdir -p $B/$name
   hipcc $FL $defs -c $C/gemm.hip -o $B/$name/gemm.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $B/$name/libdsvgp_hip.so $B/$name/gemm.o $B/assemble.o $B/elbo.o $B/potrf.o $B/ciq.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
+  hipcc $FL $defs -c $C/gemm64.hip -o $B/$name/gemm64.o   # (G64DEFS ride in the same -D list)
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $B/$name/libdsvgp_hip.so $B/$name/gemm.o $B/assemble.o $B/elbo.o $B/potrf.o $B/ciq.o $B/$name/gemm64.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
   hipcc -O2 $defs $R/tools/gemm_probe.cpp -I$R/include -L$B/$name -ldsvgp_hip -Wl,-rpath,$B/$name -o $B/$name/probe
   echo "=== variant $name  ($defs)"
   $B/$name/probe ${PROBE_ARGS}
