@@ -25,6 +25,9 @@ struct G64 {
 #ifndef G64_PRIO
 #define G64_PRIO 0
 #endif
+#ifndef G64_BAND
+#define G64_BAND 16         // tile columns per band (probed 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 56.5 / 57.1 / 60.8 / 62.8 / 63.4 / 57.0 / 62.6 / 54.2 TF) of the XCD-local walk
+#endif
 
 template <typename TB>
 __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
@@ -35,15 +38,15 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
     const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
     const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
-    // XCD-aware order: consecutive blocks of one XCD (b, b + 8, ...) walk an 8-wide band of tile columns row by row
+    // XCD-aware order: consecutive blocks of one XCD (b, b + 8, ...) walk a G64_BAND-wide band of tile columns row by row
     int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
     if (t >= g.tiles_m * g.tiles_n) return;
     int tm, tn;
     {
-        const int band = t / (8 * g.tiles_m), r = t - band * 8 * g.tiles_m;
-        const int wcols = min(8, g.tiles_n - band * 8);
+        const int band = t / (G64_BAND * g.tiles_m), r = t - band * G64_BAND * g.tiles_m;
+        const int wcols = min(G64_BAND, g.tiles_n - band * G64_BAND);
         tm = r / wcols;
-        tn = band * 8 + r - tm * wcols;
+        tn = band * G64_BAND + r - tm * wcols;
         if (triA == 1) tm = g.tiles_m - 1 - tm;              // longest K ranges first
     }
     const int m0 = tm * T, n0 = tn * T;

@@ -15,7 +15,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
