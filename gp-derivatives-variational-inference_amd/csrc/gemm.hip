@@ -487,7 +487,7 @@ static hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipS
 #define GEMM64 1            // 1: fp64 products with two mn-contiguous operands and >= GEMM64_MIN_TILES 64 x 64 tiles go to gemm64.hip
 #endif
 #ifndef GEMM64_MIN_TILES
-#define GEMM64_MIN_TILES 8192      // (the [M', B'] solves; the M' x M' x M' class keeps 128 x 128 tiles + split-K)
+#define GEMM64_MIN_TILES 1024      // (below: 128 x 128 tiles + split-K of this file)
 #endif
 #ifndef GEMM64_MIN_K
 #define GEMM64_MIN_K 256

@@ -15,7 +15,7 @@ constexpr int T = 64, BK = 16, LDS_STRIDE = T + 16;       // row stride = 16 (mo
 struct G64 {
     const double* A; const void* B; double* C; float* C32;
     int64_t lda, ldb, ldc, ldc32;
-    int M, N, K, tiles_m, tiles_n, flags;
+    int M, N, K, tiles_m, tiles_n, flags, balanced;
     double alpha;
 };
 
@@ -24,6 +24,12 @@ struct G64 {
 #endif
 #ifndef G64_PRIO
 #define G64_PRIO 0
+#endif
+#ifndef G64_CHUNK
+#define G64_CHUNK 8
+#endif
+#ifndef G64_BALANCED_BELOW
+#define G64_BALANCED_BELOW 8192
 #endif
 #ifndef G64_BAND
 #define G64_BAND 16         // tile columns per band (probed 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 56.5 / 57.1 / 60.8 / 62.8 / 63.4 / 57.0 / 62.6 / 54.2 TF) of the XCD-local walk
@@ -38,11 +44,23 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
     const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
     const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
-    // XCD-aware order: consecutive blocks of one XCD (b, b + 8, ...) walk a G64_BAND-wide band of tile columns row by row
-    int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
-    if (t >= g.tiles_m * g.tiles_n) return;
     int tm, tn;
-    {
+    if (g.balanced) {
+        // few tiles (a couple of rounds over the resident workgroups) with triangular K ranges: chunks of G64_CHUNK column
+        // tiles of ONE tile row (they share the A panel and the K range), rows in order of decreasing K range, chunks dealt
+        // round-robin to the XCDs -- every XCD gets the same mix of long and short tiles, longest first
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int per_row = (g.tiles_n + G64_CHUNK - 1) / G64_CHUNK;
+        const int chunk = (j / G64_CHUNK) * 8 + xcd;
+        const int rr = chunk / per_row;
+        if (rr >= g.tiles_m) return;
+        tn = (chunk - rr * per_row) * G64_CHUNK + j % G64_CHUNK;
+        if (tn >= g.tiles_n) return;
+        tm = (triA == 1) ? g.tiles_m - 1 - rr : rr;
+    } else {
+        // XCD-aware order: consecutive blocks of one XCD (b, b + 8, ...) walk a G64_BAND-wide band of tile columns row by row
+        int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
+        if (t >= g.tiles_m * g.tiles_n) return;
         const int band = t / (G64_BAND * g.tiles_m), r = t - band * G64_BAND * g.tiles_m;
         const int wcols = min(G64_BAND, g.tiles_n - band * G64_BAND);
         tm = r / wcols;
@@ -180,7 +198,8 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     a.M = g.M; a.N = g.N; a.K = g.K; a.flags = fl; a.alpha = g.alpha;
     a.tiles_m = cdiv(g.M, T); a.tiles_n = cdiv(g.N, T);
     const int total = a.tiles_m * a.tiles_n;
-    const dim3 grid(cdiv(total, 8) * 8);
+    a.balanced = total < G64_BALANCED_BELOW;
+    const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8);
     if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
