@@ -793,7 +793,9 @@ class ElboEngine:
         packZ = self._pending_packZ
         packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
         Kzx = self._assemble_kzx(ctx, packZ, M, packX, B, d, p, hyp, Mp)
-        S32e = self._get("S32e", (Mp, Mp + 1), f32)          # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)]
+        # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)].  Rows padded to a multiple of 4 floats: the lean fp64
+        # kernel (gemm64.hip) streams a float right-hand side with 16-byte loads
+        S32e = self._get("S32e_pad", (Mp, (Mp + 1 + 3) // 4 * 4), f32)[:, :Mp + 1]
         S32 = S32e[:, :Mp]
         _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
         _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
