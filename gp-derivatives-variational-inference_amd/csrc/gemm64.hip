@@ -52,11 +52,22 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int per_row = (g.tiles_n + G64_CHUNK - 1) / G64_CHUNK;
         const int chunk = (j / G64_CHUNK) * 8 + xcd;
-        const int rr = chunk / per_row;
-        if (rr >= g.tiles_m) return;
-        tn = (chunk - rr * per_row) * G64_CHUNK + j % G64_CHUNK;
+        if (chunk >= per_row * g.tiles_m) return;
+        int rr, cc;
+        if (triB && !triA) {
+            // the K range depends on the tile COLUMN (triangular B): walk the chunks column-major, longest columns first, so
+            // that the round-robin hands every XCD every column chunk (row-major order correlates chunk % 8 with the column)
+            const int cr = chunk / g.tiles_m;
+            rr = chunk - cr * g.tiles_m;
+            cc = (triB == 2) ? cr : per_row - 1 - cr;
+            tm = rr;
+        } else {
+            rr = chunk / per_row;
+            cc = chunk - rr * per_row;
+            tm = (triA == 1) ? g.tiles_m - 1 - rr : rr;
+        }
+        tn = cc * G64_CHUNK + j % G64_CHUNK;
         if (tn >= g.tiles_n) return;
-        tm = (triA == 1) ? g.tiles_m - 1 - rr : rr;
     } else {
         // XCD-aware order: consecutive blocks of one XCD (b, b + 8, ...) walk a G64_BAND-wide band of tile columns row by row
         int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
