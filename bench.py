@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the DSVGP ELBO training step (BASELINE.json metric) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher: this process starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a
+child BEFORE anything touches the GPU, relays its output (rank 0 prints the JSON line) and exits with its status; under a
+launcher (WORLD_SIZE set) it is one rank.  Any other WORLD_SIZE / --gpus mismatch is an error.
 
 A "step" is one iteration of ``directional_vi.train_gp``'s inner loop (reference
 directionalvi/directional_vi.py:229-254): minibatch gather, fused ELBO forward + backward, both Adam
 steps and both LR-scheduler steps.  Workload = BASELINE config 4: d=20, N=1M, M=500, p=5, global
-minibatch 4096 (sharded by rows over the ranks, one RCCL all-reduce per step: strong scaling).
+minibatch 4096 (sharded by rows over the ranks, packed-triangle RCCL all-reduce per step: strong scaling).
 Synthetic data (X ~ U[0,1]^d, y=[f, grad f], f=sin(2 pi |x|^2), reference tests/testfun.py) is resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line with the roofline of the dominant kernel
-(the fp64 MFMA panel-solve GEMM, timed live with HIP events on the launch stream) and the CPU
-baseline (oracle step, reference-faithful op sequence, on this host's cores).
+HBM before the timed region.  Rank 0 prints ONE JSON line with
+  roofline           the dominant kernel (fp64 MFMA panel-solve GEMM), timed live with HIP events on its launch stream;
+  roofline_assembly  the HBM-bound kernel assembly forward (K_ZX) and backward (K_ZX-bar), same method (north_star);
+  cpu_baseline       the oracle's reference-op-sequence training step on this host's cores (N = 1 only).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,6 +32,8 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     "c4": dict(name="DSVGP d=20 N=1M M=500 p=5 B=4096", d=20, N=1_000_000, M=500, p=5, B=4096),
     "c2": dict(name="DSVGP d=5 N=10k M=200 p=2 B=512", d=5, N=10_000, M=200, p=2, B=512),
+    # BASELINE config 3: full-gradient SVGP (grad_svgp harness), p = d, M' = M (d + 1) = 3300
+    "c3": dict(name="GradSVGP d=10 N=50k M=300 (M'=3300) B=512", d=10, N=50_000, M=300, p=10, B=512, grad=True),
     # diagnostics: the per-rank shard of C4 at 8 GPUs (B = 4096 / 8) run alone -- what one rank computes per step
     "c4shard8": dict(name="DSVGP d=20 N=1M M=500 p=5 B=512 (one rank's share of C4 at 8 GPUs)", d=20, N=1_000_000, M=500,
                      p=5, B=512),
@@ -39,9 +45,24 @@ CONFIGS = {
     "c5": dict(name="CIQ-DSVGP d=50 N=100k M=1024 p=5 B=512", d=50, N=100_000, M=1024, p=5, B=512, ciq=True),
 }
 PEAK_F64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (spec)
+PEAK_HBM_TBPS = 8.0             # HBM3E (MI355X_MICROARCH.md)
+
+
+def _self_launch(args):
+    """--gpus N > 1 from a plain invocation: one child launcher, N ranks, before any GPU call in this process."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def synthetic_data(N, d, device):
+    import torch
     g = torch.Generator(device=device).manual_seed(0)
     X = torch.rand(N, d, device=device, generator=g)
     sq = (X * X).sum(1)
@@ -49,27 +70,35 @@ def synthetic_data(N, d, device):
     return X.contiguous(), Y.contiguous()
 
 
-def cpu_baseline(cfg, budget_s=30.0):
-    """Reference-faithful CPU step (oracle/train_ref.py) on a bounded sample: full C-config steps, as many
-    as fit the budget after one untimed warm-up step."""
+def cpu_baseline(cfg, budget_s=150.0, min_steps=3):
+    """The oracle's reference-op-sequence training step (oracle/train_ref.py: DataLoader over the FULL dataset, the four
+    kernel assemblies in the reference's matmul / gather / shuffle form, fp64 Cholesky + 2 solves, autograd backward, two
+    Adam steps) on this host: 1 untimed warm-up step, then >= 3 timed full-size steps (more while the budget lasts)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import train_ref
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    n_sample = min(cfg["N"], 50_000)           # DataLoader over a bounded slice of the dataset (same batch shape)
-    st = train_ref.RefTrainer(n_sample, cfg["d"], cfg["M"], cfg["p"], cfg["B"], num_data_override=(cfg["d"] + 1) * cfg["N"])
+    st = train_ref.RefTrainer(cfg["N"], cfg["d"], cfg["M"], cfg["p"], cfg["B"], full_gradient=bool(cfg.get("grad")))
     t0 = time.time()
     st.step()
     first = time.time() - t0
+    st.assembly_seconds = 0.0
     steps, t_acc = 0, 0.0
-    while steps < 1 or (t_acc + first * 0.9 < budget_s and steps < 10):
+    while steps < min_steps or (t_acc + first * 0.9 < budget_s and steps < 10):
         t0 = time.time()
         st.step()
         t_acc += time.time() - t0
         steps += 1
-    return dict(value=steps / t_acc, unit="steps/s", cores=cores, kind="port",
-                sample="%d timed full-size steps (B=%d, M'=%d) after 1 warm-up, dataset slice of %d rows; %.1f s/step"
-                       % (steps, cfg["B"], cfg["M"] * (cfg["p"] + 1), n_sample, t_acc / steps))
+        if steps >= 1 and t_acc > 2.0 * budget_s:          # a very slow host: report what was timed, say so in `sample`
+            break
+    return dict(value=steps / t_acc, unit="steps/s", cores=cores, threads=torch.get_num_threads(), kind="port",
+                assembly="reference-sequence",
+                assembly_fwd_s_per_step=st.assembly_seconds / steps,
+                sample="%d timed full-size steps (B=%d, M'=%d, DataLoader over all N=%d rows) after 1 warm-up step "
+                       "(%.1f s); %.1f s/step, of which %.2f s in the forward of the 4 kernel assemblies"
+                       % (steps, cfg["B"], cfg["M"] * (cfg["p"] + 1), cfg["N"], first, t_acc / steps,
+                          st.assembly_seconds / steps))
 
 
 def main():
@@ -79,24 +108,35 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--trsm-nb", type=int, default=int(os.environ.get("DSVGP_TRSM_NB", "4096")))
+    ap.add_argument("--trsm-nb", type=int, default=int(os.environ.get("DSVGP_TRSM_NB", "0")),
+                    help="panel width of the triangular solve; 0 = the engine's automatic regime (explicit inverse up to M' = 8192)")
     ap.add_argument("--no-overlap", action="store_true", help="diagnostics: no side stream under the Cholesky chain")
     ap.add_argument("--no-fused-inverse", action="store_true", help="diagnostics: potrf + trtri recursion instead")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="diagnostics (N = 1): rank 0's work of a W-rank job, collectives skipped")
     ap.add_argument("--no-global-gram", action="store_true",
                     help="diagnostics (N > 1): all-reduce the variational gradients instead of [G ; b^T], replicated Cholesky backward")
-    ap.add_argument("--no-lib-gemm", action="store_true", help="diagnostics: the dense K_ZX-bar product on gemm.hip")
+    ap.add_argument("--lib-gemm", action="store_true",
+                    help="diagnostics: the dense K_ZX-bar product through rocBLAS sgemm instead of the hand-written kernel")
+    ap.add_argument("--no-pack-reduce", action="store_true", help="diagnostics (N > 1): dense instead of packed-triangle all-reduce")
+    ap.add_argument("--dp-algo", default=os.environ.get("DSVGP_DP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
+                    help="(N > 1) collective of the large operand: RCCL all-reduce, or reduce-scatter + all-gather")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            sys.exit(_self_launch(args))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world, rank, local_rank = int(env_world), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit("bench.py: WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # before the HIP runtime comes up in this process
+
+    import torch
+    import torch.distributed as dist
     # rehearsal on a one-GPU box: DSVGP_REHEARSE_GLOO=1 runs all ranks on cuda:0 over gloo (exercises the sharded path,
     # not a measurement); the driver's multi-GPU runs use one GPU per rank over RCCL
     rehearse = os.environ.get("DSVGP_REHEARSE_GLOO") == "1"
@@ -105,7 +145,6 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -114,16 +153,24 @@ def main():
     import dsvgp_amd
     d, N, M, p, B = cfg["d"], cfg["N"], cfg["M"], cfg["p"], cfg["B"]
     X, Y = synthetic_data(N, d, device)
-    loop = dsvgp_amd.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
-                                    num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True,
-                                    seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
+    if cfg.get("grad"):
+        loop = dsvgp_amd.grad_svgp.setup_training(None, d, num_inducing=M, minibatch_size=B, num_epochs=1,
+                                                  learning_rate_hypers=0.01, seed=0, tensors=(X, Y))
+    else:
+        loop = dsvgp_amd.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
+                                        num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True,
+                                        seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
     eng = loop.model.engine
-    eng.trsm_nb = args.trsm_nb
+    if args.trsm_nb > 0:
+        eng.trsm_nb = args.trsm_nb
     if args.no_overlap:
         eng.overlap = False        # (default None: automatic by problem size)
     eng.fused_inverse = not args.no_fused_inverse
-    eng.lib_dense_gemm = not args.no_lib_gemm
+    eng.lib_dense_gemm = bool(args.lib_gemm)
     eng.global_gram = not args.no_global_gram
+    eng.pack_reduce = not args.no_pack_reduce
+    if loop.dp is not None:
+        loop.dp.algo = args.dp_algo
     if args.emulate_world > 1 and world == 1:
         # diagnostics on a one-GPU box: run rank 0's share of the work of a W-rank job with the collectives skipped
         # (use with --config c4shardW; not a measurement of the job, only of one rank's kernels)
@@ -166,24 +213,48 @@ def main():
 
     # dominant kernel: the fp64 MFMA GEMM of the forward panel solve A = L^-1 K_ZX (one launch when nb >= M')
     Mp = M * (p + 1)
-    Bp_local = (B // world) * (p + 1)
-    durs = [s.elapsed_time(e) * 1e-3 for (name, s, e) in eng.events if name == "solve_fwd"]
+    B_local = B // world
+    Bp_local = B_local * (p + 1)
+
+    def avg(name):
+        durs = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in eng.events if nm == name]
+        return (sum(durs) / len(durs), len(durs)) if durs else (None, 0)
+
     roof = None
-    if durs:
-        avg = sum(durs) / len(durs)
+    t_solve, n_solve = avg("solve_fwd")
+    if t_solve:
         flops = float(Mp) * Mp * Bp_local           # F_trsm = M'^2 B' per solve
-        ach = flops / avg / 1e12
+        ach = flops / t_solve / 1e12
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 corrections applied by tools/summarize_pmc.py); only valid for the 1-GPU C4 shape
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if world == 1 and args.config == "c4" and args.trsm_nb >= Mp and os.path.exists(pmc):
-            cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm64_kernel<float>")]
-            if cands:   # the forward solve is the largest launch of that instantiation
-                traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+        if world == 1 and args.config == "c4" and eng.trsm_nb >= Mp:
+            for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+                pmc = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(pmc):
+                    cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm64_kernel<float>")]
+                    if cands:   # the forward solve is the largest launch of that instantiation
+                        traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+                    break
         roof = dict(bound="mfma", kernel="gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
-                    traffic=traffic, launches=len(durs), avg_ms=avg * 1e3, flops_per_launch=flops)
+                    traffic=traffic, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
+
+    # kernel assembly (north_star: HBM GB/s of the assembly): algorithmic bytes per launch =
+    # 4 [M' B' + (M + B) d (p + 1)] -- write the block matrix once (forward) / read its gradient once (backward) plus the
+    # points and directions -- over the live HIP-event duration on the stream the kernel was queued on
+    roof_asm = None
+    t_f, n_f = avg("assemble_fwd")
+    t_b, n_b = avg("assemble_bwd")
+    if t_f and t_b and not cfg.get("ciq"):
+        nbytes = 4.0 * (float(Mp) * Bp_local + (M + B_local) * d * (p + 1))
+        roof_asm = dict(bound="hbm", peak=PEAK_HBM_TBPS, unit="TB/s", bytes_per_launch=nbytes,
+                        forward=dict(kernel="kernel_fwd (K_ZX, %d x %d fp32, interleaved block layout)" % (Mp, Bp_local),
+                                     avg_ms=t_f * 1e3, launches=n_f, achieved=nbytes / t_f / 1e12,
+                                     frac=nbytes / t_f / 1e12 / PEAK_HBM_TBPS,
+                                     note="queued on the side stream under the Cholesky chain when M' >= 2048: shares the CUs"),
+                        backward=dict(kernel="kernel_bwd (reads K_ZX-bar once -> dZ, dV, d ell, d s)", avg_ms=t_b * 1e3,
+                                      launches=n_b, achieved=nbytes / t_b / 1e12, frac=nbytes / t_b / 1e12 / PEAK_HBM_TBPS))
 
     if rank == 0:
         out = {
@@ -192,9 +263,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32 (f64 Cholesky/solves)", "data": "synthetic",
             "config": {"workload": cfg["name"], "global_batch": B, "per_gpu_batch": B // world, "M_prime": Mp,
-                       "parallelism": "dp%d rows" % world, "trsm_nb": args.trsm_nb, "final_loss": final_loss},
+                       "parallelism": "dp%d rows" % world, "trsm_nb": eng.trsm_nb, "final_loss": final_loss,
+                       "dense_product": "rocBLAS sgemm" if eng.lib_dense_gemm else "hand-written (gemm.hip)",
+                       "timed_step": "TrainLoop.step(need_variance=False): ELBO fast path every step; the reference's "
+                                     "every-50th-step nll print (per-output path, ~+9 ms once per 50 steps at C4) is "
+                                     "outside the timed region"},
             "roofline": roof,
+            "roofline_assembly": roof_asm,
         }
+        if world > 1:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["config"]["collective"] = dict(backend=dist.get_backend(), algo=args.dp_algo, packed_triangle=eng.pack_reduce,
+                                               early_operand_floats=int(eng.early_wire_numel))
         if cfg.get("ciq"):
             out["config"]["ciq"] = dict(eng.ciq_stats)
         if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq"):

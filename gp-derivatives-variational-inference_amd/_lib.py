@@ -72,6 +72,8 @@ SIGNATURES = {
     "dsvgp_elbo_fast_finalize": (_i, [_p, _p, _p, _i, _i, _d, _p]),
     "dsvgp_mirror_lower_f32": (_i, [_p, _p, _i, _l]),
     "dsvgp_add_diag_f32": (_i, [_p, _p, _i, _l, _f]),
+    "dsvgp_tril_pack_f32": (_i, [_p, _p, _l, _i, _p, _i, _p]),
+    "dsvgp_tril_unpack_f32": (_i, [_p, _p, _i, _p, _l, _p, _i]),
     "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
     "dsvgp_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "dsvgp_adam_step_multi": (_i, [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i]),

@@ -162,34 +162,41 @@ def kernel_bwd(ctx, G, pack1, n1, pack2, n2, d, p, hyp, symmetric, d_x1, d_v1, d
     return workspace
 
 
-_potrf_ws = {}
+def potrf_workspace(n, device):
+    """Scratch of the blocked MFMA Cholesky (inverted 64 x 64 diagonal blocks, W_k tiles).  Owned by the caller, ONE per
+    factor: ``trtri_blocks`` later seeds its recursion from the blocks the factorisation left in it."""
+    return torch.empty(int(lib.dsvgp_potrf_workspace_bytes(int(n), 1)), dtype=torch.uint8, device=device)
 
 
-def potrf_(ctx, A, info, algo=1):
-    """In-place lower Cholesky.  algo 0 = rocSOLVER dpotrf, 1 = blocked MFMA Cholesky (default)."""
+def _potrf_scratch(A, ws):
+    need = int(lib.dsvgp_potrf_workspace_bytes(A.shape[0], 1))
+    if ws is None:
+        return potrf_workspace(A.shape[0], A.device)
+    if not ws.is_cuda or ws.numel() * ws.element_size() < need:
+        raise ValueError("potrf workspace too small: %d < %d" % (ws.numel() * ws.element_size(), need))
+    return ws
+
+
+def potrf_(ctx, A, info, algo=1, ws=None):
+    """In-place lower Cholesky.  algo 0 = rocSOLVER dpotrf, 1 = blocked MFMA Cholesky (default).
+    ``ws``: ``potrf_workspace(n)`` owned by the caller for THIS factor (a fresh one is allocated when omitted);
+    returned so that ``trtri_blocks(..., potrf_ws=)`` can reuse the inverted diagonal blocks."""
     _req(A, f64, "A", 2)
     n = A.shape[0]
-    ws = None
     if algo == 1:
-        key = (A.device.index, n)
-        ws = _potrf_ws.get(key)
-        if ws is None:
-            ws = torch.empty(int(lib.dsvgp_potrf_workspace_bytes(n, 1)), dtype=torch.uint8, device=A.device)
-            _potrf_ws[key] = ws
+        ws = _potrf_scratch(A, ws)
+    else:
+        ws = None
     check(lib.dsvgp_potrf(ctx.h, _ptr(A), n, _ld(A), _ptr(info), int(algo), _ptr(ws)), "dsvgp_potrf")
     return ws
 
 
-def potrf_inverse_(ctx, A, info, nb, workspace):
+def potrf_inverse_(ctx, A, info, nb, workspace, ws=None):
     """In-place lower Cholesky (blocked MFMA algorithm) AND the explicit inverse into the trsm workspace, in the same
-    launches.  Only for nb >= n; later ``trsm(..., reuse_inverse=True)`` calls use the inverse."""
+    launches.  Only for nb >= n; later ``trsm(..., reuse_inverse=True)`` calls use the inverse.  ``ws`` as in ``potrf_``."""
     _req(A, f64, "A", 2)
     n = A.shape[0]
-    key = (A.device.index, n)
-    ws = _potrf_ws.get(key)
-    if ws is None:
-        ws = torch.empty(int(lib.dsvgp_potrf_workspace_bytes(n, 1)), dtype=torch.uint8, device=A.device)
-        _potrf_ws[key] = ws
+    ws = _potrf_scratch(A, ws)
     check(lib.dsvgp_potrf_inverse(ctx.h, _ptr(A), n, _ld(A), _ptr(info), _ptr(ws), int(nb), _ptr(workspace)),
           "dsvgp_potrf_inverse")
     return ws
@@ -326,6 +333,29 @@ def add_diag_f32_(ctx, A, n, delta):
 def transpose_f32(ctx, src, dst):
     check(lib.dsvgp_transpose_f32(ctx.h, _ptr(src), _ld(src), src.shape[0], src.shape[1], _ptr(dst), _ld(dst)),
           "dsvgp_transpose_f32")
+
+
+def tril_packed_numel(n, nextra=0):
+    return n * (n + 1) // 2 + nextra
+
+
+def tril_pack_f32(ctx, src, extra, dst):
+    """dst = [packed lower triangle of src[n, n] | extra]: the half-volume data-parallel all-reduce operand."""
+    n = src.shape[0]
+    _req(src, f32, "src", 2); _req(extra, f32, "extra", 1); _req(dst, f32, "dst", 1)
+    if src.shape[1] < n or dst.numel() < tril_packed_numel(n, extra.numel()):
+        raise ValueError("tril_pack shape mismatch")
+    check(lib.dsvgp_tril_pack_f32(ctx.h, _ptr(src), _ld(src), n, _ptr(extra), extra.numel(), _ptr(dst)),
+          "dsvgp_tril_pack_f32")
+
+
+def tril_unpack_f32(ctx, src, dst, extra):
+    n = dst.shape[0]
+    _req(src, f32, "src", 1); _req(extra, f32, "extra", 1); _req(dst, f32, "dst", 2)
+    if dst.shape[1] < n or src.numel() < tril_packed_numel(n, extra.numel()):
+        raise ValueError("tril_unpack shape mismatch")
+    check(lib.dsvgp_tril_unpack_f32(ctx.h, _ptr(src), n, _ptr(dst), _ld(dst), _ptr(extra), extra.numel()),
+          "dsvgp_tril_unpack_f32")
 
 
 def gather_batch(ctx, X, Y, idx, cols, p, xb, yb):

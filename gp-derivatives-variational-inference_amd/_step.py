@@ -60,6 +60,11 @@ class ElboEngine:
         self._early_handle = None
         self._allow_early = False
         self._global_gram = False
+        # the early all-reduce operand ([G ; b^T] or [m-bar, L_S-bar]) travels as its packed lower triangle (SURVEY 8e:
+        # 18 MB instead of 36 MB at M' = 3000); early_wire_numel = floats actually handed to the collective last step
+        self.pack_reduce = True
+        self.early_wire_numel = 0
+        self._ctx = None
         self.variational_grads_global = False     # the last step returned m-bar / L_S-bar already summed over the ranks
         self._buf = {}
         self.chol_jitter = CHOL_JITTER  # base of the psd_safe_cholesky retry ladder (1e-8 for GradVariationalStrategy)
@@ -87,7 +92,7 @@ class ElboEngine:
         self.shared_directions = False
         self._no_middle = False
         self.fused_inverse = True       # L^-1 by forward elimination inside the Cholesky launches (csrc/potrf.hip)
-        self.lib_dense_gemm = True      # plain dense K_ZX-bar product through rocBLAS (129 vs 108 TF); False: gemm.hip
+        self.lib_dense_gemm = False     # True (diagnostics / test comparator only): the dense K_ZX-bar product through rocBLAS
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
@@ -160,7 +165,7 @@ class ElboEngine:
         _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
         nrhs = max(int(nrhs), Mp + 1)
         ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, nrhs, self.trsm_nb))
-        self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs)       # L and the inverted blocks of L
+        self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs, "kzz")   # L and the inverted blocks of L
         self._inverse_ws = ws
         self._pending = (hyp, packZ, L, (M, d, p, Mp), info)
         # status word + hyper-parameters go to pinned host memory right behind the factorisation: the later read waits for
@@ -176,13 +181,20 @@ class ElboEngine:
             self._finish_factor(ctx, ladder=True)
         return hyp, packZ, L, (M, d, p, Mp)
 
-    def _potrf_and_inverse(self, ctx, L, info, ws, nrhs):
+    def _potrf_scratch(self, name, n):
+        """Cholesky scratch of ONE factor of THIS engine (``name``: kzz / ngd_P / ngd_LS / root).  It keeps the inverted
+        64 x 64 diagonal blocks that a later ``trtri_blocks`` of the same factor copies verbatim, so it is never shared
+        between factors, engines or models."""
+        return self._bytes("potrf_ws_" + name, _lib.lib.dsvgp_potrf_workspace_bytes(int(n), 1))
+
+    def _potrf_and_inverse(self, ctx, L, info, ws, nrhs, name):
         """L <- chol(L) and the inverted blocks of L into the trsm workspace ``ws``: ONE fused chain of launches when the
         explicit-inverse regime applies (blocked algorithm, nb >= n), else potrf followed by the trtri recursion."""
         n = L.shape[0]
+        scratch = self._potrf_scratch(name, n) if self.potrf_algo == 1 else None
         if self.potrf_algo == 1 and self.trsm_nb >= n and self.fused_inverse:
-            return _ops.potrf_inverse_(ctx, L, info, self.trsm_nb, ws)
-        pws = _ops.potrf_(ctx, L, info, self.potrf_algo)
+            return _ops.potrf_inverse_(ctx, L, info, self.trsm_nb, ws, scratch)
+        pws = _ops.potrf_(ctx, L, info, self.potrf_algo, scratch)
         _ops.trtri_blocks(ctx, L, nrhs, self.trsm_nb, ws, pws)
         return pws
 
@@ -202,7 +214,7 @@ class ElboEngine:
         for t in range(CHOL_TRIES):                     # rare path: psd_safe_cholesky jitter ladder
             _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
             _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
-            self._potrf_ws = self._potrf_and_inverse(ctx, L, info, self._inverse_ws, Mp + 1)
+            self._potrf_ws = self._potrf_and_inverse(ctx, L, info, self._inverse_ws, Mp + 1, "kzz")
             if int(info.item()) == 0:
                 return
         raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
@@ -221,8 +233,22 @@ class ElboEngine:
             Kzx.copy_(full[:, ::p + 1])
             return Kzx
         Kzx = self._get("Kzx", (Mp, B * (p + 1)), f32)
+        ev = self._event_pair()                          # (on whichever stream the assembly is queued: main or side)
         _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        self._event_done("assemble_fwd", ev)
         return Kzx
+
+    def _event_pair(self):
+        if not self.record_events:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0, e1
+
+    def _event_done(self, name, ev):
+        if ev is not None:
+            ev[1].record()
+            self.events.append((name, ev[0], ev[1]))
 
     def _kernel_bwd_zx(self, ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws):
         if self.data_outputs == "values" and p > 0:
@@ -230,7 +256,9 @@ class ElboEngine:
             full.zero_()
             full[:, ::p + 1] = Kb32                      # derivative columns carry no gradient
             Kb32 = full
+        ev = self._event_pair()
         _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
+        self._event_done("assemble_bwd", ev)
 
     def _interp(self, ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=False):
         """K_ZX, A = L^-1 K_ZX (fp64 + fp32 copy), W = L_S^T A, mu, var."""
@@ -320,7 +348,7 @@ class ElboEngine:
                 jit = self.chol_jitter * 10.0 ** t
                 _ops.add_diag_(ctx, R, jit)
             info.zero_()
-            _ops.potrf_(ctx, R, info, self.potrf_algo)
+            _ops.potrf_(ctx, R, info, self.potrf_algo, self._potrf_scratch("root", n) if self.potrf_algo == 1 else None)
             if int(info.item()) == 0:
                 return R
         raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %g" % jit)
@@ -419,12 +447,49 @@ class ElboEngine:
         self.flat = flat[:off + 1]                      # [grads (padded)..., loss]
         self.flat_early, self.flat_late = flat[:early], flat[early:off + 1]
         self._early_handle = None
+        v0, v1 = views[order[0]], views[order[1]]
+        self._early_views = (v0, v1) if (v1.dim() == 2 and v1.shape[0] == v1.shape[1] == v0.numel()) else None
         return {k: views[k] for k in names}, flat[off:off + 1], flat[off + 1:off + 5]
 
     def _variational_grads_final(self):
         """called once m-bar and L_S-bar are complete: hand them to the data-parallel layer (asynchronous all-reduce)"""
         if self.collective is not None and self._allow_early and self.collective.world > 1:
-            self._early_handle = self.collective.all_reduce_async(self.flat_early)
+            views = getattr(self, "_early_views", None)
+            if self.pack_reduce and views is not None:
+                dm, dLS = views                  # L_S-bar is lower triangular: send [tril(L_S-bar) | m-bar]
+                self._early_handle = self._reduce_tril_async(self._ctx, self.collective, dLS, dm.reshape(-1))
+            else:
+                self.early_wire_numel = self.flat_early.numel()
+                self._early_handle = self.collective.all_reduce_async(self.flat_early)
+
+    # ---- packed-triangle collective operand ----
+    def _tril_pack(self, ctx, src, extra, dst):
+        _ops.tril_pack_f32(ctx, src, extra, dst)
+
+    def _tril_unpack(self, ctx, src, dst, extra):
+        _ops.tril_unpack_f32(ctx, src, dst, extra)
+
+    def _reduce_tril_async(self, ctx, coll, mat, extra):
+        """all-reduce(sum) of the lower triangle of ``mat`` [n, n] and of ``extra`` [k] through ONE packed buffer
+        (n(n+1)/2 + k floats, rounded up to a multiple of 2048 so that any world size <= 8 can reduce-scatter it).
+        Returns a handle whose ``wait()`` orders the current stream after the collective and unpacks in place."""
+        n, k = mat.shape[0], extra.numel()
+        used = _ops.tril_packed_numel(n, k)
+        total = (used + 2047) // 2048 * 2048
+        pk = self._buf.get("pk_early")
+        if pk is None or pk.numel() != total or pk.device != mat.device:
+            pk = self._buf["pk_early"] = torch.zeros(total, dtype=f32, device=mat.device)    # (the tail stays zero)
+        self._tril_pack(ctx, mat, extra, pk)
+        self.early_wire_numel = total
+        inner = coll.all_reduce_async(pk)
+        engine = self
+
+        class _Handle:
+            def wait(self_inner):
+                inner.wait()
+                engine._tril_unpack(ctx, pk, mat, extra)
+
+        return _Handle()
 
     # ---- q(u) in natural parameters (gpytorch 1.4.0 NaturalVariationalDistribution / _NaturalToMuVarSqrt) ----
     def _natural_moments(self, ctx, nat_vec, nat_mat):
@@ -439,7 +504,7 @@ class ElboEngine:
         info = self._get("ngd_info", (2,), torch.int32)
         info.zero_()
         wsP = self._bytes("ngd_wsP", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
-        self._potrf_and_inverse(ctx, P, info[0:1], wsP, Mp)
+        self._potrf_and_inverse(ctx, P, info[0:1], wsP, Mp, "ngd_P")
         eye = self._buf.get("ngd_eye")
         if eye is None or eye.shape[0] != Mp:
             eye = self._buf["ngd_eye"] = torch.eye(Mp, dtype=f64, device=self.device)
@@ -460,7 +525,7 @@ class ElboEngine:
         nb = self.trsm_nb
         LS64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)
         wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
-        self._potrf_and_inverse(ctx, LS64, info[1:2], wsS, Mp)                          # L_S (lower triangle) and L_S^-1
+        self._potrf_and_inverse(ctx, LS64, info[1:2], wsS, Mp, "ngd_LS")                # L_S (lower triangle) and L_S^-1
         bad = info.tolist()
         if bad[0] or bad[1]:
             raise NotPSDError("natural_mat does not define a positive definite precision (potrf info %s)" % bad)
@@ -545,6 +610,11 @@ class ElboEngine:
         if not torch.isfinite(eigs).all() or eigs.min() <= 0:
             eigs = torch.diagonal(K32).double().cpu()
         lmin, lmax = float(eigs.min()), float(eigs.max())
+        coll = self.collective
+        if coll is not None and coll.world > 1:
+            # data parallel: K_ZZ is replicated but the Lanczos start (first row of the LOCAL K_XZ shard) is not; rank 0's
+            # start is the single-process one (first row of the global batch), so its bounds define the quadrature for all
+            lmin, lmax = coll.broadcast_floats([lmin, lmax], self.device)
         Q = int(self.ciq_num_quadrature)
         k2 = lmin / lmax
         Kp = scipy.special.ellipk(1.0 - k2)
@@ -689,6 +759,7 @@ class ElboEngine:
 
     def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         use_fast = mll_type == "ELBO" and fast
+        self._ctx = ctx
         Mz = params["inducing_points"].shape[0]
         p = params["inducing_directions"].shape[0] // Mz if Mz else 0
         B = x.shape[0]
@@ -856,7 +927,11 @@ class ElboEngine:
             # THAT (36 MB, under the Q' solve and the K_ZX-bar product) instead of the L_S gradient at the end: L_S-bar and
             # m-bar then come out global on every rank, and the replicated Cholesky backward can be split by column blocks
             self._finish_factor(ctx)
-            handle = coll.all_reduce_async(Ge)
+            if self.pack_reduce:                             # [tril(G) | b]: half the bytes on the wire
+                handle = self._reduce_tril_async(ctx, coll, G, Ge[Mp])
+            else:
+                self.early_wire_numel = Ge.numel()
+                handle = coll.all_reduce_async(Ge)
         else:
             _ops.mirror_lower_f32_(ctx, G, Mp)
             self._finish_factor(ctx)                         # host sync, hidden behind the queued solve + Gram product

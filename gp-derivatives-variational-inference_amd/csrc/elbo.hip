@@ -380,6 +380,33 @@ __global__ void add_diag_f32_kernel(float* A, int n, int64_t lda, float delta) {
     if (i < n) A[(int64_t)i * lda + i] += delta;
 }
 
+// Packed lower triangle (row i at offset i(i+1)/2, i+1 entries) + `nextra` trailing floats: the data-parallel all-reduce
+// operand ([tril(G) ; b^T] or [tril(L_S-bar) ; m-bar]) at half the dense volume.  One workgroup per row.
+__global__ void tril_pack_f32_kernel(const float* __restrict__ src, int64_t ld, int n, const float* __restrict__ extra,
+                                     int nextra, float* __restrict__ dst) {
+    const int i = blockIdx.x;
+    if (i < n) {
+        const float* r = src + (int64_t)i * ld;
+        float* o = dst + (int64_t)i * (i + 1) / 2;
+        for (int j = threadIdx.x; j <= i; j += blockDim.x) o[j] = r[j];
+    } else {
+        float* o = dst + (int64_t)n * (n + 1) / 2;
+        for (int j = threadIdx.x + (i - n) * blockDim.x; j < nextra; j += blockDim.x * (gridDim.x - n)) o[j] = extra[j];
+    }
+}
+__global__ void tril_unpack_f32_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int64_t ld,
+                                       float* __restrict__ extra, int nextra) {
+    const int i = blockIdx.x;
+    if (i < n) {
+        const float* r = src + (int64_t)i * (i + 1) / 2;
+        float* o = dst + (int64_t)i * ld;
+        for (int j = threadIdx.x; j <= i; j += blockDim.x) o[j] = r[j];
+    } else {
+        const float* r = src + (int64_t)n * (n + 1) / 2;
+        for (int j = threadIdx.x + (i - n) * blockDim.x; j < nextra; j += blockDim.x * (gridDim.x - n)) extra[j] = r[j];
+    }
+}
+
 }  // namespace
 
 extern "C" int dsvgp_hyp_forward(dsvgp_ctx* ctx, const float* rl, const float* rs, const float* rn, float* hyp) {
@@ -598,6 +625,27 @@ extern "C" int dsvgp_mirror_lower_f32(dsvgp_ctx* ctx, float* G, int n, int64_t l
 extern "C" int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, float delta) {
     if (!ctx || !A || n <= 0) return DSVGP_EINVAL;
     hipLaunchKernelGGL(add_diag_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, delta);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_tril_pack_f32(dsvgp_ctx* ctx, const float* src, int64_t ld, int n, const float* extra, int nextra,
+                                   float* dst) {
+    if (!ctx || n < 0 || nextra < 0 || (n > 0 && (!src || ld < n)) || (nextra > 0 && !extra)) return DSVGP_EINVAL;
+    if (n == 0 && nextra == 0) return 0;
+    if (!dst) return DSVGP_EINVAL;
+    const int xb = nextra > 0 ? (cdiv(nextra, 256 * 8) < 64 ? cdiv(nextra, 256 * 8) : 64) : 0;
+    hipLaunchKernelGGL(tril_pack_f32_kernel, dim3(n + xb), dim3(256), 0, ctx->stream, src, ld, n, extra, nextra, dst);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_tril_unpack_f32(dsvgp_ctx* ctx, const float* src, int n, float* dst, int64_t ld, float* extra,
+                                     int nextra) {
+    if (!ctx || n < 0 || nextra < 0 || (n > 0 && (!dst || ld < n)) || (nextra > 0 && !extra)) return DSVGP_EINVAL;
+    if (n == 0 && nextra == 0) return 0;
+    if (!src) return DSVGP_EINVAL;
+    const int xb = nextra > 0 ? (cdiv(nextra, 256 * 8) < 64 ? cdiv(nextra, 256 * 8) : 64) : 0;
+    hipLaunchKernelGGL(tril_unpack_f32_kernel, dim3(n + xb), dim3(256), 0, ctx->stream, src, n, dst, ld, extra, nextra);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -149,8 +149,10 @@ class TrainLoop:
         dim, p, dev, dp = self.dim, self.minibatch_dim, self.device, self.dp
         if dp is not None:
             dp.global_batch = idx.shape[0]
-            lo, hi = dp.shard_bounds(idx.shape[0])
-            idx = idx[lo:hi]
+            dp.replicated_step = idx.shape[0] < dp.world      # tail smaller than the world: no empty shards (see parallel.py)
+            if not dp.replicated_step:
+                lo, hi = dp.shard_bounds(idx.shape[0])
+                idx = idx[lo:hi]
         # select random columns of y to train on (function values always included), :68-90
         if self.dfree or getattr(self, "plain", False):      # scalar targets: dfree_directional_vi / traditional_vi
             idx_y = [0]

@@ -67,25 +67,17 @@ class GPModel(ApproximateGP):
         return {k: v.detach() for k, v in zip(self._param_names(), self._param_list(likelihood))}
 
 
-def train_gp(train_dataset, dim, num_inducing=128,
-             minibatch_size=1,
-             num_epochs=1,
-             use_ngd=False,
-             use_ciq=False,
-             learning_rate_hypers=0.01,
-             learning_rate_ngd=0.1,
-             lr_sched=None,
-             mll_type="ELBO",
-             num_contour_quadrature=15,
-             watch_model=False, gamma=0.1,
-             verbose=True,
-             **args):
+def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_epochs=1, use_ngd=False, use_ciq=False,
+                   learning_rate_hypers=0.01, learning_rate_ngd=0.1, lr_sched=None, mll_type="ELBO", gamma=0.1,
+                   tensors=None, **args):
+    """Everything ``train_gp`` does before its loop (grad_svgp.py:41-127); returns a TrainLoop (``tensors``: an
+    already-resident (X, Y) pair instead of a Dataset)."""
     if use_ciq:
         raise NotImplementedError("grad_svgp with gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27) is not built")
     if not torch.cuda.is_available():
         raise RuntimeError("train_gp needs an MI355X (HIP) device: this path has no CPU fallback")
     device = torch.device("cuda", torch.cuda.current_device())
-    X, Y = _dataset_tensors(train_dataset, device)
+    X, Y = tensors if tensors is not None else _dataset_tensors(train_dataset, device)
     n_samples = X.shape[0]
 
     inducing_points = torch.rand(num_inducing, dim).to(device)            # :61
@@ -139,8 +131,27 @@ def train_gp(train_dataset, dim, num_inducing=128,
     else:
         raise ValueError("mll_type must be 'ELBO' or 'PLL'")
 
-    loop = TrainLoop(X, Y, model, likelihood, mll, (variational_optimizer, hyperparameter_optimizer),
+    return TrainLoop(X, Y, model, likelihood, mll, (variational_optimizer, hyperparameter_optimizer),
                      (variational_scheduler, hyperparameter_scheduler), dim, dp, None, perm_gen, full_gradient=True)
+
+
+def train_gp(train_dataset, dim, num_inducing=128,
+             minibatch_size=1,
+             num_epochs=1,
+             use_ngd=False,
+             use_ciq=False,
+             learning_rate_hypers=0.01,
+             learning_rate_ngd=0.1,
+             lr_sched=None,
+             mll_type="ELBO",
+             num_contour_quadrature=15,
+             watch_model=False, gamma=0.1,
+             verbose=True,
+             **args):
+    loop = setup_training(train_dataset, dim, num_inducing, minibatch_size, num_epochs, use_ngd, use_ciq,
+                          learning_rate_hypers, learning_rate_ngd, lr_sched, mll_type, gamma, **args)
+    model, likelihood = loop.model, loop.likelihood
+    n_samples = loop.X.shape[0]
     max_steps = args.get("max_steps")
     total_step = 0
     loss = None

@@ -23,6 +23,13 @@ class DataParallel:
         self.rank = dist.get_rank(group)
         self.global_batch = None      # set by the training loop before every step
         self.resync_every = 256       # steps between broadcasts of the variational parameters (see ``resync``)
+        # collective algorithm of the large (early) operand: "allreduce" (RCCL picks ring / tree) or "rs_ag"
+        # (reduce-scatter + all-gather); DSVGP_DP_ALGO overrides for A/B runs on an 8-GPU node
+        import os
+        self.algo = os.environ.get("DSVGP_DP_ALGO", "allreduce")
+        self.rs_ag_min_numel = 1 << 16
+        self._shards = {}
+        self.replicated_step = False  # set by the training loop for a tail minibatch with fewer rows than ranks
 
     def shard_bounds(self, n):
         """rows [lo, hi) of a global batch of n rows owned by this rank (ragged tails go to low ranks)."""
@@ -45,9 +52,44 @@ class DataParallel:
         for t in ts:
             dist.broadcast(t, 0, group=self.group)
 
+    def broadcast_floats(self, values, device):
+        """rank 0's host scalars on every rank (e.g. the eigenvalue bounds of the CIQ quadrature)"""
+        t = torch.tensor(values, dtype=torch.float64, device=device)
+        dist.broadcast(t, dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return [float(v) for v in t.tolist()]
+
     def all_reduce_async(self, t):
-        """sum over the ranks, asynchronously on the collective's own stream; ``.wait()`` orders the current stream after it"""
+        """sum over the ranks, asynchronously on the collective's own stream; ``.wait()`` orders the current stream after it.
+        ``algo = "rs_ag"``: one reduce-scatter + one all-gather (every rank owns 1/world of the buffer: with RCCL's direct
+        algorithms all 7 xGMI peers of a rank carry traffic at once instead of one ring neighbour); buffers that do not
+        split evenly keep the plain all-reduce."""
+        if self.algo == "rs_ag" and self.world > 1 and t.is_contiguous() and t.numel() % self.world == 0 \
+                and t.numel() >= self.rs_ag_min_numel:
+            return self._rs_ag_async(t.view(-1))
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _rs_ag_async(self, flat):
+        n = flat.numel() // self.world
+        shard = self._shards.get((flat.dtype, n))
+        if shard is None or shard.device != flat.device:
+            shard = self._shards[(flat.dtype, n)] = torch.empty(n, dtype=flat.dtype, device=flat.device)
+        if dist.get_backend(self.group) == "gloo":
+            # gloo has no reduce-scatter: the same data movement as world point-to-point reductions (CPU rehearsal only)
+            for r in range(self.world):
+                dist.reduce(flat[r * n:(r + 1) * n], dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                            op=dist.ReduceOp.SUM, group=self.group)
+            shard.copy_(flat[self.rank * n:(self.rank + 1) * n])
+            h = dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True)
+            return h
+        h1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        h2 = dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True)   # same communicator: stream-ordered
+
+        class _Pair:
+            def wait(self_inner):
+                h1.wait()
+                h2.wait()
+
+        return _Pair()
 
     def loss_and_grads(self, engine, params, x, y, D, num_data, mll_type):
         """x, y, D are this rank's shard.  Returns globally reduced (loss, grads, local mu, local varn)."""
@@ -56,6 +98,20 @@ class DataParallel:
         # engines with a flat gradient buffer use this object as their collective while the step runs (``all_reduce_async``):
         # either [G ; b^T] is summed early and m-bar / L_S-bar come back global, or they are reduced as soon as they are
         # final, under the rest of the backward; what is left for the end of the step is the small ``flat_late`` segment
+        if self.replicated_step:
+            # fewer rows than ranks (ragged tail of an epoch): an empty shard is not a case the kernels take, so every rank
+            # computes the whole (tiny) batch and rank 0's result is broadcast -- replicas stay bit-identical
+            loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type)
+            flat = getattr(engine, "flat", None)
+            if flat is not None:
+                dist.broadcast(flat, 0, group=self.group)
+                loss = flat[-1]
+            else:
+                for k in grads:
+                    dist.broadcast(grads[k], 0, group=self.group)
+                loss = loss.clone()
+                dist.broadcast(loss, 0, group=self.group)
+            return loss, grads, mu, varn
         hooked = hasattr(engine, "collective")
         if hooked:
             engine.collective = self

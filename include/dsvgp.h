@@ -201,6 +201,14 @@ int dsvgp_elbo_fast_finalize(dsvgp_ctx* ctx, const float* sums, const float* hyp
 int dsvgp_mirror_lower_f32(dsvgp_ctx* ctx, float* G, int n, int64_t ldg);
 int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, float delta);
 
+/* ---- data-parallel all-reduce operand (the reference is single-process and has no counterpart):
+ * dst = [ packed lower triangle of src[n,n] (row i at offset i(i+1)/2) | extra[nextra] ], i.e. n(n+1)/2 + nextra floats
+ * instead of n*n + nextra ([tril(G) ; b^T] or [tril(L_S-bar) ; m-bar]: 18 MB instead of 36 MB at M' = 3000).
+ * dsvgp_tril_unpack_f32 writes the lower triangle of dst (the strict upper part is left untouched) and extra back.  */
+int dsvgp_tril_pack_f32(dsvgp_ctx* ctx, const float* src, int64_t ld, int n, const float* extra, int nextra,
+                        float* dst);
+int dsvgp_tril_unpack_f32(dsvgp_ctx* ctx, const float* src, int n, float* dst, int64_t ld, float* extra, int nextra);
+
 /* ---- minibatch gather: DataLoader batch + select_cols_of_y (directional_vi.py:68-90,229-241)
  * xb[b,:] = X[idx[b],:] ; yb[b*(p+1)+c] = Y[idx[b], cols[c]]  (cols[0] == 0)                     */
 int dsvgp_gather_batch(dsvgp_ctx* ctx, const float* X, const float* Y, const int64_t* idx, int nb,

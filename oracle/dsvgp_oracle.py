@@ -68,6 +68,59 @@ def kernel_matrix(x1, x2, v1, v2, lengthscale):
     return K.reshape(n1 * (p + 1), n2 * (p + 1))                   # interleaved, :105-107
 
 
+def _rbf_sq_dist(a, b):
+    """gpytorch 1.4.0 ``Kernel.covar_dist(square_dist=True, dist_postprocess_func=postprocess_rbf)`` (un-vendored; reached
+    from reference RBFKernelDirectionalGrad.py:71): both point sets shifted by the mean of the first, the squared
+    distance from ONE matmul of the padded operands [-2a, |a|^2, 1] [b, 1, |b|^2]^T, clamped at 0, then exp(-r/2)."""
+    shift = a.mean(-2, keepdim=True)
+    a, b = a - shift, b - shift
+    an, bn = (a * a).sum(-1, keepdim=True), (b * b).sum(-1, keepdim=True)
+    lhs = torch.cat([-2.0 * a, an, torch.ones_like(an)], dim=-1)
+    rhs = torch.cat([b, torch.ones_like(bn), bn], dim=-1)
+    return (lhs @ rhs.t()).clamp_min(0).div(-2).exp()
+
+
+def kernel_matrix_refseq(x1, x2, v1, v2, lengthscale):
+    """The SAME matrix as :func:`kernel_matrix`, evaluated with the reference's op structure
+    (RBFKernelDirectionalGrad.py:57-107) instead of pair-wise differences: blocked layout
+    [[values, right derivatives], [left derivatives, Hessian]] filled through matmul / bmm projections of the scaled
+    points on the directions, column-permutation gathers, ``repeat`` broadcasts of the value block, and one final
+    perfect-shuffle gather of rows and columns into the interleaved order.  Used by the ``cpu_baseline`` leg of bench.py
+    (what the reference costs on a CPU) and pinned to :func:`kernel_matrix` / the golden vectors in tests."""
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    p = v1.shape[0] // n1
+    assert v2.shape[0] // n2 == p, "v1 and v2 must contain same number of directions"
+    ell = lengthscale.reshape(1, 1) if torch.is_tensor(lengthscale) else torch.tensor([[lengthscale]], dtype=x1.dtype)
+    u1 = (v1.t() / v1.norm(dim=1)).t()                                  # :57-58
+    u2 = (v2.t() / v2.norm(dim=1)).t()
+    K = torch.zeros(n1 * (p + 1), n2 * (p + 1), dtype=x1.dtype)         # :61-62 (the reference allocates it twice)
+    K = torch.zeros(n1 * (p + 1), n2 * (p + 1), dtype=x1.dtype)
+    a, b = x1 / ell, x2 / ell                                           # :67-68
+    kv = _rbf_sq_dist(a, b)                                             # :71-73
+    K[:n1, :n2] = kv
+    if p > 0:
+        # right-derivative block (:77-83): (a_i - b_j) . u2_{j,t} from a dense product minus the per-point self terms
+        b_u2 = torch.bmm(b.reshape(n2, 1, d), u2.reshape(n2, p, d).transpose(-2, -1))
+        right = a @ u2.t() - b_u2.flatten()
+        by_dir_c = torch.arange(n2 * p).view(n2, p).t().reshape(n2 * p)         # columns grouped by direction index
+        right = right[:, by_dir_c] / ell
+        K[:n1, n2:] = right * kv.repeat(1, p)
+        # left-derivative block (:86-93)
+        a_u1 = torch.bmm(a.reshape(n1, 1, d), u1.reshape(n1, p, d).transpose(-2, -1))
+        left = a_u1.flatten() - b @ u1.t()
+        by_dir_r = torch.arange(n1 * p).view(n1, p).t().reshape(n1 * p)
+        left = left[:, by_dir_r].t() / ell
+        K[n1:, :n2] = -left * kv.repeat(p, 1)
+        # Hessian block (:97-102)
+        cross = right.repeat(p, 1) * left.repeat(1, p)
+        gram = (u1 @ u2.t() / ell.pow(2))[:, by_dir_c][by_dir_r, :]
+        K[n1:, n2:] = (gram - cross) * kv.repeat(p, p)
+    rows = torch.arange(n1 * (p + 1)).view(p + 1, n1).t().reshape(n1 * (p + 1))   # perfect shuffle, :105-107
+    cols = torch.arange(n2 * (p + 1)).view(p + 1, n2).t().reshape(n2 * (p + 1))
+    return K[rows, :][:, cols]
+
+
 def kernel_diag(n, p, lengthscale, dtype=torch.float64):
     """diag=True branch, reference RBFKernelDirectionalGrad.py:110-119."""
     ell = lengthscale.reshape(()) if torch.is_tensor(lengthscale) else torch.tensor(lengthscale, dtype=dtype)
@@ -104,7 +157,7 @@ def psd_safe_cholesky(K):
     raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %g" % prev)
 
 
-def predictive(params, x, D, solve_dtype=torch.float64, data_outputs="all"):
+def predictive(params, x, D, solve_dtype=torch.float64, data_outputs="all", assembly=None):
     """DirectionalGradVariationalStrategy.forward, reference DGVS.py:89-208.
 
     Returns (mu, var) with ``var = diag(Sigma)`` of q(f) (no likelihood noise).
@@ -121,6 +174,7 @@ def predictive(params, x, D, solve_dtype=torch.float64, data_outputs="all"):
     B = x.shape[0]
     assert D.shape[0] // B == p, "Need minibatch dim to be same as number of directions for kernel"
     dt = x.dtype
+    kernel_matrix = assembly or globals()["kernel_matrix"]         # (``kernel_matrix_refseq``: the reference's op sequence)
     K_ZX = s * kernel_matrix(Z, x, V, D, ell)                      # :128-132
     K_XZ = s * kernel_matrix(x, Z, D, V, ell)                      # :133-137
     K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
@@ -171,14 +225,14 @@ def kl_whitened(m, L_S):
 
 
 def elbo_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64,
-                 data_outputs="all"):
+                 data_outputs="all", assembly=None):
     """loss = -mll(likelihood(model(x)), y), reference directional_vi.py:245-246.
 
     ``y`` is the interleaved target vector of length B*(p+1) (:241).  ``global_rows`` lets a
     data-parallel rank normalise by the global batch (defaults to the local one).
     Note the reference feeds the *noised* marginal into the mll, so the noise enters twice.
     """
-    mu, var = predictive(params, x, D, solve_dtype, data_outputs)
+    mu, var = predictive(params, x, D, solve_dtype, data_outputs, assembly)
     _, _, noise = constrained(params)
     L_S = torch.tril(params["chol_variational_covar"])
     Bp = y.shape[0] if global_rows is None else global_rows

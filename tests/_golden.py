@@ -1,0 +1,30 @@
+"""Shared reader of the reference-generated kernel vectors (tests/golden/kernel_*.npz, oracle/make_golden.py).
+Small kernels are stored whole (``K``); large ones as a seeded sub-matrix around every tile edge (``K_sub`` at
+``K_rows`` x ``K_cols``) plus the row and column sums of the whole matrix, which pin every entry in aggregate."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "kernel_*.npz")))
+
+
+def load(path):
+    return np.load(path)
+
+
+def kernel_error(K, g):
+    """max |K - K_ref| / max |K_ref| over the stored entries, and the same for the row / column sums (None when whole)."""
+    K = K.double().cpu()
+    if "K" in g:
+        ref = torch.from_numpy(g["K"])
+        assert K.shape == ref.shape
+        return ((K - ref).abs().max() / ref.abs().max()).item(), None
+    assert tuple(K.shape) == tuple(int(v) for v in g["K_shape"])
+    rows, cols = torch.from_numpy(g["K_rows"]), torch.from_numpy(g["K_cols"])
+    ref = torch.from_numpy(g["K_sub"])
+    e_sub = ((K[rows][:, cols] - ref).abs().max() / ref.abs().max()).item()
+    rs, cs = torch.from_numpy(g["K_rowsum"]), torch.from_numpy(g["K_colsum"])
+    e_sum = max(((K.sum(1) - rs).abs().max() / rs.abs().max()).item(), ((K.sum(0) - cs).abs().max() / cs.abs().max()).item())
+    return e_sub, e_sum

@@ -95,3 +95,25 @@ def test_select_cols_of_y_matches_reference_contract(dsvgp):
     assert cols == sorted(cols)
     for r, c in enumerate(cols[1:]):
         assert D[r].sum() == 1 and D[r, c - 1] == 1                      # canonical direction e_{k-1} for column k
+
+
+def test_select_cols_of_y_against_reference_generated_vectors(dsvgp):
+    """tests/golden/select_cols.npz: outputs of the REFERENCE function (directional_vi.py:68-90) for seeded ``random``
+    states and several calls in a row (oracle/make_host_fixtures.py).  The product's drop-in must draw the same columns
+    and directions from the same state, and so must the seeded sampler ``TrainLoop.step`` uses on the GPU path."""
+    import random
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "select_cols.npz"))
+    ncases = len([k for k in g.files if k.endswith("_meta")])
+    assert ncases >= 6
+    for ci in range(ncases):
+        dim, p, B, seed, calls = (int(v) for v in g["case%d_meta" % ci])
+        random.seed(seed)
+        rng = random.Random(seed)                       # TrainLoop's col_rng (setup_training(seed=...))
+        for k in range(calls):
+            y = torch.from_numpy(g["case%d_call%d_y" % (ci, k)])
+            ysel, D = dsvgp.select_cols_of_y(y, p, dim)
+            assert torch.equal(ysel, torch.from_numpy(g["case%d_call%d_ysel" % (ci, k)])), (ci, k)
+            assert torch.equal(D, torch.from_numpy(g["case%d_call%d_D" % (ci, k)])), (ci, k)
+            idx_y = sorted(rng.sample(range(1, dim + 1), p) + [0])          # directional_vi.TrainLoop.step
+            assert torch.equal(y[:, idx_y], ysel) and torch.equal(torch.eye(dim)[[c - 1 for c in idx_y[1:]]], D)

@@ -157,3 +157,50 @@ def test_train_gp_use_ciq_drop_in(dsvgp, gpu_device, capsys):
     means, variances = dsvgp.eval_gp(TensorDataset(train_x[:60], train_y[:60]), model, likelihood,
                                      num_directions=p, minibatch_size=30, minibatch_dim=p)
     assert means.shape == (180,) and (variances > 0).all() and torch.isfinite(means).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("state", ["init", "mid"])
+def test_c5_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, state):
+    """BASELINE config 5 at FULL size: CIQ-whitened DSVGP d=50, M=1024, p=5 -> M'=6144, B=512 -> B'=3072, Q=15
+    (reference CiqDirectionalGradVariationalStrategy.py:19-123,197-295) against the oracle runs committed as
+    tests/golden/c5_step_{init,mid}.npz (oracle/make_c5_fixture.py; inputs regenerated from the seed).
+    Tolerances as in test_ciq_step_matches_oracle: both sides stop msMINRES at a mean relative update of 1e-4 tested every
+    10 iterations and take the spectrum from 20 Lanczos steps in fp32, so loss 1e-3, mean / variance 5e-3, gradients
+    2e-2 of the max magnitude per parameter."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_c5_fixture import make_inputs, Q
+    path = os.path.join(os.path.dirname(__file__), "golden", "c5_step_%s.npz" % state)
+    g = np.load(path)
+    P, x, y, D, nd = make_inputs(state)
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.whitening = "ciq"
+    eng.ciq_num_quadrature = Q
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    torch.cuda.synchronize()
+    t = lambda k: torch.from_numpy(g[k])
+    errs = {"lmax": abs(eng.ciq_stats["lmax"] - float(g["lmax"])) / float(g["lmax"]),
+            "lmin": abs(eng.ciq_stats["lmin"] - float(g["lmin"])) / float(g["lmin"]),
+            "loss": abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])),
+            "mu": relmax(mu, t("mu")), "var": relmax(varn, t("varn"))}
+    gm = grads["natural_mat"]
+    errs["g_nm_norm"] = abs(gm.double().norm().item() - float(g["g_nm_norm"])) / float(g["g_nm_norm"])
+    errs["g_nm_block"] = relmax(gm[:96, :96], t("g_nm_block"))
+    errs["g_nm_diag"] = relmax(torch.diagonal(gm), t("g_nm_diag"))
+    errs["g_nm_lastrows"] = relmax(gm[-8:, :], t("g_nm_lastrows"))
+    for k in O.NGD_PARAM_NAMES:
+        if k != "natural_mat" and t("g_" + k).numel() and t("g_" + k).abs().max() > 0:
+            errs["g_" + k] = relmax(grads[k], t("g_" + k))
+    print("[parity] C5 %s: iterations %d (oracle %d), %s" % (state, eng.ciq_stats["iterations"], int(g["iterations"]),
+                                                            ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert abs(eng.ciq_stats["iterations"] - int(g["iterations"])) <= 10
+    assert errs["lmax"] < 1e-3 and errs["lmin"] < 5e-2
+    assert errs["loss"] < 1e-3 and errs["mu"] < 5e-3 and errs["var"] < 5e-3, errs
+    assert errs["g_nm_norm"] < 2e-2
+    for k, v in errs.items():
+        if k.startswith("g_"):
+            assert v < 2e-2, (k, v)

@@ -19,6 +19,12 @@ def relmax(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def _report(tag, errs):
+    """measured GPU-vs-oracle errors go to the test output (``pytest -rP`` / the captured log): the margin under each
+    stated tolerance stays visible and regressions show before they fail"""
+    print("[parity] %s: %s" % (tag, ", ".join("%s %.2e" % (k, v) for k, v in errs.items())))
+
+
 def make_problem(N, d, M, p, B, seed=0, perturb=True):
     g = torch.Generator().manual_seed(seed)
     X = torch.rand(N, d, generator=g)
@@ -80,6 +86,7 @@ def test_step_matches_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
         assert relmax(varn, var_ref) < 2e-4
     P64 = {k: v.double() for k, v in P.items()}
     _, g64, _, _ = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), nd, mll)
+    errs = {"loss": abs(loss.item() - l_ref.item()) / abs(l_ref.item()), "mu": relmax(mu, mu_ref)}
     for k in O.PARAM_NAMES:
         if p == 0 and k == "inducing_directions":
             continue
@@ -87,7 +94,9 @@ def test_step_matches_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
         if k == "chol_variational_covar":
             assert grads[k].triu(1).abs().max().item() == 0.0
         e_mixed, e_64 = relmax(grads[k], gr), relmax(grads[k], g64[k])
+        errs[k] = min(e_mixed, e_64)
         assert min(e_mixed, e_64) < 2e-3, (k, e_mixed, e_64)
+    _report("step N=%d d=%d M=%d p=%d B=%d %s%s" % (N, d, M, p, B, mll, "" if not fast else " fast"), errs)
 
 
 def test_step_at_c2_sizes_against_oracle(dsvgp, gpu_device):
@@ -282,6 +291,10 @@ def test_c4_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device):
                 assert relmax(gl[-8:, :], torch.from_numpy(g["g_LS_lastrows"])) < 5e-3
             else:
                 assert relmax(grads[k], torch.from_numpy(g["g_" + k])) < 5e-3, (fast, k, relmax(grads[k], torch.from_numpy(g["g_" + k])))
+        errs = {"loss": abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), "mu": relmax(mu[:256], torch.from_numpy(g["mu_head"]))}
+        errs.update({"g_" + k: relmax(grads[k], torch.from_numpy(g["g_" + k])) for k in O.PARAM_NAMES if k != "chol_variational_covar"})
+        errs["g_LS_block"] = relmax(grads["chol_variational_covar"][:96, :96], torch.from_numpy(g["g_LS_block"]))
+        _report("C4 ELBO %s" % ("fast" if fast else "per-output"), errs)
 
 
 # ------------------------------------------------------------------ derivative-free data
@@ -579,3 +592,72 @@ def test_ten_step_trajectory_matches_oracle_training(dsvgp, gpu_device, mll):
             got = Pd[k].detach().cpu()
         scale = max(ref.abs().max().item(), 1e-2)
         assert (got - ref).abs().max().item() < 2e-3 * scale, (k, (got - ref).abs().max().item(), scale)
+
+
+def test_two_engines_of_equal_size_keep_their_own_cholesky_scratch(dsvgp, gpu_device):
+    """Two models with the same M' (BO drivers), eval-mode Cholesky cache, and a LARGER batch after the other model has
+    factored its own K_ZZ: the re-allocated solve workspace is re-seeded from THIS engine's inverted diagonal blocks, never
+    from another factor of the same size (the potrf scratch is owned per engine and per factor)."""
+    d, M, p = 4, 50, 2                                  # M' = 150: three 64-blocks
+    out = []
+    for nb in (64, None):                               # panel regime (trtri from the 64 x 64 seeds) and explicit inverse
+        PA, xa, _, Da, _ = make_problem(400, d, M, p, 40, seed=71)
+        PB, xb, _, Db, _ = make_problem(400, d, M, p, 40, seed=72)
+        PB["raw_lengthscale"] = torch.tensor([[-0.4]])
+        ea, eb = dsvgp.ElboEngine(gpu_device, trsm_nb=nb), dsvgp.ElboEngine(gpu_device, trsm_nb=nb)
+        ga = {k: v.to(gpu_device) for k, v in PA.items()}
+        gb = {k: v.to(gpu_device) for k, v in PB.items()}
+        g = torch.Generator().manual_seed(3)
+        xbig = torch.rand(300, d, generator=g)
+        Dbig = torch.eye(d)[:p].repeat(300, 1)
+        ea.predict(ga, xa.to(gpu_device), Da.to(gpu_device), cache=True)          # A factors, small batch
+        eb.predict(gb, xb.to(gpu_device), Db.to(gpu_device), cache=True)          # B factors a different K_ZZ of the same size
+        eb.covariance_root(torch.eye(M * (p + 1), device=gpu_device) * 2.0)       # ... and another potrf of size M'
+        mu, varn = ea.predict(ga, xbig.to(gpu_device), Dbig.to(gpu_device), cache=True)   # A: cache hit, larger batch
+        mu_ref, var_ref = O.predictive(PA, xbig, Dbig)
+        _, _, noise = O.constrained(PA)
+        assert relmax(mu, mu_ref) < 2e-4 and relmax(varn, var_ref + noise) < 2e-4, nb
+        mu2, varn2 = eb.predict(gb, xbig.to(gpu_device), Dbig.to(gpu_device), cache=True)
+        mu2_ref, var2_ref = O.predictive(PB, xbig, Dbig)
+        _, _, noise2 = O.constrained(PB)
+        assert relmax(mu2, mu2_ref) < 5e-4 and relmax(varn2, var2_ref + noise2) < 5e-4, nb
+
+
+@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+def test_c3_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, mll):
+    """BASELINE config 3 at FULL size: full-gradient SVGP d=10, M=300 -> M' = 3300, B=512 -> B' = 5632 (reference
+    GradVariationalStrategy.py:87-137, grad_svgp.py:119,143) against the oracle run committed as tests/golden/c3_step.npz
+    (oracle/make_c3_fixture.py; inputs regenerated from the seed).  Tolerances: loss 2e-5, mean / variance 2e-4,
+    gradients 5e-3 of the max magnitude per parameter (fp32 model, fp64 solves, M' = 3300)."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_c3_fixture import make_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c3_step.npz"))
+    P, x, y, D, nd = make_inputs()
+    pre = mll + "_"
+    for fast in ((True, False) if mll == "ELBO" else (False,)):
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.chol_jitter = 1e-8                              # GradVariationalStrategy.py:72 (fp64 psd_safe_cholesky default)
+        Pg = {k: v.to(gpu_device) for k, v in P.items()}
+        loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll, fast=fast)
+        torch.cuda.synchronize()
+        errs = {"loss": abs(loss.item() - float(g[pre + "loss"])) / abs(float(g[pre + "loss"])),
+                "mu": relmax(mu[:256], torch.from_numpy(g[pre + "mu_head"]))}
+        if not fast:
+            errs["var"] = relmax(varn[:256], torch.from_numpy(g[pre + "varn_head"]))
+        gl = grads["chol_variational_covar"]
+        errs["g_LS_norm"] = abs(gl.double().norm().item() - float(g[pre + "g_LS_norm"])) / float(g[pre + "g_LS_norm"])
+        errs["g_LS_block"] = relmax(gl[:96, :96], torch.from_numpy(g[pre + "g_LS_block"]))
+        errs["g_LS_diag"] = relmax(torch.diagonal(gl), torch.from_numpy(g[pre + "g_LS_diag"]))
+        errs["g_LS_lastrows"] = relmax(gl[-8:, :], torch.from_numpy(g[pre + "g_LS_lastrows"]))
+        for k in O.PARAM_NAMES:
+            if k not in ("chol_variational_covar", "inducing_directions"):
+                errs["g_" + k] = relmax(grads[k], torch.from_numpy(g[pre + "g_" + k]))
+        _report("C3 %s %s" % (mll, "fast" if fast else "per-output"), errs)
+        assert errs["loss"] < 2e-5 and errs["mu"] < 2e-4 and errs.get("var", 0.0) < 2e-4, errs
+        assert errs["g_LS_norm"] < 2e-3
+        for k, v in errs.items():
+            if k.startswith("g_"):
+                assert v < 5e-3, (k, v)

@@ -47,6 +47,19 @@ def _flat_engine(dsvgp_amd):
             loss_out.copy_(loss.reshape(1))
             return loss_out[0], grads, mu, varn
 
+        # CPU stand-ins for the two HIP pack kernels (dsvgp_tril_pack_f32 / _unpack_f32): same packed layout
+        def _tril_pack(self, ctx, src, extra, dst):
+            n = src.shape[0]
+            i, j = torch.tril_indices(n, n)
+            dst[:i.numel()] = src[i, j]
+            dst[i.numel():i.numel() + extra.numel()] = extra
+
+        def _tril_unpack(self, ctx, src, dst, extra):
+            n = dst.shape[0]
+            i, j = torch.tril_indices(n, n)
+            dst[i, j] = src[:i.numel()]
+            extra.copy_(src[i.numel():i.numel() + extra.numel()])
+
     return FlatOracleEngine(torch.device("cpu"))
 
 
@@ -77,6 +90,26 @@ def _worker(rank, world, port, out):
     eng = _flat_engine(dsvgp_amd)
     loss2, grads2, _, _ = dp.loss_and_grads(eng, P, x[lo:hi], y[lo * (p + 1):hi * (p + 1)], D[lo * p:hi * p], nd, "ELBO")
     assert eng.fired and eng.collective is None and eng._early_handle is None
+    # the early operand travelled as [tril(L_S-bar) | m-bar]: about half of the dense [m-bar, L_S-bar] segment
+    Mp = P["variational_mean"].shape[0]
+    assert eng.pack_reduce and eng.early_wire_numel == (Mp * (Mp + 1) // 2 + Mp + 2047) // 2048 * 2048
+    assert Mp * (Mp + 1) // 2 + Mp < 0.55 * eng.flat_early.numel()
+    # ... and the dense operand / the reduce-scatter + all-gather algorithm give the same numbers
+    for pack, algo in ((False, "allreduce"), (True, "rs_ag"), (False, "rs_ag")):
+        eng3 = _flat_engine(dsvgp_amd)
+        eng3.pack_reduce = pack
+        dp.algo, dp.rs_ag_min_numel = algo, 1
+        loss3, grads3, _, _ = dp.loss_and_grads(eng3, P, x[lo:hi], y[lo * (p + 1):hi * (p + 1)], D[lo * p:hi * p], nd, "ELBO")
+        e3 = max((grads3[k].double() - grads[k]).abs().max().item() / (1e-30 + grads[k].abs().max().item()) for k in grads)
+        assert e3 < 1e-6 and abs(loss3.item() - loss.item()) < 1e-5 * abs(loss.item()), (pack, algo, e3)
+    dp.algo = "allreduce"
+    # a tail minibatch with fewer rows than ranks: computed on every rank, rank 0's gradients broadcast (no empty shard)
+    dp.replicated_step = True
+    dp.global_batch = 1
+    l1, g1, _, _ = dp.loss_and_grads(OracleEngine(), P, x[:1], y[:p + 1], D[:p], nd, "ELBO")
+    dp.replicated_step = False
+    l1r, g1r, _, _ = O.elbo_loss_and_grads(P, x[:1], y[:p + 1], D[:p], nd)
+    assert abs(l1.item() - l1r.item()) < 1e-12 and all((g1[k] - g1r[k]).abs().max().item() < 1e-12 for k in g1r)
     assert grads2["variational_mean"].data_ptr() == eng.flat.data_ptr()       # variational segment leads the buffer
     assert eng.flat_early.numel() + eng.flat_late.numel() == eng.flat.numel()
     err = max((grads2[k].double() - grads[k]).abs().max().item() / (1e-30 + grads[k].abs().max().item()) for k in grads)
