@@ -70,6 +70,26 @@ def synthetic_data(N, d, device):
     return X.contiguous(), Y.contiguous()
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask and the cgroup CPU quota, not the host's core count (a GPU box
+    shows 256 logical CPUs to a container limited to a share of them; 256 threads on that share thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(cfg, budget_s=150.0, min_steps=3):
     """The oracle's reference-op-sequence training step (oracle/train_ref.py: DataLoader over the FULL dataset, the four
     kernel assemblies in the reference's matmul / gather / shuffle form, fp64 Cholesky + 2 solves, autograd backward, two
@@ -77,7 +97,7 @@ def cpu_baseline(cfg, budget_s=150.0, min_steps=3):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import train_ref
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     st = train_ref.RefTrainer(cfg["N"], cfg["d"], cfg["M"], cfg["p"], cfg["B"], full_gradient=bool(cfg.get("grad")))
     t0 = time.time()
@@ -92,7 +112,8 @@ def cpu_baseline(cfg, budget_s=150.0, min_steps=3):
         steps += 1
         if steps >= 1 and t_acc > 2.0 * budget_s:          # a very slow host: report what was timed, say so in `sample`
             break
-    return dict(value=steps / t_acc, unit="steps/s", cores=cores, threads=torch.get_num_threads(), kind="port",
+    return dict(value=steps / t_acc, unit="steps/s", cores=cores, threads=torch.get_num_threads(),
+                host_logical_cpus=os.cpu_count(), kind="port",
                 assembly="reference-sequence",
                 assembly_fwd_s_per_step=st.assembly_seconds / steps,
                 sample="%d timed full-size steps (B=%d, M'=%d, DataLoader over all N=%d rows) after 1 warm-up step "

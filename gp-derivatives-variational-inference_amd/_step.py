@@ -121,6 +121,14 @@ class ElboEngine:
             self._buf[name] = t
         return t
 
+    def _get_zeroed(self, name, shape, dtype):
+        """like ``_get`` but zero-filled when (re)allocated: buffers whose padding must read as zero"""
+        t = self._buf.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            self._buf[name] = t
+        return t
+
     def _bytes(self, name, nbytes):
         t = self._buf.get(name)
         if t is None or t.numel() < nbytes:
@@ -603,6 +611,14 @@ class ElboEngine:
         iters = min(20, n)
         alpha, beta = _ops.ciq_lanczos(ctx, K32, v0.contiguous(), iters)
         a, b = alpha.double().cpu(), beta.double().cpu()              # host sync (40 floats)
+        # an invariant subspace was reached at step k (beta_k ~ 0: e.g. a start vector that is an eigenvector of an almost
+        # diagonal K_ZZ, the reference's CIQ initialisation lengthscale = 1 / M): the recurrence stops there and the
+        # tridiagonal is its leading (k + 1) x (k + 1) block, as in the oracle's ``lanczos_eig_bounds``
+        for k in range(iters - 1):
+            if not (float(b[k]) >= 1e-12 * abs(float(a[k]))):
+                iters = k + 1
+                a, b = a[:iters], b[:iters]
+                break
         Tm = torch.diag(a)
         if iters > 1:
             Tm = Tm + torch.diag(b[:iters - 1], 1) + torch.diag(b[:iters - 1], -1)
@@ -955,16 +971,15 @@ class ElboEngine:
         def solve_part():
             # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
             Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
-            Qe32 = self._get("Qe32", (Mp, Mp + 1), f32)
+            # fp32 copy with rows padded to a multiple of 4 floats, pad zeroed once: the LDS-DMA GEMM (gemm32.hip) streams the
+            # k-contiguous [Q' | a] in 16-byte chunks and takes K = M' + 1 as it lies in memory (DSVGP_GEMM_K_PADDED)
+            Qe32 = self._get_zeroed("Qe32_pad", (Mp, (Mp + 1 + 3) // 4 * 4), f32)[:, :Mp + 1]
             _ops.trsm(ctx, L, S32e, True, Qe64, Qe32, self.trsm_nb, ws, reuse_inverse=True)
-            # K_ZX-bar (fp32, dense)
+            # K_ZX-bar (fp32, dense): hand-written 32x32x2 MFMA kernel; the rocBLAS route stays as a diagnostics comparator
             if self.lib_dense_gemm:
-                # the one product of the step without structure or fused epilogue: the library's tuned dense kernel
                 _ops.gemm_lib_f32(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
             else:
-                QeT32 = self._get("QeT32", (Mp + 1, Mp), f32)  # the fp32 GEMM streams an mn-contiguous A operand ~5 % faster
-                _ops.transpose_f32(ctx, Qe32, QeT32)
-                _ops.gemm(ctx, TRANS_A, QeT32, A32e, Kb32, alpha=vbar2)
+                _ops.gemm(ctx, _lib.K_PADDED, Qe32, A32e, Kb32, alpha=vbar2)
             return Qe64
 
         if coll is None:

@@ -486,6 +486,9 @@ static hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipS
 #ifndef GEMM64
 #define GEMM64 1            // 1: fp64 products with two mn-contiguous operands and >= GEMM64_MIN_TILES 64 x 64 tiles go to gemm64.hip
 #endif
+#ifndef GEMM32
+#define GEMM32 1            // 1: plain fp32 products (no triangular operands / Cin / kscale) go to gemm32.hip (32x32x2 MFMA)
+#endif
 #ifndef GEMM64_MIN_TILES
 #define GEMM64_MIN_TILES 1024      // (below: 128 x 128 tiles + split-K of this file)
 #endif
@@ -499,6 +502,13 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
 #if GEMM64
     if (is_double && (g.C || g.C32) && (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) >= GEMM64_MIN_TILES && g.K >= GEMM64_MIN_K) {
         const int rc = launch_gemm64(st, g);
+        if (rc == 1) return 0;
+        if (rc > 1) return rc;
+    }
+#endif
+#if GEMM32
+    if (!is_double) {
+        const int rc = launch_gemm32(st, g);
         if (rc == 1) return 0;
         if (rc > 1) return rc;
     }

@@ -141,7 +141,9 @@ enum {
     DSVGP_GEMM_B_UPPER = 32,     /* op(B)[k,n] == 0 for n < k                                  */
     DSVGP_GEMM_OUT_LOWER = 64,   /* only m >= n is computed; m < n is written as 0             */
     DSVGP_GEMM_B_IS_FLOAT = 128, /* (double compute only) B is float                           */
-    DSVGP_GEMM_CIN_IS_FLOAT = 256/* (double compute only) Cin is float                         */
+    DSVGP_GEMM_CIN_IS_FLOAT = 256,/* (double compute only) Cin is float                        */
+    DSVGP_GEMM_K_PADDED = 512    /* (float compute) operands stored with K as their minor axis are zero-filled by the
+                                    caller from K up to the next multiple of 4 (lets the LDS-DMA kernel take K % 4 != 0) */
 };
 int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N, int K, double alpha,
                const void* A, int64_t lda, const void* B, int64_t ldb, double beta, const void* Cin,

@@ -493,3 +493,45 @@ def test_tril_pack_unpack_roundtrip(dsvgp, gpu_device, n, nextra, ld_pad):
     ops.tril_unpack_f32(ctx, pk, B, e2)
     assert torch.equal(B.tril(), A.tril()) and (B.triu(1) == torch.full_like(B, 5.0).triu(1)).all()
     assert torch.equal(e2, extra)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,lower,pad", [
+    (700, 1100, 1300, 0, 0, 0, 0),        # ragged in M, N and K; A k-contiguous, B n-contiguous (the dense K_ZX-bar layout)
+    (700, 1100, 1300, 1, 1, 0, 0),        # A m-contiguous, B k-contiguous
+    (640, 1000, 1301, 0, 0, 0, 1),        # K % 4 != 0 with caller-zeroed padding (DSVGP_GEMM_K_PADDED): LDS-DMA kernel
+    (640, 1000, 1301, 0, 0, 0, 0),        # ... and without the promise: register-staged kernel
+    (1001, 1000, 6000, 0, 1, 1, 0),       # [G ; b^T] = tril([A ; mu^T] A^T): both k-contiguous, split-K atomics, square tile grid
+    (1025, 1024, 2048, 0, 1, 1, 0),       # the extra row opens a tile row of its own (tiles_m = tiles_n + 1)
+    (900, 1000, 2048, 1, 0, 1, 0),        # lower output, fewer tile rows than columns
+])
+def test_gemm32_mfma_32x32x2_kernels(dsvgp, gpu_device, M, N, K, ta, tb, lower, pad):
+    """csrc/gemm32.hip (fp32 products >= 512^3 without triangular operands) against fp64 torch; 3e-5 of the max magnitude
+    (fp32 accumulation over K <= 6000, split-K partial sums met in atomics)."""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(M + N + K)
+    K4 = (K + 3) // 4 * 4
+    ka = K4 if (not ta) else K            # leading dimension of a k-contiguous operand: rows padded to a multiple of 4
+    A = torch.randn((K, M) if ta else (M, ka), generator=g)
+    B = torch.randn((N, K4) if tb else (K, N), generator=g)
+    if pad:
+        if not ta:
+            A[:, K:] = 0
+        if tb:
+            B[:, K:] = 0
+    Ad, Bd = A.to(gpu_device), B.to(gpu_device)
+    Av = Ad if ta else Ad[:, :K]
+    Bv = Bd[:, :K] if tb else Bd
+    C = torch.full((M, N), 5.0, device=gpu_device)
+    flags = (L.TRANS_A if ta else 0) | (L.TRANS_B if tb else 0) | (L.OUT_LOWER if lower else 0) | (L.K_PADDED if pad else 0)
+    ops.gemm(ctx, flags, Av, Bv, C, alpha=0.75)
+    opA = (A.t() if ta else A[:, :K]).double()
+    opB = (B[:, :K].t() if tb else B).double()
+    ref = 0.75 * opA @ opB
+    if lower:
+        ref = ref.tril()
+    err = relmax(C, ref)
+    print("gemm32 M=%d N=%d K=%d ta=%d tb=%d lower=%d pad=%d: rel. error %.2e" % (M, N, K, ta, tb, lower, pad, err))
+    assert err < 3e-5
+    if lower:
+        assert C.triu(1).abs().max().item() == 0.0
