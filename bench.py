@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--lib-gemm", action="store_true",
                     help="diagnostics: the dense K_ZX-bar product through rocBLAS sgemm instead of the hand-written kernel")
     ap.add_argument("--no-pack-reduce", action="store_true", help="diagnostics (N > 1): dense instead of packed-triangle all-reduce")
+    ap.add_argument("--graph", default="off", choices=["on", "off"],
+                    help="HIP-graph replay of the step (one rank, ELBO fast path); measured no faster than eager at C2, see DESIGN.md")
     ap.add_argument("--dp-algo", default=os.environ.get("DSVGP_DP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
                     help="(N > 1) collective of the large operand: RCCL all-reduce, or reduce-scatter + all-gather")
     args = ap.parse_args()
@@ -181,6 +183,7 @@ def main():
         loop = dsvgp_amd.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
                                         num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True,
                                         seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
+    loop.graph = args.graph == "on"
     eng = loop.model.engine
     if args.trsm_nb > 0:
         eng.trsm_nb = args.trsm_nb
@@ -221,10 +224,19 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         loss, _, _ = loop.step(batch(args.warmup + k))
+    loop.finish()                    # (graph replay: the status of the last replayed step is read here)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if loop._graphs:
+        # the timed steps were graph replays (no HIP events inside a graph): the per-kernel timings of the roofline entries
+        # come from three more, untimed, eager steps of the same loop
+        loop.graph = False
+        eng.events = []
+        for k in range(3):
+            loop.step(batch(args.warmup + args.steps + k))
+        torch.cuda.synchronize()
     eng.record_events = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -285,7 +297,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32 (f64 Cholesky/solves)", "data": "synthetic",
             "config": {"workload": cfg["name"], "global_batch": B, "per_gpu_batch": B // world, "M_prime": Mp,
                        "parallelism": "dp%d rows" % world, "trsm_nb": eng.trsm_nb, "final_loss": final_loss,
-                       "dense_product": "rocBLAS sgemm" if eng.lib_dense_gemm else "hand-written (gemm.hip)",
+                       "graph_replay": bool(loop._graphs),
+                       "dense_product": "rocBLAS sgemm" if eng.lib_dense_gemm else "hand-written (gemm32.hip, v_mfma_f32_32x32x2_f32)",
                        "timed_step": "TrainLoop.step(need_variance=False): ELBO fast path every step; the reference's "
                                      "every-50th-step nll print (per-output path, ~+9 ms once per 50 steps at C4) is "
                                      "outside the timed region"},

@@ -298,6 +298,48 @@ def kl_terms(ctx, m, LS, num_data, kl_buf, d_m, d_LS):
                              _ptr(d_m), _ptr(d_LS), _ld(d_LS)), "dsvgp_kl_terms")
 
 
+def kl_terms_scaled(ctx, m, LS, num_data, add_kl, hyp, global_rows, kl_buf, d_m, d_LS):
+    """d_LS(lower) <- d_LS / (noise rows) [+ KL gradient], d_m [+= m / num_data], kl_buf[0] = KL or 0 -- noise read on the device"""
+    Mp = m.shape[0]
+    check(lib.dsvgp_kl_terms_scaled(ctx.h, _ptr(m), _ptr(_req(LS, f32, "L_S", 2)), _ld(LS), Mp, float(num_data),
+                                    1 if add_kl else 0, _ptr(hyp), float(global_rows), _ptr(kl_buf), _ptr(d_m), _ptr(d_LS),
+                                    _ld(d_LS)), "dsvgp_kl_terms_scaled")
+
+
+def scale_by_vbar_(ctx, tensors, hyp, global_rows):
+    """x *= 1 / (noise * global_rows) for up to three contiguous float32 tensors, noise read on the device"""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if len(ts) > 3:
+        raise ValueError("at most three tensors")
+    for t in ts:
+        if t.dtype != f32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("scale_by_vbar: contiguous float32 GPU tensors only")
+    args = []
+    for k in range(3):
+        if k < len(ts):
+            args += [_ptr(ts[k]), ts[k].numel()]
+        else:
+            args += [C.c_void_p(0), 0]
+    check(lib.dsvgp_scale_by_vbar(ctx.h, *args, _ptr(hyp), float(global_rows)), "dsvgp_scale_by_vbar")
+
+
+def adam_step_multi_dev_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr_step_dev, beta1, beta2, eps, guard=None):
+    """``adam_step_multi_`` with (lr, step) read from the device float[2] ``lr_step_dev``; skipped while ``guard[0] != 0``"""
+    import ctypes
+    n = len(params)
+    if n > ADAM_MAX_TENSORS:
+        raise ValueError("at most %d tensors per launch" % ADAM_MAX_TENSORS)
+    for group in (params, grads, exp_avgs, exp_avg_sqs):
+        for t in group:
+            if t.dtype != f32 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("adam: tensors must be contiguous float32 GPU tensors")
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (ctypes.c_int64 * n)(*[t.numel() for t in params])
+    check(lib.dsvgp_adam_step_multi_dev(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes,
+                                        _ptr(_req(lr_step_dev, f32, "lr_step_dev", 1)), float(beta1), float(beta2), float(eps),
+                                        _ptr(guard)), "dsvgp_adam_step_multi_dev")
+
+
 def phi_symmetrize_(ctx, G):
     check(lib.dsvgp_phi_symmetrize(ctx.h, _ptr(G), G.shape[0], _ld(G)), "dsvgp_phi_symmetrize")
 

@@ -98,6 +98,10 @@ class ElboEngine:
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
         self.ciq_stats = {}                 # lmin / lmax / iterations of the last CIQ forward + backward
         self._eval_cache = None
+        # True while a step is being captured into / replayed from a HIP graph (directional_vi.TrainLoop): nothing may read
+        # device results on the host -- the potrf status is checked by the caller one step later, and the Adam kernels of the
+        # captured step are guarded by the status word instead
+        self.capture_mode = False
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
 
@@ -247,7 +251,7 @@ class ElboEngine:
         return Kzx
 
     def _event_pair(self):
-        if not self.record_events:
+        if not self.record_events or self.capture_mode:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -284,13 +288,9 @@ class ElboEngine:
         if not ((reuse_inverse and ws is old) or ws is self._inverse_ws):   # a re-allocated workspace has no inverse in it
             _ops.trtri_blocks(ctx, L, max(Bp, Mp), self.trsm_nb, ws, self._potrf_ws)
             self._inverse_ws = ws
-        if self.record_events:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        ev = self._event_pair()
         _ops.trsm(ctx, L, Kzx, False, A64, A32, self.trsm_nb, ws, reuse_inverse=True)
-        if self.record_events:
-            e1.record()
-            self.events.append(("solve_fwd", e0, e1))
+        self._event_done("solve_fwd", ev)
         LS = params["chol_variational_covar"]
         if self._no_middle:
             W = A32                         # zero middle term: colsum(W^2 - A^2) vanishes
@@ -790,7 +790,10 @@ class ElboEngine:
         if use_fast and overlap:
             def side_job(c, hyp_):
                 side.update(self._fast_prologue(c, params, hyp_, x, D, rows))
-        hyp, packZ, L, dims = self._factor(ctx, params, sync=sync or not use_fast, side_job=side_job, nrhs=Bp)
+        if self.capture_mode and not use_fast:
+            raise RuntimeError("only the ELBO fast path can be captured into a HIP graph")
+        hyp, packZ, L, dims = self._factor(ctx, params, sync=(sync or not use_fast) and not self.capture_mode,
+                                           side_job=side_job, nrhs=Bp)
         M, d, p, Mp = dims
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
@@ -806,6 +809,7 @@ class ElboEngine:
         coll = self.collective
         self._global_gram = bool(use_fast and self.global_gram and self._allow_early and coll is not None
                                  and coll.world > 1 and self.trsm_nb >= Mp and M >= coll.world)
+        self._dev_scale = False
         if use_fast:
             if not side:        # no overlap: the prologue runs in line
                 side.update(self._fast_prologue(ctx, params, hyp, x, D, rows))
@@ -860,6 +864,9 @@ class ElboEngine:
             Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp)
             _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
 
+        if self._dev_scale:
+            # the kernel gradients above came from the UNSCALED K_ZX-bar / K_ZZ-bar: apply 2 vbar = 1 / (noise rows) now
+            _ops.scale_by_vbar_(ctx, [dZ, dV if dV.numel() else None, d_hyp[0:2]], hyp, rows)
         # ---- scalars: d_hyp += data-term scalars, softplus chain rule, d constant, loss (one launch) ----
         _ops.step_epilogue(ctx, scal, kl_buf, rows, num_data, params["raw_lengthscale"].reshape(-1),
                            params["raw_outputscale"].reshape(-1), params["raw_noise"].reshape(-1), d_hyp,
@@ -917,13 +924,9 @@ class ElboEngine:
         if ws is not self._inverse_ws:                       # (re-allocated: the factorisation's inverse is not in it)
             _ops.trtri_blocks(ctx, L, max(Bp, Mp + 1), self.trsm_nb, ws, self._potrf_ws)
             self._inverse_ws = ws
-        if self.record_events:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        ev = self._event_pair()
         _ops.trsm(ctx, L, Kzx, False, A64, A32, self.trsm_nb, ws, reuse_inverse=True)       # A = L^-1 K_ZX (fp64)
-        if self.record_events:
-            e1.record()
-            self.events.append(("solve_fwd", e0, e1))
+        self._event_done("solve_fwd", ev)
         mu = torch.empty(Bp, dtype=f32, device=dev)
         var0 = torch.empty(Bp, dtype=f32, device=dev)
         sws = self._bytes("stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, Bp))
@@ -937,6 +940,9 @@ class ElboEngine:
         # tril([A ; mu_bar^T] A^T) = [tril(G) ; b^T], split-K over the minibatch axis: b = A mu_bar rides along as row M'
         _ops.gemm(ctx, TRANS_B | OUT_LOWER, A32e, A32, Ge)
         coll = self.collective if self._global_gram else None
+        # one rank: 2 vbar = 1 / (noise rows) multiplies the FINAL gradients on the device (the products below run unscaled),
+        # so the noise never has to visit the host -- a precondition for replaying the step from a HIP graph
+        dev_scale = self._dev_scale = self.collective is None or self.collective.world == 1
         handle = None
         if coll is not None:
             # data parallel, "global Gram" schedule: everything downstream of [G ; b^T] is linear in it, so the ranks sum
@@ -950,9 +956,13 @@ class ElboEngine:
                 handle = coll.all_reduce_async(Ge)
         else:
             _ops.mirror_lower_f32_(ctx, G, Mp)
-            self._finish_factor(ctx)                         # host sync, hidden behind the queued solve + Gram product
-        noise = self._hyp_host[2]
-        vbar2 = 1.0 / (noise * rows)                         # 2 * vbar
+            if not self.capture_mode:
+                self._finish_factor(ctx)                     # host sync, hidden behind the queued solve + Gram product
+        if dev_scale:
+            vbar2 = 1.0
+        else:
+            noise = self._hyp_host[2]
+            vbar2 = 1.0 / (noise * rows)                     # 2 * vbar
 
         def variational_part():
             _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
@@ -961,7 +971,9 @@ class ElboEngine:
                 sums[2:4].zero_()                            # the trace terms of the GLOBAL G are counted on one rank only
             _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
             dm.copy_(Ge[Mp])                                 # b = A mu_bar, the data part of m-bar (global under coll)
-            if include_kl or coll is not None:               # (global schedule: m-bar / L_S-bar are not reduced again, so
+            if dev_scale:                                    # tril(G L_S) -> 2 vbar tril(G L_S) [+ KL gradient] in one pass
+                _ops.kl_terms_scaled(ctx, m, LS, num_data, include_kl, hyp, rows, kl_buf, dm, dLS)
+            elif include_kl or coll is not None:             # (global schedule: m-bar / L_S-bar are not reduced again, so
                 _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)            # every rank adds the KL gradient itself)
                 if not include_kl:
                     kl_buf[0:1].zero_()                      # ... and one rank the KL value

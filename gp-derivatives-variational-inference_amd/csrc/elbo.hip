@@ -299,6 +299,75 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
     }
 }
 
+// Graph-capturable variants: every per-step scalar comes from device memory.
+//  adam_multi_dev_kernel: hp = {lr, step} (floats, written by a captured host-to-device copy), guard (may be null): the
+//    update is skipped while *guard != 0 (the Cholesky status word: a failed factorisation must not touch the parameters).
+//  scale3_kernel: x_k *= 1 / (noise rows) = 2 vbar for up to three arrays (Z-bar, V-bar, d_hyp[0..1] of the ELBO fast path,
+//    whose K_ZX-bar / L-bar products run unscaled when the noise is not known on the host).
+//  kl_scaled_kernel: like kl_kernel, with d_LS(lower) first multiplied by 2 vbar and the KL part optional.
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const AdamTable t, const float* __restrict__ hp, float b1, float b2,
+                                                             float eps, const int* __restrict__ guard) {
+    if (guard && *guard != 0) return;
+    const float lr = hp[0];
+    const double step = (double)hp[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, step)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first[k + 1]) ++k;
+    const int nb = t.first[k + 1] - t.first[k];
+    float* __restrict__ param = t.param[k];
+    const float* __restrict__ grad = t.grad[k];
+    float* __restrict__ m = t.m[k];
+    float* __restrict__ v = t.v[k];
+    const int64_t n = t.n[k];
+    for (int64_t i = (int64_t)(blockIdx.x - t.first[k]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        const float g = grad[i];
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+__global__ __launch_bounds__(256) void scale3_kernel(float* __restrict__ x0, int64_t n0, float* __restrict__ x1, int64_t n1,
+                                                     float* __restrict__ x2, int64_t n2, const float* __restrict__ hyp,
+                                                     float inv_rows) {
+    const float s = inv_rows / hyp[2];
+    const int64_t tot = n0 + n1 + n2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+        if (i < n0) x0[i] *= s;
+        else if (i < n0 + n1) x1[i - n0] *= s;
+        else x2[i - n0 - n1] *= s;
+    }
+}
+__global__ __launch_bounds__(256) void kl_scaled_kernel(const float* __restrict__ m, const float* __restrict__ LS, int64_t ldls,
+                                                        int Mp, float inv_nd, int add_kl, const float* __restrict__ hyp,
+                                                        float inv_rows, float* __restrict__ rowsum, float* __restrict__ d_m,
+                                                        float* __restrict__ dLS, int64_t lddls) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    const float sc = inv_rows / hyp[2];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < Mp; j += 256) {
+        if (j <= i) {
+            const float l = LS[(int64_t)i * ldls + j];
+            s = fmaf(l, l, s);
+            const float g = add_kl ? ((j == i) ? (l - 1.f / l) * inv_nd : l * inv_nd) : 0.f;
+            dLS[(int64_t)i * lddls + j] = fmaf(dLS[(int64_t)i * lddls + j], sc, g);
+        } else {
+            dLS[(int64_t)i * lddls + j] = 0.f;    // masked upper triangle carries no gradient
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lii = LS[(int64_t)i * ldls + i], mi = m[i];
+        rowsum[i] = add_kl ? 0.5f * (mi * mi + red[0] + red[1] + red[2] + red[3] - 1.f - logf(lii * lii)) : 0.f;
+        if (add_kl) d_m[i] += mi * inv_nd;
+    }
+}
+
 // ---- ELBO fast path (constant dLoss/dvar): residuals, traces, scalar assembly -----------------------
 __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ mu, const float* __restrict__ y,
                                                        int ncols, const float* __restrict__ hyp, float inv_rows,
@@ -646,6 +715,56 @@ extern "C" int dsvgp_tril_unpack_f32(dsvgp_ctx* ctx, const float* src, int n, fl
     if (!src) return DSVGP_EINVAL;
     const int xb = nextra > 0 ? (cdiv(nextra, 256 * 8) < 64 ? cdiv(nextra, 256 * 8) : 64) : 0;
     hipLaunchKernelGGL(tril_unpack_f32_kernel, dim3(n + xb), dim3(256), 0, ctx->stream, src, n, dst, ld, extra, nextra);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- graph-capturable entry points (per-step scalars in device memory) ---------------------------------
+extern "C" int dsvgp_adam_step_multi_dev(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
+                                         float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes,
+                                         const float* lr_step_dev, float beta1, float beta2, float eps, const int* guard_dev) {
+    if (!ctx || count < 0 || count > DSVGP_ADAM_MAX_TENSORS || !lr_step_dev) return DSVGP_EINVAL;
+    if (count && (!params || !grads || !exp_avgs || !exp_avg_sqs || !sizes)) return DSVGP_EINVAL;
+    AdamTable t{};
+    int nblocks = 0;
+    for (int k = 0; k < count; ++k) {
+        if (sizes[k] < 0 || (sizes[k] > 0 && (!params[k] || !grads[k] || !exp_avgs[k] || !exp_avg_sqs[k]))) return DSVGP_EINVAL;
+        if (sizes[k] == 0) continue;
+        const int c = t.count++;
+        t.param[c] = params[k]; t.grad[c] = grads[k]; t.m[c] = exp_avgs[k]; t.v[c] = exp_avg_sqs[k]; t.n[c] = sizes[k];
+        int b = cdiv(sizes[k], 256);
+        if (b > 2048) b = 2048;
+        t.first[c] = nblocks;
+        nblocks += b;
+    }
+    if (!t.count) return 0;
+    t.first[t.count] = nblocks;
+    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, t, lr_step_dev, beta1, beta2, eps,
+                       guard_dev);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_scale_by_vbar(dsvgp_ctx* ctx, float* x0, int64_t n0, float* x1, int64_t n1, float* x2, int64_t n2,
+                                   const float* hyp, double global_rows) {
+    if (!ctx || !hyp || n0 < 0 || n1 < 0 || n2 < 0 || global_rows <= 0) return DSVGP_EINVAL;
+    if ((n0 && !x0) || (n1 && !x1) || (n2 && !x2)) return DSVGP_EINVAL;
+    const int64_t tot = n0 + n1 + n2;
+    if (tot == 0) return 0;
+    int blocks = cdiv(tot, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale3_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x0, n0, x1, n1, x2, n2, hyp,
+                       (float)(1.0 / global_rows));
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dsvgp_kl_terms_scaled(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data,
+                                     int add_kl, const float* hyp, double global_rows, float* kl_out, float* d_m, float* d_LS,
+                                     int64_t lddls) {
+    if (!ctx || !m || !LS || !kl_out || !d_m || !d_LS || !hyp || Mp <= 0 || num_data <= 0 || global_rows <= 0) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(kl_scaled_kernel, dim3(Mp), dim3(256), 0, ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data),
+                       add_kl ? 1 : 0, hyp, (float)(1.0 / global_rows), kl_out + 1, d_m, d_LS, lddls);
+    DSVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), Mp, kl_out);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -544,7 +544,9 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     a.splitk = cdiv(g.K, a.kslice);
     if (a.splitk > 1 || out_lower) {
         // atomics accumulate onto zeros / the strict upper triangle is defined as zero
-        hipError_t e = hipMemset2DAsync(a.C, sizeof(float) * (size_t)a.ldc, 0, sizeof(float) * (size_t)a.N, (size_t)a.M, st);
+        // (contiguous rows: one linear fill -- the 2-D fill kernel of the runtime takes 104 us for 36 MB, the linear one ~10)
+        hipError_t e = (a.ldc == a.N) ? hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, st)
+                                      : hipMemset2DAsync(a.C, sizeof(float) * (size_t)a.ldc, 0, sizeof(float) * (size_t)a.N, (size_t)a.M, st);
         if (e != hipSuccess) return 1000 + (int)e;
     }
     const dim3 grid(cdiv((int64_t)a.ntiles * a.splitk, 8) * 8);

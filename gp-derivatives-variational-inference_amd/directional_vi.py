@@ -15,6 +15,7 @@ What is different underneath (MI355X-first):
 same engine; ``use_ciq=True`` additionally whitens with K_ZZ^{-1/2} by contour-integral quadrature + msMINRES
 (``CiqDirectionalGradVariationalStrategy``, ``csrc/ciq.hip``).
 """
+import os
 import random
 import sys
 
@@ -137,6 +138,8 @@ class TrainLoop:
         self.dim = X.shape[1]
         self.ctx = _ops.Context.get(self.device)
         self.E_canonical = torch.eye(self.dim, device=self.device)
+        self.graph = None                       # HIP-graph replay of the step: True = on (also DSVGP_GRAPH=1), None / False = eager
+        self._graphs, self._graph_seen, self._graph_pending = {}, {}, None
 
     def epoch_permutation(self):
         return torch.randperm(self.X.shape[0], device=self.device, generator=self.perm_gen)   # DataLoader(shuffle=True)
@@ -146,7 +149,7 @@ class TrainLoop:
         ``need_variance``: the caller will read ``output.variance`` of THIS forward (the reference's
         every-50-steps nll print, :255-260), so the per-output path is used instead of the ELBO fast path."""
         self.model.engine.elbo_fast = not need_variance
-        dim, p, dev, dp = self.dim, self.minibatch_dim, self.device, self.dp
+        dim, p, dp = self.dim, self.minibatch_dim, self.dp
         if dp is not None:
             dp.global_batch = idx.shape[0]
             dp.replicated_step = idx.shape[0] < dp.world      # tail smaller than the world: no empty shards (see parallel.py)
@@ -158,18 +161,40 @@ class TrainLoop:
             idx_y = [0]
         else:
             idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
+        if self._graph_eligible(need_variance):
+            return self._graph_step(idx, idx_y)
+        if self._graph_pending is not None:
+            self._graph_check_previous()
+        return self._eager_step(idx, idx_y)
+
+    def _eager_step(self, idx, idx_y):
+        dp = self.dp
         # host -> device without a stream sync: pinned staging ring + non_blocking copy (a pageable torch.tensor(...,
         # device=) blocks the host until the stream has drained, i.e. until the previous step has finished)
         slot = self._cols_slot = (getattr(self, "_cols_slot", -1) + 1) % 8
         if not hasattr(self, "_cols_pinned") or self._cols_pinned.shape[1] != len(idx_y):
             self._cols_pinned = torch.empty(8, len(idx_y), dtype=torch.int32).pin_memory()
         self._cols_pinned[slot].copy_(torch.tensor(idx_y, dtype=torch.int32))
-        cols = self._cols_pinned[slot].to(dev, non_blocking=True)
+        cols = self._cols_pinned[slot].to(self.device, non_blocking=True)
+        loss, output, y_batch = self._device_step(idx.contiguous(), cols, len(idx_y) - 1)
+        self.variational_optimizer.step()
+        self.variational_scheduler.step()
+        self.hyperparameter_optimizer.step()
+        self.hyperparameter_scheduler.step()
+        if dp is not None and self.model.engine.variational_grads_global:
+            self._dp_steps = getattr(self, "_dp_steps", 0) + 1
+            if self._dp_steps % dp.resync_every == 0:
+                dp.resync(self.model, (self.variational_optimizer, self.hyperparameter_optimizer))
+        return loss, output, y_batch
+
+    def _device_step(self, idx, cols, py):
+        """minibatch gather + fused ELBO forward / backward (gradients land in ``.grad``); everything here is stream work"""
+        dim, p, dev = self.dim, self.minibatch_dim, self.device
         nb = idx.shape[0]
-        py = len(idx_y) - 1                     # derivative columns of y per point
+        self.ctx.bind()                         # the library launches on torch's CURRENT stream (the capture stream under a graph)
         x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
         y_batch = torch.empty(nb * (py + 1), dtype=torch.float32, device=dev)
-        _ops.gather_batch(self.ctx, self.X, self.Y, idx.contiguous(), cols, py, x_batch, y_batch)  # interleaved y, :241
+        _ops.gather_batch(self.ctx, self.X, self.Y, idx, cols, py, x_batch, y_batch)  # interleaved y, :241
         kwargs = {}
         if self.dfree:                          # dfree_directional_vi.py:224-227
             kwargs["derivative_directions"] = self.E_canonical[:p].repeat(nb, 1)
@@ -185,15 +210,117 @@ class TrainLoop:
             loss.backward()
         else:
             loss = self.mll.backward_step(output, y_batch)      # same numbers, gradients assigned directly
-        self.variational_optimizer.step()
-        self.variational_scheduler.step()
-        self.hyperparameter_optimizer.step()
-        self.hyperparameter_scheduler.step()
-        if dp is not None and self.model.engine.variational_grads_global:
-            self._dp_steps = getattr(self, "_dp_steps", 0) + 1
-            if self._dp_steps % dp.resync_every == 0:
-                dp.resync(self.model, (self.variational_optimizer, self.hyperparameter_optimizer))
         return loss, output, y_batch
+
+    # ---- HIP-graph replay of the steady-state step (launch-bound regimes: M' of a few hundred, per-rank shards) ----------
+    # The whole device side of a step -- gather, assembly, Cholesky chain, solves, ELBO terms, backward, both Adam updates,
+    # ~110 launches at M' = 600 -- is captured once per batch shape and replayed with ONE launch.  What varies per step
+    # lives in device memory: the row indices and derivative columns (static buffers refreshed before the replay), the
+    # learning rates and step counts of the two optimizers (pinned table + captured copy), the noise (the 2 vbar factor is
+    # applied by the kernels, _step._elbo_fast).  The potrf status cannot be read inside a graph: the captured Adam kernels
+    # are guarded by the status word, and the host looks at the status of step t before it launches step t + 1; a failed
+    # factorisation (parameters untouched) is then redone eagerly through psd_safe_cholesky's jitter ladder.
+    def _graph_eligible(self, need_variance):
+        mode = self.graph
+        if mode is None:
+            env = os.environ.get("DSVGP_GRAPH")
+            mode = None if env is None else env == "1"
+        if mode is False or need_variance or self.dp is not None or self.autograd_protocol:
+            return False
+        eng = self.model.engine
+        ok = (eng.whitening == "cholesky" and not eng.shared_directions and self.mll.mll_type == "ELBO"
+              and isinstance(self.variational_optimizer, FusedAdam) and isinstance(self.hyperparameter_optimizer, FusedAdam)
+              and eng.collective is None)
+        if not ok:
+            return False
+        # opt-in only (``loop.graph = True`` / DSVGP_GRAPH=1 / ``bench.py --graph on``).  Measured on MI355X (round 2): the C2 step
+        # (M' = 600, ~110 launches) takes 0.80 ms eager and 0.82-0.84 ms replayed -- it is bound by its chain of DEPENDENT kernels
+        # (ten 25 us Cholesky launches, four 20-60 us fp64 products, ~35 kernels at the ~5 us floor), which a graph replays
+        # at the same kernel-boundary cost; the host was never the bottleneck on one GPU.
+        return mode is True
+
+    def _graph_step(self, idx, idx_y):
+        key = (idx.shape[0], len(idx_y))
+        gs = self._graphs.get(key)
+        if gs is None:
+            seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if seen <= 2 or len(self._graphs) >= 2:        # eager warm-up (allocations, optimizer state); ragged tails stay eager
+                self._graph_check_previous()
+                return self._eager_step(idx, idx_y)
+            self._graph_check_previous()
+            gs = self._graphs[key] = self._capture(idx, idx_y)
+        self._graph_check_previous()
+        gs.idx.copy_(idx)
+        gs.cols_host.copy_(torch.tensor(idx_y, dtype=torch.int32))
+        for opt in (self.variational_optimizer, self.hyperparameter_optimizer):
+            opt.fill_host_table()
+        gs.graph.replay()
+        gs.done.record()
+        self._graph_pending = (gs, idx, list(idx_y))
+        for opt, sch in ((self.variational_optimizer, self.variational_scheduler),
+                         (self.hyperparameter_optimizer, self.hyperparameter_scheduler)):
+            opt.advance_host_state()
+            sch.step()
+        return gs.loss, gs.output, gs.y_batch
+
+    def _capture(self, idx, idx_y):
+        import types
+        dev, eng = self.device, self.model.engine
+        gs = types.SimpleNamespace()
+        gs.idx = idx.clone().contiguous()
+        gs.cols_host = torch.tensor(idx_y, dtype=torch.int32).pin_memory()
+        for opt in (self.variational_optimizer, self.hyperparameter_optimizer):
+            opt.capture_tables(dev)
+            opt.fill_host_table()
+        torch.cuda.synchronize(dev)
+        gs.graph = torch.cuda.CUDAGraph()
+        guard = eng._buf["info"]                            # the potrf status word of the K_ZZ factorisation
+        eng.capture_mode = True
+        try:
+            with torch.cuda.graph(gs.graph):
+                cols = gs.cols_host.to(dev, non_blocking=True)
+                gs.loss, gs.output, gs.y_batch = self._device_step(gs.idx, cols, len(idx_y) - 1)
+                self.variational_optimizer.step_captured(guard)
+                self.hyperparameter_optimizer.step_captured(guard)
+        finally:
+            eng.capture_mode = False
+            self.ctx.bind()
+        gs.done = torch.cuda.Event()
+        gs.host_info = eng._host_info
+        return gs
+
+    def _graph_check_previous(self):
+        """status of the previously replayed step (its Adam kernels did nothing if the factorisation failed)"""
+        pend, self._graph_pending = self._graph_pending, None
+        if pend is None:
+            return
+        gs, idx, idx_y = pend
+        gs.done.synchronize()
+        if int(gs.host_info[0]) == 0:
+            return
+        # K_ZZ + 1e-3 I was not positive definite in fp64: the parameters are untouched; redo the step eagerly (jitter
+        # ladder of psd_safe_cholesky, NotPSDError after three tries) with the learning rates it was issued with
+        opts = (self.variational_optimizer, self.hyperparameter_optimizer)
+        lrs = [[g["lr"] for g in o.param_groups] for o in opts]
+        for o in opts:
+            for gi, g in enumerate(o.param_groups):
+                g["lr"] = float(o._hp_host[gi, 0])
+                for prm in g["params"]:
+                    if o.state.get(prm):
+                        o.state[prm]["step"] -= 1
+        try:
+            cols = torch.tensor(idx_y, dtype=torch.int32, device=self.device)
+            self._device_step(idx.contiguous(), cols, len(idx_y) - 1)
+            for o in opts:
+                o.step()
+        finally:
+            for o, ls in zip(opts, lrs):
+                for g, lr in zip(o.param_groups, ls):
+                    g["lr"] = lr
+
+    def finish(self):
+        """drain the replay pipeline (the status of the last replayed step is checked here)"""
+        self._graph_check_previous()
 
 
 def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_size=1, minibatch_dim=1,
@@ -344,6 +471,7 @@ def train_gp(train_dataset, num_inducing=128,
         if max_steps is not None and total_step >= max_steps:
             break
 
+    loop.finish()
     if verbose and loss is not None:
         print(f"Done! loss: {loss.item()}")
         print("\nDone Training!")

@@ -173,6 +173,7 @@ def train_gp(train_dataset, dim, num_inducing=128,
                 break
         if max_steps is not None and total_step >= max_steps:
             break
+    loop.finish()
     if verbose and loss is not None:
         print(f"Done! loss: {loss.item()}")
     print("\nDone Training!")

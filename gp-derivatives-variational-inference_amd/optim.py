@@ -28,6 +28,56 @@ class NGD(torch.optim.Optimizer):
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._hp_host = self._hp_dev = None
+
+    # ---- HIP-graph replay of the step (directional_vi.TrainLoop): the update is captured ONCE with (lr, step) read from
+    # device memory; per replay the host only refreshes a pinned [groups, 2] table that a captured copy brings over, and
+    # keeps ``state[p]["step"]`` in sync so that eager steps, schedulers and checkpoints continue seamlessly ----
+    def capture_tables(self, device):
+        n = len(self.param_groups)
+        if self._hp_host is None or self._hp_host.shape[0] != n:
+            self._hp_host = torch.zeros(n, 2, dtype=torch.float32).pin_memory()
+            self._hp_dev = torch.zeros(n, 2, dtype=torch.float32, device=device)
+        return self._hp_host, self._hp_dev
+
+    def fill_host_table(self):
+        """(lr, step number of the NEXT update) of every group into the pinned table"""
+        for gi, group in enumerate(self.param_groups):
+            steps = [self.state[p]["step"] for p in group["params"] if p in self.state and self.state[p]]
+            self._hp_host[gi, 0] = float(group["lr"])
+            self._hp_host[gi, 1] = float((steps[0] if steps else 0) + 1)
+
+    @torch.no_grad()
+    def step_captured(self, guard=None):
+        """the update of ``step`` as launches that read (lr, step) from ``_hp_dev`` (refreshed by the caller's captured
+        copy of ``_hp_host``); skipped on the device while ``guard[0] != 0``.  State must exist (one eager step before)."""
+        self._hp_dev.copy_(self._hp_host, non_blocking=True)
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            items = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    raise RuntimeError("FusedAdam.step_captured needs initialised state (run one eager step first)")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                items.append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+            if not items:
+                continue
+            ctx = _ops.Context.get(items[0][0].device)
+            for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
+                ps, gs, ms, vs = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
+                _ops.adam_step_multi_dev_(ctx, ps, gs, ms, vs, self._hp_dev[gi], b1, b2, group["eps"], guard)
+
+    def advance_host_state(self):
+        """what ``step`` does to the Python-side state, after a replayed update"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] += 1
+        self._opt_called = True          # (the LR schedulers check that the optimizer stepped before them)
 
     @torch.no_grad()
     def step(self, closure=None):

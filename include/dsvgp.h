@@ -229,6 +229,21 @@ int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const
                           float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
                           float beta1, float beta2, float eps, int step);
 
+/* ---- graph-capturable variants (HIP-graph replay of the steady-state step: every per-step scalar lives in device memory)
+ * dsvgp_adam_step_multi_dev: dsvgp_adam_step_multi with {lr, step} read from the device float[2] lr_step_dev (the host
+ *   refreshes it through a captured copy; directional_vi.py:251-254 steps the LR schedulers every iteration) and an optional
+ *   guard: while *guard_dev != 0 (the potrf status word) nothing is updated.
+ * dsvgp_scale_by_vbar: x_k *= 1 / (noise * global_rows) (= 2 dLoss/dvar of the ELBO) for up to three arrays.
+ * dsvgp_kl_terms_scaled: dsvgp_kl_terms with d_LS(lower) first multiplied by 1 / (noise * global_rows); add_kl = 0 leaves the
+ *   KL value and gradients out (kl_out[0] = 0).                                                                          */
+int dsvgp_adam_step_multi_dev(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
+                              float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes,
+                              const float* lr_step_dev, float beta1, float beta2, float eps, const int* guard_dev);
+int dsvgp_scale_by_vbar(dsvgp_ctx* ctx, float* x0, int64_t n0, float* x1, int64_t n1, float* x2, int64_t n2,
+                        const float* hyp, double global_rows);
+int dsvgp_kl_terms_scaled(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int add_kl,
+                          const float* hyp, double global_rows, float* kl_out, float* d_m, float* d_LS, int64_t lddls);
+
 /* Plain dense fp32 GEMM through rocBLAS (row-major, flags: DSVGP_GEMM_TRANS_A / _TRANS_B only): for products without
  * structure or fused epilogue (the dense K_ZX-bar product of the ELBO fast path); everything else is dsvgp_gemm.      */
 int dsvgp_gemm_lib_f32(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alpha, const float* A, int64_t lda,

@@ -661,3 +661,66 @@ def test_c3_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, ml
         for k, v in errs.items():
             if k.startswith("g_"):
                 assert v < 5e-3, (k, v)
+
+
+def _graph_loop(dsvgp, gpu_device, graph, lr_sched=None, seed=7, M=24):
+    torch.manual_seed(11)                                    # the 1e-3 randn initialisation of the variational mean
+    g = torch.Generator().manual_seed(5)
+    X = torch.rand(900, 4, generator=g).to(gpu_device)
+    Y = O.testfun(X.cpu()).to(gpu_device)
+    loop = dsvgp.setup_training(None, num_inducing=M, num_directions=2, minibatch_size=128, minibatch_dim=2, num_epochs=3,
+                                learning_rate_hypers=0.01, lr_sched=lr_sched, seed=seed, tensors=(X, Y))
+    loop.graph = graph
+    return loop
+
+
+@pytest.mark.parametrize("lr_sched", [None, "step_lr"])
+def test_graph_replay_matches_eager_steps(dsvgp, gpu_device, lr_sched):
+    """HIP-graph replay of the step (gather -> ELBO forward / backward -> both Adam updates captured once, replayed with
+    per-step indices, derivative columns, learning rates and step counts read from device memory) against the eager
+    loop: same losses (to the run-to-run spread of the split-K atomics), same parameters, same optimizer state, and the
+    per-iteration LR schedule honoured (``step_lr`` puts both milestones inside the 21 steps)."""
+    out = {}
+    for graph in (False, True):
+        loop = _graph_loop(dsvgp, gpu_device, graph, lr_sched)
+        losses = []
+        for epoch in range(3):
+            perm = loop.epoch_permutation()
+            for k in range(7):                                # 7 full batches of 128 (the ragged tail is left out)
+                loss, _, _ = loop.step(perm[k * 128:(k + 1) * 128])
+                losses.append(loss.item())                    # (reads the static loss tensor after the replay)
+        loop.finish()
+        assert bool(loop._graphs) == graph
+        P = {k: v.detach().clone() for k, v in loop.model._param_dict(loop.likelihood).items()}
+        steps = [loop.variational_optimizer.state[p]["step"] for p in loop.variational_optimizer.param_groups[0]["params"]]
+        out[graph] = (losses, P, steps, [g["lr"] for g in loop.hyperparameter_optimizer.param_groups])
+    (le, Pe, se, lre), (lg, Pg, sg, lrg) = out[False], out[True]
+    assert se == sg == [21, 21] and lre == lrg
+    for a, b in zip(le, lg):
+        assert abs(a - b) < 2e-5 * abs(a), (a, b)
+    for k in Pe:
+        # (Adam moves a parameter by ~lr per step whatever the gradient's size: last-bit differences of the split-K atomics in a
+        #  near-zero gradient component show up as ~1e-4..1e-3 after 21 steps of lr = 0.01, in eager-vs-eager runs too)
+        assert (Pe[k] - Pg[k]).abs().max().item() < 2e-3 * max(Pe[k].abs().max().item(), 1e-2), k
+
+
+def test_graph_replay_failed_factorisation_leaves_parameters_untouched(dsvgp, gpu_device):
+    """A replayed step whose K_ZZ is not positive definite: the captured Adam kernels are guarded by the potrf status word, so
+    nothing is updated; the host sees the status before the next launch, redoes the step eagerly through the jitter ladder and
+    raises NotPSDError like the reference's psd_safe_cholesky."""
+    loop = _graph_loop(dsvgp, gpu_device, True)
+    perm = loop.epoch_permutation()
+    for k in range(5):
+        loop.step(perm[k * 128:(k + 1) * 128])
+    loop.finish()
+    assert loop._graphs
+    before = {k: v.detach().clone() for k, v in loop.model._param_dict(loop.likelihood).items()}
+    with torch.no_grad():
+        loop.model.covar_module.raw_outputscale.fill_(float("nan"))
+    loop.step(perm[5 * 128:6 * 128])                          # replayed: every gradient is NaN, the guard holds the update back
+    with pytest.raises(dsvgp.NotPSDError):
+        loop.finish()
+    after = loop.model._param_dict(loop.likelihood)
+    for k in before:
+        if k != "raw_outputscale":
+            assert torch.equal(before[k], after[k]), k
