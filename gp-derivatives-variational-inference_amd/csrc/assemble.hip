@@ -219,12 +219,27 @@ __global__ __launch_bounds__(256) void kernel_fwd_kernel(const float* __restrict
 // pair(s) into the kernel micro-block with one exp and writes it straight to HBM in the interleaved layout.
 // ~15 KB of LDS per wave: 8 waves per CU overlap each other's staging, MFMA and store phases.
 constexpr int FWD_PAIR_LDT = 52;
+#ifndef FWDP_ABL
+#define FWDP_ABL 0        // tools only (results wrong): 1 = no global stores, 2 = no T' MFMA product, 4 = no P2 staging loads
+#endif
+#ifndef FWDP_ST16
+#define FWDP_ST16 1       // q = 6, float output: 16-byte stores shared by lane pairs (two store instructions per row instead of three)
+#endif
+#ifndef FWDP_AREG
+#define FWDP_AREG 1       // A fragments of the wave's 48 rows in registers for the whole column sweep (LDS: 10 KB per wave, 16 waves per CU)
+#endif
+#ifndef FWDP_OVERLAY
+#define FWDP_OVERLAY 1    // T' overlays the P2 image (10 instead of 8 waves per CU) and the next tile's P2 rows are prefetched
+#endif
 #ifndef FWD_PAIR_WGS_
 #define FWD_PAIR_WGS_ (256 * 16)      // probed 4 / 6 / 8 / 12 / 16 / 32 per CU: 207 / 170 / 137 / 133 / 121 / 135 us for K_ZX at C4
 #endif
 
+#ifndef FWDP_MINW
+#define FWDP_MINW 1
+#endif
 template <typename OutT, int Q>
-__global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
+__global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
                                                              int n1q, const float* __restrict__ P2,
                                                              const float* __restrict__ self2, int n2q, int K4, int DP,
                                                              int ovec, const float* __restrict__ hyp, float jitter,
@@ -234,9 +249,9 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
     constexpr int LDT2 = FWD_PAIR_LDT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LDP = K4 + 5;
-    float* P1s = smem;                  // [48][LDP]
-    float* P2s = P1s + 48 * LDP;        // [48][LDP]
-    float* TT = P2s + 48 * LDP;         // [48][LDT2]
+    float* P1s = smem;                  // [48][LDP]   (FWDP_AREG: not used, the A fragments of the wave's 48 rows stay in registers)
+    float* P2s = FWDP_AREG ? smem : P1s + 48 * LDP;        // [48][LDP]
+    float* TT = FWDP_OVERLAY ? P2s : P2s + 48 * LDP;         // [48][LDT2] (overlay: T' is written once every P2 fragment is in registers)
     const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
     const int row0 = blockIdx.y * T;
     const int ncoltiles = (n2q + T - 1) / T;
@@ -245,6 +260,24 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
     const float ell = hyp[0], s = hyp[1];
     const float il = 1.f / ell, il2 = il * il;
 
+    float areg[3][8];                   // A fragments: areg[i][ks] = P1'[row0 + 16 i + m16][4 ks + kg]  (KS <= 8 since DP <= 32)
+    if (FWDP_AREG) {
+        for (int e = lane; e < 48 * LDP; e += 64) P2s[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int gr = row0 + i * 16 + m16;
+            const bool ok = gr < n1q;
+            const int a = (i * 16 + m16) % Q;
+            const float sf = ok ? self1[gr] : 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float v = 0.f;
+                if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
+                else if (ks == K4 / 4 && ok) v = (kg == 1) ? (a == 0 ? 1.f : 0.f) : ((kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f);
+                areg[i][ks] = v;
+            }
+        }
+    } else {
     for (int e = lane; e < 48 * LDP; e += 64) { P1s[e] = 0.f; P2s[e] = 0.f; }
     __syncthreads();
     for (int e = lane; e < T * K4; e += 64) {
@@ -255,6 +288,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
         const int a = lane % Q;
         P1s[lane * LDP + K4 + 1] = a == 0 ? 1.f : 0.f;
         P1s[lane * LDP + K4 + 2] = a == 0 ? 0.f : -self1[row0 + lane];
+    }
     }
     int pr0[PPL], pc0[PPL];
     float s1r0[PPL];
@@ -268,12 +302,45 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
         s1r0[pp] = prow[pp] ? self1[row0 + pr0[pp]] : 0.f;
     }
 
+    constexpr int NPFP = (48 * 8 + 63) / 64;       // float4 per lane of one prefetched P2 tile (DP <= 32)
+    f4 pf[NPFP];
+    float pselfv = 0.f;
+    auto prefetch = [&](int ct_) {
+        const int c0_ = ct_ * T;
+#pragma unroll
+        for (int u = 0; u < NPFP; ++u) {
+            const int e = lane + 64 * u;
+            const int r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (e < T * pch && c0_ + r < n2q) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(c0_ + r) * DP + k);
+        }
+        pselfv = (lane < T && c0_ + lane < n2q) ? -self2[c0_ + lane] : 0.f;
+    };
+    if (FWDP_OVERLAY && (int)blockIdx.x < ncoltiles) prefetch(blockIdx.x);
     for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
         const int col0 = ct * T;
         float s2c0[PPL];
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) s2c0[pp] = (prow[pp] && col0 + pc0[pp] < n2q) ? self2[col0 + pc0[pp]] : 0.f;
         __syncthreads();   // single wave: orders the previous tile's LDS reads before the new stores
+        if (FWDP_OVERLAY) {
+#pragma unroll
+            for (int u = 0; u < NPFP; ++u) {
+                const int e = lane + 64 * u;
+                if (e < T * pch) {
+                    const int r = e / pch, k = (e - r * pch) * 4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
+                }
+            }
+            __syncthreads();
+            if (lane < T) {
+                P2s[lane * LDP + K4 + 1] = pselfv;
+                P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
+            }
+            if (ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);      // in flight under the rest of this tile
+        } else {
+        if (!(FWDP_ABL & 4))
         for (int e = lane; e < T * pch; e += 64) {
             const int r = e / pch, k = (e - r * pch) * 4;
             const int gr = col0 + r;
@@ -289,6 +356,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
             P2s[lane * LDP + K4 + 1] = ok ? -self2[gr] : 0.f;
             P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
         }
+        }
         __syncthreads();
         {
             f4 t[3][3];
@@ -298,7 +366,21 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
                 for (int j = 0; j < 3; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
             const float* pa = P1s + m16 * LDP + kg;
             const float* pb = P2s + m16 * LDP + kg;
-            for (int ks = 0; ks < KS; ++ks) {
+            if (FWDP_AREG) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks < KS) {
+                        float bv[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) bv[j] = pb[j * 16 * LDP + ks * 4];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], t[i][j], 0, 0, 0);
+                    }
+                }
+            } else
+            for (int ks = 0; ks < ((FWDP_ABL & 2) ? 1 : KS); ++ks) {
                 float av[3], bv[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { av[i] = pa[i * 16 * LDP + ks * 4]; bv[i] = pb[i * 16 * LDP + ks * 4]; }
@@ -307,6 +389,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
 #pragma unroll
                     for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
             }
+            if (FWDP_OVERLAY) __syncthreads();          // every P2 fragment has been read: T' may overlay the image
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -317,52 +400,256 @@ __global__ __launch_bounds__(64) void kernel_fwd_pair_kernel(const float* __rest
         __syncthreads();
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) {
-            if (prow[pp] && col0 + pc0[pp] < n2q) {
-                const float* blk = TT + pr0[pp] * LDT2 + pc0[pp];
-                float tq[Q][Q];
+            const bool mine = prow[pp] && col0 + pc0[pp] < n2q;
+            // (computed by every lane, stored by the valid ones: the 16-byte store path below exchanges values between
+            //  neighbouring lanes, which must not sit inside divergent control flow)
+            const float* blk = TT + pr0[pp] * LDT2 + pc0[pp];
+            float tq[Q][Q];
 #pragma unroll
-                for (int a = 0; a < Q; ++a) {
-                    if constexpr (Q % 2 == 0) {
-                        using F2 = float __attribute__((ext_vector_type(2)));
+            for (int a = 0; a < Q; ++a) {
+                if constexpr (Q % 2 == 0) {
+                    using F2 = float __attribute__((ext_vector_type(2)));
 #pragma unroll
-                        for (int b = 0; b < Q; b += 2) {
-                            const F2 v = *reinterpret_cast<const F2*>(blk + a * LDT2 + b);
-                            tq[a][b] = v[0]; tq[a][b + 1] = v[1];
-                        }
-                    } else {
+                    for (int b = 0; b < Q; b += 2) {
+                        const F2 v = *reinterpret_cast<const F2*>(blk + a * LDT2 + b);
+                        tq[a][b] = v[0]; tq[a][b + 1] = v[1];
+                    }
+                } else {
 #pragma unroll
-                        for (int b = 0; b < Q; ++b) tq[a][b] = blk[a * LDT2 + b];
+                    for (int b = 0; b < Q; ++b) tq[a][b] = blk[a * LDT2 + b];
+                }
+            }
+            const float nn = fmaxf(s1r0[pp] - s2c0[pp] - 2.f * tq[0][0], 0.f);     // covar_dist clamps at 0
+            const float k = s * expf(-0.5f * nn);                                  // postprocess_rbf, ScaleKernel
+            const float kil = k * il, kil2 = k * il2;
+            const int64_t gr0 = (int64_t)row0 + pr0[pp], gc0 = (int64_t)col0 + pc0[pp];
+            OutT* o = out + gr0 * ld + gc0;
+            // Q = 6, float: lanes 2j / 2j + 1 hold horizontally adjacent micro-blocks = 12 consecutive floats per row, 48-byte
+            // aligned.  The even lane stores floats 0..3 and 4..7 (its last two + the neighbour's first two, fetched with a
+            // DPP quad permute), the odd lane floats 8..11: two 16-byte store instructions per row instead of three 8-byte ones
+            // (the kernel is store-issue bound)
+            bool both = false;
+            if constexpr (Q == 6 && sizeof(OutT) == 4) {
+                const int nb = __builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+                both = mine && nb && (ovec & 2);
+            }
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                float v[Q];
+                if (a == 0) {
+                    v[0] = k;
+#pragma unroll
+                    for (int b = 1; b < Q; ++b) v[b] = tq[0][b] * kil;                          // w_b k / ell
+                } else {
+                    v[0] = tq[a][0] * kil;                                                      // -u_a k / ell
+#pragma unroll
+                    for (int b = 1; b < Q; ++b) v[b] = (tq[a][b] + tq[a][0] * tq[0][b]) * kil2;  // (G_ab - u_a w_b) k / ell^2
+                }
+                if (jitter != 0.f && gr0 == gc0) v[a] += jitter;      // diagonal micro-block: global row == global column
+                if ((FWDP_ABL & 1) && v[0] != 123.456f) continue;
+                if constexpr (Q == 6 && sizeof(OutT) == 4) {
+                    const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0]), 0xB1, 0xF, 0xF, false));
+                    const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[1]), 0xB1, 0xF, 0xF, false));
+                    if (both) {
+                        const bool odd = lane & 1;
+                        const f4 x = odd ? f4{v[2], v[3], v[4], v[5]} : f4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f4*>((float*)o + a * ld + (odd ? 2 : 0)) = x;
+                        if (!odd) *reinterpret_cast<f4*>((float*)o + a * ld + 4) = f4{v[4], v[5], n0, n1};
+                        continue;
                     }
                 }
-                const float nn = fmaxf(s1r0[pp] - s2c0[pp] - 2.f * tq[0][0], 0.f);     // covar_dist clamps at 0
-                const float k = s * expf(-0.5f * nn);                                  // postprocess_rbf, ScaleKernel
+                if (!mine) continue;
+                if constexpr (Q % 2 == 0) {
+                    if (ovec & 1) {
+                        using O2 = OutT __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) *reinterpret_cast<O2*>(o + a * ld + b) = O2{(OutT)v[b], (OutT)v[b + 1]};
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < Q; ++b) o[a * ld + b] = (OutT)v[b];
+            }
+        }
+    }
+}
+
+// ---- forward, "run" variant: 16-byte stores ------------------------------------------------------------------------
+// The pair kernel above is store-ISSUE bound (ablation, K_ZX at C4: 121 us, 89 without the stores, 87 without the MFMA
+// product, 94 without the P2 loads, 49 without stores and MFMA): every lane writes its 6 x 6 micro-block as 18 8-byte pieces.
+// Here a lane owns a RUN of 12 consecutive output columns (two micro-blocks at q = 6, four at q = 3) of its Q rows: 48 bytes
+// per row, 16-byte aligned, three dwordx4 stores -- half the store instructions per byte.  The tile is 48 rows x TC columns
+// (TC = 96 at q = 6, 48 at q = 3: 64 lanes = 48/Q point rows x TC/12 runs), the packed rows of the NEXT column tile travel
+// through registers while the current one is transformed (the global-load latency no longer sits on the per-tile chain), and
+// the T' tile overlays the P2 image it was computed from (the wave is alone in its workgroup: barriers order the phases).
+#ifndef FWD_RUN_WGS_
+#define FWD_RUN_WGS_ (256 * 12)
+#endif
+#ifndef FWD_RUN
+#define FWD_RUN 0           // measured slower than the pair kernel (128-135 vs 87-123 us for K_ZX at C4): kept for the record, not dispatched
+#endif
+template <typename OutT, int Q>
+__global__ __launch_bounds__(64) void kernel_fwd_run_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
+                                                            int n1q, const float* __restrict__ P2,
+                                                            const float* __restrict__ self2, int n2q, int K4, int DP,
+                                                            const float* __restrict__ hyp, float jitter,
+                                                            OutT* __restrict__ out, int64_t ld) {
+    constexpr int R = 48 / Q, NRUN = 64 / R, PPR = 12 / Q, TC = NRUN * 12, NCT = TC / 16;
+    constexpr int LDTT = TC + 4;                        // T' row stride (floats): rows 16-byte aligned
+    constexpr int NPF = (TC * 32 / 4 + 63) / 64;        // float4 per lane that hold a prefetched P2 tile (DP <= 32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP = K4 + 5;
+    float* P1s = smem;                                  // [48][LDP]
+    float* P2s = P1s + 48 * LDP;                        // [TC][LDP], later overlaid by TT [48][LDTT]
+    float* TT = P2s;
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * 48;
+    const int ncoltiles = (n2q + TC - 1) / TC;
+    const int KS = K4 / 4 + 1;
+    const int pch = DP / 4;                             // float4 chunks per packed row
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+
+    for (int e = lane; e < 48 * LDP; e += 64) P1s[e] = 0.f;
+    __syncthreads();
+    for (int e = lane; e < 48 * K4; e += 64) {
+        const int r = e / K4, k = e - r * K4;
+        if (row0 + r < n1q) P1s[r * LDP + k] = P1[(int64_t)(row0 + r) * DP + k];
+    }
+    if (lane < 48 && row0 + lane < n1q) {
+        const int a = lane % Q;
+        P1s[lane * LDP + K4 + 1] = a == 0 ? 1.f : 0.f;
+        P1s[lane * LDP + K4 + 2] = a == 0 ? 0.f : -self1[row0 + lane];
+    }
+    // this lane's run: point row pi (rows pr0 .. pr0 + Q - 1), columns pc0 .. pc0 + 11 of the tile
+    const int pi = lane / NRUN, run = lane - pi * NRUN;
+    const int pr0 = pi * Q, pc0 = run * 12;
+    const bool rowok = row0 + pr0 < n1q;
+    const float s1r0 = rowok ? self1[row0 + pr0] : 0.f;
+    const int nchunk = TC * pch;                        // float4 chunks of one P2 tile
+
+    f4 pf[NPF];
+    float pself = 0.f;                                  // -self2 of tile row `lane` (+ lane + 64 at TC = 96)
+    float pself2 = 0.f;
+    auto prefetch = [&](int ct) {
+        const int col0 = ct * TC;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = lane + 64 * u;
+            const int r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (e < nchunk && col0 + r < n2q) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(col0 + r) * DP + k);
+        }
+        pself = (lane < TC && col0 + lane < n2q) ? -self2[col0 + lane] : 0.f;
+        if (TC > 64) pself2 = (lane + 64 < TC && col0 + lane + 64 < n2q) ? -self2[col0 + lane + 64] : 0.f;
+    };
+    int ct = blockIdx.x;
+    if (ct < ncoltiles) prefetch(ct);
+    for (; ct < ncoltiles; ct += gridDim.x) {
+        const int col0 = ct * TC;
+        __syncthreads();                                // the previous tile's T' reads are done: the overlay may be rewritten
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = lane + 64 * u;
+            if (e < nchunk) {
+                const int r = e / pch, k = (e - r * pch) * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
+            }
+        }
+        __syncthreads();
+        if (lane < TC) {
+            P2s[lane * LDP + K4 + 1] = pself;
+            P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
+        }
+        if (TC > 64 && lane + 64 < TC) {
+            P2s[(lane + 64) * LDP + K4 + 1] = pself2;
+            P2s[(lane + 64) * LDP + K4 + 2] = (col0 + lane + 64 < n2q && (lane + 64) % Q == 0) ? 1.f : 0.f;
+        }
+        float s2v[PPR];
+#pragma unroll
+        for (int pp = 0; pp < PPR; ++pp) s2v[pp] = (col0 + pc0 + pp * Q < n2q) ? self2[col0 + pc0 + pp * Q] : 0.f;
+        if (ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);       // in flight under everything below
+        __syncthreads();
+        f4 t[3][NCT];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* pa = P1s + m16 * LDP + kg;
+            const float* pb = P2s + m16 * LDP + kg;
+            for (int ks = 0; ks < KS; ++ks) {
+                float av[3], bv[NCT];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) av[i] = pa[i * 16 * LDP + ks * 4];
+#pragma unroll
+                for (int j = 0; j < NCT; ++j) bv[j] = pb[j * 16 * LDP + ks * 4];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < NCT; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                // every P2 fragment has been read: T' may overlay the image
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < NCT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDTT + j * 16 + m16] = t[i][j][r];
+        __syncthreads();
+        if (rowok && col0 + pc0 < n2q) {
+            float tq[Q][12];
+#pragma unroll
+            for (int a = 0; a < Q; ++a)
+#pragma unroll
+                for (int c4 = 0; c4 < 3; ++c4) {
+                    const f4 v = *reinterpret_cast<const f4*>(TT + (pr0 + a) * LDTT + pc0 + 4 * c4);
+                    tq[a][4 * c4] = v[0]; tq[a][4 * c4 + 1] = v[1]; tq[a][4 * c4 + 2] = v[2]; tq[a][4 * c4 + 3] = v[3];
+                }
+            float val[Q][12];
+#pragma unroll
+            for (int pp = 0; pp < PPR; ++pp) {
+                const int o = pp * Q;
+                const float nn = fmaxf(s1r0 - s2v[pp] - 2.f * tq[0][o], 0.f);       // covar_dist clamps at 0
+                const float k = s * expf(-0.5f * nn);                                // postprocess_rbf, ScaleKernel
                 const float kil = k * il, kil2 = k * il2;
-                const int64_t gr0 = (int64_t)row0 + pr0[pp], gc0 = (int64_t)col0 + pc0[pp];
-                OutT* o = out + gr0 * ld + gc0;
+                const bool diag = jitter != 0.f && (int64_t)row0 + pr0 == (int64_t)col0 + pc0 + o;
 #pragma unroll
                 for (int a = 0; a < Q; ++a) {
-                    float v[Q];
                     if (a == 0) {
-                        v[0] = k;
+                        val[0][o] = k;
 #pragma unroll
-                        for (int b = 1; b < Q; ++b) v[b] = tq[0][b] * kil;                          // w_b k / ell
+                        for (int b = 1; b < Q; ++b) val[0][o + b] = tq[0][o + b] * kil;                              // w_b k / ell
                     } else {
-                        v[0] = tq[a][0] * kil;                                                      // -u_a k / ell
+                        val[a][o] = tq[a][o] * kil;                                                                  // -u_a k / ell
 #pragma unroll
-                        for (int b = 1; b < Q; ++b) v[b] = (tq[a][b] + tq[a][0] * tq[0][b]) * kil2;  // (G_ab - u_a w_b) k / ell^2
+                        for (int b = 1; b < Q; ++b) val[a][o + b] = (tq[a][o + b] + tq[a][o] * tq[0][o + b]) * kil2;  // (G_ab - u_a w_b) k / ell^2
                     }
-                    if (jitter != 0.f && gr0 == gc0) v[a] += jitter;      // diagonal micro-block: global row == global column
-                    if constexpr (Q % 2 == 0) {
-                        if (ovec) {
-                            using O2 = OutT __attribute__((ext_vector_type(2)));
-#pragma unroll
-                            for (int b = 0; b < Q; b += 2) *reinterpret_cast<O2*>(o + a * ld + b) = O2{(OutT)v[b], (OutT)v[b + 1]};
-                            continue;
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < Q; ++b) o[a * ld + b] = (OutT)v[b];
+                    if (diag) val[a][o + a] += jitter;
                 }
+            }
+            OutT* op = out + ((int64_t)row0 + pr0) * ld + col0 + pc0;
+            const int vc = min(12, n2q - (col0 + pc0));                  // valid columns of the run (a multiple of Q)
+            if (vc == 12) {
+                using O4 = OutT __attribute__((ext_vector_type(16 / sizeof(OutT))));
+                constexpr int EPV = 16 / sizeof(OutT);
+#pragma unroll
+                for (int a = 0; a < Q; ++a)
+#pragma unroll
+                    for (int c = 0; c < 12; c += EPV) {
+                        O4 v;
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) v[e] = (OutT)val[a][c + e];
+                        *reinterpret_cast<O4*>(op + a * ld + c) = v;
+                    }
+            } else {
+#pragma unroll
+                for (int a = 0; a < Q; ++a)
+#pragma unroll
+                    for (int c = 0; c < 12; ++c)
+                        if (c < vc) op[a * ld + c] = (OutT)val[a][c];
             }
         }
     }
@@ -1095,15 +1382,42 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
     if (n1 == 0 || n2 == 0) return 0;
     const int n1q = n1 * g.q, n2q = n2 * g.q;
     if (ld < n2q) return DSVGP_EINVAL;
+    if (FWD_RUN && (g.q == 6 || g.q == 3) && g.NP <= 32 && n1q % g.q == 0) {
+        // "run" kernel (16-byte stores): needs 16-byte aligned rows of the output
+        const int esz = out_is_double ? 8 : 4;
+        const bool aligned = (ld * esz) % 16 == 0 && (uintptr_t)out % 16 == 0;
+        if (aligned) {
+            const int TC = g.q == 6 ? 96 : 48;
+            const int rt = cdiv(n1q, 48), ctiles = cdiv(n2q, TC);
+            int ns = FWD_RUN_WGS_ / rt;
+            if (ns < 1) ns = 1;
+            if (ns > ctiles) ns = ctiles;
+            const size_t p2w = (size_t)TC * (g.K4 + 5), ttw = (size_t)48 * (TC + 4);
+            const size_t lds = sizeof(float) * (48 * (size_t)(g.K4 + 5) + (p2w > ttw ? p2w : ttw));
+            dim3 grid(ns, rt);
+#define DSVGP_FWD_RUN(OT_, Q_)                                                                                       \
+            hipLaunchKernelGGL((kernel_fwd_run_kernel<OT_, Q_>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, \
+                               n2q, g.K4, g.DP, hyp, jitter, (OT_*)out, ld)
+            if (out_is_double) { if (g.q == 6) DSVGP_FWD_RUN(double, 6); else DSVGP_FWD_RUN(double, 3); }
+            else { if (g.q == 6) DSVGP_FWD_RUN(float, 6); else DSVGP_FWD_RUN(float, 3); }
+#undef DSVGP_FWD_RUN
+            DSVGP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if ((g.q == 6 || g.q == 3) && g.NP <= 32) {
         const int T = (48 / g.q) * g.q;
         const int rt = cdiv(n1q, T), ctiles = cdiv(n2q, T);
         int ns = FWD_PAIR_WGS_ / rt;
         if (ns < 1) ns = 1;
         if (ns > ctiles) ns = ctiles;
-        const size_t lds = sizeof(float) * (2 * 48 * (size_t)(g.K4 + 5) + 48 * (size_t)FWD_PAIR_LDT);
+        const size_t p2w_ = 48 * (size_t)(g.K4 + 5), ttw_ = 48 * (size_t)FWD_PAIR_LDT;
+        const size_t lds = sizeof(float) * (FWDP_OVERLAY ? (FWDP_AREG ? 0 : 48 * (size_t)(g.K4 + 5)) + (p2w_ > ttw_ ? p2w_ : ttw_)
+                                                         : 2 * 48 * (size_t)(g.K4 + 5) + 48 * (size_t)FWD_PAIR_LDT);
         const int esz = out_is_double ? 8 : 4;
-        const int ovec = (ld % 2 == 0) && ((uintptr_t)out % (2 * esz) == 0);      // 2-wide stores of the micro-block rows
+        // bit 0: 2-wide stores of the micro-block rows; bit 1: 16-byte stores of lane pairs (float output, 16-byte aligned rows)
+        const int ovec = (((ld % 2 == 0) && ((uintptr_t)out % (2 * esz) == 0)) ? 1 : 0) |
+                         ((!out_is_double && ld % 4 == 0 && (uintptr_t)out % 16 == 0 && FWDP_ST16) ? 2 : 0);
         dim3 grid(ns, rt);
 #define DSVGP_FWD_PAIR(OT_, Q_)                                                                                      \
         hipLaunchKernelGGL((kernel_fwd_pair_kernel<OT_, Q_>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, \
