@@ -8,9 +8,11 @@ Parameter / buffer names are the reference's (``inducing_points``, ``inducing_di
 ``B(p+1)`` (interleaved); the arithmetic is ``_step.ElboEngine`` (Cholesky of K_ZZ + 1e-3 I in fp64,
 panel solve on MFMA, variance diag), the lazy ``K_XX`` is never materialised (only its diagonal is used).
 """
+import warnings
+
 import torch
 
-from .gp_shim import PredictiveDistribution
+from .gp_shim import OldVersionWarning, PredictiveDistribution, PriorDistribution
 
 
 class DirectionalGradVariationalStrategy(torch.nn.Module):
@@ -42,9 +44,45 @@ class DirectionalGradVariationalStrategy(torch.nn.Module):
             self.variational_params_initialized.fill_(1)
         self._init_known = True
 
-    def _load_from_state_dict(self, *args, **kwargs):
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         self._init_known = False
-        return super()._load_from_state_dict(*args, **kwargs)
+        self._updated_known = None
+        # reference ``_ensure_updated_strategy_flag_set`` (DGVS.py:17-29, registered at :68): a checkpoint without the flag was
+        # written by the un-whitened VariationalStrategy of an older gpytorch -- mark it, the first call converts q(u)
+        if ("updated_strategy" in self._buffers and prefix + "updated_strategy" not in state_dict
+                and any(k.startswith(prefix) for k in state_dict)):
+            device = state_dict[list(state_dict.keys())[0]].device
+            state_dict[prefix + "updated_strategy"] = torch.tensor(False, device=device)
+            warnings.warn(
+                "You have loaded a variational GP model (using `VariationalStrategy`) from a previous version of "
+                "GPyTorch. We have updated the parameters of your model to work with the new version of "
+                "`VariationalStrategy` that uses whitened parameters.\nYour model will work as expected, but we "
+                "recommend that you re-save your model.", OldVersionWarning)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _strategy_is_updated(self):
+        # (device buffer for state_dict compatibility, mirrored on the host once read)
+        if getattr(self, "_updated_known", None) is None:
+            # (the CIQ strategy registers no such buffer, reference CiqDGVS.py:160-162: nothing to convert)
+            self._updated_known = bool(self._buffers["updated_strategy"].item()) if "updated_strategy" in self._buffers else True
+        return self._updated_known
+
+    def _whiten_legacy_parameters(self):
+        """reference ``__call__`` (DGVS.py:210-240): change the variational parameters of a legacy checkpoint to be whitened"""
+        vd = self._variational_distribution
+        if getattr(self, "shared_directions", False):
+            raise NotImplementedError("legacy (un-whitened) checkpoints of the shared-directions variant are not converted")
+        if not hasattr(vd, "chol_variational_covar"):
+            raise NotImplementedError("legacy (un-whitened) checkpoints are converted for a CholeskyVariationalDistribution only")
+        with torch.no_grad():
+            params = self.model._param_dict(None)
+            m_w, L_w = self.model.engine.whiten_legacy(params)
+            vd.variational_mean.copy_(m_w)              # initialize_variational_distribution(whitened q(u)), mean_init_std = 0
+            vd.chol_variational_covar.copy_(L_w)
+            self.variational_params_initialized.fill_(1)
+            self._init_known = True
+            self.updated_strategy.fill_(True)           # mark that we have updated the variational strategy
+            self._updated_known = True
 
     def forward(self, x, inducing_points=None, inducing_values=None, variational_inducing_covar=None, **kwargs):
         derivative_directions = kwargs["derivative_directions"]
@@ -59,7 +97,12 @@ class DirectionalGradVariationalStrategy(torch.nn.Module):
 
     def __call__(self, x, prior=False, **kwargs):
         if prior:
-            raise NotImplementedError("prior=True is only used by the legacy un-whitened checkpoint path")
+            # _VariationalStrategy.__call__(prior=True) -> model.forward(x): only ever evaluated at the inducing points (the
+            # legacy conversion above); the inducing directions stand in for the kwargs the reference does not pass
+            loc, K = self.model.engine.prior_moments(self.model._param_dict(None))
+            return PriorDistribution(loc, K)
+        if not self._strategy_is_updated():
+            self._whiten_legacy_parameters()
         if self.training:
             self._maybe_init()
         return self.forward(x, **kwargs)

@@ -40,7 +40,7 @@ SIGNATURES = {
     "dsvgp_ciq_workspace_bytes": (_z, [_i, _i, _i]),
     "dsvgp_ciq_lanczos": (_i, [_p, _p, _l, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_solve": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _f, _i, _i, _p, _p, _l, _p, _p]),
-    "dsvgp_ciq_rowstats": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "dsvgp_ciq_rowstats": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "dsvgp_ciq_tbar": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_sym_average_f32": (_i, [_p, _p, _i, _l, _p, _l]),
     "dsvgp_packed_width": (_i, [_i]),

@@ -477,11 +477,11 @@ def ciq_solve(ctx, K, R, sigma, omega, X, out, workspace, tol=1e-4, max_iter=100
     return its.value
 
 
-def ciq_rowstats(ctx, T, ST, p, m, constant, hyp):
+def ciq_rowstats(ctx, T, ST, p, m, constant, hyp, kxx_jitter=0.0):
     t, n = T.shape
     dev = T.device
     imean, mu, var, live = (torch.empty(t, dtype=f32, device=dev) for _ in range(4))
-    check(lib.dsvgp_ciq_rowstats(ctx.h, _ptr(T), _ptr(ST), t, n, p, _ptr(m), _ptr(constant), _ptr(hyp), _ptr(imean),
+    check(lib.dsvgp_ciq_rowstats(ctx.h, _ptr(T), _ptr(ST), t, n, p, _ptr(m), _ptr(constant), _ptr(hyp), float(kxx_jitter), _ptr(imean),
                                  _ptr(mu), _ptr(var), _ptr(live)), "dsvgp_ciq_rowstats")
     return imean, mu, var, live
 

@@ -93,6 +93,11 @@ class ElboEngine:
         self._no_middle = False
         self.fused_inverse = True       # L^-1 by forward elimination inside the Cholesky launches (csrc/potrf.hip)
         self.lib_dense_gemm = False     # True (diagnostics / test comparator only): the dense K_ZX-bar product through rocBLAS
+        # K_ZZ jitter: LazyTensor.add_jitter() default 1e-3 (DGVS.py:144, CiqDGVS.py:233); gpytorch's plain CiqVariationalStrategy
+        # (grad_svgp.py:25-27, traditional_vi.py:22-24; its forward is quoted in CiqDGVS.py:243-251) adds 1e-2 to K_ZZ and 1e-4 to
+        # diag K_XX instead
+        self.kzz_jitter = KZZ_JITTER
+        self.ciq_kxx_jitter = 0.0
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
@@ -174,7 +179,7 @@ class ElboEngine:
             ctx.bind()                                  # back on the caller's stream
         L = self._get("L", (Mp, Mp), f64)
         info = self._get("info", (1,), torch.int32)
-        _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
+        _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=self.kzz_jitter, out=L, dtype=f64)
         nrhs = max(int(nrhs), Mp + 1)
         ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, nrhs, self.trsm_nb))
         self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs, "kzz")   # L and the inverted blocks of L
@@ -224,7 +229,7 @@ class ElboEngine:
         if not ladder:
             raise _Refactored()
         for t in range(CHOL_TRIES):                     # rare path: psd_safe_cholesky jitter ladder
-            _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=L, dtype=f64)
+            _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=self.kzz_jitter, out=L, dtype=f64)
             _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
             self._potrf_ws = self._potrf_and_inverse(ctx, L, info, self._inverse_ws, Mp + 1, "kzz")
             if int(info.item()) == 0:
@@ -342,6 +347,46 @@ class ElboEngine:
             finally:
                 self._no_middle = False
         return self._predict_chol(ctx, params, x, D, cache, joint=True)
+
+    @torch.no_grad()
+    def whiten_legacy(self, params):
+        """Un-whitened q(u) = N(m_u, L_u L_u^T) of a checkpoint written before gpytorch's whitened VariationalStrategy ->
+        the whitened parameters this strategy works with (reference DGVS.py:210-240):
+            L = chol(K_ZZ + 1e-3 I),  m_w = L^-1 (m_u - c),  L_w = chol(L^-1 S_u L^-T)
+        (fp64 throughout, like the reference's ``.double()`` solves).  The reference evaluates the prior p(u) through
+        ``self(inducing_points, prior=True)`` WITHOUT direction kwargs, which its directional kernel cannot take: the
+        model's own inducing directions are used here, the evident intent.  Returns (m_w fp32, L_w fp32 lower)."""
+        ctx = _ops.Context.get(self.device)
+        self._eval_cache = None
+        m_u, L_u = params["variational_mean"], params["chol_variational_covar"]
+        Mp = m_u.shape[0]
+        hyp, packZ, L, dims = self._factor(ctx, params, sync=True, nrhs=Mp + 1)
+        rhs = torch.empty(Mp, Mp + 1, dtype=f64, device=self.device)
+        rhs[:, 0] = (m_u - params["constant"].reshape(())).to(f64)
+        rhs[:, 1:] = torch.tril(L_u).to(f64)
+        X = torch.empty_like(rhs)
+        _ops.trsm(ctx, L, rhs, False, X, None, self.trsm_nb, self._inverse_ws, reuse_inverse=True)     # L^-1 [m_u - c | L_u]
+        R = X[:, 1:].contiguous()
+        Sw = torch.empty(Mp, Mp, dtype=f64, device=self.device)
+        _ops.gemm(ctx, TRANS_B, R, R, Sw)                                                             # L^-1 S_u L^-T
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _ops.potrf_(ctx, Sw, info, self.potrf_algo, self._potrf_scratch("legacy", Mp) if self.potrf_algo == 1 else None)
+        if int(info.item()) != 0:
+            raise NotPSDError("the un-whitened variational covariance of the checkpoint is not positive definite")
+        return X[:, 0].to(f32).contiguous(), torch.tril(Sw).to(f32).contiguous()
+
+    @torch.no_grad()
+    def prior_moments(self, params):
+        """p(u) = N(c 1, s K(Z, Z; V, V)) at the inducing points, un-jittered, fp32: ``strategy(Z, prior=True)``"""
+        ctx = _ops.Context.get(self.device)
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        hyp = _ops.hyp_forward(ctx, params["raw_lengthscale"], params["raw_outputscale"], params["raw_noise"])
+        center = _ops.column_mean(ctx, Z.contiguous())
+        packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp, center)
+        K = _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp)
+        return params["constant"].reshape(()).expand(M * (p + 1)).clone(), K
 
     @torch.no_grad()
     def covariance_root(self, Sigma):
@@ -667,7 +712,7 @@ class ElboEngine:
         packZ = _ops.pack_points(ctx, Z.contiguous(), V.contiguous(), p, hyp, self.center)
         packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
         K32 = self._get("ciq_K", (Mp, Mp), f32)
-        _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=KZZ_JITTER, out=K32)         # :230-234
+        _ops.kernel_fwd(ctx, packZ, M, packZ, M, d, p, hyp, jitter=self.kzz_jitter, out=K32)     # :230-234
         Rrow = self._get("ciq_R", (Bp, Mp), f32)                                                 # K_XZ = K_ZX^T, one RHS per row
         _ops.kernel_fwd(ctx, packX, B, packZ, M, d, p, hyp, out=Rrow)
         sigma, omega, omega_host = self._ciq_quadrature(ctx, K32, Rrow[0])
@@ -686,7 +731,8 @@ class ElboEngine:
         m32 = m64.reshape(Mp).to(f32)
         STrow = self._get("ciq_ST", (Bp, Mp), f32)
         _ops.gemm(ctx, 0, Trow, S32, STrow)                                                      # (S T)^T = T^T S
-        imean, mu, var, live = _ops.ciq_rowstats(ctx, Trow, STrow, p, m32, params["constant"].reshape(-1), hyp)   # :65-69,265-266
+        imean, mu, var, live = _ops.ciq_rowstats(ctx, Trow, STrow, p, m32, params["constant"].reshape(-1), hyp,
+                                                 self.ciq_kxx_jitter)                              # :65-69,265-266
         mu_bar = torch.empty(Bp, dtype=f32, device=dev)
         var_bar = torch.empty(Bp, dtype=f32, device=dev)
         varn = torch.empty(Bp, dtype=f32, device=dev)

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void ciq_combine_kernel(float* __restrict__ x,
 // mu = imean + c, var = max(s dg_j - tsq + ivar, 1e-6), live = var not clamped
 __global__ __launch_bounds__(256) void ciq_rowstats_kernel(const float* __restrict__ T, const float* __restrict__ ST,
                                                            const float* __restrict__ m, const float* __restrict__ constant,
-                                                           const float* __restrict__ hyp, int p, int n,
+                                                           const float* __restrict__ hyp, int p, int n, float kxx_jitter,
                                                            float* __restrict__ imean, float* __restrict__ mu,
                                                            float* __restrict__ var, float* __restrict__ live) {
     __shared__ double red[4];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void ciq_rowstats_kernel(const float* __restri
     if (threadIdx.x == 0) {
         const float ell = hyp[0], s = hyp[1];
         const float dg = (j % (p + 1) == 0) ? s : s / (ell * ell);
-        const float v = (float)((double)dg - a2 + a1);
+        const float v = (float)((double)dg + (double)kxx_jitter - a2 + a1);      // (data_data_covar.add_jitter(1e-4) of gpytorch's plain CIQ strategy)
         imean[j] = (float)a0;
         mu[j] = (float)a0 + constant[0];
         var[j] = fmaxf(v, 1e-6f);
@@ -336,12 +336,12 @@ extern "C" int dsvgp_ciq_lanczos(dsvgp_ctx* ctx, const float* K, int64_t ldk, co
 }
 
 extern "C" int dsvgp_ciq_rowstats(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, int p, const float* m,
-                                  const float* constant, const float* hyp, float* imean, float* mu, float* var,
+                                  const float* constant, const float* hyp, float kxx_jitter, float* imean, float* mu, float* var,
                                   float* live) {
     if (!ctx || !T || !ST || !m || !constant || !hyp || !imean || !mu || !var || !live || t <= 0 || n <= 0 || p < 0)
         return DSVGP_EINVAL;
-    hipLaunchKernelGGL(ciq_rowstats_kernel, dim3(t), dim3(256), 0, ctx->stream, T, ST, m, constant, hyp, p, n, imean, mu,
-                       var, live);
+    hipLaunchKernelGGL(ciq_rowstats_kernel, dim3(t), dim3(256), 0, ctx->stream, T, ST, m, constant, hyp, p, n, kxx_jitter,
+                       imean, mu, var, live);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

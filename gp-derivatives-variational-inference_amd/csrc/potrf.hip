@@ -10,6 +10,9 @@ namespace {
 
 constexpr int NBC = 64;
 
+#ifndef POTRF_NW
+#define POTRF_NW 4          // waves per workgroup of the step launches: 4; 8 (each 64 x 64 tile product split 32 x 16 per wave) measured slower at M' = 3000 (1.78-1.93 vs 1.70 ms), 5 % faster at 600
+#endif
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
 #endif
@@ -53,24 +56,25 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // 64 x 64 x 64 product by 4 waves (wave -> 32 x 32 outputs):  acc[i][j] = sum_q Aop[m][q] * Bop(q, n)
 //   B_NK: Bop(q, n) = Bs[n][q]   (B given as [n][k]);  else Bop(q, n) = Bs[q][n]
-template <bool B_NK>
+template <bool B_NK, int NW = 4>
 __device__ __forceinline__ void tile_product(const double (*As)[LDT], const double (*Bs)[LDT], int lane, int wr, int wc,
-                                             acc4 (&acc)[2][2]) {
+                                             acc4 (&acc)[2][8 / NW]) {
+    constexpr int NJ = 8 / NW;            // 16-column sub-tiles per wave: 2 (4 waves, 32 x 32 each) or 1 (8 waves, 32 x 16 each)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = acc4{0, 0, 0, 0};
-    // all operands of the wave (2 x 16 + 2 x 16 doubles per lane) first, then 64 back-to-back MFMAs: the loops are
+        for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+    // all operands of the wave first, then back-to-back MFMAs: the loops are
     // fully unrolled (a rolled loop moves the accumulators AGPR <-> VGPR and drains the MFMA pipe every trip)
-    double a[2][16], b[2][16];
+    double a[2][16], b[NJ][16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         const int kq = 4 * ks + (lane >> 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i][ks] = As[wr * 32 + i * 16 + (lane & 15)][kq];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = wc * 32 + j * 16 + (lane & 15);
+        for (int j = 0; j < NJ; ++j) {
+            const int n = wc * (16 * NJ) + j * 16 + (lane & 15);
             b[j][ks] = B_NK ? Bs[n][kq] : Bs[kq][n];
         }
     }
@@ -79,7 +83,7 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
 }
 
@@ -166,7 +170,9 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
                                              double* __restrict__ Wg) {
     const int lane = tid & 63, wave = tid >> 6;
     const int mrow = (lane >> 4), ncol = lane & 15;
-    for (int e = tid; e < 64 * 64; e += 256) Y[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+    // (written for waves 0..3; in an 8-wave workgroup waves 4..7 only take part in the barriers)
+    if (wave < 4)
+        for (int e = tid; e < 64 * 64; e += 256) Y[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
     acc4 wacc[4];                        // waves 1..3: lower blocks idx = (wave - 1) + 3 s of W
 #pragma unroll
     for (int sI = 0; sI < 4; ++sI) wacc[sI] = acc4{0, 0, 0, 0};
@@ -183,7 +189,7 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 #endif
         __syncthreads();
         // (b) 4 tasks, one per wave: panel blocks ib > kb, row-block kb of X (cb < kb), and X_{kb,kb} = Xd
-        {
+        if (wave < 4) {
             const int t = wave;
             if (t < 3 - kb) {                    // L_{ib,kb} = F_{ib,kb} Xd^T
                 const int ib = kb + 1 + t;
@@ -208,7 +214,8 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
         // Look-ahead: wave 0 updates only the NEXT diagonal sub-block (from the panel block it produced itself) and goes
         // straight on to factor it; waves 1..3 touch neither that sub-block nor Xd / colbuf / rowbuf; the barrier after
         // the next factor16 closes the phase.
-        if (wave == 0) {
+        if (wave >= 4) {
+        } else if (wave == 0) {
             if (kb < 3) {
                 const int ib = kb + 1;
                 acc4 r = prod16<true>(&F[ib * 16][o], LDT, &F[ib * 16][o], LDT, lane);
@@ -260,7 +267,7 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
         if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[11] = __builtin_amdgcn_s_memtime();
 #endif
     }
-    if (wave > 0) {
+    if (wave > 0 && wave < 4) {
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) {
             const int idx = (wave - 1) + 3 * sI;
@@ -283,12 +290,14 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 //   Y-tiles  (j <= k):         Y_kj  = X_k R_kj                        (row block k of L^-1 is final)
 // Row k of R was completed by launch k-1 and is read-only here; these tiles ride on the CUs the latency-bound
 // factorisation chain leaves idle.
+template <int NW = 4>
 __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n,
                                                   int k, int e, const double* __restrict__ Xws,
                                                   const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
                                                   double* __restrict__ Y, int64_t ldy, int nblk,
                                                   double* __restrict__ YT) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;     // column groups of waves, 16-column sub-tiles per wave, rows per thread
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int nt = nblk - (k + 1), nR = nt * (k + 1);
     const int k0 = k * 64;
     const bool ytile = e >= nR;
@@ -297,59 +306,59 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     const int j0 = j * 64;
     const double* Lk = ytile ? (Xws + (size_t)k * 4096) : (Wws + (size_t)k * 4096);
     // two LDS tiles only (two workgroups per CU): R_kj waits in registers until T = A_ik W_k has been formed
-    double rc[16];
+    double rc[NU];
     {
-        double ra[16], rb[16];
+        double ra[NU], rb[NU];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+        for (int u = 0; u < NU; ++u) {
+            const int r = (tid >> 6) + NW * u, c = tid & 63;
             ra[u] = ytile ? 0.0 : A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
             rb[u] = Lk[r * 64 + c];
             rc[u] = (j == k) ? ((r == c) ? 1.0 : 0.0) : Rw[(int64_t)(k0 + r) * ldr + j0 + c];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+        for (int u = 0; u < NU; ++u) {
+            const int r = (tid >> 6) + NW * u, c = tid & 63;
             S[0][r][c] = ytile ? rb[u] : ((i0 + r < n) ? ra[u] : 0.0);      // Y-tile: X_k is the left operand already
             S[1][r][c] = ytile ? rc[u] : rb[u];
         }
     }
     __syncthreads();
-    acc4 acc[2][2];
+    acc4 acc[2][NJ];
     if (!ytile) {
-        tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k
+        tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + jj * 16 + (lane & 15)] = acc[i][jj][q];
+                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + jj * 16 + (lane & 15)] = acc[i][jj][q];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) S[1][(tid >> 6) + 4 * u][tid & 63] = rc[u];
+        for (int u = 0; u < NU; ++u) S[1][(tid >> 6) + NW * u][tid & 63] = rc[u];
         __syncthreads();
-        tile_product<false>(S[0], S[1], lane, wr, wc, acc);         // T R_kj
+        tile_product<false, NW>(S[0], S[1], lane, wr, wc, acc);         // T R_kj
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * 32 + jj * 16 + (lane & 15);
+                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * (16 * NJ) + jj * 16 + (lane & 15);
                     double* dst = Rw + (int64_t)(i0 + ml) * ldr + j0 + nl;
                     *dst = ((j == k) ? 0.0 : *dst) - acc[i][jj][q];
                 }
     } else {
-        tile_product<false>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
+        tile_product<false, NW>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
         if (YT == nullptr) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int m = k0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, c = j0 + wc * 32 + jj * 16 + (lane & 15);
+                        const int m = k0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, c = j0 + wc * (16 * NJ) + jj * 16 + (lane & 15);
                         if (m < n && c < n) Y[(int64_t)m * ldy + c] = acc[i][jj][q];
                     }
         } else {
@@ -359,14 +368,14 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + jj * 16 + (lane & 15)] = acc[i][jj][q];
+                        S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + jj * 16 + (lane & 15)] = acc[i][jj][q];
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            for (int u = 0; u < NU; ++u) {
+                const int r = (tid >> 6) + NW * u, c = tid & 63;
                 if (k0 + r < n && j0 + c < n) Y[(int64_t)(k0 + r) * ldy + j0 + c] = S[0][r][c];
                 if (j0 + r < n && k0 + c < n) YT[(int64_t)(j0 + r) * ldy + k0 + c] = S[0][c][r];
             }
@@ -374,7 +383,11 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     }
 }
 
-__global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
+#ifndef POTRF_MINW
+#define POTRF_MINW (POTRF_NW / 2)
+#endif
+template <int NW>
+__global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
                                                            double* __restrict__ Xws, double* __restrict__ Wws,
                                                            int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
                                                            double* __restrict__ Yinv, int64_t ldy, int nA,
@@ -385,10 +398,11 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     __shared__ double S[2][64][LDT];
     __shared__ double Xd[16][17];
     __shared__ double colbuf[32], rowbuf[32];      // [16..31]: dummy slots of the non-owner lanes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int b = blockIdx.x;
     if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
-        chol_inverse_tile(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT);
+        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT);
         return;
     }
     int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
@@ -401,13 +415,13 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     if (k >= 0) {
         const int k0 = k * 64;
         const double* Wk = Wws + (size_t)k * 4096;
-        double cv[2][2][4];    // C tile, requested behind the operand loads (clamped addresses: no predicated load -> wait -> store chains)
-        double rb[16];         // A_jk, parked until T = A_ik W_k is in LDS
+        double cv[2][NJ][4];    // C tile, requested behind the operand loads (clamped addresses: no predicated load -> wait -> store chains)
+        double rb[NU];         // A_jk, parked until T = A_ik W_k is in LDS
         {   // all 48 + 16 loads of a thread in flight at once (a rolled loop pays the global latency 16 times)
-            double ra[16], rw[16];
+            double ra[NU], rw[NU];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            for (int u = 0; u < NU; ++u) {
+                const int r = (tid >> 6) + NW * u, c = tid & 63;
                 ra[u] = A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
                 rb[u] = A[(int64_t)min(j0 + r, n - 1) * lda + k0 + c];
                 rw[u] = Wk[r * 64 + c];
@@ -415,48 +429,48 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int m = min(i0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, n - 1);
-                        const int nn = min(j0 + wc * 32 + j * 16 + (lane & 15), n - 1);
+                        const int nn = min(j0 + wc * (16 * NJ) + j * 16 + (lane & 15), n - 1);
                         cv[i][j][q] = A[(int64_t)m * lda + nn];
                     }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            for (int u = 0; u < NU; ++u) {
+                const int r = (tid >> 6) + NW * u, c = tid & 63;
                 S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
                 S[1][r][c] = rw[u];
             }
         }
         __syncthreads();
         CHOL_STAMP(1);
-        acc4 acc[2][2];
-        tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
+        acc4 acc[2][NJ];
+        tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
+                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + j * 16 + (lane & 15)] = acc[i][j][q];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+        for (int u = 0; u < NU; ++u) {
+            const int r = (tid >> 6) + NW * u, c = tid & 63;
             S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
         }
         __syncthreads();
-        tile_product<true>(S[0], S[1], lane, wr, wc, acc);          // T A_jk^T
+        tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T A_jk^T
         const bool diag = ti == tj;
         if (b == 0) __syncthreads();                                // F aliases the T tile: every wave is done reading it
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * 32 + j * 16 + (lane & 15);
+                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * (16 * NJ) + j * 16 + (lane & 15);
                     const int m = i0 + ml, nn = j0 + nl;
                     const bool in = m < n && nn < n && !(diag && nl > ml);
                     const double v = cv[i][j][q] - acc[i][j][q];
@@ -465,15 +479,15 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
                 }
         if (b != 0) return;
     } else {
-        double ra[16];
+        double ra[NU];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+        for (int u = 0; u < NU; ++u) {
+            const int r = (tid >> 6) + NW * u, c = tid & 63;
             ra[u] = A[(int64_t)min(r, n - 1) * lda + min(c, n - 1)];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+        for (int u = 0; u < NU; ++u) {
+            const int r = (tid >> 6) + NW * u, c = tid & 63;
             F[r][c] = (r < n && c <= r) ? ra[u] : ((r == c) ? 1.0 : 0.0);
         }
     }
@@ -560,8 +574,8 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
         const int nt = nblk - (k + 1);
         const int nA = (k < 0) ? 1 : nt * (nt + 1) / 2;
         const int nI = (k >= 0 && Yinv) ? nt * (k + 1) + (k + 1) : 0;
-        hipLaunchKernelGGL(chol_step_kernel, dim3(nA + nI), dim3(256), 0, st, A, lda, n, k, Xws, Wws, info, Rw, ldr, Yinv, ldy,
-                           nA, YinvT);
+        hipLaunchKernelGGL(chol_step_kernel<POTRF_NW>, dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info, Rw,
+                           ldr, Yinv, ldy, nA, YinvT);
         DSVGP_LAUNCH_CHECK();
     }
     if (Yinv) {

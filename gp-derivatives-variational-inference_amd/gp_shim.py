@@ -11,6 +11,18 @@ import torch
 from ._step import ElboEngine, NGD_PARAM_NAMES, PARAM_NAMES
 
 
+class OldVersionWarning(UserWarning):
+    """gpytorch.utils.warnings.OldVersionWarning: a checkpoint written before the whitened VariationalStrategy was loaded"""
+
+
+class PriorDistribution:
+    """``strategy(x, prior=True)``: the un-whitened prior p(u) at the inducing points (``.loc``, ``.covariance_matrix``)"""
+
+    def __init__(self, loc, covariance_matrix):
+        self.loc = self.mean = loc
+        self.covariance_matrix = covariance_matrix
+
+
 class ConstantMean(torch.nn.Module):
     """gpytorch.means.ConstantMean: parameter ``constant`` of shape [1], init 0."""
 

@@ -26,8 +26,10 @@ class GPModel(ApproximateGP):
     def __init__(self, inducing_points, **kwargs):
         torch.nn.Module.__init__(self)
         dim = inducing_points.size(1)
-        if kwargs.get("variational_strategy") == "CIQ":
-            raise NotImplementedError("grad_svgp with gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27) is not built")
+        # gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27): the same CIQ whitening + NGD interpolation terms as the
+        # directional strategy (whose file quotes its forward, CiqDGVS.py:243-251) with K_ZZ.add_jitter(1e-2) and
+        # diag K_XX + 1e-4; no lengthscale re-initialisation
+        self._ciq = kwargs.get("variational_strategy") == "CIQ"
         if kwargs.get("variational_distribution") == "NGD":                               # grad_svgp.py:21-22
             variational_distribution = NaturalVariationalDistribution(inducing_points.size(0) * (dim + 1))
         else:
@@ -45,6 +47,8 @@ class GPModel(ApproximateGP):
     def engine(self):
         eng = ApproximateGP.engine.fget(self)
         eng.chol_jitter = 1e-8          # psd_safe_cholesky default for a double matrix (GradVariationalStrategy.py:72)
+        if getattr(self, "_ciq", False):
+            eng.whitening, eng.kzz_jitter, eng.ciq_kxx_jitter = "ciq", 1e-2, 1e-4
         return eng
 
     def _param_list(self, likelihood=None):
@@ -72,8 +76,6 @@ def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_e
                    tensors=None, **args):
     """Everything ``train_gp`` does before its loop (grad_svgp.py:41-127); returns a TrainLoop (``tensors``: an
     already-resident (X, Y) pair instead of a Dataset)."""
-    if use_ciq:
-        raise NotImplementedError("grad_svgp with gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27) is not built")
     if not torch.cuda.is_available():
         raise RuntimeError("train_gp needs an MI355X (HIP) device: this path has no CPU fallback")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -81,7 +83,10 @@ def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_e
     n_samples = X.shape[0]
 
     inducing_points = torch.rand(num_inducing, dim).to(device)            # :61
-    if use_ngd:                                                           # grad_svgp.py:66-67
+    if use_ciq:                                                           # grad_svgp.py:63-65
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD", variational_strategy="CIQ").to(device)
+        model.engine.ciq_num_quadrature = int(args.get("num_contour_quadrature", 15))
+    elif use_ngd:                                                         # grad_svgp.py:66-67
         model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(device)
     else:
         model = GPModel(inducing_points=inducing_points).to(device)
@@ -105,7 +110,7 @@ def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_e
         for t in model._param_list(likelihood):
             dist.broadcast(t.data, 0)
 
-    if use_ngd:                                                           # grad_svgp.py:87-88
+    if use_ngd or use_ciq:                                                # grad_svgp.py:87-88
         variational_optimizer = NGD(list(model.variational_parameters()), num_data=n_samples, lr=learning_rate_ngd)
     else:
         variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
@@ -149,7 +154,8 @@ def train_gp(train_dataset, dim, num_inducing=128,
              verbose=True,
              **args):
     loop = setup_training(train_dataset, dim, num_inducing, minibatch_size, num_epochs, use_ngd, use_ciq,
-                          learning_rate_hypers, learning_rate_ngd, lr_sched, mll_type, gamma, **args)
+                          learning_rate_hypers, learning_rate_ngd, lr_sched, mll_type, gamma,
+                          num_contour_quadrature=num_contour_quadrature, **args)
     model, likelihood = loop.model, loop.likelihood
     n_samples = loop.X.shape[0]
     max_steps = args.get("max_steps")

@@ -36,8 +36,9 @@ class VariationalStrategy(GradVariationalStrategy):
 class GPModel(ApproximateGP):
     def __init__(self, inducing_points, **kwargs):
         torch.nn.Module.__init__(self)
-        if kwargs.get("variational_strategy") == "CIQ":
-            raise NotImplementedError("gpytorch's plain CiqVariationalStrategy (traditional_vi.py:22-24) is not built")
+        # gpytorch's plain CiqVariationalStrategy (traditional_vi.py:22-24): CIQ whitening + NGD interpolation terms on the
+        # p = 0 path of the same engine, K_ZZ.add_jitter(1e-2) and diag K_XX + 1e-4 (its forward is quoted at CiqDGVS.py:243-251)
+        self._ciq = kwargs.get("variational_strategy") == "CIQ"
         if kwargs.get("variational_distribution") == "NGD":                               # :19-20
             variational_distribution = NaturalVariationalDistribution(inducing_points.size(0))
         else:
@@ -49,6 +50,13 @@ class GPModel(ApproximateGP):
         self.mean_module = ConstantMean()
         self.covar_module = ScaleKernel(RBFKernelDirectionalGrad())      # p = 0: the plain RBF kernel
         self.register_buffer("_no_directions", torch.empty(0, inducing_points.size(1)), persistent=False)
+
+    @property
+    def engine(self):
+        eng = ApproximateGP.engine.fget(self)
+        if getattr(self, "_ciq", False):
+            eng.whitening, eng.kzz_jitter, eng.ciq_kxx_jitter = "ciq", 1e-2, 1e-4
+        return eng
 
     def _param_list(self, likelihood=None):
         vs = self.variational_strategy
@@ -84,8 +92,6 @@ def train_gp(train_dataset, dim, num_inducing=128,
              verbose=True,
              **args):
     """Argument meaning identical to the reference (traditional_vi.py:39-52); ``seed`` / ``max_steps`` via ``**args``."""
-    if use_ciq:
-        raise NotImplementedError("gpytorch's plain CiqVariationalStrategy (traditional_vi.py:22-24) is not built")
     if not torch.cuda.is_available():
         raise RuntimeError("train_gp needs an MI355X (HIP) device: this path has no CPU fallback")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -95,7 +101,10 @@ def train_gp(train_dataset, dim, num_inducing=128,
     n_samples = X.shape[0]
 
     inducing_points = torch.rand(num_inducing, dim).to(device)            # :57
-    if use_ngd:
+    if use_ciq:                                                           # :59-61
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD", variational_strategy="CIQ").to(device)
+        model.engine.ciq_num_quadrature = int(num_contour_quadrature)
+    elif use_ngd:
         model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(device)
     else:
         model = GPModel(inducing_points=inducing_points).to(device)
@@ -120,7 +129,7 @@ def train_gp(train_dataset, dim, num_inducing=128,
             if t.numel():
                 dist.broadcast(t.data, 0)
 
-    if use_ngd:                                                           # :72-73
+    if use_ngd or use_ciq:                                                # :72-73
         variational_optimizer = NGD(list(model.variational_parameters()), num_data=n_samples, lr=learning_rate_ngd)
     else:
         variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)

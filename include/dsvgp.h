@@ -267,7 +267,9 @@ int dsvgp_ciq_solve(dsvgp_ctx* ctx, const float* K, int64_t ldk, const float* R,
                     const float* sigma, const float* omega, int Q, float tol, int max_iter, int check_every, float* X,
                     float* out, int64_t ldo, void* workspace, int* iters_out);
 int dsvgp_ciq_rowstats(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, int p, const float* m,
-                       const float* constant, const float* hyp, float* imean, float* mu, float* var, float* live);
+                       const float* constant, const float* hyp, float kxx_jitter, float* imean, float* mu, float* var,
+                       float* live);   /* kxx_jitter: 0 for the directional strategy (:235-239), 1e-4 for gpytorch's plain
+                                          CiqVariationalStrategy (its forward is quoted at :243-251)                    */
 int dsvgp_ciq_tbar(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, const float* m, const float* mu_bar,
                    const float* var_bar, const float* live, const float* imean, float* Tbar, float* VT, float* cvec);
 int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, float* out, int64_t ldo);

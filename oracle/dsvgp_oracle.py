@@ -582,7 +582,7 @@ class _NgdInterpTermsFn(torch.autograd.Function):
         return d_interp, d_vec, d_mat
 
 
-def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=None):
+def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0):
     """CiqDirectionalGradVariationalStrategy.forward with a NaturalVariationalDistribution (:197-268).
     Returns (mu, var, kl) with kl == 0 as in the reference's forward (:74)."""
     Z, V = params["inducing_points"], params["inducing_directions"]
@@ -595,17 +595,19 @@ def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=No
     dt = x.dtype
     K_ZX = s * kernel_matrix(Z, x, V, D, ell)                                  # :218-222
     K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
-    K_ZZ = K_ZZ + KZZ_JITTER * torch.eye(K_ZZ.shape[0], dtype=dt)              # :230-234
+    # (gpytorch's plain CiqVariationalStrategy -- grad_svgp.py:25-27, traditional_vi.py:22-24, forward quoted at CiqDGVS.py:243-251
+    #  -- uses add_jitter(1e-2) here and data_data_covar.add_jitter(1e-4) below)
+    K_ZZ = K_ZZ + kzz_jitter * torch.eye(K_ZZ.shape[0], dtype=dt)              # :230-234
     dg = s * kernel_diag(B, p, ell).to(dt)                                     # :235-239, diag only (:265)
     T = sqrt_inv_matmul_exact(K_ZZ, K_ZX) if exact else sqrt_inv_matmul(K_ZZ, K_ZX, Q, stats)     # :255-256
     interp_mean, interp_var, kl = _NgdInterpTermsFn.apply(T, params["natural_vec"], params["natural_mat"])  # :261-263
-    var = (dg - (T * T).sum(0) + interp_var).clamp_min(MIN_VARIANCE)           # :265-266
+    var = (dg + kxx_jitter - (T * T).sum(0) + interp_var).clamp_min(MIN_VARIANCE)           # :265-266
     return interp_mean + c, var, kl                                            # :126 (constant mean on all rows), :293
 
 
 def ciq_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=NUM_CONTOUR_QUADRATURE, exact=False,
-                stats=None):
-    mu, var, kl = ciq_predictive(params, x, D, Q, exact, stats)
+                stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0):
+    mu, var, kl = ciq_predictive(params, x, D, Q, exact, stats, kzz_jitter, kxx_jitter)
     _, _, noise = constrained(params)
     Bp = y.shape[0] if global_rows is None else global_rows
     varn = (var + noise).clamp_min(MIN_VARIANCE)
@@ -621,9 +623,9 @@ def ciq_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=
 
 
 def ciq_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=NUM_CONTOUR_QUADRATURE,
-                       exact=False, stats=None):
+                       exact=False, stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0):
     ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    loss, mu, varn = ciq_forward(ps, x, y, D, num_data, mll_type, global_rows, Q, exact, stats)
+    loss, mu, varn = ciq_forward(ps, x, y, D, num_data, mll_type, global_rows, Q, exact, stats, kzz_jitter, kxx_jitter)
     loss.backward()
     grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps}
     grads["natural_mat"] = 0.5 * (grads["natural_mat"] + grads["natural_mat"].t())

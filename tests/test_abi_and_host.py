@@ -117,3 +117,25 @@ def test_select_cols_of_y_against_reference_generated_vectors(dsvgp):
             assert torch.equal(D, torch.from_numpy(g["case%d_call%d_D" % (ci, k)])), (ci, k)
             idx_y = sorted(rng.sample(range(1, dim + 1), p) + [0])          # directional_vi.TrainLoop.step
             assert torch.equal(y[:, idx_y], ysel) and torch.equal(torch.eye(dim)[[c - 1 for c in idx_y[1:]]], D)
+
+
+def test_legacy_checkpoint_load_hook_marks_unwhitened_strategy(dsvgp):
+    """reference ``_ensure_updated_strategy_flag_set`` (DGVS.py:17-29): a state_dict without ``updated_strategy`` comes from the
+    un-whitened VariationalStrategy of an older gpytorch -- the flag is set to False with an OldVersionWarning, and the first
+    call converts q(u) (GPU test ``test_legacy_unwhitened_checkpoint_is_converted_on_first_call``)."""
+    import warnings
+    Z, V = torch.rand(6, 3), torch.eye(3)[:2].repeat(6, 1)
+    sd = dsvgp.GPModel(Z, V, 3).state_dict()
+    del sd["variational_strategy.updated_strategy"]
+    m = dsvgp.GPModel(torch.rand(6, 3), V, 3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.load_state_dict(sd)
+    assert any(issubclass(x.category, dsvgp.gp_shim.OldVersionWarning) for x in w)
+    assert not bool(m.variational_strategy.updated_strategy) and not m.variational_strategy._strategy_is_updated()
+    # a current checkpoint keeps the flag and raises no warning
+    m2 = dsvgp.GPModel(torch.rand(6, 3), V, 3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m2.load_state_dict(dsvgp.GPModel(Z, V, 3).state_dict())
+    assert not w and m2.variational_strategy._strategy_is_updated()

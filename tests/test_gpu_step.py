@@ -724,3 +724,104 @@ def test_graph_replay_failed_factorisation_leaves_parameters_untouched(dsvgp, gp
     for k in before:
         if k != "raw_outputscale":
             assert torch.equal(before[k], after[k]), k
+
+
+def test_legacy_unwhitened_checkpoint_is_converted_on_first_call(dsvgp, gpu_device):
+    """reference DGVS.py:210-240: a checkpoint whose q(u) = N(m_u, L_u L_u^T) is NOT whitened (no ``updated_strategy`` key) is
+    re-parameterised on the first call, m_w = L^-1 (m_u - c), L_w = chol(L^-1 S_u L^-T) with L = chol(K_ZZ + 1e-3 I); afterwards
+    the model predicts what the un-whitened q(u) means:  mu = c + K_XZ K^-1 (m_u - c),
+    var = diag K_XX + 1e-4 - diag(K_XZ K^-1 K_ZX) + diag(K_XZ K^-1 S_u K^-1 K_ZX)  (+ noise)."""
+    import warnings
+    d, M, p, nx = 3, 14, 2, 40
+    g = torch.Generator().manual_seed(8)
+    Z = torch.rand(M, d, generator=g)
+    V = torch.eye(d)[:p].repeat(M, 1) + 0.1 * torch.randn(M * p, d, generator=g)
+    Mp = M * (p + 1)
+    m_u = 0.5 * torch.randn(Mp, generator=g)
+    L_u = torch.tril(0.3 * torch.eye(Mp) + 0.05 * torch.randn(Mp, Mp, generator=g))
+    src = dsvgp.GPModel(Z, V, d)
+    lik = dsvgp.gp_shim.GaussianLikelihood()
+    with torch.no_grad():
+        src.mean_module.constant.fill_(0.2)
+        src.covar_module.raw_outputscale.fill_(0.3)
+        src.covar_module.base_kernel.raw_lengthscale.fill_(0.4)
+        src.variational_strategy._variational_distribution.variational_mean.copy_(m_u)
+        src.variational_strategy._variational_distribution.chol_variational_covar.copy_(L_u)
+        src.variational_strategy.variational_params_initialized.fill_(1)
+    sd = src.state_dict()
+    del sd["variational_strategy.updated_strategy"]                      # what an old gpytorch wrote
+    model = dsvgp.GPModel(torch.rand(M, d), torch.eye(d)[:p].repeat(M, 1), d)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.load_state_dict(sd)
+    model, lik = model.to(gpu_device), lik.to(gpu_device)
+    model.eval(); lik.eval()
+    x = torch.rand(nx, d, generator=g)
+    D = torch.eye(d)[:p].repeat(nx, 1)
+    with torch.no_grad():
+        preds = lik(model(x.to(gpu_device), derivative_directions=D.to(gpu_device)))
+        mean, var = preds.mean.cpu().double(), preds.variance.cpu().double()
+    assert bool(model.variational_strategy.updated_strategy)
+    # fp64 ground truth of the un-whitened predictive
+    P = {k: v.detach().cpu().double() for k, v in src._param_dict(lik.cpu()).items()}
+    ell, s, noise = O.constrained(P)
+    Kzz = s * O.kernel_matrix(P["inducing_points"], P["inducing_points"], P["inducing_directions"], P["inducing_directions"], ell)
+    Kzz = Kzz + 1e-3 * torch.eye(Mp, dtype=torch.float64)
+    Kzx = s * O.kernel_matrix(P["inducing_points"], x.double(), P["inducing_directions"], D.double(), ell)
+    Kinv_Kzx = torch.linalg.solve(Kzz, Kzx)
+    S_u = L_u.double() @ L_u.double().t()
+    mu_ref = 0.2 + Kinv_Kzx.t() @ (m_u.double() - 0.2)
+    var_ref = (s * O.kernel_diag(nx, p, ell) + 1e-4 - (Kzx * Kinv_Kzx).sum(0) + (Kinv_Kzx * (S_u @ Kinv_Kzx)).sum(0) + noise)
+    assert relmax(mean, mu_ref) < 5e-4 and relmax(var, var_ref) < 5e-4
+    # the prior p(u) the reference evaluates with ``prior=True``
+    pr = model.variational_strategy(model.variational_strategy.inducing_points, prior=True)
+    assert relmax(pr.covariance_matrix, Kzz - 1e-3 * torch.eye(Mp, dtype=torch.float64)) < 2e-5 and relmax(pr.loc, torch.full((Mp,), 0.2)) < 1e-6
+
+
+@pytest.mark.parametrize("harness", ["grad_svgp", "traditional_vi"])
+def test_plain_ciq_strategy_of_the_other_harnesses(dsvgp, gpu_device, harness, capsys):
+    """``use_ciq=True`` in grad_svgp / traditional_vi builds gpytorch's plain CiqVariationalStrategy (grad_svgp.py:25-27,
+    traditional_vi.py:22-24): the same CIQ + NGD terms with K_ZZ.add_jitter(1e-2) and diag K_XX + 1e-4 (its forward is quoted in the
+    reference at CiqDGVS.py:243-251).  One step of the engine against the oracle with those constants, then the drop-in."""
+    from torch.utils.data import TensorDataset
+    from test_ngd import make_ngd_problem
+    full = harness == "grad_svgp"
+    d = 3
+    p = d if full else 0
+    P, x, y, D, nd = make_ngd_problem(400, d, 18, p, 60, seed=77) if p else make_ngd_problem(400, d, 40, 0, 60, seed=78)
+    if full:
+        P["inducing_directions"] = torch.eye(d).repeat(18, 1)
+        D = torch.eye(d).repeat(60, 1)
+        g = torch.Generator().manual_seed(1)
+        y = O.testfun(x).reshape(-1).contiguous()
+    st = {}
+    l_ref, g_ref, mu_ref, var_ref = O.ciq_loss_and_grads(P, x, y, D, nd, stats=st, kzz_jitter=1e-2, kxx_jitter=1e-4)
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.whitening, eng.kzz_jitter, eng.ciq_kxx_jitter = "ciq", 1e-2, 1e-4
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
+    assert relmax(mu, mu_ref) < 5e-3 and relmax(varn, var_ref) < 5e-3
+    for k in O.NGD_PARAM_NAMES:
+        if g_ref[k].numel() and g_ref[k].abs().max() > 0 and not (full and k == "inducing_directions"):
+            assert relmax(grads[k], g_ref[k]) < 2e-2, k
+    # and without the jitter constants the numbers differ (the knobs are live)
+    eng2 = dsvgp.ElboEngine(gpu_device)
+    eng2.whitening = "ciq"
+    loss2, _, _, _ = eng2.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    assert abs(loss2.item() - loss.item()) > 1e-4 * abs(loss.item())      # (HIP vs HIP: the two jitters move the loss by ~3e-4)
+    # drop-in
+    torch.manual_seed(0)
+    n = 400
+    tx = torch.rand(n, 2)
+    ty = O.testfun(tx) if full else O.testfun(tx)[:, 0].contiguous()
+    H = getattr(dsvgp, harness)
+    model, likelihood = H.train_gp(TensorDataset(tx, ty), 2, num_inducing=16, minibatch_size=100, num_epochs=30, use_ciq=True,
+                                   learning_rate_ngd=0.1, num_contour_quadrature=15, tqdm=False, seed=3)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert len(losses) >= 2 and all(math.isfinite(v) for v in losses) and losses[-1] < losses[0]
+    assert model.engine.whitening == "ciq" and model.engine.kzz_jitter == 1e-2 and model.engine.ciq_kxx_jitter == 1e-4
+    assert "variational_strategy._variational_distribution.natural_mat" in model.state_dict()
+    means, variances = H.eval_gp(TensorDataset(tx[:50], ty[:50]), model, likelihood, minibatch_size=25)
+    assert torch.isfinite(means).all() and (variances > 0).all()
