@@ -46,6 +46,18 @@ class RBFKernelDirectionalGrad(torch.nn.Module):
         assert n_dir1 == n_dir2, "v1 and v2 must contain same number of directions"
         self.set_num_directions(n_dir1)
         ctx = _ops.Context.get(x1.device)
+        if x1.dtype == torch.float64:                   # fp64 model mode (exp_script.py:56): csrc/assemble64.hip
+            hyp = torch.stack([self.lengthscale.reshape(()).to(x1), *torch.tensor([1.0, 0.0, 0.0]).to(x1)]).contiguous()
+            if not diag:
+                x1c = x1.contiguous()
+                center = x1c.mean(0).contiguous()
+                p1 = _ops.pack_points_f64(ctx, x1c, v1.double().contiguous(), n_dir1, hyp, center)
+                p2 = _ops.pack_points_f64(ctx, x2.double().contiguous(), v2.double().contiguous(), n_dir2, hyp, center)
+                return _ops.kernel_fwd_f64(ctx, p1, n1, p2, n2, d, n_dir1, hyp)
+            if not (n1 == n2 and torch.eq(x1, x2).all() and torch.eq(v1, v2).all()):
+                raise RuntimeError("diag=True only works when x1 == x2 and v1 == v2")
+            row = torch.cat([torch.ones(1).to(x1), (1.0 / hyp[0] ** 2).expand(n_dir2)])
+            return row.repeat(n2)
         hyp = self._hyp(x1.device)
         if not diag:
             x1c = x1.float().contiguous()

@@ -50,6 +50,12 @@ SIGNATURES = {
     "dsvgp_kernel_diag": (_i, [_p, _i, _i, _p, _p]),
     "dsvgp_kernel_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_kernel_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "dsvgp_pack_points_f64": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "dsvgp_kernel_transform_f64": (_i, [_p, _p, _l, _p, _i, _p, _i, _i, _p, _d]),
+    "dsvgp_kernel_bwd_transform_f64": (_i, [_p, _p, _l, _p, _l, _p, _i, _p, _i, _i, _p, _p]),
+    "dsvgp_kernel_bwd_points_f64": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "dsvgp_colstats_f64": (_i, [_p, _p, _l, _p, _l, _p, _i, _i, _p, _p]),
+    "dsvgp_abar_f64": (_i, [_p, _p, _l, _p, _l, _p, _p, _p, _i, _i, _p, _l, _p, _l]),
     "dsvgp_potrf_workspace_bytes": (_z, [_i, _i]),
     "dsvgp_potrf": (_i, [_p, _p, _i, _l, _p, _i, _p]),
     "dsvgp_add_diag": (_i, [_p, _p, _i, _l, _d]),

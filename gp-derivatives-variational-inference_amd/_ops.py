@@ -142,6 +142,75 @@ def kernel_fwd(ctx, pack1, n1, pack2, n2, d, p, hyp, jitter=0.0, out=None, dtype
     return out
 
 
+# ---- fp64 model mode (csrc/assemble64.hip) ---------------------------------------------------------------------
+def pack_points_f64(ctx, x, v, p, hyp, center=None):
+    """-> (P[n(p+1), DP], self[n(p+1)], vnorm[n p]) in double precision"""
+    _req(x, f64, "x", 2)
+    n, d = x.shape
+    if p > 0:
+        _req(v, f64, "v", 2)
+        if v.shape != (n * p, d):
+            raise ValueError("directions must be [n*p, d] = [%d, %d], got %s" % (n * p, d, tuple(v.shape)))
+    if not x.is_contiguous() or (p > 0 and not v.is_contiguous()):
+        raise ValueError("x and v must be contiguous")
+    DP = packed_width(d)
+    P = torch.empty(n * (p + 1), DP, dtype=f64, device=x.device)
+    sf = torch.empty(n * (p + 1), dtype=f64, device=x.device)
+    vn = torch.empty(max(n * p, 1), dtype=f64, device=x.device)
+    check(lib.dsvgp_pack_points_f64(ctx.h, _ptr(x), _ptr(v if p > 0 else None), n, d, p, _ptr(_req(hyp, f64, "hyp", 1)),
+                                    _ptr(center), _ptr(P), _ptr(sf), _ptr(vn)), "dsvgp_pack_points_f64")
+    return P, sf, vn
+
+
+def kernel_fwd_f64(ctx, pack1, n1, pack2, n2, d, p, hyp, jitter=0.0, out=None):
+    """outputscale * K(x1, x2; v1, v2) [+ jitter I] in fp64: T = P1 P2^T on the fp64 MFMA GEMM, micro-block transform in place"""
+    q = p + 1
+    if out is None:
+        out = torch.empty(n1 * q, n2 * q, dtype=f64, device=pack1[0].device)
+    _req(out, f64, "out", 2)
+    K4 = (d + 3) // 4 * 4
+    gemm(ctx, _lib.TRANS_B, pack1[0], pack2[0], out, M=n1 * q, N=n2 * q, K=K4)
+    check(lib.dsvgp_kernel_transform_f64(ctx.h, _ptr(out), _ld(out), _ptr(pack1[1]), n1, _ptr(pack2[1]), n2, p, _ptr(hyp),
+                                         float(jitter)), "dsvgp_kernel_transform_f64")
+    return out
+
+
+def kernel_bwd_f64(ctx, G, pack1, n1, pack2, n2, d, p, hyp, symmetric, d_x1, d_v1, d_hyp, scratch=None):
+    """backward of kernel_fwd_f64 w.r.t. (x1, v1, lengthscale, outputscale); accumulates into d_x1, d_v1, d_hyp[0..1]"""
+    q = p + 1
+    _req(G, f64, "G", 2)
+    K4 = (d + 3) // 4 * 4
+    DP = pack1[0].shape[1]
+    T = scratch if scratch is not None else torch.empty(n1 * q, n2 * q, dtype=f64, device=G.device)
+    gemm(ctx, _lib.TRANS_B, pack1[0], pack2[0], T, M=n1 * q, N=n2 * q, K=K4)
+    check(lib.dsvgp_kernel_bwd_transform_f64(ctx.h, _ptr(G), _ld(G), _ptr(T), _ld(T), _ptr(pack1[1]), n1, _ptr(pack2[1]), n2, p,
+                                             _ptr(hyp), _ptr(_req(d_hyp, f64, "d_hyp", 1))), "dsvgp_kernel_bwd_transform_f64")
+    dP = torch.empty(n1 * q, DP, dtype=f64, device=G.device)
+    gemm(ctx, 0, T, pack2[0], dP)                                   # Tbar [P2 | indicator]
+    check(lib.dsvgp_kernel_bwd_points_f64(ctx.h, _ptr(dP), _ptr(pack1[0]), _ptr(pack1[2]), n1, d, p, _ptr(hyp),
+                                          1 if symmetric else 0, _ptr(_req(d_x1, f64, "d_x1", 2)),
+                                          _ptr(d_v1 if p > 0 else None)), "dsvgp_kernel_bwd_points_f64")
+
+
+def colstats_f64(ctx, A, W, m):
+    """(mu0 = A^T m, cs = colsum(W^2 - A^2)) in fp64; W None -> cs None"""
+    _req(A, f64, "A", 2); _req(m, f64, "m", 1)
+    Mp, Bp = A.shape
+    mu = torch.empty(Bp, dtype=f64, device=A.device)
+    cs = torch.empty(Bp, dtype=f64, device=A.device) if W is not None else None
+    check(lib.dsvgp_colstats_f64(ctx.h, _ptr(A), _ld(A), _ptr(W), _ld(W) if W is not None else 0, _ptr(m), Mp, Bp, _ptr(mu),
+                                 _ptr(cs)), "dsvgp_colstats_f64")
+    return mu, cs
+
+
+def abar_f64(ctx, A, U, m, mu_bar, var_bar, Abar, Av=None):
+    _req(A, f64, "A", 2); _req(Abar, f64, "Abar", 2)
+    Mp, Bp = A.shape
+    check(lib.dsvgp_abar_f64(ctx.h, _ptr(A), _ld(A), _ptr(U), _ld(U) if U is not None else 0, _ptr(_req(m, f64, "m", 1)),
+                             _ptr(_req(mu_bar, f64, "mu_bar", 1)), _ptr(_req(var_bar, f64, "var_bar", 1)), Mp, Bp, _ptr(Abar),
+                             _ld(Abar), _ptr(Av), _ld(Av) if Av is not None else 0), "dsvgp_abar_f64")
+
+
 def kernel_diag(ctx, n, p, hyp):
     out = torch.empty(n * (p + 1), dtype=f32, device=hyp.device)
     check(lib.dsvgp_kernel_diag(ctx.h, n, p, _ptr(hyp), _ptr(out)), "dsvgp_kernel_diag")

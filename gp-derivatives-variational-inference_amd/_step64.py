@@ -1,0 +1,230 @@
+"""fp64 model mode of the DSVGP step.
+
+The reference's experiment drivers switch the whole model to double precision (``torch.set_default_dtype(torch.float64)``,
+experiments/synthetic/exp_script.py:56 and the other exp scripts): parameters, data, kernel matrices, the whitening solve
+and the ELBO are then all fp64.  ``ElboEngine64`` is that mode of ``directional_vi.train_gp`` / ``DirectionalGradVariationalStrategy
+.forward`` (DGVS.py:89-208) on the MI355X:
+
+  * every O(M'^2 d), O(M' B' d), O(M'^3) and O(M'^2 B') term runs on the library's own HIP kernels -- the fp64 kernel assembly
+    (csrc/assemble64.hip: T = P1 P2^T on the fp64 MFMA GEMM + per-pair transforms), the blocked MFMA Cholesky with fused inverse
+    (csrc/potrf.hip), the triangular products (csrc/gemm64.hip / gemm.hip) and the column statistics (assemble64.hip);
+  * the O(B') likelihood terms, the O(M'^2) KL term and the softplus constraints are elementwise torch fp64 tensor
+    expressions on the device, differentiated by autograd exactly like the reference does (directional_vi.py:245-249).
+
+It is the general (variance-carrying) formulation, so ELBO and PLL are both covered; it is not the benchmark path (the
+headline configs run the reference's default fp32 model) and it is single-rank.  No CPU fallback: the inputs must be HIP tensors.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, _ops
+from ._step import CHOL_TRIES, PARAM_NAMES, ElboEngine, NotPSDError
+
+KXX_JITTER = 1e-4       # data_data_covar.add_jitter(1e-4), DGVS.py:202
+MIN_VARIANCE = 1e-6     # MultivariateNormal.variance clamp (gpytorch settings.min_variance)
+NOISE_FLOOR = 1e-4      # GaussianLikelihood noise constraint GreaterThan(1e-4)
+
+f64 = torch.float64
+TRANS_A, TRANS_B = _lib.TRANS_A, _lib.TRANS_B
+A_LOWER, A_UPPER, B_LOWER, OUT_LOWER = _lib.A_LOWER, _lib.A_UPPER, _lib.B_LOWER, _lib.OUT_LOWER
+
+
+class ElboEngine64(ElboEngine):
+    """Double-precision DSVGP step on one GPU (see module docstring).  Same call surface as ``ElboEngine``."""
+
+    dtype = f64
+
+    def __init__(self, device, trsm_nb=None):
+        super().__init__(device, trsm_nb)
+        self.elbo_fast = False
+
+    # ---- forward pieces -----------------------------------------------------------------------
+    def _check(self, params, x, D):
+        for k in PARAM_NAMES:
+            if k not in params:
+                raise NotImplementedError("fp64 model mode covers the Cholesky-whitened DSVGP parameterisation (%s missing)" % k)
+            if params[k].dtype != f64:
+                raise TypeError("fp64 model mode: parameter %s is %s" % (k, params[k].dtype))
+            if not params[k].is_cuda:
+                raise _lib.DsvgpError("%s must live on the GPU: the DSVGP hot path has no CPU fallback" % k)
+        if x.dtype != f64 or (D is not None and D.numel() and D.dtype != f64):
+            raise TypeError("fp64 model mode: inputs must be float64")
+        if self.whitening != "cholesky" or self.shared_directions:
+            raise NotImplementedError("fp64 model mode covers the Cholesky-whitened strategies only")
+        if self.collective is not None and self.collective.world > 1:
+            raise NotImplementedError("fp64 model mode is single-rank")
+
+    def _hyp64(self, params, grad=False):
+        """(raw leaves, hyp[4] = {lengthscale, outputscale, noise, 0}): gpytorch Positive / GreaterThan(1e-4) softplus constraints"""
+        raw = [params[k].detach().reshape(()).clone().requires_grad_(grad)
+               for k in ("raw_lengthscale", "raw_outputscale", "raw_noise")]
+        ell, s, noise = F.softplus(raw[0]), F.softplus(raw[1]), F.softplus(raw[2]) + NOISE_FLOOR
+        return raw, (ell, s, noise), torch.stack([ell, s, noise, torch.zeros_like(ell)]).detach().contiguous()
+
+    def _factor64(self, ctx, params, hyp, nrhs):
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        Mp = M * (p + 1)
+        self._problem_size(Mp)
+        self.center = Z.mean(0).contiguous()
+        packZ = _ops.pack_points_f64(ctx, Z.contiguous(), V.contiguous(), p, hyp, self.center)
+        L = self._get("L", (Mp, Mp), f64)
+        info = self._get("info", (1,), torch.int32)
+        nrhs = max(int(nrhs), Mp + 1)
+        ws = self._bytes("trsm_ws", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, nrhs, self.trsm_nb))
+        for t in range(-1, CHOL_TRIES):                         # psd_safe_cholesky: plain, then jitter * 10^t
+            _ops.kernel_fwd_f64(ctx, packZ, M, packZ, M, d, p, hyp, jitter=self.kzz_jitter, out=L)
+            if t >= 0:
+                _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
+            self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs, "kzz")
+            if int(info.item()) == 0:
+                break
+        else:
+            raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
+                              % (self.chol_jitter * 10 ** (CHOL_TRIES - 1)))
+        self._inverse_ws = ws
+        return packZ, L, (M, d, p, Mp), ws
+
+    def _interp64(self, ctx, params, hyp, packZ, L, dims, ws, x, D):
+        """K_ZX, A = L^-1 K_ZX, W = L_S^T A, mu0 = A^T m, cs = colsum(W^2 - A^2): all fp64"""
+        M, d, p, Mp = dims
+        B = x.shape[0]
+        pd = self._pd(p)
+        Bp = B * (pd + 1)
+        packX = _ops.pack_points_f64(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        if pd != p:                                             # derivative-free data: value columns of the full block matrix
+            full = self._get("Kzx_full", (Mp, B * (p + 1)), f64)
+            _ops.kernel_fwd_f64(ctx, packZ, M, packX, B, d, p, hyp, out=full)
+            Kzx = self._get("Kzx", (Mp, Bp), f64)
+            Kzx.copy_(full[:, ::p + 1])
+        else:
+            Kzx = self._get("Kzx", (Mp, Bp), f64)
+            _ops.kernel_fwd_f64(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        A = self._get("A64", (Mp, Bp), f64)
+        _ops.trsm(ctx, L, Kzx, False, A, None, self.trsm_nb, ws, reuse_inverse=True)
+        W = self._get("W", (Mp, Bp), f64)
+        _ops.gemm(ctx, TRANS_A | A_UPPER, params["chol_variational_covar"], A, W)      # tril(L_S)^T A
+        mu0, cs = _ops.colstats_f64(ctx, A, W, params["variational_mean"].contiguous())
+        return packX, A, W, mu0, cs
+
+    @staticmethod
+    def _prior_diag(B, p, pd, ell, s, like):
+        """s * diag K_XX (RBFKernelDirectionalGrad.py:110-119): 1 for value rows, 1/ell^2 for derivative rows"""
+        row = torch.cat([torch.ones(1, dtype=f64, device=like.device), (1.0 / ell ** 2).expand(pd)]) if pd else \
+            torch.ones(1, dtype=f64, device=like.device)
+        return s * row.repeat(B)
+
+    # ---- public API -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict(self, params, x, D, cache=False):
+        ctx = _ops.Context.get(self.device)
+        self._check(params, x, D)
+        _, (ell, s, noise), hyp = self._hyp64(params)
+        Mz = params["inducing_points"].shape[0]
+        pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
+        packZ, L, dims, ws = self._factor64(ctx, params, hyp, x.shape[0] * (self._pd(pz) + 1))
+        _, _, _, mu0, cs = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+        p = dims[2]
+        var = self._prior_diag(x.shape[0], p, self._pd(p), ell, s, x) + KXX_JITTER + cs
+        return mu0 + params["constant"].reshape(()), (var + noise).clamp_min(MIN_VARIANCE)
+
+    def predict_joint(self, params, x, D, cache=False):
+        raise NotImplementedError("fp64 model mode: joint predictive covariance not built")
+
+    @torch.no_grad()
+    def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True, fast=None):
+        """(loss, grads dict, mu, varn), all fp64; see ``ElboEngine.loss_and_grads`` for the arguments."""
+        ctx = _ops.Context.get(self.device)
+        self._check(params, x, D)
+        self._eval_cache = None
+        dev = self.device
+        m = params["variational_mean"].contiguous()
+        LS = params["chol_variational_covar"]
+        Mz = params["inducing_points"].shape[0]
+        pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
+        B = x.shape[0]
+        pd = self._pd(pz)
+        Bp = B * (pd + 1)
+        if y.shape != (Bp,) or y.dtype != f64:
+            raise ValueError("y must be the interleaved float64 target vector of length B*(p+1)=%d" % Bp)
+        rows = float(Bp if global_rows is None else global_rows)
+
+        raw, _, hyp = self._hyp64(params)
+        packZ, L, dims, ws = self._factor64(ctx, params, hyp, Bp)
+        M, d, p, Mp = dims
+        packX, A, W, mu0, cs = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+
+        # ---- O(B') likelihood terms, O(M'^2) KL, constraints: torch fp64 expressions + autograd (directional_vi.py:245-249) ----
+        with torch.enable_grad():
+            raw, (ell, s, noise), _ = self._hyp64(params, grad=True)
+            mu0_, cs_ = mu0.requires_grad_(True), cs.requires_grad_(True)
+            c_ = params["constant"].detach().reshape(()).clone().requires_grad_(True)
+            m_ = m.detach().clone().requires_grad_(True)
+            LS_ = LS.detach().clone().requires_grad_(True)
+            mu = mu0_ + c_
+            var = self._prior_diag(B, p, pd, ell, s, x) + KXX_JITTER + cs_
+            varn = (var + noise).clamp_min(MIN_VARIANCE)
+            if mll_type == "ELBO":
+                ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+            elif mll_type == "PLL":
+                tot = (varn + noise).clamp_min(1e-8)
+                ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
+            else:
+                raise ValueError("mll_type must be 'ELBO' or 'PLL'")
+            loss = -ll.sum() / rows
+            if include_kl:
+                LSl = torch.tril(LS_)
+                kl = 0.5 * ((m_ * m_).sum() + (LSl * LSl).sum() - Mp - torch.log(torch.diagonal(LSl) ** 2).sum())
+                loss = loss + kl / num_data
+            leaves = [mu0_, cs_, c_, raw[0], raw[1], raw[2]] + ([m_, LS_] if include_kl else [])
+            g = torch.autograd.grad(loss, leaves, allow_unused=True)
+        mu_bar, var_bar, dc = g[0].contiguous(), g[1].contiguous(), g[2]
+        zero = torch.zeros((), dtype=f64, device=dev)
+        d_raw = [t if t is not None else zero for t in g[3:6]]
+        grads = {k: torch.zeros_like(params[k]) for k in PARAM_NAMES}
+        dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
+        if include_kl:
+            dm.add_(g[6])
+            dLS.add_(g[7])
+
+        # ---- variational parameters: m-bar += A mu_bar, L_S-bar += tril(2 A diag(var_bar) W^T) ----
+        U = self._get("U", (Mp, Bp), f64)
+        _ops.gemm(ctx, A_LOWER, LS, W, U)                                           # U = tril(L_S) W
+        Abar = self._get("Abar", (Mp, Bp), f64)
+        Av = self._get("Av", (Mp, Bp), f64)
+        _ops.abar_f64(ctx, A, U, m, mu_bar, var_bar, Abar, Av)
+        tmp = self._get("dLS_data", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, Av, W, tmp)
+        dLS.add_(torch.tril(tmp))
+        dmd = torch.empty(Mp, 1, dtype=f64, device=dev)
+        _ops.gemm(ctx, 0, A, mu_bar.reshape(Bp, 1), dmd)
+        dm.add_(dmd.reshape(-1))
+
+        # ---- through the solve and the factorisation ----
+        Kb = self._get("Kb64", (Mp, Bp), f64)
+        _ops.trsm(ctx, L, Abar, True, Kb, None, self.trsm_nb, ws, reuse_inverse=True)     # K_ZX-bar = L^-T Abar
+        Lbar = self._get("Lbar", (Mp, Mp), f64)
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb, A, Lbar, alpha=-1.0)                      # L-bar = -tril(K_ZX-bar A^T)
+        dZ, dV = grads["inducing_points"], grads["inducing_directions"]
+        d_hyp = torch.zeros(4, dtype=f64, device=dev)
+        if pd != p:
+            full = self._get("Kzx_full", (Mp, B * (p + 1)), f64)
+            full.zero_()
+            full[:, ::p + 1] = Kb
+            Kb = full
+        scratch = self._get("T_zx", (Mp, B * (p + 1)), f64)
+        _ops.kernel_bwd_f64(ctx, Kb, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, scratch)
+        Kzzbar = self._chol_backward(ctx, L, Lbar, ws, Mp)
+        scratch = self._get("T_zz", (Mp, Mp), f64)
+        _ops.kernel_bwd_f64(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, scratch)
+
+        # softplus chain rule of the kernel hyper-parameters; autograd already holds the likelihood / prior-diagonal parts
+        sig = [torch.sigmoid(params[k].reshape(())) for k in ("raw_lengthscale", "raw_outputscale")]
+        grads["raw_lengthscale"].add_((d_raw[0] + d_hyp[0] * sig[0]).reshape(grads["raw_lengthscale"].shape))
+        grads["raw_outputscale"].add_((d_raw[1] + d_hyp[1] * sig[1]).reshape(grads["raw_outputscale"].shape))
+        grads["raw_noise"].add_(d_raw[2].reshape(grads["raw_noise"].shape))
+        grads["constant"].add_(dc.reshape(grads["constant"].shape))
+        return loss.detach(), grads, mu.detach(), varn.detach()

@@ -29,7 +29,7 @@ from .DirectionalGradVariationalStrategy import DirectionalGradVariationalStrate
 from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
                       NaturalVariationalDistribution, PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
-from .optim import NGD, FusedAdam
+from .optim import NGD, FusedAdam, make_adam
 from .parallel import DataParallel
 
 
@@ -108,16 +108,19 @@ def select_cols_of_y(y_batch, minibatch_dim, dim):
     return y_batch, derivative_directions
 
 
-def _dataset_tensors(dataset, device):
-    """Materialise a torch Dataset of (x[d], y[d+1]) pairs as two HBM-resident float32 matrices."""
+def _dataset_tensors(dataset, device, dtype=None):
+    """Materialise a torch Dataset of (x[d], y[d+1]) pairs as two HBM-resident matrices: float32, or float64 when the
+    process runs with ``torch.set_default_dtype(torch.float64)`` like the reference's experiment scripts (exp_script.py:56)."""
+    if dtype is None:
+        dtype = torch.float64 if torch.get_default_dtype() == torch.float64 else torch.float32
     tensors = getattr(dataset, "tensors", None)
     if tensors is not None and len(tensors) == 2:
         X, Y = tensors
     else:
         xs, ys = zip(*[dataset[i] for i in range(len(dataset))])
         X, Y = torch.stack(xs), torch.stack(ys)
-    return (X.to(device=device, dtype=torch.float32).contiguous(),
-            Y.to(device=device, dtype=torch.float32).contiguous())
+    return (X.to(device=device, dtype=dtype).contiguous(),
+            Y.to(device=device, dtype=dtype).contiguous())
 
 
 class TrainLoop:
@@ -137,7 +140,7 @@ class TrainLoop:
         self.device = X.device
         self.dim = X.shape[1]
         self.ctx = _ops.Context.get(self.device)
-        self.E_canonical = torch.eye(self.dim, device=self.device)
+        self.E_canonical = torch.eye(self.dim, device=self.device, dtype=X.dtype)
         self.graph = None                       # HIP-graph replay of the step: True = on (also DSVGP_GRAPH=1), None / False = eager
         self._graphs, self._graph_seen, self._graph_pending = {}, {}, None
 
@@ -192,9 +195,13 @@ class TrainLoop:
         dim, p, dev = self.dim, self.minibatch_dim, self.device
         nb = idx.shape[0]
         self.ctx.bind()                         # the library launches on torch's CURRENT stream (the capture stream under a graph)
-        x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
-        y_batch = torch.empty(nb * (py + 1), dtype=torch.float32, device=dev)
-        _ops.gather_batch(self.ctx, self.X, self.Y, idx, cols, py, x_batch, y_batch)  # interleaved y, :241
+        if self.X.dtype == torch.float64:       # fp64 model mode: plain index_select (O(B d) copies)
+            x_batch = self.X.index_select(0, idx)
+            y_batch = self.Y.index_select(0, idx).index_select(1, cols.long()).reshape(-1)
+        else:
+            x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
+            y_batch = torch.empty(nb * (py + 1), dtype=torch.float32, device=dev)
+            _ops.gather_batch(self.ctx, self.X, self.Y, idx, cols, py, x_batch, y_batch)  # interleaved y, :241
         kwargs = {}
         if self.dfree:                          # dfree_directional_vi.py:224-227
             kwargs["derivative_directions"] = self.E_canonical[:p].repeat(nb, 1)
@@ -346,10 +353,10 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
     if inducing_data_initialization is True:
         inducing_points = X[:num_inducing].clone()                        # first M data rows, :140-145
     else:
-        inducing_points = torch.rand(num_inducing, dim).to(device)        # :149
-    inducing_directions = torch.eye(dim)[:num_directions].repeat(num_inducing, 1).to(device)
+        inducing_points = torch.rand(num_inducing, dim).to(X)             # :149
+    inducing_directions = torch.eye(dim)[:num_directions].repeat(num_inducing, 1).to(X)
     if shared and inducing_data_initialization is not True:          # shared_directional_vi.py:150-155: not tiled
-        inducing_directions = torch.eye(dim)[:num_directions].to(device)
+        inducing_directions = torch.eye(dim)[:num_directions].to(X)
 
     learn_inducing_locations = True
     if fixed_inducing_locations is not None:
@@ -366,8 +373,8 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
         model = model_class(inducing_points, inducing_directions, dim,
                             learn_inducing_locations=learn_inducing_locations)
     likelihood = GaussianLikelihood()
-    model = model.to(device)
-    likelihood = likelihood.to(device)
+    model = model.to(X)                      # device and dtype of the data (fp64 model mode: see _step64)
+    likelihood = likelihood.to(X)
     model.train()
     likelihood.train()
 
@@ -395,8 +402,8 @@ def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_
     if use_ngd or use_ciq:                                                # :186-187
         variational_optimizer = NGD(list(model.variational_parameters()), num_data=num_data, lr=learning_rate_ngd)
     else:
-        variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
-    hyperparameter_optimizer = FusedAdam([
+        variational_optimizer = make_adam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
+    hyperparameter_optimizer = make_adam([
         {"params": list(model.hyperparameters())},
         {"params": list(likelihood.parameters())},
     ], lr=learning_rate_hypers)
@@ -485,7 +492,7 @@ def eval_gp(test_dataset, model, likelihood,
     assert num_directions == minibatch_dim
     dim = len(test_dataset[0][0])
     device = model.variational_strategy.inducing_points.device
-    X, _ = _dataset_tensors(test_dataset, device)
+    X, _ = _dataset_tensors(test_dataset, device, model.variational_strategy.inducing_points.dtype)
     n_test = X.shape[0]
 
     model.eval()

@@ -275,9 +275,12 @@ class ApproximateGP(torch.nn.Module):
 
     @property
     def engine(self):
-        dev = self.variational_strategy.inducing_points.device
-        if self._engine is None or self._engine.device != dev:
-            self._engine = ElboEngine(dev)
+        Z = self.variational_strategy.inducing_points
+        cls = ElboEngine
+        if Z.dtype == torch.float64:        # model built under torch.set_default_dtype(torch.float64) (exp_script.py:56)
+            from ._step64 import ElboEngine64 as cls
+        if self._engine is None or self._engine.device != Z.device or type(self._engine) is not cls:
+            self._engine = cls(Z.device)
         return self._engine
 
     def variational_parameters(self):

@@ -18,7 +18,7 @@ from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .directional_vi import TrainLoop, _dataset_tensors
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
                       NaturalVariationalDistribution, PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
-from .optim import NGD, FusedAdam
+from .optim import NGD, FusedAdam, make_adam
 from .parallel import DataParallel
 
 
@@ -82,15 +82,15 @@ def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_e
     X, Y = tensors if tensors is not None else _dataset_tensors(train_dataset, device)
     n_samples = X.shape[0]
 
-    inducing_points = torch.rand(num_inducing, dim).to(device)            # :61
+    inducing_points = torch.rand(num_inducing, dim).to(X)            # :61
     if use_ciq:                                                           # grad_svgp.py:63-65
-        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD", variational_strategy="CIQ").to(device)
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD", variational_strategy="CIQ").to(X)
         model.engine.ciq_num_quadrature = int(args.get("num_contour_quadrature", 15))
     elif use_ngd:                                                         # grad_svgp.py:66-67
-        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(device)
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(X)
     else:
-        model = GPModel(inducing_points=inducing_points).to(device)
-    likelihood = GaussianLikelihood().to(device)
+        model = GPModel(inducing_points=inducing_points).to(X)
+    likelihood = GaussianLikelihood().to(X)
     model.train()
     likelihood.train()
 
@@ -113,8 +113,8 @@ def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_e
     if use_ngd or use_ciq:                                                # grad_svgp.py:87-88
         variational_optimizer = NGD(list(model.variational_parameters()), num_data=n_samples, lr=learning_rate_ngd)
     else:
-        variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
-    hyperparameter_optimizer = FusedAdam([
+        variational_optimizer = make_adam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
+    hyperparameter_optimizer = make_adam([
         {"params": list(model.hyperparameters())},
         {"params": list(likelihood.parameters())},
     ], lr=learning_rate_hypers)
@@ -189,7 +189,7 @@ def train_gp(train_dataset, dim, num_inducing=128,
 
 def eval_gp(test_dataset, model, likelihood, mll_type="ELBO", num_inducing=128, minibatch_size=1):
     device = model.variational_strategy.inducing_points.device
-    X, _ = _dataset_tensors(test_dataset, device)
+    X, _ = _dataset_tensors(test_dataset, device, model.variational_strategy.inducing_points.dtype)
     model.eval()
     likelihood.eval()
     means, variances = [], []

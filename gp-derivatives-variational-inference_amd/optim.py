@@ -12,6 +12,9 @@ class NGD(torch.optim.Optimizer):
     (reference directional_vi.py:186-187)."""
 
     def __init__(self, params, num_data, lr=0.1):
+        params = list(params)
+        if any(p.dtype != torch.float32 for p in params):
+            raise NotImplementedError("NGD: natural-gradient updates are built for the fp32 model only")
         self.num_data = num_data
         super().__init__(params, defaults=dict(lr=lr))
 
@@ -108,3 +111,13 @@ class FusedAdam(torch.optim.Optimizer):
                     else:
                         _ops.adam_step_multi_(ctx, ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], step)
         return loss
+
+
+def make_adam(param_groups, lr=1e-3):
+    """torch.optim.Adam(param_groups, lr) of the reference loop (directional_vi.py:189-198): the fused multi-tensor HIP update for
+    the fp32 model, torch's own Adam for the fp64 model mode (``_step64``; the update is O(parameters) elementwise work)."""
+    groups = list(param_groups)
+    tensors = [p for g in groups for p in (g["params"] if isinstance(g, dict) else [g])]
+    if any(p.dtype == torch.float64 for p in tensors):
+        return torch.optim.Adam(groups, lr=lr)
+    return FusedAdam(groups, lr=lr)

@@ -19,7 +19,7 @@ from .directional_vi import TrainLoop, _dataset_tensors
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
                       NaturalVariationalDistribution, PredictiveDistribution, PredictiveLogLikelihood, ScaleKernel,
                       VariationalELBO)
-from .optim import NGD, FusedAdam
+from .optim import NGD, FusedAdam, make_adam
 from .parallel import DataParallel
 
 
@@ -100,15 +100,15 @@ def train_gp(train_dataset, dim, num_inducing=128,
         Y = Y.reshape(-1, 1).contiguous()
     n_samples = X.shape[0]
 
-    inducing_points = torch.rand(num_inducing, dim).to(device)            # :57
+    inducing_points = torch.rand(num_inducing, dim).to(X)            # :57
     if use_ciq:                                                           # :59-61
-        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD", variational_strategy="CIQ").to(device)
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD", variational_strategy="CIQ").to(X)
         model.engine.ciq_num_quadrature = int(num_contour_quadrature)
     elif use_ngd:
-        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(device)
+        model = GPModel(inducing_points=inducing_points, variational_distribution="NGD").to(X)
     else:
-        model = GPModel(inducing_points=inducing_points).to(device)
-    likelihood = GaussianLikelihood().to(device)
+        model = GPModel(inducing_points=inducing_points).to(X)
+    likelihood = GaussianLikelihood().to(X)
     model.train()
     likelihood.train()
 
@@ -132,8 +132,8 @@ def train_gp(train_dataset, dim, num_inducing=128,
     if use_ngd or use_ciq:                                                # :72-73
         variational_optimizer = NGD(list(model.variational_parameters()), num_data=n_samples, lr=learning_rate_ngd)
     else:
-        variational_optimizer = FusedAdam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
-    hyperparameter_optimizer = FusedAdam([
+        variational_optimizer = make_adam([{"params": list(model.variational_parameters())}], lr=learning_rate_hypers)
+    hyperparameter_optimizer = make_adam([
         {"params": list(model.hyperparameters())},
         {"params": list(likelihood.parameters())},
     ], lr=learning_rate_hypers)
@@ -190,7 +190,7 @@ def train_gp(train_dataset, dim, num_inducing=128,
 def eval_gp(test_dataset, model, likelihood, mll_type="ELBO", num_inducing=128, minibatch_size=1):
     """Predictive means / variances (with likelihood noise), CPU vectors of length N_test (traditional_vi.py:153-178)."""
     device = model.variational_strategy.inducing_points.device
-    X, _ = _dataset_tensors(test_dataset, device)
+    X, _ = _dataset_tensors(test_dataset, device, model.variational_strategy.inducing_points.dtype)
     model.eval()
     likelihood.eval()
     means, variances = [], []

@@ -97,6 +97,30 @@ int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double
                      const float* self2, int n2, int d, int p, const float* hyp, int symmetric,
                      float* d_x1, float* d_v1, float* d_hyp, void* workspace);
 
+/* ---- fp64 model mode (the reference's experiments set torch.set_default_dtype(torch.float64),
+ * experiments/synthetic/exp_script.py:56): RBFKernelDirectionalGrad.forward / backward in double precision.
+ * Same packed-row formulation as the fp32 assembly; the two contractions T = P1 P2^T and dP1 = Tbar P2 go through
+ * dsvgp_gemm (fp64 MFMA), these entry points do the rest:
+ *   dsvgp_pack_points_f64           x[n,d], v[n*p,d] -> P[n(p+1), DP] (DP = dsvgp_packed_width(d)), self, vnorm (doubles)
+ *   dsvgp_kernel_transform_f64      T[n1(p+1), n2(p+1)] -> outputscale * K in place (+ jitter on the global diagonal)
+ *   dsvgp_kernel_bwd_transform_f64  (G = dLoss/dK, T) -> Tbar in place of T; d_hyp[0] += d lengthscale, d_hyp[1] += d outputscale
+ *   dsvgp_kernel_bwd_points_f64     dP1[n1(p+1), DP] = Tbar [P2 | indicator] -> d_x1 +=, d_v1 += (x2 when symmetric)
+ * hyp: device double[3+] = {lengthscale, outputscale, noise}.  p <= 16.                                              */
+int dsvgp_pack_points_f64(dsvgp_ctx* ctx, const double* x, const double* v, int n, int d, int p, const double* hyp,
+                          const double* center, double* P, double* self, double* vnorm);
+int dsvgp_kernel_transform_f64(dsvgp_ctx* ctx, double* T, int64_t ld, const double* self1, int n1, const double* self2,
+                               int n2, int p, const double* hyp, double jitter);
+int dsvgp_kernel_bwd_transform_f64(dsvgp_ctx* ctx, const double* G, int64_t ldg, double* T, int64_t ldt, const double* self1,
+                                   int n1, const double* self2, int n2, int p, const double* hyp, double* d_hyp);
+ /* fp64 column statistics and their backward (DGVS.py:188,192-205): mu_j = sum_i A_ij m_i, cs_j = sum_i (W_ij^2 - A_ij^2) (W may be
+ * NULL: mean only);  Abar = m mu_bar^T + 2 (U - A) diag(var_bar), Av = 2 A diag(var_bar) (U NULL: U = A; Av may be NULL) */
+int dsvgp_colstats_f64(dsvgp_ctx* ctx, const double* A, int64_t lda, const double* W, int64_t ldw, const double* m, int Mp, int Bp,
+                       double* mu, double* cs);
+int dsvgp_abar_f64(dsvgp_ctx* ctx, const double* A, int64_t lda, const double* U, int64_t ldu, const double* m, const double* mu_bar,
+                   const double* var_bar, int Mp, int Bp, double* Abar, int64_t ldo, double* Av, int64_t ldv);
+int dsvgp_kernel_bwd_points_f64(dsvgp_ctx* ctx, const double* dP, const double* P1, const double* vnorm1, int n1, int d,
+                                int p, const double* hyp, int symmetric, double* d_x1, double* d_v1);
+
 /* ---- Cholesky: psd_safe_cholesky(K_ZZ.double()) (DirectionalGradVariationalStrategy.py:72-75)
  * In-place lower Cholesky of the row-major fp64 matrix A[n,n] (rocSOLVER dpotrf); only the lower
  * triangle is read/written.  info_dev is a device int (0 = ok, k>0 = leading minor k not PD).   */

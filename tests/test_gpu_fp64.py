@@ -1,0 +1,245 @@
+"""GPU parity tests of the fp64 model mode (``torch.set_default_dtype(torch.float64)`` in the reference's experiment
+scripts, experiments/synthetic/exp_script.py:56): the fp64 kernel assembly against the reference-generated golden
+vectors and the oracle, the full step (loss, every gradient, predictive moments) against the fp64 oracle, and the
+``train_gp`` / ``eval_gp`` drop-in run under a float64 default dtype.
+
+Stated tolerance (everything is double precision on both sides; what remains is summation order and the cond(K_ZZ)
+amplification of ~1e3 through the Cholesky backward): kernel entries 1e-12, loss 1e-9 relative, predictive moments 1e-9,
+gradients 1e-7 relative in max-norm per parameter."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dsvgp_oracle as O
+from _golden import GOLDEN, kernel_error
+
+pytestmark = pytest.mark.gpu
+f64 = torch.float64
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+def _kernel64(dsvgp, dev, x1, x2, v1, v2, ell, s=1.0, jitter=0.0):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(dev)
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    p = v1.shape[0] // n1 if n1 else 0
+    hyp = torch.tensor([ell, s, 0.1, 0.0], dtype=f64, device=dev)
+    x1d = x1.double().to(dev).contiguous()
+    center = x1d.mean(0).contiguous()
+    p1 = ops.pack_points_f64(ctx, x1d, v1.double().to(dev).contiguous(), p, hyp, center)
+    p2 = ops.pack_points_f64(ctx, x2.double().to(dev).contiguous(), v2.double().to(dev).contiguous(), p, hyp, center)
+    return ops.kernel_fwd_f64(ctx, p1, n1, p2, n2, d, p, hyp, jitter=jitter), (ctx, hyp, p1, p2)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_kernel_fwd_f64_matches_reference_golden_vectors(dsvgp, gpu_device, path):
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(g[k])
+    if int(g["p"]) > 16:
+        pytest.skip("fp64 assembly keeps p <= 16 directions in registers")
+    K, _ = _kernel64(dsvgp, gpu_device, t("x1"), t("x2"), t("v1"), t("v2"), float(g["lengthscale"]))
+    e_sub, e_sum = kernel_error(K, g)
+    print("kernel_fwd_f64 %s: error %.2e (row/col sums %s)" % (os.path.basename(path), e_sub,
+                                                                "%.2e" % e_sum if e_sum is not None else "-"))
+    assert e_sub < 1e-12 and (e_sum is None or e_sum < 1e-12)
+
+
+@pytest.mark.parametrize("n1,n2,d,p", [(37, 53, 5, 2), (16, 16, 20, 5), (9, 130, 3, 0), (20, 11, 10, 10), (7, 40, 45, 1),
+                                       (130, 7, 2, 1), (5, 6, 17, 16)])
+def test_kernel_f64_forward_backward_random_shapes(dsvgp, gpu_device, n1, n2, d, p):
+    """forward vs the oracle's pair-wise kernel; backward (x1, v1, lengthscale, outputscale) vs autograd through it"""
+    g = torch.Generator().manual_seed(n1 * 1000 + n2)
+    x1, x2 = torch.rand(n1, d, generator=g, dtype=f64), torch.rand(n2, d, generator=g, dtype=f64)
+    v1 = torch.randn(n1 * p, d, generator=g, dtype=f64)
+    v2 = torch.randn(n2 * p, d, generator=g, dtype=f64)
+    ell, s = 0.9, 1.7
+    K, (ctx, hyp, p1, p2) = _kernel64(dsvgp, gpu_device, x1, x2, v1, v2, ell, s, jitter=0.0)
+    xr, vr = x1.clone().requires_grad_(True), v1.clone().requires_grad_(True)
+    er, sr = torch.tensor(ell, dtype=f64, requires_grad=True), torch.tensor(s, dtype=f64, requires_grad=True)
+    Kref = sr * O.kernel_matrix(xr, x2, vr, v2, er)
+    assert relmax(K, Kref.detach()) < 1e-12
+    G = torch.randn(K.shape, generator=g, dtype=f64)
+    (Kref * G).sum().backward()
+    ops = dsvgp._ops
+    dx = torch.zeros(n1, d, dtype=f64, device=gpu_device)
+    dv = torch.zeros(max(n1 * p, 1), d, dtype=f64, device=gpu_device)[:n1 * p]
+    d_hyp = torch.zeros(4, dtype=f64, device=gpu_device)
+    ops.kernel_bwd_f64(ctx, G.to(gpu_device), p1, n1, p2, n2, d, p, hyp, False, dx, dv, d_hyp)
+    errs = dict(dx=relmax(dx, xr.grad), dell=abs(d_hyp[0].item() - er.grad.item()) / abs(er.grad.item()),
+                ds=abs(d_hyp[1].item() - sr.grad.item()) / abs(sr.grad.item()))
+    if p:
+        errs["dv"] = relmax(dv, vr.grad)
+    print("[parity] kernel_bwd_f64 %s: %s" % ((n1, n2, d, p), errs))
+    assert max(errs.values()) < 1e-10
+
+
+def test_kernel_f64_symmetric_backward_and_jitter(dsvgp, gpu_device):
+    """K_ZZ: the same points on both sides (gradient flows through both arguments), jitter on the diagonal only"""
+    g = torch.Generator().manual_seed(3)
+    n, d, p = 23, 6, 3
+    x = torch.rand(n, d, generator=g, dtype=f64)
+    v = torch.randn(n * p, d, generator=g, dtype=f64)
+    K, (ctx, hyp, p1, _) = _kernel64(dsvgp, gpu_device, x, x, v, v, 0.7, 1.3, jitter=1e-3)
+    xr, vr = x.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    Kref = 1.3 * O.kernel_matrix(xr, xr, vr, vr, torch.tensor(0.7, dtype=f64))
+    assert relmax(K, Kref.detach() + 1e-3 * torch.eye(K.shape[0], dtype=f64)) < 1e-12
+    G = torch.randn(K.shape, generator=g, dtype=f64)
+    G = G + G.t()                                      # the engine's K_ZZ-bar is symmetric
+    (Kref * G).sum().backward()
+    ops = dsvgp._ops
+    dx = torch.zeros(n, d, dtype=f64, device=gpu_device)
+    dv = torch.zeros(n * p, d, dtype=f64, device=gpu_device)
+    d_hyp = torch.zeros(4, dtype=f64, device=gpu_device)
+    ops.kernel_bwd_f64(ctx, G.to(gpu_device), p1, n, p1, n, d, p, hyp, True, dx, dv, d_hyp)
+    assert relmax(dx, xr.grad) < 1e-10 and relmax(dv, vr.grad) < 1e-10
+
+
+def make_problem64(N, d, M, p, B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(N, d, generator=g, dtype=f64)
+    Y = O.testfun(X)
+    Z = X[:M].clone()
+    V = torch.eye(d, dtype=f64)[:p].repeat(M, 1) + 0.1 * torch.randn(M * p, d, generator=g, dtype=f64)
+    P = O.init_params(Z, V, f64, mean_init_std=0.2, generator=g)
+    Mp = M * (p + 1)
+    P["chol_variational_covar"] = torch.eye(Mp, dtype=f64) + 0.05 * torch.randn(Mp, Mp, generator=g, dtype=f64)
+    P["constant"] = torch.tensor([0.1], dtype=f64)
+    P["raw_outputscale"] = torch.tensor(0.2, dtype=f64)
+    P["raw_lengthscale"] = torch.tensor([[0.3]], dtype=f64)
+    P["raw_noise"] = torch.tensor([-0.5], dtype=f64)
+    cols = sorted([0] + (torch.randperm(d, generator=g)[:p] + 1).tolist())
+    x = X[M:M + B].contiguous()
+    y = Y[M:M + B][:, cols].reshape(-1).contiguous()
+    D = torch.eye(d, dtype=f64)[[c - 1 for c in cols[1:]]].repeat(B, 1)
+    return P, x, y, D, (d + 1) * N
+
+
+CASES = [
+    # N, d, M, p, B
+    (400, 2, 20, 2, 200),      # reference tests/test_dsvgp.py sizes
+    (600, 5, 40, 2, 128),      # scaled-down C2
+    (500, 20, 30, 5, 96),      # C4 geometry
+    (300, 4, 25, 4, 50),       # p == d
+    (300, 6, 70, 0, 64),       # p = 0
+    (300, 7, 18, 3, 33),       # odd sizes
+]
+
+
+@pytest.mark.parametrize("N,d,M,p,B", CASES)
+@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+def test_fp64_step_matches_fp64_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
+    from dsvgp_amd._step64 import ElboEngine64
+    P, x, y, D, nd = make_problem64(N, d, M, p, B, seed=N + d)
+    assert all(v.dtype == f64 for v in P.values())
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd, mll)
+    eng = ElboEngine64(gpu_device)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
+    torch.cuda.synchronize()
+    assert loss.dtype == f64 and all(v.dtype == f64 for v in grads.values())
+    errs = {"loss": abs(loss.item() - l_ref.item()) / abs(l_ref.item()), "mu": relmax(mu, mu_ref), "var": relmax(varn, var_ref)}
+    assert errs["loss"] < 1e-9 and errs["mu"] < 1e-9 and errs["var"] < 1e-9, errs
+    for k in O.PARAM_NAMES:
+        if k == "inducing_directions" and p == 0:
+            continue
+        gk, rk = grads[k], g_ref[k]
+        if k == "chol_variational_covar":
+            assert torch.triu(gk, 1).abs().max().item() == 0.0
+        errs[k] = relmax(gk, rk)
+    print("[parity] fp64 step %s %s: %s" % ((N, d, M, p, B), mll, ", ".join("%s %.1e" % kv for kv in errs.items())))
+    assert max(errs[k] for k in O.PARAM_NAMES if k in errs) < 1e-7, errs
+    # prediction entry point
+    mu_p, var_p = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu_p, mu_ref) < 1e-9 and relmax(var_p, var_ref) < 1e-9
+
+
+def test_fp64_dfree_data_outputs(dsvgp, gpu_device):
+    """derivative-free data (DFreeDirectionalGradVariationalStrategy.py:113-136) in the fp64 mode"""
+    from dsvgp_amd._step64 import ElboEngine64
+    P, x, y, D, nd = make_problem64(300, 5, 24, 2, 60, seed=9)
+    y = y.reshape(60, 3)[:, 0].contiguous()
+    l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd, "ELBO", data_outputs="values")
+    eng = ElboEngine64(gpu_device)
+    eng.data_outputs = "values"
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO")
+    assert abs(loss.item() - l_ref.item()) / abs(l_ref.item()) < 1e-9
+    assert relmax(mu, mu_ref) < 1e-9 and relmax(varn, var_ref) < 1e-9
+    for k in O.PARAM_NAMES:
+        assert relmax(grads[k], g_ref[k]) < 1e-7, k
+
+
+def test_fp64_mode_refuses_what_it_does_not_cover(dsvgp, gpu_device):
+    from dsvgp_amd._step64 import ElboEngine64
+    P, x, y, D, nd = make_problem64(200, 3, 10, 1, 20, seed=1)
+    eng = ElboEngine64(gpu_device)
+    with pytest.raises(dsvgp._lib.DsvgpError):                     # host tensors: no CPU fallback
+        eng.loss_and_grads(P, x, y, D, nd)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    with pytest.raises(TypeError):                                 # fp32 data into the fp64 model
+        eng.loss_and_grads(Pg, x.float().to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    eng.whitening = "ciq"
+    with pytest.raises(NotImplementedError):
+        eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+
+
+def test_operator_forward_fp64(dsvgp, gpu_device):
+    """RBFKernelDirectionalGrad.forward on float64 inputs (the reference's tests/test_dsvgp.py builds it under a fp64 default)"""
+    g = torch.Generator().manual_seed(5)
+    n1, n2, d, p = 12, 9, 4, 2
+    x1, x2 = torch.rand(n1, d, generator=g, dtype=f64), torch.rand(n2, d, generator=g, dtype=f64)
+    v1, v2 = torch.randn(n1 * p, d, generator=g, dtype=f64), torch.randn(n2 * p, d, generator=g, dtype=f64)
+    k = dsvgp._rbf_mod.RBFKernelDirectionalGrad().to(device=gpu_device, dtype=f64)
+    K = k(x1.to(gpu_device), x2.to(gpu_device), v1=v1.to(gpu_device), v2=v2.to(gpu_device))
+    ell = torch.nn.functional.softplus(torch.zeros((), dtype=f64))
+    assert K.dtype == f64 and relmax(K, O.kernel_matrix(x1, x2, v1, v2, ell)) < 1e-12
+    dg = k(x1.to(gpu_device), x1.to(gpu_device), diag=True, v1=v1.to(gpu_device), v2=v1.to(gpu_device))
+    assert relmax(dg, O.kernel_diag(n1, p, ell)) < 1e-14
+
+
+def test_train_gp_eval_gp_under_float64_default(dsvgp, gpu_device):
+    """the reference's experiment setting: torch.set_default_dtype(torch.float64) before building data and model"""
+    from torch.utils.data import TensorDataset
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(0)
+        n, d, M, p, B = 400, 2, 20, 2, 200
+        X = torch.rand(n, d)
+        Y = O.testfun(X)
+        assert X.dtype == f64
+        model, lik = dsvgp.train_gp(TensorDataset(X, Y), num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
+                                    num_epochs=3, seed=0, verbose=False)
+        prm = model._param_dict(lik)
+        assert all(v.dtype == f64 for v in prm.values())
+        from dsvgp_amd._step64 import ElboEngine64
+        assert isinstance(model.engine, ElboEngine64)
+        # one more step from the trained state: engine (through the harness objects) vs the fp64 oracle
+        P = {k: v.detach().cpu().clone() for k, v in prm.items()}
+        xb, yb = X[:B], Y[:B][:, [0, 1, 2]].reshape(-1)
+        Db = torch.eye(d)[[0, 1]].repeat(B, 1)
+        l_ref, g_ref, _, _ = O.elbo_loss_and_grads(P, xb, yb, Db, (d + 1) * n, "ELBO")
+        out = lik(model(xb.to(gpu_device), derivative_directions=Db.to(gpu_device)))
+        mll = dsvgp.gp_shim.VariationalELBO(lik, model, num_data=(d + 1) * n)
+        model.zero_grad(); lik.zero_grad()
+        loss = -mll(out, yb.to(gpu_device))
+        loss.backward()
+        assert abs(loss.item() - l_ref.item()) / abs(l_ref.item()) < 1e-9
+        vs = model.variational_strategy
+        assert relmax(vs.inducing_points.grad, g_ref["inducing_points"]) < 1e-7
+        assert relmax(vs._variational_distribution.chol_variational_covar.grad, g_ref["chol_variational_covar"]) < 1e-7
+        means, variances = dsvgp.eval_gp(TensorDataset(X[:50], Y[:50]), model, lik, num_directions=p, minibatch_size=25,
+                                         minibatch_dim=p)
+        assert means.dtype == f64 and means.shape == (50 * (p + 1),) and bool((variances > 0).all())
+        mu_ref, var_ref = O.predictive(P, X[:50], torch.eye(d)[:p].repeat(50, 1))
+        _, _, noise = O.constrained(P)
+        assert relmax(means, mu_ref) < 1e-9 and relmax(variances, var_ref + noise) < 1e-9
+    finally:
+        torch.set_default_dtype(prev)
