@@ -278,8 +278,9 @@ extern "C" int dsvgp_colstats_f64(dsvgp_ctx* ctx, const double* A, int64_t lda, 
                                   int Mp, int Bp, double* mu, double* cs) {
     if (!ctx || !A || !m || !mu || (W && !cs) || Mp < 0 || Bp < 0 || lda < Bp || (W && ldw < Bp)) return DSVGP_EINVAL;
     if (Bp == 0) return 0;
-    hipMemsetAsync(mu, 0, sizeof(double) * Bp, ctx->stream);
-    if (W) hipMemsetAsync(cs, 0, sizeof(double) * Bp, ctx->stream);
+    hipError_t e;
+    if ((e = hipMemsetAsync(mu, 0, sizeof(double) * Bp, ctx->stream)) != hipSuccess) return 1000 + (int)e;
+    if (W && (e = hipMemsetAsync(cs, 0, sizeof(double) * Bp, ctx->stream)) != hipSuccess) return 1000 + (int)e;
     if (Mp == 0) return 0;
     const int splits = max(1, min(64, Mp / 64));
     hipLaunchKernelGGL(colstats64_kernel, dim3(cdiv(Bp, 64), splits), dim3(256), 0, ctx->stream, A, lda, W, ldw, m, Mp, Bp, mu, cs);

@@ -2,11 +2,8 @@
 # tools only: build potrf.hip with -DPOTRF_DEBUG and print in-kernel cycle stamps of the diagonal workgroup of the
 # fused Cholesky step kernel (block column 20 of a 3000 x 3000 matrix)
 set -e
-R=${GRAFT_REPO_ROOT:-/root/repo}; C=$R/gp-derivatives-variational-inference_amd/csrc; B=/tmp/potrf_dbg; mkdir -p $B
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed -I$R/include -I$C"
-for f in gemm gemm64 elbo assemble ciq api; do hipcc $FL -c $C/$f.hip -o $B/$f.o & done; wait
-hipcc $FL -DPOTRF_DEBUG ${POTRF_DEFS} -c $C/potrf.hip -o $B/potrf.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libdsvgp_hip.so $B/potrf.o $B/assemble.o $B/gemm.o $B/elbo.o $B/ciq.o $B/gemm64.o $B/api.o -L/opt/rocm/lib -lrocsolver -lrocblas
+R=${GRAFT_REPO_ROOT:-/root/repo}; B=$(mktemp -d /tmp/potrf_dbg_XXXX)
+$R/tools/build_variant.sh $B "potrf.hip:-DPOTRF_DEBUG ${POTRF_DEFS}"
 DSVGP_LIB_PATH=$B/libdsvgp_hip.so python - <<'PY'
 import os, sys, ctypes
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -14,9 +14,11 @@ Z, V = torch.rand(M, d, device=dev), torch.eye(d, device=dev)[:p].repeat(M, 1)
 pz = ops.pack_points(ctx, Z, V, p, hyp)
 K = ops.kernel_fwd(ctx, pz, M, pz, M, d, p, hyp, jitter=1e-3, dtype=torch.float64)
 info = torch.zeros(1, dtype=torch.int32, device=dev)
-for algo in (0, 1, 0, 1):
+ALGOS, REPS = (0, 1, 0, 1), 6
+print("probe: runs_algo1=%d reps=%d" % (ALGOS.count(1), REPS))      # read by tools/potrf_trace.sh
+for algo in ALGOS:
     ts = []
-    for rep in range(6):
+    for rep in range(REPS):
         A = K.clone()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); ops.potrf_(ctx, A, info, algo); e1.record(); torch.cuda.synchronize()
