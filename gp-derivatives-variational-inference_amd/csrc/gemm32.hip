@@ -150,7 +150,11 @@ __device__ __forceinline__ bool pick_unit(const G32& g, int& m0, int& n0, int& k
 
 // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (c & 3) + 8 (c >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ void store_tile(const G32& g, const acc16 (&acc)[2][2], int m0, int n0, int wr, int wc, int h, int r) {
+#ifdef G32_ABL_NOATOMIC          // (timing ablation only: wrong results under split-K)
+    const bool atomic = false, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
+#else
     const bool atomic = g.splitk > 1, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -16,6 +16,12 @@ constexpr int NBC = 64;
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
 #endif
+#ifndef POTRF_FOLD
+#define POTRF_FOLD 0
+#endif
+#ifndef POTRF_PIPE
+#define POTRF_PIPE 0        // k-steps per operand chunk of tile_product (0: all 16 first)
+#endif
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
 #pragma unroll
@@ -40,10 +46,21 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // -------------------------------------------------------------------------------------------------
 using acc4 = double __attribute__((ext_vector_type(4)));
 #ifdef POTRF_DEBUG
-__device__ unsigned long long chol_dbg[16];
-#define CHOL_STAMP(slot) do { if (tid == 0 && b == 0 && k == 20) chol_dbg[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef POTRF_DEBUG_K
+#define POTRF_DEBUG_K 20      // block column whose critical workgroup is stamped
+#endif
+__device__ unsigned long long chol_dbg[32];
+// stamps pinned in place (the scalar s_memtime would otherwise be scheduled ahead of the MFMAs it is meant to follow) and kept
+// in registers until the end of the kernel (a global store per stamp would sit in vmcnt and stretch the waits that follow it)
+#define CHOL_STAMP_DECL unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CHOL_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[slot]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CHOL_STAMP_FLUSH do { if (b == 0 && k == POTRF_DEBUG_K) { if (tid == 0) { for (int q_ = 0; q_ < 8; ++q_) chol_dbg[q_] = st_[q_]; chol_dbg[28] = st_[11]; } \
+        if ((tid & 63) == 0) { chol_dbg[16 + (tid >> 6)] = st_[8]; chol_dbg[20 + (tid >> 6)] = st_[9]; chol_dbg[24 + (tid >> 6)] = st_[10]; } } } while (0)
 #else
+#define CHOL_STAMP_DECL
 #define CHOL_STAMP(slot) do { } while (0)
+#define CHOL_STAMP_FLUSH do { } while (0)
 #endif
 constexpr int LDT = 66;                       // LDS row stride of a 64 x 64 tile (doubles)
 
@@ -56,14 +73,48 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // 64 x 64 x 64 product by 4 waves (wave -> 32 x 32 outputs):  acc[i][j] = sum_q Aop[m][q] * Bop(q, n)
 //   B_NK: Bop(q, n) = Bs[n][q]   (B given as [n][k]);  else Bop(q, n) = Bs[q][n]
-template <bool B_NK, int NW = 4>
+//   ACC_INIT: the caller has loaded the accumulators (acc += product)
+template <bool B_NK, int NW = 4, bool ACC_INIT = false>
 __device__ __forceinline__ void tile_product(const double (*As)[LDT], const double (*Bs)[LDT], int lane, int wr, int wc,
                                              acc4 (&acc)[2][8 / NW]) {
     constexpr int NJ = 8 / NW;            // 16-column sub-tiles per wave: 2 (4 waves, 32 x 32 each) or 1 (8 waves, 32 x 16 each)
+    if constexpr (!ACC_INIT) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+    }
+#if POTRF_PIPE
+    // operands in chunks of POTRF_PIPE k-steps, the reads of chunk c + 1 issued before the MFMAs of chunk c (everything
+    // unrolled: the accumulators never leave the AGPRs); the matrix pipe starts after the first chunk instead of after all 64 reads
+    constexpr int CH = POTRF_PIPE, NC = 16 / CH;
+    double a[2][2][CH], b[2][NJ][CH];
+    auto fetch = [&](int c, int slot) {
+#pragma unroll
+        for (int kc = 0; kc < CH; ++kc) {
+            const int kq = 4 * (c * CH + kc) + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[slot][i][kc] = As[wr * 32 + i * 16 + (lane & 15)][kq];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = wc * (16 * NJ) + j * 16 + (lane & 15);
+                b[slot][j][kc] = B_NK ? Bs[n][kq] : Bs[kq][n];
+            }
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) fetch(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int kc = 0; kc < CH; ++kc)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c & 1][i][kc], b[c & 1][j][kc], acc[i][j], 0, 0, 0);
+    }
+#else
     // all operands of the wave first, then back-to-back MFMAs: the loops are
     // fully unrolled (a rolled loop moves the accumulators AGPR <-> VGPR and drains the MFMA pipe every trip)
     double a[2][16], b[NJ][16];
@@ -85,6 +136,7 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+#endif
 }
 
 // one wave: Cholesky factor L_d (in place, upper part zeroed) and inverse Xd = L_d^-1 of the 16 x 16 block at F[o.., o..].
@@ -129,11 +181,21 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
         const double li = ci * rinv;                                // L[i][j]  (0 above the diagonal, sqrt(a_jj) on it)
         const double ls = (i == j) ? 0.0 : li;
         ri = (i == j) ? rinv : ri;
+#if POTRF_FOLD
+        // multipliers folded once per column: a -= (l_i / l_jj) a_cj, y -= (l_i / l_jj) y_j   (2 products instead of 8)
+        const double ma = -li * rinv, my = -ls * rinv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = fma(ma, cc[t], a[t]);
+            y[t] = fma(my, rr[t], y[t]);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             a[t] = fma(-li, cc[t] * rinv, a[t]);
             y[t] = fma(-ls, rr[t] * rinv, y[t]);
         }
+#endif
         if (g == gj) a[tj] = li;
     }
     if (lane == 0 && bad >= 0 && o + bad < nvalid && *info == 0) *info = gidx0 + o + bad + 1;   // LAPACK convention
@@ -181,11 +243,11 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
     for (int kb = 0; kb < 4; ++kb) {
         const int o = kb * 16;
 #ifdef POTRF_DEBUG
-        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[8] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && kb == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[8] = __builtin_amdgcn_s_memtime();
 #endif
         if (wave == 0) factor16_wave(F, o, Xd, colbuf, rowbuf, lane, info, gidx0, nvalid);
 #ifdef POTRF_DEBUG
-        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[9] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && kb == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[9] = __builtin_amdgcn_s_memtime();
 #endif
         __syncthreads();
         // (b) 4 tasks, one per wave: panel blocks ib > kb, row-block kb of X (cb < kb), and X_{kb,kb} = Xd
@@ -208,7 +270,7 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
         }
         __syncthreads();
 #ifdef POTRF_DEBUG
-        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[10] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && kb == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[10] = __builtin_amdgcn_s_memtime();
 #endif
         // (c) trailing sub-blocks:  F_{ib,jb} -= L_{ib,kb} L_{jb,kb}^T (kb < jb <= ib),  Y_{ib,cb} -= L_{ib,kb} X_{kb,cb} (cb <= kb).
         // Look-ahead: wave 0 updates only the NEXT diagonal sub-block (from the panel block it produced itself) and goes
@@ -264,7 +326,8 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
             }
         }
 #ifdef POTRF_DEBUG
-        if (tid == 0 && kb == 0 && gidx0 == 21 * 64) chol_dbg[11] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && kb == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[11] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[12 + kb] = __builtin_amdgcn_s_memtime();      // end of sub-step kb
 #endif
     }
     if (wave > 0 && wave < 4) {
@@ -307,14 +370,32 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     const double* Lk = ytile ? (Xws + (size_t)k * 4096) : (Wws + (size_t)k * 4096);
     // two LDS tiles only (two workgroups per CU): R_kj waits in registers until T = A_ik W_k has been formed
     double rc[NU];
+    double ro[2][NJ][4];      // R-tile: the old R_ij, requested with the operands (not as 16 load -> wait -> store round trips at the end)
+    double* const rdst = Rw + (int64_t)(i0 + wr * 32 + (lane >> 4)) * ldr + j0 + wc * (16 * NJ) + (lane & 15);
     {
         double ra[NU], rb[NU];
+        const int64_t arow0 = (int64_t)(i0 + (tid >> 6)) * lda, alast = (int64_t)(n - 1) * lda, astep = (int64_t)NW * lda;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int r = (tid >> 6) + NW * u, c = tid & 63;
-            ra[u] = ytile ? 0.0 : A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
+            ra[u] = ytile ? 0.0 : A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
             rb[u] = Lk[r * 64 + c];
             rc[u] = (j == k) ? ((r == c) ? 1.0 : 0.0) : Rw[(int64_t)(k0 + r) * ldr + j0 + c];
+        }
+        if (!ytile && j != k) {              // (R is padded to whole blocks: no clamping)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ro[i][jj][q] = rdst[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ro[i][jj][q] = 0.0;
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -326,29 +407,34 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     __syncthreads();
     acc4 acc[2][NJ];
     if (!ytile) {
+#ifdef POTRF_ABL_P1
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = acc4{1e-3, 1e-3, 1e-3, 1e-3};
+#else
         tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k
+#endif
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + jj * 16 + (lane & 15)] = acc[i][jj][q];
+                for (int q = 0; q < 4; ++q) {       // -T to LDS, accumulators restart from the old R_ij: the second product leaves R_ij - T R_kj
+                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + jj * 16 + (lane & 15)] = -acc[i][jj][q];
+                    acc[i][jj][q] = ro[i][jj][q];
+                }
 #pragma unroll
         for (int u = 0; u < NU; ++u) S[1][(tid >> 6) + NW * u][tid & 63] = rc[u];
         __syncthreads();
-        tile_product<false, NW>(S[0], S[1], lane, wr, wc, acc);         // T R_kj
+        tile_product<false, NW, true>(S[0], S[1], lane, wr, wc, acc);   // R_ij - T R_kj
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * (16 * NJ) + jj * 16 + (lane & 15);
-                    double* dst = Rw + (int64_t)(i0 + ml) * ldr + j0 + nl;
-                    *dst = ((j == k) ? 0.0 : *dst) - acc[i][jj][q];
-                }
+                for (int q = 0; q < 4; ++q) rdst[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16] = acc[i][jj][q];
     } else {
         tile_product<false, NW>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
         if (YT == nullptr) {
@@ -411,6 +497,7 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     const int tj = b - ti * (ti + 1) / 2;
     const int i0 = (k + 1 + ti) * 64, j0 = (k + 1 + tj) * 64;
     double (*F)[LDT] = S[0];
+    CHOL_STAMP_DECL;
     CHOL_STAMP(0);
     if (k >= 0) {
         const int k0 = k * 64;
@@ -419,23 +506,28 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
         double rb[NU];         // A_jk, parked until T = A_ik W_k is in LDS
         {   // all 48 + 16 loads of a thread in flight at once (a rolled loop pays the global latency 16 times)
             double ra[NU], rw[NU];
+            const int64_t alast = (int64_t)(n - 1) * lda, astep = (int64_t)NW * lda;
+            const int64_t arow0 = (int64_t)(i0 + (tid >> 6)) * lda, brow0 = (int64_t)(j0 + (tid >> 6)) * lda;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
+            for (int u = 0; u < NU; ++u) {       // (rows past the matrix: clamped to the last row, zeroed on the way to LDS)
                 const int r = (tid >> 6) + NW * u, c = tid & 63;
-                ra[u] = A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
-                rb[u] = A[(int64_t)min(j0 + r, n - 1) * lda + k0 + c];
+                ra[u] = A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
+                rb[u] = A[((j0 + r < n) ? brow0 + u * astep : alast) + k0 + c];
                 rw[u] = Wk[r * 64 + c];
             }
+            const int m0 = i0 + wr * 32 + (lane >> 4);
+            const int64_t crow0 = (int64_t)m0 * lda;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
+                for (int j = 0; j < NJ; ++j) {
+                    const int nn = min(j0 + wc * (16 * NJ) + j * 16 + (lane & 15), n - 1);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int m = min(i0 + wr * 32 + i * 16 + (lane >> 4) + 4 * q, n - 1);
-                        const int nn = min(j0 + wc * (16 * NJ) + j * 16 + (lane & 15), n - 1);
-                        cv[i][j][q] = A[(int64_t)m * lda + nn];
+                        const int dm = i * 16 + 4 * q;
+                        cv[i][j][q] = A[((m0 + dm < n) ? crow0 + (int64_t)dm * lda : alast) + nn];
                     }
+                }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int r = (tid >> 6) + NW * u, c = tid & 63;
@@ -446,38 +538,78 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
         __syncthreads();
         CHOL_STAMP(1);
         acc4 acc[2][NJ];
+#ifdef POTRF_ABL_P1     // timing ablation (wrong numbers): every tile but the critical one skips its first product
+        if (b == 0) tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);
+        else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{1e-3, 1e-3, 1e-3, 1e-3};
+        }
+#else
         tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
+#endif
+        CHOL_STAMP(4);
         __syncthreads();
+        CHOL_STAMP(5);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + j * 16 + (lane & 15)] = acc[i][j][q];
+                for (int q = 0; q < 4; ++q) {       // -T to LDS, the accumulators restart from the C tile: the second product leaves C - T A_jk^T
+                    S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + j * 16 + (lane & 15)] = -acc[i][j][q];
+                    acc[i][j][q] = cv[i][j][q];
+                }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int r = (tid >> 6) + NW * u, c = tid & 63;
             S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
         }
         __syncthreads();
-        tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T A_jk^T
+        CHOL_STAMP(6);
+        tile_product<true, NW, true>(S[0], S[1], lane, wr, wc, acc);    // C - T A_jk^T
+        CHOL_STAMP(7);
+        CHOL_STAMP(8);
         const bool diag = ti == tj;
-        if (b == 0) __syncthreads();                                // F aliases the T tile: every wave is done reading it
+        const int ml0 = wr * 32 + (lane >> 4), nl0 = wc * (16 * NJ) + (lane & 15);
+        if (b != 0) {                                               // ordinary tile: back to global memory, done
+            double* const cdst = A + (int64_t)(i0 + ml0) * lda + j0 + nl0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ml = ml0 + i * 16 + 4 * q, nl = nl0 + j * 16;
+                        if (i0 + ml < n && j0 + nl < n && !(diag && nl > ml))
+                            cdst[(int64_t)(i * 16 + 4 * q) * lda + j * 16] = acc[i][j][q];
+                    }
+            return;
+        }
+        __syncthreads();                                            // F aliases the T tile: every wave is done reading it
+#ifndef POTRF_ABL_TWICE
+        CHOL_STAMP(10);
+#endif
+#ifdef POTRF_ABL_TWICE      // diagnostic: the same code a second time (first-touch effects: instruction cache)
+#pragma unroll 1
+        for (int rep_ = 0; rep_ < 2; ++rep_) {
+        if (rep_ == 1) CHOL_STAMP(10);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int ml = wr * 32 + i * 16 + (lane >> 4) + 4 * q, nl = wc * (16 * NJ) + j * 16 + (lane & 15);
-                    const int m = i0 + ml, nn = j0 + nl;
-                    const bool in = m < n && nn < n && !(diag && nl > ml);
-                    const double v = cv[i][j][q] - acc[i][j][q];
-                    if (b == 0) F[ml][nl] = in ? v : ((ml == nl) ? 1.0 : 0.0);   // identity padding of a ragged last block
-                    else if (in) A[(int64_t)m * lda + nn] = v;
+                    const int ml = ml0 + i * 16 + 4 * q, nl = nl0 + j * 16;
+                    const bool in = i0 + ml < n && j0 + nl < n && nl <= ml;
+                    F[ml][nl] = in ? acc[i][j][q] : ((ml == nl) ? 1.0 : 0.0);   // identity padding of a ragged last block
                 }
-        if (b != 0) return;
+#ifdef POTRF_ABL_TWICE
+        }
+#endif
+        CHOL_STAMP(9);
     } else {
         double ra[NU];
 #pragma unroll
@@ -496,9 +628,28 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     // ---- factor the diagonal tile kk = k + 1 ----
     const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
     double (*Y)[LDT] = S[1];
+#ifdef POTRF_ABL_TWICE      // diagnostic: factor the tile twice (from a register backup), stamp the second pass separately
+    double bk_[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bk_[u] = F[(tid >> 6) + NW * u][tid & 63];
+#pragma unroll 1
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+        if (rep_ == 1) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NU; ++u) F[(tid >> 6) + NW * u][tid & 63] = bk_[u];
+            __syncthreads();
+            CHOL_STAMP(11);
+        }
+        factor64_lds(F, Y, Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
+                     Wws + (size_t)kk * 4096);
+    }
+#else
     factor64_lds(F, Y, Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
                  Wws + (size_t)kk * 4096);
+#endif
     CHOL_STAMP(3);
+    CHOL_STAMP_FLUSH;
 }
 
 // the last block row of L^-1 (its X is produced by the last step launch): Y_kj = X_k R_kj, j <= k = nblk - 1
@@ -592,6 +743,6 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
 
 #ifdef POTRF_DEBUG
 extern "C" int dsvgp_debug_potrf_clock(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 32);
 }
 #endif
