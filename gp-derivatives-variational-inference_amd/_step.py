@@ -322,6 +322,10 @@ class ElboEngine:
             _, _, mu, varn = self._ciq_step(ctx, params, x, None, D, 1.0, "ELBO", None, False, False)
             return mu, varn
         if self.shared_directions:
+            if "natural_vec" in params:                 # natural q(u) over the M + p shared values
+                m32, LS32, _, _ = self._natural_to_mu_chol(ctx, params["natural_vec"], params["natural_mat"])
+                params = {k: v for k, v in params.items() if not k.startswith("natural_")}
+                params["variational_mean"], params["chol_variational_covar"] = m32, LS32
             params, _ = self._shared_expand(params)
             self._no_middle = True
             try:
@@ -338,8 +342,15 @@ class ElboEngine:
         Sigma = s K_XX + 1e-4 I + W^T W - A^T A + noise I: one symmetric kernel assembly and two MFMA Gram products."""
         ctx = _ops.Context.get(self.device)
         if self.whitening == "ciq":
-            raise NotImplementedError("joint predictive covariance is built for the Cholesky-whitened strategies only")
+            # NGD-CIQ: the reference's q(f) carries a DIAGONAL covariance, DiagLazyTensor(predictive_var) (CiqDGVS.py:264-267);
+            # the likelihood adds its noise on that diagonal -- joint samples are independent draws
+            _, _, mu, varn = self._ciq_step(ctx, params, x, None, D, 1.0, "ELBO", None, False, False)
+            return mu, torch.diag(varn)
         if self.shared_directions:
+            if "natural_vec" in params:
+                m32, LS32, _, _ = self._natural_to_mu_chol(ctx, params["natural_vec"], params["natural_mat"])
+                params = {k: v for k, v in params.items() if not k.startswith("natural_")}
+                params["variational_mean"], params["chol_variational_covar"] = m32, LS32
             params, _ = self._shared_expand(params)
             self._no_middle = True
             try:
@@ -462,8 +473,6 @@ class ElboEngine:
         self.variational_grads_global = False
         if self.whitening == "ciq":
             return self._ciq_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, True)
-        if self.shared_directions:
-            return self._shared_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl)
         nat = None
         if "natural_vec" in params:
             # NaturalVariationalDistribution.forward: (theta_1, theta_2) -> (mu, chol S); the step itself is unchanged
@@ -472,10 +481,13 @@ class ElboEngine:
             params = {k: v for k, v in params.items() if not k.startswith("natural_")}
             params["variational_mean"], params["chol_variational_covar"] = m32, LS32
         self._allow_early = nat is None     # (natural / shared parameterisations post-process m-bar and L_S-bar)
-        try:        # first attempt: potrf status read only after the forward solve has been queued
-            out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
-        except _Refactored:
-            out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, True)
+        if self.shared_directions:
+            out = self._shared_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl)
+        else:
+            try:    # first attempt: potrf status read only after the forward solve has been queued
+                out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
+            except _Refactored:
+                out = self._loss_and_grads(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, True)
         if nat is not None:
             loss, grads, mu, varn = out
             self._natural_grads(ctx, grads, *nat)
@@ -591,6 +603,7 @@ class ElboEngine:
         (``_NaturalToMuVarSqrt.backward``): dS through the Cholesky factor, d eta_2 = dS, d eta_1 = dm - 2 dS mu.
         In place in the slots of (dm, dL_S)."""
         Mp = m32.shape[0]
+        self._problem_size(Mp)          # (the shared strategy factors an M(p+1) system in between: back to q(u)'s size)
         dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
         Lbar = self._get("Lbar", (Mp, Mp), f64)
         Lbar.copy_(dLS)

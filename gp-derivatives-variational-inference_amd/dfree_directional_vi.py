@@ -4,6 +4,10 @@ values, the model still learns inducing directional derivatives.  Same engine, `
 Differences from ``directional_vi`` that the reference has and are kept: no ``fixed_inducing_locations`` argument, the
 derivative directions handed to the model are the first p canonical ones (:224-227, no column sampling),
 ``num_data = (dim+1) n`` (:130).
+
+``use_ciq=True`` (:45-47,154-156) selects the ORDINARY ``CiqDirectionalGradVariationalStrategy`` in the reference (there is no
+derivative-free CIQ strategy): its forward returns all B (p + 1) outputs (CiqDGVS.py:197-295) while the targets are the B function
+values, so the reference's own loss evaluation fails on the shapes.  Nothing to mirror; refused up front here.
 """
 import sys
 
@@ -20,7 +24,8 @@ class GPModel(_dvi.GPModel):
     def __init__(self, inducing_points, inducing_directions, dim, **kwargs):
         kwargs.pop("learn_inducing_locations", None)
         if kwargs.get("variational_strategy") == "CIQ":
-            raise NotImplementedError("derivative-free data with the CIQ strategy is not built")
+            raise NotImplementedError("derivative-free data with the CIQ strategy: the reference pairs B (p + 1) CIQ outputs with B "
+                                      "targets (see the module docstring); not built")
         super().__init__(inducing_points, inducing_directions, dim, learn_inducing_locations=True, **kwargs)
 
     @property
@@ -46,7 +51,8 @@ def train_gp(train_dataset, num_inducing=128,
     dfree_directional_vi.py:66-123; ``seed`` / ``max_steps`` as in ``directional_vi.train_gp``)."""
     assert num_directions == minibatch_dim
     if use_ciq:
-        raise NotImplementedError("derivative-free data with the CIQ strategy is not built")
+        raise NotImplementedError("derivative-free data with the CIQ strategy: the reference pairs B (p + 1) CIQ outputs with B "
+                                      "targets (see the module docstring); not built")
     loop = _dvi.setup_training(train_dataset, num_inducing, num_directions, minibatch_size, minibatch_dim, num_epochs,
                                learning_rate_hypers, inducing_data_initialization, lr_sched, mll_type, gamma, None,
                                seed=args.get("seed"), use_ngd=use_ngd, learning_rate_ngd=learning_rate_ngd,

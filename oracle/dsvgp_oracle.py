@@ -370,8 +370,11 @@ def init_natural_params(Z, V, dtype=torch.float32, mean_init_std=0.0, generator=
     return P
 
 
-def ngd_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64):
-    """One step's loss and the gradients gpytorch hands to its optimizers when q(u) is a
+def ngd_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, solve_dtype=torch.float64,
+                       forward=None):
+    """(``forward``: ``elbo_forward`` by default; ``shared_forward`` for the shared-directions strategy with a natural q(u),
+    reference shared_directional_vi.py:37-39,170-171.)
+    One step's loss and the gradients gpytorch hands to its optimizers when q(u) is a
     NaturalVariationalDistribution: ordinary gradients for the hyper-parameters, and for (theta_1, theta_2) the
     gradients with respect to the EXPECTATION parameters eta_1 = mu, eta_2 = S + mu mu^T
     (``_NaturalToMuVarSqrt.backward``) -- stepping theta along them is natural gradient descent."""
@@ -384,7 +387,7 @@ def ngd_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=N
     ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if not k.startswith("natural_")}
     ps["variational_mean"] = eta1.to(dt)
     ps["chol_variational_covar"] = L_S.to(dt)
-    loss, mu, varn = elbo_forward(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype)
+    loss, mu, varn = (forward or elbo_forward)(ps, x, y, D, num_data, mll_type, global_rows, solve_dtype)
     loss.backward()
     grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps
              if k not in ("variational_mean", "chol_variational_covar")}

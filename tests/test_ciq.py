@@ -157,6 +157,18 @@ def test_train_gp_use_ciq_drop_in(dsvgp, gpu_device, capsys):
     means, variances = dsvgp.eval_gp(TensorDataset(train_x[:60], train_y[:60]), model, likelihood,
                                      num_directions=p, minibatch_size=30, minibatch_dim=p)
     assert means.shape == (180,) and (variances > 0).all() and torch.isfinite(means).all()
+    # joint distribution under NGD-CIQ: the reference's q(f) is MultivariateNormal(mean, DiagLazyTensor(var)) (CiqDGVS.py:264-267)
+    model.eval(); likelihood.eval()
+    x = train_x[:20].to(gpu_device)
+    D = torch.eye(dim, device=gpu_device)[:p].repeat(20, 1)
+    preds = likelihood(model(x, derivative_directions=D))
+    Sigma = preds.covariance_matrix
+    assert Sigma.shape == (60, 60) and relmax(torch.diagonal(Sigma), preds.variance) < 1e-6
+    assert (Sigma - torch.diag(torch.diagonal(Sigma))).abs().max().item() == 0.0
+    torch.manual_seed(1)
+    smp = preds.sample(torch.Size([3000]))
+    assert smp.shape == (3000, 60)
+    assert relmax(smp.mean(0), preds.mean) < 0.1 and relmax(smp.var(0), preds.variance) < 0.15
 
 
 @pytest.mark.gpu

@@ -162,3 +162,54 @@ def test_grad_svgp_use_ngd(dsvgp, gpu_device, capsys):
     assert "variational_strategy._variational_distribution.natural_mat" in model.state_dict()
     means, variances = G.eval_gp(TensorDataset(train_x[:40], train_y[:40]), model, likelihood, minibatch_size=20)
     assert means.shape == (120,) and (variances > 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+def test_shared_directions_with_natural_distribution(dsvgp, gpu_device, mll):
+    """shared inducing directions + NaturalVariationalDistribution over the M + p shared values
+    (reference shared_directional_vi.py:37-39,170-171,188-189 with SharedDirectionalGradVariationalStrategy.py:95-107)"""
+    N, d, M, p, B = 400, 4, 14, 2, 80
+    P, x, y, D, nd = make_ngd_problem(N, d, M, p, B, seed=33)
+    g = torch.Generator().manual_seed(7)
+    P["inducing_directions"] = torch.eye(d)[:p] + 0.2 * torch.randn(p, d, generator=g)        # ONE shared set
+    P["natural_vec"] = 0.3 * torch.randn(M + p, generator=g)
+    R = 0.15 * torch.randn(M + p, M + p, generator=g)
+    P["natural_mat"] = -0.5 * (torch.eye(M + p) + R @ R.t())
+    l_ref, g_ref, mu_ref, var_ref = O.ngd_loss_and_grads(P, x, y, D, nd, mll, forward=O.shared_forward)
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.shared_directions = True
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
+    assert set(grads) == set(O.NGD_PARAM_NAMES)
+    assert abs(loss.item() - l_ref.item()) < 2e-5 * abs(l_ref.item())
+    assert relmax(mu, mu_ref) < 2e-4 and relmax(varn, var_ref) < 2e-4
+    for k in O.NGD_PARAM_NAMES:
+        assert grads[k].shape == g_ref[k].shape, k
+        if g_ref[k].abs().max() > 0:
+            assert relmax(grads[k], g_ref[k]) < 5e-3, k
+    mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu2, mu_ref) < 2e-4 and relmax(varn2, var_ref) < 2e-4
+
+
+@pytest.mark.gpu
+def test_shared_train_gp_with_ngd(dsvgp, gpu_device, capsys):
+    from torch.utils.data import TensorDataset
+    torch.manual_seed(0)
+    n, dim, p = 600, 2, 2
+    train_x = torch.rand(n, dim)
+    train_y = O.testfun(train_x)
+    S = dsvgp.shared_directional_vi
+    model, likelihood = S.train_gp(TensorDataset(train_x, train_y), num_inducing=20, num_directions=p, minibatch_size=200,
+                                   minibatch_dim=p, num_epochs=40, inducing_data_initialization=False, use_ngd=True, seed=2,
+                                   learning_rate_ngd=2e-4)     # (the shared strategy's zero middle term leaves S at the prior: the
+                                                                #  natural step on the mean is an un-preconditioned full-data step)
+    out = capsys.readouterr().out
+    losses = [float(l.split("loss: ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("Epoch")]
+    assert len(losses) >= 2 and losses[-1] < losses[0]
+    sd = model.state_dict()
+    assert sd["variational_strategy._variational_distribution.natural_vec"].shape == (20 + p,)
+    assert sd["variational_strategy._variational_distribution.natural_mat"].shape == (20 + p, 20 + p)
+    with pytest.raises(NotImplementedError):              # the reference's own shared + CIQ call is shape-inconsistent
+        S.train_gp(TensorDataset(train_x, train_y), num_inducing=20, num_directions=p, minibatch_size=200, minibatch_dim=p,
+                   num_epochs=1, inducing_data_initialization=False, use_ciq=True, verbose=False)
