@@ -96,7 +96,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 # GEMM flags (include/dsvgp.h)
 TRANS_A, TRANS_B = 1, 2
 A_LOWER, A_UPPER, B_LOWER, B_UPPER = 4, 8, 16, 32
-OUT_LOWER, B_IS_FLOAT, CIN_IS_FLOAT, K_PADDED = 64, 128, 256, 512
+OUT_LOWER, B_IS_FLOAT, CIN_IS_FLOAT, K_PADDED, BACKGROUND = 64, 128, 256, 512, 1024
 
 
 class DsvgpError(RuntimeError):

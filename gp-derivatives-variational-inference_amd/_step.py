@@ -15,6 +15,8 @@ K_XZ is not assembled (it is K_ZX^T) and the second triangular solve of the refe
 repeated (A_t == A); everything else keeps the reference's arithmetic precision: fp32 model, fp64
 Cholesky / triangular solves.
 """
+import os
+
 import torch
 
 from . import _lib, _ops
@@ -77,6 +79,9 @@ class ElboEngine:
         self._potrf_ws = None
         self._inverse_ws = None         # the trsm workspace that holds the inverse of the current factor
         self._side = None               # second HIP stream (work overlapped with the Cholesky chain)
+        # S = L_S L_S^T on the side stream as a one-workgroup-per-CU launch (DSVGP_GEMM_BACKGROUND).  Measured alternatives that
+        # did not help: least-priority side stream (hipStreamCreateWithPriority), CU-masked side stream (hipExtStreamCreateWithCUMask)
+        self.side_background = os.environ.get("DSVGP_SIDE_BACKGROUND", "1") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -848,7 +853,7 @@ class ElboEngine:
         overlap = self.overlap if self.overlap is not None else Mz * (p + 1) >= 2048
         if use_fast and overlap:
             def side_job(c, hyp_):
-                side.update(self._fast_prologue(c, params, hyp_, x, D, rows))
+                side.update(self._fast_prologue(c, params, hyp_, x, D, rows, background=self.side_background))
         if self.capture_mode and not use_fast:
             raise RuntimeError("only the ELBO fast path can be captured into a HIP graph")
         hyp, packZ, L, dims = self._factor(ctx, params, sync=(sync or not use_fast) and not self.capture_mode,
@@ -934,7 +939,7 @@ class ElboEngine:
         loss = loss_out[0]
         return loss, grads, mu, varn
 
-    def _fast_prologue(self, ctx, params, hyp, x, D, rows):
+    def _fast_prologue(self, ctx, params, hyp, x, D, rows, background=False):
         """The part of the ELBO fast path that does not depend on L: K_ZX assembly and [S - I | m / (2 vbar)]."""
         Z, V = params["inducing_points"], params["inducing_directions"]
         M, d = Z.shape
@@ -950,7 +955,10 @@ class ElboEngine:
         # kernel (gemm64.hip) streams a float right-hand side with 16-byte loads
         S32e = self._get("S32e_pad", (Mp, (Mp + 1 + 3) // 4 * 4), f32)[:, :Mp + 1]
         S32 = S32e[:, :Mp]
-        _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER, LS, LS, S32)       # S = tril(L_S) tril(L_S)^T
+        # S = tril(L_S) tril(L_S)^T.  On the side stream it is launched as a one-workgroup-per-CU filler: at full occupancy its
+        # 4600 workgroups leave no CU with the LDS share a Cholesky step workgroup needs, and two launches of the chain wait
+        # 130-190 us each for it to drain
+        _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER | (_lib.BACKGROUND if background else 0), LS, LS, S32)
         _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
         S32e[:, Mp].copy_(m * (hyp[2] * rows))               # m / (2 vbar), 2 vbar = 1 / (noise rows)
         return dict(packX=packX, Kzx=Kzx, S32e=S32e)

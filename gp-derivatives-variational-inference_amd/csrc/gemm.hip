@@ -417,7 +417,20 @@ int launch_one(hipStream_t st, const GemmArgs& g, dim3 grid) {
         return 0;
     }
 #endif
-    hipLaunchKernelGGL((gemm_kernel<TC, TB, AKC, BKC, BN, NTH>), grid, dim3(NTH), 0, st, g);
+    size_t pad = 0;
+    if (g.flags & DSVGP_GEMM_BACKGROUND) {
+        // filler product next to a latency-bound chain on another stream: ONE workgroup per CU (dynamic LDS padding up to
+        // just over half of the CU's 160 KB), so that every CU keeps room for a workgroup of the chain
+        static size_t static_lds = ~(size_t)0;
+        if (static_lds == ~(size_t)0) {
+            hipFuncAttributes at{};
+            static_lds = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&gemm_kernel<TC, TB, AKC, BKC, BN, NTH>)) == hipSuccess
+                             ? at.sharedSizeBytes : 0;
+        }
+        const size_t want = 82 * 1024;
+        pad = static_lds < want ? want - static_lds : 0;
+    }
+    hipLaunchKernelGGL((gemm_kernel<TC, TB, AKC, BKC, BN, NTH>), grid, dim3(NTH), pad, st, g);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

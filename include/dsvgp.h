@@ -166,8 +166,10 @@ enum {
     DSVGP_GEMM_OUT_LOWER = 64,   /* only m >= n is computed; m < n is written as 0             */
     DSVGP_GEMM_B_IS_FLOAT = 128, /* (double compute only) B is float                           */
     DSVGP_GEMM_CIN_IS_FLOAT = 256,/* (double compute only) Cin is float                        */
-    DSVGP_GEMM_K_PADDED = 512    /* (float compute) operands stored with K as their minor axis are zero-filled by the
+    DSVGP_GEMM_K_PADDED = 512,   /* (float compute) operands stored with K as their minor axis are zero-filled by the
                                     caller from K up to the next multiple of 4 (lets the LDS-DMA kernel take K % 4 != 0) */
+    DSVGP_GEMM_BACKGROUND = 1024 /* filler product overlapped with a latency-bound chain on another stream: launched with one
+                                    workgroup per CU, so that every CU keeps LDS room for a workgroup of the chain */
 };
 int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N, int K, double alpha,
                const void* A, int64_t lda, const void* B, int64_t ldb, double beta, const void* Cin,
