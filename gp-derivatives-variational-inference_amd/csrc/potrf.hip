@@ -233,12 +233,14 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
     const int lane = tid & 63, wave = tid >> 6;
     const int mrow = (lane >> 4), ncol = lane & 15;
     // (written for waves 0..3; in an 8-wave workgroup waves 4..7 only take part in the barriers)
-    if (wave < 4)
-        for (int e = tid; e < 64 * 64; e += 256) Y[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+    // No barrier between the caller's writes of F and the first 16-column chain: wave 0 wrote the 16 x 16 block it starts
+    // with ITSELF (the caller guarantees that), so it goes straight on while waves 1..3 finish their parts of F and set Y = I;
+    // the barrier behind the first chain closes both.
+    if (wave >= 1 && wave < 4)
+        for (int e = tid - 64; e < 64 * 64; e += 192) Y[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
     acc4 wacc[4];                        // waves 1..3: lower blocks idx = (wave - 1) + 3 s of W
 #pragma unroll
     for (int sI = 0; sI < 4; ++sI) wacc[sI] = acc4{0, 0, 0, 0};
-    __syncthreads();
 #pragma unroll 1      // one copy of the 16-column chain: trips 2..4 hit the instruction cache
     for (int kb = 0; kb < 4; ++kb) {
         const int o = kb * 16;
@@ -622,8 +624,9 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
             const int r = (tid >> 6) + NW * u, c = tid & 63;
             F[r][c] = (r < n && c <= r) ? ra[u] : ((r == c) ? 1.0 : 0.0);
         }
+        __syncthreads();        // (row-wise fill: the leading 16 x 16 block comes from several waves)
     }
-    __syncthreads();
+    // (update path: wave 0 owns rows / columns 0..31 of F, so the block its first chain reads is its own -- no barrier here)
     CHOL_STAMP(2);
     // ---- factor the diagonal tile kk = k + 1 ----
     const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
