@@ -237,6 +237,20 @@ def main():
         for k in range(3):
             loop.step(batch(args.warmup + args.steps + k))
         torch.cuda.synchronize()
+    # the kernel assembly forward alone on the GPU (it shares the CUs with the Cholesky chain in the step when M' >= 2048):
+    # three more untimed steps with the side stream off, HIP events around the same launch
+    step_events = list(eng.events)
+    iso_fwd = None
+    if not cfg.get("ciq") and world == 1:
+        saved = eng.overlap
+        eng.overlap, eng.events = False, []
+        for k in range(3):
+            loop.step(batch(args.warmup + args.steps + 3 + k))
+        torch.cuda.synchronize()
+        durs = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in eng.events if nm == "assemble_fwd"]
+        iso_fwd = sum(durs) / len(durs) if durs else None
+        eng.overlap = saved
+    eng.events = step_events
     eng.record_events = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -285,7 +299,10 @@ def main():
                         forward=dict(kernel="kernel_fwd (K_ZX, %d x %d fp32, interleaved block layout)" % (Mp, Bp_local),
                                      avg_ms=t_f * 1e3, launches=n_f, achieved=nbytes / t_f / 1e12,
                                      frac=nbytes / t_f / 1e12 / PEAK_HBM_TBPS,
-                                     note="queued on the side stream under the Cholesky chain when M' >= 2048: shares the CUs"),
+                                     note="queued on the side stream under the Cholesky chain when M' >= 2048: shares the CUs",
+                                     alone_avg_ms=iso_fwd * 1e3 if iso_fwd else None,
+                                     alone_achieved=nbytes / iso_fwd / 1e12 if iso_fwd else None,
+                                     alone_frac=nbytes / iso_fwd / 1e12 / PEAK_HBM_TBPS if iso_fwd else None),
                         backward=dict(kernel="kernel_bwd (reads K_ZX-bar once -> dZ, dV, d ell, d s)", avg_ms=t_b * 1e3,
                                       launches=n_b, achieved=nbytes / t_b / 1e12, frac=nbytes / t_b / 1e12 / PEAK_HBM_TBPS))
 
