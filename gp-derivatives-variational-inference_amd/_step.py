@@ -485,7 +485,7 @@ class ElboEngine:
             nat = (m32, LS64, wsS)
             params = {k: v for k, v in params.items() if not k.startswith("natural_")}
             params["variational_mean"], params["chol_variational_covar"] = m32, LS32
-        self._allow_early = nat is None     # (natural / shared parameterisations post-process m-bar and L_S-bar)
+        self._allow_early = nat is None and not self.shared_directions     # (natural / shared parameterisations post-process m-bar and L_S-bar)
         if self.shared_directions:
             out = self._shared_step(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl)
         else:
