@@ -3,7 +3,10 @@
 //
 // rocSOLVER's dpotrf takes 8.1 ms at M' = 3000 (serial single-workgroup panel kernels + many small launches); a first
 // blocked version here (diagonal-block kernel + panel GEMM + trailing GEMM per block column, 141 launches) took 4.5 ms.
-// This version: 48 launches, 1.35 ms (tools/potrf_probe.py, tools/potrf_trace.sh, tools/potrf_clock.sh).
+// This version: 48 launches, 1.35 ms for the factor alone, 1.60 ms with the fused inverse (tools/potrf_inv_probe.py; per-launch
+// trace tools/potrf_inv_trace.sh; in-kernel stamps of the diagonal workgroup tools/potrf_clock.sh; anatomy in DESIGN.md section 5).
+// Measured without effect on the chain (+-1 %, removed again): one Newton step behind v_rsq_f64 instead of two, multipliers folded
+// once per column of the 16-column chain, operand reads of the 64^3 products pipelined in chunks, 8-wave workgroups (POTRF_NW).
 #include "common.h"
 
 namespace {
@@ -15,12 +18,6 @@ constexpr int NBC = 64;
 #endif
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
-#endif
-#ifndef POTRF_FOLD
-#define POTRF_FOLD 0
-#endif
-#ifndef POTRF_PIPE
-#define POTRF_PIPE 0        // k-steps per operand chunk of tile_product (0: all 16 first)
 #endif
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
@@ -55,7 +52,7 @@ __device__ unsigned long long chol_dbg[32];
 #define CHOL_STAMP_DECL unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define CHOL_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[slot]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define CHOL_STAMP_FLUSH do { if (b == 0 && k == POTRF_DEBUG_K) { if (tid == 0) { for (int q_ = 0; q_ < 8; ++q_) chol_dbg[q_] = st_[q_]; chol_dbg[28] = st_[11]; } \
+#define CHOL_STAMP_FLUSH do { if (b == 0 && k == POTRF_DEBUG_K) { if (tid == 0) { for (int q_ = 0; q_ < 8; ++q_) chol_dbg[q_] = st_[q_]; } \
         if ((tid & 63) == 0) { chol_dbg[16 + (tid >> 6)] = st_[8]; chol_dbg[20 + (tid >> 6)] = st_[9]; chol_dbg[24 + (tid >> 6)] = st_[10]; } } } while (0)
 #else
 #define CHOL_STAMP_DECL
@@ -84,37 +81,6 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
     }
-#if POTRF_PIPE
-    // operands in chunks of POTRF_PIPE k-steps, the reads of chunk c + 1 issued before the MFMAs of chunk c (everything
-    // unrolled: the accumulators never leave the AGPRs); the matrix pipe starts after the first chunk instead of after all 64 reads
-    constexpr int CH = POTRF_PIPE, NC = 16 / CH;
-    double a[2][2][CH], b[2][NJ][CH];
-    auto fetch = [&](int c, int slot) {
-#pragma unroll
-        for (int kc = 0; kc < CH; ++kc) {
-            const int kq = 4 * (c * CH + kc) + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[slot][i][kc] = As[wr * 32 + i * 16 + (lane & 15)][kq];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = wc * (16 * NJ) + j * 16 + (lane & 15);
-                b[slot][j][kc] = B_NK ? Bs[n][kq] : Bs[kq][n];
-            }
-        }
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (c + 1 < NC) fetch(c + 1, (c + 1) & 1);
-#pragma unroll
-        for (int kc = 0; kc < CH; ++kc)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c & 1][i][kc], b[c & 1][j][kc], acc[i][j], 0, 0, 0);
-    }
-#else
     // all operands of the wave first, then back-to-back MFMAs: the loops are
     // fully unrolled (a rolled loop moves the accumulators AGPR <-> VGPR and drains the MFMA pipe every trip)
     double a[2][16], b[NJ][16];
@@ -136,7 +102,6 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
-#endif
 }
 
 // one wave: Cholesky factor L_d (in place, upper part zeroed) and inverse Xd = L_d^-1 of the 16 x 16 block at F[o.., o..].
@@ -181,21 +146,11 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
         const double li = ci * rinv;                                // L[i][j]  (0 above the diagonal, sqrt(a_jj) on it)
         const double ls = (i == j) ? 0.0 : li;
         ri = (i == j) ? rinv : ri;
-#if POTRF_FOLD
-        // multipliers folded once per column: a -= (l_i / l_jj) a_cj, y -= (l_i / l_jj) y_j   (2 products instead of 8)
-        const double ma = -li * rinv, my = -ls * rinv;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = fma(ma, cc[t], a[t]);
-            y[t] = fma(my, rr[t], y[t]);
-        }
-#else
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             a[t] = fma(-li, cc[t] * rinv, a[t]);
             y[t] = fma(-ls, rr[t] * rinv, y[t]);
         }
-#endif
         if (g == gj) a[tj] = li;
     }
     if (lane == 0 && bad >= 0 && o + bad < nvalid && *info == 0) *info = gidx0 + o + bad + 1;   // LAPACK convention
@@ -590,14 +545,7 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
             return;
         }
         __syncthreads();                                            // F aliases the T tile: every wave is done reading it
-#ifndef POTRF_ABL_TWICE
         CHOL_STAMP(10);
-#endif
-#ifdef POTRF_ABL_TWICE      // diagnostic: the same code a second time (first-touch effects: instruction cache)
-#pragma unroll 1
-        for (int rep_ = 0; rep_ < 2; ++rep_) {
-        if (rep_ == 1) CHOL_STAMP(10);
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -608,9 +556,6 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                     const bool in = i0 + ml < n && j0 + nl < n && nl <= ml;
                     F[ml][nl] = in ? acc[i][j][q] : ((ml == nl) ? 1.0 : 0.0);   // identity padding of a ragged last block
                 }
-#ifdef POTRF_ABL_TWICE
-        }
-#endif
         CHOL_STAMP(9);
     } else {
         double ra[NU];
@@ -631,26 +576,8 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     // ---- factor the diagonal tile kk = k + 1 ----
     const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
     double (*Y)[LDT] = S[1];
-#ifdef POTRF_ABL_TWICE      // diagnostic: factor the tile twice (from a register backup), stamp the second pass separately
-    double bk_[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) bk_[u] = F[(tid >> 6) + NW * u][tid & 63];
-#pragma unroll 1
-    for (int rep_ = 0; rep_ < 2; ++rep_) {
-        if (rep_ == 1) {
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NU; ++u) F[(tid >> 6) + NW * u][tid & 63] = bk_[u];
-            __syncthreads();
-            CHOL_STAMP(11);
-        }
-        factor64_lds(F, Y, Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
-                     Wws + (size_t)kk * 4096);
-    }
-#else
     factor64_lds(F, Y, Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
                  Wws + (size_t)kk * 4096);
-#endif
     CHOL_STAMP(3);
     CHOL_STAMP_FLUSH;
 }

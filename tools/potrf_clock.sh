@@ -28,8 +28,7 @@ prev = t[0]
 for s in (1, 4, 5, 6, 7, 2, 3):
     print("  %-28s %8d  (+%d)" % (names[s], t[s] - t[0], t[s] - prev))
     prev = t[s]
-print("  per wave, end of product 2:", [t[16 + w] - t[0] for w in range(4)], " F written:", [t[20 + w] - t[0] for w in range(4)], " (after the barrier / 2nd pass starts:", [t[24 + w] - t[0] for w in range(4)], ")")
-if t[28]: print("  factor64 run twice: first pass %d cycles, second pass %d cycles" % (t[28] - t[2], t[3] - t[28]))
+print("  per wave, end of product 2:", [t[16 + w] - t[0] for w in range(4)], " F written:", [t[20 + w] - t[0] for w in range(4)], " (after the barrier before it:", [t[24 + w] - t[0] for w in range(4)], ")")
 print("  factor64 sub-steps kb = 0..3 (cycles each):", [t[12] - t[8]] + [t[12 + q] - t[11 + q] for q in (1, 2, 3)])
 print("  inside factor64, kb = 0:  factor16 (1 wave) %d, phase (b) %d, phase (c) %d" % (t[9] - t[8], t[10] - t[9], t[11] - t[10]))
 PY
