@@ -22,7 +22,10 @@ constexpr int NBC = 64;
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
 #pragma unroll
-    for (int it = 0; it < POTRF_NEWTON; ++it) y = y + y * (0.5 * fma(-d * y, y, 1.0));
+    for (int it = 0; it < POTRF_NEWTON; ++it) {      // y += (y / 2) (1 - d y^2): three dependent operations per step (y / 2 runs beside d y)
+        const double h = 0.5 * y;
+        y = fma(h, fma(-(d * y), y, 1.0), y);
+    }
     return y;
 }
 
