@@ -412,7 +412,7 @@ class ElboEngine:
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
         jit = 0.0
         for t in range(-1, 3):
-            R = Sigma.to(f64)
+            R = Sigma.to(f64, copy=True)        # (factorised in place: never the caller's matrix)
             if t >= 0:
                 jit = self.chol_jitter * 10.0 ** t
                 _ops.add_diag_(ctx, R, jit)
@@ -424,11 +424,11 @@ class ElboEngine:
 
     @torch.no_grad()
     def draw(self, mu, root, eps):
-        """mu + tril(root) eps_i for every row eps_i of eps [n, B']: one triangular fp64 MFMA product.  Returns [n, B'] fp32."""
+        """mu + tril(root) eps_i for every row eps_i of eps [n, B']: one triangular fp64 MFMA product.  Returns [n, B'] in mu's dtype."""
         ctx = _ops.Context.get(self.device)
         out = torch.empty(mu.shape[0], eps.shape[0], dtype=f64, device=self.device)
         _ops.gemm(ctx, A_LOWER, root, eps.t().contiguous(), out)
-        return out.t().to(f32) + mu
+        return out.t().to(mu.dtype) + mu
 
     def _predict_chol(self, ctx, params, x, D, cache, joint=False):
         key = tuple((t.data_ptr(), t._version) for t in params.values()) if cache else None

@@ -12,7 +12,8 @@ and the ELBO are then all fp64.  ``ElboEngine64`` is that mode of ``directional_
     expressions on the device, differentiated by autograd exactly like the reference does (directional_vi.py:245-249).
 
 It is the general (variance-carrying) formulation, so ELBO and PLL are both covered; it is not the benchmark path (the
-headline configs run the reference's default fp32 model) and it is single-rank.  No CPU fallback: the inputs must be HIP tensors.
+headline configs run the reference's default fp32 model).  Under ``parallel.DataParallel`` the gradients of the row shards are
+summed by one all-reduce at the end of the step (no early operand).  No CPU fallback: the inputs must be HIP tensors.
 """
 import math
 
@@ -53,8 +54,6 @@ class ElboEngine64(ElboEngine):
             raise TypeError("fp64 model mode: inputs must be float64")
         if self.whitening != "cholesky" or self.shared_directions:
             raise NotImplementedError("fp64 model mode covers the Cholesky-whitened strategies only")
-        if self.collective is not None and self.collective.world > 1:
-            raise NotImplementedError("fp64 model mode is single-rank")
 
     def _hyp64(self, params, grad=False):
         """(raw leaves, hyp[4] = {lengthscale, outputscale, noise, 0}): gpytorch Positive / GreaterThan(1e-4) softplus constraints"""
@@ -131,8 +130,26 @@ class ElboEngine64(ElboEngine):
         var = self._prior_diag(x.shape[0], p, self._pd(p), ell, s, x) + KXX_JITTER + cs
         return mu0 + params["constant"].reshape(()), (var + noise).clamp_min(MIN_VARIANCE)
 
+    @torch.no_grad()
     def predict_joint(self, params, x, D, cache=False):
-        raise NotImplementedError("fp64 model mode: joint predictive covariance not built")
+        """Mean [B'] and the full predictive covariance [B', B'] (fp64, likelihood noise on the diagonal):
+        Sigma = s K_XX + 1e-4 I + W^T W - A^T A + noise I  (DGVS.py:199-208 + likelihood)"""
+        ctx = _ops.Context.get(self.device)
+        self._check(params, x, D)
+        _, (ell, s, noise), hyp = self._hyp64(params)
+        Mz = params["inducing_points"].shape[0]
+        pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
+        packZ, L, dims, ws = self._factor64(ctx, params, hyp, x.shape[0] * (self._pd(pz) + 1))
+        packX, A, W, mu0, _ = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+        M, d, p, Mp = dims
+        B = x.shape[0]
+        Sigma = _ops.kernel_fwd_f64(ctx, packX, B, packX, B, d, p, hyp)
+        if self._pd(p) != p:
+            Sigma = Sigma[::p + 1, ::p + 1].contiguous()
+        _ops.gemm(ctx, TRANS_A, W, W, Sigma, beta=1.0, Cin=Sigma)
+        _ops.gemm(ctx, TRANS_A, A, A, Sigma, alpha=-1.0, beta=1.0, Cin=Sigma)
+        Sigma.diagonal().add_(noise + KXX_JITTER)
+        return mu0 + params["constant"].reshape(()), Sigma
 
     @torch.no_grad()
     def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True, fast=None):

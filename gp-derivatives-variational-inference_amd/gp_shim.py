@@ -200,9 +200,9 @@ class PredictiveDistribution:
         sample_shape = torch.Size(sample_shape)
         n = int(sample_shape.numel()) if len(sample_shape) else 1
         if base_samples is None:
-            eps = torch.randn(n, n_out, dtype=torch.float32, device=self._mu.device)
+            eps = torch.randn(n, n_out, dtype=self._mu.dtype, device=self._mu.device)
         else:
-            eps = base_samples.reshape(n, n_out).to(torch.float32)
+            eps = base_samples.reshape(n, n_out).to(self._mu.dtype)
         return eng.draw(self._mu, self._root, eps).reshape(tuple(sample_shape) + (n_out,))
 
     def sample(self, sample_shape=torch.Size(), base_samples=None):

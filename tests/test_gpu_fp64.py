@@ -176,6 +176,33 @@ def test_fp64_dfree_data_outputs(dsvgp, gpu_device):
         assert relmax(grads[k], g_ref[k]) < 1e-7, k
 
 
+def test_fp64_row_shards_add_up_and_joint_covariance(dsvgp, gpu_device):
+    """what DataParallel relies on: shard losses / gradients (global row count, KL on one shard) sum to the full-batch step;
+    and the joint predictive covariance against the oracle"""
+    from dsvgp_amd._step64 import ElboEngine64
+    P, x, y, D, nd = make_problem64(300, 5, 24, 2, 60, seed=4)
+    eng = ElboEngine64(gpu_device)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    xg, yg, Dg = x.to(gpu_device), y.to(gpu_device), D.to(gpu_device)
+    l_full, g_full, _, _ = eng.loss_and_grads(Pg, xg, yg, Dg, nd)
+    g_full = {k: v.clone() for k, v in g_full.items()}
+    rows = float(y.shape[0])
+    tot_l, tot_g = 0.0, None
+    for r, (lo, hi) in enumerate(((0, 25), (25, 60))):
+        l, g, _, _ = eng.loss_and_grads(Pg, xg[lo:hi].contiguous(), yg[lo * 3:hi * 3].contiguous(), Dg[lo * 2:hi * 2].contiguous(),
+                                        nd, global_rows=rows, include_kl=(r == 0))
+        tot_l += l.item()
+        tot_g = {k: v.clone() for k, v in g.items()} if tot_g is None else {k: tot_g[k] + g[k] for k in g}
+    assert abs(tot_l - l_full.item()) < 1e-12 * abs(l_full.item())
+    for k in g_full:
+        assert relmax(tot_g[k], g_full[k]) < 1e-10, k
+    mu_ref, Sigma_ref = O.predictive_joint(P, x, D)
+    _, _, noise = O.constrained(P)
+    mu, Sigma = eng.predict_joint(Pg, xg, Dg)
+    assert relmax(mu, mu_ref) < 1e-9
+    assert relmax(Sigma, Sigma_ref + noise * torch.eye(Sigma_ref.shape[0], dtype=f64)) < 1e-9
+
+
 def test_fp64_mode_refuses_what_it_does_not_cover(dsvgp, gpu_device):
     from dsvgp_amd._step64 import ElboEngine64
     P, x, y, D, nd = make_problem64(200, 3, 10, 1, 20, seed=1)
@@ -238,6 +265,15 @@ def test_train_gp_eval_gp_under_float64_default(dsvgp, gpu_device):
         means, variances = dsvgp.eval_gp(TensorDataset(X[:50], Y[:50]), model, lik, num_directions=p, minibatch_size=25,
                                          minibatch_dim=p)
         assert means.dtype == f64 and means.shape == (50 * (p + 1),) and bool((variances > 0).all())
+        # joint distribution protocol of the BO drivers in double precision
+        model.eval(); lik.eval()
+        xs, Ds = X[:12].to(gpu_device), torch.eye(d)[:p].repeat(12, 1).to(gpu_device)
+        preds = lik(model(xs, derivative_directions=Ds))
+        Sig = preds.covariance_matrix
+        smp = preds.sample(torch.Size([5]))
+        assert Sig.dtype == f64 and smp.dtype == f64 and smp.shape == (5, 12 * (p + 1))
+        assert relmax(torch.diagonal(Sig), preds.variance) < 1e-10
+        assert relmax(preds.covariance_matrix, Sig) == 0.0            # (sampling did not touch the covariance)
         mu_ref, var_ref = O.predictive(P, X[:50], torch.eye(d)[:p].repeat(50, 1))
         _, _, noise = O.constrained(P)
         assert relmax(means, mu_ref) < 1e-9 and relmax(variances, var_ref + noise) < 1e-9
