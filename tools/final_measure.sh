@@ -4,16 +4,19 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final; mkdir -p $O
 cd $R
+if [ "$SKIP_BENCH" != "1" ]; then
 python3 bench.py > $O/bench_c4.json 2> $O/bench_c4.err && tail -1 $O/bench_c4.json | cut -c1-400
 for cfg in "c2 300" "c3 40" "c5 8" "c4shard8 40"; do set -- $cfg
-  python3 bench.py --config $1 --steps $2 --warmup 5 --no-cpu-baseline > $O/bench_$1.json 2>/dev/null && tail -1 $O/bench_$1.json | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1', round(j['ms_per_step'],4), j.get('roofline',{}).get('frac'))"
+  python3 bench.py --config $1 --steps $2 --warmup 5 --no-cpu-baseline > $O/bench_$1.json 2>/dev/null && tail -1 $O/bench_$1.json | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1', round(j['ms_per_step'],4), (j.get('roofline') or {}).get('frac'))"
 done
+fi
 cd /tmp && export TMPDIR=/tmp
 for cfg in "c4 9" "c3 9" "c5 4" "c2 40"; do set -- $cfg
   rm -rf /tmp/ks
   rocprofv3 --kernel-trace --stats -d /tmp/ks -o run -- python3 $R/bench.py --config $1 --steps $2 --warmup 3 --no-cpu-baseline > /tmp/ks.log 2>&1
   db=$(find /tmp/ks -name "*.db" | head -1)
-  python3 $R/tools/kernel_stats.py $db --steps $(($2 + 3)) > $O/kernel_stats_$1.txt 2>&1 || cp /tmp/ks.log $O/kernel_stats_$1.err
+  extra=6; [ "$1" = "c5" ] && extra=3      # warm-up 3 (+ the 3 untimed steps bench.py adds for the assembly-alone timing; not for CIQ)
+  python3 $R/tools/kernel_stats.py $db --steps $(($2 + extra)) > $O/kernel_stats_$1.txt 2>&1 || cp /tmp/ks.log $O/kernel_stats_$1.err
   if [ "$1" = "c4" ] || [ "$1" = "c2" ]; then python3 $R/tools/step_timeline.py $db > $O/timeline_$1.txt 2>&1; fi
   head -3 $O/kernel_stats_$1.txt
 done
