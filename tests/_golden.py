@@ -28,3 +28,22 @@ def kernel_error(K, g):
     rs, cs = torch.from_numpy(g["K_rowsum"]), torch.from_numpy(g["K_colsum"])
     e_sum = max(((K.sum(1) - rs).abs().max() / rs.abs().max()).item(), ((K.sum(0) - cs).abs().max() / cs.abs().max()).item())
     return e_sub, e_sum
+
+
+STRATEGY = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_*.npz")))
+
+
+def strategy_problem(path, dtype=torch.float64):
+    """(params dict with gpytorch-style raw hyper-parameters, x, D, flags, reference mean, reference covariance) of one
+    reference-generated strategy vector (oracle/make_strategy_fixtures.py: the reference's own strategy ``forward`` text)."""
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(g[k]).to(dtype)
+    inv_softplus = lambda v: float(np.log(np.expm1(float(v))))
+    P = dict(inducing_points=t("Z"), inducing_directions=t("V"), variational_mean=t("variational_mean"),
+             chol_variational_covar=t("chol_variational_covar"),
+             constant=torch.tensor([float(g["constant"])], dtype=dtype),
+             raw_outputscale=torch.tensor(inv_softplus(g["outputscale"]), dtype=dtype),
+             raw_lengthscale=torch.tensor([[inv_softplus(g["lengthscale"])]], dtype=dtype),
+             raw_noise=torch.tensor([0.0], dtype=dtype))
+    flags = dict(outputs=str(g["outputs"]), shared=bool(g["shared"]), p=int(g["p"]))
+    return P, t("x"), t("D"), flags, torch.from_numpy(g["mean"]), torch.from_numpy(g["covariance"])

@@ -76,6 +76,48 @@ def test_ciq_step_close_to_exact_whitening_and_plain_autograd():
             assert relmax(g[k], g2[k]) < 3e-2, k
 
 
+def test_ngd_interp_terms_match_the_reference_function():
+    """the oracle's restatement against vectors produced by the reference file's OWN autograd function ``_NgdInterpTerms``
+    (CiqDirectionalGradVariationalStrategy.py:19-123; forward and hand-written backward), oracle/make_strategy_fixtures.py"""
+    import glob, os
+    import numpy as np
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ngd_interp_*.npz")))
+    assert len(paths) >= 2
+    for path in paths:
+        g = np.load(path)
+        t = lambda k: torch.from_numpy(g[k])
+        T, nv, nm = (t(k).clone().requires_grad_(True) for k in ("interp_term", "natural_vec", "natural_mat"))
+        im, iv, kl = O._NgdInterpTermsFn.apply(T, nv, nm)
+        assert relmax(im, t("interp_mean")) < 1e-12 and relmax(iv, t("interp_var")) < 1e-12 and kl.item() == float(g["kl_div"]) == 0.0
+        ((im * t("g_mean")).sum() + (iv * t("g_var")).sum() + kl * t("g_kl")).backward()
+        assert relmax(T.grad, t("d_interp_term")) < 1e-12
+        assert relmax(nv.grad, t("d_natural_vec")) < 1e-12
+        assert relmax(nm.grad, t("d_natural_mat")) < 1e-12
+
+
+def test_ciq_predictive_matches_the_reference_strategy_forward():
+    """``ciq_predictive`` (exact K^-1/2: the limit of the quadrature) against the reference's CIQ strategy ``forward`` text run
+    with the exact inverse square root in place of gpytorch's ``sqrt_inv_matmul`` (CiqDGVS.py:197-295)"""
+    import glob, os
+    import numpy as np
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_*.npz")))
+    assert len(paths) >= 2
+    for path in paths:
+        g = np.load(path)
+        t = lambda k: torch.from_numpy(g[k])
+        inv_softplus = lambda v: float(np.log(np.expm1(float(v))))
+        P = dict(inducing_points=t("Z"), inducing_directions=t("V"), natural_vec=t("natural_vec"), natural_mat=t("natural_mat"),
+                 constant=torch.tensor([float(g["constant"])], dtype=torch.float64),
+                 raw_outputscale=torch.tensor(inv_softplus(g["outputscale"]), dtype=torch.float64),
+                 raw_lengthscale=torch.tensor([[inv_softplus(g["lengthscale"])]], dtype=torch.float64),
+                 raw_noise=torch.tensor([0.0], dtype=torch.float64))
+        mu, var, kl = O.ciq_predictive(P, t("x"), t("D"), exact=True)
+        assert relmax(mu, t("mean")) < 1e-9 and relmax(var, t("variance")) < 1e-9, path
+        # ... and the quadrature itself stays within its tolerance of that limit
+        mu_q, var_q, _ = O.ciq_predictive(P, t("x"), t("D"))
+        assert relmax(mu_q, t("mean")) < 2e-3 and relmax(var_q, t("variance")) < 2e-3
+
+
 # ------------------------------------------------------------------ HIP kernels vs oracle
 @pytest.mark.gpu
 def test_ciq_lanczos_and_solve_match_oracle(dsvgp, gpu_device):
@@ -226,3 +268,28 @@ def test_c5_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, st
             # well-scaled "mid" state.
             loose = state == "init" and k in ("g_inducing_points", "g_inducing_directions")
             assert v < (0.35 if loose else 2e-2), (k, v)
+
+
+@pytest.mark.gpu
+def test_ciq_engine_matches_the_reference_strategy_forward(dsvgp, gpu_device):
+    """HIP CIQ path (Lanczos bounds, quadrature, msMINRES, NGD interpolation terms) against the reference's CIQ strategy forward
+    text (tests/golden/strategy_ciq_*.npz, exact K^-1/2): within the quadrature / msMINRES tolerance of the reference (1e-4
+    relative residual; 5e-3 on the moments)"""
+    import glob, os
+    import numpy as np
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_*.npz"))):
+        g = np.load(path)
+        t = lambda k: torch.from_numpy(g[k]).float().to(gpu_device)
+        inv_softplus = lambda v: float(np.log(np.expm1(float(v))))
+        P = dict(inducing_points=t("Z"), inducing_directions=t("V"), natural_vec=t("natural_vec"), natural_mat=t("natural_mat"),
+                 constant=torch.tensor([float(g["constant"])], device=gpu_device),
+                 raw_outputscale=torch.tensor(inv_softplus(g["outputscale"]), device=gpu_device),
+                 raw_lengthscale=torch.tensor([[inv_softplus(g["lengthscale"])]], device=gpu_device),
+                 raw_noise=torch.tensor([0.0], device=gpu_device))
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.whitening = "ciq"
+        mu, varn = eng.predict(P, t("x"), t("D"))
+        noise = float(torch.nn.functional.softplus(torch.zeros(())) + 1e-4)
+        e_mu, e_var = relmax(mu, torch.from_numpy(g["mean"])), relmax(varn.double().cpu() - noise, torch.from_numpy(g["variance"]))
+        print("[parity] CIQ strategy vector %s: mean %.2e, variance %.2e" % (os.path.basename(path), e_mu, e_var))
+        assert e_mu < 5e-3 and e_var < 5e-3

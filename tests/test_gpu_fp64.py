@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import dsvgp_oracle as O
-from _golden import GOLDEN, kernel_error
+from _golden import GOLDEN, STRATEGY, kernel_error, strategy_problem
 
 pytestmark = pytest.mark.gpu
 f64 = torch.float64
@@ -201,6 +201,20 @@ def test_fp64_row_shards_add_up_and_joint_covariance(dsvgp, gpu_device):
     mu, Sigma = eng.predict_joint(Pg, xg, Dg)
     assert relmax(mu, mu_ref) < 1e-9
     assert relmax(Sigma, Sigma_ref + noise * torch.eye(Sigma_ref.shape[0], dtype=f64)) < 1e-9
+
+
+@pytest.mark.parametrize("path", [p for p in STRATEGY if "shared" not in p], ids=lambda p: os.path.basename(p))
+def test_fp64_predictive_matches_reference_strategy_vectors(dsvgp, gpu_device, path):
+    """fp64 engine against the fp64 run of the reference's own strategy forward text: 1e-10"""
+    from dsvgp_amd._step64 import ElboEngine64
+    P, x, D, fl, mean_ref, cov_ref = strategy_problem(path)
+    eng = ElboEngine64(gpu_device)
+    eng.data_outputs = fl["outputs"]
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    mu, Sigma = eng.predict_joint(Pg, x.to(gpu_device), D.to(gpu_device))
+    noise = torch.nn.functional.softplus(torch.zeros((), dtype=f64)) + 1e-4
+    Sigma = Sigma.cpu() - noise * torch.eye(Sigma.shape[0], dtype=f64)
+    assert relmax(mu, mean_ref) < 1e-10 and relmax(Sigma, cov_ref) < 1e-10
 
 
 def test_fp64_mode_refuses_what_it_does_not_cover(dsvgp, gpu_device):

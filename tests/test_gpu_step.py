@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import dsvgp_oracle as O
+from _golden import STRATEGY, strategy_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -825,3 +826,23 @@ def test_plain_ciq_strategy_of_the_other_harnesses(dsvgp, gpu_device, harness, c
     assert "variational_strategy._variational_distribution.natural_mat" in model.state_dict()
     means, variances = H.eval_gp(TensorDataset(tx[:50], ty[:50]), model, likelihood, minibatch_size=25)
     assert torch.isfinite(means).all() and (variances > 0).all()
+
+
+# ------------------------------------------------------------------ the reference's own strategy forward, as vectors
+@pytest.mark.parametrize("path", STRATEGY, ids=[__import__("os").path.basename(p) for p in STRATEGY])
+def test_predictive_matches_reference_strategy_vectors(dsvgp, gpu_device, path):
+    """q(f) of the HIP engine (mean, full covariance) against what the reference's strategy ``forward`` text computed in fp64
+    (oracle/make_strategy_fixtures.py; DGVS.py:89-208, DFree / Shared siblings).  fp32 model: 2e-4 of the max magnitude."""
+    P, x, D, fl, mean_ref, cov_ref = strategy_problem(path, torch.float32)
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.data_outputs = fl["outputs"]
+    eng.shared_directions = fl["shared"]
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    mu, Sigma = eng.predict_joint(Pg, x.to(gpu_device), D.to(gpu_device))
+    noise = torch.nn.functional.softplus(torch.zeros(())) + 1e-4
+    Sigma = Sigma.double().cpu() - noise.double() * torch.eye(Sigma.shape[0], dtype=torch.float64)
+    errs = dict(mean=relmax(mu, mean_ref), cov=relmax(Sigma, cov_ref))
+    _report("strategy vector " + __import__("os").path.basename(path), errs)
+    assert errs["mean"] < 2e-4 and errs["cov"] < 2e-4
+    mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu2, mean_ref) < 2e-4 and relmax(varn2.double().cpu() - noise.double(), torch.diagonal(cov_ref)) < 2e-4
