@@ -337,7 +337,42 @@ def main():
             name, fname, tuple(mean.shape), tuple(cov.shape), mean.abs().max().item(), torch.diagonal(cov).min().item()))
 
 
+    grad_case(Kern, O)
     ciq_cases(Kern, NatDist)
+
+
+def grad_case(Kern, O):
+    """``GradVariationalStrategy.forward`` (GradVariationalStrategy.py:87-137, BASELINE config 3): joint covariance of [Z ; x] from
+    ONE model call, sliced into its three blocks.  Its kernel is gpytorch's RBFKernelGrad (not a file of the reference); the
+    reference's directional kernel with all d canonical directions at every point is the same matrix (value + full gradient per
+    point, interleaved) and stands in for it here."""
+    ref = _load("GradVariationalStrategy.py", "_ref_grad_strategy")
+    for ci, (N, d, M, B) in enumerate(((40, 3, 6, 7), (60, 5, 8, 9))):
+        g = torch.Generator().manual_seed(500 + ci)
+        X = torch.rand(N, d, generator=g, dtype=torch.float64)
+        Z, x = X[:M].clone(), X[M:M + B].contiguous()
+        nq = M * (d + 1)
+        m = 0.3 * torch.randn(nq, generator=g, dtype=torch.float64)
+        LS = torch.tril(torch.eye(nq, dtype=torch.float64) + 0.1 * torch.randn(nq, nq, generator=g, dtype=torch.float64))
+        ell, s, c = 0.7 + 0.1 * ci, 1.1, -0.1
+        kern = Kern()
+        kern._ell = torch.tensor([[ell]], dtype=torch.float64)
+        model = _Model(kern, c, s)
+        eye = torch.eye(d, dtype=torch.float64)
+
+        def forward(xx, _model=model, _eye=eye):
+            v = _eye.repeat(xx.shape[0], 1)
+            return MultivariateNormal(_model.mean_module(xx), _model.covar_module(xx, xx, v1=v, v2=v))
+
+        model.forward = forward
+        strat = ref.GradVariationalStrategy(model, Z, _VarDist(nq), learn_inducing_locations=True)
+        with torch.no_grad():
+            out = strat.forward(x, strat.inducing_points, m, CholLazyTensor(LS))
+        np.savez(os.path.join(OUT, "strategy_gradvs_%d.npz" % ci), x=x.numpy(), Z=Z.numpy(), V=eye.repeat(M, 1).numpy(),
+                 D=eye.repeat(B, 1).numpy(), variational_mean=m.numpy(), chol_variational_covar=LS.numpy(),
+                 lengthscale=np.float64(ell), outputscale=np.float64(s), constant=np.float64(c), p=np.int64(d),
+                 outputs=np.str_("all"), shared=np.bool_(False), mean=out.mean.numpy(), covariance=out.covariance_matrix.numpy())
+        print("gradvs_%d             GradVariationalStrategy.forward: mean %s" % (ci, tuple(out.mean.shape)))
 
 
 def ciq_cases(Kern, NatDist):
