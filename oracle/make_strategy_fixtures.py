@@ -274,7 +274,7 @@ class _Model:
         self.covar_module = _Scale()
 
     def mean_module(self, x):
-        return torch.full((x.shape[0],), float(self.c), dtype=x.dtype)
+        return torch.ones(x.shape[0], dtype=x.dtype) * self.c
 
     def forward(self, x, **params):
         return MultivariateNormal(self.mean_module(x), self.covar_module(x, **params))
@@ -339,6 +339,63 @@ def main():
 
     grad_case(Kern, O)
     ciq_cases(Kern, NatDist)
+    elbo_gradient_cases(Kern)
+
+
+def elbo_gradient_cases(Kern):
+    """Gradients THROUGH the reference's strategy forward and kernel file (torch autograd over the reference's own operations,
+    the dense stand-ins are plain torch): loss = -(sum_j ll_j / B' - KL / num_data) with the closed forms of gpytorch's
+    GaussianLikelihood.expected_log_prob and of KL(N(m, S) || N(0, I)) written out here (those two formulas are restated, as
+    in the oracle; everything they are applied to -- mean and variance of q(f) as functions of Z, V, m, L_S, lengthscale,
+    outputscale, constant -- is the reference's text)."""
+    import math
+    import torch.nn.functional as F
+    cases = [("dgvs", "DirectionalGradVariationalStrategy.py", 70, 4, 9, 2, 13, "all", False),
+             ("dgvs_c4geom", "DirectionalGradVariationalStrategy.py", 80, 20, 5, 5, 7, "all", False),
+             ("dfree", "DFreeDirectionalGradVariationalStrategy.py", 60, 4, 8, 2, 11, "values", False),
+             ("shared", "SharedDirectionalGradVariationalStrategy.py", 60, 4, 8, 2, 11, "all", True)]
+    for ci, (name, fname, N, d, M, p, B, outputs, shared) in enumerate(cases):
+        g = torch.Generator().manual_seed(600 + ci)
+        X = torch.rand(N, d, generator=g, dtype=torch.float64)
+        Z, x = X[:M].clone(), X[M:M + B].contiguous()
+        nV = p if shared else M * p
+        V = torch.eye(d, dtype=torch.float64)[:p].repeat(1 if shared else M, 1) + 0.2 * torch.randn(nV, d, generator=g,
+                                                                                                      dtype=torch.float64)
+        D = torch.eye(d, dtype=torch.float64)[:p].repeat(B, 1) + 0.1 * torch.randn(B * p, d, generator=g, dtype=torch.float64)
+        nq = M + p if shared else M * (p + 1)
+        nout = B if outputs == "values" else B * (p + 1)
+        y = torch.randn(nout, generator=g, dtype=torch.float64)
+        m = (0.3 * torch.randn(nq, generator=g, dtype=torch.float64)).requires_grad_(True)
+        LS = (torch.eye(nq, dtype=torch.float64) + 0.1 * torch.randn(nq, nq, generator=g, dtype=torch.float64)).requires_grad_(True)
+        raw_ell = torch.tensor([[0.3]], dtype=torch.float64, requires_grad=True)
+        raw_s = torch.tensor(0.2, dtype=torch.float64, requires_grad=True)
+        raw_noise = torch.tensor([-0.5], dtype=torch.float64, requires_grad=True)
+        const = torch.tensor([0.1], dtype=torch.float64, requires_grad=True)
+        num_data = float((d + 1) * N)
+        kern = Kern()
+        kern._ell = F.softplus(raw_ell)
+        model = _Model(kern, const.reshape(()), F.softplus(raw_s))
+        Strat = getattr(_load(fname, "_ref_strategy_g%d" % ci), "DirectionalGradVariationalStrategy")
+        strat = Strat(model, Z, V, _VarDist(nq), learn_inducing_locations=True)
+        out = strat.forward(x, strat.inducing_points, m, CholLazyTensor(torch.tril(LS)), derivative_directions=D)
+        mu, var = out.mean, torch.diagonal(out.covariance_matrix)
+        noise = F.softplus(raw_noise).reshape(()) + 1e-4                       # GaussianLikelihood: GreaterThan(1e-4)
+        varn = (var + noise).clamp_min(1e-6)                                   # likelihood(q(f)).variance
+        ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+        Lt = torch.tril(LS)
+        kl = 0.5 * ((m * m).sum() + (Lt * Lt).sum() - nq - torch.log(torch.diagonal(Lt) ** 2).sum())
+        loss = -(ll.sum() / nout - kl / num_data)
+        loss.backward()
+        np.savez(os.path.join(OUT, "strategy_grad_%s.npz" % name), x=x.numpy(), y=y.numpy(), Z=Z.numpy(), V=V.numpy(), D=D.numpy(),
+                 variational_mean=m.detach().numpy(), chol_variational_covar=LS.detach().numpy(), raw_lengthscale=raw_ell.detach().numpy(),
+                 raw_outputscale=raw_s.detach().numpy(), raw_noise=raw_noise.detach().numpy(), constant=const.detach().numpy(),
+                 num_data=np.float64(num_data), p=np.int64(p), outputs=np.str_(outputs), shared=np.bool_(shared),
+                 loss=loss.detach().numpy(), d_inducing_points=strat.inducing_points.grad.numpy(),
+                 d_inducing_directions=strat.inducing_directions.grad.numpy(), d_variational_mean=m.grad.numpy(),
+                 d_chol_variational_covar=LS.grad.numpy(), d_raw_lengthscale=raw_ell.grad.numpy(), d_raw_outputscale=raw_s.grad.numpy(),
+                 d_raw_noise=raw_noise.grad.numpy(), d_constant=const.grad.numpy())
+        print("grad_%-16s loss %.6f, |dZ| max %.3e, |dV| max %.3e" % (name, loss.item(), strat.inducing_points.grad.abs().max().item(),
+                                                                      strat.inducing_directions.grad.abs().max().item()))
 
 
 def grad_case(Kern, O):

@@ -31,7 +31,24 @@ def kernel_error(K, g):
 
 
 STRATEGY = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_*.npz")))
-            if "_ciq_" not in os.path.basename(p) and "_ngd_" not in os.path.basename(p)]      # (CIQ vectors: tests/test_ciq.py)
+            if not any(t in os.path.basename(p) for t in ("_ciq_", "_ngd_", "_grad_"))]      # (CIQ vectors: tests/test_ciq.py)
+GRADIENT = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_grad_*.npz")))
+PARAM_KEYS = ("inducing_points", "inducing_directions", "variational_mean", "chol_variational_covar", "constant",
+              "raw_outputscale", "raw_lengthscale", "raw_noise")
+
+
+def gradient_problem(path, dtype=torch.float64):
+    """(params, x, y, D, num_data, flags, reference loss, reference gradients) of one ``strategy_grad_*.npz`` vector: the ELBO
+    step differentiated by autograd THROUGH the reference's strategy forward and kernel file (oracle/make_strategy_fixtures.py)"""
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(g[k]).to(dtype)
+    P = dict(inducing_points=t("Z"), inducing_directions=t("V"), variational_mean=t("variational_mean"),
+             chol_variational_covar=t("chol_variational_covar"), constant=t("constant"), raw_outputscale=t("raw_outputscale"),
+             raw_lengthscale=t("raw_lengthscale"), raw_noise=t("raw_noise"))
+    grads = {k: torch.from_numpy(g["d_" + k]) for k in PARAM_KEYS}
+    grads["chol_variational_covar"] = torch.tril(grads["chol_variational_covar"])
+    flags = dict(outputs=str(g["outputs"]), shared=bool(g["shared"]), p=int(g["p"]))
+    return P, t("x"), t("y"), t("D"), float(g["num_data"]), flags, float(g["loss"]), grads
 
 
 def strategy_problem(path, dtype=torch.float64):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import dsvgp_oracle as O
-from _golden import GOLDEN, STRATEGY, kernel_error, strategy_problem
+from _golden import GOLDEN, GRADIENT, PARAM_KEYS, STRATEGY, gradient_problem, kernel_error, strategy_problem
 
 pytestmark = pytest.mark.gpu
 f64 = torch.float64
@@ -215,6 +215,21 @@ def test_fp64_predictive_matches_reference_strategy_vectors(dsvgp, gpu_device, p
     noise = torch.nn.functional.softplus(torch.zeros((), dtype=f64)) + 1e-4
     Sigma = Sigma.cpu() - noise * torch.eye(Sigma.shape[0], dtype=f64)
     assert relmax(mu, mean_ref) < 1e-10 and relmax(Sigma, cov_ref) < 1e-10
+
+
+@pytest.mark.parametrize("path", [p for p in GRADIENT if "shared" not in p], ids=lambda p: os.path.basename(p))
+def test_fp64_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device, path):
+    """fp64 engine: loss 1e-10, gradients 1e-7 against autograd through the reference's own strategy forward + kernel file"""
+    from dsvgp_amd._step64 import ElboEngine64
+    P, x, y, D, nd, fl, loss_ref, g_ref = gradient_problem(path)
+    eng = ElboEngine64(gpu_device)
+    eng.data_outputs = fl["outputs"]
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    assert abs(loss.item() - loss_ref) < 1e-10 * abs(loss_ref)
+    for k in PARAM_KEYS:
+        gk = torch.tril(grads[k]) if k == "chol_variational_covar" else grads[k]
+        assert relmax(gk, g_ref[k]) < 1e-7, (k, relmax(gk, g_ref[k]))
 
 
 def test_fp64_mode_refuses_what_it_does_not_cover(dsvgp, gpu_device):

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import dsvgp_oracle as O
-from _golden import STRATEGY, strategy_problem
+from _golden import GRADIENT, PARAM_KEYS, STRATEGY, gradient_problem, strategy_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -846,3 +846,21 @@ def test_predictive_matches_reference_strategy_vectors(dsvgp, gpu_device, path):
     assert errs["mean"] < 2e-4 and errs["cov"] < 2e-4
     mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
     assert relmax(mu2, mean_ref) < 2e-4 and relmax(varn2.double().cpu() - noise.double(), torch.diagonal(cov_ref)) < 2e-4
+
+
+@pytest.mark.parametrize("path", GRADIENT, ids=[__import__("os").path.basename(p) for p in GRADIENT])
+@pytest.mark.parametrize("fast", [True, False])
+def test_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device, path, fast):
+    """loss and every gradient of the HIP step (Gram fast path and per-output path) against torch autograd run THROUGH the
+    reference's own strategy forward and kernel file in fp64 (tests/golden/strategy_grad_*.npz)"""
+    P, x, y, D, nd, fl, loss_ref, g_ref = gradient_problem(path, torch.float32)
+    eng = dsvgp.ElboEngine(gpu_device)
+    eng.data_outputs, eng.shared_directions = fl["outputs"], fl["shared"]
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO", fast=fast)
+    errs = {"loss": abs(loss.item() - loss_ref) / abs(loss_ref)}
+    for k in PARAM_KEYS:
+        gk = torch.tril(grads[k]) if k == "chol_variational_covar" else grads[k]
+        errs[k] = relmax(gk, g_ref[k])
+    _report("reference-forward gradient vector %s (fast=%s)" % (__import__("os").path.basename(path), fast), errs)
+    assert errs["loss"] < 2e-5 and max(errs[k] for k in PARAM_KEYS) < 2e-3, errs
