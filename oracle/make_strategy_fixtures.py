@@ -396,6 +396,47 @@ def elbo_gradient_cases(Kern):
                  d_raw_noise=raw_noise.grad.numpy(), d_constant=const.grad.numpy())
         print("grad_%-16s loss %.6f, |dZ| max %.3e, |dV| max %.3e" % (name, loss.item(), strat.inducing_points.grad.abs().max().item(),
                                                                       strat.inducing_directions.grad.abs().max().item()))
+    # the CIQ strategy with a natural q(u): its own autograd function returns the gradients w.r.t. the EXPECTATION parameters
+    # (natural gradient descent); K^-1/2 R is the exact inverse square root (differentiated by autograd through eigh)
+    ref = _load("CiqDirectionalGradVariationalStrategy.py", "_ref_ciq_strategy_g")
+    NatDist = sys.modules["gpytorch.variational.natural_variational_distribution"].NaturalVariationalDistribution
+    for ci, (N, d, M, p, B) in enumerate(((60, 4, 8, 2, 11),)):
+        g = torch.Generator().manual_seed(700 + ci)
+        X = torch.rand(N, d, generator=g, dtype=torch.float64)
+        Z, x = X[:M].clone(), X[M:M + B].contiguous()
+        V = torch.eye(d, dtype=torch.float64)[:p].repeat(M, 1) + 0.2 * torch.randn(M * p, d, generator=g, dtype=torch.float64)
+        D = torch.eye(d, dtype=torch.float64)[:p].repeat(B, 1) + 0.1 * torch.randn(B * p, d, generator=g, dtype=torch.float64)
+        nq, nout = M * (p + 1), B * (p + 1)
+        y = torch.randn(nout, generator=g, dtype=torch.float64)
+        nv = 0.3 * torch.randn(nq, generator=g, dtype=torch.float64)
+        R = 0.2 * torch.randn(nq, nq, generator=g, dtype=torch.float64)
+        nm = -0.5 * (torch.eye(nq, dtype=torch.float64) + R @ R.t())
+        raw_ell = torch.tensor([[0.3]], dtype=torch.float64, requires_grad=True)
+        raw_s = torch.tensor(0.2, dtype=torch.float64, requires_grad=True)
+        raw_noise = torch.tensor([-0.5], dtype=torch.float64, requires_grad=True)
+        const = torch.tensor([0.1], dtype=torch.float64, requires_grad=True)
+        num_data = float((d + 1) * N)
+        kern = Kern()
+        kern._ell = F.softplus(raw_ell)
+        dist = NatDist(nv, nm)
+        strat = ref.CiqDirectionalGradVariationalStrategy(_Model(kern, const.reshape(()), F.softplus(raw_s)), Z, V, dist)
+        out = strat.forward(x, strat.inducing_points, None, None, derivative_directions=D)
+        mu, var = out.mean, torch.diagonal(out.covariance_matrix)
+        kl = strat._memoize_cache["kl"]                                         # (value 0 in the forward, :74; its gradient is what counts)
+        noise = F.softplus(raw_noise).reshape(()) + 1e-4
+        varn = (var + noise).clamp_min(1e-6)
+        ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+        loss = -(ll.sum() / nout - kl / num_data)
+        loss.backward()
+        np.savez(os.path.join(OUT, "strategy_ciq_grad_%d.npz" % ci), x=x.numpy(), y=y.numpy(), Z=Z.numpy(), V=V.numpy(), D=D.numpy(),
+                 natural_vec=nv.numpy(), natural_mat=nm.numpy(), raw_lengthscale=raw_ell.detach().numpy(),
+                 raw_outputscale=raw_s.detach().numpy(), raw_noise=raw_noise.detach().numpy(), constant=const.detach().numpy(),
+                 num_data=np.float64(num_data), p=np.int64(p), loss=loss.detach().numpy(),
+                 d_inducing_points=strat.inducing_points.grad.numpy(), d_inducing_directions=strat.inducing_directions.grad.numpy(),
+                 d_natural_vec=dist.natural_vec.grad.numpy(), d_natural_mat=dist.natural_mat.grad.numpy(),
+                 d_raw_lengthscale=raw_ell.grad.numpy(), d_raw_outputscale=raw_s.grad.numpy(), d_raw_noise=raw_noise.grad.numpy(),
+                 d_constant=const.grad.numpy())
+        print("ciq_grad_%d           loss %.6f, |d natural_mat| max %.3e" % (ci, loss.item(), dist.natural_mat.grad.abs().max().item()))
 
 
 def grad_case(Kern, O):

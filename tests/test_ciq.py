@@ -100,7 +100,7 @@ def test_ciq_predictive_matches_the_reference_strategy_forward():
     with the exact inverse square root in place of gpytorch's ``sqrt_inv_matmul`` (CiqDGVS.py:197-295)"""
     import glob, os
     import numpy as np
-    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_*.npz")))
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_[0-9].npz")))
     assert len(paths) >= 2
     for path in paths:
         g = np.load(path)
@@ -119,6 +119,30 @@ def test_ciq_predictive_matches_the_reference_strategy_forward():
 
 
 # ------------------------------------------------------------------ HIP kernels vs oracle
+def _ciq_grad_problem(path, dtype=torch.float64):
+    import numpy as np
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(g[k]).to(dtype)
+    P = dict(inducing_points=t("Z"), inducing_directions=t("V"), natural_vec=t("natural_vec"), natural_mat=t("natural_mat"),
+             constant=t("constant"), raw_outputscale=t("raw_outputscale"), raw_lengthscale=t("raw_lengthscale"), raw_noise=t("raw_noise"))
+    ref = {k: torch.from_numpy(g["d_" + k]) for k in O.NGD_PARAM_NAMES}
+    return P, t("x"), t("y"), t("D"), float(g["num_data"]), float(g["loss"]), ref
+
+
+def test_ciq_gradients_match_autograd_through_the_reference_forward():
+    """the oracle's CIQ step (exact K^-1/2) against torch autograd run THROUGH the reference's CIQ strategy forward, its own
+    ``_NgdInterpTerms`` backward and the reference kernel file (tests/golden/strategy_ciq_grad_*.npz)"""
+    import glob, os
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_grad_*.npz")))
+    assert paths
+    for path in paths:
+        P, x, y, D, nd, loss_ref, g_ref = _ciq_grad_problem(path)
+        loss, grads, _, _ = O.ciq_loss_and_grads(P, x, y, D, nd, exact=True)
+        assert abs(loss.item() - loss_ref) < 1e-10 * abs(loss_ref)
+        for k in O.NGD_PARAM_NAMES:
+            assert relmax(grads[k], g_ref[k]) < 1e-7, (k, relmax(grads[k], g_ref[k]))
+
+
 @pytest.mark.gpu
 def test_ciq_lanczos_and_solve_match_oracle(dsvgp, gpu_device):
     ops = dsvgp._ops
@@ -277,7 +301,7 @@ def test_ciq_engine_matches_the_reference_strategy_forward(dsvgp, gpu_device):
     relative residual; 5e-3 on the moments)"""
     import glob, os
     import numpy as np
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_*.npz"))):
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_[0-9].npz"))):
         g = np.load(path)
         t = lambda k: torch.from_numpy(g[k]).float().to(gpu_device)
         inv_softplus = lambda v: float(np.log(np.expm1(float(v))))
@@ -293,3 +317,20 @@ def test_ciq_engine_matches_the_reference_strategy_forward(dsvgp, gpu_device):
         e_mu, e_var = relmax(mu, torch.from_numpy(g["mean"])), relmax(varn.double().cpu() - noise, torch.from_numpy(g["variance"]))
         print("[parity] CIQ strategy vector %s: mean %.2e, variance %.2e" % (os.path.basename(path), e_mu, e_var))
         assert e_mu < 5e-3 and e_var < 5e-3
+
+
+@pytest.mark.gpu
+def test_ciq_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device):
+    """HIP CIQ step (quadrature + msMINRES forward and backward, NGD interpolation terms) against autograd through the reference's
+    CIQ forward with the exact inverse square root: loss 1e-3, gradients 2e-2 (the stated CIQ tolerance)"""
+    import glob, os
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_grad_*.npz"))):
+        P, x, y, D, nd, loss_ref, g_ref = _ciq_grad_problem(path, torch.float32)
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.whitening = "ciq"
+        Pg = {k: v.to(gpu_device) for k, v in P.items()}
+        loss, grads, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+        errs = {"loss": abs(loss.item() - loss_ref) / abs(loss_ref)}
+        errs.update({k: relmax(grads[k], g_ref[k]) for k in O.NGD_PARAM_NAMES})
+        print("[parity] CIQ reference-forward gradient vector %s: %s" % (os.path.basename(path), ", ".join("%s %.1e" % kv for kv in errs.items())))
+        assert errs["loss"] < 1e-3 and max(errs[k] for k in O.NGD_PARAM_NAMES) < 2e-2, errs
