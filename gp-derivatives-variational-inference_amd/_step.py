@@ -82,6 +82,9 @@ class ElboEngine:
         # S = L_S L_S^T on the side stream as a one-workgroup-per-CU launch (DSVGP_GEMM_BACKGROUND).  Measured alternatives that
         # did not help: least-priority side stream (hipStreamCreateWithPriority), CU-masked side stream (hipExtStreamCreateWithCUMask)
         self.side_background = os.environ.get("DSVGP_SIDE_BACKGROUND", "1") == "1"
+        # K_ZX-bar's kernel backward on the side stream next to the L-bar / Cholesky-backward products.  Off by default: measured
+        # C3 8.65 -> 8.58 ms/step, but C4 14.04-14.18 -> 14.13-14.21 and the 8-rank share unchanged
+        self.bwd_overlap = os.environ.get("DSVGP_BWD_OVERLAP", "0") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -911,7 +914,22 @@ class ElboEngine:
         dZ, dV = grads["inducing_points"], grads["inducing_directions"]
         kws = self._bytes("kbwd_ws", max(_lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p),
                                          _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, M, d, p)))
-        self._kernel_bwd_zx(ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws)     # data side: no gradient
+        # K_ZX-bar's kernel backward (HBM-bound read of 4 M' B' bytes) next to the fp64 products of L-bar and the Cholesky backward
+        # (matrix-pipe bound): on the side stream from the moment the dense product is done, joined before the K_ZZ kernel backward
+        # (both accumulate into Z-bar, V-bar and the hyper-parameter slots)
+        zx_done = None
+        dense_done, self._dense_done = getattr(self, "_dense_done", None), None
+        if self.bwd_overlap and use_fast and dense_done is not None and self._side is not None and not self.capture_mode:
+            kws2 = self._bytes("kbwd_ws_zx", _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(dense_done)
+                ctx.bind()
+                self._kernel_bwd_zx(ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws2)
+                zx_done = torch.cuda.Event()
+                zx_done.record(self._side)
+            ctx.bind()
+        else:
+            self._kernel_bwd_zx(ctx, Kb32, packZ, M, packX, B, d, p, hyp, dZ, dV, d_hyp, kws)     # data side: no gradient
         if self._global_gram:
             # L-bar is the same on every rank: each takes the inducing points [m0, m1) = columns [m0 q, m1 q) of the
             # symmetric K_ZZ-bar, whose contributions sum in the final all-reduce of (Z-bar, V-bar, hyper-parameters)
@@ -920,12 +938,16 @@ class ElboEngine:
             m0 = coll.rank * base + min(coll.rank, rem)
             m1 = m0 + base + (1 if coll.rank < rem else 0)
             Kcols = self._chol_backward_cols(ctx, L, Lbar, self._buf["trsm_ws"], Mp, m0 * q, m1 * q)
+            if zx_done is not None:
+                torch.cuda.current_stream(self.device).wait_event(zx_done)
             sub = (packZ[0][m0 * q:m1 * q], packZ[1][m0 * q:m1 * q])
             _ops.kernel_bwd(ctx, Kcols, packZ, M, sub, m1 - m0, d, p, hyp, True, dZ, dV, d_hyp, kws)
             self.variational_grads_global = True
         else:
             # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1, symmetric kernel backward ----
             Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp)
+            if zx_done is not None:
+                torch.cuda.current_stream(self.device).wait_event(zx_done)
             _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
 
         if self._dev_scale:
@@ -1059,6 +1081,9 @@ class ElboEngine:
                 _ops.gemm_lib_f32(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
             else:
                 _ops.gemm(ctx, _lib.K_PADDED, Qe32, A32e, Kb32, alpha=vbar2)
+            if self._side is not None and not self.capture_mode:        # K_ZX-bar is final: its kernel backward may start (side stream)
+                self._dense_done = torch.cuda.Event()
+                self._dense_done.record(torch.cuda.current_stream(dev))
             return Qe64
 
         if coll is None:
