@@ -19,6 +19,16 @@ constexpr int NBC = 64;
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
 #endif
+// Update / inverse tiles of one tile row are dealt to workgroups in STRIPS of up to `strip` block columns: T = A_ik W_k is formed
+// once per strip (1 + strip products for strip tiles instead of 2 per tile, A_ik and W_k loaded once).  The launcher picks the
+// strip length per launch from the tile count: long strips only where the launch is bound by its tiles, not by the diagonal
+// workgroup (a strip of 4 lasts about as long as the diagonal workgroup's load -> update -> factor chain).
+#ifndef POTRF_STRIP_T4
+#define POTRF_STRIP_T4 512      // tiles in the launch above which strips of 4 are used
+#endif
+#ifndef POTRF_STRIP_T2
+#define POTRF_STRIP_T2 256      // ... strips of 2
+#endif
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
 #pragma unroll
@@ -318,20 +328,21 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                                                   int k, int e, const double* __restrict__ Xws,
                                                   const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
                                                   double* __restrict__ Y, int64_t ldy, int nblk,
-                                                  double* __restrict__ YT) {
+                                                  double* __restrict__ YT, int strip = 1) {
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;     // column groups of waves, 16-column sub-tiles per wave, rows per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
-    const int nt = nblk - (k + 1), nR = nt * (k + 1);
+    const int nt = nblk - (k + 1), spr = (k + strip) / strip, nR = nt * spr;     // strips per tile row of R
     const int k0 = k * 64;
     const bool ytile = e >= nR;
-    const int j = ytile ? (e - nR) : (e % (k + 1));
-    const int i0 = ytile ? k0 : (k + 1 + e / (k + 1)) * 64;
-    const int j0 = j * 64;
+    int j = ytile ? (e - nR) : (e % spr) * strip;                    // (first) block column
+    const int ncols = ytile ? 1 : min(strip, k + 1 - j);
+    const int i0 = ytile ? k0 : (k + 1 + e / spr) * 64;
+    int j0 = j * 64;
     const double* Lk = ytile ? (Xws + (size_t)k * 4096) : (Wws + (size_t)k * 4096);
     // two LDS tiles only (two workgroups per CU): R_kj waits in registers until T = A_ik W_k has been formed
     double rc[NU];
     double ro[2][NJ][4];      // R-tile: the old R_ij, requested with the operands (not as 16 load -> wait -> store round trips at the end)
-    double* const rdst = Rw + (int64_t)(i0 + wr * 32 + (lane >> 4)) * ldr + j0 + wc * (16 * NJ) + (lane & 15);
+    double* rdst = Rw + (int64_t)(i0 + wr * 32 + (lane >> 4)) * ldr + j0 + wc * (16 * NJ) + (lane & 15);
     {
         double ra[NU], rb[NU];
         const int64_t arow0 = (int64_t)(i0 + (tid >> 6)) * lda, alast = (int64_t)(n - 1) * lda, astep = (int64_t)NW * lda;
@@ -385,16 +396,44 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                     S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + jj * 16 + (lane & 15)] = -acc[i][jj][q];
                     acc[i][jj][q] = ro[i][jj][q];
                 }
+#pragma unroll 1
+        for (int cc = 0; cc < ncols; ++cc) {         // the strip: -T stays in S[0], R_kj and the old R_ij change per block column
+            if (cc > 0) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) S[1][(tid >> 6) + NW * u][tid & 63] = rc[u];
-        __syncthreads();
-        tile_product<false, NW, true>(S[0], S[1], lane, wr, wc, acc);   // R_ij - T R_kj
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-            for (int jj = 0; jj < NJ; ++jj)
+                        for (int q = 0; q < 4; ++q) acc[i][jj][q] = ro[i][jj][q];
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rdst[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16] = acc[i][jj][q];
+            for (int u = 0; u < NU; ++u) S[1][(tid >> 6) + NW * u][tid & 63] = rc[u];
+            __syncthreads();
+            double* const rcur = rdst;
+            if (cc + 1 < ncols) {                    // next block column: requested now, consumed after this product
+                ++j; j0 += 64; rdst += 64;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int r = (tid >> 6) + NW * u, c = tid & 63;
+                    rc[u] = (j == k) ? ((r == c) ? 1.0 : 0.0) : Rw[(int64_t)(k0 + r) * ldr + j0 + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ro[i][jj][q] = (j == k) ? 0.0 : rdst[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16];
+            }
+            tile_product<false, NW, true>(S[0], S[1], lane, wr, wc, acc);   // R_ij - T R_kj
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rcur[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16] = acc[i][jj][q];
+            if (cc + 1 < ncols) __syncthreads();     // every wave is done reading R_kj out of S[1]
+        }
     } else {
         tile_product<false, NW>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
         if (YT == nullptr) {
@@ -437,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                                                            double* __restrict__ Xws, double* __restrict__ Wws,
                                                            int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
                                                            double* __restrict__ Yinv, int64_t ldy, int nA,
-                                                           double* __restrict__ YinvT) {
+                                                           double* __restrict__ YinvT, int strip) {
     // TWO 64 x 64 LDS tiles (70 KB with the factorisation scratch): two workgroups share a CU, which halves the rounds
     // the ~1100 update / inverse tiles of a mid-chain launch need.  The second right operand of every tile waits in
     // registers while the first product runs.
@@ -448,14 +487,17 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int b = blockIdx.x;
     if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
-        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT);
+        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip);
         return;
     }
-    int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    while (ti * (ti + 1) / 2 > b) --ti;
-    const int tj = b - ti * (ti + 1) / 2;
-    const int i0 = (k + 1 + ti) * 64, j0 = (k + 1 + tj) * 64;
+    // tile row ti holds ti + 1 update tiles, dealt to workgroups in strips of strip block columns (block 0: the diagonal tile
+    // of row 0, alone: the critical workgroup)
+    int ti = 0, first = 0;
+    while (first + (ti + strip) / strip <= b) { first += (ti + strip) / strip; ++ti; }
+    int tj = (b - first) * strip;
+    const int ncols = min(strip, ti + 1 - tj);
+    const int i0 = (k + 1 + ti) * 64;
+    int j0 = (k + 1 + tj) * 64;
     double (*F)[LDT] = S[0];
     CHOL_STAMP_DECL;
     CHOL_STAMP(0);
@@ -521,20 +563,54 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                     S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * (16 * NJ) + j * 16 + (lane & 15)] = -acc[i][j][q];
                     acc[i][j][q] = cv[i][j][q];
                 }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int r = (tid >> 6) + NW * u, c = tid & 63;
-            S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
-        }
-        __syncthreads();
-        CHOL_STAMP(6);
-        tile_product<true, NW, true>(S[0], S[1], lane, wr, wc, acc);    // C - T A_jk^T
-        CHOL_STAMP(7);
-        CHOL_STAMP(8);
-        const bool diag = ti == tj;
         const int ml0 = wr * 32 + (lane >> 4), nl0 = wc * (16 * NJ) + (lane & 15);
-        if (b != 0) {                                               // ordinary tile: back to global memory, done
-            double* const cdst = A + (int64_t)(i0 + ml0) * lda + j0 + nl0;
+#pragma unroll 1
+        for (int cc = 0; cc < ncols; ++cc) {         // the strip: -T stays in S[0]; A_jk and the C tile change per block column
+            if (cc > 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int r = (tid >> 6) + NW * u, c = tid & 63;
+                S[1][r][c] = (j0 + r < n) ? rb[u] : 0.0;
+            }
+            __syncthreads();
+            CHOL_STAMP(6);
+            const bool diag = ti == tj;
+            const int jcur = j0;
+            if (cc + 1 < ncols) {                    // next block column of the strip: requested now, consumed after this product
+                ++tj; j0 += 64;
+                const int64_t alast = (int64_t)(n - 1) * lda, astep = (int64_t)NW * lda;
+                const int64_t brow0 = (int64_t)(j0 + (tid >> 6)) * lda;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int r = (tid >> 6) + NW * u, c = tid & 63;
+                    rb[u] = A[((j0 + r < n) ? brow0 + u * astep : alast) + k * 64 + c];
+                }
+                const int m0 = i0 + ml0;
+                const int64_t crow0 = (int64_t)m0 * lda;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int nn = min(j0 + nl0 + j * 16, n - 1);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int dm = i * 16 + 4 * q;
+                            cv[i][j][q] = A[((m0 + dm < n) ? crow0 + (int64_t)dm * lda : alast) + nn];
+                        }
+                    }
+            }
+            tile_product<true, NW, true>(S[0], S[1], lane, wr, wc, acc);    // C - T A_jk^T
+            CHOL_STAMP(7);
+            CHOL_STAMP(8);
+            if (b == 0) break;                                          // (the critical tile: a strip of one, kept in LDS below)
+            double* const cdst = A + (int64_t)(i0 + ml0) * lda + jcur + nl0;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -542,11 +618,12 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ml = ml0 + i * 16 + 4 * q, nl = nl0 + j * 16;
-                        if (i0 + ml < n && j0 + nl < n && !(diag && nl > ml))
+                        if (i0 + ml < n && jcur + nl < n && !(diag && nl > ml))
                             cdst[(int64_t)(i * 16 + 4 * q) * lda + j * 16] = acc[i][j][q];
                     }
-            return;
+            if (cc + 1 < ncols) __syncthreads();     // every wave is done reading A_jk out of S[1]
         }
+        if (b != 0) return;
         __syncthreads();                                            // F aliases the T tile: every wave is done reading it
         CHOL_STAMP(10);
 #pragma unroll
@@ -656,10 +733,16 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
     const int64_t ldr = (int64_t)nblk * NBC;
     for (int k = -1; k < nblk - 1; ++k) {
         const int nt = nblk - (k + 1);
-        const int nA = (k < 0) ? 1 : nt * (nt + 1) / 2;
-        const int nI = (k >= 0 && Yinv) ? nt * (k + 1) + (k + 1) : 0;
+        const int tiles = (k < 0) ? 1 : nt * (nt + 1) / 2 + (Yinv ? nt * (k + 1) + (k + 1) : 0);
+        const int strip = tiles > POTRF_STRIP_T4 ? 4 : (tiles > POTRF_STRIP_T2 ? 2 : 1);
+        int nA = 1;                                  // update tiles, in strips of `strip` block columns per tile row
+        if (k >= 0) {
+            nA = 0;
+            for (int ti = 0; ti < nt; ++ti) nA += (ti + strip) / strip;
+        }
+        const int nI = (k >= 0 && Yinv) ? nt * ((k + strip) / strip) + (k + 1) : 0;     // R strips + Y tiles
         hipLaunchKernelGGL(chol_step_kernel<POTRF_NW>, dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info, Rw,
-                           ldr, Yinv, ldy, nA, YinvT);
+                           ldr, Yinv, ldy, nA, YinvT, strip);
         DSVGP_LAUNCH_CHECK();
     }
     if (Yinv) {
