@@ -23,8 +23,11 @@ constexpr int NBC = 64;
 // once per strip (1 + strip products for strip tiles instead of 2 per tile, A_ik and W_k loaded once).  The launcher picks the
 // strip length per launch from the tile count: long strips only where the launch is bound by its tiles, not by the diagonal
 // workgroup (a strip of 4 lasts about as long as the diagonal workgroup's load -> update -> factor chain).
+#ifndef POTRF_STRIP_T6
+#define POTRF_STRIP_T6 900      // tiles in the launch above which strips of 6 are used (8: slower, 1.56 vs 1.41 ms at n = 3000)
+#endif
 #ifndef POTRF_STRIP_T4
-#define POTRF_STRIP_T4 512      // tiles in the launch above which strips of 4 are used
+#define POTRF_STRIP_T4 512      // ... strips of 4
 #endif
 #ifndef POTRF_STRIP_T2
 #define POTRF_STRIP_T2 256      // ... strips of 2
@@ -734,7 +737,7 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
     for (int k = -1; k < nblk - 1; ++k) {
         const int nt = nblk - (k + 1);
         const int tiles = (k < 0) ? 1 : nt * (nt + 1) / 2 + (Yinv ? nt * (k + 1) + (k + 1) : 0);
-        const int strip = tiles > POTRF_STRIP_T4 ? 4 : (tiles > POTRF_STRIP_T2 ? 2 : 1);
+        const int strip = tiles > POTRF_STRIP_T6 ? 6 : (tiles > POTRF_STRIP_T4 ? 4 : (tiles > POTRF_STRIP_T2 ? 2 : 1));
         int nA = 1;                                  // update tiles, in strips of `strip` block columns per tile row
         if (k >= 0) {
             nA = 0;
