@@ -33,21 +33,19 @@ using f4 = float __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int fdiv_small(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
 
 // ---- pack -------------------------------------------------------------------------------------
-// column means of x[n, d] (one block, one column per thread slot): the common shift of both point sets
+// column means of x[n, d] (one block per column, fixed summation order): the common shift of both point sets
 __global__ void column_mean_kernel(const float* __restrict__ x, int n, int d, float* __restrict__ out) {
     __shared__ double part[256];
-    for (int k = 0; k < d; ++k) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) acc += x[(int64_t)i * d + k];
-        part[threadIdx.x] = acc;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[k] = (float)(part[0] / (double)n);
+    const int k = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[(int64_t)i * d + k];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
         __syncthreads();
     }
+    if (threadIdx.x == 0) out[k] = (float)(part[0] / (double)n);
 }
 
 __global__ void pack_points_kernel(const float* __restrict__ x, const float* __restrict__ v, int n, int d,
@@ -1355,7 +1353,7 @@ extern "C" int dsvgp_packed_width(int d) { return ((d + 3) & ~3) + 4; }
 
 extern "C" int dsvgp_column_mean(dsvgp_ctx* ctx, const float* x, int n, int d, float* out) {
     if (!ctx || !x || !out || n < 1 || d < 1) return DSVGP_EINVAL;
-    hipLaunchKernelGGL(column_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, x, n, d, out);
+    hipLaunchKernelGGL(column_mean_kernel, dim3(d), dim3(256), 0, ctx->stream, x, n, d, out);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
