@@ -3,7 +3,7 @@
 // written for register economy (<= 80 VGPRs: 6 workgroups = 24 waves per CU) instead of per-wave tile size: the
 // latency of a stage is hidden by the other workgroups of the CU, not by software pipelining inside one.
 // Same conventions as gemm.hip (triangular operands trim the K range and mask the diagonal stages, OUT_LOWER skips /
-// zeroes the tiles above the diagonal, optional fp32 copy of the result).  No split-K, no Cin: the caller (launch_gemm)
+// zeroes the tiles above the diagonal, optional fp32 copy of the result).  No Cin; split-K only in the few-tile regime (below): the caller (launch_gemm)
 // sends products with >= GEMM64_MIN_TILES tiles here and keeps gemm.hip for everything else.  Two ways of dealing tiles
 // to the 8 XCDs: >= G64_BALANCED_BELOW tiles (the [M', B'] solves) walk 16-column bands per XCD for L2 reuse; fewer tiles
 // (the M' x M' x M' class, ~1.5 rounds over the resident workgroups) are dealt in chunks ordered by decreasing K range so
@@ -20,6 +20,7 @@ struct G64 {
     const double* A; const void* B; double* C; float* C32;
     int64_t lda, ldb, ldc, ldc32;
     int M, N, K, tiles_m, tiles_n, flags, balanced;
+    int kchunk;          // > 0: split-K, blockIdx.y-th chunk of this many k of the tile's (trimmed) range; fp64 atomics onto zeros
     double alpha;
 };
 
@@ -35,6 +36,9 @@ struct G64 {
 #ifndef G64_BALANCED_BELOW
 #define G64_BALANCED_BELOW 8192
 #endif
+#ifndef G64_KCHUNK
+#define G64_KCHUNK 768      // split-K chunk (512 / 768 / 1024 measured within 0.3 %) of the few-tile (M' x M' x M') products: the longest tile's 188 dependent stages (K = 3000) set
+#endif                      // the duration of a launch whose ~1100-2200 tiles are all resident at once
 #ifndef G64_BAND
 #define G64_BAND 16         // tile columns per band (probed 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 56.5 / 57.1 / 60.8 / 62.8 / 63.4 / 57.0 / 62.6 / 54.2 TF) of the XCD-local walk
 #endif
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     }
     const int m0 = tm * T, n0 = tn * T;
     if (out_lower && n0 >= m0 + T) {                         // strictly above the diagonal: defined as zero
+        if (g.kchunk) return;                                // (split-K: the caller zeroed the whole output)
         for (int e = tid; e < T * T; e += 256) {
             const int m = m0 + e / T, n = n0 + e % T;
             if (m < g.M && n < g.N) {
@@ -98,6 +103,11 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     if (triA == 2) klo = max(klo, (m0 / BK) * BK);
     if (triB == 2) klo = max(klo, (n0 / BK) * BK);
     if (triB == 1) khi = min(khi, n0 + T);
+    if (g.kchunk) {
+        klo += (int)blockIdx.y * g.kchunk;                   // (klo is a multiple of BK, kchunk too)
+        khi = min(khi, klo + g.kchunk);
+        if (klo >= khi) return;
+    }
 
     // staging: thread -> (k = tid / 16, 4 consecutive columns at 4 (tid % 16)) of the 16 x 64 stage of each operand
     const int sk = tid >> 4, sc = (tid & 15) * 4;
@@ -191,10 +201,24 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
                 const int n = n0 + wc * 32 + j * 16 + (lane & 15);
                 if (m >= g.M || n >= g.N) continue;
                 double v = g.alpha * acc[i][j][r];
+                if (g.kchunk) {
+                    if (!(out_lower && n > m)) atomicAdd(&g.C[(int64_t)m * g.ldc + n], v);
+                    continue;
+                }
                 if (out_lower && n > m) v = 0.0;
                 if (g.C) g.C[(int64_t)m * g.ldc + n] = v;
                 if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
             }
+}
+
+// fp32 copy of a split-K result (the atomics accumulate in fp64 only)
+__global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double* __restrict__ C, int64_t ldc, float* __restrict__ C32,
+                                                          int64_t ldc32, int M, int N) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / N, c = e - r * N;
+        C32[r * ldc32 + c] = (float)C[r * ldc + c];
+    }
 }
 
 }  // namespace
@@ -214,9 +238,25 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     a.tiles_m = cdiv(g.M, T); a.tiles_n = cdiv(g.N, T);
     const int total = a.tiles_m * a.tiles_n;
     a.balanced = total < G64_BALANCED_BELOW;
-    const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8);
+    // split-K for the few-tile products with a long K: every tile is resident at once, so the launch lasts as long as its
+    // longest tile's chain of K / 16 dependent stages; chunks of G64_KCHUNK accumulate with fp64 atomics onto a zeroed output
+    a.kchunk = (G64_KCHUNK > 0 && a.balanced && g.K >= 2 * G64_KCHUNK && g.C) ? G64_KCHUNK : 0;
+    int ysplit = 1;
+    if (a.kchunk) {
+        ysplit = cdiv(g.K, a.kchunk);
+        hipError_t ez = (a.ldc == a.N) ? hipMemsetAsync(a.C, 0, sizeof(double) * (size_t)a.M * a.N, st)
+                                       : hipMemset2DAsync(a.C, sizeof(double) * (size_t)a.ldc, 0, sizeof(double) * (size_t)a.N, (size_t)a.M, st);
+        if (ez != hipSuccess) return 1000 + (int)ez;
+    }
+    const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
     if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
+    if (a.kchunk && a.C32) {
+        const int64_t tot = (int64_t)a.M * a.N;
+        const int blocks = (int)((tot + 2047) / 2048 < 4096 ? (tot + 2047) / 2048 : 4096);
+        hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, (const double*)a.C, a.ldc, a.C32,
+                           a.ldc32, a.M, a.N);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : 1000 + (int)e;
 }
