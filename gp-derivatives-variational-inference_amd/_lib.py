@@ -37,9 +37,11 @@ SIGNATURES = {
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_step_epilogue": (_i, [_p, _p, _p, _d, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_gemm_lib_f32": (_i, [_p, _i, _i, _i, _i, _f, _p, _l, _p, _l, _f, _p, _l]),
-    "dsvgp_ciq_workspace_bytes": (_z, [_i, _i, _i]),
+    "dsvgp_ciq_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_ciq_lanczos": (_i, [_p, _p, _l, _p, _i, _i, _p, _p, _p]),
-    "dsvgp_ciq_solve": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _f, _i, _i, _p, _p, _l, _p, _p]),
+    "dsvgp_ciq_solve": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _f, _i, _i, _p, _i, _p, _p, _p, _l, _p, _p]),
+    "dsvgp_ciq_mix": (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _l]),
+    "dsvgp_ciq_cross": (_i, [_p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_rowstats": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "dsvgp_ciq_tbar": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_sym_average_f32": (_i, [_p, _p, _i, _l, _p, _l]),
@@ -103,9 +105,13 @@ class DsvgpError(RuntimeError):
     pass
 
 
+ENOSPACE = -4
+
+
 def check(rc, what):
     if rc != 0:
-        kind = {-1: "invalid argument", -2: "matrix not positive definite", -3: "misaligned"}.get(rc)
+        kind = {-1: "invalid argument", -2: "matrix not positive definite", -3: "misaligned",
+                -4: "caller-sized buffer too small"}.get(rc)
         if kind is None:
             kind = "hipError %d" % (rc - 1000) if rc < 2000 else "rocblas_status %d" % (rc - 2000)
         raise DsvgpError("%s failed: %s (code %d)" % (what, kind, rc))

@@ -528,22 +528,62 @@ def ciq_lanczos(ctx, K, v0, iters):
     return alpha, beta
 
 
-def ciq_solve(ctx, K, R, sigma, omega, X, out, workspace, tol=1e-4, max_iter=1000, check_every=10):
-    """X[Q,t,n] = (K + sigma_q)^-1 R rows, out[t,n] = sum_q omega_q X[q]; returns the iteration count."""
+def ciq_qp(Q):
+    """Shift / output counts of the CIQ coefficient tables are padded to multiples of 4 (csrc/ciq.hip)."""
+    return 4 * ((int(Q) + 3) // 4)
+
+
+def ciq_solve(ctx, K, R, sigma, omega, basis, ycoef, rnorm, out, workspace, tol=1e-4, max_iter=1000, check_every=10):
+    """out[t,n] = sum_q omega_q (K + sigma_q)^-1 R rows by basis-resident msMINRES: basis[cap+1,t,n] receives the Lanczos
+    rows, ycoef[t,cap,QP] the per-shift coefficients (x_q = rnorm * mix(basis, ycoef)), rnorm[t] the row norms of R.
+    Returns the iteration count, or None when `cap` iterations were not enough (call again with a larger basis)."""
     _req(K, f32, "K", 2)
     _req(R, f32, "R", 2)
     t, n = R.shape
     Q = sigma.shape[0]
-    if K.shape != (n, n) or X.shape != (Q, t, n) or out.shape != (t, n) or not X.is_contiguous():
+    cap = basis.shape[0] - 1
+    if (K.shape != (n, n) or basis.shape != (cap + 1, t, n) or cap < 1 or ycoef.shape != (t, cap, ciq_qp(Q)) or
+            rnorm.shape != (t,) or out.shape != (t, n) or not basis.is_contiguous() or not ycoef.is_contiguous()):
         raise ValueError("ciq_solve shape mismatch")
-    need = int(lib.dsvgp_ciq_workspace_bytes(Q, t, n))
+    for a, name in ((basis, "basis"), (ycoef, "ycoef"), (rnorm, "rnorm")):
+        if a.dtype != f32 or not a.is_cuda:
+            raise TypeError("%s must be a float32 GPU tensor" % name)
+    need = int(lib.dsvgp_ciq_workspace_bytes(Q, t, n, cap))
     if workspace.numel() * workspace.element_size() < need:
         raise ValueError("ciq workspace too small")
     its = C.c_int(0)
-    check(lib.dsvgp_ciq_solve(ctx.h, _ptr(K), _ld(K), _ptr(R), _ld(R), t, n, _ptr(_req(sigma, f32, "sigma", 1)),
-                              _ptr(_req(omega, f32, "omega", 1)), Q, float(tol), int(max_iter), int(check_every), _ptr(X),
-                              _ptr(out), _ld(out), _ptr(workspace), C.byref(its)), "dsvgp_ciq_solve")
+    rc = lib.dsvgp_ciq_solve(ctx.h, _ptr(K), _ld(K), _ptr(R), _ld(R), t, n, _ptr(_req(sigma, f32, "sigma", 1)),
+                             _ptr(_req(omega, f32, "omega", 1)), Q, float(tol), int(max_iter), int(check_every), _ptr(basis),
+                             cap, _ptr(ycoef), _ptr(rnorm), _ptr(out), _ld(out), _ptr(workspace), C.byref(its))
+    if rc == _lib.ENOSPACE:
+        return None
+    check(rc, "dsvgp_ciq_solve")
     return its.value
+
+
+def ciq_mix(ctx, basis, J, coef, Kout, rowscale, out):
+    """out[k,row,:] = rowscale[row] * sum_{j<J} coef[row,j,k] basis[j,row,:] for k < Kout (coef[t,ldj,KP], KP % 4 == 0)."""
+    _, t, n = basis.shape
+    ldj, KP = coef.shape[1], coef.shape[2]
+    if (coef.shape[0] != t or J > ldj or J > basis.shape[0] or out.shape != (Kout, t, n) or not out.is_contiguous() or
+            not coef.is_contiguous() or not basis.is_contiguous() or basis.dtype != f32 or coef.dtype != f32 or out.dtype != f32):
+        raise ValueError("ciq_mix shape mismatch")
+    check(lib.dsvgp_ciq_mix(ctx.h, _ptr(basis), int(J), t, n, _ptr(coef), ldj, KP, int(Kout), _ptr(rowscale), _ptr(out), n),
+          "dsvgp_ciq_mix")
+    return out
+
+
+def ciq_cross(ctx, ya, Ja, yb, Jb, omega, rn_a, rn_b):
+    """C[t,Jb,KPa] = rn_a rn_b sum_q omega_q ya[:,ia,q] yb[:,jb,q]: coefficients that turn sum_q omega_q A_q^T B_q into
+    stack(basisA[:Ja])^T stack(mix(basisB, C)) (A_q = rn_a mix(basisA, ya)_q, B_q likewise)."""
+    t = ya.shape[0]
+    Q = omega.shape[0]
+    if yb.shape[0] != t or ya.shape[2] != ciq_qp(Q) or yb.shape[2] != ciq_qp(Q) or Ja > ya.shape[1] or Jb > yb.shape[1]:
+        raise ValueError("ciq_cross shape mismatch")
+    out = torch.empty(t, Jb, ciq_qp(Ja), dtype=f32, device=ya.device)
+    check(lib.dsvgp_ciq_cross(ctx.h, _ptr(ya), int(Ja), ya.shape[1], _ptr(yb), int(Jb), yb.shape[1], _ptr(omega), Q, t,
+                              _ptr(rn_a), _ptr(rn_b), _ptr(out)), "dsvgp_ciq_cross")
+    return out
 
 
 def ciq_rowstats(ctx, T, ST, p, m, constant, hyp, kxx_jitter=0.0):

@@ -109,6 +109,9 @@ class ElboEngine:
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
+        self.ciq_capacity = 20              # Lanczos rows kept per solve (csrc/ciq.hip); doubled when a solve needs more
+        self.ciq_backward_form = None       # stacking of the backward's sum over shifts: None = the shortest of "backward" /
+                                            # "forward" (rows of that solve's basis) / "shifts" (the Q materialised solves)
         self.ciq_stats = {}                 # lmin / lmax / iterations of the last CIQ forward + backward
         self._eval_cache = None
         # True while a step is being captured into / replayed from a HIP graph (directional_vi.TrainLoop): nothing may read
@@ -578,11 +581,14 @@ class ElboEngine:
         info.zero_()
         wsP = self._bytes("ngd_wsP", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))
         self._potrf_and_inverse(ctx, P, info[0:1], wsP, Mp, "ngd_P")
-        eye = self._buf.get("ngd_eye")
-        if eye is None or eye.shape[0] != Mp:
-            eye = self._buf["ngd_eye"] = torch.eye(Mp, dtype=f64, device=self.device)
-        X = self._get("ngd_X", (Mp, Mp), f64)
-        _ops.trsm(ctx, P, eye, False, X, None, nb, wsP, reuse_inverse=True)            # X = L_P^-1 (lower)
+        if nb >= Mp:
+            X = wsP[:Mp * Mp * 8].view(f64).view(Mp, Mp)                               # the explicit inverse is already there
+        else:                                                                          # (only its lower triangle is read below)
+            eye = self._buf.get("ngd_eye")
+            if eye is None or eye.shape[0] != Mp:
+                eye = self._buf["ngd_eye"] = torch.eye(Mp, dtype=f64, device=self.device)
+            X = self._get("ngd_X", (Mp, Mp), f64)
+            _ops.trsm(ctx, P, eye, False, X, None, nb, wsP, reuse_inverse=True)        # X = L_P^-1 (lower)
         S64 = self._get("ngd_LS64", (Mp, Mp), f64)
         _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, X, X, S64)                          # S = X^T X
         m64 = self._get("ngd_m64", (Mp, 1), f64)
@@ -709,6 +715,35 @@ class ElboEngine:
         return (torch.tensor(sigma, dtype=f32, device=dev), torch.tensor(omega, dtype=f32, device=dev),
                 [float(w) for w in omega])
 
+    def _ciq_solve(self, ctx, tag, K32, R, sigma, omega, out):
+        """out = sum_q omega_q (K + sigma_q)^-1 R by basis-resident msMINRES (csrc/ciq.hip); returns the Lanczos basis, the
+        per-shift coefficient table, the row norms and the iteration count.  The basis is sized for ``ciq_capacity``
+        iterations; a solve that needs more is run again with twice the room (and the engine keeps the larger size)."""
+        t, n = R.shape
+        Q = sigma.shape[0]
+        names = ("ciq_basis_" + tag, "ciq_ycoef_" + tag)
+        while True:
+            cap = min(int(self.ciq_capacity), int(self.ciq_max_iter))
+            have = self._buf.get(names[0])
+            if have is not None and have.shape != torch.Size((cap + 1, t, n)):
+                for nm in names:
+                    self._buf.pop(nm, None)
+                del have
+                free, _ = torch.cuda.mem_get_info(self.device)
+                cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+                if 4 * (cap + 1) * t * n > free + cached:
+                    raise RuntimeError("msMINRES did not converge within the %d Lanczos rows [%d, %d] that fit this GPU's "
+                                       "free memory" % (cap, t, n))
+            basis = self._get(names[0], (cap + 1, t, n), f32)
+            ycoef = self._get(names[1], (t, cap, _ops.ciq_qp(Q)), f32)
+            rnorm = self._get("ciq_rnorm_" + tag, (t,), f32)
+            ws = self._bytes("ciq_ws", _lib.lib.dsvgp_ciq_workspace_bytes(Q, t, n, cap))
+            its = _ops.ciq_solve(ctx, K32, R, sigma, omega, basis, ycoef, rnorm, out, ws, self.ciq_tolerance,
+                                 self.ciq_max_iter)
+            if its is not None:
+                return basis, ycoef, rnorm, its
+            self.ciq_capacity = min(2 * cap, int(self.ciq_max_iter))
+
     def _ciq_step(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, want_grads):
         """One step with K_ZZ^{-1/2} whitening by CIQ (reference CiqDirectionalGradVariationalStrategy.py:197-295) and the
         NGD interpolation terms (:19-123).  Everything Krylov lives in the row layout [B', M'] (csrc/ciq.hip).
@@ -738,10 +773,8 @@ class ElboEngine:
         _ops.kernel_fwd(ctx, packX, B, packZ, M, d, p, hyp, out=Rrow)
         sigma, omega, omega_host = self._ciq_quadrature(ctx, K32, Rrow[0])
         Q = sigma.shape[0]
-        X = self._get("ciq_X", (Q, Bp, Mp), f32)
         Trow = self._get("ciq_T", (Bp, Mp), f32)
-        ws = self._bytes("ciq_ws", _lib.lib.dsvgp_ciq_workspace_bytes(Q, Bp, Mp))
-        its = _ops.ciq_solve(ctx, K32, Rrow, sigma, omega, X, Trow, ws, self.ciq_tolerance, self.ciq_max_iter)   # :255-256
+        basisF, ycoefF, rnF, its = self._ciq_solve(ctx, "f", K32, Rrow, sigma, omega, Trow)        # :255-256
         self.ciq_stats.update(iterations=its)
         # natural parameters -> S, m (the reference's preconditioned CG on the precision, :51-61, as a direct fp64 solve)
         S64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)
@@ -776,14 +809,31 @@ class ElboEngine:
         d2.add_(nat_mat, alpha=kl_bar)                                                            # kl/2 (I - prec), prec = -2 theta_2
         d2.diagonal().add_(0.5 * kl_bar)
         # backward of sqrt_inv_matmul: dR = K^-1/2 Tbar, dK = -sym sum_q omega_q Y_q^T X_q (same quadrature)
-        Y = self._get("ciq_Y", (Q, Bp, Mp), f32)
         Rbar = self._get("ciq_Rbar", (Bp, Mp), f32)
-        its_b = _ops.ciq_solve(ctx, K32, Tbar, sigma, omega, Y, Rbar, ws, self.ciq_tolerance, self.ciq_max_iter)
+        basisB, ycoefB, rnB, its_b = self._ciq_solve(ctx, "b", K32, Tbar, sigma, omega, Rbar)
         self.ciq_stats.update(iterations_backward=its_b)
+        # the solves X_q = rnF mix(basisF, ycoefF)_q, Y_q = rnB mix(basisB, ycoefB)_q are never formed: with per-row cross
+        # coefficients the sum over shifts is ONE product over the stacked rows of the shorter basis (or, when both solves took
+        # more iterations than there are shifts, over the Q materialised solves)
         dK = self._get("ciq_dK", (Mp, Mp), f32)
-        dK.zero_()
-        for q in range(Q):
-            _ops.gemm(ctx, TRANS_A, Y[q], X[q], dK, alpha=-omega_host[q], beta=1.0, Cin=dK)
+        form = self.ciq_backward_form
+        if form is None:
+            form = "backward" if its_b <= min(its, Q) else ("forward" if its <= Q else "shifts")
+        kmin = {"backward": its_b, "forward": its, "shifts": Q}[form]
+        if form == "backward":
+            ctab = _ops.ciq_cross(ctx, ycoefB, its_b, ycoefF, its, omega, rnB, rnF)
+            Zs = _ops.ciq_mix(ctx, basisF, its, ctab, its_b, None, self._get("ciq_Z", (its_b, Bp, Mp), f32))
+            left, right = basisB[:its_b], Zs
+        elif form == "forward":
+            ctab = _ops.ciq_cross(ctx, ycoefF, its, ycoefB, its_b, omega, rnF, rnB)
+            Zs = _ops.ciq_mix(ctx, basisB, its_b, ctab, its, None, self._get("ciq_Z", (its, Bp, Mp), f32))
+            left, right = Zs, basisF[:its]
+        else:
+            om = torch.zeros(_ops.ciq_qp(Q), dtype=f32, device=dev)
+            om[:Q] = omega
+            right = _ops.ciq_mix(ctx, basisF, its, ycoefF * om, Q, rnF, self._get("ciq_Z", (Q, Bp, Mp), f32))
+            left = _ops.ciq_mix(ctx, basisB, its_b, ycoefB, Q, rnB, self._get("ciq_Z2", (Q, Bp, Mp), f32))
+        _ops.gemm(ctx, TRANS_A, left.reshape(kmin * Bp, Mp), right.reshape(kmin * Bp, Mp), dK, alpha=-1.0)
         Kzzbar = self._get("ciq_Kzzbar", (Mp, Mp), f32)
         _ops.sym_average_f32(ctx, dK, Kzzbar)
         Kb32 = self._get("Kb32", (Mp, Bp), f32)

@@ -37,7 +37,8 @@ enum {
     DSVGP_OK = 0,
     DSVGP_EINVAL = -1,     /* bad argument / unsupported shape        */
     DSVGP_ENOTPD = -2,     /* Cholesky failed (matrix not PD)         */
-    DSVGP_EALIGN = -3      /* pointer / leading dimension misaligned  */
+    DSVGP_EALIGN = -3,     /* pointer / leading dimension misaligned  */
+    DSVGP_ENOSPACE = -4    /* a caller-sized buffer filled up: call again with a larger one */
 };
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -280,18 +281,30 @@ int dsvgp_gemm_lib_f32(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alp
  * utils/contour_integral_quad.py, utils/minres.py).  Layout: one right-hand side per ROW, R[t, n], K[n, n] symmetric.
  * dsvgp_ciq_lanczos: `iters` Lanczos steps from v0 -> alpha[iters], beta[iters] (host takes the Ritz values of the
  *   tridiagonal as eigenvalue bounds, max_lanczos_iter = 20).  workspace: 3 n + 2 floats.
- * dsvgp_ciq_solve: X[Q, t, n] = (K + sigma_q I)^-1 R for all shifts from one Lanczos process per row, and
- *   out[t, n] = sum_q omega_q X[q]; stops when the mean of |update| / |solution| over (shift, row) < tol, tested every
- *   `check_every` iterations (gpytorch: tol 1e-4, every 10, at most 1000).  workspace: dsvgp_ciq_workspace_bytes.
+ * dsvgp_ciq_solve: out[t, n] = sum_q omega_q (K + sigma_q I)^-1 R for all shifts from one Lanczos process per row; stops
+ *   when the mean of |update| / |solution| over (shift, row) < tol, tested every `check_every` iterations (gpytorch: tol 1e-4,
+ *   every 10, at most 1000).  Basis-resident msMINRES: basis[cap + 1][t][n] receives the Lanczos rows q_0 .. q_J, the
+ *   per-shift solutions are not stored but left as coefficients, x_q[row] = rnorm[row] sum_j ycoef[row][j][q] q_j[row]
+ *   (ycoef[t][cap][QP], QP = Q rounded up to a multiple of 4); DSVGP_ENOSPACE when J would exceed cap.
+ *   workspace: dsvgp_ciq_workspace_bytes(Q, t, n, cap).
+ * dsvgp_ciq_mix: out[k][row][:] = rowscale[row] sum_{j<J} C[row][j][k] basis[j][row][:], k < Kout (C[t][ldj][KP], KP % 4 == 0):
+ *   materialises solves (C = ycoef) or any per-row combination of them.
+ * dsvgp_ciq_cross: C[t][Jb][KPa] = rn_a rn_b sum_q omega_q ya[.][ia][q] yb[.][jb][q] (KPa = Ja rounded up to 4): with it the
+ *   backward's sum_q omega_q A_q^T B_q = stack_ia(basisA)^T stack_ia(mix(basisB, C)) is ONE product of depth Ja t instead of Q
+ *   products of depth t (gpytorch's sqrt_inv_matmul backward, utils/contour_integral_quad.py + functions/_sqrt_inv_matmul.py).
  * dsvgp_ciq_rowstats / dsvgp_ciq_tbar: the mean / variance interpolation terms of _NgdInterpTerms (:65-69,265-266)
  *   and the gradient factors of its backward (:94-118) for rows of T = (K^-1/2 K_ZX)^T and ST = T S.
  * dsvgp_sym_average_f32: out = (A + A^T) / 2.                                                                  */
-size_t dsvgp_ciq_workspace_bytes(int Q, int t, int n);
+size_t dsvgp_ciq_workspace_bytes(int Q, int t, int n, int cap);
 int dsvgp_ciq_lanczos(dsvgp_ctx* ctx, const float* K, int64_t ldk, const float* v0, int n, int iters, float* alpha,
                       float* beta, void* workspace);
 int dsvgp_ciq_solve(dsvgp_ctx* ctx, const float* K, int64_t ldk, const float* R, int64_t ldr, int t, int n,
-                    const float* sigma, const float* omega, int Q, float tol, int max_iter, int check_every, float* X,
-                    float* out, int64_t ldo, void* workspace, int* iters_out);
+                    const float* sigma, const float* omega, int Q, float tol, int max_iter, int check_every, float* basis,
+                    int cap, float* ycoef, float* rnorm, float* out, int64_t ldo, void* workspace, int* iters_out);
+int dsvgp_ciq_mix(dsvgp_ctx* ctx, const float* basis, int J, int t, int n, const float* C, int ldj, int KP, int Kout,
+                  const float* rowscale, float* out, int64_t ldo);
+int dsvgp_ciq_cross(dsvgp_ctx* ctx, const float* ya, int Ja, int lda, const float* yb, int Jb, int ldb, const float* omega,
+                    int Q, int t, const float* rn_a, const float* rn_b, float* Cout);
 int dsvgp_ciq_rowstats(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, int p, const float* m,
                        const float* constant, const float* hyp, float kxx_jitter, float* imean, float* mu, float* var,
                        float* live);   /* kxx_jitter: 0 for the directional strategy (:235-239), 1e-4 for gpytorch's plain

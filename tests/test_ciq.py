@@ -162,10 +162,20 @@ def test_ciq_lanczos_and_solve_match_oracle(dsvgp, gpu_device):
     lmin, lmax = O.lanczos_eig_bounds(K.float().double(), R.float().double()[0])
     assert abs(eigs.max().item() - lmax) < 1e-4 * lmax and abs(eigs.min().item() - lmin) < 2e-2 * lmin
     sigma, omega = O.ciq_quadrature(lmin, lmax, Q)
-    X = torch.empty(Q, t, n, device=dev)
     out = torch.empty(t, n, device=dev)
-    ws = torch.empty(int(dsvgp._lib.lib.dsvgp_ciq_workspace_bytes(Q, t, n)), dtype=torch.uint8, device=dev)
-    its = ops.ciq_solve(ctx, K32, R32, sigma.float().to(dev), omega.float().to(dev), X, out, ws)
+    sig32, om32 = sigma.float().to(dev), omega.float().to(dev)
+
+    def solve(cap):
+        basis = torch.empty(cap + 1, t, n, device=dev)
+        ycoef = torch.empty(t, cap, ops.ciq_qp(Q), device=dev)
+        rnorm = torch.empty(t, device=dev)
+        ws = torch.empty(int(dsvgp._lib.lib.dsvgp_ciq_workspace_bytes(Q, t, n, cap)), dtype=torch.uint8, device=dev)
+        return ops.ciq_solve(ctx, K32, R32, sig32, om32, basis, ycoef, rnorm, out, ws), basis, ycoef, rnorm
+
+    assert solve(10)[0] is None                                      # DSVGP_ENOSPACE: more than 10 Lanczos rows are needed
+    its, basis, ycoef, rnorm = solve(200)
+    # the per-shift solves are not stored: materialise them from the basis and the coefficient table
+    X = ops.ciq_mix(ctx, basis, its, ycoef, Q, rnorm, torch.empty(Q, t, n, device=dev))
     Xr, its_r = O.msminres(K, R.t().contiguous(), sigma)             # oracle: columns
     assert abs(its - its_r) <= 10
     for q in (0, 7, 14):                                              # fp32 vs fp64, stopped within 10 iterations of each other
@@ -174,6 +184,28 @@ def test_ciq_lanczos_and_solve_match_oracle(dsvgp, gpu_device):
     assert relmax(out.t(), T_ref) < 5e-3
     # and against the exact inverse square root (quadrature + solver error)
     assert relmax(out.t(), O.sqrt_inv_matmul_exact(K, R.t().contiguous())) < 2e-2
+
+
+@pytest.mark.gpu
+def test_ciq_backward_forms_and_basis_growth_agree(dsvgp, gpu_device):
+    """the backward's sum over shifts stacked over the backward basis, the forward basis or the materialised solves is the
+    same matrix; a basis sized too small is grown (ENOSPACE -> twice the rows) without changing the result"""
+    P, x, y, D, nd = make_ngd_problem(400, 2, 20, 2, 100, seed=402)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    args = (x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    res = {}
+    for form, cap in (("backward", 20), ("forward", 20), ("shifts", 20), (None, 4)):
+        eng = dsvgp.ElboEngine(gpu_device, trsm_nb=4096)
+        eng.whitening, eng.ciq_backward_form, eng.ciq_capacity = "ciq", form, cap
+        loss, grads, mu, varn = eng.loss_and_grads(Pg, *args)
+        res[(form, cap)] = (loss.item(), {k: grads[k].clone() for k in O.NGD_PARAM_NAMES}, eng.ciq_stats["iterations"])
+        assert eng.ciq_capacity >= eng.ciq_stats["iterations"] and eng.ciq_capacity >= eng.ciq_stats["iterations_backward"]
+    l0, g0, it0 = res[("backward", 20)]
+    for key, (l, g, it) in res.items():
+        assert it == it0 and abs(l - l0) <= 1e-6 * abs(l0), key
+        for k in O.NGD_PARAM_NAMES:
+            if g0[k].numel() and g0[k].abs().max() > 0:
+                assert relmax(g[k], g0[k]) < 2e-4, (key, k, relmax(g[k], g0[k]))
 
 
 @pytest.mark.gpu
