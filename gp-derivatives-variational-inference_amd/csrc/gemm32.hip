@@ -44,6 +44,15 @@ constexpr int TM = 128, TN = 128;
 #ifndef G32_DMAPRIO
 #define G32_DMAPRIO 0
 #endif
+#ifndef G32_SK_BELOW
+#define G32_SK_BELOW 4096   // tile count below which the split-K cost model is consulted (few rounds: a ragged last round costs most)
+#endif
+#ifndef G32_SK_SLOTS
+#define G32_SK_SLOTS 256    // work units per round in the split-K cost model: one per CU (a CU's matrix pipe is shared by its resident workgroups)
+#endif
+#ifndef G32_SK_MINT
+#define G32_SK_MINT 0
+#endif
 #ifndef G32_ABL
 #define G32_ABL 0           // timing ablations (results are WRONG): 1 no global fetch in the loop, 2 no LDS stores, 4 no LDS fragment reads, 8 no barriers
 #endif
@@ -529,19 +538,21 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     } else {
         a.ntiles = a.tiles_m * a.tiles_n;
     }
-    // split-K: few tiles and a long K (the Gram product over the minibatch axis).  Cost model: rounds over 2 resident
-    // workgroups per CU (below that a CU's matrix pipe idles at stage boundaries) x (slice length + fixed cost)
+    // split-K: few rounds of tiles and a long K (the Gram product over the minibatch axis; the [B', M'] x [M', M'] products of
+    // CIQ: 1152 tiles = 4.5 per CU).  Cost model: per-CU makespan, ceil(units / 256) x (slice length + fixed cost); measured
+    // against fixed slice counts: C5's K_ZZ products 1 / 2 / 3 / 4 / 6 slices -> 80.9 / 77.1 / 78.7 / 77.7 / 78.7 ms per step
+    // (the model picks 2), the Gram product of C4 5 slices as before
     int sk = 1;
-    if (a.ntiles < 1024 && g.K >= 1024) {
+    if (a.ntiles < G32_SK_BELOW && g.K >= 1024) {
         double best = 1e300;
         const int maxsk = g.K / 256 < 64 ? g.K / 256 : 64;
         for (int c = 1; c <= maxsk; ++c) {
-            const double tcost = (double)cdiv((int64_t)a.ntiles * c, 512) * ((double)g.K / c + 384.0);
+            const double tcost = (double)cdiv((int64_t)a.ntiles * c, G32_SK_SLOTS) * ((double)g.K / c + 384.0);
             if (tcost < best * 0.999) { best = tcost; sk = c; }
         }
     }
-#ifdef G32_SK
-    if (a.ntiles < 1024 && g.K >= 1024) sk = G32_SK;
+#ifdef G32_SK      // probe: fixed slice count for the products of G32_SK_MINT..G32_SK_BELOW tiles
+    if (a.ntiles < G32_SK_BELOW && a.ntiles >= G32_SK_MINT && g.K >= 1024 && g.K < 16384) sk = G32_SK;
 #endif
     a.splitk = sk;
     a.kslice = cdiv(cdiv(g.K, sk), 32) * 32;
