@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--lib-gemm", action="store_true",
                     help="diagnostics: the dense K_ZX-bar product through rocBLAS sgemm instead of the hand-written kernel")
     ap.add_argument("--no-pack-reduce", action="store_true", help="diagnostics (N > 1): dense instead of packed-triangle all-reduce")
+    ap.add_argument("--fp64", action="store_true",
+                    help="the reference's experiment-script mode (torch.set_default_dtype(torch.float64), "
+                         "experiments/synthetic/exp_script.py:56): data, model and every kernel in double precision")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="HIP-graph replay of the step (one rank, ELBO fast path); measured no faster than eager at C2, see DESIGN.md")
     ap.add_argument("--dp-algo", default=os.environ.get("DSVGP_DP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
@@ -162,6 +165,8 @@ def main():
     import torch.distributed as dist
     # rehearsal on a one-GPU box: DSVGP_REHEARSE_GLOO=1 runs all ranks on cuda:0 over gloo (exercises the sharded path,
     # not a measurement); the driver's multi-GPU runs use one GPU per rank over RCCL
+    if args.fp64:
+        torch.set_default_dtype(torch.float64)
     rehearse = os.environ.get("DSVGP_REHEARSE_GLOO") == "1"
     if rehearse:
         local_rank = 0
@@ -241,7 +246,7 @@ def main():
     # three more untimed steps with the side stream off, HIP events around the same launch
     step_events = list(eng.events)
     iso_fwd = None
-    if not cfg.get("ciq") and world == 1:
+    if not cfg.get("ciq") and world == 1 and not args.fp64:
         saved = eng.overlap
         eng.overlap, eng.events = False, []
         for k in range(3):
@@ -286,6 +291,12 @@ def main():
         roof = dict(bound="mfma", kernel="gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                     traffic=traffic, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
+        if rank == 0:
+            # what THIS card sustains on the same instruction with no memory traffic (40 ms of back-to-back MFMAs after the
+            # timed region): `peak` above is the data-sheet figure at 2.4 GHz, which no MI355X of this pool holds under matrix load
+            sus = dsvgp_amd._ops.mfma_rate(dsvgp_amd._ops.Context.get(device), True, 40)
+            roof["sustained"] = dict(measured_mfma_only=sus, unit="TFLOP/s", frac_of_sustained=ach / sus,
+                                     note="v_mfma_f64_16x16x4_f64 from registers on all CUs (dsvgp_mfma_rate)")
 
     # kernel assembly (north_star: HBM GB/s of the assembly): algorithmic bytes per launch =
     # 4 [M' B' + (M + B) d (p + 1)] -- write the block matrix once (forward) / read its gradient once (backward) plus the
@@ -311,7 +322,8 @@ def main():
             "metric": "ELBO steps/sec, DSVGP d=20 N=1M M=500 p=5" if args.config == "c4" else "ELBO steps/sec, " + cfg["name"],
             "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (f64 Cholesky/solves)", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.fp64 else "f32 (f64 Cholesky/solves)",
+            "data": "synthetic",
             "config": {"workload": cfg["name"], "global_batch": B, "per_gpu_batch": B // world, "M_prime": Mp,
                        "parallelism": "dp%d rows" % world, "trsm_nb": eng.trsm_nb, "final_loss": final_loss,
                        "graph_replay": bool(loop._graphs),
@@ -328,7 +340,7 @@ def main():
                                                early_operand_floats=int(eng.early_wire_numel))
         if cfg.get("ciq"):
             out["config"]["ciq"] = dict(eng.ciq_stats)
-        if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq"):
+        if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq") and not args.fp64:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -40,6 +40,7 @@ SIGNATURES = {
     "dsvgp_ciq_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_ciq_lanczos": (_i, [_p, _p, _l, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_solve": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _f, _i, _i, _p, _i, _p, _p, _p, _l, _p, _p]),
+    "dsvgp_mfma_rate": (_i, [_p, _i, _i, _p, _p]),
     "dsvgp_ciq_mix": (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _l]),
     "dsvgp_ciq_cross": (_i, [_p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_rowstats": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),

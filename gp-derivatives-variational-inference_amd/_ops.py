@@ -606,3 +606,12 @@ def ciq_tbar(ctx, T, ST, m, mu_bar, var_bar, live, imean, Tbar, VT):
 def sym_average_f32(ctx, A, out):
     check(lib.dsvgp_sym_average_f32(ctx.h, _ptr(_req(A, f32, "A", 2)), A.shape[0], _ld(A), _ptr(out), _ld(out)),
           "dsvgp_sym_average_f32")
+
+
+def mfma_rate(ctx, is_double=True, millis=40):
+    """TFLOP/s this card sustains on back-to-back MFMA instructions from registers (fp64 16x16x4 or fp32 32x32x2): the roof a
+    GEMM kernel can reach under the card's power management.  Measurement aid for bench.py."""
+    scratch = torch.empty(2 << 20, dtype=torch.uint8, device=ctx.device)
+    out = C.c_double(0.0)
+    check(lib.dsvgp_mfma_rate(ctx.h, 1 if is_double else 0, int(millis), _ptr(scratch), C.byref(out)), "dsvgp_mfma_rate")
+    return out.value

@@ -193,3 +193,83 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
     }
     return 0;
 }
+
+// ---- measurement aid: what the matrix pipes of THIS card sustain -------------------------------------------------
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_32x32x2_f32 back to back from registers (no memory traffic) on every CU, long enough
+// for the clocks to settle: the roof a GEMM kernel can reach under the card's power management (the data-sheet peaks are at
+// 2.4 GHz; MI355X boxes hold 2.0-2.1 GHz under sustained matrix load, and differ by a few per cent among themselves).
+namespace {
+using d4v = double __attribute__((ext_vector_type(4)));
+using f16v = float __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mfma_rate_f64_kernel(double* out, int iters) {
+    d4v acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4v{0, 0, 0, 0};
+    const double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void mfma_rate_f32_kernel(float* out, int iters) {
+    f16v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    const float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += acc[i][k];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}  // namespace
+
+// is_double: 1 = v_mfma_f64_16x16x4_f64, 0 = v_mfma_f32_32x32x2_f32.  Runs ~`millis` ms of launches on the context's stream
+// (synchronises it) and returns the rate of the second half in *tflops.  scratch: 256 * 1024 * 8 bytes.
+extern "C" int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* scratch, double* tflops) {
+    if (!ctx || !scratch || !tflops || millis < 2 || millis > 2000) return DSVGP_EINVAL;
+    hipStream_t st = ctx->stream;
+    const int grid = 256 * 4, iters = 2000;                      // 4 workgroups (16 waves) per CU; ~1.7 ms (f64) per launch
+    const double flop_per_launch = is_double ? (double)grid * 4 * iters * 32 * 2048.0 : (double)grid * 4 * iters * 32 * 4096.0;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1000 + (int)hipGetLastError();
+    auto launch = [&]() {
+        if (is_double) hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(grid), dim3(256), 0, st, (double*)scratch, iters);
+        else hipLaunchKernelGGL(mfma_rate_f32_kernel, dim3(grid), dim3(256), 0, st, (float*)scratch, iters);
+    };
+    // calibrate the launch count on one launch, warm up for half the budget, time the other half
+    hipEventRecord(e0, st); launch(); hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) return 1000 + (int)hipGetLastError();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    int n = (int)(0.5 * millis / (ms > 1e-3f ? ms : 1e-3f));
+    n = n < 1 ? 1 : (n > 2000 ? 2000 : n);
+    for (int i = 0; i < n; ++i) launch();
+    hipEventRecord(e0, st);
+    for (int i = 0; i < n; ++i) launch();
+    hipEventRecord(e1, st);
+    hipError_t e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (e != hipSuccess) return 1000 + (int)e;
+    *tflops = flop_per_launch * n / (ms * 1e-3) / 1e12;
+    return 0;
+}

@@ -313,6 +313,12 @@ int dsvgp_ciq_tbar(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n
                    const float* var_bar, const float* live, const float* imean, float* Tbar, float* VT, float* cvec);
 int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, float* out, int64_t ldo);
 
+/* ---- measurement aid (bench.py `roofline.sustained`): the MFMA rate this card holds with no memory traffic, ~`millis` ms of
+ * v_mfma_f64_16x16x4_f64 (is_double = 1) or v_mfma_f32_32x32x2_f32 (0) on every CU; synchronises the stream.
+ * scratch: 2 MiB of device memory.  Not part of the reference's interface (SURVEY.md 8d asks for achieved-vs-peak; the
+ * data-sheet peak is at 2.4 GHz, which the card does not hold under matrix load).                                        */
+int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* scratch, double* tflops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -535,3 +535,13 @@ def test_gemm32_mfma_32x32x2_kernels(dsvgp, gpu_device, M, N, K, ta, tb, lower, 
     assert err < 3e-5
     if lower:
         assert C.triu(1).abs().max().item() == 0.0
+
+
+@pytest.mark.gpu
+def test_mfma_rate_probe_reports_a_plausible_roof(dsvgp, gpu_device):
+    """bench.py's `roofline.sustained`: back-to-back MFMAs from registers must land between half the data-sheet peak and the peak"""
+    ctx = dsvgp._ops.Context.get(gpu_device)
+    r64 = dsvgp._ops.mfma_rate(ctx, True, 10)
+    r32 = dsvgp._ops.mfma_rate(ctx, False, 10)
+    assert 39.0 < r64 <= 78.6 * 1.02, r64
+    assert 78.0 < r32 <= 157.3 * 1.02, r32
