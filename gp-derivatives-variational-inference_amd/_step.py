@@ -109,7 +109,8 @@ class ElboEngine:
         self.ciq_num_quadrature = 15        # train_gp(num_contour_quadrature=15)
         self.ciq_tolerance = 1e-4           # gpytorch settings.minres_tolerance
         self.ciq_max_iter = 1000            # gpytorch settings.max_cg_iterations
-        self.ciq_capacity = 20              # Lanczos rows kept per solve (csrc/ciq.hip); doubled when a solve needs more
+        self.ciq_capacity = None            # Lanczos rows kept per solve (csrc/ciq.hip): None = as many as fit 4 GiB (at least
+                                            # 20, at most ciq_max_iter); doubled (and the solve repeated) when one needs more
         self.ciq_backward_form = None       # stacking of the backward's sum over shifts: None = the shortest of "backward" /
                                             # "forward" (rows of that solve's basis) / "shifts" (the Q materialised solves)
         self.ciq_stats = {}                 # lmin / lmax / iterations of the last CIQ forward + backward
@@ -722,6 +723,8 @@ class ElboEngine:
         t, n = R.shape
         Q = sigma.shape[0]
         names = ("ciq_basis_" + tag, "ciq_ycoef_" + tag)
+        if self.ciq_capacity is None:
+            self.ciq_capacity = max(20, (4 << 30) // (4 * t * n))
         while True:
             cap = min(int(self.ciq_capacity), int(self.ciq_max_iter))
             have = self._buf.get(names[0])
@@ -862,7 +865,8 @@ class ElboEngine:
             # mn-contiguous operand path), then only the lower half of the symmetric result, mirrored
             Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
             Yt = Lbar                                                       # reuse
-            _ops.gemm(ctx, TRANS_A | B_LOWER, G1, Linv, Yt)                 # S L^-1 = (L^-T S)^T
+            # only the lower triangle of S L^-1 is read by the next product (rows k >= i >= j of column j): n^3/3 instead of n^3/2
+            _ops.gemm(ctx, TRANS_A | B_LOWER | OUT_LOWER, G1, Linv, Yt)     # tril(S L^-1), S L^-1 = (L^-T S)^T
             _ops.gemm(ctx, TRANS_A | A_UPPER | OUT_LOWER, Linv, Yt, Kbar, alpha=0.5)        # 1/2 tril(L^-T S L^-1)
             _ops.phi_symmetrize_(ctx, Kbar)
         else:
