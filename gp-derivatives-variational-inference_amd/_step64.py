@@ -11,8 +11,9 @@ and the ELBO are then all fp64.  ``ElboEngine64`` is that mode of ``directional_
   * the O(B') likelihood terms, the O(M'^2) KL term and the softplus constraints are elementwise torch fp64 tensor
     expressions on the device, differentiated by autograd exactly like the reference does (directional_vi.py:245-249).
 
-It is the general (variance-carrying) formulation, so ELBO and PLL are both covered; it is not the benchmark path (the
-headline configs run the reference's default fp32 model).  Under ``parallel.DataParallel`` the gradients of the row shards are
+Two formulations, as in the fp32 engine: the general (variance-carrying) one covers ELBO and PLL; in ELBO mode, when the caller
+does not read the per-output variances, the Gram-matrix formulation (``_elbo_fast64``) needs three [M', B'] products instead
+of six.  It is not the benchmark path (the headline configs run the reference's default fp32 model; ``bench.py --fp64`` times it).  Under ``parallel.DataParallel`` the gradients of the row shards are
 summed by one all-reduce at the end of the step (no early operand).  No CPU fallback: the inputs must be HIP tensors.
 """
 import math
@@ -39,7 +40,8 @@ class ElboEngine64(ElboEngine):
 
     def __init__(self, device, trsm_nb=None):
         super().__init__(device, trsm_nb)
-        self.elbo_fast = False
+        self.elbo_fast = True
+        self.fast_min_work = 4_000_000      # M' B' below which the per-output path is used anyway (C2: host-bound, 2.42 vs 2.58 ms)
 
     # ---- forward pieces -----------------------------------------------------------------------
     def _check(self, params, x, D):
@@ -169,9 +171,15 @@ class ElboEngine64(ElboEngine):
             raise ValueError("y must be the interleaved float64 target vector of length B*(p+1)=%d" % Bp)
         rows = float(Bp if global_rows is None else global_rows)
 
+        if mll_type not in ("ELBO", "PLL"):
+            raise ValueError("mll_type must be 'ELBO' or 'PLL'")
+        if fast is None:
+            fast = self.elbo_fast
         raw, _, hyp = self._hyp64(params)
         packZ, L, dims, ws = self._factor64(ctx, params, hyp, Bp)
         M, d, p, Mp = dims
+        if fast and mll_type == "ELBO" and Mp * Bp >= self.fast_min_work:
+            return self._elbo_fast64(ctx, params, hyp, packZ, L, dims, ws, x, y, D, rows, num_data, include_kl)
         packX, A, W, mu0, cs = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
 
         # ---- O(B') likelihood terms, O(M'^2) KL, constraints: torch fp64 expressions + autograd (directional_vi.py:245-249) ----
@@ -186,11 +194,9 @@ class ElboEngine64(ElboEngine):
             varn = (var + noise).clamp_min(MIN_VARIANCE)
             if mll_type == "ELBO":
                 ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
-            elif mll_type == "PLL":
+            else:
                 tot = (varn + noise).clamp_min(1e-8)
                 ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
-            else:
-                raise ValueError("mll_type must be 'ELBO' or 'PLL'")
             loss = -ll.sum() / rows
             if include_kl:
                 LSl = torch.tril(LS_)
@@ -198,9 +204,7 @@ class ElboEngine64(ElboEngine):
                 loss = loss + kl / num_data
             leaves = [mu0_, cs_, c_, raw[0], raw[1], raw[2]] + ([m_, LS_] if include_kl else [])
             g = torch.autograd.grad(loss, leaves, allow_unused=True)
-        mu_bar, var_bar, dc = g[0].contiguous(), g[1].contiguous(), g[2]
-        zero = torch.zeros((), dtype=f64, device=dev)
-        d_raw = [t if t is not None else zero for t in g[3:6]]
+        mu_bar, var_bar = g[0].contiguous(), g[1].contiguous()
         grads = {k: torch.zeros_like(params[k]) for k in PARAM_NAMES}
         dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
         if include_kl:
@@ -225,6 +229,15 @@ class ElboEngine64(ElboEngine):
         _ops.trsm(ctx, L, Abar, True, Kb, None, self.trsm_nb, ws, reuse_inverse=True)     # K_ZX-bar = L^-T Abar
         Lbar = self._get("Lbar", (Mp, Mp), f64)
         _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb, A, Lbar, alpha=-1.0)                      # L-bar = -tril(K_ZX-bar A^T)
+        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, g[2], g[3:6])
+        return loss.detach(), grads, mu.detach(), varn.detach()
+
+    def _kernel_part64(self, ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, dc, d_raw):
+        """K_ZX-bar and L-bar -> inducing points / directions and the kernel hyper-parameters (both formulations)"""
+        M, d, p, Mp = dims
+        dev = self.device
+        zero = torch.zeros((), dtype=f64, device=dev)
+        d_raw = [t if t is not None else zero for t in d_raw]
         dZ, dV = grads["inducing_points"], grads["inducing_directions"]
         d_hyp = torch.zeros(4, dtype=f64, device=dev)
         if pd != p:
@@ -237,11 +250,92 @@ class ElboEngine64(ElboEngine):
         Kzzbar = self._chol_backward(ctx, L, Lbar, ws, Mp)
         scratch = self._get("T_zz", (Mp, Mp), f64)
         _ops.kernel_bwd_f64(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, scratch)
-
         # softplus chain rule of the kernel hyper-parameters; autograd already holds the likelihood / prior-diagonal parts
         sig = [torch.sigmoid(params[k].reshape(())) for k in ("raw_lengthscale", "raw_outputscale")]
         grads["raw_lengthscale"].add_((d_raw[0] + d_hyp[0] * sig[0]).reshape(grads["raw_lengthscale"].shape))
         grads["raw_outputscale"].add_((d_raw[1] + d_hyp[1] * sig[1]).reshape(grads["raw_outputscale"].shape))
         grads["raw_noise"].add_(d_raw[2].reshape(grads["raw_noise"].shape))
         grads["constant"].add_(dc.reshape(grads["constant"].shape))
-        return loss.detach(), grads, mu.detach(), varn.detach()
+
+    def _elbo_fast64(self, ctx, params, hyp, packZ, L, dims, ws, x, y, D, rows, num_data, include_kl):
+        """ELBO through the Gram matrix G = A A^T (the fp64 form of ``ElboEngine._elbo_fast``): d loss / d var_j = vbar is the
+        same for every output, so  sum_j var_j = prior + tr(L_S^T G L_S) - tr G,  L_S-bar = 2 vbar tril(G L_S),
+        K_ZX-bar = [2 vbar Q' | a] [A ; mu_bar^T],  L-bar = -tril([2 vbar Q' | a] [G ; b^T])  with  Q' = L^-T (S - I), a = L^-T m,
+        b = A mu_bar.  [M', B'] products: the solve, the Gram product and one dense product (the general path has six).
+        The min-variance clamp of the per-output path (1e-6 on var + noise, noise >= 1e-4) is taken as inactive, as there.
+        Returns an empty ``varn``."""
+        M, d, p, Mp = dims
+        B = x.shape[0]
+        pd = self._pd(p)
+        Bp = B * (pd + 1)
+        dev = self.device
+        m = params["variational_mean"].contiguous()
+        LS = params["chol_variational_covar"]
+        packX = _ops.pack_points_f64(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        Ae = self._get("Ae64", (Mp + 1, Bp), f64)                   # [A ; mu_bar^T]
+        A = Ae[:Mp]
+        Kzx = self._get("Kzx", (Mp, Bp), f64)
+        if pd != p:                                                 # derivative-free data: value columns of the full block matrix
+            full = self._get("Kzx_full", (Mp, B * (p + 1)), f64)
+            _ops.kernel_fwd_f64(ctx, packZ, M, packX, B, d, p, hyp, out=full)
+            Kzx.copy_(full[:, ::p + 1])
+        else:
+            _ops.kernel_fwd_f64(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        _ops.trsm(ctx, L, Kzx, False, A, None, self.trsm_nb, ws, reuse_inverse=True)      # A = L^-1 K_ZX
+        mu0 = torch.empty(Bp, 1, dtype=f64, device=dev)
+        _ops.gemm(ctx, TRANS_A, A, m.reshape(Mp, 1), mu0)                                 # A^T m
+        mu0 = mu0.reshape(Bp)
+        # G = A A^T needs no gradient information, but b = A mu_bar does: the likelihood terms first
+        Ge = self._get("Ge64", (Mp + 1, Mp), f64)                   # [tril(G) ; b^T] -> [G ; b^T]
+        G = Ge[:Mp]
+        _ops.gemm(ctx, TRANS_B | OUT_LOWER, A, A, G)
+        H = self._get("H64", (Mp, Mp), f64)
+        LSl = torch.tril(LS).contiguous()
+        Gs = torch.tril(G)
+        Gs = Gs + torch.tril(G, -1).t()                             # the symmetric G
+        G.copy_(Gs)
+        _ops.gemm(ctx, B_LOWER, G, LSl, H)                                                # G L_S
+        tvar = ((H * LSl).sum() - torch.diagonal(G).sum()).detach()                     # tr(L_S^T G L_S) - tr G
+        with torch.enable_grad():
+            raw, (ell, s, noise), _ = self._hyp64(params, grad=True)
+            mu0_ = mu0.requires_grad_(True)
+            tvar_ = tvar.requires_grad_(True)
+            c_ = params["constant"].detach().reshape(()).clone().requires_grad_(True)
+            m_ = m.detach().clone().requires_grad_(True)
+            LS_ = LS.detach().clone().requires_grad_(True)
+            mu = mu0_ + c_
+            sum_varn = self._prior_diag(B, p, pd, ell, s, x).sum() + Bp * (KXX_JITTER + noise) + tvar_
+            ll = -0.5 * ((((y - mu) ** 2).sum() + sum_varn) / noise + Bp * (torch.log(noise) + math.log(2 * math.pi)))
+            loss = -ll / rows
+            if include_kl:
+                LSt = torch.tril(LS_)
+                kl = 0.5 * ((m_ * m_).sum() + (LSt * LSt).sum() - Mp - torch.log(torch.diagonal(LSt) ** 2).sum())
+                loss = loss + kl / num_data
+            leaves = [mu0_, tvar_, c_, raw[0], raw[1], raw[2]] + ([m_, LS_] if include_kl else [])
+            g = torch.autograd.grad(loss, leaves, allow_unused=True)
+        mu_bar, vbar = g[0].contiguous(), g[1]                      # vbar = 1 / (2 noise rows)
+        grads = {k: torch.zeros_like(params[k]) for k in PARAM_NAMES}
+        dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
+        if include_kl:
+            dm.add_(g[6])
+            dLS.add_(g[7])
+        dLS.add_(torch.tril(H) * (2.0 * vbar))                                            # 2 vbar tril(G L_S)
+        Ae[Mp].copy_(mu_bar)
+        b = torch.empty(Mp, 1, dtype=f64, device=dev)
+        _ops.gemm(ctx, 0, A, mu_bar.reshape(Bp, 1), b)                                    # b = A mu_bar
+        dm.add_(b.reshape(-1))
+        Ge[Mp].copy_(b.reshape(-1))
+        # [Q' | a] = L^-T [S - I | m], then the 2 vbar of the variance terms on the Q' block
+        Se = self._get("Se64", (Mp, Mp + 1), f64)
+        _ops.gemm(ctx, TRANS_B | A_LOWER, LSl, LSl, Se[:, :Mp])                           # S = L_S L_S^T
+        Se[:, :Mp].diagonal().sub_(1.0)
+        Se[:, Mp].copy_(m)
+        Qe = self._get("Qe64", (Mp, Mp + 1), f64)
+        _ops.trsm(ctx, L, Se, True, Qe, None, self.trsm_nb, ws, reuse_inverse=True)
+        Qe[:, :Mp].mul_(2.0 * vbar)
+        Kb = self._get("Kb64", (Mp, Bp), f64)
+        _ops.gemm(ctx, 0, Qe, Ae, Kb)                                                     # K_ZX-bar (the one dense [M', B'] product)
+        Lbar = self._get("Lbar", (Mp, Mp), f64)
+        _ops.gemm(ctx, OUT_LOWER, Qe, Ge, Lbar, alpha=-1.0)                               # L-bar = -tril([2 vbar Q' | a] [G ; b^T])
+        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, g[2], g[3:6])
+        return loss.detach(), grads, mu.detach(), torch.empty(0, dtype=f64, device=dev)

@@ -133,17 +133,24 @@ CASES = [
 
 
 @pytest.mark.parametrize("N,d,M,p,B", CASES)
-@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+@pytest.mark.parametrize("mll", ["ELBO", "PLL", "ELBO-gram"])
 def test_fp64_step_matches_fp64_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
+    """both formulations of the fp64 step: per-output (ELBO, PLL) and the Gram-matrix ELBO (no per-output variances)"""
     from dsvgp_amd._step64 import ElboEngine64
+    fast = mll == "ELBO-gram"
+    mll = "ELBO" if fast else mll
     P, x, y, D, nd = make_problem64(N, d, M, p, B, seed=N + d)
     assert all(v.dtype == f64 for v in P.values())
     l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd, mll)
     eng = ElboEngine64(gpu_device)
+    eng.fast_min_work = 0                  # (the Gram formulation at test sizes too)
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
-    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll, fast=fast)
     torch.cuda.synchronize()
     assert loss.dtype == f64 and all(v.dtype == f64 for v in grads.values())
+    if fast:
+        assert varn.numel() == 0
+        varn = var_ref.to(gpu_device)
     errs = {"loss": abs(loss.item() - l_ref.item()) / abs(l_ref.item()), "mu": relmax(mu, mu_ref), "var": relmax(varn, var_ref)}
     assert errs["loss"] < 1e-9 and errs["mu"] < 1e-9 and errs["var"] < 1e-9, errs
     for k in O.PARAM_NAMES:
@@ -167,13 +174,14 @@ def test_fp64_dfree_data_outputs(dsvgp, gpu_device):
     y = y.reshape(60, 3)[:, 0].contiguous()
     l_ref, g_ref, mu_ref, var_ref = O.elbo_loss_and_grads(P, x, y, D, nd, "ELBO", data_outputs="values")
     eng = ElboEngine64(gpu_device)
-    eng.data_outputs = "values"
+    eng.data_outputs, eng.fast_min_work = "values", 0
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
-    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO")
-    assert abs(loss.item() - l_ref.item()) / abs(l_ref.item()) < 1e-9
-    assert relmax(mu, mu_ref) < 1e-9 and relmax(varn, var_ref) < 1e-9
-    for k in O.PARAM_NAMES:
-        assert relmax(grads[k], g_ref[k]) < 1e-7, k
+    for fast in (False, True):
+        loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO", fast=fast)
+        assert abs(loss.item() - l_ref.item()) / abs(l_ref.item()) < 1e-9
+        assert relmax(mu, mu_ref) < 1e-9 and (fast or relmax(varn, var_ref) < 1e-9)
+        for k in O.PARAM_NAMES:
+            assert relmax(grads[k], g_ref[k]) < 1e-7, (fast, k)
 
 
 def test_fp64_row_shards_add_up_and_joint_covariance(dsvgp, gpu_device):
@@ -184,18 +192,20 @@ def test_fp64_row_shards_add_up_and_joint_covariance(dsvgp, gpu_device):
     eng = ElboEngine64(gpu_device)
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
     xg, yg, Dg = x.to(gpu_device), y.to(gpu_device), D.to(gpu_device)
-    l_full, g_full, _, _ = eng.loss_and_grads(Pg, xg, yg, Dg, nd)
-    g_full = {k: v.clone() for k, v in g_full.items()}
-    rows = float(y.shape[0])
-    tot_l, tot_g = 0.0, None
-    for r, (lo, hi) in enumerate(((0, 25), (25, 60))):
-        l, g, _, _ = eng.loss_and_grads(Pg, xg[lo:hi].contiguous(), yg[lo * 3:hi * 3].contiguous(), Dg[lo * 2:hi * 2].contiguous(),
-                                        nd, global_rows=rows, include_kl=(r == 0))
-        tot_l += l.item()
-        tot_g = {k: v.clone() for k, v in g.items()} if tot_g is None else {k: tot_g[k] + g[k] for k in g}
-    assert abs(tot_l - l_full.item()) < 1e-12 * abs(l_full.item())
-    for k in g_full:
-        assert relmax(tot_g[k], g_full[k]) < 1e-10, k
+    for min_work in (eng.fast_min_work, 0):                     # per-output formulation (small problem), then the Gram one
+        eng.fast_min_work = min_work
+        l_full, g_full, _, _ = eng.loss_and_grads(Pg, xg, yg, Dg, nd)
+        g_full = {k: v.clone() for k, v in g_full.items()}
+        rows = float(y.shape[0])
+        tot_l, tot_g = 0.0, None
+        for r, (lo, hi) in enumerate(((0, 25), (25, 60))):
+            l, g, _, _ = eng.loss_and_grads(Pg, xg[lo:hi].contiguous(), yg[lo * 3:hi * 3].contiguous(),
+                                            Dg[lo * 2:hi * 2].contiguous(), nd, global_rows=rows, include_kl=(r == 0))
+            tot_l += l.item()
+            tot_g = {k: v.clone() for k, v in g.items()} if tot_g is None else {k: tot_g[k] + g[k] for k in g}
+        assert abs(tot_l - l_full.item()) < 1e-12 * abs(l_full.item())
+        for k in g_full:
+            assert relmax(tot_g[k], g_full[k]) < 1e-10, (min_work, k)
     mu_ref, Sigma_ref = O.predictive_joint(P, x, D)
     _, _, noise = O.constrained(P)
     mu, Sigma = eng.predict_joint(Pg, xg, Dg)
