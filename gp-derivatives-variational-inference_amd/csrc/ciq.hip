@@ -81,6 +81,30 @@ __global__ __launch_bounds__(256) void ciq_lanczos_kernel(const float* __restric
     for (int i = threadIdx.x; i < n; i += 256) qnext[o + i] = row[i] * inv;
 }
 
+// y = K x for ONE vector (the Ritz-bound Lanczos run): one wave per row of the symmetric row-major K, 16-byte loads along the
+// row -- HBM-bound (the GEMM path spends a 128-row tile on the single row: 115 us at n = 6144 against ~35 here)
+__global__ __launch_bounds__(256) void ciq_symv_kernel(const float* __restrict__ K, int64_t ldk, const float* __restrict__ x,
+                                                       int n, float* __restrict__ y, int vec4) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* k = K + (int64_t)row * ldk;
+    double acc = 0.0;
+    if (vec4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = lane * 4; j < n; j += 256) {
+            const float4 kv = *(const float4*)(k + j), xv = *(const float4*)(x + j);
+            a0 = fmaf(kv.x, xv.x, a0); a1 = fmaf(kv.y, xv.y, a1); a2 = fmaf(kv.z, xv.z, a2); a3 = fmaf(kv.w, xv.w, a3);
+        }
+        acc = ((double)a0 + a1) + ((double)a2 + a3);
+    } else {
+        float a0 = 0.f;
+        for (int j = lane; j < n; j += 64) a0 = fmaf(k[j], x[j], a0);
+        acc = a0;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) y[row] = (float)acc;
+}
+
 // Paige-Saunders rotations for every (shift q, row j).  state[5][Q*t] = cs, sn, dbar, eps, phibar;
 // coef[4][Q*t] = oldeps, delta, 1/gamma, phi of this iteration (one slot of the history ciq_backsub_kernel reads).
 __global__ void ciq_givens_kernel(const float* __restrict__ alpha, const float* __restrict__ beta_next,
@@ -509,12 +533,10 @@ extern "C" int dsvgp_ciq_lanczos(dsvgp_ctx* ctx, const float* K, int64_t ldk, co
     DSVGP_LAUNCH_CHECK();
     float* qcur = qa;
     float* qprev = qb;
+    const int vec4 = n % 4 == 0 && ldk % 4 == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)workspace % 16) == 0;
     for (int k = 0; k < iters; ++k) {
-        GemmArgs g{};
-        g.M = 1; g.N = n; g.K = n; g.A = qcur; g.lda = n; g.B = K; g.ldb = ldk; g.C = V; g.ldc = n;
-        g.alpha = 1.0; g.beta = 0.0; g.flags = 0; g.batch = 1; g.splitk = 1;
-        int rc = launch_gemm(st, 0, g);
-        if (rc) return rc;
+        hipLaunchKernelGGL(ciq_symv_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, K, ldk, qcur, n, V, vec4);   // V = K q (K symmetric)
+        DSVGP_LAUNCH_CHECK();
         hipLaunchKernelGGL(ciq_lanczos_kernel, dim3(1), dim3(256), sizeof(float) * n, st, V, qcur, (const float*)qprev, qprev,
                            k == 0 ? b0 : beta + (k - 1), n, alpha + k, beta + k);
         DSVGP_LAUNCH_CHECK();

@@ -19,8 +19,10 @@ def main():
     c = sqlite3.connect(a.db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
-    by_name = c.execute("select %s, count(*), sum(end-start), min(end-start), max(end-start) from kernels group by %s "
-                        "order by 3 desc" % (namecol, namecol)).fetchall()
+    # (bench.py's MFMA-rate probe runs once after the timed region: not part of a step)
+    notprobe = "%s not like '%%mfma_rate_%%'" % namecol
+    by_name = c.execute("select %s, count(*), sum(end-start), min(end-start), max(end-start) from kernels where %s group by %s "
+                        "order by 3 desc" % (namecol, notprobe, namecol)).fetchall()
     tot = sum(r[2] for r in by_name)
     print("total kernel ms/step %.3f" % (tot / a.steps / 1e6))
     out = ["kernel,calls,calls_per_step,ms_per_step,avg_us,min_us,max_us"]
@@ -35,8 +37,8 @@ def main():
     # forward solve and the Q' solve both run gemm64_kernel<float>), and the bench's roofline entry is about ONE of them
     gridcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
     if gridcol:
-        rows = c.execute("select %s, %s, count(*), sum(end-start) from kernels group by %s, %s order by 4 desc"
-                         % (namecol, gridcol, namecol, gridcol)).fetchall()
+        rows = c.execute("select %s, %s, count(*), sum(end-start) from kernels where %s group by %s, %s order by 4 desc"
+                         % (namecol, gridcol, notprobe, namecol, gridcol)).fetchall()
         print("-- by kernel and launch size (grid threads), the 12 largest")
         for n, g, cnt, ns in rows[:12]:
             print("%-88s grid=%-9d calls/step=%6.1f ms/step=%7.3f avg_us=%9.1f" % (n[:88], g, cnt / a.steps, ns / a.steps / 1e6,
