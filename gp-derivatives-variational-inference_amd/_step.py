@@ -591,7 +591,8 @@ class ElboEngine:
             X = self._get("ngd_X", (Mp, Mp), f64)
             _ops.trsm(ctx, P, eye, False, X, None, nb, wsP, reuse_inverse=True)        # X = L_P^-1 (lower)
         S64 = self._get("ngd_LS64", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER, X, X, S64)                          # S = X^T X
+        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, X, X, S64)              # tril(S), S = X^T X (symmetric:
+        _ops.phi_symmetrize_(ctx, S64)                                                  # n^3/6 multiply-adds + a mirror pass)
         m64 = self._get("ngd_m64", (Mp, 1), f64)
         t64 = self._get("ngd_t64", (Mp, 1), f64)
         t64.copy_(nat_vec.reshape(Mp, 1))
