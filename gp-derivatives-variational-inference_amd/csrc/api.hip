@@ -188,6 +188,11 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
         f.alpha = 1.0; f.beta = 0.0;
         f.C = X64 ? X64 + (size_t)r0 * ldx64 : nullptr; f.ldc = ldx64;
         if (X32) { f.C32 = X32 + (size_t)r0 * ldx32; f.ldc32 = ldx32; }
+        if (!X64 && (int64_t)cdiv(nr, 64) * cdiv(nrhs, 64) < 1024) {
+            // small solve, fp32 result only (b >= n here: T is unused scratch of n x nrhs doubles): give the product an fp64
+            // target so that it may split K -- few tiles, each a chain of n / 16 dependent stages -- and convert afterwards
+            f.C = T; f.ldc = nrhs;
+        }
         int rc = launch_gemm(st, 1, f);
         if (rc) return rc;
     }

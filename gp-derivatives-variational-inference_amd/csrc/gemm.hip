@@ -567,7 +567,9 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     // grid fills the 512 resident-workgroup slots a few times over; partial sums meet in atomics.
     const bool inplace_acc = g.Cin && g.Cin == g.C && g.beta == 1.0 && g.ldcin == g.ldc;
     if (!g.C && !g.C32) return DSVGP_EINVAL;
-    if (a.batch == 1 && a.splitk == 1 && !a.C32 && (!a.Cin || inplace_acc) && a.K >= sk_min_k) {
+    // (a result wanted in fp32 AND fp64 may split too: the slices meet in the fp64 copy, a conversion pass writes the other)
+    float* cvt32 = nullptr;
+    if (a.batch == 1 && a.splitk == 1 && (!a.C32 || (is_double && a.C && !a.Cin)) && (!a.Cin || inplace_acc) && a.K >= sk_min_k) {
         const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (a.bm / a.bn) : a.tiles_m * a.tiles_n;
         // split factor: minimise (rounds over the 256 CUs -- two resident workgroups share a CU's matrix pipe, so the
         // CU, not the slot, is the unit of throughput) x (K slice + fixed per-workgroup cost)
@@ -585,6 +587,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
         }
         if (sk > 1) {
             a.splitk = sk;
+            if (a.C32) { cvt32 = a.C32; a.C32 = nullptr; }
             if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; }      // atomics accumulate onto the existing C
             else {
                 hipError_t e = zero_block(a.C, esz, a.ldc, a.M, a.N, st);
@@ -617,8 +620,12 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
         grid = dim3(cdiv(cdiv(total, (int64_t)cs), 8) * 8 * cs, 1, 1);
     }
     if (is_double) {
-        if (g.flags & DSVGP_GEMM_B_IS_FLOAT) return dispatch<double, float>(st, a, grid);
-        return dispatch<double, double>(st, a, grid);
+        const int rc = (g.flags & DSVGP_GEMM_B_IS_FLOAT) ? dispatch<double, float>(st, a, grid) : dispatch<double, double>(st, a, grid);
+        if (rc == 0 && cvt32) {
+            launch_cvt_f64_f32(st, (const double*)a.C, a.ldc, cvt32, g.ldc32, a.M, a.N);
+            DSVGP_LAUNCH_CHECK();
+        }
+        return rc;
     }
     if (g.flags & (DSVGP_GEMM_B_IS_FLOAT | DSVGP_GEMM_CIN_IS_FLOAT)) return DSVGP_EINVAL;
     return dispatch<float, float>(st, a, grid);

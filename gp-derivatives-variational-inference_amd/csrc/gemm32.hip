@@ -47,6 +47,9 @@ constexpr int TM = 128, TN = 128;
 #ifndef G32_SK_BELOW
 #define G32_SK_BELOW 4096   // tile count below which the split-K cost model is consulted (few rounds: a ragged last round costs most)
 #endif
+#ifndef G32_SK_MINK
+#define G32_SK_MINK 512     // shortest K that may be split (slices of >= 256)
+#endif
 #ifndef G32_SK_SLOTS
 #define G32_SK_SLOTS 256    // work units per round in the split-K cost model: one per CU (a CU's matrix pipe is shared by its resident workgroups)
 #endif
@@ -543,7 +546,7 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     // against fixed slice counts: C5's K_ZZ products 1 / 2 / 3 / 4 / 6 slices -> 80.9 / 77.1 / 78.7 / 77.7 / 78.7 ms per step
     // (the model picks 2), the Gram product of C4 5 slices as before
     int sk = 1;
-    if (a.ntiles < G32_SK_BELOW && g.K >= 1024) {
+    if (a.ntiles < G32_SK_BELOW && g.K >= G32_SK_MINK) {
         double best = 1e300;
         const int maxsk = g.K / 256 < 64 ? g.K / 256 : 64;
         for (int c = 1; c <= maxsk; ++c) {

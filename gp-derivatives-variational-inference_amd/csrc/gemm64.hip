@@ -223,6 +223,13 @@ __global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double* __restri
 
 }  // namespace
 
+// C32 = (float) C: the fp32 copy of a split-K result that was accumulated in fp64
+void launch_cvt_f64_f32(hipStream_t st, const double* C, int64_t ldc, float* C32, int64_t ldc32, int M, int N) {
+    const int64_t tot = (int64_t)M * N;
+    const int blocks = (int)((tot + 2047) / 2048 < 4096 ? (tot + 2047) / 2048 : 4096);
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, C, ldc, C32, ldc32, M, N);
+}
+
 // returns 1 if the product was taken, 0 if the caller must use gemm.hip, > 1 on a launch error
 int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     const int fl = g.flags;
@@ -251,12 +258,7 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
     if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
-    if (a.kchunk && a.C32) {
-        const int64_t tot = (int64_t)a.M * a.N;
-        const int blocks = (int)((tot + 2047) / 2048 < 4096 ? (tot + 2047) / 2048 : 4096);
-        hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, (const double*)a.C, a.ldc, a.C32,
-                           a.ldc32, a.M, a.N);
-    }
+    if (a.kchunk && a.C32) launch_cvt_f64_f32(st, a.C, a.ldc, a.C32, a.ldc32, a.M, a.N);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : 1000 + (int)e;
 }
