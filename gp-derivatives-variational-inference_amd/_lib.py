@@ -81,12 +81,13 @@ SIGNATURES = {
     "dsvgp_elbo_fast_finalize": (_i, [_p, _p, _p, _i, _i, _d, _p]),
     "dsvgp_mirror_lower_f32": (_i, [_p, _p, _i, _l]),
     "dsvgp_add_diag_f32": (_i, [_p, _p, _i, _l, _f]),
+    "dsvgp_sminus_i_col": (_i, [_p, _p, _i, _l, _p, _p, _d]),
     "dsvgp_adam_step_multi_dev": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p]),
     "dsvgp_scale_by_vbar": (_i, [_p, _p, _l, _p, _l, _p, _l, _p, _d]),
     "dsvgp_kl_terms_scaled": (_i, [_p, _p, _p, _l, _i, _d, _i, _p, _d, _p, _p, _p, _l]),
     "dsvgp_tril_pack_f32": (_i, [_p, _p, _l, _i, _p, _i, _p]),
     "dsvgp_tril_unpack_f32": (_i, [_p, _p, _i, _p, _l, _p, _i]),
-    "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
     "dsvgp_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "dsvgp_adam_step_multi": (_i, [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i]),
 }

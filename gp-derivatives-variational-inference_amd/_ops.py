@@ -437,6 +437,14 @@ def mirror_lower_f32_(ctx, G, n):
     check(lib.dsvgp_mirror_lower_f32(ctx.h, _ptr(_req(G, f32, "G", 2)), n, _ld(G)), "dsvgp_mirror_lower_f32")
 
 
+def sminus_i_col_(ctx, A, n, m, hyp, rows):
+    """A[n, n+1] -> [A[:, :n] - I | m * noise * rows] in place (one launch)"""
+    if A.shape != (n, n + 1) or A.dtype != f32 or A.stride(1) != 1:
+        raise ValueError("sminus_i_col_ wants a float32 [n, n + 1] view with unit column stride")
+    check(lib.dsvgp_sminus_i_col(ctx.h, _ptr(A), n, int(A.stride(0)), _ptr(_req(m, f32, "m", 1)), _ptr(hyp), float(rows)),
+          "dsvgp_sminus_i_col")
+
+
 def add_diag_f32_(ctx, A, n, delta):
     check(lib.dsvgp_add_diag_f32(ctx.h, _ptr(_req(A, f32, "A", 2)), n, _ld(A), float(delta)), "dsvgp_add_diag_f32")
 
@@ -469,10 +477,16 @@ def tril_unpack_f32(ctx, src, dst, extra):
           "dsvgp_tril_unpack_f32")
 
 
-def gather_batch(ctx, X, Y, idx, cols, p, xb, yb):
+def gather_batch(ctx, X, Y, idx, cols, p, xb, yb, E=None, Db=None):
+    """minibatch rows of X, the selected columns of Y and (with the [d, d] direction table E) the batch's derivative
+    directions Db[nb * p, d] in one launch"""
+    if E is not None and (E.shape != (X.shape[1], X.shape[1]) or not E.is_contiguous() or E.dtype != f32 or Db is None or
+                          Db.shape != (idx.shape[0] * p, X.shape[1]) or not Db.is_contiguous() or Db.dtype != f32):
+        raise ValueError("gather_batch: E must be [d, d] and Db [nb * p, d] float32 contiguous")
     check(lib.dsvgp_gather_batch(ctx.h, _ptr(_req(X, f32, "X", 2)), _ptr(_req(Y, f32, "Y", 2)),
                                  _ptr(_req(idx, torch.int64, "idx", 1)), idx.shape[0], X.shape[1], Y.shape[1],
-                                 _ptr(_req(cols, torch.int32, "cols", 1)), p, _ptr(xb), _ptr(yb)), "dsvgp_gather_batch")
+                                 _ptr(_req(cols, torch.int32, "cols", 1)), p, _ptr(xb), _ptr(yb), _ptr(E), _ptr(Db)),
+          "dsvgp_gather_batch")
 
 
 ADAM_MAX_TENSORS = 16

@@ -1036,8 +1036,7 @@ class ElboEngine:
         # 4600 workgroups leave no CU with the LDS share a Cholesky step workgroup needs, and two launches of the chain wait
         # 130-190 us each for it to drain
         _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER | (_lib.BACKGROUND if background else 0), LS, LS, S32)
-        _ops.add_diag_f32_(ctx, S32, Mp, -1.0)
-        S32e[:, Mp].copy_(m * (hyp[2] * rows))               # m / (2 vbar), 2 vbar = 1 / (noise rows)
+        _ops.sminus_i_col_(ctx, S32e, Mp, m.contiguous(), hyp, rows)   # S - I and the column m / (2 vbar), 2 vbar = 1 / (noise rows)
         return dict(packX=packX, Kzx=Kzx, S32e=S32e)
 
     def _elbo_fast(self, ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl, scal, kl_buf, dm,

@@ -247,11 +247,16 @@ __global__ void add_diag_kernel(double* A, int n, int64_t lda, double delta) {
 
 __global__ void gather_kernel(const float* __restrict__ X, const float* __restrict__ Y, const int64_t* __restrict__ idx,
                               int nb, int d, int ycols, const int* __restrict__ cols, int p, float* __restrict__ xb,
-                              float* __restrict__ yb) {
+                              float* __restrict__ yb, const float* __restrict__ E, float* __restrict__ Db) {
     const int b = blockIdx.x;
     const int64_t src = idx[b];
     for (int k = threadIdx.x; k < d; k += blockDim.x) xb[(int64_t)b * d + k] = X[src * d + k];
     for (int c = threadIdx.x; c <= p; c += blockDim.x) yb[(int64_t)b * (p + 1) + c] = Y[src * ycols + cols[c]];
+    if (E)      // the batch's derivative directions: row a of point b = row cols[a + 1] - 1 of E (the canonical basis, :238)
+        for (int e = threadIdx.x; e < p * d; e += blockDim.x) {
+            const int a = e / d, k = e - a * d;
+            Db[((int64_t)b * p + a) * d + k] = E[(int64_t)(cols[a + 1] - 1) * d + k];
+        }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
@@ -449,6 +454,16 @@ __global__ void add_diag_f32_kernel(float* A, int n, int64_t lda, float delta) {
     if (i < n) A[(int64_t)i * lda + i] += delta;
 }
 
+// [S | .] -> [S - I | m noise rows]: the right-hand side of the [Q' | a / (2 vbar)] solve in one pass (2 vbar = 1 / (noise rows))
+__global__ void sminus_i_col_kernel(float* A, int n, int64_t lda, const float* __restrict__ m, const float* __restrict__ hyp,
+                                    float rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        A[(int64_t)i * lda + i] -= 1.f;
+        A[(int64_t)i * lda + n] = m[i] * (hyp[2] * rows);
+    }
+}
+
 // Packed lower triangle (row i at offset i(i+1)/2, i+1 entries) + `nextra` trailing floats: the data-parallel all-reduce
 // operand ([tril(G) ; b^T] or [tril(L_S-bar) ; m-bar]) at half the dense volume.  One workgroup per row.
 __global__ void tril_pack_f32_kernel(const float* __restrict__ src, int64_t ld, int n, const float* __restrict__ extra,
@@ -608,10 +623,11 @@ extern "C" int dsvgp_add_diag(dsvgp_ctx* ctx, double* A, int n, int64_t lda, dou
 }
 
 extern "C" int dsvgp_gather_batch(dsvgp_ctx* ctx, const float* X, const float* Y, const int64_t* idx, int nb, int d,
-                                  int ycols, const int* cols, int p, float* xb, float* yb) {
-    if (!ctx || !X || !Y || !idx || !cols || !xb || !yb || nb < 0 || d <= 0 || p < 0 || ycols <= p) return DSVGP_EINVAL;
+                                  int ycols, const int* cols, int p, float* xb, float* yb, const float* E, float* Db) {
+    if (!ctx || !X || !Y || !idx || !cols || !xb || !yb || nb < 0 || d <= 0 || p < 0 || ycols <= p || (E && !Db))
+        return DSVGP_EINVAL;
     if (nb == 0) return 0;
-    hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(64), 0, ctx->stream, X, Y, idx, nb, d, ycols, cols, p, xb, yb);
+    hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(64), 0, ctx->stream, X, Y, idx, nb, d, ycols, cols, p, xb, yb, E, Db);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -694,6 +710,13 @@ extern "C" int dsvgp_mirror_lower_f32(dsvgp_ctx* ctx, float* G, int n, int64_t l
 extern "C" int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, float delta) {
     if (!ctx || !A || n <= 0) return DSVGP_EINVAL;
     hipLaunchKernelGGL(add_diag_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, delta);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsvgp_sminus_i_col(dsvgp_ctx* ctx, float* A, int n, int64_t lda, const float* m, const float* hyp, double rows) {
+    if (!ctx || !A || !m || !hyp || n <= 0 || lda < n + 1) return DSVGP_EINVAL;
+    hipLaunchKernelGGL(sminus_i_col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, m, hyp, (float)rows);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -195,19 +195,27 @@ class TrainLoop:
         dim, p, dev = self.dim, self.minibatch_dim, self.device
         nb = idx.shape[0]
         self.ctx.bind()                         # the library launches on torch's CURRENT stream (the capture stream under a graph)
+        Db = None
         if self.X.dtype == torch.float64:       # fp64 model mode: plain index_select (O(B d) copies)
             x_batch = self.X.index_select(0, idx)
             y_batch = self.Y.index_select(0, idx).index_select(1, cols.long()).reshape(-1)
         else:
             x_batch = torch.empty(nb, dim, dtype=torch.float32, device=dev)
             y_batch = torch.empty(nb * (py + 1), dtype=torch.float32, device=dev)
-            _ops.gather_batch(self.ctx, self.X, self.Y, idx, cols, py, x_batch, y_batch)  # interleaved y, :241
+            fused_dirs = (not self.dfree and not self.full_gradient and py == p and p > 0
+                          and self.E_canonical.shape == (dim, dim) and self.E_canonical.dtype == torch.float32)
+            Db = torch.empty(nb * p, dim, dtype=torch.float32, device=dev) if fused_dirs else None
+            _ops.gather_batch(self.ctx, self.X, self.Y, idx, cols, py, x_batch, y_batch,  # interleaved y, :241
+                              self.E_canonical if fused_dirs else None, Db)              # + the directions, :238
         kwargs = {}
         if self.dfree:                          # dfree_directional_vi.py:224-227
             kwargs["derivative_directions"] = self.E_canonical[:p].repeat(nb, 1)
         elif not self.full_gradient:
-            derivative_directions = self.E_canonical.index_select(0, cols[1:].long() - 1)
-            kwargs["derivative_directions"] = derivative_directions.repeat(nb, 1)   # :238
+            if Db is not None:
+                kwargs["derivative_directions"] = Db
+            else:
+                derivative_directions = self.E_canonical.index_select(0, cols[1:].long() - 1)
+                kwargs["derivative_directions"] = derivative_directions.repeat(nb, 1)   # :238
 
         self.variational_optimizer.zero_grad()
         self.hyperparameter_optimizer.zero_grad()
@@ -241,9 +249,9 @@ class TrainLoop:
         if not ok:
             return False
         # opt-in only (``loop.graph = True`` / DSVGP_GRAPH=1 / ``bench.py --graph on``).  Measured on MI355X (round 2): the C2 step
-        # (M' = 600, ~110 launches) takes 0.80 ms eager and 0.82-0.84 ms replayed -- it is bound by its chain of DEPENDENT kernels
-        # (ten 25 us Cholesky launches, four 20-60 us fp64 products, ~35 kernels at the ~5 us floor), which a graph replays
-        # at the same kernel-boundary cost; the host was never the bottleneck on one GPU.
+        # (M' = 600, ~75 launches) is bound by its chain of DEPENDENT kernels (ten 24 us Cholesky launches, the fp64 products,
+        # ~35 kernels at the few-us floor), which a graph replays at the same kernel-boundary cost: 0.74 ms replayed against
+        # 0.77-0.80 ms eager at the end of round 2 (0.82-0.84 against 0.80 before the small products split K).
         return mode is True
 
     def _graph_step(self, idx, idx_y):

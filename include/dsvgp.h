@@ -229,6 +229,9 @@ int dsvgp_elbo_fast_finalize(dsvgp_ctx* ctx, const float* sums, const float* hyp
 /* copy the lower triangle of the float matrix onto its upper triangle (symmetrise a tril GEMM result)   */
 int dsvgp_mirror_lower_f32(dsvgp_ctx* ctx, float* G, int n, int64_t ldg);
 int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, float delta);
+/* A[n, n + 1] (lda >= n + 1): A[i][i] -= 1, A[i][n] = m[i] * noise * rows -- [S - I | m / (2 vbar)], the right-hand side of the
+ * [Q' | a] solve of the ELBO fast path (DGVS.py:192-205: the (S - I) middle term and the mean term) in one pass            */
+int dsvgp_sminus_i_col(dsvgp_ctx* ctx, float* A, int n, int64_t lda, const float* m, const float* hyp, double rows);
 
 /* ---- data-parallel all-reduce operand (the reference is single-process and has no counterpart):
  * dst = [ packed lower triangle of src[n,n] (row i at offset i(i+1)/2) | extra[nextra] ], i.e. n(n+1)/2 + nextra floats
@@ -239,9 +242,10 @@ int dsvgp_tril_pack_f32(dsvgp_ctx* ctx, const float* src, int64_t ld, int n, con
 int dsvgp_tril_unpack_f32(dsvgp_ctx* ctx, const float* src, int n, float* dst, int64_t ld, float* extra, int nextra);
 
 /* ---- minibatch gather: DataLoader batch + select_cols_of_y (directional_vi.py:68-90,229-241)
- * xb[b,:] = X[idx[b],:] ; yb[b*(p+1)+c] = Y[idx[b], cols[c]]  (cols[0] == 0)                     */
+ * xb[b,:] = X[idx[b],:] ; yb[b*(p+1)+c] = Y[idx[b], cols[c]]  (cols[0] == 0); with E[d, d] != NULL also the batch's
+ * derivative directions Db[(b p + a), :] = E[cols[a+1] - 1, :]  (derivative_directions.repeat(n_samples, 1), :238)  */
 int dsvgp_gather_batch(dsvgp_ctx* ctx, const float* X, const float* Y, const int64_t* idx, int nb,
-                       int d, int ycols, const int* cols, int p, float* xb, float* yb);
+                       int d, int ycols, const int* cols, int p, float* xb, float* yb, const float* E, float* Db);
 
 /* ---- fused Adam (torch.optim.Adam semantics, directional_vi.py:193-199,251-254)
  * lr_dev / step_dev are device scalars so the update is graph-capturable.                         */
