@@ -85,6 +85,9 @@ class ElboEngine:
         # K_ZX-bar's kernel backward on the side stream next to the L-bar / Cholesky-backward products.  Off by default: measured
         # C3 8.65 -> 8.58 ms/step, but C4 14.04-14.18 -> 14.13-14.21 and the 8-rank share unchanged
         self.bwd_overlap = os.environ.get("DSVGP_BWD_OVERLAP", "0") == "1"
+        # one GPU: the L_S / m gradient kernels (need only G) on the side stream next to the Q' solve and the dense product.
+        # Measured: C3 8.26 -> 8.18 ms/step, C4 unchanged (14.01 / 13.97-14.02)
+        self.var_overlap = os.environ.get("DSVGP_VAR_OVERLAP", "1") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -1140,7 +1143,22 @@ class ElboEngine:
                 self._dense_done.record(torch.cuda.current_stream(dev))
             return Qe64
 
-        if coll is None:
+        var_done = None
+        if coll is None and self.var_overlap and self.collective is None and self._side is not None and not self.capture_mode:
+            # one GPU: the L_S / m gradients (the few-tile fp32 product G L_S, trace / KL / loss kernels) need only G; they run on
+            # the side stream next to the Q' solve and the dense product, joined before L-bar
+            main = torch.cuda.current_stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(fork)
+                ctx.bind()
+                variational_part()
+                var_done = torch.cuda.Event()
+                var_done.record(self._side)
+            ctx.bind()
+            Qe64 = solve_part()
+        elif coll is None:
             variational_part()
             Qe64 = solve_part()
         else:
@@ -1149,4 +1167,6 @@ class ElboEngine:
             _ops.mirror_lower_f32_(ctx, G, Mp)
             variational_part()
         _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)                 # L-bar (fp64)
+        if var_done is not None:
+            torch.cuda.current_stream(dev).wait_event(var_done)
         return packX, mu
