@@ -260,20 +260,20 @@ extern "C" int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* 
         else hipLaunchKernelGGL(mfma_rate_f32_kernel, dim3(grid), dim3(256), 0, st, (float*)scratch, iters);
     };
     // calibrate the launch count on one launch, warm up for half the budget, time the other half
-    hipEventRecord(e0, st); launch(); hipEventRecord(e1, st);
+    (void)hipEventRecord(e0, st); launch(); (void)hipEventRecord(e1, st);
     if (hipEventSynchronize(e1) != hipSuccess) return 1000 + (int)hipGetLastError();
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     int n = (int)(0.5 * millis / (ms > 1e-3f ? ms : 1e-3f));
     n = n < 1 ? 1 : (n > 2000 ? 2000 : n);
     for (int i = 0; i < n; ++i) launch();
-    hipEventRecord(e0, st);
+    (void)hipEventRecord(e0, st);
     for (int i = 0; i < n; ++i) launch();
-    hipEventRecord(e1, st);
+    (void)hipEventRecord(e1, st);
     hipError_t e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipGetLastError();
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (e != hipSuccess) return 1000 + (int)e;
     *tflops = flop_per_launch * n / (ms * 1e-3) / 1e12;
     return 0;

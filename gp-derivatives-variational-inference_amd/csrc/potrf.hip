@@ -32,6 +32,15 @@ constexpr int NBC = 64;
 #ifndef POTRF_STRIP_T2
 #define POTRF_STRIP_T2 256      // ... strips of 2
 #endif
+#ifndef POTRF_STRIP_V6
+#define POTRF_STRIP_V6 6        // strip lengths of the three classes (probes)
+#endif
+#ifndef POTRF_STRIP_V4
+#define POTRF_STRIP_V4 4
+#endif
+#ifndef POTRF_STRIP_V2
+#define POTRF_STRIP_V2 2
+#endif
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
 #pragma unroll
@@ -737,7 +746,7 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
     for (int k = -1; k < nblk - 1; ++k) {
         const int nt = nblk - (k + 1);
         const int tiles = (k < 0) ? 1 : nt * (nt + 1) / 2 + (Yinv ? nt * (k + 1) + (k + 1) : 0);
-        const int strip = tiles > POTRF_STRIP_T6 ? 6 : (tiles > POTRF_STRIP_T4 ? 4 : (tiles > POTRF_STRIP_T2 ? 2 : 1));
+        const int strip = tiles > POTRF_STRIP_T6 ? POTRF_STRIP_V6 : (tiles > POTRF_STRIP_T4 ? POTRF_STRIP_V4 : (tiles > POTRF_STRIP_T2 ? POTRF_STRIP_V2 : 1));
         int nA = 1;                                  // update tiles, in strips of `strip` block columns per tile row
         if (k >= 0) {
             nA = 0;
