@@ -187,6 +187,40 @@ def test_ciq_lanczos_and_solve_match_oracle(dsvgp, gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("t,n,J,Kout", [(13, 40, 7, 5), (9, 37, 21, 19), (6, 64, 3, 1)])
+def test_ciq_mix_and_cross_against_plain_tensor_expressions(dsvgp, gpu_device, t, n, J, Kout):
+    """dsvgp_ciq_mix: out[k, row] = scale_row sum_j C[row, j, k] basis[j, row]; dsvgp_ciq_cross: the per-row coefficients that turn
+    sum_q omega_q A_q^T B_q into one stacked product -- both against torch expressions (vector widths 4 and 1, > 16 outputs)"""
+    ops = dsvgp._ops
+    dev = gpu_device
+    ctx = ops.Context.get(dev)
+    g = torch.Generator().manual_seed(t * 100 + n)
+    ld = J + 2
+    KP = ops.ciq_qp(Kout)
+    basis = torch.randn(J + 1, t, n, generator=g)
+    C = torch.randn(t, ld, KP, generator=g)
+    scale = torch.rand(t, generator=g) + 0.5
+    out = ops.ciq_mix(ctx, basis.to(dev), J, C.to(dev), Kout, scale.to(dev), torch.empty(Kout, t, n, device=dev))
+    ref = torch.einsum("rjk,jrn->krn", C[:, :J, :Kout].double(), basis[:J].double()) * scale.double()[None, :, None]
+    assert relmax(out, ref) < 2e-6
+    # cross coefficients: A_q = rn_a mix(basisA, ya)_q, B_q = rn_b mix(basisB, yb)_q, Q shifts
+    Q, Ja, Jb = 5, min(J, 6), J
+    QP = ops.ciq_qp(Q)
+    ya, yb = torch.randn(t, Ja + 1, QP, generator=g), torch.randn(t, Jb + 3, QP, generator=g)
+    omega = torch.rand(Q, generator=g)
+    rn_a, rn_b = torch.rand(t, generator=g) + 0.5, torch.rand(t, generator=g) + 0.5
+    basisA = torch.randn(Ja + 1, t, n, generator=g)
+    ctab = ops.ciq_cross(ctx, ya.to(dev), Ja, yb.to(dev), Jb, omega.to(dev), rn_a.to(dev), rn_b.to(dev))
+    assert ctab.shape == (t, Jb, ops.ciq_qp(Ja))
+    Z = ops.ciq_mix(ctx, basis.to(dev), Jb, ctab, Ja, None, torch.empty(Ja, t, n, device=dev))
+    stacked = basisA[:Ja].reshape(Ja * t, n).double().t() @ Z.double().cpu().reshape(Ja * t, n)
+    Aq = torch.einsum("rjq,jrn->qrn", ya[:, :Ja, :Q].double(), basisA[:Ja].double()) * rn_a.double()[None, :, None]
+    Bq = torch.einsum("rjq,jrn->qrn", yb[:, :Jb, :Q].double(), basis[:Jb].double()) * rn_b.double()[None, :, None]
+    direct = sum(omega[q].double() * Aq[q].t() @ Bq[q] for q in range(Q))
+    assert relmax(stacked, direct) < 1e-5
+
+
+@pytest.mark.gpu
 def test_ciq_backward_forms_and_basis_growth_agree(dsvgp, gpu_device):
     """the backward's sum over shifts stacked over the backward basis, the forward basis or the materialised solves is the
     same matrix; a basis sized too small is grown (ENOSPACE -> twice the rows) without changing the result"""

@@ -427,6 +427,24 @@ def test_gather_batch_and_fused_adam(dsvgp, gpu_device):
     yb = torch.empty(64 * (p + 1), device=dev)
     ops.gather_batch(ctx, X.to(dev), Y.to(dev), idx.to(dev), torch.tensor(cols, dtype=torch.int32, device=dev), p, xb, yb)
     assert torch.equal(xb.cpu(), X[idx]) and torch.equal(yb.cpu(), Y[idx][:, cols].reshape(-1))
+    # ... and the batch's derivative directions in the same launch: rows cols[1:] - 1 of the direction table, repeated per point
+    E = torch.rand(d, d, generator=g)
+    Db = torch.empty(64 * p, d, device=dev)
+    xb.zero_(); yb.zero_()
+    ops.gather_batch(ctx, X.to(dev), Y.to(dev), idx.to(dev), torch.tensor(cols, dtype=torch.int32, device=dev), p, xb, yb,
+                     E.to(dev), Db)
+    assert torch.equal(xb.cpu(), X[idx]) and torch.equal(yb.cpu(), Y[idx][:, cols].reshape(-1))
+    assert torch.equal(Db.cpu(), E[torch.tensor(cols[1:]) - 1].repeat(64, 1))
+    # [S | .] -> [S - I | m noise rows] (the right-hand side of the [Q' | a] solve) in one launch
+    n = 37
+    Se = torch.rand(n, n + 3, generator=g)
+    mvec, hyp = torch.rand(n, generator=g), torch.tensor([0.7, 1.3, 0.02, 0.0])
+    Sd = Se.to(dev)
+    ops.sminus_i_col_(ctx, Sd[:, :n + 1], n, mvec.to(dev), hyp.to(dev), 1536.0)
+    ref = Se.clone()
+    ref[:, :n] -= torch.eye(n)
+    ref[:, n] = mvec * (hyp[2] * 1536.0)
+    assert torch.equal(Sd.cpu(), ref)
     # Adam: 5 steps against torch.optim.Adam
     w0 = torch.randn(1000, generator=g)
     wt = w0.clone().requires_grad_(True)
