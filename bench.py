@@ -263,6 +263,33 @@ def main():
     elapsed = float(t.item())
     final_loss = float(loss.item())
 
+    # N > 1: what the collectives this design could use cost on THIS node, measured after the timed region (all ranks take part;
+    # priced for the next design step: sharding the replicated M' x M' products would add two 72 MB all-gathers per step)
+    coll_probe = None
+    if world > 1 and not rehearse and os.environ.get("DSVGP_BENCH_COLL_PROBE", "1") == "1":
+        coll_probe = {}
+        Mp_ = M * (p + 1)
+        for name, fn, numel, dt in (("allreduce_packed_G_ms", "ar", Mp_ * (Mp_ + 1) // 2 + Mp_, torch.float32),
+                                    ("allgather_MxM_f64_ms", "ag", Mp_ * Mp_ // world * world, torch.float64),
+                                    ("allgather_MxM_f32_ms", "ag", Mp_ * Mp_ // world * world, torch.float32)):
+            try:
+                buf = torch.zeros(numel, dtype=dt, device=device)
+                shard = buf[:numel // world].clone()
+                for it in range(13):
+                    if it == 3:
+                        torch.cuda.synchronize()
+                        dist.barrier()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    if fn == "ar":
+                        dist.all_reduce(buf)
+                    else:
+                        dist.all_gather_into_tensor(buf, shard)
+                e1.record()
+                torch.cuda.synchronize()
+                coll_probe[name] = e0.elapsed_time(e1) / 10.0
+            except Exception as ex:      # (a backend without the collective: report, do not fail the bench line)
+                coll_probe[name] = "unavailable: %s" % type(ex).__name__
     # dominant kernel: the fp64 MFMA GEMM of the forward panel solve A = L^-1 K_ZX (one launch when nb >= M')
     Mp = M * (p + 1)
     B_local = B // world
@@ -336,8 +363,15 @@ def main():
         }
         if world > 1:
             out["rccl_ranks"] = dist.get_world_size()
+            t_w, n_w = avg("early_reduce_wait")
+            t_r, n_r = avg("final_reduce")
             out["config"]["collective"] = dict(backend=dist.get_backend(), algo=args.dp_algo, packed_triangle=eng.pack_reduce,
-                                               early_operand_floats=int(eng.early_wire_numel))
+                                               early_operand_floats=int(eng.early_wire_numel),
+                                               exposed_early_reduce_wait_ms=t_w * 1e3 if t_w else None,
+                                               final_reduce_ms=t_r * 1e3 if t_r else None,
+                                               note="rank 0, HIP events on the main stream: the time the step stalls for the "
+                                                    "[tril(G) | b] sum and the time of the closing gradient all-reduce",
+                                               probe=coll_probe)
         if cfg.get("ciq"):
             out["config"]["ciq"] = dict(eng.ciq_stats)
         if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq") and not args.fp64:

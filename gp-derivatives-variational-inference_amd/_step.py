@@ -1163,7 +1163,9 @@ class ElboEngine:
             Qe64 = solve_part()
         else:
             Qe64 = solve_part()
+            ev_w = self._event_pair()                        # (bench.py: how long the main stream stalls for [G ; b^T])
             handle.wait()
+            self._event_done("early_reduce_wait", ev_w)
             _ops.mirror_lower_f32_(ctx, G, Mp)
             variational_part()
         _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)                 # L-bar (fp64)

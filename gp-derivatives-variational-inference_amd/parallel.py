@@ -132,6 +132,8 @@ class DataParallel:
         else:
             views = grads                       # the engine's gradients ARE views of [grads..., loss]
         early = getattr(engine, "_early_handle", None) if views is not None else None
+        # (bench.py: HIP events around the final reduction on the main stream = the communication the step does not hide)
+        ev = engine._event_pair() if hasattr(engine, "_event_pair") else None
         if views is not None and getattr(engine, "variational_grads_global", False):
             dist.all_reduce(engine.flat_late, op=dist.ReduceOp.SUM, group=self.group)     # [Z-bar, V-bar, scalars, loss]
         elif early is not None:
@@ -140,6 +142,8 @@ class DataParallel:
             engine._early_handle = None
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if ev is not None:
+            engine._event_done("final_reduce", ev)
         if views is not None:
             return flat[-1], views, mu, varn
         off = 0
