@@ -13,7 +13,8 @@ and the ELBO are then all fp64.  ``ElboEngine64`` is that mode of ``directional_
 
 Two formulations, as in the fp32 engine: the general (variance-carrying) one covers ELBO and PLL; in ELBO mode, when the caller
 does not read the per-output variances, the Gram-matrix formulation (``_elbo_fast64``) needs three [M', B'] products instead
-of six.  It is not the benchmark path (the headline configs run the reference's default fp32 model; ``bench.py --fp64`` times it).  Under ``parallel.DataParallel`` the gradients of the row shards are
+of six.  q(u) may be a NaturalVariationalDistribution (``train_gp(use_ngd=True)``: natural parameters in, expectation-parameter gradients out).
+It is not the benchmark path (the headline configs run the reference's default fp32 model; ``bench.py --fp64`` times it).  Under ``parallel.DataParallel`` the gradients of the row shards are
 summed by one all-reduce at the end of the step (no early operand).  No CPU fallback: the inputs must be HIP tensors.
 """
 import math
@@ -22,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, _ops
-from ._step import CHOL_TRIES, PARAM_NAMES, ElboEngine, NotPSDError
+from ._step import CHOL_TRIES, PARAM_NAMES, _NGD_RENAME, ElboEngine, NotPSDError
 
 KXX_JITTER = 1e-4       # data_data_covar.add_jitter(1e-4), DGVS.py:202
 MIN_VARIANCE = 1e-6     # MultivariateNormal.variance clamp (gpytorch settings.min_variance)
@@ -118,10 +119,46 @@ class ElboEngine64(ElboEngine):
             torch.ones(1, dtype=f64, device=like.device)
         return s * row.repeat(B)
 
+    # ---- NaturalVariationalDistribution (train_gp(use_ngd=True), reference directional_vi.py:35-37,186-187) in fp64 ----
+    def _from_natural(self, ctx, params):
+        """(theta_1, theta_2) -> (m, tril L_S) through the fp64 factorisations of the base engine; returns the parameter dict
+        of the Cholesky parameterisation and what ``_natural_grads64`` needs, or (params, None)"""
+        if "natural_vec" not in params:
+            return params, None
+        nv, nm = params["natural_vec"], params["natural_mat"]
+        if nv.dtype != f64 or nm.dtype != f64:
+            raise TypeError("fp64 model mode: natural parameters must be float64")
+        Mp = nv.shape[0]
+        LS64, m64, info = self._natural_moments(ctx, nv, nm)
+        wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, self.trsm_nb))
+        self._potrf_and_inverse(ctx, LS64, info[1:2], wsS, Mp, "ngd_LS")                # L_S (lower triangle) and L_S^-1
+        bad = info.tolist()
+        if bad[0] or bad[1]:
+            raise NotPSDError("natural_mat does not define a positive definite precision (potrf info %s)" % bad)
+        m = m64.reshape(Mp).clone()
+        out = {k: v for k, v in params.items() if not k.startswith("natural_")}
+        out["variational_mean"], out["chol_variational_covar"] = m, torch.tril(LS64)
+        return out, (m, LS64, wsS)
+
+    def _natural_grads64(self, ctx, grads, m, LS64, wsS):
+        """(dm, dL_S) -> gradients w.r.t. the expectation parameters (``_NaturalToMuVarSqrt.backward``): d eta_2 = dS through
+        the Cholesky factor of S, d eta_1 = dm - 2 dS mu; in place, all fp64"""
+        Mp = m.shape[0]
+        self._problem_size(Mp)
+        dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
+        Lbar = self._get("Lbar", (Mp, Mp), f64)
+        Lbar.copy_(dLS)
+        dS = self._chol_backward(ctx, LS64, Lbar, wsS, Mp)
+        dLS.copy_(dS)
+        t = torch.empty(Mp, 1, dtype=f64, device=self.device)
+        _ops.gemm(ctx, 0, dS, m.reshape(Mp, 1).contiguous(), t)
+        dm.add_(t.reshape(Mp), alpha=-2.0)
+
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
     def predict(self, params, x, D, cache=False):
         ctx = _ops.Context.get(self.device)
+        params, _ = self._from_natural(ctx, params)
         self._check(params, x, D)
         _, (ell, s, noise), hyp = self._hyp64(params)
         Mz = params["inducing_points"].shape[0]
@@ -137,6 +174,7 @@ class ElboEngine64(ElboEngine):
         """Mean [B'] and the full predictive covariance [B', B'] (fp64, likelihood noise on the diagonal):
         Sigma = s K_XX + 1e-4 I + W^T W - A^T A + noise I  (DGVS.py:199-208 + likelihood)"""
         ctx = _ops.Context.get(self.device)
+        params, _ = self._from_natural(ctx, params)
         self._check(params, x, D)
         _, (ell, s, noise), hyp = self._hyp64(params)
         Mz = params["inducing_points"].shape[0]
@@ -155,8 +193,18 @@ class ElboEngine64(ElboEngine):
 
     @torch.no_grad()
     def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True, fast=None):
-        """(loss, grads dict, mu, varn), all fp64; see ``ElboEngine.loss_and_grads`` for the arguments."""
+        """(loss, grads dict, mu, varn), all fp64; see ``ElboEngine.loss_and_grads`` for the arguments.  With natural parameters
+        (``natural_vec``, ``natural_mat``) the gradients of those two slots are the expectation-parameter gradients NGD steps along."""
         ctx = _ops.Context.get(self.device)
+        params, nat = self._from_natural(ctx, params)
+        out = self._loss_and_grads64(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast)
+        if nat is not None:
+            loss, grads, mu, varn = out
+            self._natural_grads64(ctx, grads, *nat)
+            out = (loss, {_NGD_RENAME.get(k, k): v for k, v in grads.items()}, mu, varn)
+        return out
+
+    def _loss_and_grads64(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast):
         self._check(params, x, D)
         self._eval_cache = None
         dev = self.device

@@ -13,8 +13,6 @@ class NGD(torch.optim.Optimizer):
 
     def __init__(self, params, num_data, lr=0.1):
         params = list(params)
-        if any(p.dtype != torch.float32 for p in params):
-            raise NotImplementedError("NGD: natural-gradient updates are built for the fp32 model only")
         self.num_data = num_data
         super().__init__(params, defaults=dict(lr=lr))
 

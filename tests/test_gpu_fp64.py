@@ -318,3 +318,61 @@ def test_train_gp_eval_gp_under_float64_default(dsvgp, gpu_device):
         assert relmax(means, mu_ref) < 1e-9 and relmax(variances, var_ref + noise) < 1e-9
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("mll,fast", [("ELBO", False), ("ELBO", True), ("PLL", False)])
+def test_fp64_natural_parameters_match_oracle(dsvgp, gpu_device, mll, fast):
+    """train_gp(use_ngd=True) under a float64 default (the bunny / GNN experiment drivers offer both): q(u) as a
+    NaturalVariationalDistribution in the fp64 engine -- loss, predictive moments, ordinary gradients and the
+    expectation-parameter gradients of (theta_1, theta_2) against the fp64 oracle"""
+    from dsvgp_amd._step64 import ElboEngine64
+    from test_ngd import make_ngd_problem
+    P, x, y, D, nd = make_ngd_problem(300, 4, 14, 2, 40, seed=7, dtype=f64)
+    P["natural_mat"] = 0.5 * (P["natural_mat"] + P["natural_mat"].t())     # (built in fp32: symmetric only to 1e-8; the factorisation
+    l_ref, g_ref, mu_ref, var_ref = O.ngd_loss_and_grads(P, x, y, D, nd, mll)       # reads the lower triangle, the oracle the mean)
+    eng = ElboEngine64(gpu_device)
+    eng.fast_min_work = 0
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll, fast=fast)
+    assert set(grads) == set(O.NGD_PARAM_NAMES) and all(v.dtype == f64 for v in grads.values())
+    errs = {"loss": abs(loss.item() - l_ref.item()) / abs(l_ref.item()), "mu": relmax(mu, mu_ref)}
+    if not fast:
+        errs["var"] = relmax(varn, var_ref)
+    for k in O.NGD_PARAM_NAMES:
+        errs[k] = relmax(grads[k], g_ref[k])
+    print("[parity] fp64 natural parameters %s%s: %s" % (mll, " (Gram)" if fast else "", ", ".join("%s %.1e" % kv for kv in errs.items())))
+    assert errs["loss"] < 1e-9 and errs["mu"] < 1e-9 and errs.get("var", 0.0) < 1e-9, errs
+    assert max(errs[k] for k in O.NGD_PARAM_NAMES) < 1e-7, errs
+    mu_p, var_p = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu_p, mu_ref) < 1e-9 and relmax(var_p, var_ref) < 1e-9
+
+
+def test_train_gp_with_ngd_under_float64_default(dsvgp, gpu_device):
+    from torch.utils.data import TensorDataset
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(0)
+        n, d, M, p, B = 400, 2, 16, 2, 200
+        X = torch.rand(n, d)
+        Y = O.testfun(X)
+        model, lik = dsvgp.train_gp(TensorDataset(X, Y), num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
+                                    num_epochs=3, seed=0, use_ngd=True, learning_rate_ngd=0.05, verbose=False)
+        prm = model._param_dict(lik)
+        assert "natural_vec" in prm and all(v.dtype == f64 for v in prm.values())
+        from dsvgp_amd._step64 import ElboEngine64
+        assert isinstance(model.engine, ElboEngine64)
+        P = {k: v.detach().cpu().clone() for k, v in prm.items()}
+        xb, yb = X[:B], Y[:B][:, [0, 1, 2]].reshape(-1)
+        Db = torch.eye(d)[[0, 1]].repeat(B, 1)
+        l_ref, g_ref, _, _ = O.ngd_loss_and_grads(P, xb, yb, Db, (d + 1) * n, "ELBO")
+        loss, grads, _, _ = model.engine.loss_and_grads({k: v.to(gpu_device) for k, v in P.items()}, xb.to(gpu_device),
+                                                        yb.to(gpu_device), Db.to(gpu_device), (d + 1) * n)
+        assert abs(loss.item() - l_ref.item()) / abs(l_ref.item()) < 1e-9
+        for k in ("natural_vec", "natural_mat", "inducing_points"):
+            assert relmax(grads[k], g_ref[k]) < 1e-7, k
+        means, variances = dsvgp.eval_gp(TensorDataset(X[:50], Y[:50]), model, lik, num_directions=p, minibatch_size=25,
+                                         minibatch_dim=p)
+        assert means.dtype == f64 and bool(torch.isfinite(means).all()) and bool((variances > 0).all())
+    finally:
+        torch.set_default_dtype(prev)
