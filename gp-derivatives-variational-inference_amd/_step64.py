@@ -16,6 +16,8 @@ does not read the per-output variances, the Gram-matrix formulation (``_elbo_fas
 of six.  q(u) may be a NaturalVariationalDistribution (``train_gp(use_ngd=True)``: natural parameters in, expectation-parameter gradients out).
 It is not the benchmark path (the headline configs run the reference's default fp32 model; ``bench.py --fp64`` times it).  Under ``parallel.DataParallel`` the gradients of the row shards are
 summed by one all-reduce at the end of the step (no early operand).  No CPU fallback: the inputs must be HIP tensors.
+Shared inducing directions run in fp64 (``_shared_step64``); the CIQ strategy of a float64 model runs on the fp32 CIQ kernels
+(``_ciq_call``: see the comment there and DESIGN.md section 9).
 """
 import math
 
@@ -55,8 +57,8 @@ class ElboEngine64(ElboEngine):
                 raise _lib.DsvgpError("%s must live on the GPU: the DSVGP hot path has no CPU fallback" % k)
         if x.dtype != f64 or (D is not None and D.numel() and D.dtype != f64):
             raise TypeError("fp64 model mode: inputs must be float64")
-        if self.whitening != "cholesky" or self.shared_directions:
-            raise NotImplementedError("fp64 model mode covers the Cholesky-whitened strategies only")
+        if self.whitening != "cholesky":
+            raise NotImplementedError("fp64 model mode covers the Cholesky-whitened strategies (and CIQ through the fp32 kernels)")
 
     def _hyp64(self, params, grad=False):
         """(raw leaves, hyp[4] = {lengthscale, outputscale, noise, 0}): gpytorch Positive / GreaterThan(1e-4) softplus constraints"""
@@ -107,6 +109,9 @@ class ElboEngine64(ElboEngine):
             _ops.kernel_fwd_f64(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
         A = self._get("A64", (Mp, Bp), f64)
         _ops.trsm(ctx, L, Kzx, False, A, None, self.trsm_nb, ws, reuse_inverse=True)
+        if self._no_middle:                                     # shared directions: zero middle term, var = prior diagonal
+            mu0, _ = _ops.colstats_f64(ctx, A, None, params["variational_mean"].contiguous())
+            return packX, A, None, mu0, torch.zeros_like(mu0)
         W = self._get("W", (Mp, Bp), f64)
         _ops.gemm(ctx, TRANS_A | A_UPPER, params["chol_variational_covar"], A, W)      # tril(L_S)^T A
         mu0, cs = _ops.colstats_f64(ctx, A, W, params["variational_mean"].contiguous())
@@ -118,6 +123,31 @@ class ElboEngine64(ElboEngine):
         row = torch.cat([torch.ones(1, dtype=f64, device=like.device), (1.0 / ell ** 2).expand(pd)]) if pd else \
             torch.ones(1, dtype=f64, device=like.device)
         return s * row.repeat(B)
+
+    # ---- CIQ whitening under a float64 model (train_gp(use_ciq=True): the bunny / GNN drivers offer it under their fp64 default) ----
+    # msMINRES stops at a mean relative update of 1e-4 and the quadrature itself is a 1e-4-class approximation of K_ZZ^-1/2
+    # (tests/test_ciq.py), so the CIQ strategy of a float64 model runs on the fp32 CIQ kernels (csrc/ciq.hip): parameters, data
+    # and optimizer state stay float64, the step's arithmetic is that of the reference's default (fp32) CIQ model, the
+    # gradients come back as float64.  Stated in DESIGN.md section 9; a float64 msMINRES is not built.
+    _CIQ_ATTRS = ("whitening", "ciq_num_quadrature", "ciq_tolerance", "ciq_max_iter", "ciq_kxx_jitter", "kzz_jitter",
+                  "chol_jitter", "data_outputs", "shared_directions", "collective", "ciq_backward_form")
+
+    def _ciq_delegate(self):
+        e = self.__dict__.get("_ciq32")
+        if e is None:
+            e = self._ciq32 = ElboEngine(self.device)
+        for k in self._CIQ_ATTRS:
+            setattr(e, k, getattr(self, k))
+        return e
+
+    def _ciq_call(self, fn, params, *tensors, **kw):
+        if any(v.dtype != f64 for v in params.values()):
+            raise TypeError("fp64 model mode: parameters must be float64")
+        e = self._ciq_delegate()
+        out = getattr(e, fn)({k: v.float() for k, v in params.items()},
+                             *[t.float() if torch.is_tensor(t) and t.is_floating_point() else t for t in tensors], **kw)
+        self.ciq_stats = e.ciq_stats
+        return out
 
     # ---- NaturalVariationalDistribution (train_gp(use_ngd=True), reference directional_vi.py:35-37,186-187) in fp64 ----
     def _from_natural(self, ctx, params):
@@ -154,17 +184,70 @@ class ElboEngine64(ElboEngine):
         _ops.gemm(ctx, 0, dS, m.reshape(Mp, 1).contiguous(), t)
         dm.add_(t.reshape(Mp), alpha=-2.0)
 
+    # ---- shared inducing directions (SharedDirectionalGradVariationalStrategy.py:95-107,210-212) in fp64 ----
+    def _shared_expand64(self, params):
+        """tile the p shared directions over the M points, interleave the M + p variational values; the covariance of q(u) does
+        not reach the predictive (zero middle term), so a unit factor stands in for it"""
+        Z, Vs, ms = params["inducing_points"], params["inducing_directions"], params["variational_mean"]
+        M, p = Z.shape[0], Vs.shape[0]
+        if ms.shape[0] != M + p:
+            raise ValueError("shared directions: q(u) has M + p = %d values, got %d" % (M + p, ms.shape[0]))
+        idx = torch.cat([torch.arange(M, device=self.device).reshape(M, 1),
+                         torch.arange(M, M + p, device=self.device).reshape(1, p).expand(M, p)], dim=1).reshape(-1)
+        full = dict(params)
+        full["inducing_directions"] = Vs.repeat(M, 1).contiguous()
+        full["variational_mean"] = ms[idx].contiguous()
+        full["chol_variational_covar"] = torch.zeros(1, 1, dtype=f64, device=self.device)      # never read
+        return full, idx
+
+    def _shared_step64(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl):
+        full, idx = self._shared_expand64(params)
+        M, p = params["inducing_points"].shape[0], params["inducing_directions"].shape[0]
+        self._no_middle = True
+        try:
+            loss, g, mu, varn = self._loss_and_grads64(ctx, full, x, y, D, num_data, mll_type, global_rows, False, False)
+        finally:
+            self._no_middle = False
+        ms, LS = params["variational_mean"], params["chol_variational_covar"]
+        grads = {k: g[k] for k in PARAM_NAMES if k not in ("inducing_directions", "variational_mean", "chol_variational_covar")}
+        grads["inducing_directions"] = g["inducing_directions"].reshape(M, p, -1).sum(0)
+        dm = torch.zeros_like(ms)
+        dm.index_add_(0, idx, g["variational_mean"])
+        dLS = torch.zeros_like(LS, memory_format=torch.contiguous_format)
+        if include_kl:                                             # KL of the (M + p)-dimensional q(u)
+            Lt = torch.tril(LS)
+            dg = torch.diagonal(Lt)
+            kl = 0.5 * ((ms * ms).sum() + (Lt * Lt).sum() - (M + p) - torch.log(dg * dg).sum())
+            loss = loss + kl / float(num_data)
+            dm.add_(ms, alpha=1.0 / float(num_data))
+            dLS.add_(Lt - torch.diag(1.0 / dg), alpha=1.0 / float(num_data))
+        grads["variational_mean"], grads["chol_variational_covar"] = dm, dLS
+        return loss, {k: grads[k] for k in PARAM_NAMES}, mu, varn
+
+    def _shared_predict_params(self, params):
+        full, _ = self._shared_expand64(params)
+        return full
+
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
     def predict(self, params, x, D, cache=False):
+        if self.whitening == "ciq":
+            mu, varn = self._ciq_call("predict", params, x, D, cache=cache)
+            return mu.double(), varn.double()
         ctx = _ops.Context.get(self.device)
         params, _ = self._from_natural(ctx, params)
+        if self.shared_directions:
+            params = self._shared_predict_params(params)
         self._check(params, x, D)
         _, (ell, s, noise), hyp = self._hyp64(params)
         Mz = params["inducing_points"].shape[0]
         pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
         packZ, L, dims, ws = self._factor64(ctx, params, hyp, x.shape[0] * (self._pd(pz) + 1))
-        _, _, _, mu0, cs = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+        self._no_middle = bool(self.shared_directions)
+        try:
+            _, _, _, mu0, cs = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+        finally:
+            self._no_middle = False
         p = dims[2]
         var = self._prior_diag(x.shape[0], p, self._pd(p), ell, s, x) + KXX_JITTER + cs
         return mu0 + params["constant"].reshape(()), (var + noise).clamp_min(MIN_VARIANCE)
@@ -173,21 +256,31 @@ class ElboEngine64(ElboEngine):
     def predict_joint(self, params, x, D, cache=False):
         """Mean [B'] and the full predictive covariance [B', B'] (fp64, likelihood noise on the diagonal):
         Sigma = s K_XX + 1e-4 I + W^T W - A^T A + noise I  (DGVS.py:199-208 + likelihood)"""
+        if self.whitening == "ciq":
+            mu, Sigma = self._ciq_call("predict_joint", params, x, D, cache=cache)
+            return mu.double(), Sigma.double()
         ctx = _ops.Context.get(self.device)
         params, _ = self._from_natural(ctx, params)
+        if self.shared_directions:
+            params = self._shared_predict_params(params)
         self._check(params, x, D)
         _, (ell, s, noise), hyp = self._hyp64(params)
         Mz = params["inducing_points"].shape[0]
         pz = params["inducing_directions"].shape[0] // Mz if Mz else 0
         packZ, L, dims, ws = self._factor64(ctx, params, hyp, x.shape[0] * (self._pd(pz) + 1))
-        packX, A, W, mu0, _ = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+        self._no_middle = bool(self.shared_directions)
+        try:
+            packX, A, W, mu0, _ = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
+        finally:
+            self._no_middle = False
         M, d, p, Mp = dims
         B = x.shape[0]
         Sigma = _ops.kernel_fwd_f64(ctx, packX, B, packX, B, d, p, hyp)
         if self._pd(p) != p:
             Sigma = Sigma[::p + 1, ::p + 1].contiguous()
-        _ops.gemm(ctx, TRANS_A, W, W, Sigma, beta=1.0, Cin=Sigma)
-        _ops.gemm(ctx, TRANS_A, A, A, Sigma, alpha=-1.0, beta=1.0, Cin=Sigma)
+        if W is not None:
+            _ops.gemm(ctx, TRANS_A, W, W, Sigma, beta=1.0, Cin=Sigma)
+            _ops.gemm(ctx, TRANS_A, A, A, Sigma, alpha=-1.0, beta=1.0, Cin=Sigma)
         Sigma.diagonal().add_(noise + KXX_JITTER)
         return mu0 + params["constant"].reshape(()), Sigma
 
@@ -195,9 +288,18 @@ class ElboEngine64(ElboEngine):
     def loss_and_grads(self, params, x, y, D, num_data, mll_type="ELBO", global_rows=None, include_kl=True, fast=None):
         """(loss, grads dict, mu, varn), all fp64; see ``ElboEngine.loss_and_grads`` for the arguments.  With natural parameters
         (``natural_vec``, ``natural_mat``) the gradients of those two slots are the expectation-parameter gradients NGD steps along."""
+        if self.whitening == "ciq":
+            if x.dtype != f64 or y.dtype != f64:
+                raise TypeError("fp64 model mode: inputs must be float64")
+            loss, grads, mu, varn = self._ciq_call("loss_and_grads", params, x, y, D, num_data, mll_type=mll_type,
+                                                   global_rows=global_rows, include_kl=include_kl)
+            return loss.double(), {k: g.double() for k, g in grads.items()}, mu.double(), varn.double()
         ctx = _ops.Context.get(self.device)
         params, nat = self._from_natural(ctx, params)
-        out = self._loss_and_grads64(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast)
+        if self.shared_directions:
+            out = self._shared_step64(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl)
+        else:
+            out = self._loss_and_grads64(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast)
         if nat is not None:
             loss, grads, mu, varn = out
             self._natural_grads64(ctx, grads, *nat)
@@ -260,14 +362,17 @@ class ElboEngine64(ElboEngine):
             dLS.add_(g[7])
 
         # ---- variational parameters: m-bar += A mu_bar, L_S-bar += tril(2 A diag(var_bar) W^T) ----
-        U = self._get("U", (Mp, Bp), f64)
-        _ops.gemm(ctx, A_LOWER, LS, W, U)                                           # U = tril(L_S) W
         Abar = self._get("Abar", (Mp, Bp), f64)
-        Av = self._get("Av", (Mp, Bp), f64)
-        _ops.abar_f64(ctx, A, U, m, mu_bar, var_bar, Abar, Av)
-        tmp = self._get("dLS_data", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_B | OUT_LOWER, Av, W, tmp)
-        dLS.add_(torch.tril(tmp))
+        if W is None:                                                               # zero middle term: A-bar = m mu_bar^T
+            _ops.abar_f64(ctx, A, None, m, mu_bar, var_bar, Abar, None)
+        else:
+            U = self._get("U", (Mp, Bp), f64)
+            _ops.gemm(ctx, A_LOWER, LS, W, U)                                       # U = tril(L_S) W
+            Av = self._get("Av", (Mp, Bp), f64)
+            _ops.abar_f64(ctx, A, U, m, mu_bar, var_bar, Abar, Av)
+            tmp = self._get("dLS_data", (Mp, Mp), f64)
+            _ops.gemm(ctx, TRANS_B | OUT_LOWER, Av, W, tmp)
+            dLS.add_(torch.tril(tmp))
         dmd = torch.empty(Mp, 1, dtype=f64, device=dev)
         _ops.gemm(ctx, 0, A, mu_bar.reshape(Bp, 1), dmd)
         dm.add_(dmd.reshape(-1))

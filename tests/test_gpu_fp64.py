@@ -376,3 +376,122 @@ def test_train_gp_with_ngd_under_float64_default(dsvgp, gpu_device):
         assert means.dtype == f64 and bool(torch.isfinite(means).all()) and bool((variances > 0).all())
     finally:
         torch.set_default_dtype(prev)
+
+
+def test_fp64_model_with_ciq_strategy(dsvgp, gpu_device):
+    """train_gp(use_ciq=True) under a float64 default: the CIQ step of a float64 model runs on the fp32 CIQ kernels (msMINRES stops at
+    1e-4) and hands float64 gradients back -- same tolerances against the fp64 oracle as the fp32 model's test"""
+    from torch.utils.data import TensorDataset
+    from dsvgp_amd._step64 import ElboEngine64
+    from test_ngd import make_ngd_problem
+    P, x, y, D, nd = make_ngd_problem(400, 2, 20, 2, 100, seed=402, dtype=f64)
+    st = {}
+    l_ref, g_ref, mu_ref, var_ref = O.ciq_loss_and_grads(P, x, y, D, nd, stats=st)
+    eng = ElboEngine64(gpu_device)
+    eng.whitening = "ciq"
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    assert loss.dtype == f64 and all(v.dtype == f64 for v in grads.values()) and mu.dtype == f64
+    assert abs(eng.ciq_stats["iterations"] - st["iterations"]) <= 10
+    assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
+    assert relmax(mu, mu_ref) < 5e-3 and relmax(varn, var_ref) < 5e-3
+    for k in O.NGD_PARAM_NAMES:
+        if g_ref[k].numel() and g_ref[k].abs().max() > 0:
+            assert relmax(grads[k], g_ref[k]) < 2e-2, k
+    mu_p, var_p = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert mu_p.dtype == f64 and relmax(mu_p, mu_ref) < 5e-3 and relmax(var_p, var_ref) < 5e-3
+    # the harness: a float64 model with the CIQ strategy trains and evaluates
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(0)
+        n, d, M, p, B = 400, 2, 16, 2, 100
+        X = torch.rand(n, d)
+        Y = O.testfun(X)
+        model, lik = dsvgp.train_gp(TensorDataset(X, Y), num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
+                                    num_epochs=2, seed=0, use_ngd=True, use_ciq=True, learning_rate_ngd=0.01, verbose=False)
+        assert isinstance(model.engine, ElboEngine64) and model.engine.whitening == "ciq"
+        assert all(v.dtype == f64 for v in model._param_dict(lik).values())
+        means, variances = dsvgp.eval_gp(TensorDataset(X[:50], Y[:50]), model, lik, num_directions=p, minibatch_size=25,
+                                         minibatch_dim=p)
+        assert means.dtype == f64 and bool(torch.isfinite(means).all()) and bool((variances > 0).all())
+    finally:
+        torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("mll", ["ELBO", "PLL"])
+def test_fp64_shared_directions_match_oracle(dsvgp, gpu_device, mll):
+    """SharedDirectionalGradVariationalStrategy (the GNN BO driver imports it under its float64 default,
+    experiments/GNN_bo/gcn_turbo.py:24,120) in the fp64 engine: one shared direction set, q(u) over M + p values, zero middle term"""
+    from dsvgp_amd._step64 import ElboEngine64
+    N, d, M, p, B = 400, 4, 14, 2, 80
+    P, x, y, D, nd = make_problem64(N, d, M, p, B, seed=21)
+    g = torch.Generator().manual_seed(4)
+    P["inducing_directions"] = torch.eye(d, dtype=f64)[:p] + 0.2 * torch.randn(p, d, generator=g, dtype=f64)
+    P["variational_mean"] = 0.3 * torch.randn(M + p, generator=g, dtype=f64)
+    P["chol_variational_covar"] = torch.eye(M + p, dtype=f64) + 0.05 * torch.randn(M + p, M + p, generator=g, dtype=f64)
+    l_ref, g_ref, mu_ref, var_ref = O.shared_loss_and_grads(P, x, y, D, nd, mll)
+    eng = ElboEngine64(gpu_device)
+    eng.shared_directions = True
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
+    errs = {"loss": abs(loss.item() - l_ref.item()) / abs(l_ref.item()), "mu": relmax(mu, mu_ref), "var": relmax(varn, var_ref)}
+    for k in O.PARAM_NAMES:
+        assert grads[k].shape == g_ref[k].shape and grads[k].dtype == f64, k
+        errs[k] = relmax(grads[k], g_ref[k])
+    print("[parity] fp64 shared directions %s: %s" % (mll, ", ".join("%s %.1e" % kv for kv in errs.items())))
+    assert errs["loss"] < 1e-9 and errs["mu"] < 1e-9 and errs["var"] < 1e-9, errs
+    assert max(errs[k] for k in O.PARAM_NAMES) < 1e-7, errs
+    mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu2, mu_ref) < 1e-9 and relmax(varn2, var_ref) < 1e-9
+
+
+def test_shared_train_gp_under_float64_default(dsvgp, gpu_device):
+    from torch.utils.data import TensorDataset
+    from dsvgp_amd._step64 import ElboEngine64
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(0)
+        n, dim, p = 400, 2, 2
+        X = torch.rand(n, dim)
+        Y = O.testfun(X)
+        S = dsvgp.shared_directional_vi
+        model, lik = S.train_gp(TensorDataset(X, Y), num_inducing=16, num_directions=p, minibatch_size=200, minibatch_dim=p,
+                                num_epochs=3, inducing_data_initialization=False, tqdm=False, seed=2, verbose=False)
+        assert isinstance(model.engine, ElboEngine64) and model.engine.shared_directions
+        sd = model.state_dict()
+        assert sd["variational_strategy.inducing_directions"].shape == (p, dim)
+        assert sd["variational_strategy._variational_distribution.variational_mean"].dtype == f64
+        means, variances = S.eval_gp(TensorDataset(X[:50], Y[:50]), model, lik, num_directions=p, minibatch_size=25, minibatch_dim=p)
+        assert means.dtype == f64 and means.shape == (150,) and bool((variances > 0).all())
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def test_fp64_shared_directions_with_natural_parameters(dsvgp, gpu_device):
+    """shared directions + NaturalVariationalDistribution over the M + p shared values, all float64 (shared_directional_vi.py:37-39)"""
+    from dsvgp_amd._step64 import ElboEngine64
+    from test_ngd import make_ngd_problem
+    N, d, M, p, B = 400, 4, 14, 2, 80
+    P, x, y, D, nd = make_ngd_problem(N, d, M, p, B, seed=33, dtype=f64)
+    g = torch.Generator().manual_seed(7)
+    P["inducing_directions"] = torch.eye(d, dtype=f64)[:p] + 0.2 * torch.randn(p, d, generator=g, dtype=f64)
+    P["natural_vec"] = 0.3 * torch.randn(M + p, generator=g, dtype=f64)
+    R = 0.15 * torch.randn(M + p, M + p, generator=g, dtype=f64)
+    P["natural_mat"] = -0.5 * (torch.eye(M + p, dtype=f64) + R @ R.t())
+    P["natural_mat"] = 0.5 * (P["natural_mat"] + P["natural_mat"].t())
+    l_ref, g_ref, mu_ref, var_ref = O.ngd_loss_and_grads(P, x, y, D, nd, "ELBO", forward=O.shared_forward)
+    eng = ElboEngine64(gpu_device)
+    eng.shared_directions = True
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO")
+    assert set(grads) == set(O.NGD_PARAM_NAMES)
+    assert abs(loss.item() - l_ref.item()) < 1e-9 * abs(l_ref.item())
+    assert relmax(mu, mu_ref) < 1e-9 and relmax(varn, var_ref) < 1e-9
+    for k in O.NGD_PARAM_NAMES:
+        assert grads[k].shape == g_ref[k].shape, k
+        if g_ref[k].abs().max() > 0:
+            assert relmax(grads[k], g_ref[k]) < 1e-7, (k, relmax(grads[k], g_ref[k]))
+    mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert relmax(mu2, mu_ref) < 1e-9 and relmax(varn2, var_ref) < 1e-9
