@@ -495,3 +495,53 @@ def test_fp64_shared_directions_with_natural_parameters(dsvgp, gpu_device):
             assert relmax(grads[k], g_ref[k]) < 1e-7, (k, relmax(grads[k], g_ref[k]))
     mu2, varn2 = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
     assert relmax(mu2, mu_ref) < 1e-9 and relmax(varn2, var_ref) < 1e-9
+
+
+def test_other_harnesses_under_float64_default(dsvgp, gpu_device):
+    """grad_svgp (tests/test_grad_svgp.py sizes), dfree_directional_vi and traditional_vi built under a float64 default: fp64 engine,
+    float64 parameters and predictions, the loss goes down"""
+    import math as _m
+    from torch.utils.data import TensorDataset
+    from dsvgp_amd._step64 import ElboEngine64
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(0)
+        n, dim, p = 400, 2, 2
+        X, Xt = torch.rand(n, dim), torch.rand(60, dim)
+        Y, Yt = O.testfun(X), O.testfun(Xt)
+
+        def first_last_loss(loop_fn):
+            import io, contextlib
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                out = loop_fn()
+            ls = [float(l.split("loss: ")[1].split(",")[0]) for l in buf.getvalue().splitlines() if l.startswith("Epoch")]
+            return out, ls
+
+        G = dsvgp.grad_svgp
+        (model, lik), ls = first_last_loss(lambda: G.train_gp(TensorDataset(X, Y), dim, num_inducing=16, minibatch_size=200,
+                                                              num_epochs=30, mll_type="PLL", tqdm=False, seed=1))
+        assert isinstance(model.engine, ElboEngine64) and len(ls) >= 2 and ls[-1] < ls[0]
+        means, variances = G.eval_gp(TensorDataset(Xt, Yt), model, lik, minibatch_size=30)
+        assert means.dtype == f64 and means.shape == (60 * 3,) and bool((variances > 0).all())
+
+        F = dsvgp.dfree_directional_vi
+        (model, lik), ls = first_last_loss(lambda: F.train_gp(TensorDataset(X, Y[:, 0].contiguous()), num_inducing=16,
+                                                              num_directions=p, minibatch_size=200, minibatch_dim=p, num_epochs=30,
+                                                              inducing_data_initialization=False, tqdm=False, seed=5))
+        assert isinstance(model.engine, ElboEngine64) and len(ls) >= 2 and ls[-1] < ls[0]
+        means, variances = F.eval_gp(TensorDataset(Xt, Yt[:, 0].contiguous()), model, lik, num_directions=p, minibatch_size=30,
+                                     minibatch_dim=p)
+        assert means.dtype == f64 and means.shape == (60,) and bool((variances > 0).all())
+
+        T = dsvgp.traditional_vi
+        x1 = torch.rand(300, 1)
+        y1 = torch.sin(2 * _m.pi * x1[:, 0]) + 0.05 * torch.randn(300)
+        (model, lik), ls = first_last_loss(lambda: T.train_gp(TensorDataset(x1, y1), 1, num_inducing=30, minibatch_size=100,
+                                                              num_epochs=40, learning_rate_hypers=0.02, tqdm=False, seed=4))
+        assert isinstance(model.engine, ElboEngine64) and len(ls) >= 2 and ls[-1] < ls[0]
+        means, variances = T.eval_gp(TensorDataset(x1[:40], y1[:40]), model, lik, minibatch_size=20)
+        assert means.dtype == f64 and means.shape == (40,) and bool((variances > 0).all())
+    finally:
+        torch.set_default_dtype(prev)
