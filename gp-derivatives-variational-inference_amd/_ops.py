@@ -211,6 +211,19 @@ def abar_f64(ctx, A, U, m, mu_bar, var_bar, Abar, Av=None):
                              _ld(Abar), _ptr(Av), _ld(Av) if Av is not None else 0), "dsvgp_abar_f64")
 
 
+def likelihood_terms_f64(ctx, mu0, cs, y, constant, p, hyp, mll_type, rows):
+    """(mu, varn, mu_bar, var_bar, scal[8]) of the fp64 model's likelihood + objective in one launch (see dsvgp.h)"""
+    n = mu0.shape[0]
+    dev = mu0.device
+    mu, varn, mu_bar, var_bar = (torch.empty(n, dtype=f64, device=dev) for _ in range(4))
+    scal = torch.empty(8, dtype=f64, device=dev)
+    check(lib.dsvgp_likelihood_terms_f64(ctx.h, _ptr(_req(mu0, f64, "mu0", 1)), _ptr(_req(cs, f64, "cs", 1)),
+                                         _ptr(_req(y, f64, "y", 1)), _ptr(_req(constant, f64, "constant", 1)), n, int(p), _ptr(hyp),
+                                         int(mll_type), float(rows), _ptr(mu), _ptr(varn), _ptr(mu_bar), _ptr(var_bar), _ptr(scal)),
+          "dsvgp_likelihood_terms_f64")
+    return mu, varn, mu_bar, var_bar, scal
+
+
 def kernel_diag(ctx, n, p, hyp):
     out = torch.empty(n * (p + 1), dtype=f32, device=hyp.device)
     check(lib.dsvgp_kernel_diag(ctx.h, n, p, _ptr(hyp), _ptr(out)), "dsvgp_kernel_diag")

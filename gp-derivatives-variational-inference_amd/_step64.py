@@ -67,7 +67,10 @@ class ElboEngine64(ElboEngine):
         ell, s, noise = F.softplus(raw[0]), F.softplus(raw[1]), F.softplus(raw[2]) + NOISE_FLOOR
         return raw, (ell, s, noise), torch.stack([ell, s, noise, torch.zeros_like(ell)]).detach().contiguous()
 
-    def _factor64(self, ctx, params, hyp, nrhs):
+    def _factor64(self, ctx, params, hyp, nrhs, sync=True):
+        """``sync=False``: one plain attempt whose potrf status is NOT read here (``self._info64`` holds it): the training step
+        queues everything behind it and looks at the status once at its end -- a host read in the middle of the step leaves the
+        GPU idle while the host queues the ~100 launches that follow"""
         Z, V = params["inducing_points"], params["inducing_directions"]
         M, d = Z.shape
         p = V.shape[0] // M if M else 0
@@ -84,7 +87,8 @@ class ElboEngine64(ElboEngine):
             if t >= 0:
                 _ops.add_diag_(ctx, L, self.chol_jitter * (10 ** t))
             self._potrf_ws = self._potrf_and_inverse(ctx, L, info, ws, nrhs, "kzz")
-            if int(info.item()) == 0:
+            self._info64 = info
+            if not sync or int(info.item()) == 0:
                 break
         else:
             raise NotPSDError("Matrix not positive definite after repeatedly adding jitter up to %.1e."
@@ -116,6 +120,23 @@ class ElboEngine64(ElboEngine):
         _ops.gemm(ctx, TRANS_A | A_UPPER, params["chol_variational_covar"], A, W)      # tril(L_S)^T A
         mu0, cs = _ops.colstats_f64(ctx, A, W, params["variational_mean"].contiguous())
         return packX, A, W, mu0, cs
+
+    @staticmethod
+    def _kl64(m, LS, Mp, num_data, dm, dLS):
+        """KL(q(u) || N(0, I)) / num_data of the whitened prior (a6) and its gradients added to (dm, dLS), closed form"""
+        Lt = torch.tril(LS)
+        dg = torch.diagonal(Lt)
+        kl = 0.5 * ((m * m).sum() + (Lt * Lt).sum() - Mp - torch.log(dg * dg).sum())
+        dm.add_(m, alpha=1.0 / float(num_data))
+        dLS.add_(Lt - torch.diag(1.0 / dg), alpha=1.0 / float(num_data))
+        return kl / float(num_data)
+
+    @staticmethod
+    def _raw_grads64(params, scal):
+        """(d lengthscale, d outputscale, d noise) of the likelihood / prior-diagonal terms -> raw parameters through the softplus
+        constraints (Positive: d raw = d * sigmoid(raw); GreaterThan(1e-4): the same slope)"""
+        sg = [torch.sigmoid(params[k].reshape(())) for k in ("raw_lengthscale", "raw_outputscale", "raw_noise")]
+        return [scal[4] * sg[0], scal[3] * sg[1], scal[1] * sg[2]]
 
     @staticmethod
     def _prior_diag(B, p, pd, ell, s, like):
@@ -307,6 +328,14 @@ class ElboEngine64(ElboEngine):
         return out
 
     def _loss_and_grads64(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast):
+        """first attempt without a host read of the potrf status inside the step; the status is read once at the end and a failed
+        factorisation (rare: psd_safe_cholesky's jitter ladder) repeats the step synchronously"""
+        out = self._loss_and_grads64_once(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, False)
+        if int(self._info64.item()) != 0:
+            out = self._loss_and_grads64_once(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, True)
+        return out
+
+    def _loss_and_grads64_once(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         self._check(params, x, D)
         self._eval_cache = None
         dev = self.device
@@ -326,40 +355,22 @@ class ElboEngine64(ElboEngine):
         if fast is None:
             fast = self.elbo_fast
         raw, _, hyp = self._hyp64(params)
-        packZ, L, dims, ws = self._factor64(ctx, params, hyp, Bp)
+        packZ, L, dims, ws = self._factor64(ctx, params, hyp, Bp, sync=sync)
         M, d, p, Mp = dims
         if fast and mll_type == "ELBO" and Mp * Bp >= self.fast_min_work:
             return self._elbo_fast64(ctx, params, hyp, packZ, L, dims, ws, x, y, D, rows, num_data, include_kl)
         packX, A, W, mu0, cs = self._interp64(ctx, params, hyp, packZ, L, dims, ws, x, D)
 
-        # ---- O(B') likelihood terms, O(M'^2) KL, constraints: torch fp64 expressions + autograd (directional_vi.py:245-249) ----
-        with torch.enable_grad():
-            raw, (ell, s, noise), _ = self._hyp64(params, grad=True)
-            mu0_, cs_ = mu0.requires_grad_(True), cs.requires_grad_(True)
-            c_ = params["constant"].detach().reshape(()).clone().requires_grad_(True)
-            m_ = m.detach().clone().requires_grad_(True)
-            LS_ = LS.detach().clone().requires_grad_(True)
-            mu = mu0_ + c_
-            var = self._prior_diag(B, p, pd, ell, s, x) + KXX_JITTER + cs_
-            varn = (var + noise).clamp_min(MIN_VARIANCE)
-            if mll_type == "ELBO":
-                ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
-            else:
-                tot = (varn + noise).clamp_min(1e-8)
-                ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
-            loss = -ll.sum() / rows
-            if include_kl:
-                LSl = torch.tril(LS_)
-                kl = 0.5 * ((m_ * m_).sum() + (LSl * LSl).sum() - Mp - torch.log(torch.diagonal(LSl) ** 2).sum())
-                loss = loss + kl / num_data
-            leaves = [mu0_, cs_, c_, raw[0], raw[1], raw[2]] + ([m_, LS_] if include_kl else [])
-            g = torch.autograd.grad(loss, leaves, allow_unused=True)
-        mu_bar, var_bar = g[0].contiguous(), g[1].contiguous()
+        # ---- O(B') likelihood terms in one launch (dsvgp_likelihood_terms_f64), O(M'^2) KL and the softplus constraints in closed
+        #      form (directional_vi.py:245-249 differentiates the same expressions by autograd) ----
+        mu, varn, mu_bar, var_bar, scal = _ops.likelihood_terms_f64(ctx, mu0, cs, y, params["constant"].reshape(1).contiguous(), pd,
+                                                                    hyp, 0 if mll_type == "ELBO" else 1, rows)
+        loss = -scal[0] / rows
         grads = {k: torch.zeros_like(params[k]) for k in PARAM_NAMES}
         dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
         if include_kl:
-            dm.add_(g[6])
-            dLS.add_(g[7])
+            loss = loss + self._kl64(m, LS, Mp, num_data, dm, dLS)
+        d_con = self._raw_grads64(params, scal)
 
         # ---- variational parameters: m-bar += A mu_bar, L_S-bar += tril(2 A diag(var_bar) W^T) ----
         Abar = self._get("Abar", (Mp, Bp), f64)
@@ -382,8 +393,8 @@ class ElboEngine64(ElboEngine):
         _ops.trsm(ctx, L, Abar, True, Kb, None, self.trsm_nb, ws, reuse_inverse=True)     # K_ZX-bar = L^-T Abar
         Lbar = self._get("Lbar", (Mp, Mp), f64)
         _ops.gemm(ctx, TRANS_B | OUT_LOWER, Kb, A, Lbar, alpha=-1.0)                      # L-bar = -tril(K_ZX-bar A^T)
-        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, g[2], g[3:6])
-        return loss.detach(), grads, mu.detach(), varn.detach()
+        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, scal[2], d_con)
+        return loss, grads, mu, varn
 
     def _kernel_part64(self, ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, dc, d_raw):
         """K_ZX-bar and L-bar -> inducing points / directions and the kernel hyper-parameters (both formulations)"""

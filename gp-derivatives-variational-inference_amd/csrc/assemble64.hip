@@ -231,7 +231,81 @@ __global__ __launch_bounds__(256) void abar64_kernel(const double* __restrict__ 
     if (Av) Av[(int64_t)i * ldv + j] = a * vb2;
 }
 
+// GaussianLikelihood + VariationalELBO / PredictiveLogLikelihood terms of the fp64 model (directional_vi.py:245-246, gpytorch
+// expected_log_prob / log_marginal): per output j  mu = mu0 + c,  var = s dg_j + 1e-4 + cs_j,  vn = max(var + noise, 1e-6);
+// writes mu, vn, mu_bar = d loss / d mu0, var_bar = d loss / d cs and accumulates
+// scal: 0 sum_ll, 1 d loss / d noise, 2 d / d constant, 3 d / d outputscale (prior diagonal), 4 d / d lengthscale (prior diagonal)
+__global__ __launch_bounds__(256) void likelihood64_kernel(const double* __restrict__ mu0, const double* __restrict__ cs,
+                                                           const double* __restrict__ y, const double* __restrict__ constant,
+                                                           int ncols, int p, const double* __restrict__ hyp, int mll_type,
+                                                           double inv_rows, double* __restrict__ mu_out,
+                                                           double* __restrict__ varn_out, double* __restrict__ mu_bar,
+                                                           double* __restrict__ var_bar, double* __restrict__ scal) {
+    __shared__ double red[5][4];
+    const double ell = hyp[0], s = hyp[1], noise = hyp[2], c = constant[0];
+    const double LOG2PI = 1.8378770664093454835606594728112;
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < ncols; j += gridDim.x * 256) {
+        const bool isf = (j % (p + 1)) == 0;
+        const double mj = mu0[j] + c, r = y[j] - mj;
+        const double var = s * (isf ? 1.0 : 1.0 / (ell * ell)) + 1e-4 + cs[j];
+        const double vraw = var + noise;
+        const bool clamped = vraw < 1e-6;
+        const double vn = clamped ? 1e-6 : vraw;
+        double ll, dmu, dvn, dnoise;
+        if (mll_type == 0) {
+            ll = -0.5 * ((r * r + vn) / noise + log(noise) + LOG2PI);
+            dmu = r / noise;
+            dvn = -0.5 / noise;
+            dnoise = 0.5 * (r * r + vn) / (noise * noise) - 0.5 / noise;
+        } else {
+            const double tot = fmax(vn + noise, 1e-8);
+            ll = -0.5 * (r * r / tot + log(tot) + LOG2PI);
+            dmu = r / tot;
+            dvn = (vn + noise < 1e-8) ? 0.0 : 0.5 * (r * r / (tot * tot) - 1.0 / tot);
+            dnoise = dvn;
+        }
+        const double dvar = clamped ? 0.0 : dvn;
+        dnoise += dvar;
+        const double mb = -dmu * inv_rows, vb = -dvar * inv_rows;
+        mu_out[j] = mj;
+        varn_out[j] = vn;
+        mu_bar[j] = mb;
+        var_bar[j] = vb;
+        acc[0] += ll;
+        acc[1] += -dnoise * inv_rows;
+        acc[2] += mb;
+        acc[3] += vb * (isf ? 1.0 : 1.0 / (ell * ell));
+        acc[4] += isf ? 0.0 : vb * (-2.0 * s / (ell * ell * ell));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[q][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(&scal[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 }  // namespace
+
+extern "C" int dsvgp_likelihood_terms_f64(dsvgp_ctx* ctx, const double* mu0, const double* cs, const double* y, const double* constant,
+                                          int ncols, int p, const double* hyp, int mll_type, double rows, double* mu, double* varn,
+                                          double* mu_bar, double* var_bar, double* scal) {
+    if (!ctx || !mu0 || !cs || !y || !constant || !hyp || !mu || !varn || !mu_bar || !var_bar || !scal || ncols <= 0 || p < 0 ||
+        rows <= 0.0 || (mll_type != 0 && mll_type != 1))
+        return DSVGP_EINVAL;
+    hipError_t e = hipMemsetAsync(scal, 0, sizeof(double) * 8, ctx->stream);
+    if (e != hipSuccess) return 1000 + (int)e;
+    int blocks = cdiv(ncols, 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(likelihood64_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mu0, cs, y, constant, ncols, p, hyp, mll_type,
+                       1.0 / rows, mu, varn, mu_bar, var_bar, scal);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dsvgp_pack_points_f64(dsvgp_ctx* ctx, const double* x, const double* v, int n, int d, int p, const double* hyp,
                                      const double* center, double* P, double* self, double* vnorm) {

@@ -119,6 +119,13 @@ int dsvgp_colstats_f64(dsvgp_ctx* ctx, const double* A, int64_t lda, const doubl
                        double* mu, double* cs);
 int dsvgp_abar_f64(dsvgp_ctx* ctx, const double* A, int64_t lda, const double* U, int64_t ldu, const double* m, const double* mu_bar,
                    const double* var_bar, int Mp, int Bp, double* Abar, int64_t ldo, double* Av, int64_t ldv);
+/* likelihood terms of the fp64 model (GaussianLikelihood + VariationalELBO mll_type 0 / PredictiveLogLikelihood 1,
+ * directional_vi.py:172,217,245-246): mu = mu0 + constant, varn = max(s dg + 1e-4 + cs + noise, 1e-6) per output (p derivative
+ * outputs per point), mu_bar / var_bar = d loss / d mu0, d cs with loss = -(sum ll) / rows, and
+ * scal[8] (zeroed here) = {sum ll, d/d noise, d/d constant, d/d outputscale, d/d lengthscale (prior-diagonal parts), 0, 0, 0}  */
+int dsvgp_likelihood_terms_f64(dsvgp_ctx* ctx, const double* mu0, const double* cs, const double* y, const double* constant,
+                               int ncols, int p, const double* hyp, int mll_type, double rows, double* mu, double* varn,
+                               double* mu_bar, double* var_bar, double* scal);
 int dsvgp_kernel_bwd_points_f64(dsvgp_ctx* ctx, const double* dP, const double* P1, const double* vnorm1, int n1, int d,
                                 int p, const double* hyp, int symmetric, double* d_x1, double* d_v1);
 
