@@ -117,5 +117,10 @@ def make_adam(param_groups, lr=1e-3):
     groups = list(param_groups)
     tensors = [p for g in groups for p in (g["params"] if isinstance(g, dict) else [g])]
     if any(p.dtype == torch.float64 for p in tensors):
+        if all(p.is_cuda for p in tensors):
+            try:                    # torch's own multi-tensor kernel (same update rule): one launch per group instead of ~10
+                return torch.optim.Adam(groups, lr=lr, fused=True)
+            except (RuntimeError, ValueError, TypeError):
+                pass
         return torch.optim.Adam(groups, lr=lr)
     return FusedAdam(groups, lr=lr)
