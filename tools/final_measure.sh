@@ -9,6 +9,9 @@ python3 bench.py > $O/bench_c4.json 2> $O/bench_c4.err && tail -1 $O/bench_c4.js
 for cfg in "c2 300" "c3 40" "c5 8" "c4shard8 40"; do set -- $cfg
   python3 bench.py --config $1 --steps $2 --warmup 5 --no-cpu-baseline > $O/bench_$1.json 2>/dev/null && tail -1 $O/bench_$1.json | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1', round(j['ms_per_step'],4), (j.get('roofline') or {}).get('frac'))"
 done
+for cfg in "c4 10" "c3 20" "c2 300"; do set -- $cfg      # the double-precision model mode of the reference's experiment scripts
+  python3 bench.py --fp64 --config $1 --steps $2 > $O/bench_$1_fp64.json 2>/dev/null && tail -1 $O/bench_$1_fp64.json | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1 fp64', round(j['ms_per_step'],4))"
+done
 fi
 cd /tmp && export TMPDIR=/tmp
 for cfg in "c4 9" "c3 9" "c5 4" "c2 40"; do set -- $cfg
