@@ -82,9 +82,10 @@ class ElboEngine:
         # S = L_S L_S^T on the side stream as a one-workgroup-per-CU launch (DSVGP_GEMM_BACKGROUND).  Measured alternatives that
         # did not help: least-priority side stream (hipStreamCreateWithPriority), CU-masked side stream (hipExtStreamCreateWithCUMask)
         self.side_background = os.environ.get("DSVGP_SIDE_BACKGROUND", "1") == "1"
-        # K_ZX-bar's kernel backward on the side stream next to the L-bar / Cholesky-backward products.  Off by default: measured
-        # C3 8.65 -> 8.58 ms/step, but C4 14.04-14.18 -> 14.13-14.21 and the 8-rank share unchanged
-        self.bwd_overlap = os.environ.get("DSVGP_BWD_OVERLAP", "0") == "1"
+        # K_ZX-bar's kernel backward on the side stream next to the L-bar / Cholesky-backward products.  Measured: C3 8.11 -> 8.00
+        # ms/step, C4 14.04-14.18 -> 14.13-14.21, the 8-rank share 5.66 -> 5.68: automatic = one GPU and B' <= 2 M' only
+        _bo = os.environ.get("DSVGP_BWD_OVERLAP")
+        self.bwd_overlap = None if _bo is None else _bo == "1"
         # one GPU: the L_S / m gradient kernels (need only G) on the side stream next to the Q' solve and the dense product.
         # Measured: C3 8.26 -> 8.18 ms/step, C4 unchanged (14.01 / 13.97-14.02)
         self.var_overlap = os.environ.get("DSVGP_VAR_OVERLAP", "1") == "1"
@@ -977,7 +978,8 @@ class ElboEngine:
         # (both accumulate into Z-bar, V-bar and the hyper-parameter slots)
         zx_done = None
         dense_done, self._dense_done = getattr(self, "_dense_done", None), None
-        if self.bwd_overlap and use_fast and dense_done is not None and self._side is not None and not self.capture_mode:
+        bwd_overlap = self.bwd_overlap if self.bwd_overlap is not None else (Bp <= 2 * Mp and self.collective is None)
+        if bwd_overlap and use_fast and dense_done is not None and self._side is not None and not self.capture_mode:
             kws2 = self._bytes("kbwd_ws_zx", _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p))
             with torch.cuda.stream(self._side):
                 self._side.wait_event(dense_done)
