@@ -96,7 +96,7 @@ def test_step_matches_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
             assert grads[k].triu(1).abs().max().item() == 0.0
         e_mixed, e_64 = relmax(grads[k], gr), relmax(grads[k], g64[k])
         errs[k] = min(e_mixed, e_64)
-        assert min(e_mixed, e_64) < 2e-3, (k, e_mixed, e_64)
+        assert min(e_mixed, e_64) < 5e-4, (k, e_mixed, e_64)      # observed (MI355X, round 2): <= 1.1e-4 over the 7 geometries x 3 modes
     _report("step N=%d d=%d M=%d p=%d B=%d %s%s" % (N, d, M, p, B, mll, "" if not fast else " fast"), errs)
 
 
@@ -108,8 +108,10 @@ def test_step_at_c2_sizes_against_oracle(dsvgp, gpu_device):
         loss, grads, mu, varn, _, _ = run_gpu(dsvgp, gpu_device, P, x, y, D, nd, trsm_nb=nb, fast=fast)
         assert abs(loss.item() - l_ref.item()) < 2e-5 * abs(l_ref.item())
         assert relmax(mu, mu_ref) < 2e-4 and (fast or relmax(varn, var_ref) < 2e-4)
+        errs = {k: relmax(grads[k], g_ref[k]) for k in O.PARAM_NAMES}
+        _report("C2 full size nb=%d%s" % (nb, " fast" if fast else ""), errs)
         for k in O.PARAM_NAMES:
-            assert relmax(grads[k], g_ref[k]) < 5e-3, (nb, k, relmax(grads[k], g_ref[k]))
+            assert errs[k] < 3e-4, (nb, k, errs[k])               # observed <= 4.6e-5
 
 
 def test_predict_matches_oracle_and_initial_variance(dsvgp, gpu_device):
@@ -279,19 +281,21 @@ def test_c4_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device):
     P, x, y, D, nd = make_inputs()
     for fast in (True, False):
         loss, grads, mu, varn, _, _ = run_gpu(dsvgp, gpu_device, P, x, y, D, nd, trsm_nb=4096, fast=fast)
-        assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"])), (fast, loss.item(), float(g["loss"]))
-        assert relmax(mu[:256], torch.from_numpy(g["mu_head"])) < 2e-4
+        # stated tolerances of the headline configuration (fp32 model against the fp64-solve oracle): loss 5e-6, predictive head 5e-5,
+        # every gradient 1e-4 -- observed on MI355X (round 2): loss 3e-7, mu 1.6e-6, gradients <= 3e-6 (the [parity] line below)
+        assert abs(loss.item() - float(g["loss"])) < 5e-6 * abs(float(g["loss"])), (fast, loss.item(), float(g["loss"]))
+        assert relmax(mu[:256], torch.from_numpy(g["mu_head"])) < 5e-5
         if not fast:
-            assert relmax(varn[:256], torch.from_numpy(g["varn_head"])) < 2e-4
+            assert relmax(varn[:256], torch.from_numpy(g["varn_head"])) < 5e-5
         for k in O.PARAM_NAMES:
             if k == "chol_variational_covar":
                 gl = grads[k]
-                assert abs(gl.double().norm().item() - float(g["g_LS_norm"])) < 2e-3 * float(g["g_LS_norm"])
-                assert relmax(gl[:96, :96], torch.from_numpy(g["g_LS_block"])) < 5e-3
-                assert relmax(torch.diagonal(gl), torch.from_numpy(g["g_LS_diag"])) < 5e-3
-                assert relmax(gl[-8:, :], torch.from_numpy(g["g_LS_lastrows"])) < 5e-3
+                assert abs(gl.double().norm().item() - float(g["g_LS_norm"])) < 1e-4 * float(g["g_LS_norm"])
+                assert relmax(gl[:96, :96], torch.from_numpy(g["g_LS_block"])) < 1e-4
+                assert relmax(torch.diagonal(gl), torch.from_numpy(g["g_LS_diag"])) < 1e-4
+                assert relmax(gl[-8:, :], torch.from_numpy(g["g_LS_lastrows"])) < 1e-4
             else:
-                assert relmax(grads[k], torch.from_numpy(g["g_" + k])) < 5e-3, (fast, k, relmax(grads[k], torch.from_numpy(g["g_" + k])))
+                assert relmax(grads[k], torch.from_numpy(g["g_" + k])) < 1e-4, (fast, k, relmax(grads[k], torch.from_numpy(g["g_" + k])))
         errs = {"loss": abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), "mu": relmax(mu[:256], torch.from_numpy(g["mu_head"]))}
         errs.update({"g_" + k: relmax(grads[k], torch.from_numpy(g["g_" + k])) for k in O.PARAM_NAMES if k != "chol_variational_covar"})
         errs["g_LS_block"] = relmax(grads["chol_variational_covar"][:96, :96], torch.from_numpy(g["g_LS_block"]))
@@ -657,11 +661,13 @@ def test_c3_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, ml
             if k not in ("chol_variational_covar", "inducing_directions"):
                 errs["g_" + k] = relmax(grads[k], torch.from_numpy(g[pre + "g_" + k]))
         _report("C3 %s %s" % (mll, "fast" if fast else "per-output"), errs)
-        assert errs["loss"] < 2e-5 and errs["mu"] < 2e-4 and errs.get("var", 0.0) < 2e-4, errs
-        assert errs["g_LS_norm"] < 2e-3
+        # stated tolerances: loss 5e-6, mean 2e-4, variance 5e-5, gradients 2e-3 (1e-8 Cholesky jitter: K_ZZ is worse conditioned here than
+        # at C4) -- observed: loss 1e-7, mean 2.4e-5, variance 2e-6, gradients <= 2.7e-4 (last rows of L_S-bar), <= 5e-5 otherwise
+        assert errs["loss"] < 5e-6 and errs["mu"] < 2e-4 and errs.get("var", 0.0) < 5e-5, errs
+        assert errs["g_LS_norm"] < 1e-4
         for k, v in errs.items():
             if k.startswith("g_"):
-                assert v < 5e-3, (k, v)
+                assert v < 2e-3, (k, v)
 
 
 def _graph_loop(dsvgp, gpu_device, graph, lr_sched=None, seed=7, M=24):
