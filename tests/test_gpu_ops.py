@@ -48,13 +48,14 @@ def test_kernel_fwd_matches_reference_golden_vectors(dsvgp, gpu_device, path):
     e_sub, e_sum = kernel_error(K, g)
     print("kernel_fwd %s: HIP fp32 error %.2e (row/col sums %s); reference's own fp32 round-off %.2e"
           % (os.path.basename(path), e_sub, "%.2e" % e_sum if e_sum is not None else "-", float(g["ref_fp32_relerr"])))
-    assert e_sub < 2e-5 and (e_sum is None or e_sum < 2e-5)        # fp32 arithmetic vs the reference run in fp64
+    assert e_sub < 2e-6 and (e_sum is None or e_sum < 2e-6)        # fp32 arithmetic vs the reference run in fp64 (observed <= 4.1e-7,
+                                                                   # the reference's own fp32 run: 1e-7 ... 7.9e-7)
     if "Kdiag" in g:                                               # diag=True branch (:110-119) for every symmetric case
         ops = dsvgp._ops
         ctx = ops.Context.get(gpu_device)
         dg = ops.kernel_diag(ctx, g["x1"].shape[0], int(g["p"]), _hyp(gpu_device, float(g["lengthscale"])))
         assert relmax(dg, t("Kdiag")) < 1e-6
-        assert relmax(torch.diagonal(K), t("Kdiag")) < 2e-5
+        assert relmax(torch.diagonal(K), t("Kdiag")) < 2e-6
         # fp64 output of the same assembly (what feeds the Cholesky), + jitter on the diagonal only
         K64, _ = _kernel_gpu(dsvgp, gpu_device, t("x1"), t("x2"), t("v1"), t("v2"), float(g["lengthscale"]), jitter=1e-3,
                              dtype=torch.float64)
