@@ -1163,6 +1163,27 @@ class ElboEngine:
         elif coll is None:
             variational_part()
             Qe64 = solve_part()
+        elif self.var_overlap and self._side is not None and not self.capture_mode:
+            # global-Gram schedule: the side stream waits for the summed [G ; b^T], mirrors it and forms the L_S / m gradients
+            # (G L_S, trace / KL / loss kernels) while the main stream goes on with L-bar and the Cholesky backward
+            Qe64 = solve_part()
+            main = torch.cuda.current_stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            ev_w = self._event_pair()                        # (bench.py: how long the main stream stalls for [G ; b^T])
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(fork)
+                ctx.bind()
+                handle.wait()
+                _ops.mirror_lower_f32_(ctx, G, Mp)
+                g_ready = torch.cuda.Event()
+                g_ready.record(self._side)
+                variational_part()
+                var_done = torch.cuda.Event()
+                var_done.record(self._side)
+            ctx.bind()
+            main.wait_event(g_ready)
+            self._event_done("early_reduce_wait", ev_w)
         else:
             Qe64 = solve_part()
             ev_w = self._event_pair()                        # (bench.py: how long the main stream stalls for [G ; b^T])
