@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
-"""Kernel timeline of the LAST bench step in a rocprofv3 --kernel-trace database (start offset, duration, stream)."""
+"""Kernel timeline of one bench step in a rocprofv3 --kernel-trace database (start offset, duration, stream).
+usage: step_timeline.py run.db [--back N] [name fragments to leave out ...]
+--back N: the step that ends N steps before the last one (default 4: bench.py appends three untimed steps with the side stream OFF
+for the assembly-alone timing, so the last TIMED step -- side stream on -- is four from the end)"""
 import sqlite3, sys
+args = sys.argv[2:]
+back = 4
+if args[:1] == ["--back"]:
+    back = int(args[1]); args = args[2:]
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name,start,end,stream_id,grid_x,workgroup_x from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if 'hyp_forward' in r[0]]
-a, b = idx[-2], idx[-1]
+back = min(back, len(idx) - 2)
+a, b = idx[-2 - back], idx[-1 - back]
 t0 = rows[a][1]
-skip = tuple(sys.argv[2:])
+skip = tuple(args)
 prev_end = t0
 for r in rows[a:b]:
     nm = r[0].replace('(anonymous namespace)::', '').replace('void ', '')[:64]
