@@ -458,7 +458,7 @@ class ElboEngine64(ElboEngine):
         Gs = torch.tril(G)
         Gs = Gs + torch.tril(G, -1).t()                             # the symmetric G
         G.copy_(Gs)
-        _ops.gemm(ctx, B_LOWER, G, LSl, H)                                                # G L_S
+        _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LSl, H)                                    # tril(G L_S): nothing else of it is read
         tvar = ((H * LSl).sum() - torch.diagonal(G).sum()).detach()                     # tr(L_S^T G L_S) - tr G
         with torch.enable_grad():
             raw, (ell, s, noise), _ = self._hyp64(params, grad=True)
@@ -491,7 +491,8 @@ class ElboEngine64(ElboEngine):
         Ge[Mp].copy_(b.reshape(-1))
         # [Q' | a] = L^-T [S - I | m], then the 2 vbar of the variance terms on the Q' block
         Se = self._get("Se64", (Mp, Mp + 1), f64)
-        _ops.gemm(ctx, TRANS_B | A_LOWER, LSl, LSl, Se[:, :Mp])                           # S = L_S L_S^T
+        _ops.gemm(ctx, TRANS_B | A_LOWER | OUT_LOWER, LSl, LSl, Se[:, :Mp])               # S = L_S L_S^T: lower triangle,
+        _ops.phi_symmetrize_(ctx, Se[:, :Mp])                                             # mirrored
         Se[:, :Mp].diagonal().sub_(1.0)
         Se[:, Mp].copy_(m)
         Qe = self._get("Qe64", (Mp, Mp + 1), f64)
