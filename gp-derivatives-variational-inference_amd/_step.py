@@ -813,7 +813,8 @@ class ElboEngine:
         _ops.gemm(ctx, 0, cvec.reshape(1, Bp), Trow, d1)                                          # :102-106
         d1.add_(nat_vec.reshape(1, Mp), alpha=kl_bar)                                             # :107
         d2 = grads["natural_mat"]
-        _ops.gemm(ctx, TRANS_A, VT, Trow, d2)                                                     # :115-116
+        _ops.gemm(ctx, TRANS_A | OUT_LOWER, VT, Trow, d2)                                         # :115-116: T^T diag(vbar) T is
+        _ops.mirror_lower_f32_(ctx, d2, Mp)                                                       # symmetric: lower triangle + mirror
         d2.add_(nat_mat, alpha=kl_bar)                                                            # kl/2 (I - prec), prec = -2 theta_2
         d2.diagonal().add_(0.5 * kl_bar)
         # backward of sqrt_inv_matmul: dR = K^-1/2 Tbar, dK = -sym sum_q omega_q Y_q^T X_q (same quadrature)
