@@ -21,7 +21,6 @@ import argparse
 import json
 import math
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -49,15 +48,13 @@ PEAK_HBM_TBPS = 8.0             # HBM3E (MI355X_MICROARCH.md)
 
 
 def _self_launch(args):
-    """--gpus N > 1 from a plain invocation: one child launcher, N ranks, before any GPU call in this process."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    """--gpus N > 1 from a plain invocation: one child launcher, N ranks, before any GPU call in this process.
+    The rendezvous port is picked by the launcher itself (``--standalone``: c10d store on an ephemeral port of 127.0.0.1),
+    so two benches starting on one node cannot race for a port probed here."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
 
 

@@ -279,6 +279,9 @@ def potrf_inverse_(ctx, A, info, nb, workspace, ws=None):
     _req(A, f64, "A", 2)
     n = A.shape[0]
     ws = _potrf_scratch(A, ws)
+    need = int(lib.dsvgp_trsm_workspace_bytes(n, n, int(nb)))       # the inverse and its transposed copy live there
+    if workspace.numel() < need:
+        raise ValueError("potrf_inverse_: trsm workspace too small: %d < %d" % (workspace.numel(), need))
     check(lib.dsvgp_potrf_inverse(ctx.h, _ptr(A), n, _ld(A), _ptr(info), _ptr(ws), int(nb), _ptr(workspace)),
           "dsvgp_potrf_inverse")
     return ws

@@ -607,6 +607,7 @@ class ElboEngine:
         """NaturalVariationalDistribution.forward: (theta_1, theta_2) -> mu and L_S = chol(S).
         Returns (mu fp32, L_S fp32, L_S fp64, trsm workspace holding the inverted blocks of L_S)."""
         Mp = nat_vec.shape[0]
+        self._problem_size(Mp)          # (before reading trsm_nb: the regime of THIS factor, not of the previous problem)
         nb = self.trsm_nb
         LS64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)
         wsS = self._bytes("ngd_wsS", _lib.lib.dsvgp_trsm_workspace_bytes(Mp, Mp, nb))

@@ -36,6 +36,9 @@ struct GemmArgs {
 };
 constexpr int DSVGP_GEMM_KEEP_UPPER = 1 << 20;   // internal flag (with OUT_LOWER): do not touch m < n
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
+// zero an M x N block (element size esz) with leading dimension ld: linear memset for contiguous rows, a fill kernel of our
+// own for padded rows (the runtime's pitched 2-D memset runs below 1 TB/s) -- gemm.hip
+hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st);
 void launch_cvt_f64_f32(hipStream_t st, const double* C, int64_t ldc, float* C32, int64_t ldc32, int M, int N);   // gemm64.hip
 int launch_gemm64(hipStream_t st, const GemmArgs& g);     // gemm64.hip: 1 = taken, 0 = not eligible, > 1 = error
 int launch_gemm32(hipStream_t st, const GemmArgs& g);     // gemm32.hip (fp32, 32x32x2 MFMA): same convention

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(T* __restrict__ C, int64
         C[r * ld + (e - r * N)] = T(0);
     }
 }
-static hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st) {
+hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st) {
     if (ld == N) return hipMemsetAsync(C, 0, esz * (size_t)M * (size_t)N, st);
     const int64_t total = (int64_t)M * N;
     const int blocks = (int)((total + 256 * 8 - 1) / (256 * 8) < 4096 ? (total + 256 * 8 - 1) / (256 * 8) : 4096);

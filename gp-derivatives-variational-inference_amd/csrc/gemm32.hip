@@ -563,8 +563,7 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     if (a.splitk > 1 || out_lower) {
         // atomics accumulate onto zeros / the strict upper triangle is defined as zero
         // (contiguous rows: one linear fill -- the 2-D fill kernel of the runtime takes 104 us for 36 MB, the linear one ~10)
-        hipError_t e = (a.ldc == a.N) ? hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, st)
-                                      : hipMemset2DAsync(a.C, sizeof(float) * (size_t)a.ldc, 0, sizeof(float) * (size_t)a.N, (size_t)a.M, st);
+        hipError_t e = zero_block(a.C, sizeof(float), a.ldc, a.M, a.N, st);
         if (e != hipSuccess) return 1000 + (int)e;
     }
     const dim3 grid(cdiv((int64_t)a.ntiles * a.splitk, 8) * 8);

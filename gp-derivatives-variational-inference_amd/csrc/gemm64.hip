@@ -251,8 +251,7 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     int ysplit = 1;
     if (a.kchunk) {
         ysplit = cdiv(g.K, a.kchunk);
-        hipError_t ez = (a.ldc == a.N) ? hipMemsetAsync(a.C, 0, sizeof(double) * (size_t)a.M * a.N, st)
-                                       : hipMemset2DAsync(a.C, sizeof(double) * (size_t)a.ldc, 0, sizeof(double) * (size_t)a.N, (size_t)a.M, st);
+        hipError_t ez = zero_block(a.C, sizeof(double), a.ldc, a.M, a.N, st);
         if (ez != hipSuccess) return 1000 + (int)ez;
     }
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);

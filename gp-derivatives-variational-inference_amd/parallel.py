@@ -29,6 +29,8 @@ class DataParallel:
         self.algo = os.environ.get("DSVGP_DP_ALGO", "allreduce")
         self.rs_ag_min_numel = 1 << 16
         self._shards = {}
+        # rank 0 OF THE GROUP as a global rank: what dist.broadcast's ``src`` means (a sub-group need not contain global rank 0)
+        self.src0 = dist.get_global_rank(group, 0) if group is not None else 0
         self.replicated_step = False  # set by the training loop for a tail minibatch with fewer rows than ranks
 
     def shard_bounds(self, n):
@@ -50,12 +52,12 @@ class DataParallel:
                 if st:
                     ts += [v for v in st.values() if torch.is_tensor(v)]
         for t in ts:
-            dist.broadcast(t, 0, group=self.group)
+            dist.broadcast(t, self.src0, group=self.group)
 
     def broadcast_floats(self, values, device):
         """rank 0's host scalars on every rank (e.g. the eigenvalue bounds of the CIQ quadrature)"""
         t = torch.tensor(values, dtype=torch.float64, device=device)
-        dist.broadcast(t, dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        dist.broadcast(t, self.src0, group=self.group)
         return [float(v) for v in t.tolist()]
 
     def all_reduce_async(self, t):
@@ -104,13 +106,13 @@ class DataParallel:
             loss, grads, mu, varn = engine.loss_and_grads(params, x, y, D, num_data, mll_type)
             flat = getattr(engine, "flat", None)
             if flat is not None:
-                dist.broadcast(flat, 0, group=self.group)
+                dist.broadcast(flat, self.src0, group=self.group)
                 loss = flat[-1]
             else:
                 for k in grads:
-                    dist.broadcast(grads[k], 0, group=self.group)
+                    dist.broadcast(grads[k], self.src0, group=self.group)
                 loss = loss.clone()
-                dist.broadcast(loss, 0, group=self.group)
+                dist.broadcast(loss, self.src0, group=self.group)
             return loss, grads, mu, varn
         hooked = hasattr(engine, "collective")
         if hooked:

@@ -145,7 +145,11 @@ int dsvgp_add_diag(dsvgp_ctx* ctx, double* A, int n, int64_t lda, double delta);
  * B[n,nrhs] is float or double (b_is_double); X64[n,nrhs] double output (may alias B when B is
  * double); X32 optional float copy (NULL to skip); X64 may be NULL when X32 is given and nb >= n
  * (single product with the explicit inverse).  Diagonal blocks of size nb are inverted
- * (stored in the workspace) and every update is a v_mfma_f64_16x16x4 GEMM.                      */
+ * (stored in the workspace) and every update is a v_mfma_f64_16x16x4 GEMM.
+ * WORKSPACE SIZE: `workspace` must hold dsvgp_trsm_workspace_bytes(n, nrhs OF THIS CALL, nb) bytes, ALSO with
+ * reuse_inverse=1 and ALSO when X64 is NULL: besides the inverted blocks it carries an n x nrhs double scratch that
+ * a small fp32-only solve (nb >= n, fewer than 1024 output tiles) uses as the fp64 target of its split-K product.
+ * The entry point has no size argument; an undersized workspace is an out-of-bounds write.                       */
 size_t dsvgp_trsm_workspace_bytes(int n, int nrhs, int nb);
 int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, int trans, const void* B,
                int64_t ldb, int b_is_double, int nrhs, double* X64, int64_t ldx64, float* X32,

@@ -157,6 +157,53 @@ def test_kernel_bwd_matches_autograd(dsvgp, gpu_device, n1, n2, d, p, sym):
         assert abs(dh[1].item() - sr.grad.item()) < 2e-4 * max(1.0, abs(sr.grad.item())), "d_outputscale"
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-4), (torch.float64, 1e-9)])
+@pytest.mark.parametrize("n1,n2,d,p,same", [(13, 21, 5, 2, False), (16, 16, 20, 5, True), (7, 40, 4, 1, False), (6, 9, 6, 0, False)])
+def test_kernel_plugin_is_differentiable_like_the_reference(dsvgp, gpu_device, dt, tol, n1, n2, d, p, same):
+    """``RBFKernelDirectionalGrad.forward`` (reference RBFKernelDirectionalGrad.py:41-108) is an autograd participant: gradients
+    w.r.t. x1, x2, v1, v2 and raw_lengthscale through the mirrored plugin (dsvgp_kernel_fwd / dsvgp_kernel_bwd behind a
+    torch.autograd.Function) against fp64 autograd through the oracle's kernel.  x1 is x2 (``same``): the K_ZZ call pattern,
+    where autograd sums both roles."""
+    g = torch.Generator().manual_seed(5 * n1 + n2 + d)
+    x1 = torch.rand(n1, d, generator=g, dtype=torch.float64)
+    v1 = torch.randn(n1 * p, d, generator=g, dtype=torch.float64)
+    x2 = x1 if same else torch.rand(n2, d, generator=g, dtype=torch.float64)
+    v2 = v1 if same else torch.randn(n2 * p, d, generator=g, dtype=torch.float64)
+    q = p + 1
+    G = torch.randn(n1 * q, (n1 if same else n2) * q, generator=g, dtype=torch.float64)
+    raw = 0.4
+    # fp64 truth: autograd through the oracle kernel
+    leaves = [t.clone().requires_grad_(True) for t in ((x1, v1) if same else (x1, x2, v1, v2))]
+    rawr = torch.tensor([[raw]], dtype=torch.float64, requires_grad=True)
+    ell = torch.nn.functional.softplus(rawr).reshape(())
+    if same:
+        Kref = O.kernel_matrix(leaves[0], leaves[0], leaves[1], leaves[1], ell)
+    else:
+        Kref = O.kernel_matrix(leaves[0], leaves[1], leaves[2], leaves[3], ell)
+    (Kref * G).sum().backward()
+    # the plugin
+    k = dsvgp._rbf_mod.RBFKernelDirectionalGrad().to(gpu_device)
+    if dt == torch.float64:
+        k = k.double()
+    with torch.no_grad():
+        k.raw_lengthscale.fill_(raw)
+    gl = [t.to(dt).to(gpu_device).requires_grad_(True) for t in ((x1, v1) if same else (x1, x2, v1, v2))]
+    if same:
+        K = k.forward(gl[0], gl[0], v1=gl[1], v2=gl[1])
+    else:
+        K = k.forward(gl[0], gl[1], v1=gl[2], v2=gl[3])
+    assert K.requires_grad and relmax(K, Kref) < (2e-6 if dt == torch.float32 else 1e-12)
+    (K * G.to(dt).to(gpu_device)).sum().backward()
+    errs = {}
+    for i, (a, b) in enumerate(zip(gl, leaves)):
+        if a.numel():
+            errs["arg%d" % i] = relmax(a.grad, b.grad)
+    errs["raw_lengthscale"] = relmax(k.raw_lengthscale.grad, rawr.grad)
+    print("[parity] differentiable kernel plugin %s %s: %s" % (str(dt).split(".")[-1], (n1, n2, d, p, same),
+                                                               ", ".join("%s %.1e" % kv for kv in errs.items())))
+    assert max(errs.values()) < tol, errs
+
+
 # ------------------------------------------------------------------ GEMM / trsm / potrf
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
