@@ -585,7 +585,8 @@ class _NgdInterpTermsFn(torch.autograd.Function):
         return d_interp, d_vec, d_mat
 
 
-def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0):
+def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0,
+                   assembly=None):
     """CiqDirectionalGradVariationalStrategy.forward with a NaturalVariationalDistribution (:197-268).
     Returns (mu, var, kl) with kl == 0 as in the reference's forward (:74)."""
     Z, V = params["inducing_points"], params["inducing_directions"]
@@ -596,6 +597,7 @@ def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=No
     B = x.shape[0]
     assert D.shape[0] // B == p, "Need minibatch dim to be same as number of directions for kernel"
     dt = x.dtype
+    kernel_matrix = assembly or globals()["kernel_matrix"]                     # (``kernel_matrix_refseq``: the reference's op sequence)
     K_ZX = s * kernel_matrix(Z, x, V, D, ell)                                  # :218-222
     K_ZZ = s * kernel_matrix(Z, Z, V, V, ell)
     # (gpytorch's plain CiqVariationalStrategy -- grad_svgp.py:25-27, traditional_vi.py:22-24, forward quoted at CiqDGVS.py:243-251
@@ -609,8 +611,8 @@ def ciq_predictive(params, x, D, Q=NUM_CONTOUR_QUADRATURE, exact=False, stats=No
 
 
 def ciq_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=NUM_CONTOUR_QUADRATURE, exact=False,
-                stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0):
-    mu, var, kl = ciq_predictive(params, x, D, Q, exact, stats, kzz_jitter, kxx_jitter)
+                stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0, assembly=None):
+    mu, var, kl = ciq_predictive(params, x, D, Q, exact, stats, kzz_jitter, kxx_jitter, assembly)
     _, _, noise = constrained(params)
     Bp = y.shape[0] if global_rows is None else global_rows
     varn = (var + noise).clamp_min(MIN_VARIANCE)
@@ -626,9 +628,9 @@ def ciq_forward(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=
 
 
 def ciq_loss_and_grads(params, x, y, D, num_data, mll_type="ELBO", global_rows=None, Q=NUM_CONTOUR_QUADRATURE,
-                       exact=False, stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0):
+                       exact=False, stats=None, kzz_jitter=KZZ_JITTER, kxx_jitter=0.0, assembly=None):
     ps = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    loss, mu, varn = ciq_forward(ps, x, y, D, num_data, mll_type, global_rows, Q, exact, stats, kzz_jitter, kxx_jitter)
+    loss, mu, varn = ciq_forward(ps, x, y, D, num_data, mll_type, global_rows, Q, exact, stats, kzz_jitter, kxx_jitter, assembly)
     loss.backward()
     grads = {k: (ps[k].grad if ps[k].grad is not None else torch.zeros_like(ps[k])) for k in ps}
     grads["natural_mat"] = 0.5 * (grads["natural_mat"] + grads["natural_mat"].t())

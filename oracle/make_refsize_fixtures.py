@@ -90,7 +90,6 @@ _REF = {}
 def _reference():
     if not _REF:
         import make_strategy_fixtures as S
-        torch.set_default_dtype(torch.float64)        # like the reference's experiment scripts (exp_script.py:56)
         S._install_stand_ins()
         _REF["S"] = S
         _REF["Kern"] = S._load("RBFKernelDirectionalGrad.py", "_ref_rbf_dirgrad_full").RBFKernelDirectionalGrad
@@ -162,6 +161,10 @@ def reference_step(P, x, y, D, num_data, full_gradient=False, shard_rows=None):
     rows_glob = y.shape[0]
     step = shard_rows or B
     loss, grads, mu_head, varn_head = 0.0, None, None, None
+    # the reference text runs under a float64 default dtype, like the reference's experiment scripts (exp_script.py:56);
+    # the seeded input generators above run under the float32 default (main() restores it): the GPU box regenerates the
+    # same inputs
+    torch.set_default_dtype(torch.float64)
     for r0 in range(0, B, step):
         r1 = min(B, r0 + step)
         t0 = time.time()
@@ -209,7 +212,9 @@ def main(names):
     os.makedirs(OUT, exist_ok=True)
     for name in names:
         inputs, full_gradient, shard_rows = CASES[name]
+        torch.set_default_dtype(torch.float32)
         P, x, y, D, nd = inputs()
+        assert x.dtype == torch.float32 and P["inducing_points"].dtype == torch.float32
         print("%s: M'=%d, B'=%d" % (name, P["variational_mean"].shape[0], y.shape[0]), flush=True)
         t0 = time.time()
         loss, grads, mu_head, varn_head = reference_step(P, x, y, D, nd, full_gradient, shard_rows)
@@ -225,6 +230,7 @@ def main(names):
                 continue
             errs[k] = relmax(go[k], grads[k])
         print("  oracle (fp64) vs reference text, %.1f s: %s" % (time.time() - t0, ", ".join("%s %.1e" % kv for kv in errs.items())), flush=True)
+        torch.set_default_dtype(torch.float32)
         for k, v in errs.items():
             out["oracle_err_" + k] = np.float64(v)
         path = os.path.join(OUT, "reftext_%s_step.npz" % name)

@@ -516,6 +516,29 @@ def ciq_cases(Kern, NatDist):
                  constant=np.float64(c), p=np.int64(p), mean=out.mean.numpy(), variance=torch.diagonal(cov).numpy())
         print("ciq_%d                CiqDirectionalGradVariationalStrategy.forward: mean %s, var min %.3e" % (
             ci, tuple(out.mean.shape), torch.diagonal(cov).min().item()))
+        # the SAME reference forward with ``sqrt_inv_matmul`` = the oracle's contour-integral quadrature + msMINRES (float64,
+        # Q = 15, tolerance 1e-4 -- the restatement of gpytorch's iteration) instead of the exact root: what the HIP CIQ path
+        # should reproduce to the iteration's own tolerance, not only in the limit
+        import dsvgp_oracle as O
+
+        class _Minres(LazyT):
+            def sqrt_inv_matmul(self, rhs):
+                return O.sqrt_inv_matmul(self.t, rhs)
+
+        keep = ref.lazify
+        ref.lazify = lambda t: _Minres(t)
+        try:
+            strat2 = ref.CiqDirectionalGradVariationalStrategy(_Model(kern, c, s), Z, V, NatDist(nv, nm))
+            with torch.no_grad():
+                out2 = strat2.forward(x, strat2.inducing_points, None, None, derivative_directions=D)
+        finally:
+            ref.lazify = keep
+        var2 = torch.diagonal(out2.covariance_matrix)
+        np.savez(os.path.join(OUT, "strategy_ciq_minres_%d.npz" % ci), x=x.numpy(), Z=Z.numpy(), V=V.numpy(), D=D.numpy(),
+                 natural_vec=nv.numpy(), natural_mat=nm.numpy(), lengthscale=np.float64(ell), outputscale=np.float64(s),
+                 constant=np.float64(c), p=np.int64(p), mean=out2.mean.numpy(), variance=var2.numpy())
+        print("ciq_minres_%d         ... with the oracle's msMINRES quadrature: |mean - exact| %.2e, |var - exact| %.2e" % (
+            ci, (out2.mean - out.mean).abs().max().item(), (var2 - torch.diagonal(cov)).abs().max().item()))
 
 
 if __name__ == "__main__":

@@ -386,6 +386,33 @@ def test_ciq_engine_matches_the_reference_strategy_forward(dsvgp, gpu_device):
 
 
 @pytest.mark.gpu
+def test_ciq_engine_matches_the_reference_forward_run_with_msminres(dsvgp, gpu_device):
+    """The same reference forward text with ``sqrt_inv_matmul`` = the oracle's quadrature + msMINRES in float64
+    (tests/golden/strategy_ciq_minres_*.npz; within 6e-6 of the exact-root vectors): the HIP CIQ path (fp32 Lanczos bounds,
+    fp32 msMINRES stopped at the same 1e-4 mean relative update) is held to 1e-3 of the max moment."""
+    import glob, os
+    import numpy as np
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_minres_[0-9].npz")))
+    assert len(paths) >= 2
+    for path in paths:
+        g = np.load(path)
+        t = lambda k: torch.from_numpy(g[k]).float().to(gpu_device)
+        inv_softplus = lambda v: float(np.log(np.expm1(float(v))))
+        P = dict(inducing_points=t("Z"), inducing_directions=t("V"), natural_vec=t("natural_vec"), natural_mat=t("natural_mat"),
+                 constant=torch.tensor([float(g["constant"])], device=gpu_device),
+                 raw_outputscale=torch.tensor(inv_softplus(g["outputscale"]), device=gpu_device),
+                 raw_lengthscale=torch.tensor([[inv_softplus(g["lengthscale"])]], device=gpu_device),
+                 raw_noise=torch.tensor([0.0], device=gpu_device))
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.whitening = "ciq"
+        mu, varn = eng.predict(P, t("x"), t("D"))
+        noise = float(torch.nn.functional.softplus(torch.zeros(())) + 1e-4)
+        e_mu, e_var = relmax(mu, torch.from_numpy(g["mean"])), relmax(varn.double().cpu() - noise, torch.from_numpy(g["variance"]))
+        print("[parity] CIQ reference forward + oracle msMINRES %s: mean %.2e, variance %.2e" % (os.path.basename(path), e_mu, e_var))
+        assert e_mu < 1e-3 and e_var < 1e-3
+
+
+@pytest.mark.gpu
 def test_ciq_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device):
     """HIP CIQ step (quadrature + msMINRES forward and backward, NGD interpolation terms) against autograd through the reference's
     CIQ forward with the exact inverse square root: loss 1e-3, gradients 2e-2 (the stated CIQ tolerance)"""

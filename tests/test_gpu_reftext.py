@@ -13,8 +13,10 @@ Inputs are regenerated on the GPU box from the seeds (oracle/make_refsize_fixtur
 
 Stated tolerances.  The vectors are float64 truth, the fp32 engine is the reference's default precision (fp32 model, fp64
 Cholesky / solves): its distance to fp64 truth is that of the reference's own fp32 run (kernel entries 1e-7, amplified by
-cond(L) ~ 1e2-1e3 on the K_ZZ path).  fp32 engine: loss 2e-6, predictive head 1e-4, gradients 1e-3 of the max entry
-(the measured errors are printed as ``[parity] reftext ...`` lines); fp64 engine: loss 1e-11, head 1e-9, gradients 1e-7."""
+cond(L) ~ 1e2-1e3 on the K_ZZ path).  fp32 engine: loss 2e-6, predictive head 1e-4, gradients 1e-3 of the max entry;
+fp64 engine: loss 1e-12, head 1e-10, gradients 1e-8.  Measured on MI355X (round 3; printed as ``[parity] reftext ...`` lines):
+fp32 loss <= 3.7e-7, head <= 4.6e-5 (C2), gradients <= 2.9e-4 (last rows of L_S-bar at C2; <= 2.4e-6 at C4);
+fp64 loss <= 2e-14, head <= 3.9e-11, gradients <= 9.2e-10 (C2; <= 7.3e-14 at C4)."""
 import os
 import sys
 
@@ -99,4 +101,4 @@ def test_fp64_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, na
                                                nd, "ELBO", fast=fast)
     torch.cuda.synchronize()
     errs = _errors(g, loss, grads, mu, varn, skip=("inducing_directions",) if name == "c3" else ())
-    _check("%s fp64 %s" % (name, "gram" if fast else "per-output"), errs, 1e-11, 1e-9, 1e-7)
+    _check("%s fp64 %s" % (name, "gram" if fast else "per-output"), errs, 1e-12, 1e-10, 1e-8)

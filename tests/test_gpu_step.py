@@ -70,6 +70,11 @@ CASES = [
 ]
 
 
+GRAD_TOL_FP64 = 3e-4      # every gradient of the fp32 HIP step against the FLOAT64 oracle, max-norm relative per parameter
+                          # (observed on MI355X, round 3: <= 1.1e-4 over the 7 geometries x 3 modes; the reference-precision
+                          # oracle's own distance to float64 on the same states: <= 1.1e-4)
+
+
 @pytest.mark.parametrize("N,d,M,p,B", CASES)
 @pytest.mark.parametrize("mll", ["ELBO", "ELBO-general", "PLL"])
 def test_step_matches_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
@@ -94,9 +99,12 @@ def test_step_matches_oracle(dsvgp, gpu_device, N, d, M, p, B, mll):
         gr = g_ref[k]
         if k == "chol_variational_covar":
             assert grads[k].triu(1).abs().max().item() == 0.0
-        e_mixed, e_64 = relmax(grads[k], gr), relmax(grads[k], g64[k])
-        errs[k] = min(e_mixed, e_64)
-        assert min(e_mixed, e_64) < 5e-4, (k, e_mixed, e_64)      # observed (MI355X, round 2): <= 1.1e-4 over the 7 geometries x 3 modes
+        # ONE named oracle: the float64 oracle (the reference-precision oracle's own distance to it is printed beside it as the
+        # yardstick of what an fp32 model can deliver at this state)
+        e_64 = relmax(grads[k], g64[k])
+        errs[k] = e_64
+        errs[k + "(ref-precision oracle)"] = relmax(gr, g64[k])
+        assert e_64 < GRAD_TOL_FP64, (k, e_64)
     _report("step N=%d d=%d M=%d p=%d B=%d %s%s" % (N, d, M, p, B, mll, "" if not fast else " fast"), errs)
 
 
@@ -225,9 +233,12 @@ def test_train_gp_eval_gp_drop_in(dsvgp, gpu_device, capsys):
     _, _, noise = O.constrained(P)
     P64 = {k: v.double() for k, v in P.items()}
     mu64, var64 = O.predictive(P64, test_x.double(), D.double())
-    # trained hyper-parameters give a worse conditioned K_ZZ: the oracle's own fp32-vs-fp64 spread is ~1e-3 here
-    assert min(relmax(means, mu_ref), relmax(means, mu64)) < 2e-3
-    assert min(relmax(variances, var_ref + noise), relmax(variances, var64 + noise.double())) < 2e-3
+    # trained hyper-parameters give a worse conditioned K_ZZ; ONE named oracle (float64), the reference-precision oracle's own
+    # distance to it printed beside the HIP path's
+    errs = {"mean": relmax(means, mu64), "mean(ref-precision oracle)": relmax(mu_ref, mu64),
+            "variance": relmax(variances, var64 + noise.double()), "variance(ref-precision oracle)": relmax(var_ref + noise, var64 + noise.double())}
+    _report("train_gp / eval_gp drop-in, trained state", errs)
+    assert errs["mean"] < 5e-4 and errs["variance"] < 5e-4, errs          # observed 1.3e-4 / 6.6e-5 (ref-precision oracle: 1.2e-4 / 8.2e-5)
 
 
 def test_grad_svgp_drop_in(dsvgp, gpu_device, capsys):
@@ -259,11 +270,15 @@ def test_grad_svgp_drop_in(dsvgp, gpu_device, capsys):
     # oracle; their own spread is ~1e-4 on the loss here
     P64 = {k: v.double() for k, v in P.items()}
     l64, g64, _, _ = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), n)
-    assert min(abs(loss.item() - l_ref.item()), abs(loss.item() - l64.item())) < 2e-4 * abs(l64.item())
+    errs = {"loss": abs(loss.item() - l64.item()) / abs(l64.item()), "loss(ref-precision oracle)": abs(l_ref.item() - l64.item()) / abs(l64.item())}
+    assert errs["loss"] < 2e-5, errs                                                   # observed 2.9e-6
     assert relmax(mu, mu_ref) < 2e-3 and relmax(varn, var_ref) < 2e-3
     for k in ("inducing_points", "variational_mean", "chol_variational_covar", "raw_lengthscale", "raw_noise"):
-        err = min(relmax(grads[k], g_ref[k]), relmax(grads[k], g64[k]))
-        assert err < 1e-2, (k, err, relmax(g_ref[k], g64[k]))
+        errs[k] = relmax(grads[k], g64[k])                        # ONE named oracle: float64
+        errs[k + "(ref-precision oracle)"] = relmax(g_ref[k], g64[k])
+    _report("grad_svgp drop-in, trained state", errs)
+    for k in ("inducing_points", "variational_mean", "chol_variational_covar", "raw_lengthscale", "raw_noise"):
+        assert errs[k] < 4e-3, (k, errs[k])                                            # observed <= 1.2e-3 (ref-precision oracle: 1.0e-3)
     mu_e, var_e = O.predictive(P, test_x, torch.eye(dim).repeat(n_test, 1))
     _, _, noise = O.constrained(P)
     assert relmax(means, mu_e) < 2e-3 and relmax(variances, var_e + noise) < 2e-3

@@ -9,7 +9,7 @@ TAG=${1:-r03}; shift || true
 ARGS=${@:---config c4 --steps 4 --warmup 2 --no-cpu-baseline}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pmc_s
+rm -rf /tmp/pmc_s; mkdir -p /tmp/pmc_s
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES" \
@@ -18,4 +18,4 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_IN
   rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_s/p$i -o run -- python3 $R/bench.py $ARGS > /tmp/pmc_s/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 /tmp/pmc_s/p$i.log; }
 done
 python3 $R/tools/summarize_pmc_step.py /tmp/pmc_s $O/${TAG}_pmc_step_mfma_busy.txt
-rm -rf /tmp/pmc_s
+rm -rf /tmp/pmc_s; mkdir -p /tmp/pmc_s
