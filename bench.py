@@ -303,18 +303,36 @@ def main():
         ach = flops / t_solve / 1e12
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 corrections applied by tools/summarize_pmc.py); only valid for the 1-GPU C4 shape
-        traffic = None
+        traffic = traffic_src = pmc_busy = None
         if world == 1 and args.config == "c4" and eng.trsm_nb >= Mp:
-            for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
-                pmc = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(pmc):
-                    cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm64_kernel<float>")]
-                    if cands:   # the forward solve is the largest launch of that instantiation
-                        traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+            import glob
+            # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+                cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm64_kernel<float>")]
+                if cands:   # the forward solve is the largest launch of that instantiation
+                    traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/" + os.path.basename(pmc)
+                    break
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_mfma_busy.txt")), reverse=True):
+                best = None
+                lines = open(pmc).read().splitlines()
+                for i, ln in enumerate(lines[:-1]):
+                    if ln.startswith("gemm64_kernel<float> grid=") and "mfma_busy=" in lines[i + 1]:
+                        grid = int(ln.split("grid=")[1].split()[0])
+                        vals = dict(kv.split("=") for kv in lines[i + 1].replace(" GHz", "").split() if "=" in kv)
+                        if best is None or grid > best[0]:
+                            best = (grid, vals, float(ln.split("avg_ms=")[1]))
+                if best:
+                    pmc_busy = dict(mfma_busy=float(best[1]["mfma_busy"]), wait_any_per_wave=float(best[1]["wait_any/wave"]),
+                                    wait_inst_any_per_wave=float(best[1]["wait_inst_any/wave"]), clock_ghz=float(best[1]["clk"]),
+                                    profiled_avg_ms=best[2], source="profiles/" + os.path.basename(pmc),
+                                    note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
+                                         "--config c4`, forward-solve launches only; committed profile, not collected by this run")
                     break
         roof = dict(bound="mfma", kernel="gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
-                    traffic=traffic, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
+                    traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
+                    mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
         if rank == 0:
             # what THIS card sustains on the same instruction with no memory traffic (40 ms of back-to-back MFMAs after the
             # timed region): `peak` above is the data-sheet figure at 2.4 GHz, which no MI355X of this pool holds under matrix load

@@ -32,6 +32,7 @@ SIGNATURES = {
     "dsvgp_create": (_i, [C.POINTER(_p)]),
     "dsvgp_destroy": (_i, [_p]),
     "dsvgp_set_stream": (_i, [_p, _p]),
+    "dsvgp_set_deterministic": (_i, [_p, _p, _z]),
     "dsvgp_version": (C.c_char_p, []),
     "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "dsvgp_adam_step_multi_dev": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p]),
     "dsvgp_scale_by_vbar": (_i, [_p, _p, _l, _p, _l, _p, _l, _p, _d]),
     "dsvgp_kl_terms_scaled": (_i, [_p, _p, _p, _l, _i, _d, _i, _p, _d, _p, _p, _p, _l]),
+    "dsvgp_variational_terms": (_i, [_p, _p, _p, _l, _i, _d, _i, _p, _d, _p, _l, _f, _p, _p, _p, _p, _l]),
     "dsvgp_tril_pack_f32": (_i, [_p, _p, _l, _i, _p, _i, _p]),
     "dsvgp_tril_unpack_f32": (_i, [_p, _p, _i, _p, _l, _p, _i]),
     "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),

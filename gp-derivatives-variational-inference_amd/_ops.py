@@ -60,6 +60,13 @@ class Context:
         ctx.bind()
         return ctx
 
+    def set_deterministic(self, scratch):
+        """scratch: a uint8 device tensor (split-K slabs / partial sums go there, no floating-point atomics) or None (atomics)"""
+        if scratch is None:
+            check(lib.dsvgp_set_deterministic(self.h, None, 0), "dsvgp_set_deterministic")
+        else:
+            check(lib.dsvgp_set_deterministic(self.h, _ptr(scratch), scratch.numel() * scratch.element_size()), "dsvgp_set_deterministic")
+
     def bind(self):
         # the library launches on this context's stream without a device guard of its own: make its device current
         # (one process per GPU is the intended use; torch.cuda.set_device(local_rank) has normally done this already)
@@ -437,6 +444,17 @@ def transpose_f64(ctx, src, dst):
 def residual_terms(ctx, mu, y, hyp, global_rows, mu_bar, sums):
     check(lib.dsvgp_residual_terms(ctx.h, _ptr(mu), _ptr(_req(y, f32, "y", 1)), mu.shape[0], _ptr(hyp),
                                    float(global_rows), _ptr(mu_bar), _ptr(sums)), "dsvgp_residual_terms")
+
+
+def variational_terms(ctx, m, LS, num_data, scale, add_kl, hyp, global_rows, G, t1_scale, kl_buf, sums, d_m, d_LS):
+    """trace terms + [scaling by 1 / (noise rows)] + [KL value and gradient] in one pass over (L_S, d_LS = tril(G L_S)); see dsvgp.h"""
+    Mp = m.shape[0]
+    if kl_buf.numel() < 1 + 2 * Mp:
+        raise ValueError("kl_buf needs 1 + 2 M' floats")
+    check(lib.dsvgp_variational_terms(ctx.h, _ptr(m), _ptr(_req(LS, f32, "L_S", 2)), _ld(LS), Mp, float(num_data),
+                                      (1 if scale else 0) | (2 if add_kl else 0), _ptr(hyp), float(global_rows), _ptr(G), _ld(G),
+                                      float(t1_scale), _ptr(kl_buf), _ptr(sums), _ptr(d_m), _ptr(d_LS), _ld(d_LS)),
+          "dsvgp_variational_terms")
 
 
 def trace_terms(ctx, LS, T1, G, n, sums, t1_scale=1.0):

@@ -125,6 +125,11 @@ class ElboEngine:
         self.capture_mode = False
         self.record_events = False      # bench.py: HIP-event timing of the dominant kernel on the launch stream
         self.events = []
+        # True: bitwise reproducible steps -- every split-K product adds its K slices from scratch slabs in a fixed order instead of
+        # meeting in floating-point atomics, scalar sums go through per-workgroup partials (dsvgp_set_deterministic), and the step
+        # runs on ONE stream (the slab serves one stream at a time).  The CPU reference is deterministic for a fixed seed; the
+        # default HIP step is not (order of atomic adds).  Measured cost: DESIGN.md section 5.
+        self.deterministic = os.environ.get("DSVGP_DETERMINISTIC", "0") == "1"
 
     @property
     def trsm_nb(self):
@@ -484,6 +489,18 @@ class ElboEngine:
         self._eval_cache = None
         if fast is None:
             fast = self.elbo_fast
+        if self.deterministic:
+            Mq = params["natural_vec" if "natural_vec" in params else "variational_mean"].shape[0]
+            Mq = max(Mq, params["inducing_points"].shape[0] * (params["inducing_directions"].shape[0] // max(params["inducing_points"].shape[0], 1) + 1))
+            # room for 5 fp64 slabs of an [M', M' + 1] product (the fp32 Gram product's 5-6 slices need half of that)
+            ctx.set_deterministic(self._bytes("det_slab", max(1 << 20, 5 * 8 * Mq * (Mq + 4))))
+            try:
+                return self._loss_and_grads_entry(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast)
+            finally:
+                ctx.set_deterministic(None)
+        return self._loss_and_grads_entry(ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast)
+
+    def _loss_and_grads_entry(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast):
         self._allow_early = False
         self._early_handle = None
         self.variational_grads_global = False
@@ -915,6 +932,8 @@ class ElboEngine:
         side = {}
         side_job = None
         overlap = self.overlap if self.overlap is not None else Mz * (p + 1) >= 2048
+        if self.deterministic:
+            overlap = False                                 # one stream: the split-K scratch serves one stream at a time
         if use_fast and overlap:
             def side_job(c, hyp_):
                 side.update(self._fast_prologue(c, params, hyp_, x, D, rows, background=self.side_background))
@@ -929,7 +948,7 @@ class ElboEngine:
         grads, loss_out, d_hyp = self._alloc_grads(params, PARAM_NAMES)
         dLS, dm = grads["chol_variational_covar"], grads["variational_mean"]
         scal = torch.empty(8, dtype=f32, device=dev)
-        kl_buf = torch.zeros(Mp + 1, dtype=f32, device=dev)
+        kl_buf = torch.zeros(2 * Mp + 1, dtype=f32, device=dev)      # [KL | per-row KL partials | per-row trace partials]
         Lbar = self._get("Lbar", (Mp, Mp), f64)
         Kb32 = self._get("Kb32", (Mp, Bp), f32)
         y = y.contiguous()
@@ -981,6 +1000,7 @@ class ElboEngine:
         zx_done = None
         dense_done, self._dense_done = getattr(self, "_dense_done", None), None
         bwd_overlap = self.bwd_overlap if self.bwd_overlap is not None else (Bp <= 2 * Mp and self.collective is None)
+        bwd_overlap = bwd_overlap and not self.deterministic
         if bwd_overlap and use_fast and dense_done is not None and self._side is not None and not self.capture_mode:
             kws2 = self._bytes("kbwd_ws_zx", _lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p))
             with torch.cuda.stream(self._side):
@@ -1119,17 +1139,16 @@ class ElboEngine:
 
         def variational_part():
             _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
-            _ops.trace_terms(ctx, LS, dLS, G, Mp, sums, 1.0 / vbar2)
-            if coll is not None and not include_kl:
-                sums[2:4].zero_()                            # the trace terms of the GLOBAL G are counted on one rank only
-            _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
             dm.copy_(Ge[Mp])                                 # b = A mu_bar, the data part of m-bar (global under coll)
-            if dev_scale:                                    # tril(G L_S) -> 2 vbar tril(G L_S) [+ KL gradient] in one pass
-                _ops.kl_terms_scaled(ctx, m, LS, num_data, include_kl, hyp, rows, kl_buf, dm, dLS)
-            elif include_kl or coll is not None:             # (global schedule: m-bar / L_S-bar are not reduced again, so
-                _ops.kl_terms(ctx, m, LS, num_data, kl_buf, dm, dLS)            # every rank adds the KL gradient itself)
-                if not include_kl:
-                    kl_buf[0:1].zero_()                      # ... and one rank the KL value
+            # ONE pass over (L_S, tril(G L_S)): trace terms |L_S^T A|_F^2 and tr G, 2 vbar tril(G L_S) where the product ran
+            # unscaled (one rank: dev_scale), KL value + gradient.  Global-Gram schedule: m-bar / L_S-bar are not reduced again,
+            # so every rank adds the KL gradient itself ...
+            add_kl = include_kl or coll is not None
+            _ops.variational_terms(ctx, m, LS, num_data, dev_scale, add_kl, hyp, rows, G, 1.0 / vbar2, kl_buf, sums, dm, dLS)
+            if coll is not None and not include_kl:
+                sums[2:4].zero_()                            # ... the trace terms of the GLOBAL G are counted on one rank only
+                kl_buf[0:1].zero_()                          # ... and so is the KL value
+            _ops.elbo_fast_finalize(ctx, sums, hyp, B, pd, rows, scal)
             if coll is None:
                 self._variational_grads_final()
 
@@ -1145,13 +1164,14 @@ class ElboEngine:
                 _ops.gemm_lib_f32(ctx, 0, Qe32, A32e, Kb32, alpha=vbar2)
             else:
                 _ops.gemm(ctx, _lib.K_PADDED, Qe32, A32e, Kb32, alpha=vbar2)
-            if self._side is not None and not self.capture_mode:        # K_ZX-bar is final: its kernel backward may start (side stream)
+            if self._side is not None and not self.capture_mode and not self.deterministic:   # K_ZX-bar is final: its kernel backward may start (side stream)
                 self._dense_done = torch.cuda.Event()
                 self._dense_done.record(torch.cuda.current_stream(dev))
             return Qe64
 
         var_done = None
-        if coll is None and self.var_overlap and self.collective is None and self._side is not None and not self.capture_mode:
+        if coll is None and self.var_overlap and self.collective is None and self._side is not None and not self.capture_mode \
+                and not self.deterministic:
             # one GPU: the L_S / m gradients (the few-tile fp32 product G L_S, trace / KL / loss kernels) need only G; they run on
             # the side stream next to the Q' solve and the dense product, joined before L-bar
             main = torch.cuda.current_stream(dev)
@@ -1168,7 +1188,7 @@ class ElboEngine:
         elif coll is None:
             variational_part()
             Qe64 = solve_part()
-        elif self.var_overlap and self._side is not None and not self.capture_mode:
+        elif self.var_overlap and self._side is not None and not self.capture_mode and not self.deterministic:
             # global-Gram schedule: the side stream waits for the summed [G ; b^T], mirrors it and forms the L_S / m gradients
             # (G L_S, trace / KL / loss kernels) while the main stream goes on with L-bar and the Cholesky backward
             Qe64 = solve_part()

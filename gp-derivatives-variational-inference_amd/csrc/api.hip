@@ -22,6 +22,17 @@ extern "C" int dsvgp_destroy(dsvgp_ctx* ctx) {
     delete ctx;
     return 0;
 }
+// Deterministic mode: with a scratch buffer set, every split-K product stores its K slices to slabs in `scratch` and adds them in a
+// fixed order (no floating-point atomics), the scalar reductions of the step go through per-workgroup partials: results are
+// bitwise reproducible run to run.  scratch == NULL switches back to atomics.  The scratch is caller-owned, used by the launches
+// queued on the context's CURRENT stream only (one stream at a time), and sized by the caller: a product whose slices do not
+// fit uses fewer, longer slices (no split at all below two).
+extern "C" int dsvgp_set_deterministic(dsvgp_ctx* ctx, void* scratch, size_t bytes) {
+    if (!ctx || (scratch && bytes < 4096) || ((uintptr_t)scratch % 16)) return DSVGP_EINVAL;
+    ctx->det_slab = scratch;
+    ctx->det_bytes = scratch ? bytes : 0;
+    return 0;
+}
 extern "C" int dsvgp_set_stream(dsvgp_ctx* ctx, void* stream) {
     if (!ctx) return DSVGP_EINVAL;
     ctx->stream = (hipStream_t)stream;
@@ -54,6 +65,7 @@ extern "C" int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N
     g.M = M; g.N = N; g.K = K; g.A = A; g.B = B; g.Cin = Cin; g.C = C; g.C32 = C32; g.kscale = kscale;
     g.lda = lda; g.ldb = ldb; g.ldcin = ldcin; g.ldc = ldc; g.ldc32 = ldc32;
     g.alpha = alpha; g.beta = beta; g.flags = flags; g.batch = 1; g.splitk = 1;
+    g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
     // split-K / tril zero-fill policy lives in launch_gemm
     return launch_gemm(ctx->stream, is_double, g);
 }
@@ -171,6 +183,7 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
             g.Cin = Bi; g.ldcin = ldb; g.beta = 1.0; g.alpha = -1.0;
             if (!b_is_double) g.flags |= DSVGP_GEMM_CIN_IS_FLOAT;
             g.C = T; g.ldc = nrhs;
+            g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
             int rc = launch_gemm(st, 1, g);
             if (rc) return rc;
             rhs = T; ldrhs = nrhs; rhs_float = false;
@@ -193,6 +206,7 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
             // target so that it may split K -- few tiles, each a chain of n / 16 dependent stages -- and convert afterwards
             f.C = T; f.ldc = nrhs;
         }
+        f.slab = ctx->det_slab; f.slab_bytes = ctx->det_bytes;
         int rc = launch_gemm(st, 1, f);
         if (rc) return rc;
     }

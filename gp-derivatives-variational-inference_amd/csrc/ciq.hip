@@ -443,6 +443,7 @@ extern "C" int dsvgp_ciq_solve(dsvgp_ctx* ctx, const float* K, int64_t ldk, cons
         GemmArgs g{};
         g.M = t; g.N = n; g.K = n; g.A = qcur; g.lda = n; g.B = K; g.ldb = ldk; g.C = Vt; g.ldc = n;
         g.alpha = 1.0; g.beta = 0.0; g.flags = 0; g.batch = 1; g.splitk = 1;
+        g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
         int rc = launch_gemm(st, 0, g);
         if (rc) return rc;
         hipLaunchKernelGGL(ciq_lanczos_kernel, dim3(t), dim3(256), sizeof(float) * n, st, Vt, qcur,

@@ -9,6 +9,10 @@
 struct dsvgp_ctx {
     hipStream_t stream = nullptr;
     void* blas = nullptr;  // rocblas_handle (opaque here so only potrf.hip needs the rocBLAS headers)
+    // deterministic mode (dsvgp_set_deterministic): caller-owned scratch for split-K slabs / per-workgroup partial sums;
+    // null = atomics allowed (run-order dependent rounding of sums)
+    void* det_slab = nullptr;
+    size_t det_bytes = 0;
 };
 
 #define DSVGP_LAUNCH_CHECK()                                  \
@@ -33,7 +37,21 @@ struct GemmArgs {
     int batch;
     int splitk;            // >1: epilogue is atomicAdd(alpha*acc) into a caller-initialised C
     int tiles_m, tiles_n, supertile, bn, chunk, bm;   // filled by launch_gemm (bn / bm = output tile width / height, 128 or 64)
+    // deterministic mode: split-K slices store their partial tiles to this scratch ([slice][M][N], packed) and a
+    // fixed-order pass adds them (launch_splitk_reduce) instead of meeting in atomics; null = atomics
+    void* slab; size_t slab_bytes;
 };
+// how many split-K slices fit the slab (>= 2) or 1 (= do not split); esz = bytes per element
+static inline int slab_slices(const GemmArgs& g, int want, size_t esz) {
+    if (!g.slab || want <= 1) return want;
+    const size_t per = (size_t)g.M * (size_t)g.N * esz;
+    const size_t fit = per ? g.slab_bytes / per : 0;
+    const int sk = (int)(fit < (size_t)want ? fit : (size_t)want);
+    return sk >= 2 ? sk : 1;
+}
+// C (+ C32) = [C +] sum_s slab[s] in the fixed order s = 0, 1, ... (out_lower: n > m defined as zero) -- gemm.hip
+int launch_splitk_reduce(hipStream_t st, int is_double, const void* slab, int nslices, int M, int N, void* C, int64_t ldc,
+                         float* C32, int64_t ldc32, int out_lower, int accumulate);
 constexpr int DSVGP_GEMM_KEEP_UPPER = 1 << 20;   // internal flag (with OUT_LOWER): do not touch m < n
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
 // zero an M x N block (element size esz) with leading dimension ld: linear memset for contiguous rows, a fill kernel of our

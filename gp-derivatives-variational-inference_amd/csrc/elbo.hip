@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void likelihood_kernel(const float* __restrict
                                                          const float* __restrict__ y, int ncols, int p,
                                                          const float* __restrict__ hyp, int mll_type, float inv_rows,
                                                          float* __restrict__ mu_bar, float* __restrict__ var_bar,
-                                                         float* __restrict__ varn_out, float* __restrict__ scal) {
+                                                         float* __restrict__ varn_out, float* __restrict__ scal, float* __restrict__ partials) {
     __shared__ float red[5][4];
     const float ell = hyp[0], s = hyp[1], noise = hyp[2];
     const float LOG2PI = 1.8378770664093453f;
@@ -135,8 +135,17 @@ __global__ __launch_bounds__(256) void likelihood_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x < 5) {
         const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        atomicAdd(&scal[threadIdx.x], v);
+        if (partials) partials[blockIdx.x * 8 + threadIdx.x] = v;     // deterministic mode: summed in block order afterwards
+        else atomicAdd(&scal[threadIdx.x], v);
     }
+}
+// out[q] = sum over blocks of partials[b][q] in the fixed order b = 0, 1, ... (q < nq <= 8; one wave)
+__global__ void partials_reduce_kernel(const float* __restrict__ partials, int nblocks, int nq, float* __restrict__ out) {
+    const int q = threadIdx.x;
+    if (q >= nq) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += partials[b * 8 + q];
+    out[q] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void abar_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ U,
@@ -171,33 +180,6 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ A
     if (threadIdx.x == 0) out[i] += red[0] + red[1] + red[2] + red[3];
 }
 
-// one block per row of L_S: KL pieces + gradient; rowsum[i] = 0.5*(m_i^2 + sum_{j<=i} L_ij^2 - 1 - log L_ii^2)
-__global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ m, const float* __restrict__ LS, int64_t ldls,
-                                                 int Mp, float inv_nd, float* __restrict__ rowsum,
-                                                 float* __restrict__ d_m, float* __restrict__ dLS, int64_t lddls) {
-    __shared__ float red[4];
-    const int i = blockIdx.x;
-    float s = 0.f;
-    for (int j = threadIdx.x; j < Mp; j += 256) {
-        float g = 0.f;
-        if (j <= i) {
-            const float l = LS[(int64_t)i * ldls + j];
-            s = fmaf(l, l, s);
-            g = (j == i) ? (l - 1.f / l) * inv_nd : l * inv_nd;
-            dLS[(int64_t)i * lddls + j] += g;
-        } else {
-            dLS[(int64_t)i * lddls + j] = 0.f;    // masked upper triangle carries no gradient
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float lii = LS[(int64_t)i * ldls + i], mi = m[i];
-        rowsum[i] = 0.5f * (mi * mi + red[0] + red[1] + red[2] + red[3] - 1.f - logf(lii * lii));
-        d_m[i] += mi * inv_nd;
-    }
-}
 __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
     __shared__ double red[256];
     double s = 0;
@@ -309,7 +291,6 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
 //    update is skipped while *guard != 0 (the Cholesky status word: a failed factorisation must not touch the parameters).
 //  scale3_kernel: x_k *= 1 / (noise rows) = 2 vbar for up to three arrays (Z-bar, V-bar, d_hyp[0..1] of the ELBO fast path,
 //    whose K_ZX-bar / L-bar products run unscaled when the noise is not known on the host).
-//  kl_scaled_kernel: like kl_kernel, with d_LS(lower) first multiplied by 2 vbar and the KL part optional.
 __global__ __launch_bounds__(256) void adam_multi_dev_kernel(const AdamTable t, const float* __restrict__ hp, float b1, float b2,
                                                              float eps, const int* __restrict__ guard) {
     if (guard && *guard != 0) return;
@@ -345,38 +326,119 @@ __global__ __launch_bounds__(256) void scale3_kernel(float* __restrict__ x0, int
         else x2[i - n0 - n1] *= s;
     }
 }
-__global__ __launch_bounds__(256) void kl_scaled_kernel(const float* __restrict__ m, const float* __restrict__ LS, int64_t ldls,
-                                                        int Mp, float inv_nd, int add_kl, const float* __restrict__ hyp,
-                                                        float inv_rows, float* __restrict__ rowsum, float* __restrict__ d_m,
-                                                        float* __restrict__ dLS, int64_t lddls) {
-    __shared__ float red[4];
-    const int i = blockIdx.x;
-    const float sc = inv_rows / hyp[2];
-    float s = 0.f;
-    for (int j = threadIdx.x; j < Mp; j += 256) {
-        if (j <= i) {
-            const float l = LS[(int64_t)i * ldls + j];
-            s = fmaf(l, l, s);
-            const float g = add_kl ? ((j == i) ? (l - 1.f / l) * inv_nd : l * inv_nd) : 0.f;
-            dLS[(int64_t)i * lddls + j] = fmaf(dLS[(int64_t)i * lddls + j], sc, g);
+
+// ---- one pass over the lower triangles of L_S and L_S-bar (round 3) ---------------------------------------------------
+// Replaces kl_kernel / kl_scaled_kernel / trace_kernel (one workgroup per row, one scalar load per thread: 0.6 TB/s, 147 +
+// 92 us at M' = 3000) by ONE WAVE per row with 16-byte loads / stores where the rows allow, rows dealt cyclically to the
+// waves (the triangular row lengths balance), every reduction finished inside the wave (no LDS, no barrier) and NO atomics:
+// per-row partial sums go to caller scratch and a one-workgroup pass adds them in a fixed order (run-to-run identical).
+//   flags bit 0 (SCALE): dLS <- dLS * inv_rows / noise before the KL gradient is added (the fast path's unscaled G L_S)
+//         bit 1 (KL):    rowkl[i] = 1/2 (m_i^2 + sum_{j<=i} L_ij^2 - 1 - log L_ii^2), dLS += dKL/dL_S / num_data, d_m += m / num_data
+//         bit 2 (TRACE): rowtr[i] = sum_{j<=i} L_ij T_ij with T = dLS as it is READ (before scaling)
+// The strict upper triangle of dLS is written as zero (the masked part of the parameter carries no gradient).
+template <bool VEC>
+__global__ __launch_bounds__(256) void ls_rows_kernel(const float* __restrict__ m, const float* __restrict__ LS, int64_t ldls, int Mp,
+                                                      float inv_nd, int flags, const float* __restrict__ hyp, float inv_rows,
+                                                      float* __restrict__ rowkl, float* __restrict__ rowtr,
+                                                      float* __restrict__ d_m, float* __restrict__ dLS, int64_t lddls) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const bool scale = flags & 1, kl = flags & 2, trace = flags & 4;
+    const float sc = scale ? inv_rows / hyp[2] : 1.f;
+    for (int i = wave; i < Mp; i += nwaves) {
+        const float* __restrict__ l = LS + (int64_t)i * ldls;
+        float* __restrict__ t = dLS + (int64_t)i * lddls;
+        float sll = 0.f, slt = 0.f;
+        if constexpr (VEC) {
+            for (int j = lane * 4; j < Mp; j += 256) {          // (Mp % 4 == 0 on this path)
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j <= i) {
+                    const float4 lv = *(const float4*)(l + j);
+                    const float4 tv = *(const float4*)(t + j);
+                    const float la[4] = {lv.x, lv.y, lv.z, lv.w}, ta[4] = {tv.x, tv.y, tv.z, tv.w};
+                    float oa[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool in = j + c <= i;
+                        const float lc = in ? la[c] : 0.f;
+                        sll = fmaf(lc, lc, sll);
+                        slt = fmaf(lc, in ? ta[c] : 0.f, slt);
+                        const float g = kl ? ((j + c == i) ? (lc - 1.f / lc) * inv_nd : lc * inv_nd) : 0.f;
+                        oa[c] = in ? fmaf(ta[c], sc, g) : 0.f;
+                    }
+                    o = make_float4(oa[0], oa[1], oa[2], oa[3]);
+                }
+                *(float4*)(t + j) = o;
+            }
         } else {
-            dLS[(int64_t)i * lddls + j] = 0.f;    // masked upper triangle carries no gradient
+            for (int j = lane; j < Mp; j += 64) {
+                float o = 0.f;
+                if (j <= i) {
+                    const float lc = l[j], tc = t[j];
+                    sll = fmaf(lc, lc, sll);
+                    slt = fmaf(lc, tc, slt);
+                    const float g = kl ? ((j == i) ? (lc - 1.f / lc) * inv_nd : lc * inv_nd) : 0.f;
+                    o = fmaf(tc, sc, g);
+                }
+                t[j] = o;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { sll += __shfl_down(sll, off); slt += __shfl_down(slt, off); }
+        if (lane == 0) {
+            if (kl) {
+                const float lii = l[i], mi = m[i];
+                rowkl[i] = 0.5f * (mi * mi + sll - 1.f - logf(lii * lii));
+                d_m[i] += mi * inv_nd;
+            } else if (rowkl) {
+                rowkl[i] = 0.f;
+            }
+            if (trace) rowtr[i] = slt;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float lii = LS[(int64_t)i * ldls + i], mi = m[i];
-        rowsum[i] = add_kl ? 0.5f * (mi * mi + red[0] + red[1] + red[2] + red[3] - 1.f - logf(lii * lii)) : 0.f;
-        if (add_kl) d_m[i] += mi * inv_nd;
+}
+// fixed-order sums of the per-row partials (double accumulation): out_kl[0] = sum rowkl; sums[2] = t1_scale sum rowtr,
+// sums[3] = trace(G) (either group optional)
+__global__ __launch_bounds__(256) void ls_rows_reduce_kernel(const float* __restrict__ rowkl, const float* __restrict__ rowtr,
+                                                             const float* __restrict__ G, int64_t ldg, int n, float t1_scale,
+                                                             float* __restrict__ out_kl, float* __restrict__ sums) {
+    __shared__ double red[3][256];
+    double a = 0, b = 0, c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (rowkl) a += rowkl[i];
+        if (rowtr) { b += rowtr[i]; c += G[(int64_t)i * ldg + i]; }
     }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (rowkl && out_kl) out_kl[0] = (float)red[0][0];
+        if (rowtr && sums) { sums[2] = t1_scale * (float)red[1][0]; sums[3] = (float)red[2][0]; }
+    }
+}
+static int launch_ls_rows(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, float inv_nd, int flags,
+                          const float* hyp, float inv_rows, float* rowkl, float* rowtr, float* d_m, float* dLS, int64_t lddls) {
+    const bool vec = Mp % 4 == 0 && ldls % 4 == 0 && lddls % 4 == 0 && ((uintptr_t)LS % 16 == 0) && ((uintptr_t)dLS % 16 == 0);
+    int blocks = cdiv(Mp, 4);
+    if (blocks > 2048) blocks = 2048;
+    if (vec) hipLaunchKernelGGL(ls_rows_kernel<true>, dim3(blocks), dim3(256), 0, st, m, LS, ldls, Mp, inv_nd, flags, hyp, inv_rows,
+                                rowkl, rowtr, d_m, dLS, lddls);
+    else hipLaunchKernelGGL(ls_rows_kernel<false>, dim3(blocks), dim3(256), 0, st, m, LS, ldls, Mp, inv_nd, flags, hyp, inv_rows,
+                            rowkl, rowtr, d_m, dLS, lddls);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---- ELBO fast path (constant dLoss/dvar): residuals, traces, scalar assembly -----------------------
 __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ mu, const float* __restrict__ y,
                                                        int ncols, const float* __restrict__ hyp, float inv_rows,
-                                                       float* __restrict__ mu_bar, float* __restrict__ sums) {
+                                                       float* __restrict__ mu_bar, float* __restrict__ sums,
+                                                       float* __restrict__ partials) {
     __shared__ float red[2][4];
     const float noise = hyp[2];
     float a0 = 0.f, a1 = 0.f;
@@ -391,7 +453,11 @@ __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; }
     __syncthreads();
-    if (threadIdx.x < 2) atomicAdd(&sums[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 2) {
+        const float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (partials) partials[blockIdx.x * 8 + threadIdx.x] = v;     // deterministic mode
+        else atomicAdd(&sums[threadIdx.x], v);
+    }
 }
 // sums[2] += sum_{i>=j} LS_ij T1_ij  (= |L_S^T A|_F^2) ; sums[3] += trace(G)
 __global__ __launch_bounds__(256) void trace_kernel(const float* __restrict__ LS, int64_t ldls,
@@ -552,9 +618,14 @@ extern "C" int dsvgp_likelihood_terms(dsvgp_ctx* ctx, const float* mu, const flo
     if (ncols == 0) return 0;
     int blocks = cdiv(ncols, 256);
     if (blocks > 512) blocks = 512;
+    float* partials = (ctx->det_slab && ctx->det_bytes >= (size_t)blocks * 8 * sizeof(float)) ? (float*)ctx->det_slab : nullptr;
     hipLaunchKernelGGL(likelihood_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mu, var, y, ncols, p, hyp, mll_type,
-                       (float)(1.0 / global_rows), mu_bar, var_bar, varn_out, out_scalars);
+                       (float)(1.0 / global_rows), mu_bar, var_bar, varn_out, out_scalars, partials);
     DSVGP_LAUNCH_CHECK();
+    if (partials) {
+        hipLaunchKernelGGL(partials_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)partials, blocks, 5, out_scalars);
+        DSVGP_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -581,10 +652,10 @@ extern "C" int dsvgp_kl_terms(dsvgp_ctx* ctx, const float* m, const float* LS, i
                               float* kl_out, float* d_m, float* d_LS, int64_t lddls) {
     if (!ctx || !m || !LS || !kl_out || !d_m || !d_LS || Mp <= 0 || num_data <= 0) return DSVGP_EINVAL;
     // kl_out must have room for 1 + Mp floats: [0] = KL, [1..Mp] = per-row scratch
-    hipLaunchKernelGGL(kl_kernel, dim3(Mp), dim3(256), 0, ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data),
-                       kl_out + 1, d_m, d_LS, lddls);
-    DSVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), Mp, kl_out);
+    int rc = launch_ls_rows(ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data), 2, nullptr, 0.f, kl_out + 1, nullptr, d_m, d_LS, lddls);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), (const float*)nullptr,
+                       (const float*)nullptr, (int64_t)0, Mp, 0.f, kl_out, (float*)nullptr);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -680,9 +751,14 @@ extern "C" int dsvgp_residual_terms(dsvgp_ctx* ctx, const float* mu, const float
     if (ncols == 0) return 0;
     int blocks = cdiv(ncols, 256);
     if (blocks > 512) blocks = 512;
+    float* partials = (ctx->det_slab && ctx->det_bytes >= (size_t)blocks * 8 * sizeof(float)) ? (float*)ctx->det_slab : nullptr;
     hipLaunchKernelGGL(residual_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mu, y, ncols, hyp,
-                       (float)(1.0 / global_rows), mu_bar, sums);
+                       (float)(1.0 / global_rows), mu_bar, sums, partials);
     DSVGP_LAUNCH_CHECK();
+    if (partials) {
+        hipLaunchKernelGGL(partials_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)partials, blocks, 2, sums);
+        DSVGP_LAUNCH_CHECK();
+    }
     return 0;
 }
 extern "C" int dsvgp_trace_terms(dsvgp_ctx* ctx, const float* LS, int64_t ldls, const float* T1, int64_t ldt,
@@ -784,10 +860,30 @@ extern "C" int dsvgp_kl_terms_scaled(dsvgp_ctx* ctx, const float* m, const float
                                      int add_kl, const float* hyp, double global_rows, float* kl_out, float* d_m, float* d_LS,
                                      int64_t lddls) {
     if (!ctx || !m || !LS || !kl_out || !d_m || !d_LS || !hyp || Mp <= 0 || num_data <= 0 || global_rows <= 0) return DSVGP_EINVAL;
-    hipLaunchKernelGGL(kl_scaled_kernel, dim3(Mp), dim3(256), 0, ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data),
-                       add_kl ? 1 : 0, hyp, (float)(1.0 / global_rows), kl_out + 1, d_m, d_LS, lddls);
+    int rc = launch_ls_rows(ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data), 1 | (add_kl ? 2 : 0), hyp, (float)(1.0 / global_rows),
+                            kl_out + 1, nullptr, d_m, d_LS, lddls);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), (const float*)nullptr,
+                       (const float*)nullptr, (int64_t)0, Mp, 0.f, kl_out, (float*)nullptr);
     DSVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), Mp, kl_out);
+    return 0;
+}
+// The variational block of the ELBO fast path in ONE pass over (L_S, T = tril(G L_S)) -- trace terms, optional scaling by
+// 2 vbar = 1 / (noise rows), optional KL value + gradient (flags as ls_rows_kernel: 1 scale, 2 KL; the trace terms always):
+//   sums[2] = t1_scale * sum_{i>=j} L_S,ij T_ij (= |L_S^T A|_F^2), sums[3] = trace(G), kl_out[0] = KL (0 without the KL flag),
+//   d_LS <- [scale] T + dKL/dL_S / num_data, d_m += m / num_data.   kl_out: 1 + 2 Mp floats (value + per-row scratch).
+// No atomics: per-row partials + a fixed-order reduction (bitwise reproducible).
+extern "C" int dsvgp_variational_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data,
+                                       int flags, const float* hyp, double global_rows, const float* G, int64_t ldg,
+                                       float t1_scale, float* kl_out, float* sums, float* d_m, float* d_LS, int64_t lddls) {
+    if (!ctx || !m || !LS || !kl_out || !sums || !d_m || !d_LS || !G || Mp <= 0 || num_data <= 0 || global_rows <= 0 ||
+        ((flags & 1) && !hyp) || (flags & ~3))
+        return DSVGP_EINVAL;
+    int rc = launch_ls_rows(ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data), flags | 4, hyp, (float)(1.0 / global_rows),
+                            kl_out + 1, kl_out + 1 + Mp, d_m, d_LS, lddls);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1),
+                       (const float*)(kl_out + 1 + Mp), G, ldg, Mp, t1_scale, kl_out, sums);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

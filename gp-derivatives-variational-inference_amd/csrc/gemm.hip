@@ -392,7 +392,9 @@ __global__ __launch_bounds__(NTH, GEMM_MINW ? GEMM_MINW : NTH / 128) void gemm_k
                 if (m >= Mdim || n >= g.N) continue;
                 TC v = alpha * acc[i][j][r];
                 if (g.splitk > 1) {
-                    if (!(out_lower && n > m)) atomicAdd(&C[(int64_t)m * g.ldc + n], v);
+                    if (out_lower && n > m) continue;
+                    if (g.slab) ((TC*)g.slab)[((int64_t)sp * g.M + m) * g.N + n] = v;     // deterministic mode: slabs, summed in order afterwards
+                    else atomicAdd(&C[(int64_t)m * g.ldc + n], v);
                     continue;
                 }
                 if (g.Cin && beta != TC(0)) {
@@ -569,6 +571,8 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     if (!g.C && !g.C32) return DSVGP_EINVAL;
     // (a result wanted in fp32 AND fp64 may split too: the slices meet in the fp64 copy, a conversion pass writes the other)
     float* cvt32 = nullptr;
+    bool det_acc = g.splitk > 1;                                     // (caller-requested split-K: the slices add onto the caller's C)
+    if (a.batch > 1) a.slab = nullptr;                               // (batched products never split)
     if (a.batch == 1 && a.splitk == 1 && (!a.C32 || (is_double && a.C && !a.Cin)) && (!a.Cin || inplace_acc) && a.K >= sk_min_k) {
         const int active = out_lower ? (a.tiles_m * (a.tiles_m + 1)) / 2 * (a.bm / a.bn) : a.tiles_m * a.tiles_n;
         // split factor: minimise (rounds over the 256 CUs -- two resident workgroups share a CU's matrix pipe, so the
@@ -585,16 +589,19 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
                 if (t < best * 0.999) { best = t; sk = c; }
             }
         }
+        sk = slab_slices(a, sk, esz);                                // deterministic mode: as many slices as the slab holds
         if (sk > 1) {
             a.splitk = sk;
             if (a.C32) { cvt32 = a.C32; a.C32 = nullptr; }
-            if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; }      // atomics accumulate onto the existing C
-            else {
+            if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; det_acc = true; }      // the slices accumulate onto the existing C
+            else if (!a.slab) {
                 hipError_t e = zero_block(a.C, esz, a.ldc, a.M, a.N, st);
                 if (e != hipSuccess) return 1000 + (int)e;
             }
         }
     }
+    if (a.splitk == 1) a.slab = nullptr;                             // (caller-requested split-K keeps its slab)
+    else if (a.slab && slab_slices(a, a.splitk, esz) != a.splitk) return DSVGP_ENOSPACE;
     if (out_lower && !keep_upper && a.splitk == 1 && a.batch == 1 && g.Cin != g.C) {
         // supertiles strictly above the diagonal are never visited: define them as zero up front
         hipError_t e = a.C ? zero_block(a.C, esz, a.ldc, a.M, a.N, st) : hipSuccess;
@@ -619,8 +626,11 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
         a.chunk = cs;
         grid = dim3(cdiv(cdiv(total, (int64_t)cs), 8) * 8 * cs, 1, 1);
     }
+    const bool slabbed = a.slab && a.splitk > 1;
     if (is_double) {
-        const int rc = (g.flags & DSVGP_GEMM_B_IS_FLOAT) ? dispatch<double, float>(st, a, grid) : dispatch<double, double>(st, a, grid);
+        int rc = (g.flags & DSVGP_GEMM_B_IS_FLOAT) ? dispatch<double, float>(st, a, grid) : dispatch<double, double>(st, a, grid);
+        if (rc == 0 && slabbed)
+            return launch_splitk_reduce(st, 1, a.slab, a.splitk, a.M, a.N, a.C, a.ldc, cvt32, g.ldc32, out_lower ? (keep_upper ? 2 : 1) : 0, det_acc);
         if (rc == 0 && cvt32) {
             launch_cvt_f64_f32(st, (const double*)a.C, a.ldc, cvt32, g.ldc32, a.M, a.N);
             DSVGP_LAUNCH_CHECK();
@@ -628,7 +638,44 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
         return rc;
     }
     if (g.flags & (DSVGP_GEMM_B_IS_FLOAT | DSVGP_GEMM_CIN_IS_FLOAT)) return DSVGP_EINVAL;
-    return dispatch<float, float>(st, a, grid);
+    const int rc = dispatch<float, float>(st, a, grid);
+    if (rc == 0 && slabbed)
+        return launch_splitk_reduce(st, 0, a.slab, a.splitk, a.M, a.N, a.C, a.ldc, nullptr, 0, out_lower ? (keep_upper ? 2 : 1) : 0, det_acc);
+    return rc;
+}
+
+// ---- deterministic mode: the fixed-order sum of split-K slabs -----------------------------------------------------
+// out_mode: 0 dense; 1 lower (n > m written as zero); 2 lower, n > m left untouched (KEEP_UPPER)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const T* __restrict__ slab, int ns, int M, int N, T* __restrict__ C,
+                                                            int64_t ldc, float* __restrict__ C32, int64_t ldc32, int out_mode,
+                                                            int accumulate) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
+        T v = T(0);
+        if (out_mode && n > m) {
+            if (out_mode == 2) continue;
+        } else {
+            if (accumulate && C) v = C[(int64_t)m * ldc + n];
+            for (int s = 0; s < ns; ++s) v += slab[(int64_t)s * total + e];
+        }
+        if (C) C[(int64_t)m * ldc + n] = v;
+        if (C32) C32[(int64_t)m * ldc32 + n] = (float)v;
+    }
+}
+int launch_splitk_reduce(hipStream_t st, int is_double, const void* slab, int nslices, int M, int N, void* C, int64_t ldc,
+                         float* C32, int64_t ldc32, int out_lower, int accumulate) {
+    const int64_t tot = (int64_t)M * N;
+    const int blocks = (int)((tot + 1023) / 1024 < 8192 ? (tot + 1023) / 1024 : 8192);
+    if (is_double)
+        hipLaunchKernelGGL(splitk_reduce_kernel<double>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, (const double*)slab, nslices,
+                           M, N, (double*)C, ldc, C32, ldc32, out_lower, accumulate);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, (const float*)slab, nslices,
+                           M, N, (float*)C, ldc, C32, ldc32, out_lower, accumulate);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
 }
 
 // Blocked inverse of the nb x nb diagonal blocks of L by recursive doubling:

@@ -65,6 +65,7 @@ struct G32 {
     int64_t lda, ldb, ldc;
     int M, N, K, tiles_m, tiles_n, flags, splitk, kslice, ntiles;
     float alpha;
+    float* slab;             // deterministic mode: K slice s stores its tiles to slab[s][M][N] (summed in a fixed order afterwards)
 };
 
 template <int BK, bool KC>
@@ -161,11 +162,12 @@ __device__ __forceinline__ bool pick_unit(const G32& g, int& m0, int& n0, int& k
 }
 
 // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (c & 3) + 8 (c >> 2) + 4 (lane >> 5)
-__device__ __forceinline__ void store_tile(const G32& g, const acc16 (&acc)[2][2], int m0, int n0, int wr, int wc, int h, int r) {
+__device__ __forceinline__ void store_tile(const G32& g, const acc16 (&acc)[2][2], int m0, int n0, int wr, int wc, int h, int r,
+                                           float* Cb, int64_t ldcb, bool atomic_) {
 #ifdef G32_ABL_NOATOMIC          // (timing ablation only: wrong results under split-K)
     const bool atomic = false, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
 #else
-    const bool atomic = g.splitk > 1, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
+    const bool atomic = atomic_, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
 #endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -178,11 +180,17 @@ __device__ __forceinline__ void store_tile(const G32& g, const acc16 (&acc)[2][2
                 if (m >= g.M || n >= g.N) continue;
                 if (out_lower && n > m) continue;                // (the caller zero-fills m < n)
                 const float v = g.alpha * acc[i][j][c];
-                float* dst = g.C + (int64_t)m * g.ldc + n;
+                float* dst = Cb + (int64_t)m * ldcb + n;
                 if (atomic) atomicAdd(dst, v);
                 else *dst = v;
             }
 }
+// where this workgroup's tile goes: the output itself (atomics when K is split) or, in deterministic mode, its K slice's slab
+#define G32_DEST()                                                                                     \
+    const int slice_ = g.kslice > 0 ? kbeg / g.kslice : 0;                                             \
+    float* const Cb = g.slab ? g.slab + (int64_t)slice_ * g.M * g.N : g.C;                            \
+    const int64_t ldcb = g.slab ? (int64_t)g.N : g.ldc;                                                \
+    const bool atomic_ = g.splitk > 1 && !g.slab
 
 template <int BK, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, G32_MINW) void gemm32_kernel(const G32 g) {
@@ -283,7 +291,8 @@ __global__ __launch_bounds__(256, G32_MINW) void gemm32_kernel(const G32 g) {
         }
     }
 
-    store_tile(g, acc, m0, n0, wr, wc, h, r);
+    G32_DEST();
+    store_tile(g, acc, m0, n0, wr, wc, h, r, Cb, ldcb, atomic_);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -475,11 +484,12 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
         }
 #endif
     }
+    G32_DEST();
     if constexpr (MF == 32) {
-        store_tile(g, acc, m0, n0, wr, wc, h, r);
+        store_tile(g, acc, m0, n0, wr, wc, h, r, Cb, ldcb, atomic_);
     } else {
         // C/D layout of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + reg
-        const bool atomic = g.splitk > 1, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
+        const bool atomic = atomic_, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
                     if (m >= g.M || n >= g.N) continue;
                     if (out_lower && n > m) continue;
                     const float v = g.alpha * acc[i][j][c];
-                    float* dst = g.C + (int64_t)m * g.ldc + n;
+                    float* dst = Cb + (int64_t)m * ldcb + n;
                     if (atomic) atomicAdd(dst, v);
                     else *dst = v;
                 }
@@ -557,10 +567,12 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
 #ifdef G32_SK      // probe: fixed slice count for the products of G32_SK_MINT..G32_SK_BELOW tiles
     if (a.ntiles < G32_SK_BELOW && a.ntiles >= G32_SK_MINT && g.K >= 1024 && g.K < 16384) sk = G32_SK;
 #endif
+    sk = slab_slices(g, sk, sizeof(float));         // deterministic mode: as many slices as the caller's scratch holds
     a.splitk = sk;
     a.kslice = cdiv(cdiv(g.K, sk), 32) * 32;
     a.splitk = cdiv(g.K, a.kslice);
-    if (a.splitk > 1 || out_lower) {
+    a.slab = (g.slab && a.splitk > 1) ? (float*)g.slab : nullptr;
+    if (!a.slab && (a.splitk > 1 || out_lower)) {
         // atomics accumulate onto zeros / the strict upper triangle is defined as zero
         // (contiguous rows: one linear fill -- the 2-D fill kernel of the runtime takes 104 us for 36 MB, the linear one ~10)
         hipError_t e = zero_block(a.C, sizeof(float), a.ldc, a.M, a.N, st);
@@ -577,8 +589,16 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
         else if (bkc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, false, false>), grid, dim3(256), 0, st, a);
         hipError_t e = hipGetLastError();
-        return e == hipSuccess ? 1 : 1000 + (int)e;
-    }
+        if (e != hipSuccess) return 1000 + (int)e;
+    } else
 #endif
-    return dispatch32<G32_BK>(st, a, grid, akc, bkc);
+    {
+        const int rc = dispatch32<G32_BK>(st, a, grid, akc, bkc);
+        if (rc != 1) return rc;
+    }
+    if (a.slab) {
+        const int rc = launch_splitk_reduce(st, 0, a.slab, a.splitk, a.M, a.N, a.C, a.ldc, nullptr, 0, out_lower ? 1 : 0, 0);
+        if (rc) return rc;
+    }
+    return 1;
 }

@@ -21,6 +21,7 @@ struct G64 {
     int64_t lda, ldb, ldc, ldc32;
     int M, N, K, tiles_m, tiles_n, flags, balanced;
     int kchunk;          // > 0: split-K, blockIdx.y-th chunk of this many k of the tile's (trimmed) range; fp64 atomics onto zeros
+    double* slab;        // deterministic mode: chunk y stores its tiles to slab[y][M][N] instead (summed in a fixed order afterwards)
     double alpha;
 };
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     if (g.kchunk) {
         klo += (int)blockIdx.y * g.kchunk;                   // (klo is a multiple of BK, kchunk too)
         khi = min(khi, klo + g.kchunk);
-        if (klo >= khi) return;
+        if (klo >= khi && !g.slab) return;                   // (deterministic mode: an empty chunk still stores its zeros to the slab)
     }
 
     // staging: thread -> (k = tid / 16, 4 consecutive columns at 4 (tid % 16)) of the 16 x 64 stage of each operand
@@ -202,7 +203,9 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
                 if (m >= g.M || n >= g.N) continue;
                 double v = g.alpha * acc[i][j][r];
                 if (g.kchunk) {
-                    if (!(out_lower && n > m)) atomicAdd(&g.C[(int64_t)m * g.ldc + n], v);
+                    if (out_lower && n > m) continue;
+                    if (g.slab) g.slab[((int64_t)blockIdx.y * g.M + m) * g.N + n] = v;    // deterministic mode (summed in order afterwards)
+                    else atomicAdd(&g.C[(int64_t)m * g.ldc + n], v);
                     continue;
                 }
                 if (out_lower && n > m) v = 0.0;
@@ -249,14 +252,28 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     // longest tile's chain of K / 16 dependent stages; chunks of G64_KCHUNK accumulate with fp64 atomics onto a zeroed output
     a.kchunk = (G64_KCHUNK > 0 && a.balanced && g.K >= 2 * G64_KCHUNK && g.C) ? G64_KCHUNK : 0;
     int ysplit = 1;
+    a.slab = nullptr;
     if (a.kchunk) {
         ysplit = cdiv(g.K, a.kchunk);
-        hipError_t ez = zero_block(a.C, sizeof(double), a.ldc, a.M, a.N, st);
-        if (ez != hipSuccess) return 1000 + (int)ez;
+        if (g.slab) {                          // deterministic mode: one slab per K chunk (fewer, longer chunks if the scratch is small)
+            const int fit = slab_slices(g, ysplit, sizeof(double));
+            if (fit < ysplit) { a.kchunk = fit > 1 ? cdiv(cdiv(g.K, fit), BK) * BK : 0; ysplit = a.kchunk ? cdiv(g.K, a.kchunk) : 1; }
+            if (a.kchunk) a.slab = (double*)g.slab;
+        }
+        if (a.kchunk && !a.slab) {
+            hipError_t ez = zero_block(a.C, sizeof(double), a.ldc, a.M, a.N, st);
+            if (ez != hipSuccess) return 1000 + (int)ez;
+        }
     }
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
     if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
+    if (a.slab) {
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return 1000 + (int)e0;
+        const int rc = launch_splitk_reduce(st, 1, a.slab, ysplit, a.M, a.N, a.C, a.ldc, a.C32, a.ldc32, (fl & DSVGP_GEMM_OUT_LOWER) ? 1 : 0, 0);
+        return rc ? rc : 1;
+    }
     if (a.kchunk && a.C32) launch_cvt_f64_f32(st, a.C, a.ldc, a.C32, a.ldc32, a.M, a.N);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : 1000 + (int)e;

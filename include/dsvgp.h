@@ -45,6 +45,14 @@ enum {
 int dsvgp_create(dsvgp_ctx** ctx);                 /* creates the rocBLAS handle used by rocSOLVER potrf */
 int dsvgp_destroy(dsvgp_ctx* ctx);
 int dsvgp_set_stream(dsvgp_ctx* ctx, void* hip_stream);
+/* Deterministic mode (round 3).  With a caller-owned scratch buffer set, every split-K product stores its K slices to slabs in
+ * the scratch and adds them in a fixed order instead of meeting in floating-point atomics (fp32 Gram product, the fp64 M' x M' x M'
+ * products, the small-problem split-K products), and the scalar reductions of the step (residual / likelihood sums) go through
+ * per-workgroup partials: two runs on the same inputs are bitwise equal.  scratch == NULL: back to atomics (the default; their
+ * rounding depends on the order in which workgroups retire).  The scratch serves the launches queued on the context's current
+ * stream, one stream at a time; a product whose slices do not fit it runs with fewer, longer slices (unsplit below two).
+ * The reference (CPU torch) is deterministic for a fixed seed; this mode gives the HIP path the same property.          */
+int dsvgp_set_deterministic(dsvgp_ctx* ctx, void* scratch, size_t bytes);
 const char* dsvgp_version(void);
 
 /* ---- hyper-parameters: gpytorch Positive / GreaterThan(1e-4) softplus constraints ------------
@@ -285,6 +293,15 @@ int dsvgp_scale_by_vbar(dsvgp_ctx* ctx, float* x0, int64_t n0, float* x1, int64_
                         const float* hyp, double global_rows);
 int dsvgp_kl_terms_scaled(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int add_kl,
                           const float* hyp, double global_rows, float* kl_out, float* d_m, float* d_LS, int64_t lddls);
+/* The variational block of the ELBO fast path in ONE pass over (L_S, T = tril(G L_S)) (round 3; replaces the sequence
+ * dsvgp_trace_terms + dsvgp_kl_terms[_scaled] on the hot path): sums[2] = t1_scale * sum_{i>=j} L_S,ij T_ij, sums[3] = trace(G),
+ * d_LS <- [T / (noise rows) when flags & 1] + [dKL/dL_S / num_data when flags & 2], d_m += m / num_data (flags & 2),
+ * kl_out[0] = KL (0 without flag 2).  kl_out: 1 + 2 Mp floats.  One wave per row, 16-byte accesses, no atomics: the per-row
+ * partial sums are added in a fixed order (bitwise reproducible).  Reference: gpytorch kl_divergence of the whitened prior
+ * (DGVS.py:77-87) + the trace terms of the expected log-likelihood (directional_vi.py:217,245).                            */
+int dsvgp_variational_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data,
+                            int flags, const float* hyp, double global_rows, const float* G, int64_t ldg,
+                            float t1_scale, float* kl_out, float* sums, float* d_m, float* d_LS, int64_t lddls);
 
 /* Plain dense fp32 GEMM through rocBLAS (row-major, flags: DSVGP_GEMM_TRANS_A / _TRANS_B only): for products without
  * structure or fused epilogue (the dense K_ZX-bar product of the ELBO fast path); everything else is dsvgp_gemm.      */
