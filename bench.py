@@ -220,6 +220,8 @@ def main():
         loop.step(batch(k))
     eng.record_events = True
     eng.events = []
+    if hasattr(eng, "c_step_timed"):
+        eng.c_step_timed = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -236,23 +238,28 @@ def main():
         # come from three more, untimed, eager steps of the same loop
         loop.graph = False
         eng.events = []
+        if hasattr(eng, "c_step_timed"):
+            eng.c_step_timed = []
         for k in range(3):
             loop.step(batch(args.warmup + args.steps + k))
         torch.cuda.synchronize()
     # the kernel assembly forward alone on the GPU (it shares the CUs with the Cholesky chain in the step when M' >= 2048):
     # three more untimed steps with the side stream off, HIP events around the same launch
-    step_events = list(eng.events)
+    has_dur = hasattr(eng, "event_durations")
+    durations = {nm: (eng.event_durations(nm) if has_dur else [s.elapsed_time(e) * 1e-3 for (n2, s, e) in eng.events if n2 == nm])
+                 for nm in ("solve_fwd", "assemble_fwd", "assemble_bwd", "early_reduce_wait", "final_reduce")}
     iso_fwd = None
     if not cfg.get("ciq") and world == 1 and not args.fp64:
         saved = eng.overlap
         eng.overlap, eng.events = False, []
+        if hasattr(eng, "c_step_timed"):
+            eng.c_step_timed = []
         for k in range(3):
             loop.step(batch(args.warmup + args.steps + 3 + k))
         torch.cuda.synchronize()
-        durs = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in eng.events if nm == "assemble_fwd"]
+        durs = eng.event_durations("assemble_fwd") if has_dur else [s.elapsed_time(e) * 1e-3 for (nm, s, e) in eng.events if nm == "assemble_fwd"]
         iso_fwd = sum(durs) / len(durs) if durs else None
         eng.overlap = saved
-    eng.events = step_events
     eng.record_events = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -293,7 +300,7 @@ def main():
     Bp_local = B_local * (p + 1)
 
     def avg(name):
-        durs = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in eng.events if nm == name]
+        durs = durations.get(name, [])
         return (sum(durs) / len(durs), len(durs)) if durs else (None, 0)
 
     roof = None
@@ -369,6 +376,7 @@ def main():
             "config": {"workload": cfg["name"], "global_batch": B, "per_gpu_batch": B // world, "M_prime": Mp,
                        "parallelism": "dp%d rows" % world, "trsm_nb": eng.trsm_nb, "final_loss": final_loss,
                        "graph_replay": bool(loop._graphs),
+                       "one_call_step": bool(getattr(eng, "c_step_used", False)),
                        "dense_product": "rocBLAS sgemm" if eng.lib_dense_gemm else "hand-written (gemm32.hip, v_mfma_f32_32x32x2_f32)",
                        "timed_step": "TrainLoop.step(need_variance=False): ELBO fast path every step; the reference's "
                                      "every-50th-step nll print (per-output path, ~+9 ms once per 50 steps at C4) is "

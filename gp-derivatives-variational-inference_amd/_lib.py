@@ -27,12 +27,30 @@ _f = C.c_float
 _d = C.c_double
 _z = C.c_size_t
 
+class ElboStepIO(C.Structure):
+    """``dsvgp_elbo_step_io`` of include/dsvgp.h (device pointers of one ELBO step)"""
+    _fields_ = [("Z", _p), ("V", _p), ("m", _p), ("LS", _p), ("ldls", _l),
+                ("constant", _p), ("raw_lengthscale", _p), ("raw_outputscale", _p), ("raw_noise", _p),
+                ("x", _p), ("y", _p), ("D", _p),
+                ("flat", _p), ("flat_floats", _z),
+                ("dZ", _p), ("dV", _p), ("dm", _p), ("dLS", _p), ("lddls", _l),
+                ("d_hyp", _p), ("d_constant", _p), ("d_raw_lengthscale", _p), ("d_raw_outputscale", _p), ("d_raw_noise", _p),
+                ("loss", _p), ("mu", _p), ("num_data", _d), ("global_rows", _d), ("kzz_jitter", _f)]
+
+
 # name -> (restype, argtypes); mirrors include/dsvgp.h one to one
 SIGNATURES = {
     "dsvgp_create": (_i, [C.POINTER(_p)]),
     "dsvgp_destroy": (_i, [_p]),
     "dsvgp_set_stream": (_i, [_p, _p]),
     "dsvgp_set_deterministic": (_i, [_p, _p, _z]),
+    "dsvgp_elbo_step_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "dsvgp_elbo_step_plan_create": (_i, [_p, _i, _i, _i, _i, C.POINTER(_p)]),
+    "dsvgp_elbo_step_plan_destroy": (_i, [_p]),
+    "dsvgp_elbo_step_plan_bytes": (_z, [_p]),
+    "dsvgp_elbo_step_f32": (_i, [_p, _p, _p, _p, _z, _i]),
+    "dsvgp_elbo_step_status": (_i, [_p, _p, _p]),
+    "dsvgp_elbo_step_timings": (_i, [_p, _i, _p]),
     "dsvgp_version": (C.c_char_p, []),
     "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),

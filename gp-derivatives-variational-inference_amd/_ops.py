@@ -78,6 +78,43 @@ class Context:
             self._stream = s
 
 
+class StepPlan:
+    """``dsvgp_step_plan`` of one (M, d, p, B): host-side object of the one-call ELBO step (csrc/step.hip)"""
+
+    def __init__(self, ctx, M, d, p, B):
+        h = C.c_void_p()
+        check(lib.dsvgp_elbo_step_plan_create(ctx.h, int(M), int(d), int(p), int(B), C.byref(h)), "dsvgp_elbo_step_plan_create")
+        self.h = h
+        self.bytes = int(lib.dsvgp_elbo_step_plan_bytes(h))
+        self.io = _lib.ElboStepIO()
+        self._hyp = (C.c_float * 4)()
+        self._info = C.c_int(0)
+        self._ms = (C.c_float * 3)()
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            lib.dsvgp_elbo_step_plan_destroy(h)
+
+    def run(self, ctx, workspace, flags):
+        check(lib.dsvgp_elbo_step_f32(ctx.h, self.h, C.byref(self.io), _ptr(workspace), workspace.numel(), int(flags)),
+              "dsvgp_elbo_step_f32")
+
+    def status(self):
+        """(potrf status word, [lengthscale, outputscale, noise]) of the step queued last; waits for its factorisation only"""
+        check(lib.dsvgp_elbo_step_status(self.h, self._hyp, C.byref(self._info)), "dsvgp_elbo_step_status")
+        return int(self._info.value), [float(v) for v in self._hyp]
+
+    def timings(self, back=0):
+        """[solve_fwd, assemble_fwd, assemble_bwd] HIP-event durations (ms) of the timed step ``back`` steps before the last"""
+        check(lib.dsvgp_elbo_step_timings(self.h, int(back), self._ms), "dsvgp_elbo_step_timings")
+        return [float(v) for v in self._ms]
+
+
+def step_supported(M, d, p, B):
+    return int(lib.dsvgp_elbo_step_workspace_bytes(int(M), int(d), int(p), int(B))) > 0
+
+
 def packed_width(d):
     return int(lib.dsvgp_packed_width(int(d)))
 

@@ -130,6 +130,14 @@ class ElboEngine:
         # runs on ONE stream (the slab serves one stream at a time).  The CPU reference is deterministic for a fixed seed; the
         # default HIP step is not (order of atomic adds).  Measured cost: DESIGN.md section 5.
         self.deterministic = os.environ.get("DSVGP_DETERMINISTIC", "0") == "1"
+        # The ELBO fast path of one rank from ONE host call (dsvgp_elbo_step_f32, csrc/step.hip) instead of ~100 ctypes calls:
+        # same library entry points in the same order, queued from C.  Anything outside its scope (PLL, per-output variances,
+        # CIQ, shared directions, derivative-free data, data-parallel schedules, graph capture, the jitter ladder) keeps the
+        # piecewise path below.  DSVGP_C_STEP=0 switches it off (A/B runs).
+        self.c_step = os.environ.get("DSVGP_C_STEP", "1") == "1"
+        self._plans = {}
+        self.c_step_used = False        # whether the last step ran through the one-call path
+        self.c_step_timed = []          # plans of the steps queued with record_events on, in order
 
     @property
     def trsm_nb(self):
@@ -275,6 +283,20 @@ class ElboEngine:
         _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
         self._event_done("assemble_fwd", ev)
         return Kzx
+
+    def event_durations(self, name):
+        """durations (seconds) recorded for ``name`` (solve_fwd / assemble_fwd / assemble_bwd / ...) since ``events`` /
+        ``c_step_timed`` were last cleared: torch events of the piecewise path and the plan's HIP events of the one-call path"""
+        out = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in self.events if nm == name]
+        slot = {"solve_fwd": 0, "assemble_fwd": 1, "assemble_bwd": 2}.get(name)
+        if slot is not None and self.c_step_timed:
+            back = {}
+            for plan in reversed(self.c_step_timed):
+                b = back.get(id(plan), 0)
+                back[id(plan)] = b + 1
+                if b < 128:
+                    out.append(plan.timings(b)[slot] * 1e-3)
+        return out
 
     def _event_pair(self):
         if not self.record_events or self.capture_mode:
@@ -527,7 +549,7 @@ class ElboEngine:
             out = (loss, {_NGD_RENAME.get(k, k): v for k, v in grads.items()}, mu, varn)
         return out
 
-    def _alloc_grads(self, params, names):
+    def _alloc_grads(self, params, names, zero=True):
         """All gradients + the loss in ONE flat buffer (one fill; the data-parallel all-reduce needs no packing), the
         variational parameters (names[2:4], 99.8 % of the bytes) first: they are final half-way through the backward, so
         the data-parallel layer reduces ``flat_early`` while the rest of the step runs and ``flat_late`` at the end.
@@ -535,7 +557,8 @@ class ElboEngine:
         order = list(names[2:4]) + list(names[:2]) + list(names[4:])
         pad = lambda nk: (nk + 15) // 16 * 16                       # every segment starts 64-byte aligned
         total = sum(pad(params[k].numel()) for k in order)
-        flat = torch.zeros(total + 1 + 4, dtype=f32, device=self.device)
+        flat = (torch.zeros if zero else torch.empty)(total + 1 + 4, dtype=f32, device=self.device)   # (zero=False: the callee clears it)
+        self._flat_full = flat
         views, off = {}, 0
         for k in order:
             nk = params[k].numel()
@@ -918,9 +941,79 @@ class ElboEngine:
         _ops.gemm(ctx, TRANS_A | A_UPPER, Linv, T, Kc, alpha=0.5)
         return Kc
 
+    def _c_step_eligible(self, params, x, use_fast, sync):
+        if not (self.c_step and use_fast and not sync and not self.capture_mode and self.whitening == "cholesky"
+                and self.data_outputs == "all" and not self.shared_directions and not self._no_middle and self.potrf_algo == 1
+                and self.fused_inverse and self._trsm_nb is None and not self.lib_dense_gemm):
+            return False
+        coll = self.collective
+        if coll is not None and coll.world > 1:
+            return False
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        return M > 0 and x.shape[0] > 0 and M * (p + 1) <= 8192 and _ops.step_supported(M, d, p, x.shape[0])
+
+    def _c_step(self, ctx, params, x, y, D, num_data, rows, include_kl):
+        """the whole fast-path step queued by dsvgp_elbo_step_f32 (one ctypes call); raises _Refactored when the
+        factorisation failed (the caller then runs the jitter ladder on the piecewise path)"""
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M
+        B = x.shape[0]
+        Mp, Bp = M * (p + 1), B * (p + 1)
+        self._problem_size(Mp)
+        plan = self._plans.get((M, d, p, B))
+        if plan is None:
+            plan = self._plans[(M, d, p, B)] = _ops.StepPlan(ctx, M, d, p, B)
+        ws = self._bytes("cstep_ws", plan.bytes)
+        grads, loss_out, d_hyp = self._alloc_grads(params, PARAM_NAMES, zero=False)
+        mu = torch.empty(Bp, dtype=f32, device=self.device)
+        LS, dLS = params["chol_variational_covar"], grads["chol_variational_covar"]
+        for name, t in (("inducing_points", Z), ("inducing_directions", V), ("x", x), ("y", y), ("D", D),
+                        ("variational_mean", params["variational_mean"]), ("chol_variational_covar", LS)):
+            if t.numel() and (t.dtype != f32 or not t.is_cuda or (t.dim() == 2 and t.stride(1) != 1) or (t.dim() != 2 and not t.is_contiguous())):
+                raise _lib.DsvgpError("%s must be a float32 GPU tensor with unit inner stride" % name)
+        if not (Z.is_contiguous() and x.is_contiguous() and (p == 0 or (V.is_contiguous() and D.is_contiguous()))):
+            raise ValueError("points and directions must be contiguous")
+        P = lambda t: t.data_ptr() if t is not None and t.numel() else None
+        io = plan.io
+        io.Z, io.V, io.m, io.LS, io.ldls = P(Z), P(V), P(params["variational_mean"]), P(LS), _ops._ld(LS)
+        io.constant, io.raw_lengthscale = P(params["constant"]), P(params["raw_lengthscale"])
+        io.raw_outputscale, io.raw_noise = P(params["raw_outputscale"]), P(params["raw_noise"])
+        io.x, io.y, io.D = P(x), P(y), P(D)
+        full = self._flat_full
+        io.flat, io.flat_floats = full.data_ptr(), full.numel()
+        io.dZ, io.dV, io.dm = P(grads["inducing_points"]), P(grads["inducing_directions"]), P(grads["variational_mean"])
+        io.dLS, io.lddls = P(dLS), _ops._ld(dLS)
+        io.d_hyp, io.d_constant = P(d_hyp), P(grads["constant"])
+        io.d_raw_lengthscale, io.d_raw_outputscale = P(grads["raw_lengthscale"]), P(grads["raw_outputscale"])
+        io.d_raw_noise, io.loss, io.mu = P(grads["raw_noise"]), P(loss_out), P(mu)
+        io.num_data, io.global_rows, io.kzz_jitter = float(num_data), float(rows), float(self.kzz_jitter)
+        overlap = self.overlap if self.overlap is not None else Mp >= 2048
+        flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if self.record_events else 0)
+        plan.run(ctx, ws, flags)
+        info, hyp = plan.status()            # waits for the factorisation only; the rest of the step stays queued
+        self._hyp_host = hyp[:3]
+        if info != 0:
+            raise _Refactored()
+        if self.record_events:
+            self.c_step_timed.append(plan)              # bench.py reads plan.timings(back) after its timed region
+        self.c_step_used = True
+        self._pending = None
+        return loss_out[0], grads, mu, torch.empty(0, dtype=f32, device=self.device)
+
     def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         use_fast = mll_type == "ELBO" and fast
         self._ctx = ctx
+        self.c_step_used = False
+        if self._c_step_eligible(params, x, use_fast, sync):
+            pz = params["inducing_directions"].shape[0] // params["inducing_points"].shape[0]
+            Bq = x.shape[0] * (pz + 1)
+            if y.shape != (Bq,):
+                raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bq)
+            return self._c_step(ctx, params, x, y.contiguous(), D, num_data, float(Bq if global_rows is None else global_rows),
+                                include_kl)
         Mz = params["inducing_points"].shape[0]
         p = params["inducing_directions"].shape[0] // Mz if Mz else 0
         B = x.shape[0]

@@ -1,0 +1,349 @@
+// One C entry point for the whole ELBO step (round 3; SURVEY.md section 8b's `dsvgp_elbo_terms` proposal taken to its end).
+//
+// dsvgp_elbo_step_f32 queues forward + backward of one DSVGP minibatch ELBO evaluation -- the iteration body of the reference's
+// train_gp (directionalvi/directional_vi.py:245-249: output = model(x, derivative_directions=D); loss = -mll(output, y);
+// loss.backward()) with the composition of DirectionalGradVariationalStrategy.forward (DGVS.py:89-208) -- from ONE host call:
+// ~70 kernel launches on two HIP streams with events between them, no host synchronisation, every intermediate in ONE
+// caller-owned workspace.  It is the same sequence of library calls that the Python engine (`_step.ElboEngine._elbo_fast`)
+// issues through ~100 ctypes calls (1.05 ms of host time per step; the C2 step of 0.75 ms is bound by that); the arithmetic is
+// shared (the dsvgp_* entry points below), so the parity tests of either path cover both.
+//
+// Scope: the ELBO fast path (Gram formulation) of the Cholesky-whitened strategy with every data point carrying its p
+// directional derivatives, explicit-inverse regime (M' <= 8192), one rank or a data-parallel rank's "local" part
+// (global_rows / include_kl).  PLL, per-output variances, CIQ, shared directions, derivative-free data and the jitter
+// ladder after a failed factorisation stay on the Python-orchestrated path (the caller reads the status word with
+// dsvgp_elbo_step_status and falls back).
+#include "common.h"
+
+#include <string.h>
+
+#include <new>
+
+namespace {
+
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    }
+};
+
+inline int pad4(int n) { return (n + 3) / 4 * 4; }
+inline int auto_nb(int Mp) {          // _step.ElboEngine._problem_size: the explicit-inverse regime up to M' = 8192
+    int b = 64;
+    while (b < Mp) b <<= 1;
+    return b;
+}
+
+}  // namespace
+
+struct dsvgp_step_plan {
+    int M, d, p, B, Mp, Bp, DP, nb;
+    size_t bytes;
+    // workspace offsets (bytes)
+    size_t o_zero, zero_bytes;        // region cleared at the start of every step: info, sums, kl_buf
+    size_t o_info, o_sums, o_klbuf, o_scal, o_hyp, o_center;
+    size_t o_PZ, o_sZ, o_vZ, o_PX, o_sX, o_vX;
+    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_Qe32, o_Kb32, o_Lbar, o_G1, o_kbwd, o_kbwd2;
+    int ldS, ldQ32;
+    const void* pad_ready_for = nullptr;          // the workspace whose Qe32 pad columns have been zeroed
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_status = nullptr, ev_fork2 = nullptr, ev_var = nullptr, ev_dense = nullptr,
+               ev_zx = nullptr;
+    // timing pairs of the last TM_RING timed steps: forward solve, K_ZX assembly, K_ZX-bar kernel backward
+    static constexpr int TM_RING = 128;
+    hipEvent_t tm_ring[TM_RING][6] = {};
+    hipEvent_t* tm = tm_ring[0];
+    long timed_steps = 0;
+    bool timed = false;
+    float* host_status = nullptr;                 // pinned: hyp[4] + info (as float bits)
+};
+
+// workspace layout of one (M, d, p, B); returns the total byte count (0: unsupported shape)
+static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl) {
+    if (M <= 0 || d <= 0 || p < 0 || B <= 0) return 0;
+    const int q = p + 1, Mp = M * q, Bp = B * q, DP = dsvgp_packed_width(d);
+    if (DP <= 0 || Mp > 8192 || (int64_t)Mp * Bp >= ((int64_t)1 << 31)) return 0;
+    pl->M = M; pl->d = d; pl->p = p; pl->B = B; pl->Mp = Mp; pl->Bp = Bp; pl->DP = DP; pl->nb = auto_nb(Mp);
+    pl->ldS = pad4(Mp + 1); pl->ldQ32 = pad4(Mp + 1);
+    Carve c;
+    // zeroed head: info[4 ints] | sums[4] | kl_buf[2 M' + 1]
+    pl->o_zero = c.off;
+    pl->zero_bytes = 4 * sizeof(int) + 4 * sizeof(float) + (size_t)(2 * Mp + 1) * sizeof(float);
+    pl->o_info = c.take(pl->zero_bytes);
+    pl->o_sums = pl->o_info + 4 * sizeof(int);
+    pl->o_klbuf = pl->o_sums + 4 * sizeof(float);
+    pl->o_scal = c.take(8 * sizeof(float)); pl->o_hyp = c.take(4 * sizeof(float)); pl->o_center = c.take((size_t)d * sizeof(float));
+    pl->o_PZ = c.take((size_t)Mp * DP * 4); pl->o_sZ = c.take((size_t)Mp * 4); pl->o_vZ = c.take((size_t)(M * p > 0 ? M * p : 1) * 4);
+    pl->o_PX = c.take((size_t)Bp * DP * 4); pl->o_sX = c.take((size_t)Bp * 4); pl->o_vX = c.take((size_t)(B * p > 0 ? B * p : 1) * 4);
+    pl->o_L = c.take((size_t)Mp * Mp * 8);
+    pl->o_trsm = c.take(dsvgp_trsm_workspace_bytes(Mp, Bp > Mp + 1 ? Bp : Mp + 1, pl->nb));
+    pl->o_potrf = c.take(potrf_blocked_workspace_bytes(Mp));
+    pl->o_Kzx = c.take((size_t)Mp * Bp * 4); pl->o_A32e = c.take((size_t)(Mp + 1) * Bp * 4); pl->o_S32e = c.take((size_t)Mp * pl->ldS * 4);
+    pl->o_var0 = c.take((size_t)Bp * 4); pl->o_stats = c.take(dsvgp_stats_workspace_bytes(Mp, Bp) + 16);
+    pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 1) * 8 + 64); pl->o_Qe32 = c.take((size_t)Mp * pl->ldQ32 * 4);
+    pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_Lbar = c.take((size_t)Mp * Mp * 8); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
+    const size_t kb = dsvgp_kernel_bwd_workspace_bytes(M, B, d, p), kz = dsvgp_kernel_bwd_workspace_bytes(M, M, d, p);
+    pl->o_kbwd = c.take(kb > kz ? kb : kz); pl->o_kbwd2 = c.take(kb);
+    pl->bytes = c.off + 256;
+    return pl->bytes;
+}
+
+extern "C" size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B) {
+    dsvgp_step_plan pl{};
+    return step_layout(M, d, p, B, &pl);
+}
+
+extern "C" int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out) {
+    if (!ctx || !out) return DSVGP_EINVAL;
+    dsvgp_step_plan* pl = new (std::nothrow) dsvgp_step_plan();
+    if (!pl) return DSVGP_EINVAL;
+    if (!step_layout(M, d, p, B, pl)) { delete pl; return DSVGP_EINVAL; }
+    bool ok = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx};
+    for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (auto& slot : pl->tm_ring) for (hipEvent_t& e : slot) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&pl->host_status, 8 * sizeof(float), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (hipEvent_t* e : evs) if (*e) (void)hipEventDestroy(*e);
+        for (auto& slot : pl->tm_ring) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
+        if (pl->side) (void)hipStreamDestroy(pl->side);
+        if (pl->host_status) (void)hipHostFree(pl->host_status);
+        delete pl;
+        return 1000 + (int)hipErrorOutOfMemory;
+    }
+    pl->host_status[4] = 0.f;
+    *out = pl;
+    return 0;
+}
+
+extern "C" int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* pl) {
+    if (!pl) return DSVGP_EINVAL;
+    hipEvent_t evs[] = {pl->ev_fork, pl->ev_side, pl->ev_status, pl->ev_fork2, pl->ev_var, pl->ev_dense, pl->ev_zx};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    for (auto& slot : pl->tm_ring) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
+    if (pl->side) (void)hipStreamDestroy(pl->side);
+    if (pl->host_status) (void)hipHostFree(pl->host_status);
+    delete pl;
+    return 0;
+}
+
+// HIP-event durations (ms) of a step queued with flag 4 -- `back` steps before the most recent one (the plan keeps the last 128) --
+// each measured on the stream its kernel ran on: ms[0] forward panel solve A = L^-1 K_ZX, ms[1] K_ZX assembly, ms[2] K_ZX-bar
+// kernel backward.  Waits for that step.
+extern "C" int dsvgp_elbo_step_timings(dsvgp_step_plan* pl, int back, float* ms3) {
+    if (!pl || !ms3 || back < 0 || back >= dsvgp_step_plan::TM_RING || back >= pl->timed_steps) return DSVGP_EINVAL;
+    hipEvent_t* tm = pl->tm_ring[(pl->timed_steps - 1 - back) % dsvgp_step_plan::TM_RING];
+    for (int k = 0; k < 3; ++k) {
+        hipError_t e = hipEventSynchronize(tm[2 * k + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms3[k], tm[2 * k], tm[2 * k + 1]);
+        if (e != hipSuccess) return 1000 + (int)e;
+    }
+    return 0;
+}
+
+extern "C" size_t dsvgp_elbo_step_plan_bytes(const dsvgp_step_plan* pl) { return pl ? pl->bytes : 0; }
+
+// Wait for the factorisation of the step queued last (NOT for the rest of the step) and return its status word (0 = positive
+// definite; k > 0: pivot k failed -- the caller runs psd_safe_cholesky's jitter ladder on the piecewise path) and the constrained
+// hyper-parameters {lengthscale, outputscale, noise, 0} of that step.
+extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* info) {
+    if (!pl || !info) return DSVGP_EINVAL;
+    hipError_t e = hipEventSynchronize(pl->ev_status);
+    if (e != hipSuccess) return 1000 + (int)e;
+    if (hyp4) for (int i = 0; i < 4; ++i) hyp4[i] = pl->host_status[i];
+    int v;
+    memcpy(&v, &pl->host_status[4], sizeof(int));
+    *info = v;
+    return 0;
+}
+
+#define STEP_CALL(expr)                 \
+    do {                                \
+        const int rc__ = (expr);        \
+        if (rc__) { ctx->stream = main; return rc__; } \
+    } while (0)
+#define STEP_HIP(expr)                  \
+    do {                                \
+        const hipError_t e__ = (expr);  \
+        if (e__ != hipSuccess) { ctx->stream = main; return 1000 + (int)e__; } \
+    } while (0)
+
+// flags: bit 0 = overlap (second stream: K_ZX assembly + S = L_S L_S^T under the Cholesky chain, the L_S / m gradients next to
+//                the Q' solve and the dense product, K_ZX-bar's kernel backward next to the Cholesky backward when B' <= 2 M');
+//        bit 1 = include the KL term (a data-parallel rank other than 0 leaves it out).
+// io->flat .. flat + flat_floats is cleared here (the gradient slots must start from zero); every gradient pointer of io points
+// into it.  All pointers are device pointers; nothing is read back.
+extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace,
+                                   size_t workspace_bytes, int flags) {
+    if (!ctx || !pl || !io || !workspace || workspace_bytes < pl->bytes || ((uintptr_t)workspace % 256)) return DSVGP_EINVAL;
+    if (!io->Z || !io->m || !io->LS || !io->constant || !io->raw_lengthscale || !io->raw_outputscale || !io->raw_noise || !io->x ||
+        !io->y || !io->flat || !io->dZ || !io->dm || !io->dLS || !io->d_hyp || !io->d_constant || !io->d_raw_lengthscale ||
+        !io->d_raw_outputscale || !io->d_raw_noise || !io->loss || !io->mu || io->num_data <= 0 || io->global_rows <= 0)
+        return DSVGP_EINVAL;
+    const int M = pl->M, d = pl->d, p = pl->p, B = pl->B, Mp = pl->Mp, Bp = pl->Bp, nb = pl->nb;
+    if (p > 0 && (!io->V || !io->D || !io->dV)) return DSVGP_EINVAL;
+    if (io->ldls < Mp || io->lddls < Mp) return DSVGP_EINVAL;
+    char* w = (char*)workspace;
+    int* info = (int*)(w + pl->o_info);
+    float* sums = (float*)(w + pl->o_sums);
+    float* kl_buf = (float*)(w + pl->o_klbuf);
+    float* scal = (float*)(w + pl->o_scal);
+    float* hyp = (float*)(w + pl->o_hyp);
+    float* center = (float*)(w + pl->o_center);
+    float *PZ = (float*)(w + pl->o_PZ), *sZ = (float*)(w + pl->o_sZ), *vZ = (float*)(w + pl->o_vZ);
+    float *PX = (float*)(w + pl->o_PX), *sX = (float*)(w + pl->o_sX), *vX = (float*)(w + pl->o_vX);
+    double* L = (double*)(w + pl->o_L);
+    void* trsm_ws = w + pl->o_trsm;
+    void* potrf_ws = w + pl->o_potrf;
+    float* Kzx = (float*)(w + pl->o_Kzx);
+    float* A32e = (float*)(w + pl->o_A32e);          // [A ; mu_bar^T]
+    float* S32e = (float*)(w + pl->o_S32e);          // [S - I | m / (2 vbar)], rows padded to a multiple of 4 floats
+    float* var0 = (float*)(w + pl->o_var0);
+    void* stats_ws = w + pl->o_stats;
+    float* Ge = (float*)(w + pl->o_Ge);              // [G ; b^T]
+    double* Qe64 = (double*)(w + pl->o_Qe64);        // [Q' | a / (2 vbar)]
+    float* Qe32 = (float*)(w + pl->o_Qe32);
+    float* Kb32 = (float*)(w + pl->o_Kb32);
+    double* Lbar = (double*)(w + pl->o_Lbar);
+    double* G1 = (double*)(w + pl->o_G1);
+    void* kbwd_ws = w + pl->o_kbwd;
+    void* kbwd_ws2 = w + pl->o_kbwd2;
+    const int ldS = pl->ldS, ldQ32 = pl->ldQ32;
+    const double rows = io->global_rows;
+    const bool overlap = (flags & 1) && !ctx->det_slab;           // (deterministic mode: the scratch serves one stream)
+    const bool include_kl = flags & 2, timed = flags & 4;
+    pl->timed = timed;
+    if (timed) { pl->tm = pl->tm_ring[pl->timed_steps % dsvgp_step_plan::TM_RING]; ++pl->timed_steps; }
+#define STEP_TIME(slot) do { if (timed) STEP_HIP(hipEventRecord(pl->tm[slot], ctx->stream)); } while (0)
+    const hipStream_t main = ctx->stream, side = pl->side;
+
+    // ---- clears: gradient slots + loss, the status / sums / KL scratch; once per workspace the pad columns of [Q' | a] (fp32)
+    STEP_HIP(hipMemsetAsync(io->flat, 0, io->flat_floats * sizeof(float), main));
+    STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
+    if (pl->pad_ready_for != workspace) {
+        STEP_HIP(hipMemsetAsync(Qe32, 0, (size_t)Mp * ldQ32 * sizeof(float), main));
+        pl->pad_ready_for = workspace;
+    }
+    // ---- hyper-parameters, centre, packed inducing rows (DGVS.py:128-149 via RBFKernelDirectionalGrad.py:57-107)
+    STEP_CALL(dsvgp_hyp_forward(ctx, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp));
+    STEP_CALL(dsvgp_column_mean(ctx, io->Z, M, d, center));
+    STEP_CALL(dsvgp_pack_points(ctx, io->Z, io->V, M, d, p, hyp, center, PZ, sZ, vZ));
+    // ---- prologue that does not depend on L: pack x, K_ZX, [S - I | m / (2 vbar)] -- on the side stream under the Cholesky chain
+    auto prologue = [&](bool background) -> int {
+        int rc = dsvgp_pack_points(ctx, io->x, io->D, B, d, p, hyp, center, PX, sX, vX);
+        if (rc) return rc;
+        if (timed && hipEventRecord(pl->tm[2], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
+        rc = dsvgp_kernel_fwd(ctx, PZ, sZ, M, PX, sX, B, d, p, hyp, 0.f, Kzx, Bp, 0);
+        if (rc) return rc;
+        if (timed && hipEventRecord(pl->tm[3], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
+        // S = tril(L_S) tril(L_S)^T: lower triangle + mirror (n^3 / 6 multiply-adds), as a one-workgroup-per-CU filler beside the chain
+        rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_A_LOWER | DSVGP_GEMM_TRANS_B | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER |
+                        (background ? DSVGP_GEMM_BACKGROUND : 0), Mp, Mp, Mp, 1.0, io->LS, io->ldls, io->LS, io->ldls, 0.0, nullptr, 0,
+                        S32e, ldS, nullptr, 0, nullptr);
+        if (rc) return rc;
+        rc = dsvgp_mirror_lower_f32(ctx, S32e, Mp, ldS);
+        if (rc) return rc;
+        return dsvgp_sminus_i_col(ctx, S32e, Mp, ldS, io->m, hyp, rows);
+    };
+    if (overlap) {
+        STEP_HIP(hipEventRecord(pl->ev_fork, main));
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork, 0));
+        ctx->stream = side;
+        STEP_CALL(prologue(true));
+        STEP_HIP(hipEventRecord(pl->ev_side, side));
+        ctx->stream = main;
+    }
+    // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip)
+    STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
+    STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
+    STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 4 * sizeof(float), hipMemcpyDeviceToHost, main));
+    STEP_HIP(hipMemcpyAsync(pl->host_status + 4, info, sizeof(int), hipMemcpyDeviceToHost, main));
+    STEP_HIP(hipEventRecord(pl->ev_status, main));
+    if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_side, 0));
+    else STEP_CALL(prologue(false));
+    // ---- A = L^-1 K_ZX (fp64 product with the explicit inverse, fp32 result), mu = A^T m + c, residuals (DGVS.py:181-188)
+    float* A32 = A32e;
+    float* mu_bar = A32e + (size_t)Mp * Bp;
+    STEP_TIME(0);
+    STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 0, Kzx, Bp, 0, Bp, nullptr, 0, A32, Bp, nb, trsm_ws, 1));
+    STEP_TIME(1);
+    STEP_CALL(dsvgp_predictive_stats(ctx, A32, Bp, A32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var0, stats_ws));
+    STEP_CALL(dsvgp_residual_terms(ctx, io->mu, io->y, Bp, hyp, rows, mu_bar, sums));
+    // ---- [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), split-K over the minibatch axis; G mirrored
+    STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
+                         Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_mirror_lower_f32(ctx, Ge, Mp, Mp));
+    // ---- variational block (needs only G): L_S-bar = 2 vbar tril(G L_S) + KL gradient, m-bar = b + KL gradient, trace terms, scalars
+    auto variational = [&]() -> int {
+        int rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, Ge, Mp, io->LS, io->ldls, 0.0, nullptr, 0,
+                            io->dLS, io->lddls, nullptr, 0, nullptr);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(io->dm, Ge + (size_t)Mp * Mp, (size_t)Mp * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) return 1000 + (int)e;
+        rc = dsvgp_variational_terms(ctx, io->m, io->LS, io->ldls, Mp, io->num_data, 1 | (include_kl ? 2 : 0), hyp, rows, Ge, Mp, 1.f,
+                                     kl_buf, sums, io->dm, io->dLS, io->lddls);
+        if (rc) return rc;
+        return dsvgp_elbo_fast_finalize(ctx, sums, hyp, B, p, rows, scal);
+    };
+    // ---- [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64), K_ZX-bar = [Q' | a] [A ; mu_bar^T] (fp32, unscaled)
+    auto solve = [&]() -> int {
+        int rc = dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, Qe64, Mp + 1, Qe32, ldQ32, nb, trsm_ws, 1);
+        if (rc) return rc;
+        return dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qe32, ldQ32, A32e, Bp, 0.0, nullptr, 0, Kb32, Bp, nullptr, 0,
+                          nullptr);
+    };
+    if (overlap) {
+        STEP_HIP(hipEventRecord(pl->ev_fork2, main));
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
+        ctx->stream = side;
+        STEP_CALL(variational());
+        STEP_HIP(hipEventRecord(pl->ev_var, side));
+        ctx->stream = main;
+        STEP_CALL(solve());
+    } else {
+        STEP_CALL(variational());
+        STEP_CALL(solve());
+    }
+    // ---- K_ZX-bar's kernel backward: beside the fp64 products that follow when the batch is small against M' (HBM-bound read)
+    const bool zx_side = overlap && Bp <= 2 * Mp;
+    if (zx_side) {
+        STEP_HIP(hipEventRecord(pl->ev_dense, main));
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
+        ctx->stream = side;
+        STEP_TIME(4);
+        STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws2));
+        STEP_TIME(5);
+        STEP_HIP(hipEventRecord(pl->ev_zx, side));
+        ctx->stream = main;
+    }
+    // ---- L-bar = -tril([Q' | a] [G ; b^T]) (fp64), joined with the variational block
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, Qe64, Mp + 1, Ge, Mp, 0.0, nullptr, 0,
+                         Lbar, Mp, nullptr, 0, nullptr));
+    if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
+    if (!zx_side) {
+        STEP_TIME(4);
+        STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+        STEP_TIME(5);
+    }
+    // ---- Cholesky backward: K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 through the explicit inverse, lower halves + mirrors
+    const double* Linv = (const double*)trsm_ws;
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, L, Mp,
+                         Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
+                         nullptr, 0, Lbar, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Lbar, Mp, 0.0,
+                         nullptr, 0, G1, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));
+    if (zx_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
+    STEP_CALL(dsvgp_kernel_bwd(ctx, G1, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
+    STEP_CALL(dsvgp_scale_by_vbar(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, io->d_hyp, 2, hyp, rows));
+    STEP_CALL(dsvgp_step_epilogue(ctx, scal, kl_buf, rows, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
+                                  io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));
+    return 0;
+}

@@ -256,6 +256,10 @@ class TrainLoop:
         return mode is True
 
     def _graph_step(self, idx, idx_y):
+        # graph replay captures the piecewise path (its launches go to the capture stream one by one); the one-call step
+        # (dsvgp_elbo_step_f32: its own second stream, a host read of the status word) is the alternative, not a part of it --
+        # and the eager warm-up steps below must have created the piecewise path's buffers before the capture
+        self.model.engine.c_step = False
         key = (idx.shape[0], len(idx_y))
         gs = self._graphs.get(key)
         if gs is None:

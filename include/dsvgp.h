@@ -345,6 +345,46 @@ int dsvgp_ciq_tbar(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n
                    const float* var_bar, const float* live, const float* imean, float* Tbar, float* VT, float* cvec);
 int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, float* out, int64_t ldo);
 
+/* ---- the whole ELBO step from ONE host call (round 3; csrc/step.hip)
+ * dsvgp_elbo_step_f32 queues forward + backward of one minibatch ELBO evaluation -- `output = model(x, derivative_directions=D);
+ * loss = -mll(output, y); loss.backward()` of the reference's train_gp (directionalvi/directional_vi.py:245-249) with the
+ * composition of DirectionalGradVariationalStrategy.forward (DGVS.py:89-208) -- as ~70 launches on two HIP streams, without a
+ * host synchronisation: the ELBO fast path (Gram formulation) of the Cholesky-whitened strategy, every data
+ * point with its p directional derivatives, explicit-inverse regime (M(p+1) <= 8192).
+ *   plan       host object for one (M, d, p, B): workspace layout, the second stream, events, pinned status word
+ *   workspace  caller-owned device memory of dsvgp_elbo_step_workspace_bytes(M, d, p, B) bytes, 256-byte aligned, kept between steps
+ *   io         device pointers (below); io->flat[0 .. flat_floats) is cleared by the call and must contain every gradient slot
+ *   flags      1: overlap on the plan's second stream; 2: include the KL term (data-parallel ranks > 0 leave it out)
+ * Gradients are those of loss = -(sum_j ll_j / global_rows - KL / num_data); a factorisation that fails leaves NaNs in the
+ * outputs and a non-zero status word: read it with dsvgp_elbo_step_status (waits for the factorisation only, not for the step)
+ * and run the jitter ladder on the piecewise path.  Threading: one host thread per context.                                  */
+typedef struct dsvgp_step_plan dsvgp_step_plan;
+typedef struct dsvgp_elbo_step_io {
+    /* parameters (float32, device): inducing points [M,d], directions [M p,d], q(u) mean [M'], Cholesky factor [M',M'] (lower
+     * triangle read), constant mean [1], raw hyper-parameters [1] each                                                       */
+    const float *Z, *V, *m, *LS; int64_t ldls;
+    const float *constant, *raw_lengthscale, *raw_outputscale, *raw_noise;
+    /* minibatch: x [B,d], interleaved targets y [B(p+1)], derivative directions D [B p, d]                                    */
+    const float *x, *y, *D;
+    /* outputs: the flat gradient buffer (cleared here) and the slots inside it; d_hyp[4] is scratch inside flat as well       */
+    float* flat; size_t flat_floats;
+    float *dZ, *dV, *dm, *dLS; int64_t lddls;
+    float *d_hyp, *d_constant, *d_raw_lengthscale, *d_raw_outputscale, *d_raw_noise, *loss;
+    float* mu;                       /* [B(p+1)] predictive mean of q(f) at the batch (constant mean included)                  */
+    double num_data, global_rows;    /* VariationalELBO num_data ((d+1) N); B'(global) of the minibatch                          */
+    float kzz_jitter;                /* LazyTensor.add_jitter() default 1e-3 (DGVS.py:144)                                      */
+} dsvgp_elbo_step_io;
+size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B);
+int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out);
+int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* plan);
+size_t dsvgp_elbo_step_plan_bytes(const dsvgp_step_plan* plan);
+int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_elbo_step_io* io, void* workspace,
+                        size_t workspace_bytes, int flags);
+int dsvgp_elbo_step_status(dsvgp_step_plan* plan, float* hyp4, int* info);
+/* flags & 4 in dsvgp_elbo_step_f32: HIP-event pairs around the forward solve, the K_ZX assembly and K_ZX-bar's kernel backward,
+ * each on the stream its kernel runs on; ms3 = their durations in ms (waits for the step) -- bench.py's roofline entries      */
+int dsvgp_elbo_step_timings(dsvgp_step_plan* plan, int steps_back, float* ms3);   /* the plan keeps the last 128 timed steps */
+
 /* ---- measurement aid (bench.py `roofline.sustained`): the MFMA rate this card holds with no memory traffic, ~`millis` ms of
  * v_mfma_f64_16x16x4_f64 (is_double = 1) or v_mfma_f32_32x32x2_f32 (0) on every CU; synchronises the stream.
  * scratch: 2 MiB of device memory.  Not part of the reference's interface (SURVEY.md 8d asks for achieved-vs-peak; the
