@@ -59,6 +59,12 @@ class ElboEngine:
         # .all_reduce_async(tensor) -> handle with .wait()
         self.collective = None
         self.global_gram = True       # ELBO fast path on > 1 rank: reduce [G ; b^T] early, split the Cholesky backward by columns
+        # global-Gram schedule: the M' x M' x M' products that every rank used to repeat -- Q' = L^-T (S - I) and
+        # L-bar = -tril([Q' | a][G ; b^T]) -- are SHARDED: rank g forms its column block of [Q' | a] (fp64 product, balanced: every
+        # column sees the whole triangle of L^-T) and its row block of L-bar, and two fp32 all-gathers (36 MB each at M' = 3000)
+        # put the whole matrices on every rank.  DSVGP_SHARD_REPLICATED=0 restores the replicated products (A/B on a node).
+        self.shard_replicated = os.environ.get("DSVGP_SHARD_REPLICATED", "1") == "1"
+        self.shard_min_mp = 1024      # below this M' the two extra collectives cost more than the products they shard
         self._early_handle = None
         self._allow_early = False
         self._global_gram = False
@@ -1112,7 +1118,8 @@ class ElboEngine:
             base, rem = divmod(M, coll.world)
             m0 = coll.rank * base + min(coll.rank, rem)
             m1 = m0 + base + (1 if coll.rank < rem else 0)
-            Kcols = self._chol_backward_cols(ctx, L, Lbar, self._buf["trsm_ws"], Mp, m0 * q, m1 * q)
+            Lb = self._lbar_f32 if getattr(self, "_lbar_f32", None) is not None else Lbar
+            Kcols = self._chol_backward_cols(ctx, L, Lb, self._buf["trsm_ws"], Mp, m0 * q, m1 * q)
             if zx_done is not None:
                 torch.cuda.current_stream(self.device).wait_event(zx_done)
             sub = (packZ[0][m0 * q:m1 * q], packZ[1][m0 * q:m1 * q])
@@ -1262,7 +1269,79 @@ class ElboEngine:
                 self._dense_done.record(torch.cuda.current_stream(dev))
             return Qe64
 
+        shard = (coll is not None and self.shard_replicated and hasattr(coll, "all_gather_async") and Mp >= self.shard_min_mp
+                 and Mp >= 4 * coll.world)
+        self.sharded_stage_used = bool(shard)
+        self._lbar_f32 = None
+
+        def solve_part_sharded():
+            """rank g: columns [c0, c1) of [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64 product, fp32 copy), all-gathered"""
+            Gw = coll.world
+            w = ((Mp + 1 + Gw - 1) // Gw + 3) // 4 * 4                      # block width: a multiple of 4 floats (16-byte loads)
+            c0 = min(coll.rank * w, Mp + 1)
+            c1 = min(c0 + w, Mp + 1)
+            loc = self._get_zeroed("Qcols32", (Mp, w), f32)                # (pad columns beyond the matrix stay zero)
+            if c1 > c0:
+                q64 = self._get("Qcols64", (Mp, w), f64)
+                _ops.trsm(ctx, L, S32e[:, c0:c1], True, q64[:, :c1 - c0], loc[:, :c1 - c0], self.trsm_nb, ws, reuse_inverse=True)
+            allq = self._get("Qall32", (Gw, Mp, w), f32)
+            return coll.all_gather_async(allq, loc), allq, w
+
+        def dense_part_sharded(h, allq, w):
+            h.wait()
+            # block-column-major [rank][M'][w] -> row-major [M'][world w] (one strided copy); columns beyond M' + 1 are the ranks'
+            # zero pads, so the k-contiguous operand is zero-filled past K as the LDS-DMA kernel wants it (K_PADDED)
+            Qfull = self._get("Qfull32", (Mp, coll.world * w), f32)
+            Qfull.view(Mp, coll.world, w).copy_(allq.permute(1, 0, 2))
+            Qe32 = Qfull[:, :Mp + 1]
+            _ops.gemm(ctx, _lib.K_PADDED, Qe32, A32e, Kb32, alpha=vbar2)
+            if self._side is not None and not self.capture_mode and not self.deterministic:
+                self._dense_done = torch.cuda.Event()
+                self._dense_done.record(torch.cuda.current_stream(dev))
+            return Qe32
+
+        def lbar_sharded(Qe32):
+            """rank g: rows [r0, r1) of L-bar = -2 vbar [Q' | a][G ; b^T] (fp32 MFMA product; only the lower triangle is read later),
+            all-gathered; the Cholesky backward takes the fp32 L-bar as the float operand of its first fp64 product"""
+            Gw = coll.world
+            wr = (Mp + Gw - 1) // Gw
+            r0 = min(coll.rank * wr, Mp)
+            r1 = min(r0 + wr, Mp)
+            loc = self._get_zeroed("Lrows32", (wr, Mp), f32)
+            if r1 > r0:
+                _ops.gemm(ctx, _lib.K_PADDED, Qe32[r0:r1], Ge, loc[:r1 - r0], alpha=-vbar2)
+            allr = self._get("Lall32", (Gw * wr, Mp), f32)
+            h = coll.all_gather_async(allr, loc)
+            h.wait()
+            self._lbar_f32 = allr[:Mp]
+
         var_done = None
+        if shard:
+            # sharded replicated stage: own columns of [Q' | a] -> all-gather (under the wait for the summed [G ; b^T] and the
+            # L_S / m gradient kernels) -> dense product -> own rows of L-bar -> all-gather
+            hq, allq, wq = solve_part_sharded()
+            ev_w = self._event_pair()
+            handle.wait()
+            self._event_done("early_reduce_wait", ev_w)
+            _ops.mirror_lower_f32_(ctx, G, Mp)
+            if self.var_overlap and self._side is not None and not self.capture_mode and not self.deterministic:
+                main = torch.cuda.current_stream(dev)
+                fork = torch.cuda.Event()
+                fork.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(fork)
+                    ctx.bind()
+                    variational_part()
+                    var_done = torch.cuda.Event()
+                    var_done.record(self._side)
+                ctx.bind()
+            else:
+                variational_part()
+            Qe32 = dense_part_sharded(hq, allq, wq)
+            lbar_sharded(Qe32)
+            if var_done is not None:
+                torch.cuda.current_stream(dev).wait_event(var_done)
+            return packX, mu
         if coll is None and self.var_overlap and self.collective is None and self._side is not None and not self.capture_mode \
                 and not self.deterministic:
             # one GPU: the L_S / m gradients (the few-tile fp32 product G L_S, trace / KL / loss kernels) need only G; they run on

@@ -70,6 +70,15 @@ class DataParallel:
             return self._rs_ag_async(t.view(-1))
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def all_gather_async(self, out, inp):
+        """out[world * n] <- the ranks' inp[n] in rank order, asynchronously (``.wait()`` orders the current stream after it).
+        RCCL: one all_gather_into_tensor; gloo (CPU rehearsal / several ranks on one card): the list form."""
+        if dist.get_backend(self.group) == "gloo":
+            n = inp.numel()
+            views = [out.view(-1)[r * n:(r + 1) * n] for r in range(self.world)]
+            return dist.all_gather(views, inp.view(-1), group=self.group, async_op=True)
+        return dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group, async_op=True)
+
     def _rs_ag_async(self, flat):
         n = flat.numel() // self.world
         shard = self._shards.get((flat.dtype, n))

@@ -63,12 +63,15 @@ def _worker(rank, world, port, out):
     Pg = {k: v.to(dev) for k, v in P.items()}
     xs, ys, Ds = x[lo:hi].to(dev), y[lo * (p + 1):hi * (p + 1)].to(dev), D[lo * p:hi * p].to(dev)
     res = {}
-    for mode, mll in (("global", "ELBO"), ("early", "ELBO"), ("early", "PLL")):
+    for mode, mll in (("global", "ELBO"), ("globalshard", "ELBO"), ("early", "ELBO"), ("early", "PLL")):
         eng = dsvgp_amd.ElboEngine(dev)
-        eng.global_gram = mode == "global"
+        eng.global_gram = mode.startswith("global")
+        eng.shard_replicated = mode == "globalshard"        # Q' columns / L-bar rows per rank + two all-gathers
+        eng.shard_min_mp = 0
         loss, grads, mu, varn = dp.loss_and_grads(eng, Pg, xs, ys, Ds, nd, mll)
         torch.cuda.synchronize()
-        assert eng.variational_grads_global == (mode == "global"), (mode, mll)
+        assert eng.variational_grads_global == mode.startswith("global"), (mode, mll)
+        assert getattr(eng, "sharded_stage_used", False) == (mode == "globalshard"), mode
         assert eng.collective is None and eng._early_handle is None
         res[mode + mll] = (loss.item(), {k: v.cpu().clone() for k, v in grads.items()})
     for name, flags, P, x, y, D, nd, pdata in _variant_problems():
@@ -108,7 +111,7 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device, dp_resul
     for mll in ("ELBO", "PLL"):
         eng = dsvgp.ElboEngine(gpu_device)
         l1, g1, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
-        for mode in (("global", "early") if mll == "ELBO" else ("early",)):
+        for mode in (("global", "globalshard", "early") if mll == "ELBO" else ("early",)):
             for r in range(3):
                 loss, grads = out[r][mode + mll]
                 assert abs(loss - l1.item()) < 2e-5 * abs(l1.item()), (mode, mll, r, loss, l1.item())
