@@ -144,6 +144,7 @@ class ElboEngine:
         self._plans = {}
         self.c_step_used = False        # whether the last step ran through the one-call path
         self.c_step_timed = []          # plans of the steps queued with record_events on, in order
+        self.host_trace = None
 
     @property
     def trsm_nb(self):
@@ -563,7 +564,8 @@ class ElboEngine:
         order = list(names[2:4]) + list(names[:2]) + list(names[4:])
         pad = lambda nk: (nk + 15) // 16 * 16                       # every segment starts 64-byte aligned
         total = sum(pad(params[k].numel()) for k in order)
-        flat = (torch.zeros if zero else torch.empty)(total + 1 + 4, dtype=f32, device=self.device)   # (zero=False: the callee clears it)
+        # (zero=False: the callee clears it; the length is rounded up to 64 floats so that one fill kernel does it)
+        flat = (torch.zeros if zero else torch.empty)((total + 1 + 4 + 63) // 64 * 64, dtype=f32, device=self.device)
         self._flat_full = flat
         views, off = {}, 0
         for k in order:
@@ -998,8 +1000,16 @@ class ElboEngine:
         io.num_data, io.global_rows, io.kzz_jitter = float(num_data), float(rows), float(self.kzz_jitter)
         overlap = self.overlap if self.overlap is not None else Mp >= 2048
         flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if self.record_events else 0)
+        tr = self.host_trace                  # (tools/host_trace.py: where the host's time goes; None in production)
+        if tr is not None:
+            import time as _t
+            t0 = _t.perf_counter()
         plan.run(ctx, ws, flags)
+        if tr is not None:
+            t1 = _t.perf_counter()
         info, hyp = plan.status()            # waits for the factorisation only; the rest of the step stays queued
+        if tr is not None:
+            tr.append((t0, t1, _t.perf_counter()))
         self._hyp_host = hyp[:3]
         if info != 0:
             raise _Refactored()

@@ -66,6 +66,7 @@ extern "C" int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N
     g.lda = lda; g.ldb = ldb; g.ldcin = ldcin; g.ldc = ldc; g.ldc32 = ldc32;
     g.alpha = alpha; g.beta = beta; g.flags = flags; g.batch = 1; g.splitk = 1;
     g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
+    if (ctx->prezeroed) g.flags |= DSVGP_GEMM_C_ZEROED;
     // split-K / tril zero-fill policy lives in launch_gemm
     return launch_gemm(ctx->stream, is_double, g);
 }
@@ -116,7 +117,7 @@ extern "C" int dsvgp_potrf_inverse(dsvgp_ctx* ctx, double* A, int n, int64_t lda
     double* Dinv = (double*)workspace;
     double* DinvT = Dinv + (size_t)n * n;
     // both images of L^-1 come out of the factorisation launches (the inverse tiles are written straight and transposed)
-    return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n, DinvT);
+    return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n, DinvT, ctx->prezeroed);
 }
 
 // First phase of dsvgp_trsm on its own: Dinv / DinvT of `workspace` from L.  potrf_workspace (may be NULL): the
@@ -207,6 +208,7 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
             f.C = T; f.ldc = nrhs;
         }
         f.slab = ctx->det_slab; f.slab_bytes = ctx->det_bytes;
+        if (ctx->prezeroed && nblk == 1) f.flags |= DSVGP_GEMM_C_ZEROED;     // (one block row: the target is used once)
         int rc = launch_gemm(st, 1, f);
         if (rc) return rc;
     }

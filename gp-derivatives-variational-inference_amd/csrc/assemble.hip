@@ -1351,6 +1351,34 @@ inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int
 
 extern "C" int dsvgp_packed_width(int d) { return ((d + 3) & ~3) + 4; }
 
+// column means + the constrained hyper-parameters (dsvgp_hyp_forward) in one launch: block 0 also writes hyp
+__global__ void column_mean_hyp_kernel(const float* __restrict__ x, int n, int d, float* __restrict__ out, const float* rl,
+                                       const float* rs, const float* rn, float* hyp) {
+    __shared__ double part[256];
+    const int k = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[(int64_t)i * d + k];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[k] = (float)(part[0] / (double)n);
+        if (k == 0) {     // softplus constraints of gpytorch Positive / GreaterThan(1e-4) (csrc/elbo.hip: hyp_forward_kernel)
+            auto sp = [](float v) { return v > 20.f ? v : log1pf(expf(v)); };
+            hyp[0] = sp(rl[0]); hyp[1] = sp(rs[0]); hyp[2] = sp(rn[0]) + 1e-4f; hyp[3] = 0.f;
+        }
+    }
+}
+int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
+                           const float* rn, float* hyp) {
+    hipLaunchKernelGGL(column_mean_hyp_kernel, dim3(d), dim3(256), 0, st, x, n, d, center, rl, rs, rn, hyp);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dsvgp_column_mean(dsvgp_ctx* ctx, const float* x, int n, int d, float* out) {
     if (!ctx || !x || !out || n < 1 || d < 1) return DSVGP_EINVAL;
     hipLaunchKernelGGL(column_mean_kernel, dim3(d), dim3(256), 0, ctx->stream, x, n, d, out);

@@ -13,6 +13,10 @@ struct dsvgp_ctx {
     // null = atomics allowed (run-order dependent rounding of sums)
     void* det_slab = nullptr;
     size_t det_bytes = 0;
+    // set by dsvgp_elbo_step_f32 (small problems) while it runs: every output that a launcher would clear before use (split-K
+    // targets, OUT_LOWER blocks, the potrf status word, the residual sums) lies in ONE region the step has cleared with a
+    // single memset -- the launchers skip their own clears (a dozen ~5 us fill launches per step at M' = 600)
+    bool prezeroed = false;
 };
 
 #define DSVGP_LAUNCH_CHECK()                                  \
@@ -53,6 +57,7 @@ static inline int slab_slices(const GemmArgs& g, int want, size_t esz) {
 int launch_splitk_reduce(hipStream_t st, int is_double, const void* slab, int nslices, int M, int N, void* C, int64_t ldc,
                          float* C32, int64_t ldc32, int out_lower, int accumulate);
 constexpr int DSVGP_GEMM_KEEP_UPPER = 1 << 20;   // internal flag (with OUT_LOWER): do not touch m < n
+constexpr int DSVGP_GEMM_C_ZEROED = 1 << 21;     // internal flag: the caller has cleared C / C32 (skip the launcher's own clears)
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
 // zero an M x N block (element size esz) with leading dimension ld: linear memset for contiguous rows, a fill kernel of our
 // own for padded rows (the runtime's pitched 2-D memset runs below 1 TB/s) -- gemm.hip
@@ -64,7 +69,15 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g);     // gemm32.hip (fp32, 3
 // blocked Cholesky (potrf.hip)
 size_t potrf_blocked_workspace_bytes(int n);
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT);
+                         double* YinvT, bool info_zeroed = false);
+// pieces of the one-call step (csrc/step.hip) that fold tiny dependent launches into their neighbours
+int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
+                           const float* rn, float* hyp);                                       // assemble.hip
+int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows);   // elbo.hip
+int launch_variational_terms(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int flags,
+                             const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,
+                             float* sums, const float* dm_src, float* d_m, float* d_LS, int64_t lddls, int fin_npts, int fin_p,
+                             float* fin_scal);                                                 // elbo.hip
 
 // trtri of the nb x nb diagonal blocks of the lower-triangular L into Dinv (same indexing as L,
 // leading dimension ldd); tmp is an n x (nb/2) double scratch.  X64 (may be null): the inverted 64 x 64 diagonal

@@ -327,6 +327,24 @@ __global__ __launch_bounds__(256) void scale3_kernel(float* __restrict__ x0, int
     }
 }
 
+// scal layout of likelihood_kernel: 0 sum_ll, 1 d_noise, 2 d_constant, 3 d_outputscale(diag), 4 d_lengthscale(diag)
+__device__ __forceinline__ void elbo_fast_finalize_body(const float* __restrict__ sums, const float* __restrict__ hyp, int npts,
+                                                        int p, float inv_rows, float* __restrict__ scal) {
+    const float ell = hyp[0], s = hyp[1], noise = hyp[2];
+    const float LOG2PI = 1.8378770664093453f;
+    const float nrow = (float)npts * (float)(p + 1);
+    const float sum_r2 = sums[0], sum_mubar = sums[1];
+    const float sum_prior = (float)npts * s * (1.f + (float)p / (ell * ell)) + nrow * 1e-4f;   // s*diag + K_XX jitter
+    const float sum_var = sum_prior + sums[2] - sums[3];
+    const float vbar = 0.5f / noise * inv_rows;                                                 // dLoss/dvar_j (constant)
+    scal[0] = -0.5f * ((sum_r2 + sum_var) / noise + nrow * (1.f + logf(noise) + LOG2PI));
+    scal[1] = 0.5f * inv_rows * (-(sum_r2 + sum_var) / (noise * noise) + nrow / noise);
+    scal[2] = sum_mubar;
+    scal[3] = vbar * (float)npts * (1.f + (float)p / (ell * ell));
+    scal[4] = vbar * (float)npts * (float)p * (-2.f * s / (ell * ell * ell));
+    scal[5] = scal[6] = scal[7] = 0.f;
+}
+
 // ---- one pass over the lower triangles of L_S and L_S-bar (round 3) ---------------------------------------------------
 // Replaces kl_kernel / kl_scaled_kernel / trace_kernel (one workgroup per row, one scalar load per thread: 0.6 TB/s, 147 +
 // 92 us at M' = 3000) by ONE WAVE per row with 16-byte loads / stores where the rows allow, rows dealt cyclically to the
@@ -340,7 +358,8 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void ls_rows_kernel(const float* __restrict__ m, const float* __restrict__ LS, int64_t ldls, int Mp,
                                                       float inv_nd, int flags, const float* __restrict__ hyp, float inv_rows,
                                                       float* __restrict__ rowkl, float* __restrict__ rowtr,
-                                                      float* __restrict__ d_m, float* __restrict__ dLS, int64_t lddls) {
+                                                      const float* __restrict__ dm_src, float* __restrict__ d_m,
+                                                      float* __restrict__ dLS, int64_t lddls) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const bool scale = flags & 1, kl = flags & 2, trace = flags & 4;
@@ -388,9 +407,10 @@ __global__ __launch_bounds__(256) void ls_rows_kernel(const float* __restrict__ 
             if (kl) {
                 const float lii = l[i], mi = m[i];
                 rowkl[i] = 0.5f * (mi * mi + sll - 1.f - logf(lii * lii));
-                d_m[i] += mi * inv_nd;
-            } else if (rowkl) {
-                rowkl[i] = 0.f;
+                d_m[i] = (dm_src ? dm_src[i] : d_m[i]) + mi * inv_nd;       // (dm_src: the data part b = A mu_bar, copied on the way)
+            } else {
+                if (rowkl) rowkl[i] = 0.f;
+                if (dm_src) d_m[i] = dm_src[i];
             }
             if (trace) rowtr[i] = slt;
         }
@@ -400,7 +420,9 @@ __global__ __launch_bounds__(256) void ls_rows_kernel(const float* __restrict__ 
 // sums[3] = trace(G) (either group optional)
 __global__ __launch_bounds__(256) void ls_rows_reduce_kernel(const float* __restrict__ rowkl, const float* __restrict__ rowtr,
                                                              const float* __restrict__ G, int64_t ldg, int n, float t1_scale,
-                                                             float* __restrict__ out_kl, float* __restrict__ sums) {
+                                                             float* __restrict__ out_kl, float* __restrict__ sums,
+                                                             const float* __restrict__ hyp, int fin_npts, int fin_p, float inv_rows,
+                                                             float* __restrict__ fin_scal) {
     __shared__ double red[3][256];
     double a = 0, b = 0, c = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -419,17 +441,19 @@ __global__ __launch_bounds__(256) void ls_rows_reduce_kernel(const float* __rest
     if (threadIdx.x == 0) {
         if (rowkl && out_kl) out_kl[0] = (float)red[0][0];
         if (rowtr && sums) { sums[2] = t1_scale * (float)red[1][0]; sums[3] = (float)red[2][0]; }
+        if (fin_scal) elbo_fast_finalize_body(sums, hyp, fin_npts, fin_p, inv_rows, fin_scal);   // (one launch fewer in the one-call step)
     }
 }
 static int launch_ls_rows(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, float inv_nd, int flags,
-                          const float* hyp, float inv_rows, float* rowkl, float* rowtr, float* d_m, float* dLS, int64_t lddls) {
+                          const float* hyp, float inv_rows, float* rowkl, float* rowtr, float* d_m, float* dLS, int64_t lddls,
+                          const float* dm_src = nullptr) {
     const bool vec = Mp % 4 == 0 && ldls % 4 == 0 && lddls % 4 == 0 && ((uintptr_t)LS % 16 == 0) && ((uintptr_t)dLS % 16 == 0);
     int blocks = cdiv(Mp, 4);
     if (blocks > 2048) blocks = 2048;
     if (vec) hipLaunchKernelGGL(ls_rows_kernel<true>, dim3(blocks), dim3(256), 0, st, m, LS, ldls, Mp, inv_nd, flags, hyp, inv_rows,
-                                rowkl, rowtr, d_m, dLS, lddls);
+                                rowkl, rowtr, dm_src, d_m, dLS, lddls);
     else hipLaunchKernelGGL(ls_rows_kernel<false>, dim3(blocks), dim3(256), 0, st, m, LS, ldls, Mp, inv_nd, flags, hyp, inv_rows,
-                            rowkl, rowtr, d_m, dLS, lddls);
+                            rowkl, rowtr, dm_src, d_m, dLS, lddls);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -485,20 +509,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const float* __restrict__ LS
 // scal layout of likelihood_kernel: 0 sum_ll, 1 d_noise, 2 d_constant, 3 d_outputscale(diag), 4 d_lengthscale(diag)
 __global__ void elbo_fast_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ hyp, int npts,
                                           int p, float inv_rows, float* __restrict__ scal) {
-    if (threadIdx.x != 0) return;
-    const float ell = hyp[0], s = hyp[1], noise = hyp[2];
-    const float LOG2PI = 1.8378770664093453f;
-    const float nrow = (float)npts * (float)(p + 1);
-    const float sum_r2 = sums[0], sum_mubar = sums[1];
-    const float sum_prior = (float)npts * s * (1.f + (float)p / (ell * ell)) + nrow * 1e-4f;   // s*diag + K_XX jitter
-    const float sum_var = sum_prior + sums[2] - sums[3];
-    const float vbar = 0.5f / noise * inv_rows;                                                 // dLoss/dvar_j (constant)
-    scal[0] = -0.5f * ((sum_r2 + sum_var) / noise + nrow * (1.f + logf(noise) + LOG2PI));
-    scal[1] = 0.5f * inv_rows * (-(sum_r2 + sum_var) / (noise * noise) + nrow / noise);
-    scal[2] = sum_mubar;
-    scal[3] = vbar * (float)npts * (1.f + (float)p / (ell * ell));
-    scal[4] = vbar * (float)npts * (float)p * (-2.f * s / (ell * ell * ell));
-    scal[5] = scal[6] = scal[7] = 0.f;
+    if (threadIdx.x == 0) elbo_fast_finalize_body(sums, hyp, npts, p, inv_rows, scal);
 }
 __global__ void mirror_lower_f32_kernel(float* __restrict__ G, int n, int64_t ldg) {
     __shared__ float tile[32][33];
@@ -655,7 +666,7 @@ extern "C" int dsvgp_kl_terms(dsvgp_ctx* ctx, const float* m, const float* LS, i
     int rc = launch_ls_rows(ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data), 2, nullptr, 0.f, kl_out + 1, nullptr, d_m, d_LS, lddls);
     if (rc) return rc;
     hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), (const float*)nullptr,
-                       (const float*)nullptr, (int64_t)0, Mp, 0.f, kl_out, (float*)nullptr);
+                       (const float*)nullptr, (int64_t)0, Mp, 0.f, kl_out, (float*)nullptr, (const float*)nullptr, 0, 0, 0.f, (float*)nullptr);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -746,8 +757,10 @@ extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* pa
 extern "C" int dsvgp_residual_terms(dsvgp_ctx* ctx, const float* mu, const float* y, int ncols, const float* hyp,
                                     double global_rows, float* mu_bar, float* sums) {
     if (!ctx || !mu || !y || !hyp || !mu_bar || !sums || ncols < 0 || global_rows <= 0) return DSVGP_EINVAL;
-    hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(float), ctx->stream);
-    if (e != hipSuccess) return 1000 + (int)e;
+    if (!ctx->prezeroed) {
+        hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(float), ctx->stream);
+        if (e != hipSuccess) return 1000 + (int)e;
+    }
     if (ncols == 0) return 0;
     int blocks = cdiv(ncols, 256);
     if (blocks > 512) blocks = 512;
@@ -793,6 +806,38 @@ extern "C" int dsvgp_add_diag_f32(dsvgp_ctx* ctx, float* A, int n, int64_t lda, 
 extern "C" int dsvgp_sminus_i_col(dsvgp_ctx* ctx, float* A, int n, int64_t lda, const float* m, const float* hyp, double rows) {
     if (!ctx || !A || !m || !hyp || n <= 0 || lda < n + 1) return DSVGP_EINVAL;
     hipLaunchKernelGGL(sminus_i_col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, m, hyp, (float)rows);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// mirror the lower triangle of A[n, n] onto its upper triangle AND A[i][i] -= 1, A[i][n] = m[i] noise rows: dsvgp_mirror_lower_f32
+// + dsvgp_sminus_i_col in one launch (the diagonal blocks do the extra work after their mirror)
+__global__ void mirror_sminus_kernel(float* __restrict__ G, int n, int64_t ldg, const float* __restrict__ m,
+                                     const float* __restrict__ hyp, float rows) {
+    __shared__ float tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bj * 32 + r, gj = bi * 32 + tx;
+        tile[r][tx] = (gi < n && gj < n) ? G[(int64_t)gi * ldg + gj] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bi * 32 + r, gj = bj * 32 + tx;
+        if (gi < n && gj < n && gj > gi) G[(int64_t)gi * ldg + gj] = tile[tx][r];
+    }
+    if (bi == bj && ty == 0) {
+        const int i = bi * 32 + tx;
+        if (i < n) {
+            G[(int64_t)i * ldg + i] -= 1.f;
+            G[(int64_t)i * ldg + n] = m[i] * (hyp[2] * rows);
+        }
+    }
+}
+int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows) {
+    const int nb = cdiv(n, 32);
+    hipLaunchKernelGGL(mirror_sminus_kernel, dim3(nb, nb), dim3(32, 8), 0, st, A, n, lda, m, hyp, rows);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -864,7 +909,7 @@ extern "C" int dsvgp_kl_terms_scaled(dsvgp_ctx* ctx, const float* m, const float
                             kl_out + 1, nullptr, d_m, d_LS, lddls);
     if (rc) return rc;
     hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1), (const float*)nullptr,
-                       (const float*)nullptr, (int64_t)0, Mp, 0.f, kl_out, (float*)nullptr);
+                       (const float*)nullptr, (int64_t)0, Mp, 0.f, kl_out, (float*)nullptr, (const float*)nullptr, 0, 0, 0.f, (float*)nullptr);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
@@ -873,17 +918,25 @@ extern "C" int dsvgp_kl_terms_scaled(dsvgp_ctx* ctx, const float* m, const float
 //   sums[2] = t1_scale * sum_{i>=j} L_S,ij T_ij (= |L_S^T A|_F^2), sums[3] = trace(G), kl_out[0] = KL (0 without the KL flag),
 //   d_LS <- [scale] T + dKL/dL_S / num_data, d_m += m / num_data.   kl_out: 1 + 2 Mp floats (value + per-row scratch).
 // No atomics: per-row partials + a fixed-order reduction (bitwise reproducible).
+int launch_variational_terms(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int flags,
+                             const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,
+                             float* sums, const float* dm_src, float* d_m, float* d_LS, int64_t lddls, int fin_npts, int fin_p,
+                             float* fin_scal) {
+    int rc = launch_ls_rows(st, m, LS, ldls, Mp, (float)(1.0 / num_data), flags | 4, hyp, (float)(1.0 / global_rows),
+                            kl_out + 1, kl_out + 1 + Mp, d_m, d_LS, lddls, dm_src);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)(kl_out + 1),
+                       (const float*)(kl_out + 1 + Mp), G, ldg, Mp, t1_scale, kl_out, sums, hyp, fin_npts, fin_p,
+                       (float)(1.0 / global_rows), fin_scal);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int dsvgp_variational_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int64_t ldls, int Mp, double num_data,
                                        int flags, const float* hyp, double global_rows, const float* G, int64_t ldg,
                                        float t1_scale, float* kl_out, float* sums, float* d_m, float* d_LS, int64_t lddls) {
     if (!ctx || !m || !LS || !kl_out || !sums || !d_m || !d_LS || !G || Mp <= 0 || num_data <= 0 || global_rows <= 0 ||
         ((flags & 1) && !hyp) || (flags & ~3))
         return DSVGP_EINVAL;
-    int rc = launch_ls_rows(ctx->stream, m, LS, ldls, Mp, (float)(1.0 / num_data), flags | 4, hyp, (float)(1.0 / global_rows),
-                            kl_out + 1, kl_out + 1 + Mp, d_m, d_LS, lddls);
-    if (rc) return rc;
-    hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)(kl_out + 1),
-                       (const float*)(kl_out + 1 + Mp), G, ldg, Mp, t1_scale, kl_out, sums);
-    DSVGP_LAUNCH_CHECK();
-    return 0;
+    return launch_variational_terms(ctx->stream, m, LS, ldls, Mp, num_data, flags, hyp, global_rows, G, ldg, t1_scale, kl_out, sums,
+                                    nullptr, d_m, d_LS, lddls, 0, 0, nullptr);
 }

@@ -594,7 +594,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
             a.splitk = sk;
             if (a.C32) { cvt32 = a.C32; a.C32 = nullptr; }
             if (inplace_acc) { a.Cin = nullptr; a.beta = 0.0; det_acc = true; }      // the slices accumulate onto the existing C
-            else if (!a.slab) {
+            else if (!a.slab && !(g.flags & DSVGP_GEMM_C_ZEROED)) {
                 hipError_t e = zero_block(a.C, esz, a.ldc, a.M, a.N, st);
                 if (e != hipSuccess) return 1000 + (int)e;
             }
@@ -602,7 +602,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
     }
     if (a.splitk == 1) a.slab = nullptr;                             // (caller-requested split-K keeps its slab)
     else if (a.slab && slab_slices(a, a.splitk, esz) != a.splitk) return DSVGP_ENOSPACE;
-    if (out_lower && !keep_upper && a.splitk == 1 && a.batch == 1 && g.Cin != g.C) {
+    if (out_lower && !keep_upper && a.splitk == 1 && a.batch == 1 && g.Cin != g.C && !(g.flags & DSVGP_GEMM_C_ZEROED)) {
         // supertiles strictly above the diagonal are never visited: define them as zero up front
         hipError_t e = a.C ? zero_block(a.C, esz, a.ldc, a.M, a.N, st) : hipSuccess;
         if (e != hipSuccess) return 1000 + (int)e;

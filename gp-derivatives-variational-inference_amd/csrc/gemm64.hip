@@ -40,6 +40,9 @@ struct G64 {
 #ifndef G64_KCHUNK
 #define G64_KCHUNK 768      // split-K chunk (512 / 768 / 1024 measured within 0.3 %) of the few-tile (M' x M' x M') products: the longest tile's 188 dependent stages (K = 3000) set
 #endif                      // the duration of a launch whose ~1100-2200 tiles are all resident at once
+#ifndef G64_STORE_SWZ
+#define G64_STORE_SWZ 0     // 1: bank-conflict-free order of the two 16-byte LDS stores of a staged thread (probe)
+#endif
 #ifndef G64_BAND
 #define G64_BAND 16         // tile columns per band (probed 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 56.5 / 57.1 / 60.8 / 62.8 / 63.4 / 57.0 / 62.6 / 54.2 TF) of the XCD-local walk
 #endif
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
 
     // staging: thread -> (k = tid / 16, 4 consecutive columns at 4 (tid % 16)) of the 16 x 64 stage of each operand
     const int sk = tid >> 4, sc = (tid & 15) * 4;
+    const bool hs = (tid >> 2) & 1;
     const double* __restrict__ Ap = g.A + m0 + sc;
     const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc;
     const bool a_in = m0 + T <= g.M, b_in = n0 + T <= g.N;
@@ -167,10 +171,22 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
         for (int k0 = klo; k0 < khi; k0 += BK) {
             double* as = As + sk * LDS_STRIDE + sc;
             double* bs = Bs + sk * LDS_STRIDE + sc;
+#if G64_STORE_SWZ
+            // a thread's 32 bytes go out as two 16-byte stores; with every lane storing its first half first, lanes L and L + 4 of
+            // an 8-lane store group hit the same four banks (lane stride 32 B): lanes 4..7 store their halves in the opposite order
+            {
+                const int o0 = hs ? 2 : 0, o1 = hs ? 0 : 2;
+                *reinterpret_cast<double2*>(as + o0) = hs ? double2{ra[2], ra[3]} : double2{ra[0], ra[1]};
+                *reinterpret_cast<double2*>(as + o1) = hs ? double2{ra[0], ra[1]} : double2{ra[2], ra[3]};
+                *reinterpret_cast<double2*>(bs + o0) = hs ? double2{rb[2], rb[3]} : double2{rb[0], rb[1]};
+                *reinterpret_cast<double2*>(bs + o1) = hs ? double2{rb[0], rb[1]} : double2{rb[2], rb[3]};
+            }
+#else
             *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
             *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
             *reinterpret_cast<double2*>(bs) = double2{rb[0], rb[1]};
             *reinterpret_cast<double2*>(bs + 2) = double2{rb[2], rb[3]};
+#endif
             __syncthreads();
             if (k0 + BK < khi) fetch(k0 + BK);               // in flight under the 16 MFMAs of this stage
             if (G64_PRIO) __builtin_amdgcn_s_setprio(1);
@@ -260,7 +276,7 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
             if (fit < ysplit) { a.kchunk = fit > 1 ? cdiv(cdiv(g.K, fit), BK) * BK : 0; ysplit = a.kchunk ? cdiv(g.K, a.kchunk) : 1; }
             if (a.kchunk) a.slab = (double*)g.slab;
         }
-        if (a.kchunk && !a.slab) {
+        if (a.kchunk && !a.slab && !(fl & DSVGP_GEMM_C_ZEROED)) {
             hipError_t ez = zero_block(a.C, sizeof(double), a.ldc, a.M, a.N, st);
             if (ez != hipSuccess) return 1000 + (int)ez;
         }

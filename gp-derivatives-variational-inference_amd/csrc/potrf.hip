@@ -735,9 +735,11 @@ size_t potrf_blocked_workspace_bytes(int n) {
 // (lower triangle, leading dimension ldy) by the fused forward elimination, and (YinvT != nullptr) its transpose with the
 // same leading dimension.
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT) {
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
-    if (e != hipSuccess) return 1000 + (int)e;
+                         double* YinvT, bool info_zeroed) {
+    if (!info_zeroed) {
+        hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
+        if (e != hipSuccess) return 1000 + (int)e;
+    }
     const int nblk = cdiv(n, NBC);
     double* Xws = ws;
     double* Wws = ws + (size_t)nblk * NBC * NBC;

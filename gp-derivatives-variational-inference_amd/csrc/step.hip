@@ -46,7 +46,8 @@ struct dsvgp_step_plan {
     size_t o_zero, zero_bytes;        // region cleared at the start of every step: info, sums, kl_buf
     size_t o_info, o_sums, o_klbuf, o_scal, o_hyp, o_center;
     size_t o_PZ, o_sZ, o_vZ, o_PX, o_sX, o_vX;
-    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_Qe32, o_Kb32, o_Lbar, o_G1, o_kbwd, o_kbwd2;
+    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_Qe32, o_Kb32, o_Lbar, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2;
+    size_t o_arena, arena_bytes;     // contiguous region of everything a launcher would clear (see step_layout)
     int ldS, ldQ32;
     const void* pad_ready_for = nullptr;          // the workspace whose Qe32 pad columns have been zeroed
     hipStream_t side = nullptr;
@@ -69,24 +70,38 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl) {
     pl->M = M; pl->d = d; pl->p = p; pl->B = B; pl->Mp = Mp; pl->Bp = Bp; pl->DP = DP; pl->nb = auto_nb(Mp);
     pl->ldS = pad4(Mp + 1); pl->ldQ32 = pad4(Mp + 1);
     Carve c;
-    // zeroed head: info[4 ints] | sums[4] | kl_buf[2 M' + 1]
-    pl->o_zero = c.off;
-    pl->zero_bytes = 4 * sizeof(int) + 4 * sizeof(float) + (size_t)(2 * Mp + 1) * sizeof(float);
-    pl->o_info = c.take(pl->zero_bytes);
-    pl->o_sums = pl->o_info + 4 * sizeof(int);
-    pl->o_klbuf = pl->o_sums + 4 * sizeof(float);
-    pl->o_scal = c.take(8 * sizeof(float)); pl->o_hyp = c.take(4 * sizeof(float)); pl->o_center = c.take((size_t)d * sizeof(float));
+    pl->o_scal = c.take(8 * sizeof(float)); pl->o_center = c.take((size_t)d * sizeof(float));
     pl->o_PZ = c.take((size_t)Mp * DP * 4); pl->o_sZ = c.take((size_t)Mp * 4); pl->o_vZ = c.take((size_t)(M * p > 0 ? M * p : 1) * 4);
     pl->o_PX = c.take((size_t)Bp * DP * 4); pl->o_sX = c.take((size_t)Bp * 4); pl->o_vX = c.take((size_t)(B * p > 0 ? B * p : 1) * 4);
     pl->o_L = c.take((size_t)Mp * Mp * 8);
-    pl->o_trsm = c.take(dsvgp_trsm_workspace_bytes(Mp, Bp > Mp + 1 ? Bp : Mp + 1, pl->nb));
     pl->o_potrf = c.take(potrf_blocked_workspace_bytes(Mp));
-    pl->o_Kzx = c.take((size_t)Mp * Bp * 4); pl->o_A32e = c.take((size_t)(Mp + 1) * Bp * 4); pl->o_S32e = c.take((size_t)Mp * pl->ldS * 4);
+    pl->o_Kzx = c.take((size_t)Mp * Bp * 4); pl->o_A32e = c.take((size_t)(Mp + 1) * Bp * 4);
     pl->o_var0 = c.take((size_t)Bp * 4); pl->o_stats = c.take(dsvgp_stats_workspace_bytes(Mp, Bp) + 16);
-    pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 1) * 8 + 64); pl->o_Qe32 = c.take((size_t)Mp * pl->ldQ32 * 4);
-    pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_Lbar = c.take((size_t)Mp * Mp * 8); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
+    pl->o_Qe32 = c.take((size_t)Mp * pl->ldQ32 * 4);
     const size_t kb = dsvgp_kernel_bwd_workspace_bytes(M, B, d, p), kz = dsvgp_kernel_bwd_workspace_bytes(M, M, d, p);
     pl->o_kbwd = c.take(kb > kz ? kb : kz); pl->o_kbwd2 = c.take(kb);
+    // ---- the "arena": every buffer that some launcher clears before use (split-K targets, OUT_LOWER outputs), contiguous, so that
+    // a small problem clears all of them with ONE memset (prezeroed mode below).  The solve workspace comes first: its scratch
+    // T (the fp64 split-K target of a small fp32-only solve) is its tail, [trsm end - T bytes, trsm end).
+    const int nrhs_max = Bp > Mp + 1 ? Bp : Mp + 1;
+    const size_t trsm_bytes = dsvgp_trsm_workspace_bytes(Mp, nrhs_max, pl->nb);
+    pl->o_trsm = c.take(trsm_bytes);
+    // (dsvgp_trsm's layout: [L^-1 | L^-T | tmp (n + b) (b / 2) | T b x nrhs] doubles, b = nb here since nb / 2 < M' <= nb)
+    pl->o_arena = (pl->o_trsm + sizeof(double) * ((size_t)2 * Mp * Mp + (size_t)(Mp + pl->nb) * (pl->nb / 2))) / 256 * 256;   // (aligned down into
+    // the trtri scratch `tmp`, which the fused factorisation + inverse never uses: one aligned fill kernel)
+    pl->o_S32e = c.take((size_t)Mp * pl->ldS * 4);
+    pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 1) * 8 + 64);
+    pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_Lbar = c.take((size_t)Mp * Mp * 8); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
+    pl->o_Yt = c.take((size_t)Mp * Mp * 8); pl->o_Kbar = c.take((size_t)Mp * Mp * 8);
+    // head: hyp[4] | info[4 ints] | sums[4] | kl_buf[2 M' + 1]   (cleared every step; hyp + info go to the host in ONE copy).
+    // It closes the arena, so that the small-problem mode clears both with one memset.
+    pl->o_zero = c.off;
+    pl->zero_bytes = (4 * sizeof(float) + 4 * sizeof(int) + 4 * sizeof(float) + (size_t)(2 * Mp + 1) * sizeof(float) + 255) / 256 * 256;
+    pl->o_hyp = c.take(pl->zero_bytes);
+    pl->o_info = pl->o_hyp + 4 * sizeof(float);
+    pl->o_sums = pl->o_info + 4 * sizeof(int);
+    pl->o_klbuf = pl->o_sums + 4 * sizeof(float);
+    pl->arena_bytes = c.off - pl->o_arena;            // (T tail of the solve workspace ... head)
     pl->bytes = c.off + 256;
     return pl->bytes;
 }
@@ -210,6 +225,8 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     float* Kb32 = (float*)(w + pl->o_Kb32);
     double* Lbar = (double*)(w + pl->o_Lbar);
     double* G1 = (double*)(w + pl->o_G1);
+    double* Yt = (double*)(w + pl->o_Yt);
+    double* Kbar = (double*)(w + pl->o_Kbar);
     void* kbwd_ws = w + pl->o_kbwd;
     void* kbwd_ws2 = w + pl->o_kbwd2;
     const int ldS = pl->ldS, ldQ32 = pl->ldQ32;
@@ -221,16 +238,25 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
 #define STEP_TIME(slot) do { if (timed) STEP_HIP(hipEventRecord(pl->tm[slot], ctx->stream)); } while (0)
     const hipStream_t main = ctx->stream, side = pl->side;
 
-    // ---- clears: gradient slots + loss, the status / sums / KL scratch; once per workspace the pad columns of [Q' | a] (fp32)
+    // ---- clears: gradient slots + loss, the status / sums / KL scratch; once per workspace the pad columns of [Q' | a] (fp32).
+    // Small problems (launch-bound: M' of a few hundred) also clear the whole arena of split-K / OUT_LOWER outputs here, ONCE,
+    // and tell the launchers so (ctx->prezeroed): a dozen ~5 us fill launches fewer per step.  Large problems keep the launchers'
+    // own clears (only the products that actually split K clear anything there).
+    const bool prezero = pl->arena_bytes <= ((size_t)48 << 20) && !ctx->det_slab;
     STEP_HIP(hipMemsetAsync(io->flat, 0, io->flat_floats * sizeof(float), main));
-    STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
+    if (prezero) STEP_HIP(hipMemsetAsync(w + pl->o_arena, 0, pl->arena_bytes, main));
+    else STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
     if (pl->pad_ready_for != workspace) {
         STEP_HIP(hipMemsetAsync(Qe32, 0, (size_t)Mp * ldQ32 * sizeof(float), main));
         pl->pad_ready_for = workspace;
     }
-    // ---- hyper-parameters, centre, packed inducing rows (DGVS.py:128-149 via RBFKernelDirectionalGrad.py:57-107)
-    STEP_CALL(dsvgp_hyp_forward(ctx, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp));
-    STEP_CALL(dsvgp_column_mean(ctx, io->Z, M, d, center));
+    struct PrezeroGuard {               // (the flag must not outlive the call, whatever path returns)
+        dsvgp_ctx* c; bool prev;
+        PrezeroGuard(dsvgp_ctx* c_, bool on) : c(c_), prev(c_->prezeroed) { c->prezeroed = on; }
+        ~PrezeroGuard() { c->prezeroed = prev; }
+    } prezero_guard(ctx, prezero);
+    // ---- hyper-parameters + centre (one launch), packed inducing rows (DGVS.py:128-149 via RBFKernelDirectionalGrad.py:57-107)
+    STEP_CALL(launch_column_mean_hyp(main, io->Z, M, d, center, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp));
     STEP_CALL(dsvgp_pack_points(ctx, io->Z, io->V, M, d, p, hyp, center, PZ, sZ, vZ));
     // ---- prologue that does not depend on L: pack x, K_ZX, [S - I | m / (2 vbar)] -- on the side stream under the Cholesky chain
     auto prologue = [&](bool background) -> int {
@@ -245,9 +271,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
                         (background ? DSVGP_GEMM_BACKGROUND : 0), Mp, Mp, Mp, 1.0, io->LS, io->ldls, io->LS, io->ldls, 0.0, nullptr, 0,
                         S32e, ldS, nullptr, 0, nullptr);
         if (rc) return rc;
-        rc = dsvgp_mirror_lower_f32(ctx, S32e, Mp, ldS);
-        if (rc) return rc;
-        return dsvgp_sminus_i_col(ctx, S32e, Mp, ldS, io->m, hyp, rows);
+        return launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows);     // mirror + [S - I | m / (2 vbar)]
     };
     if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork, main));
@@ -260,8 +284,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip)
     STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
     STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
-    STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 4 * sizeof(float), hipMemcpyDeviceToHost, main));
-    STEP_HIP(hipMemcpyAsync(pl->host_status + 4, info, sizeof(int), hipMemcpyDeviceToHost, main));
+    STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));     // hyp[4] | info: contiguous
     STEP_HIP(hipEventRecord(pl->ev_status, main));
     if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_side, 0));
     else STEP_CALL(prologue(false));
@@ -282,12 +305,10 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         int rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, Ge, Mp, io->LS, io->ldls, 0.0, nullptr, 0,
                             io->dLS, io->lddls, nullptr, 0, nullptr);
         if (rc) return rc;
-        hipError_t e = hipMemcpyAsync(io->dm, Ge + (size_t)Mp * Mp, (size_t)Mp * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) return 1000 + (int)e;
-        rc = dsvgp_variational_terms(ctx, io->m, io->LS, io->ldls, Mp, io->num_data, 1 | (include_kl ? 2 : 0), hyp, rows, Ge, Mp, 1.f,
-                                     kl_buf, sums, io->dm, io->dLS, io->lddls);
-        if (rc) return rc;
-        return dsvgp_elbo_fast_finalize(ctx, sums, hyp, B, p, rows, scal);
+        // one pass + one reduction launch: m-bar = b + KL gradient (b = row M' of [G ; b^T], copied on the way), trace terms, scaling,
+        // KL, and the scalar assembly of dsvgp_elbo_fast_finalize in the reduction's last thread
+        return launch_variational_terms(ctx->stream, io->m, io->LS, io->ldls, Mp, io->num_data, 1 | (include_kl ? 2 : 0), hyp, rows, Ge, Mp,
+                                        1.f, kl_buf, sums, Ge + (size_t)Mp * Mp, io->dm, io->dLS, io->lddls, B, p, scal);
     };
     // ---- [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64), K_ZX-bar = [Q' | a] [A ; mu_bar^T] (fp32, unscaled)
     auto solve = [&]() -> int {
@@ -335,12 +356,12 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
                          Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));
     STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));
     STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
-                         nullptr, 0, Lbar, Mp, nullptr, 0, nullptr));
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Lbar, Mp, 0.0,
-                         nullptr, 0, G1, Mp, nullptr, 0, nullptr));
-    STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));
+                         nullptr, 0, Yt, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0,
+                         nullptr, 0, Kbar, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_phi_symmetrize(ctx, Kbar, Mp, Mp));
     if (zx_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
-    STEP_CALL(dsvgp_kernel_bwd(ctx, G1, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
     // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
     STEP_CALL(dsvgp_scale_by_vbar(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, io->d_hyp, 2, hyp, rows));
     STEP_CALL(dsvgp_step_epilogue(ctx, scal, kl_buf, rows, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
