@@ -1264,7 +1264,7 @@ class ElboEngine:
 
         def solve_part():
             # Q' = L^-T (S - I), a = L^-T m  (fp64 solves), both also as fp32 copies
-            Qe64 = self._get("Qe64", (Mp, Mp + 1), f64)
+            Qe64 = self._get("Qe64", (Mp, (Mp + 2) // 2 * 2), f64)[:, :Mp + 1]     # (even rows: 16-byte loads in the fp32 conversion pass)
             # fp32 copy with rows padded to a multiple of 4 floats, pad zeroed once: the LDS-DMA GEMM (gemm32.hip) streams the
             # k-contiguous [Q' | a] in 16-byte chunks and takes K = M' + 1 as it lies in memory (DSVGP_GEMM_K_PADDED)
             Qe32 = self._get_zeroed("Qe32_pad", (Mp, (Mp + 1 + 3) // 4 * 4), f32)[:, :Mp + 1]

@@ -495,18 +495,22 @@ __global__ __launch_bounds__(256) void trtri64_copy_kernel(const double* __restr
 // kernel of our own (the pitched 2-D memset kernel of the runtime moves < 1 TB/s: ~100 us for a 3000 x 3000 output)
 template <typename T>
 __global__ __launch_bounds__(256) void zero_rows_kernel(T* __restrict__ C, int64_t ld, int M, int N) {
-    const int64_t total = (int64_t)M * N;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t r = e / N;
-        C[r * ld + (e - r * N)] = T(0);
+    // rows over blockIdx.y, 16 bytes per thread where the row start allows it (no per-element 64-bit division)
+    constexpr int V = 16 / sizeof(T);
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (c0 >= N) return;
+    const bool vec = (ld % V == 0) && ((uintptr_t)C % 16 == 0) && c0 + V <= N;
+    for (int r = blockIdx.y; r < M; r += gridDim.y) {
+        T* dst = C + (int64_t)r * ld + c0;
+        if (vec) *reinterpret_cast<float4*>(dst) = float4{0.f, 0.f, 0.f, 0.f};
+        else
+            for (int e = 0; e < V && c0 + e < N; ++e) dst[e] = T(0);
     }
 }
 hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st) {
     if (ld == N) return hipMemsetAsync(C, 0, esz * (size_t)M * (size_t)N, st);
-    const int64_t total = (int64_t)M * N;
-    const int blocks = (int)((total + 256 * 8 - 1) / (256 * 8) < 4096 ? (total + 256 * 8 - 1) / (256 * 8) : 4096);
-    if (esz == 8) hipLaunchKernelGGL(zero_rows_kernel<double>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, (double*)C, ld, M, N);
-    else if (esz == 4) hipLaunchKernelGGL(zero_rows_kernel<float>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, (float*)C, ld, M, N);
+    if (esz == 8) hipLaunchKernelGGL(zero_rows_kernel<double>, dim3(cdiv(N, 256 * 2), M < 2048 ? M : 2048), dim3(256), 0, st, (double*)C, ld, M, N);
+    else if (esz == 4) hipLaunchKernelGGL(zero_rows_kernel<float>, dim3(cdiv(N, 256 * 4), M < 2048 ? M : 2048), dim3(256), 0, st, (float*)C, ld, M, N);
     else return hipMemset2DAsync(C, esz * (size_t)ld, 0, esz * (size_t)N, (size_t)M, st);
     return hipGetLastError();
 }

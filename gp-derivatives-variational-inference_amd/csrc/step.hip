@@ -90,7 +90,7 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl) {
     pl->o_arena = (pl->o_trsm + sizeof(double) * ((size_t)2 * Mp * Mp + (size_t)(Mp + pl->nb) * (pl->nb / 2))) / 256 * 256;   // (aligned down into
     // the trtri scratch `tmp`, which the fused factorisation + inverse never uses: one aligned fill kernel)
     pl->o_S32e = c.take((size_t)Mp * pl->ldS * 4);
-    pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 1) * 8 + 64);
+    pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 2) * 8 + 64);
     pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_Lbar = c.take((size_t)Mp * Mp * 8); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
     pl->o_Yt = c.take((size_t)Mp * Mp * 8); pl->o_Kbar = c.take((size_t)Mp * Mp * 8);
     // head: hyp[4] | info[4 ints] | sums[4] | kl_buf[2 M' + 1]   (cleared every step; hyp + info go to the host in ONE copy).
@@ -229,7 +229,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     double* Kbar = (double*)(w + pl->o_Kbar);
     void* kbwd_ws = w + pl->o_kbwd;
     void* kbwd_ws2 = w + pl->o_kbwd2;
-    const int ldS = pl->ldS, ldQ32 = pl->ldQ32;
+    const int ldS = pl->ldS, ldQ32 = pl->ldQ32, ldQ64 = (Mp + 2) / 2 * 2;     // (even fp64 rows: 16-byte loads in the conversion pass)
     const double rows = io->global_rows;
     const bool overlap = (flags & 1) && !ctx->det_slab;           // (deterministic mode: the scratch serves one stream)
     const bool include_kl = flags & 2, timed = flags & 4;
@@ -312,7 +312,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     };
     // ---- [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64), K_ZX-bar = [Q' | a] [A ; mu_bar^T] (fp32, unscaled)
     auto solve = [&]() -> int {
-        int rc = dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, Qe64, Mp + 1, Qe32, ldQ32, nb, trsm_ws, 1);
+        int rc = dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, Qe64, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
         if (rc) return rc;
         return dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qe32, ldQ32, A32e, Bp, 0.0, nullptr, 0, Kb32, Bp, nullptr, 0,
                           nullptr);
@@ -342,7 +342,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         ctx->stream = main;
     }
     // ---- L-bar = -tril([Q' | a] [G ; b^T]) (fp64), joined with the variational block
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, Qe64, Mp + 1, Ge, Mp, 0.0, nullptr, 0,
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, Qe64, ldQ64, Ge, Mp, 0.0, nullptr, 0,
                          Lbar, Mp, nullptr, 0, nullptr));
     if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
     if (!zx_side) {

@@ -357,7 +357,20 @@ def test_c5_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, st
             # 0.15 and 0.01.  So these two gradients are held to the reference's own fp32 round-off here, and to 2e-2 in the
             # well-scaled "mid" state.
             loose = state == "init" and k in ("g_inducing_points", "g_inducing_directions")
-            assert v < (0.35 if loose else 2e-2), (k, v)
+            if not loose:
+                assert v < 2e-2, (k, v)
+    if state == "init":
+        # dZ / dV at the init state, numerically: against the FLOAT64 oracle (tests/golden/c5_init_refseq.npz,
+        # oracle/make_c5_refseq_fixture.py) the HIP step must be no worse than the reference's OWN kernel op sequence evaluated in
+        # fp32 on the CPU (kernel_matrix_refseq: 0.343 / 0.0011 off float64), and within 5e-2 / 5e-3 of float64 outright.
+        # Measured on MI355X (round 3): 7.0e-3 / 4.7e-4 -- the distance of 0.15 / 0.01 to the committed fp32 vector
+        # (c5_step_init.npz, pair-wise form) seen in the loop above is that vector's own round-off (0.148 / 0.0104 off float64).
+        r = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_init_refseq.npz"))
+        for k in ("inducing_points", "inducing_directions"):
+            e_hip = relmax(grads[k], torch.from_numpy(r["g64_" + k]))
+            e_ref, e_pw = float(r["err_refseq32_" + k]), float(r["err_pairwise32_" + k])
+            print("[parity] C5 init %s vs float64: HIP %.3e, reference op sequence in fp32 %.3e, pair-wise fp32 %.3e" % (k, e_hip, e_ref, e_pw))
+            assert e_hip <= e_ref and e_hip < (5e-2 if k == "inducing_points" else 5e-3), (k, e_hip, e_ref, e_pw)
 
 
 @pytest.mark.gpu
