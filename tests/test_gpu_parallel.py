@@ -63,11 +63,12 @@ def _worker(rank, world, port, out):
     Pg = {k: v.to(dev) for k, v in P.items()}
     xs, ys, Ds = x[lo:hi].to(dev), y[lo * (p + 1):hi * (p + 1)].to(dev), D[lo * p:hi * p].to(dev)
     res = {}
-    for mode, mll in (("global", "ELBO"), ("globalshard", "ELBO"), ("early", "ELBO"), ("early", "PLL")):
+    for mode, mll in (("global", "ELBO"), ("globalshard", "ELBO"), ("globaldet", "ELBO"), ("early", "ELBO"), ("early", "PLL")):
         eng = dsvgp_amd.ElboEngine(dev)
         eng.global_gram = mode.startswith("global")
         eng.shard_replicated = mode == "globalshard"        # Q' columns / L-bar rows per rank + two all-gathers
         eng.shard_min_mp = 0
+        eng.deterministic = mode == "globaldet"             # fixed-order sums: the replicas' L_S-bar must be BITWISE equal
         loss, grads, mu, varn = dp.loss_and_grads(eng, Pg, xs, ys, Ds, nd, mll)
         torch.cuda.synchronize()
         assert eng.variational_grads_global == mode.startswith("global"), (mode, mll)
@@ -111,7 +112,7 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device, dp_resul
     for mll in ("ELBO", "PLL"):
         eng = dsvgp.ElboEngine(gpu_device)
         l1, g1, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
-        for mode in (("global", "globalshard", "early") if mll == "ELBO" else ("early",)):
+        for mode in (("global", "globalshard", "globaldet", "early") if mll == "ELBO" else ("early",)):
             for r in range(3):
                 loss, grads = out[r][mode + mll]
                 assert abs(loss - l1.item()) < 2e-5 * abs(l1.item()), (mode, mll, r, loss, l1.item())
@@ -124,6 +125,16 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device, dp_resul
                 assert torch.equal(out[0][mode + mll][1][k], out[1][mode + mll][1][k]) or \
                     (out[0][mode + mll][1][k] - out[1][mode + mll][1][k]).abs().max().item() < 1e-6 * max(
                         g1[k].abs().max().item(), 1e-30), (mode, mll, k)
+
+
+@pytest.mark.timeout(600)
+def test_deterministic_replicas_are_bitwise_equal(dsvgp, gpu_device, dp_results):
+    """global-Gram schedule under ``ElboEngine.deterministic``: every rank forms L_S-bar / m-bar itself from the same reduced
+    [G ; b^T] with fixed-order sums, so the replicas agree bit for bit (what lets ``DataParallel.resync`` be skipped)"""
+    out = dp_results
+    for k in ("variational_mean", "chol_variational_covar"):
+        for r in (1, 2):
+            assert torch.equal(out[0]["globaldetELBO"][1][k], out[r]["globaldetELBO"][1][k]), (k, r)
 
 
 @pytest.mark.timeout(600)

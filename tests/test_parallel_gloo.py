@@ -114,6 +114,29 @@ def _worker(rank, world, port, out):
     assert eng.flat_early.numel() + eng.flat_late.numel() == eng.flat.numel()
     err = max((grads2[k].double() - grads[k]).abs().max().item() / (1e-30 + grads[k].abs().max().item()) for k in grads)
     assert err < 1e-6 and abs(loss2.item() - loss.item()) < 1e-5 * abs(loss.item()), (err, loss2.item(), loss.item())
+    # the collectives of the sharded replicated stage (round 3): every rank contributes its column block of [Q' | a] (width a
+    # multiple of 4, zero padded) and its row block of L-bar; all-gather + the engine's reassembly give the whole matrices
+    n = 13
+    g = torch.Generator().manual_seed(9)
+    Q = torch.randn(n, n + 1, generator=g)
+    w = ((n + 1 + world - 1) // world + 3) // 4 * 4
+    c0 = min(rank * w, n + 1)
+    c1 = min(c0 + w, n + 1)
+    loc = torch.zeros(n, w)
+    loc[:, :c1 - c0] = Q[:, c0:c1]
+    allq = torch.empty(world, n, w)
+    dp.all_gather_async(allq, loc).wait()
+    full = torch.empty(n, world * w)
+    full.view(n, world, w).copy_(allq.permute(1, 0, 2))
+    assert torch.equal(full[:, :n + 1], Q) and full[:, n + 1:].abs().max().item() == 0.0
+    wr = (n + world - 1) // world
+    r0 = min(rank * wr, n)
+    r1 = min(r0 + wr, n)
+    rows = torch.zeros(wr, n)
+    rows[:r1 - r0] = Q[r0:r1, :n]
+    allr = torch.empty(world * wr, n)
+    dp.all_gather_async(allr, rows).wait()
+    assert torch.equal(allr[:n], Q[:, :n])
     out[rank] = (loss.item(), {k: v.clone() for k, v in grads.items()}, (lo, hi), mu.shape[0])
     dist.destroy_process_group()
 
