@@ -974,7 +974,9 @@ class ElboEngine:
         plan = self._plans.get((M, d, p, B))
         if plan is None:
             plan = self._plans[(M, d, p, B)] = _ops.StepPlan(ctx, M, d, p, B)
-        ws = self._bytes("cstep_ws", plan.bytes)
+        # one workspace PER plan: a plan clears the pad columns of its fp32 [Q' | a] once per workspace and assumes nobody else
+        # writes there (a ragged tail batch has its own plan, layout and buffer)
+        ws = self._bytes("cstep_ws_%d_%d_%d_%d" % (M, d, p, B), plan.bytes)
         grads, loss_out, d_hyp = self._alloc_grads(params, PARAM_NAMES, zero=False)
         mu = torch.empty(Bp, dtype=f32, device=self.device)
         LS, dLS = params["chol_variational_covar"], grads["chol_variational_covar"]

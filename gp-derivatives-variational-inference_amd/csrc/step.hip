@@ -189,7 +189,8 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
 
 // flags: bit 0 = overlap (second stream: K_ZX assembly + S = L_S L_S^T under the Cholesky chain, the L_S / m gradients next to
 //                the Q' solve and the dense product, K_ZX-bar's kernel backward next to the Cholesky backward when B' <= 2 M');
-//        bit 1 = include the KL term (a data-parallel rank other than 0 leaves it out).
+//        bit 1 = include the KL term (a data-parallel rank other than 0 leaves it out);
+//        bit 2 = record HIP-event timings; bit 3 = the workspace may have been written by somebody else (re-clear the paddings).
 // io->flat .. flat + flat_floats is cleared here (the gradient slots must start from zero); every gradient pointer of io points
 // into it.  All pointers are device pointers; nothing is read back.
 extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace,
@@ -246,7 +247,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     STEP_HIP(hipMemsetAsync(io->flat, 0, io->flat_floats * sizeof(float), main));
     if (prezero) STEP_HIP(hipMemsetAsync(w + pl->o_arena, 0, pl->arena_bytes, main));
     else STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
-    if (pl->pad_ready_for != workspace) {
+    if (pl->pad_ready_for != workspace || (flags & 8)) {
         STEP_HIP(hipMemsetAsync(Qe32, 0, (size_t)Mp * ldQ32 * sizeof(float), main));
         pl->pad_ready_for = workspace;
     }

@@ -353,8 +353,11 @@ int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, fl
  * point with its p directional derivatives, explicit-inverse regime (M(p+1) <= 8192).
  *   plan       host object for one (M, d, p, B): workspace layout, the second stream, events, pinned status word
  *   workspace  caller-owned device memory of dsvgp_elbo_step_workspace_bytes(M, d, p, B) bytes, 256-byte aligned, kept between steps
+ *              and used by THIS plan only (the plan clears the zero padding of one operand once per workspace address; pass
+ *              flag 8 whenever anything else may have written to the buffer since this plan's last step)
  *   io         device pointers (below); io->flat[0 .. flat_floats) is cleared by the call and must contain every gradient slot
- *   flags      1: overlap on the plan's second stream; 2: include the KL term (data-parallel ranks > 0 leave it out)
+ *   flags      1: overlap on the plan's second stream; 2: include the KL term (data-parallel ranks > 0 leave it out); 4: record
+ *              HIP-event timings (dsvgp_elbo_step_timings); 8: the workspace contents are undefined (re-clear the paddings)
  * Gradients are those of loss = -(sum_j ll_j / global_rows - KL / num_data); a factorisation that fails leaves NaNs in the
  * outputs and a non-zero status word: read it with dsvgp_elbo_step_status (waits for the factorisation only, not for the step)
  * and run the jitter ladder on the piecewise path.  Threading: one host thread per context.                                  */

@@ -7,6 +7,7 @@ Stated tolerance (everything is double precision on both sides; what remains is 
 amplification of ~1e3 through the Cholesky backward): kernel entries 1e-12, loss 1e-9 relative, predictive moments 1e-9,
 gradients 1e-7 relative in max-norm per parameter."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -545,3 +546,46 @@ def test_other_harnesses_under_float64_default(dsvgp, gpu_device):
         assert means.dtype == f64 and means.shape == (40,) and bool((variances > 0).all())
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("state", ["init", "mid"])
+def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, gpu_device, state):
+    """The reference's bunny experiment runs ``use_ciq=True`` under ``torch.set_default_dtype(torch.float64)``
+    (experiments/bunny/exp_bunny.py:66,78).  Here the float64 model's CIQ step runs on the fp32 CIQ kernels (csrc/ciq.hip; a
+    float64 msMINRES is not built -- DESIGN.md section 9), so its distance to FLOAT64 arithmetic is MEASURED at BASELINE config 5
+    size (M' = 6144, B' = 3072, Q = 15) against the oracle evaluated in float64 (tests/golden/c5_step_{init,mid}64.npz,
+    oracle/make_c5_fixture.py init64 / mid64) and held to the tolerances of the fp32 model's C5 test: loss 1e-3, moments 5e-3,
+    gradients 2e-2 (dZ / dV at ``init``: 5e-2 / 5e-3, the state where 1 / lengthscale^2 = 1e6 amplifies fp32 cancellation)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_c5_fixture import make_inputs, Q
+    from dsvgp_amd._step64 import ElboEngine64
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_step_%s64.npz" % state))
+    P, x, y, D, nd = make_inputs(state)
+    eng = ElboEngine64(gpu_device)
+    eng.whitening = "ciq"
+    eng.ciq_num_quadrature = Q
+    Pg = {k: v.double().to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.double().to(gpu_device), y.double().to(gpu_device), D.double().to(gpu_device), nd)
+    torch.cuda.synchronize()
+    assert loss.dtype == f64 and mu.dtype == f64 and all(v.dtype == f64 for v in grads.values())
+    t = lambda k: torch.from_numpy(g[k])
+    errs = {"loss": abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), "mu": relmax(mu, t("mu")), "var": relmax(varn, t("varn"))}
+    gm = grads["natural_mat"]
+    errs["g_nm_norm"] = abs(gm.norm().item() - float(g["g_nm_norm"])) / float(g["g_nm_norm"])
+    errs["g_nm_block"] = relmax(gm[:96, :96], t("g_nm_block"))
+    errs["g_nm_lastrows"] = relmax(gm[-8:, :], t("g_nm_lastrows"))
+    for k in O.NGD_PARAM_NAMES:
+        if k != "natural_mat" and t("g_" + k).numel() and t("g_" + k).abs().max() > 0:
+            errs["g_" + k] = relmax(grads[k], t("g_" + k))
+    print("[parity] float64 model, CIQ step on the fp32 CIQ kernels, C5 %s vs the float64 oracle: iterations %d (oracle %d), %s" % (
+        state, eng.ciq_stats["iterations"], int(g["iterations"]), ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert errs["loss"] < 1e-3 and errs["mu"] < 5e-3 and errs["var"] < 5e-3, errs
+    for k, v in errs.items():
+        if k.startswith("g_"):
+            tol = 2e-2
+            if state == "init" and k == "g_inducing_points":
+                tol = 5e-2
+            if state == "init" and k == "g_inducing_directions":
+                tol = 5e-3
+            assert v < tol, (k, v)

@@ -936,3 +936,21 @@ def test_one_call_step_falls_back_to_the_jitter_ladder(dsvgp, gpu_device):
         assert torch.isfinite(loss).item() and not eng.c_step_used
         out.append((loss.item(), grads["variational_mean"].cpu()))
     assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[1][0]) and relmax(out[0][1], out[1][1]) < 1e-4
+
+
+def test_one_call_step_alternating_batch_shapes(dsvgp, gpu_device):
+    """an epoch's ragged tail batch gets its own plan AND its own workspace; going back and forth between the two batch shapes
+    gives the piecewise path's numbers every time (the plan clears the zero padding of [Q' | a] once per workspace only)"""
+    N, d, M, p = 900, 5, 43, 2                      # M' = 129: [Q' | a] has 130 columns, padded to 132
+    P, x, y, D, nd = make_problem(N, d, M, p, 200, seed=8)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    eng, ref = dsvgp.ElboEngine(gpu_device), dsvgp.ElboEngine(gpu_device)
+    ref.c_step = False
+    for B in (200, 77, 200, 77, 131):
+        xb, yb, Db = x[:B].to(gpu_device), y[:B * (p + 1)].to(gpu_device), D[:B * p].to(gpu_device)
+        l1, g1, mu1, _ = eng.loss_and_grads(Pg, xb, yb, Db, nd)
+        l0, g0, mu0, _ = ref.loss_and_grads(Pg, xb, yb, Db, nd)
+        assert eng.c_step_used and not ref.c_step_used
+        assert abs(l1.item() - l0.item()) < 1e-6 * abs(l0.item()) and relmax(mu1, mu0) < 1e-6, B
+        for k in O.PARAM_NAMES:
+            assert relmax(g1[k], g0[k]) < 2e-5, (B, k, relmax(g1[k], g0[k]))
