@@ -258,7 +258,7 @@ def main():
     # three more untimed steps with the side stream off, HIP events around the same launch
     has_dur = hasattr(eng, "event_durations")
     durations = {nm: (eng.event_durations(nm) if has_dur else [s.elapsed_time(e) * 1e-3 for (n2, s, e) in eng.events if n2 == nm])
-                 for nm in ("solve_fwd", "assemble_fwd", "assemble_bwd", "early_reduce_wait", "final_reduce")}
+                 for nm in ("solve_fwd", "assemble_fwd", "assemble_bwd", "early_reduce_wait", "final_reduce", "ciq_stacked_backward")}
     iso_fwd = None
     if not cfg.get("ciq") and world == 1 and not args.fp64:
         saved = eng.overlap
@@ -358,6 +358,15 @@ def main():
             roof["sustained"] = dict(measured_mfma_only=sus, unit="TFLOP/s", frac_of_sustained=ach / sus,
                                      note="v_mfma_f64_16x16x4_f64 from registers on all CUs (dsvgp_mfma_rate)")
 
+    t_ciq, n_ciq = avg("ciq_stacked_backward")
+    if cfg.get("ciq") and t_ciq:
+        # CIQ (BASELINE config 5): the largest launch of the step is the stacked backward product of sqrt_inv_matmul,
+        # K_ZZ-bar = -sym stack_i(U_i)^T stack_i(Z_i): [M', depth] x [depth, M'] in fp32 on v_mfma_f32_32x32x2_f32
+        depth = float(eng.ciq_stats.get("stacked_depth", 0))
+        flops = 2.0 * Mp * Mp * depth
+        roof = dict(bound="mfma", kernel="gemm32 (stacked backward product of the CIQ step: [M', depth]^T x [depth, M'], fp32 MFMA)",
+                    achieved=flops / t_ciq / 1e12, peak=157.3, unit="TFLOP/s", frac=flops / t_ciq / 1e12 / 157.3, traffic=None,
+                    launches=n_ciq, avg_ms=t_ciq * 1e3, flops_per_launch=flops, depth=depth)
     # kernel assembly (north_star: HBM GB/s of the assembly): algorithmic bytes per launch =
     # 4 [M' B' + (M + B) d (p + 1)] -- write the block matrix once (forward) / read its gradient once (backward) plus the
     # points and directions -- over the live HIP-event duration on the stream the kernel was queued on

@@ -891,7 +891,10 @@ class ElboEngine:
             om[:Q] = omega
             right = _ops.ciq_mix(ctx, basisF, its, ycoefF * om, Q, rnF, self._get("ciq_Z", (Q, Bp, Mp), f32))
             left = _ops.ciq_mix(ctx, basisB, its_b, ycoefB, Q, rnB, self._get("ciq_Z2", (Q, Bp, Mp), f32))
+        ev = self._event_pair()                           # (bench.py --config c5: the largest single launch of the CIQ step)
         _ops.gemm(ctx, TRANS_A, left.reshape(kmin * Bp, Mp), right.reshape(kmin * Bp, Mp), dK, alpha=-1.0)
+        self._event_done("ciq_stacked_backward", ev)
+        self.ciq_stats.update(stacked_depth=int(kmin * Bp))
         Kzzbar = self._get("ciq_Kzzbar", (Mp, Mp), f32)
         _ops.sym_average_f32(ctx, dK, Kzzbar)
         Kb32 = self._get("Kb32", (Mp, Bp), f32)

@@ -310,8 +310,8 @@ def test_c5_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, st
     (reference CiqDirectionalGradVariationalStrategy.py:19-123,197-295) against the oracle runs committed as
     tests/golden/c5_step_{init,mid}.npz (oracle/make_c5_fixture.py; inputs regenerated from the seed).
     Tolerances as in test_ciq_step_matches_oracle: both sides stop msMINRES at a mean relative update of 1e-4 tested every
-    10 iterations and take the spectrum from 20 Lanczos steps in fp32, so loss 1e-3, mean / variance 5e-3, gradients
-    2e-2 of the max magnitude per parameter."""
+    10 iterations and take the spectrum from 20 Lanczos steps in fp32; stated (round 3): loss 1e-5, mean / variance 3e-3,
+    gradients 6e-3 of the max magnitude per parameter (the small-size CIQ tests keep loss 1e-3, moments 5e-3, gradients 2e-2)."""
     import os
     import sys
     import numpy as np
@@ -345,8 +345,10 @@ def test_c5_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, st
     # lambda_min is the smallest Ritz value of 20 fp32 Lanczos steps at n = 6144 (orthogonality already lost): it moves by
     # ~10 % between two fp32 implementations while the quadrature built on it reproduces every output below to ~1e-3
     assert errs["lmax"] < 1e-3 and errs["lmin"] < 0.25
-    assert errs["loss"] < 1e-3 and errs["mu"] < 5e-3 and errs["var"] < 5e-3, errs
-    assert errs["g_nm_norm"] < 2e-2
+    # (tightened in round 3 to ~3x the measured errors: loss 1.8e-7, mu 7.5e-4, var 1.8e-6, worst gradient 1.9e-3 -- both sides stop
+    #  msMINRES at a mean relative update of 1e-4 after the same 90 iterations)
+    assert errs["loss"] < 1e-5 and errs["mu"] < 3e-3 and errs["var"] < 3e-3, errs
+    assert errs["g_nm_norm"] < 6e-3
     for k, v in errs.items():
         if k.startswith("g_"):
             # init state only: at lengthscale = 1/1024 the x / lengthscale coordinates are O(500) and the r . v inner products
@@ -358,7 +360,7 @@ def test_c5_full_size_step_against_committed_oracle_vector(dsvgp, gpu_device, st
             # well-scaled "mid" state.
             loose = state == "init" and k in ("g_inducing_points", "g_inducing_directions")
             if not loose:
-                assert v < 2e-2, (k, v)
+                assert v < 6e-3, (k, v)
     if state == "init":
         # dZ / dV at the init state, numerically: against the FLOAT64 oracle (tests/golden/c5_init_refseq.npz,
         # oracle/make_c5_refseq_fixture.py) the HIP step must be no worse than the reference's OWN kernel op sequence evaluated in
