@@ -10,6 +10,7 @@ oracle/make_strategy_fixtures.py -- at the sizes the HIP kernels actually tile:
     c3       BASELINE config 3, full size: d=10, M=300, p=d  -> M'=3300, B=512  -> B'=5632   (GradVariationalStrategy)
     c4shard  BASELINE config 4, one rank's share at 8 GPUs: d=20, M=500, p=5 -> M'=3000, B=512 -> B'=3072
     c4       BASELINE config 4, the whole global minibatch: B=4096 -> B'=24576
+    c2pll / c3pll   the same C2 / C3 inputs under the PredictiveLogLikelihood objective (mll_type="PLL")
 
 Gradients are torch autograd THROUGH that text (the stand-ins are plain torch).  What is NOT reference text, exactly as in
 ``make_strategy_fixtures.elbo_gradient_cases``: the two gpytorch-resident closed forms applied to the (mean, variance) the
@@ -102,8 +103,10 @@ def _leaves(P):
     return {k: v.detach().double().clone().requires_grad_(True) for k, v in P.items()}
 
 
-def reference_data_term(P, x, y, D, rows_glob, full_gradient=False):
-    """-(sum_j ll_j) / rows_glob and its gradients, through the reference's strategy forward + kernel file."""
+def reference_data_term(P, x, y, D, rows_glob, full_gradient=False, mll="ELBO"):
+    """-(sum_j ll_j) / rows_glob and its gradients, through the reference's strategy forward + kernel file.
+    mll: "ELBO" (VariationalELBO: GaussianLikelihood.expected_log_prob) or "PLL" (PredictiveLogLikelihood: log_marginal of the
+    NOISED predictive -- the reference passes likelihood(model(x)) to the mll, so the noise enters twice, directional_vi.py:245)."""
     import torch.nn.functional as F
     R = _reference()
     S = R["S"]
@@ -132,7 +135,11 @@ def reference_data_term(P, x, y, D, rows_glob, full_gradient=False):
     mu, var = out.mean, torch.diagonal(out.covariance_matrix)
     noise = F.softplus(L["raw_noise"]).reshape(()) + 1e-4                    # GaussianLikelihood: GreaterThan(1e-4)
     varn = (var + noise).clamp_min(1e-6)                                     # likelihood(q(f)).variance
-    ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+    if mll == "ELBO":
+        ll = -0.5 * (((y - mu) ** 2 + varn) / noise + torch.log(noise) + math.log(2 * math.pi))
+    else:
+        tot = (varn + noise).clamp_min(1e-8)
+        ll = -0.5 * ((y - mu) ** 2 / tot + torch.log(tot) + math.log(2 * math.pi))
     part = -(ll.sum() / rows_glob)
     part.backward()
     grads = {k: (L[k].grad if L[k].grad is not None else torch.zeros_like(L[k])) for k in L}
@@ -153,7 +160,7 @@ def kl_term(P, num_data):
     return part.detach(), {"variational_mean": m.grad, "chol_variational_covar": L["chol_variational_covar"].grad}
 
 
-def reference_step(P, x, y, D, num_data, full_gradient=False, shard_rows=None):
+def reference_step(P, x, y, D, num_data, full_gradient=False, shard_rows=None, mll="ELBO"):
     """(loss, grads, mu_head, varn_head) of one ELBO step through the reference text, row shards summed when asked"""
     B = x.shape[0]
     q = y.shape[0] // B
@@ -168,7 +175,7 @@ def reference_step(P, x, y, D, num_data, full_gradient=False, shard_rows=None):
     for r0 in range(0, B, step):
         r1 = min(B, r0 + step)
         t0 = time.time()
-        part, g, mu, varn = reference_data_term(P, x[r0:r1], y[r0 * q:r1 * q], D[r0 * p:r1 * p], rows_glob, full_gradient)
+        part, g, mu, varn = reference_data_term(P, x[r0:r1], y[r0 * q:r1 * q], D[r0 * p:r1 * p], rows_glob, full_gradient, mll)
         print("    rows %d..%d through the reference forward + autograd: %.1f s" % (r0, r1, time.time() - t0), flush=True)
         loss = loss + part
         grads = g if grads is None else {k: grads[k] + g[k] for k in grads}
@@ -203,27 +210,30 @@ def pack(loss, grads, mu_head, varn_head, skip=()):
     return out
 
 
-CASES = {"c2": (c2_inputs, False, None), "c3": (c3_inputs, True, None), "c4shard": (c4shard_inputs, False, None),
-         "c4": (c4_inputs, False, 512)}
+# name -> (inputs, GradVariationalStrategy?, row shards, objective).  The PLL cases: the reference's own tests train the
+# full-gradient model with mll_type="PLL" (tests/test_grad_svgp.py) and offer it for DSVGP (directional_vi.py:218-219).
+CASES = {"c2": (c2_inputs, False, None, "ELBO"), "c3": (c3_inputs, True, None, "ELBO"), "c4shard": (c4shard_inputs, False, None, "ELBO"),
+         "c4": (c4_inputs, False, 512, "ELBO"), "c2pll": (c2_inputs, False, None, "PLL"), "c3pll": (c3_inputs, True, None, "PLL")}
+INPUTS = {"c2pll": "c2", "c3pll": "c3"}           # (cases that share another case's inputs)
 
 
 def main(names):
     torch.set_num_threads(os.cpu_count())
     os.makedirs(OUT, exist_ok=True)
     for name in names:
-        inputs, full_gradient, shard_rows = CASES[name]
+        inputs, full_gradient, shard_rows, mll = CASES[name]
         torch.set_default_dtype(torch.float32)
         P, x, y, D, nd = inputs()
         assert x.dtype == torch.float32 and P["inducing_points"].dtype == torch.float32
         print("%s: M'=%d, B'=%d" % (name, P["variational_mean"].shape[0], y.shape[0]), flush=True)
         t0 = time.time()
-        loss, grads, mu_head, varn_head = reference_step(P, x, y, D, nd, full_gradient, shard_rows)
+        loss, grads, mu_head, varn_head = reference_step(P, x, y, D, nd, full_gradient, shard_rows, mll)
         print("  reference text: %.1f s, loss %.10f" % (time.time() - t0, loss.item()), flush=True)
         out = pack(loss, grads, mu_head, varn_head, skip=("inducing_directions",) if full_gradient else ())
         # the oracle restatement (float64) on the same inputs: pinned at this size by the numbers above
         t0 = time.time()
         P64 = {k: v.double() for k, v in P.items()}
-        lo, go, muo, varo = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), nd)
+        lo, go, muo, varo = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), nd, mll)
         errs = {"loss": abs(lo.item() - loss.item()) / abs(loss.item()), "mu": relmax(muo[:256], mu_head), "varn": relmax(varo[:256], varn_head)}
         for k in O.PARAM_NAMES:
             if full_gradient and k == "inducing_directions":

@@ -400,7 +400,9 @@ def elbo_gradient_cases(Kern):
     # (natural gradient descent); K^-1/2 R is the exact inverse square root (differentiated by autograd through eigh)
     ref = _load("CiqDirectionalGradVariationalStrategy.py", "_ref_ciq_strategy_g")
     NatDist = sys.modules["gpytorch.variational.natural_variational_distribution"].NaturalVariationalDistribution
-    for ci, (N, d, M, p, B) in enumerate(((60, 4, 8, 2, 11),)):
+    # (case 1, round 3: C2 geometry at M' = 300, B' = 288 -- five 64-column blocks of the Cholesky / GEMM tiling, several msMINRES
+    #  convergence checks on the HIP side)
+    for ci, (N, d, M, p, B) in enumerate(((60, 4, 8, 2, 11), (1500, 5, 100, 2, 96))):
         g = torch.Generator().manual_seed(700 + ci)
         X = torch.rand(N, d, generator=g, dtype=torch.float64)
         Z, x = X[:M].clone(), X[M:M + B].contiguous()
@@ -409,7 +411,7 @@ def elbo_gradient_cases(Kern):
         nq, nout = M * (p + 1), B * (p + 1)
         y = torch.randn(nout, generator=g, dtype=torch.float64)
         nv = 0.3 * torch.randn(nq, generator=g, dtype=torch.float64)
-        R = 0.2 * torch.randn(nq, nq, generator=g, dtype=torch.float64)
+        R = 0.2 * min(1.0, (24.0 / nq) ** 0.5) * torch.randn(nq, nq, generator=g, dtype=torch.float64)   # (same conditioning of the precision at every size)
         nm = -0.5 * (torch.eye(nq, dtype=torch.float64) + R @ R.t())
         raw_ell = torch.tensor([[0.3]], dtype=torch.float64, requires_grad=True)
         raw_s = torch.tensor(0.2, dtype=torch.float64, requires_grad=True)

@@ -430,7 +430,11 @@ def test_ciq_engine_matches_the_reference_forward_run_with_msminres(dsvgp, gpu_d
 @pytest.mark.gpu
 def test_ciq_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device):
     """HIP CIQ step (quadrature + msMINRES forward and backward, NGD interpolation terms) against autograd through the reference's
-    CIQ forward with the exact inverse square root: loss 1e-3, gradients 2e-2 (the stated CIQ tolerance)"""
+    CIQ forward with the EXACT inverse square root.  Two bounds per vector: (i) against the oracle's own quadrature step in
+    the same fp32 arithmetic, 5e-3 -- what the kernels add; (ii) against the exact-root reference, loss 1e-3 and gradients
+    max(2e-2, 1.5 x the error the float64 oracle's quadrature has against the same reference) -- the method's own error:
+    at M'=300 (strategy_ciq_grad_1) the Lanczos lower Ritz bound overestimates lambda_min and Q=15 quadrature is 2.6e-2 off
+    the exact root in float64 already"""
     import glob, os
     for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "strategy_ciq_grad_*.npz"))):
         P, x, y, D, nd, loss_ref, g_ref = _ciq_grad_problem(path, torch.float32)
@@ -441,4 +445,13 @@ def test_ciq_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_devi
         errs = {"loss": abs(loss.item() - loss_ref) / abs(loss_ref)}
         errs.update({k: relmax(grads[k], g_ref[k]) for k in O.NGD_PARAM_NAMES})
         print("[parity] CIQ reference-forward gradient vector %s: %s" % (os.path.basename(path), ", ".join("%s %.1e" % kv for kv in errs.items())))
-        assert errs["loss"] < 1e-3 and max(errs[k] for k in O.NGD_PARAM_NAMES) < 2e-2, errs
+        loss32, g32, _, _ = O.ciq_loss_and_grads(P, x, y, D, nd)
+        P64, x64, y64, D64, _, _, _ = _ciq_grad_problem(path, torch.float64)
+        _, g64, _, _ = O.ciq_loss_and_grads(P64, x64, y64, D64, nd)
+        e32 = {"loss": abs(loss.item() - loss32.item()) / abs(loss32.item())}
+        e32.update({k: relmax(grads[k], g32[k]) for k in O.NGD_PARAM_NAMES})
+        method = max(relmax(g64[k], g_ref[k]) for k in O.NGD_PARAM_NAMES)
+        print("[parity]   ... against the fp32 oracle's quadrature step: %s; float64 quadrature vs exact root %.1e" % (
+            ", ".join("%s %.1e" % kv for kv in e32.items()), method))
+        assert e32["loss"] < 1e-5 and max(e32[k] for k in O.NGD_PARAM_NAMES) < 5e-3, e32
+        assert errs["loss"] < 1e-3 and max(errs[k] for k in O.NGD_PARAM_NAMES) < max(2e-2, 1.5 * method), errs

@@ -271,6 +271,13 @@ def _rccl_worker(rank, world, port, out):
                    / g0["variational_mean"].abs().max().item(),
                    (grads["inducing_points"] - g0["inducing_points"]).abs().max().item()
                    / g0["inducing_points"].abs().max().item())
+    # the all-gather of the sharded replicated stage on the nccl backend (one rank: an identity on RCCL's stream, asynchronous)
+    dp1 = dsvgp_amd.DataParallel()
+    inp = torch.randn(37, 12, device=dev)
+    got = torch.zeros(1, 37, 12, device=dev)
+    dp1.all_gather_async(got, inp).wait()
+    torch.cuda.synchronize()
+    res["allgather"] = bool(torch.equal(got[0], inp))
     out[0] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -290,3 +297,4 @@ def test_multi_rank_schedules_on_an_rccl_communicator(dsvgp, gpu_device):
         dl, dLS, dm, dZ = res[gg]
         assert dl < 1e-5 and dLS < 1e-4 and dm < 1e-4, (gg, res[gg])
     assert res[False][3] < 1e-4            # general schedule: everything is local, so Z-bar is complete too
+    assert res["allgather"]

@@ -40,7 +40,7 @@ def relmax(a, b):
 def _load(name):
     import make_refsize_fixtures as R
     g = np.load(os.path.join(GOLD, "reftext_%s_step.npz" % name))
-    P, x, y, D, nd = getattr(R, name + "_inputs")()
+    P, x, y, D, nd = getattr(R, R.INPUTS.get(name, name) + "_inputs")()
     return g, P, x, y, D, nd
 
 
@@ -102,3 +102,28 @@ def test_fp64_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, na
     torch.cuda.synchronize()
     errs = _errors(g, loss, grads, mu, varn, skip=("inducing_directions",) if name == "c3" else ())
     _check("%s fp64 %s" % (name, "gram" if fast else "per-output"), errs, 1e-12, 1e-10, 1e-8)
+
+
+@pytest.mark.parametrize("name", ["c2pll", "c3pll"])
+def test_pll_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, name):
+    """mll_type="PLL" (PredictiveLogLikelihood; what the reference's tests/test_grad_svgp.py trains with, and an option of
+    directional_vi.train_gp, :218-219) at C2 / C3 size: the per-output path of the fp32 engine and the fp64 engine against the
+    reference's strategy forward + kernel file + autograd (the log_marginal closed form of the noised predictive is restated)."""
+    from dsvgp_amd._step64 import ElboEngine64
+    g, P, x, y, D, nd = _load(name)
+    skip = ("inducing_directions",) if name.startswith("c3") else ()
+    eng = dsvgp.ElboEngine(gpu_device)
+    if name.startswith("c3"):
+        eng.chol_jitter = 1e-8
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "PLL")
+    torch.cuda.synchronize()
+    _check("%s fp32" % name, _errors(g, loss, grads, mu, varn, skip=skip), 2e-6, 1e-4, 1e-3)
+    eng64 = ElboEngine64(gpu_device)
+    if name.startswith("c3"):
+        eng64.chol_jitter = 1e-8
+    Pd = {k: v.double().to(gpu_device) for k, v in P.items()}
+    loss, grads, mu, varn = eng64.loss_and_grads(Pd, x.double().to(gpu_device), y.double().to(gpu_device), D.double().to(gpu_device),
+                                                 nd, "PLL")
+    torch.cuda.synchronize()
+    _check("%s fp64" % name, _errors(g, loss, grads, mu, varn, skip=skip), 1e-12, 1e-10, 1e-8)
