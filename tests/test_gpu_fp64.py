@@ -554,8 +554,9 @@ def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, g
     (experiments/bunny/exp_bunny.py:66,78).  Here the float64 model's CIQ step runs on the fp32 CIQ kernels (csrc/ciq.hip; a
     float64 msMINRES is not built -- DESIGN.md section 9), so its distance to FLOAT64 arithmetic is MEASURED at BASELINE config 5
     size (M' = 6144, B' = 3072, Q = 15) against the oracle evaluated in float64 (tests/golden/c5_step_{init,mid}64.npz,
-    oracle/make_c5_fixture.py init64 / mid64) and held to the tolerances of the fp32 model's C5 test: loss 1e-3, moments 5e-3,
-    gradients 2e-2 (dZ / dV at ``init``: 5e-2 / 5e-3, the state where 1 / lengthscale^2 = 1e6 amplifies fp32 cancellation)."""
+    oracle/make_c5_fixture.py init64 / mid64; 190 s and 1530 s of 8 CPU cores) and held to: loss 1e-6; ``init`` moments 1e-6,
+    gradients 1e-5 except dZ 2e-2 / dV 2e-3 (the state where 1 / lengthscale^2 = 1e6 amplifies fp32 cancellation in the kernel
+    backward); ``mid`` mean 4e-3, variance 1e-4, gradients 6e-3."""
     import numpy as np
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
     from make_c5_fixture import make_inputs, Q
@@ -580,12 +581,16 @@ def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, g
             errs["g_" + k] = relmax(grads[k], t("g_" + k))
     print("[parity] float64 model, CIQ step on the fp32 CIQ kernels, C5 %s vs the float64 oracle: iterations %d (oracle %d), %s" % (
         state, eng.ciq_stats["iterations"], int(g["iterations"]), ", ".join("%s %.2e" % kv for kv in errs.items())))
-    assert errs["loss"] < 1e-3 and errs["mu"] < 5e-3 and errs["var"] < 5e-3, errs
+    # measured (MI355X): init  loss 5e-8, moments 4e-8, dZ 7.0e-3, dV 4.7e-4, every other gradient <= 2.2e-7;
+    #                    mid   loss 6e-8, mu 1.2e-3, var 2.7e-6, gradients <= 2.2e-3 (natural_vec; msMINRES stopped at the same
+    #                          1e-4 mean relative update in both arithmetics, 90 iterations each)
+    tol_loss, tol_mu, tol_var = (1e-6, 1e-6, 1e-6) if state == "init" else (1e-6, 4e-3, 1e-4)
+    assert errs["loss"] < tol_loss and errs["mu"] < tol_mu and errs["var"] < tol_var, errs
     for k, v in errs.items():
         if k.startswith("g_"):
-            tol = 2e-2
+            tol = 1e-5 if state == "init" else 6e-3
             if state == "init" and k == "g_inducing_points":
-                tol = 5e-2
+                tol = 2e-2
             if state == "init" and k == "g_inducing_directions":
-                tol = 5e-3
+                tol = 2e-3
             assert v < tol, (k, v)
