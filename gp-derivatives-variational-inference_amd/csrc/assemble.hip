@@ -17,6 +17,7 @@
 // The self terms use the same k-ordered fma chain as the MFMA, so r == 0 exactly on the diagonal
 // of K_ZZ.  The backward recomputes T, forms Tbar per micro-block and contracts Tbar . P2 on MFMA.
 #include "common.h"
+#include <type_traits>
 
 #ifndef ASM_ABLATE
 #define ASM_ABLATE 0      // tools only: 1 = no global stores, 2 = stores of a constant (no MFMA / epilogue math)
@@ -236,6 +237,12 @@ constexpr int FWD_PAIR_LDT = 52;
 #ifndef FWDP_MINW
 #define FWDP_MINW 1
 #endif
+#ifndef FWDP_CHUNK
+#define FWDP_CHUNK 1      // consecutive column tiles per wave (87.7 -> 85.7 us)
+#endif
+#ifndef FWDP_FAST
+#define FWDP_FAST 1       // interior tiles leave through the T' tile as fully coalesced 16-byte stores
+#endif
 template <typename OutT, int Q>
 __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
                                                              int n1q, const float* __restrict__ P2,
@@ -314,8 +321,15 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
         }
         pselfv = (lane < T && c0_ + lane < n2q) ? -self2[c0_ + lane] : 0.f;
     };
-    if (FWDP_OVERLAY && (int)blockIdx.x < ncoltiles) prefetch(blockIdx.x);
-    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
+#if FWDP_CHUNK
+    // consecutive column tiles per wave: the 192-byte row pieces of neighbouring tiles complete each other's 128-byte lines in ONE L2
+    const int cper = (ncoltiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ct_lo = blockIdx.x * cper, ct_hi = min(ct_lo + cper, ncoltiles), ct_step = 1;
+#else
+    const int ct_lo = blockIdx.x, ct_hi = ncoltiles, ct_step = gridDim.x;
+#endif
+    if (FWDP_OVERLAY && ct_lo < ct_hi) prefetch(ct_lo);
+    for (int ct = ct_lo; ct < ct_hi; ct += ct_step) {
         const int col0 = ct * T;
         float s2c0[PPL];
 #pragma unroll
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                 P2s[lane * LDP + K4 + 1] = pselfv;
                 P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
             }
-            if (ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);      // in flight under the rest of this tile
+            if (ct + ct_step < ct_hi) prefetch(ct + ct_step);      // in flight under the rest of this tile
         } else {
         if (!(FWDP_ABL & 4))
         for (int e = lane; e < T * pch; e += 64) {
@@ -358,24 +372,39 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
         __syncthreads();
         {
             f4 t[3][3];
+            if (!FWDP_AREG) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 3; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+            }
             const float* pa = P1s + m16 * LDP + kg;
             const float* pb = P2s + m16 * LDP + kg;
             if (FWDP_AREG) {
+                // one straight-line copy per K depth: no per-step branches, the first product starts from the inline zero
+                auto product = [&](auto ksc) {
+                    constexpr int KS_ = decltype(ksc)::value;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    if (ks < KS) {
+                    for (int ks = 0; ks < KS_; ++ks) {
                         float bv[3];
 #pragma unroll
                         for (int j = 0; j < 3; ++j) bv[j] = pb[j * 16 * LDP + ks * 4];
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], t[i][j], 0, 0, 0);
+                            for (int j = 0; j < 3; ++j)
+                                t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i][j], 0, 0, 0);
                     }
+                };
+                switch ((FWDP_ABL & 2) ? 1 : KS) {
+                    case 1: product(std::integral_constant<int, 1>{}); break;
+                    case 2: product(std::integral_constant<int, 2>{}); break;
+                    case 3: product(std::integral_constant<int, 3>{}); break;
+                    case 4: product(std::integral_constant<int, 4>{}); break;
+                    case 5: product(std::integral_constant<int, 5>{}); break;
+                    case 6: product(std::integral_constant<int, 6>{}); break;
+                    case 7: product(std::integral_constant<int, 7>{}); break;
+                    default: product(std::integral_constant<int, 8>{}); break;
                 }
             } else
             for (int ks = 0; ks < ((FWDP_ABL & 2) ? 1 : KS); ++ks) {
@@ -396,6 +425,71 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                     for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
         }
         __syncthreads();
+#if FWDP_FAST
+        // Interior tile, float output, 16-byte aligned rows: the micro-blocks go back to the T' tile IN PLACE (every lane rewrites
+        // only what it read) and the tile leaves as nine fully coalesced store instructions -- every row 192 contiguous bytes,
+        // 12 lanes x 16 B.  The per-lane micro-block stores of the general path below write 16-byte pieces 16 bytes apart: each
+        // instruction touches 16 cache lines partially and the next one touches them again; the CU's store path, not HBM, was the
+        // bound (stores redirected to an L2-resident region: 86 -> 81 us; no stores: 60 us).
+        if constexpr (sizeof(OutT) == 4 && T == 48) {
+            if ((ovec & 2) && row0 + T <= n1q && col0 + T <= n2q && !(jitter != 0.f && row0 == col0)) {
+#pragma unroll
+                for (int pp = 0; pp < PPL; ++pp) {
+                    if (lane + 64 * pp < NPAIR) {
+                        float* blk = TT + pr0[pp] * LDT2 + pc0[pp];
+                        float tq[Q][Q];
+#pragma unroll
+                        for (int a = 0; a < Q; ++a) {
+                            if constexpr (Q % 2 == 0) {
+                                using F2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+                                for (int b = 0; b < Q; b += 2) {
+                                    const F2 v = *reinterpret_cast<const F2*>(blk + a * LDT2 + b);
+                                    tq[a][b] = v[0]; tq[a][b + 1] = v[1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < Q; ++b) tq[a][b] = blk[a * LDT2 + b];
+                            }
+                        }
+                        const float nn = fmaxf(s1r0[pp] - s2c0[pp] - 2.f * tq[0][0], 0.f);
+                        const float k = s * expf(-0.5f * nn);
+                        const float kil = k * il, kil2 = k * il2;
+#pragma unroll
+                        for (int a = 0; a < Q; ++a) {
+                            float v[Q];
+                            if (a == 0) {
+                                v[0] = k;
+#pragma unroll
+                                for (int b = 1; b < Q; ++b) v[b] = tq[0][b] * kil;
+                            } else {
+                                v[0] = tq[a][0] * kil;
+#pragma unroll
+                                for (int b = 1; b < Q; ++b) v[b] = (tq[a][b] + tq[a][0] * tq[0][b]) * kil2;
+                            }
+                            if constexpr (Q % 2 == 0) {
+                                using F2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+                                for (int b = 0; b < Q; b += 2) *reinterpret_cast<F2*>(blk + a * LDT2 + b) = F2{v[b], v[b + 1]};
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < Q; ++b) blk[a * LDT2 + b] = v[b];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                float* orow = (float*)out + (int64_t)row0 * ld + col0;
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    const int id = lane + 64 * u, r = id / 12, c4 = (id - 12 * r) * 4;
+                    const f4 x = *reinterpret_cast<const f4*>(TT + r * LDT2 + c4);
+                    if (!(FWDP_ABL & 1)) *reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4) = x;
+                }
+                continue;
+            }
+        }
+#endif
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) {
             const bool mine = prow[pp] && col0 + pc0[pp] < n2q;
@@ -421,7 +515,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
             const float k = s * expf(-0.5f * nn);                                  // postprocess_rbf, ScaleKernel
             const float kil = k * il, kil2 = k * il2;
             const int64_t gr0 = (int64_t)row0 + pr0[pp], gc0 = (int64_t)col0 + pc0[pp];
-            OutT* o = out + gr0 * ld + gc0;
+            OutT* o = out + ((FWDP_ABL & 8) ? (gr0 & 63) : gr0) * ld + gc0;      // (ablation 8: every store lands in the first 64 rows -- L2 hits)
             // Q = 6, float: lanes 2j / 2j + 1 hold horizontally adjacent micro-blocks = 12 consecutive floats per row, 48-byte
             // aligned.  The even lane stores floats 0..3 and 4..7 (its last two + the neighbour's first two, fetched with a
             // DPP quad permute), the odd lane floats 8..11: two 16-byte store instructions per row instead of three 8-byte ones
@@ -976,19 +1070,26 @@ __global__ __launch_bounds__(BWD_NT) void kernel_bwd_kernel(const GT* __restrict
 // to LDS in place as the A operand of dP1 += Tbar P2ext.  Two extra packed columns fold the self terms into T':
 //   P1'[r, K4+1] = [a == 0],  P2'[c, K4+1] = -self2[c]      =>  T'[r0, cb] = x1~.v2_b - beta_b = w_b
 //   P1'[r, K4+2] = -self1[r] [a > 0],  P2'[c, K4+2] = [b == 0]  =>  T'[ra, c0] = v1_a.x2~ - alpha_a = -u_a
-// so the transform reads nothing but its own 36 T' values.  ~21 KB of LDS per wave: 7 waves per CU hide each
-// other's LDS / HBM latency.
+// so the transform reads nothing but its own 36 T' values.  The A fragments of the wave's 48 side-1 rows stay in registers for
+// the whole sweep (no LDS image of P1'), the T' product is one straight-line copy per K depth: ~16 KB of LDS per wave, 8 waves
+// per CU hide each other's LDS / HBM latency (K_ZX-bar at C4, whole dsvgp_kernel_bwd: 194 -> 157 us on one box).
 constexpr int PAIR_LDT = 52;     // LDS row stride of the 48 x 48 T' / Tbar tile (even: 8-byte strips)
 #ifndef PAIR_WGS_
-#define PAIR_WGS_ (256 * 7)
+#define PAIR_WGS_ (256 * 8)       // 8 waves per CU (registers: 2 per SIMD; LDS: 16 KB per wave); 7 / 8 / 9 / 10 / 12: 169 / 157 / 262 / 246 / 225 us
 #endif
 #ifndef PAIR_ABLATE
 #define PAIR_ABLATE 0      // tools only: bit 0 = no transform, bit 1 = no dP1 MFMA, bit 2 = no T' MFMA, bit 3 = no Gbar loads
 #endif
 constexpr int PAIR_WGS = PAIR_WGS_;
 
+#ifndef BWDP_MINW
+#define BWDP_MINW 2        // waves per SIMD the register allocation leaves room for: 2 (<= 256 VGPRs; the micro-block transform holds
+#endif                     // 36 upstream + 36 T' + 24 A-fragment + 24 accumulator registers); 3 (<= 168) spills: 270 us instead of 157
+#ifndef BWDP_PREFETCH
+#define BWDP_PREFETCH 0    // 1: the next tile's packed side-2 rows travel through registers under the current tile (36 more registers,
+#endif                     //    same time at 8 waves per CU: 157 us either way)
 template <typename GT, int Q>
-__global__ __launch_bounds__(64) void kernel_bwd_pair_kernel(const GT* __restrict__ G, int64_t ldg,
+__global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT* __restrict__ G, int64_t ldg,
                                                              const float* __restrict__ P1, const float* __restrict__ self1,
                                                              int n1q, const float* __restrict__ P2,
                                                              const float* __restrict__ self2, int n2q, int K4, int DP,
@@ -998,9 +1099,9 @@ __global__ __launch_bounds__(64) void kernel_bwd_pair_kernel(const GT* __restric
     constexpr int NPAIR = R * R, PPL = (NPAIR + 63) / 64;      // point pairs per lane
     constexpr int LDT2 = PAIR_LDT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LDP1 = K4 + 5, LDP = NP + 1;
-    float* P1s = smem;                  // [48][LDP1]  extended side-1 packs (fixed over the sweep)
-    float* P2s = P1s + 48 * LDP1;       // [48][LDP]   extended side-2 packs of the current tile
+    const int LDP = NP + 1;
+    // (the A fragments of the wave's 48 side-1 rows stay in registers for the whole sweep: no LDS image of P1')
+    float* P2s = smem;                  // [48][LDP]   extended side-2 packs of the current tile
     float* TT = P2s + 48 * LDP;         // [48][LDT2]  T', then Tbar in place
     const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
     const int row0 = blockIdx.y * T;
@@ -1012,18 +1113,43 @@ __global__ __launch_bounds__(64) void kernel_bwd_pair_kernel(const GT* __restric
     const float il = 1.f / ell, il2 = il * il;
     const bool vec = gvec != 0;
 
-    for (int e = lane; e < 48 * LDP1; e += 64) P1s[e] = 0.f;
     for (int e = lane; e < 48 * LDP; e += 64) P2s[e] = 0.f;
-    __syncthreads();
-    for (int e = lane; e < T * K4; e += 64) {
-        const int r = e / K4, k = e - r * K4;
-        if (row0 + r < n1q) P1s[r * LDP1 + k] = P1[(int64_t)(row0 + r) * DP + k];
+    float areg[3][8];                   // areg[i][ks] = P1'[row0 + 16 i + m16][4 ks + kg]  (KS <= 8 since DP <= 32)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int gr = row0 + i * 16 + m16;
+        const bool ok = i * 16 + m16 < T && gr < n1q;
+        const int a = (i * 16 + m16) % Q;
+        const float sf = ok ? self1[gr] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float v = 0.f;
+            if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
+            else if (ks == K4 / 4 && ok) v = (kg == 1) ? (a == 0 ? 1.f : 0.f) : ((kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f);
+            areg[i][ks] = v;
+        }
     }
-    if (lane < T && row0 + lane < n1q) {
-        const int a = lane % Q;
-        P1s[lane * LDP1 + K4 + 1] = a == 0 ? 1.f : 0.f;
-        P1s[lane * LDP1 + K4 + 2] = a == 0 ? 0.f : -self1[row0 + lane];
+    // the packed rows of the NEXT column tile travel through registers under the current tile's work
+    constexpr int NPFP = (48 * 8 + 63) / 64;       // float4 per lane of one P2 tile (DP <= 32)
+    int pf_r[NPFP], pf_k[NPFP];
+#pragma unroll
+    for (int u = 0; u < NPFP; ++u) {
+        const int e = lane + 64 * u;
+        const int r = e / pch;
+        pf_r[u] = (e < T * pch) ? r : -1;
+        pf_k[u] = (e - r * pch) * 4;
     }
+    f4 pf[NPFP];
+    float pselfv = 0.f;
+    auto prefetch = [&](int ct_) {
+        const int c0_ = ct_ * T;
+#pragma unroll
+        for (int u = 0; u < NPFP; ++u) {
+            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (pf_r[u] >= 0 && c0_ + pf_r[u] < n2q) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(c0_ + pf_r[u]) * DP + pf_k[u]);
+        }
+        pselfv = (lane < T && c0_ + lane < n2q) ? -self2[c0_ + lane] : 0.f;
+    };
 
     // lane-invariant pair geometry
     int pr0[PPL], pc0[PPL];
@@ -1043,6 +1169,7 @@ __global__ __launch_bounds__(64) void kernel_bwd_pair_kernel(const GT* __restric
     for (int i = 0; i < 3; ++i) { acc[i][0] = f4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f4{0.f, 0.f, 0.f, 0.f}; }
     float sK_sum = 0.f, l_acc = 0.f;
 
+    if (BWDP_PREFETCH && (int)blockIdx.x < ncoltiles) prefetch(blockIdx.x);
     for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
         const int col0 = ct * T;
         // upstream micro-blocks straight into registers (consumed after the T' product)
@@ -1071,40 +1198,50 @@ __global__ __launch_bounds__(64) void kernel_bwd_pair_kernel(const GT* __restric
             }
         }
         __syncthreads();   // (single wave: orders the previous tile's MFMA reads of P2s / TT before the new stores)
-        for (int e = lane; e < T * pch; e += 64) {
-            const int r = e / pch, k = (e - r * pch) * 4;
-            const int gr = col0 + r;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gr < n2q) v = *reinterpret_cast<const f4*>(P2 + (int64_t)gr * DP + k);
+        if (!BWDP_PREFETCH) prefetch(ct);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = v[t];
+        for (int u = 0; u < NPFP; ++u) {
+            if (pf_r[u] >= 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P2s[pf_r[u] * LDP + pf_k[u] + t] = pf[u][t];
+            }
         }
         __syncthreads();   // the extension columns go on top of the packed zeros
         if (lane < T) {
-            const int gr = col0 + lane;
-            const bool ok = gr < n2q;
-            P2s[lane * LDP + K4 + 1] = ok ? -self2[gr] : 0.f;
-            P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
+            P2s[lane * LDP + K4 + 1] = pselfv;
+            P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
         }
+        if (BWDP_PREFETCH && ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);      // in flight under the rest of this tile
         __syncthreads();
 
-        // T' = P1' P2'^T : 3 x 3 tiles of 16 x 16, K = K4 + 4
+        // T' = P1' P2'^T : 3 x 3 tiles of 16 x 16, K = K4 + 4  (one straight-line copy per K depth: no per-step branches, the
+        // first product starts from the inline zero)
         if (!(PAIR_ABLATE & 4)) {
             f4 t[3][3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) t[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-            const float* pa = P1s + m16 * LDP1 + kg;
             const float* pb = P2s + m16 * LDP + kg;
-            for (int ks = 0; ks < KS; ++ks) {
-                float av[3], bv[3];
+            auto product = [&](auto ksc) {
+                constexpr int KS_ = decltype(ksc)::value;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { av[i] = pa[i * 16 * LDP1 + ks * 4]; bv[i] = pb[i * 16 * LDP + ks * 4]; }
+                for (int ks = 0; ks < KS_; ++ks) {
+                    float bv[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) bv[j] = pb[j * 16 * LDP + ks * 4];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i][j], 0, 0, 0);
+                }
+            };
+            switch (KS) {
+                case 1: product(std::integral_constant<int, 1>{}); break;
+                case 2: product(std::integral_constant<int, 2>{}); break;
+                case 3: product(std::integral_constant<int, 3>{}); break;
+                case 4: product(std::integral_constant<int, 4>{}); break;
+                case 5: product(std::integral_constant<int, 5>{}); break;
+                case 6: product(std::integral_constant<int, 6>{}); break;
+                case 7: product(std::integral_constant<int, 7>{}); break;
+                default: product(std::integral_constant<int, 8>{}); break;
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -1507,7 +1644,7 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     float* slab = (float*)workspace;
     float* partials = slab + (size_t)ns * n1q * g.NP;
     if (bwd_use_pair(g)) {
-        const size_t lds = sizeof(float) * (48 * (size_t)(g.K4 + 5) + 48 * (size_t)(g.NP + 1) + 48 * (size_t)PAIR_LDT);
+        const size_t lds = sizeof(float) * (48 * (size_t)(g.NP + 1) + 48 * (size_t)PAIR_LDT);
         const int esz = g_is_double ? 8 : 4;
         const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);    // 2-wide loads of the micro-block rows
         dim3 grid(ns, rt);
