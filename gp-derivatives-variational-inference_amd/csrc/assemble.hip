@@ -1373,29 +1373,38 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
     }
 }
 
-// one 64-thread block per point: slabs -> d_x1, d_v1 (through the x/ell scaling and the direction normalisation)
-__global__ __launch_bounds__(64) void kernel_bwd_points_kernel(const float* __restrict__ slab, int nsplit,
-                                                               const float* __restrict__ P1,
-                                                               const float* __restrict__ vnorm1, int n1, int d, int p,
-                                                               int K4, int DP, int NP, const float* __restrict__ hyp,
-                                                               float sym, float* __restrict__ d_x1,
-                                                               float* __restrict__ d_v1) {
-    extern __shared__ float dPs[];          // [q][DP] summed over the split slabs, then [q] dots
-    const int i = blockIdx.x, t = threadIdx.x;
-    const int q = p + 1;
+// one 256-thread block per point: slabs -> d_x1, d_v1 (through the x/ell scaling and the direction normalisation).  Each of the
+// four waves sums every fourth slab (the slabs are 384 KB apart at C4: 32 dependent-latency loads per element on one wave was
+// 21 us for 500 points), the partial sums meet in LDS.  Block 0 also folds the per-workgroup scalar partials into d_hyp (was a
+// launch of its own).
+constexpr int PTS_NT = 256;
+__global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* __restrict__ slab, int nsplit,
+                                                                   const float* __restrict__ P1,
+                                                                   const float* __restrict__ vnorm1, int n1, int d, int p,
+                                                                   int K4, int DP, int NP, const float* __restrict__ hyp,
+                                                                   float sym, float* __restrict__ d_x1,
+                                                                   float* __restrict__ d_v1, const float* __restrict__ partials,
+                                                                   int nblocks, float* __restrict__ d_hyp) {
+    extern __shared__ float dPs[];          // [q][DP] summed over the split slabs, then [q + 1] dots, then [3][q][DP] wave partials
+    const int i = blockIdx.x, t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int q = p + 1, qd = q * DP;
     const int64_t n1q = (int64_t)n1 * q;
     const float ell = hyp[0];
-    for (int e = t; e < q * DP; e += 64) {
+    float* part = dPs + qd + q + 1;
+    for (int e = l; e < qd; e += 64) {
         const int a = e / DP, col = e - a * DP;
+        const float* src = slab + ((int64_t)i * q + a) * NP + col;
         float sum = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) sum += slab[((int64_t)sp * n1q + (int64_t)i * q + a) * NP + col];
-        dPs[e] = sum;
+        for (int sp = w; sp < nsplit; sp += 4) sum += src[(int64_t)sp * n1q * NP];
+        if (w == 0) dPs[e] = sum; else part[(w - 1) * qd + e] = sum;
     }
     __syncthreads();
+    for (int e = t; e < qd; e += PTS_NT) dPs[e] += part[e] + part[qd + e] + part[2 * qd + e];
+    __syncthreads();
     const float* xt = P1 + (int64_t)i * q * DP;
-    float* dots = dPs + q * DP;
+    float* dots = dPs + qd;
     // vhat-bar_a = dP[a,:] + alphabar_a x~ ; dots[a] = vhat_a . vhat-bar_a ; alphabar_a = -dP[a,K4]
-    for (int a = 1 + t; a <= p; a += 64) {
+    for (int a = 1 + t; a <= p; a += PTS_NT) {
         const float* vh = P1 + ((int64_t)i * q + a) * DP;
         const float ab = -dPs[a * DP + K4];
         float dot = 0.f;
@@ -1404,35 +1413,33 @@ __global__ __launch_bounds__(64) void kernel_bwd_points_kernel(const float* __re
     }
     __syncthreads();
     const float nbar = -0.5f * dPs[K4];
-    for (int k = t; k < d; k += 64) {
+    for (int k = t; k < d; k += PTS_NT) {
         // x~bar = dP[0,:] + 2 nbar x~ + sum_a alphabar_a vhat_a
         float xb = dPs[k] + 2.f * nbar * xt[k];
         for (int a = 1; a <= p; ++a) xb += -dPs[a * DP + K4] * P1[((int64_t)i * q + a) * DP + k];
         d_x1[(int64_t)i * d + k] += sym * xb / ell;
     }
-    for (int e = t; e < p * d; e += 64) {
+    for (int e = t; e < p * d; e += PTS_NT) {
         const int a = 1 + e / d, k = e - (a - 1) * d;
         const float* vh = P1 + ((int64_t)i * q + a) * DP;
         const float vb = dPs[a * DP + k] - dPs[a * DP + K4] * xt[k];
         const float inv = 1.f / vnorm1[(int64_t)i * p + (a - 1)];
         d_v1[((int64_t)i * p + (a - 1)) * d + k] += sym * (vb - vh[k] * dots[a]) * inv;   // normalisation Jacobian
     }
-}
-
-__global__ void kernel_bwd_scalars_kernel(const float* __restrict__ partials, int nblocks,
-                                          const float* __restrict__ hyp, float* __restrict__ d_hyp) {
-    __shared__ double r0[256], r1[256];
-    double a = 0, b = 0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
-    r0[threadIdx.x] = a; r1[threadIdx.x] = b;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { r0[threadIdx.x] += r0[threadIdx.x + off]; r1[threadIdx.x] += r1[threadIdx.x + off]; }
+    if (i == 0) {       // sum(G o K) and the lengthscale partials of the tile workgroups -> d_hyp (fixed order: deterministic)
+        __shared__ double r0[PTS_NT], r1[PTS_NT];
+        double a = 0, b = 0;
+        for (int j = t; j < nblocks; j += PTS_NT) { a += partials[2 * j]; b += partials[2 * j + 1]; }
+        r0[t] = a; r1[t] = b;
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        d_hyp[1] += (float)(r0[0] / (double)hyp[1]);   // d outputscale = sum(G o K)/s
-        d_hyp[0] += (float)r1[0];                       // d lengthscale
+        for (int off = PTS_NT / 2; off > 0; off >>= 1) {
+            if (t < off) { r0[t] += r0[t + off]; r1[t] += r1[t + off]; }
+            __syncthreads();
+        }
+        if (t == 0) {
+            d_hyp[1] += (float)(r0[0] / (double)hyp[1]);   // d outputscale = sum(G o K)/s
+            d_hyp[0] += (float)r1[0];                       // d lengthscale
+        }
     }
 }
 
@@ -1669,10 +1676,8 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     DSVGP_LAUNCH_CHECK();
     }
     const float sym = symmetric ? 2.f : 1.f;
-    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64), sizeof(float) * (g.q * g.DP + g.q + 1), ctx->stream,
-                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1);
-    DSVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kernel_bwd_scalars_kernel, dim3(1), dim3(256), 0, ctx->stream, partials, ns * rt, hyp, d_hyp);
+    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(PTS_NT), sizeof(float) * (4 * g.q * g.DP + g.q + 1), ctx->stream,
+                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }
