@@ -675,21 +675,28 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
 }
 
 // the last block row of L^-1 (its X is produced by the last step launch): Y_kj = X_k R_kj, j <= k = nblk - 1
-__global__ __launch_bounds__(256) void chol_yrow_kernel(const double* __restrict__ A, int64_t lda, int n, int k,
-                                                        const double* __restrict__ Xws, const double* __restrict__ Wws,
-                                                        double* __restrict__ Rw, int64_t ldr, double* __restrict__ Yinv,
-                                                        int64_t ldy, double* __restrict__ YinvT) {
-    __shared__ double S[2][64][LDT];
-    const int nblk = (n + 63) / 64;
-    chol_inverse_tile(S, A, lda, n, k, (nblk - (k + 1)) * (k + 1) + blockIdx.x, Xws, Wws, Rw, ldr, Yinv, ldy, nblk, YinvT);
+__device__ __forceinline__ void chol_yrow_tile(double (*S)[64][LDT], int b, const double* __restrict__ A, int64_t lda, int n,
+                                               const double* __restrict__ Xws, const double* __restrict__ Wws,
+                                               double* __restrict__ Rw, int64_t ldr, double* __restrict__ Yinv, int64_t ldy,
+                                               double* __restrict__ YinvT) {
+    const int nblk = (n + 63) / 64, k = nblk - 1;
+    chol_inverse_tile(S, A, lda, n, k, (nblk - (k + 1)) * (k + 1) + b, Xws, Wws, Rw, ldr, Yinv, ldy, nblk, YinvT);
 }
 
 // all solved panels in one launch:  L_ik = A_ik X_k^T  (i > k), in place, one 64 x 64 tile per workgroup
+// (the same launch carries the last block row of L^-1 in its first ny workgroups: the two are independent, and at M' = 600 a
+//  launch of its own costs as much as either of them)
 __global__ __launch_bounds__(256) void chol_panels_kernel(double* __restrict__ A, int64_t lda, int n,
-                                                          const double* __restrict__ Xws) {
+                                                          const double* __restrict__ Xws, const double* __restrict__ Wws,
+                                                          double* __restrict__ Rw, int64_t ldr, double* __restrict__ Yinv,
+                                                          int64_t ldy, double* __restrict__ YinvT, int ny) {
     __shared__ double S[2][64][LDT];
+    if ((int)blockIdx.x < ny) {
+        chol_yrow_tile(S, blockIdx.x, A, lda, n, Xws, Wws, Rw, ldr, Yinv, ldy, YinvT);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x - ny;
     int ti = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while (ti * (ti + 1) / 2 > b) --ti;
@@ -759,13 +766,10 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
                            ldr, Yinv, ldy, nA, YinvT, strip);
         DSVGP_LAUNCH_CHECK();
     }
-    if (Yinv) {
-        hipLaunchKernelGGL(chol_yrow_kernel, dim3(nblk), dim3(256), 0, st, (const double*)A, lda, n, nblk - 1,
-                           (const double*)Xws, (const double*)Wws, Rw, ldr, Yinv, ldy, YinvT);
-        DSVGP_LAUNCH_CHECK();
-    }
-    if (nblk > 1) {
-        hipLaunchKernelGGL(chol_panels_kernel, dim3(nblk * (nblk - 1) / 2), dim3(256), 0, st, A, lda, n, (const double*)Xws);
+    const int ny = Yinv ? nblk : 0, npan = nblk * (nblk - 1) / 2;
+    if (ny + npan > 0) {
+        hipLaunchKernelGGL(chol_panels_kernel, dim3(ny + npan), dim3(256), 0, st, A, lda, n, (const double*)Xws, (const double*)Wws, Rw,
+                           ldr, Yinv, ldy, YinvT, ny);
         DSVGP_LAUNCH_CHECK();
     }
     return 0;

@@ -907,14 +907,16 @@ def test_one_call_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, 
         l1, g1, mu1, varn1 = eng.loss_and_grads(Pg, xd, yd, Dd, nd)
         torch.cuda.synchronize()
         assert eng.c_step_used and varn1.numel() == 0
-        assert abs(l1.item() - l0.item()) < 1e-6 * abs(l0.item())
-        assert relmax(mu1, mu0) < 1e-6
+        # (two runs of the same arithmetic: what differs is the order in which fp32 atomics meet -- a few ulps of the loss)
+        assert abs(l1.item() - l0.item()) < 4e-6 * abs(l0.item()), (overlap, l1.item(), l0.item())
+        assert relmax(mu1, mu0) < 4e-6, (overlap, relmax(mu1, mu0))
         for k in O.PARAM_NAMES:
             if g0[k].numel():
                 assert relmax(g1[k], g0[k]) < 2e-5, (overlap, k, relmax(g1[k], g0[k]))
         assert g1["chol_variational_covar"].triu(1).abs().max().item() == 0.0
         l2, g2, _, _ = eng.loss_and_grads(Pg, xd, yd, Dd, nd)        # second call on the same plan / workspace
-        assert abs(l2.item() - l1.item()) < 1e-6 * abs(l1.item()) and relmax(g2["inducing_points"], g1["inducing_points"]) < 2e-5
+        assert abs(l2.item() - l1.item()) < 4e-6 * abs(l1.item()), (overlap, l2.item(), l1.item())
+        assert relmax(g2["inducing_points"], g1["inducing_points"]) < 2e-5, (overlap, relmax(g2["inducing_points"], g1["inducing_points"]))
     l_ref, g_ref, mu_ref, _ = O.elbo_loss_and_grads(P, x, y, D, nd)
     assert abs(l1.item() - l_ref.item()) < 2e-5 * abs(l_ref.item()) and relmax(mu1, mu_ref) < 2e-4
 
