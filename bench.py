@@ -144,8 +144,13 @@ def main():
                     help="HIP-graph replay of the step (one rank, ELBO fast path); measured no faster than eager at C2, see DESIGN.md")
     ap.add_argument("--dp-algo", default=os.environ.get("DSVGP_DP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
                     help="(N > 1) collective of the large operand: RCCL all-reduce, or reduce-scatter + all-gather")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="HIP events (dominant-kernel / assembly timings) on every K-th timed step; 0 = every step, except on the "
+                         "sub-millisecond configuration c2 where six event records are 5 %% of the step: every 8th there")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.event_every <= 0:
+        args.event_every = 8 if args.config == "c2" else 1
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None:
@@ -191,6 +196,8 @@ def main():
         eng.trsm_nb = args.trsm_nb
     if args.no_overlap:
         eng.overlap = False        # (default None: automatic by problem size)
+    if os.environ.get("DSVGP_OVERLAP") == "1":
+        eng.overlap = True         # diagnostics: the side stream also below M' = 2048
     eng.fused_inverse = not args.no_fused_inverse
     eng.lib_dense_gemm = bool(args.lib_gemm)
     eng.global_gram = not args.no_global_gram
@@ -233,6 +240,7 @@ def main():
     eng.events = []
     if hasattr(eng, "c_step_timed"):
         eng.c_step_timed = []
+        eng.record_every, eng._rec_count = args.event_every, 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -244,6 +252,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if hasattr(eng, "record_every"):
+        eng.record_every = 1             # (the untimed passes below: every step)
     if loop._graphs:
         # the timed steps were graph replays (no HIP events inside a graph): the per-kernel timings of the roofline entries
         # come from three more, untimed, eager steps of the same loop
@@ -397,6 +407,8 @@ def main():
                        "parallelism": "dp%d rows" % world, "trsm_nb": eng.trsm_nb, "final_loss": final_loss,
                        "graph_replay": bool(loop._graphs),
                        "one_call_step": bool(getattr(eng, "c_step_used", False)),
+                       "kernel_events": "HIP events around the roofline kernels on every %s timed step" % (
+                           "single" if args.event_every == 1 else "%d-th" % args.event_every),
                        "dense_product": "rocBLAS sgemm" if eng.lib_dense_gemm else "hand-written (gemm32.hip, v_mfma_f32_32x32x2_f32)",
                        "timed_step": "TrainLoop.step(need_variance=False): ELBO fast path every step; the reference's "
                                      "every-50th-step nll print (per-output path, ~+9 ms once per 50 steps at C4) is "

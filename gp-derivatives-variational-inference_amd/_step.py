@@ -144,6 +144,8 @@ class ElboEngine:
         self._plans = {}
         self.c_step_used = False        # whether the last step ran through the one-call path
         self.c_step_timed = []          # plans of the steps queued with record_events on, in order
+        self.record_every = 1           # bench.py: HIP events on every record_every-th one-call step only (an event record costs the
+        self._rec_count = 0             # stream ~5 us: six of them are 5 % of a 0.6 ms step, nothing of a 14 ms one)
         self.host_trace = None
 
     @property
@@ -1003,8 +1005,13 @@ class ElboEngine:
         io.d_raw_lengthscale, io.d_raw_outputscale = P(grads["raw_lengthscale"]), P(grads["raw_outputscale"])
         io.d_raw_noise, io.loss, io.mu = P(grads["raw_noise"]), P(loss_out), P(mu)
         io.num_data, io.global_rows, io.kzz_jitter = float(num_data), float(rows), float(self.kzz_jitter)
-        overlap = self.overlap if self.overlap is not None else Mp >= 2048
-        flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if self.record_events else 0)
+        # the second stream from M' = 512 up: queued from C (two event records + two waits per fork / join) it pays at C2 already
+        # (M' = 600: 0.632 -> 0.615 ms/step); the Python-orchestrated path keeps its M' >= 2048 rule
+        overlap = self.overlap if self.overlap is not None else Mp >= 512
+        timed = self.record_events and self._rec_count % max(1, self.record_every) == 0
+        if self.record_events:
+            self._rec_count += 1
+        flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if timed else 0)
         tr = self.host_trace                  # (tools/host_trace.py: where the host's time goes; None in production)
         if tr is not None:
             import time as _t
@@ -1018,7 +1025,7 @@ class ElboEngine:
         self._hyp_host = hyp[:3]
         if info != 0:
             raise _Refactored()
-        if self.record_events:
+        if timed:
             self.c_step_timed.append(plan)              # bench.py reads plan.timings(back) after its timed region
         self.c_step_used = True
         self._pending = None

@@ -78,6 +78,14 @@ int launch_variational_terms(hipStream_t st, const float* m, const float* LS, in
                              const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,
                              float* sums, const float* dm_src, float* d_m, float* d_LS, int64_t lddls, int fin_npts, int fin_p,
                              float* fin_scal);                                                 // elbo.hip
+// column statistics (mu = A^T m + c, prior diagonal) + residuals / mu-bar / their sums: two launches instead of three
+int launch_stats_residual(dsvgp_ctx* ctx, const float* A, int64_t lda, int Mp, int ncols, int p, const float* m,
+                          const float* constant, const float* hyp, float* mu, float* var, void* workspace, const float* y,
+                          double global_rows, float* mu_bar, float* sums);                     // elbo.hip
+// Z-bar, V-bar, d_hyp[0..1] *= 2 vbar and the scalar tail of the step (dsvgp_scale_by_vbar + dsvgp_step_epilogue) in one launch
+int launch_scale_epilogue(dsvgp_ctx* ctx, float* x0, int64_t n0, float* x1, int64_t n1, const float* hyp, double rows,
+                          const float* scal, const float* kl0, double num_data, const float* rl, const float* rs, const float* rn,
+                          float* dh, float* drl, float* drs, float* drn, float* dconst, float* loss);   // elbo.hip
 
 // trtri of the nb x nb diagonal blocks of the lower-triangular L into Dinv (same indexing as L,
 // leading dimension ldd); tmp is an n x (nb/2) double scratch.  X64 (may be null): the inverted 64 x 64 diagonal

@@ -327,6 +327,30 @@ __global__ __launch_bounds__(256) void scale3_kernel(float* __restrict__ x0, int
     }
 }
 
+// scale3_kernel (Z-bar, V-bar, d_hyp[0..1] *= 2 vbar) + step_epilogue_kernel in one launch: the first thread of the grid scales
+// d_hyp[0..1] itself and goes on with the scalar tail
+__global__ __launch_bounds__(256) void scale_epilogue_kernel(float* __restrict__ x0, int64_t n0, float* __restrict__ x1, int64_t n1,
+                                                             const float* __restrict__ hyp, float inv_rows, const float* scal,
+                                                             const float* kl0, float inv_num_data, const float* rl, const float* rs,
+                                                             const float* rn, float* dh, float* drl, float* drs, float* drn,
+                                                             float* dconst, float* loss) {
+    const float s = inv_rows / hyp[2];
+    const int64_t tot = n0 + n1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+        if (i < n0) x0[i] *= s;
+        else x1[i - n0] *= s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float d0 = dh[0] * s + scal[4], d1 = dh[1] * s + scal[3], d2 = dh[2] + scal[1];
+        dh[0] = d0; dh[1] = d1; dh[2] = d2;
+        drl[0] += d0 * sigmoidf(rl[0]);
+        drs[0] += d1 * sigmoidf(rs[0]);
+        drn[0] += d2 * sigmoidf(rn[0]);
+        dconst[0] += scal[2];
+        loss[0] = -scal[0] * inv_rows + kl0[0] * inv_num_data;
+    }
+}
+
 // scal layout of likelihood_kernel: 0 sum_ll, 1 d_noise, 2 d_constant, 3 d_outputscale(diag), 4 d_lengthscale(diag)
 __device__ __forceinline__ void elbo_fast_finalize_body(const float* __restrict__ sums, const float* __restrict__ hyp, int npts,
                                                         int p, float inv_rows, float* __restrict__ scal) {
@@ -482,6 +506,38 @@ __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__
         if (partials) partials[blockIdx.x * 8 + threadIdx.x] = v;     // deterministic mode
         else atomicAdd(&sums[threadIdx.x], v);
     }
+}
+// colstats_finish_kernel + residual_kernel in one launch (the one-call step: two ~5 us launches at M' = 600): mu_j = sum of the
+// chunk partials + c, r_j = y_j - mu_j, mu-bar_j, sums[0] += r^2, sums[1] += mu-bar
+__global__ __launch_bounds__(256) void colstats_residual_kernel(const float* __restrict__ part, int nchunk, int ncols, int p,
+                                                                const float* __restrict__ constant, const float* __restrict__ hyp,
+                                                                float* __restrict__ mu, float* __restrict__ var,
+                                                                const float* __restrict__ y, float inv_rows,
+                                                                float* __restrict__ mu_bar, float* __restrict__ sums) {
+    __shared__ float red[2][4];
+    const float ell = hyp[0], s = hyp[1], noise = hyp[2], c0 = constant[0];
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < ncols; j += gridDim.x * 256) {
+        float sm = 0.f, sq = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            sm += part[((int64_t)c * 2) * ncols + j];
+            sq += part[((int64_t)c * 2 + 1) * ncols + j];
+        }
+        const float dg = (j % (p + 1) == 0) ? s : s / (ell * ell);
+        const float mj = sm + c0;
+        mu[j] = mj;
+        var[j] = dg + KXX_JITTER + sq;
+        const float r = y[j] - mj;
+        const float mb = -r / noise * inv_rows;
+        mu_bar[j] = mb;
+        a0 = fmaf(r, r, a0);
+        a1 += mb;
+    }
+    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2) atomicAdd(&sums[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 // sums[2] += sum_{i>=j} LS_ij T1_ij  (= |L_S^T A|_F^2) ; sums[3] += trace(G)
 __global__ __launch_bounds__(256) void trace_kernel(const float* __restrict__ LS, int64_t ldls,
@@ -749,6 +805,43 @@ extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* pa
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, t, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2));
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused launches of the one-call step (csrc/step.hip) ---------------------------------------------
+int launch_stats_residual(dsvgp_ctx* ctx, const float* A, int64_t lda, int Mp, int ncols, int p, const float* m,
+                          const float* constant, const float* hyp, float* mu, float* var, void* workspace, const float* y,
+                          double global_rows, float* mu_bar, float* sums) {
+    if (ctx->det_slab || ncols == 0) {          // deterministic mode keeps its per-workgroup partials: the two public calls
+        int rc = dsvgp_predictive_stats(ctx, A, lda, A, lda, Mp, ncols, p, m, constant, hyp, mu, var, workspace);
+        if (rc) return rc;
+        return dsvgp_residual_terms(ctx, mu, y, ncols, hyp, global_rows, mu_bar, sums);
+    }
+    if (!ctx->prezeroed) {
+        hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(float), ctx->stream);
+        if (e != hipSuccess) return 1000 + (int)e;
+    }
+    const int nch = stats_chunks(Mp), rpc = cdiv(Mp, nch);
+    hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(ncols, 256), nch), dim3(256), 0, ctx->stream, A, lda, A, lda, Mp, ncols, m, rpc,
+                       (float*)workspace);
+    DSVGP_LAUNCH_CHECK();
+    int blocks = cdiv(ncols, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(colstats_residual_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)workspace, nch, ncols, p,
+                       constant, hyp, mu, var, y, (float)(1.0 / global_rows), mu_bar, sums);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+int launch_scale_epilogue(dsvgp_ctx* ctx, float* x0, int64_t n0, float* x1, int64_t n1, const float* hyp, double rows,
+                          const float* scal, const float* kl0, double num_data, const float* rl, const float* rs, const float* rn,
+                          float* dh, float* drl, float* drs, float* drn, float* dconst, float* loss) {
+    const int64_t tot = n0 + n1;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_epilogue_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x0, n0, x1, n1, hyp, (float)(1.0 / rows), scal,
+                       kl0, (float)(1.0 / num_data), rl, rs, rn, dh, drl, drs, drn, dconst, loss);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

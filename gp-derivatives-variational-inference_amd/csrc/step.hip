@@ -295,8 +295,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     STEP_TIME(0);
     STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 0, Kzx, Bp, 0, Bp, nullptr, 0, A32, Bp, nb, trsm_ws, 1));
     STEP_TIME(1);
-    STEP_CALL(dsvgp_predictive_stats(ctx, A32, Bp, A32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var0, stats_ws));
-    STEP_CALL(dsvgp_residual_terms(ctx, io->mu, io->y, Bp, hyp, rows, mu_bar, sums));
+    STEP_CALL(launch_stats_residual(ctx, A32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var0, stats_ws, io->y, rows, mu_bar, sums));
     // ---- [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), split-K over the minibatch axis; G mirrored
     STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
                          Mp, nullptr, 0, nullptr));
@@ -364,8 +363,8 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     if (zx_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
     STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
     // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
-    STEP_CALL(dsvgp_scale_by_vbar(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, io->d_hyp, 2, hyp, rows));
-    STEP_CALL(dsvgp_step_epilogue(ctx, scal, kl_buf, rows, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
-                                  io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));
+    STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,
+                                    kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
+                                    io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));
     return 0;
 }

@@ -86,9 +86,9 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        batch = {}      # tensors that share device, step count and hyper-parameters go out in ONE launch, whatever group they are in
+        for group in self.param_groups:                  # (train_gp's hyper-parameter optimizer has two groups with equal settings)
             b1, b2 = group["betas"]
-            batch = {}                                   # tensors that share the step count go out in one launch
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -99,15 +99,16 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                batch.setdefault((st["step"], p.device), []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
-            for (step, dev), items in batch.items():
-                ctx = _ops.Context.get(dev)
-                for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
-                    ps, gs, ms, vs = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
-                    if len(ps) == 1:
-                        _ops.adam_step_(ctx, ps[0], gs[0], ms[0], vs[0], group["lr"], b1, b2, group["eps"], step)
-                    else:
-                        _ops.adam_step_multi_(ctx, ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], step)
+                key = (st["step"], p.device, float(group["lr"]), float(b1), float(b2), float(group["eps"]))
+                batch.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+        for (step, dev, lr, b1, b2, eps), items in batch.items():
+            ctx = _ops.Context.get(dev)
+            for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
+                ps, gs, ms, vs = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
+                if len(ps) == 1:
+                    _ops.adam_step_(ctx, ps[0], gs[0], ms[0], vs[0], lr, b1, b2, eps, step)
+                else:
+                    _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step)
         return loss
 
 

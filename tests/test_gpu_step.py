@@ -893,7 +893,7 @@ def test_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device, 
 def test_one_call_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, B):
     """dsvgp_elbo_step_f32 queues the same library calls in the same order as the Python-orchestrated fast path: loss, mean and
     every gradient agree to the run-order noise of the split-K atomics (1e-5), with and without the second stream, and against
-    the oracle like the piecewise path.  (M' = 2220 >= 2048: the overlap schedule is on by default.)"""
+    the oracle like the piecewise path.  (M' = 600 and 2220 >= 512: the overlap schedule is on by default there.)"""
     P, x, y, D, nd = make_problem(N, d, M, p, B, seed=N + d + 1)
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
     xd, yd, Dd = x.to(gpu_device), y.to(gpu_device), D.to(gpu_device)
