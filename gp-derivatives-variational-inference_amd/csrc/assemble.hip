@@ -1385,8 +1385,9 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
                                                                    float sym, float* __restrict__ d_x1,
                                                                    float* __restrict__ d_v1, const float* __restrict__ partials,
                                                                    int nblocks, float* __restrict__ d_hyp) {
-    extern __shared__ float dPs[];          // [q][DP] summed over the split slabs, then [q + 1] dots, then [3][q][DP] wave partials
+    extern __shared__ float dPs[];          // [q][DP] summed over the split slabs, then [q + 1] dots, then [waves - 1][q][DP] wave partials
     const int i = blockIdx.x, t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int nth = blockDim.x, nw = nth >> 6;          // 4 waves; 1 when the partials would not fit into LDS (q DP > 3072)
     const int q = p + 1, qd = q * DP;
     const int64_t n1q = (int64_t)n1 * q;
     const float ell = hyp[0];
@@ -1395,16 +1396,22 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
         const int a = e / DP, col = e - a * DP;
         const float* src = slab + ((int64_t)i * q + a) * NP + col;
         float sum = 0.f;
-        for (int sp = w; sp < nsplit; sp += 4) sum += src[(int64_t)sp * n1q * NP];
+        for (int sp = w; sp < nsplit; sp += nw) sum += src[(int64_t)sp * n1q * NP];
         if (w == 0) dPs[e] = sum; else part[(w - 1) * qd + e] = sum;
     }
     __syncthreads();
-    for (int e = t; e < qd; e += PTS_NT) dPs[e] += part[e] + part[qd + e] + part[2 * qd + e];
-    __syncthreads();
+    if (nw > 1) {
+        for (int e = t; e < qd; e += nth) {
+            float sum = dPs[e];
+            for (int ww = 1; ww < nw; ++ww) sum += part[(ww - 1) * qd + e];
+            dPs[e] = sum;
+        }
+        __syncthreads();
+    }
     const float* xt = P1 + (int64_t)i * q * DP;
     float* dots = dPs + qd;
     // vhat-bar_a = dP[a,:] + alphabar_a x~ ; dots[a] = vhat_a . vhat-bar_a ; alphabar_a = -dP[a,K4]
-    for (int a = 1 + t; a <= p; a += PTS_NT) {
+    for (int a = 1 + t; a <= p; a += nth) {
         const float* vh = P1 + ((int64_t)i * q + a) * DP;
         const float ab = -dPs[a * DP + K4];
         float dot = 0.f;
@@ -1413,13 +1420,13 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
     }
     __syncthreads();
     const float nbar = -0.5f * dPs[K4];
-    for (int k = t; k < d; k += PTS_NT) {
+    for (int k = t; k < d; k += nth) {
         // x~bar = dP[0,:] + 2 nbar x~ + sum_a alphabar_a vhat_a
         float xb = dPs[k] + 2.f * nbar * xt[k];
         for (int a = 1; a <= p; ++a) xb += -dPs[a * DP + K4] * P1[((int64_t)i * q + a) * DP + k];
         d_x1[(int64_t)i * d + k] += sym * xb / ell;
     }
-    for (int e = t; e < p * d; e += PTS_NT) {
+    for (int e = t; e < p * d; e += nth) {
         const int a = 1 + e / d, k = e - (a - 1) * d;
         const float* vh = P1 + ((int64_t)i * q + a) * DP;
         const float vb = dPs[a * DP + k] - dPs[a * DP + K4] * xt[k];
@@ -1429,10 +1436,11 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
     if (i == 0) {       // sum(G o K) and the lengthscale partials of the tile workgroups -> d_hyp (fixed order: deterministic)
         __shared__ double r0[PTS_NT], r1[PTS_NT];
         double a = 0, b = 0;
-        for (int j = t; j < nblocks; j += PTS_NT) { a += partials[2 * j]; b += partials[2 * j + 1]; }
+        for (int j = t; j < nblocks; j += nth) { a += partials[2 * j]; b += partials[2 * j + 1]; }
         r0[t] = a; r1[t] = b;
+        for (int j = nth + t; j < PTS_NT; j += nth) { r0[j] = 0; r1[j] = 0; }
         __syncthreads();
-        for (int off = PTS_NT / 2; off > 0; off >>= 1) {
+        for (int off = PTS_NT / 2; off > 0; off >>= 1) {        // (threads past nth hold zeros)
             if (t < off) { r0[t] += r0[t + off]; r1[t] += r1[t + off]; }
             __syncthreads();
         }
@@ -1676,7 +1684,8 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     DSVGP_LAUNCH_CHECK();
     }
     const float sym = symmetric ? 2.f : 1.f;
-    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(PTS_NT), sizeof(float) * (4 * g.q * g.DP + g.q + 1), ctx->stream,
+    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;       // (wave partials: <= 48 KB of LDS)
+    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), ctx->stream,
                        slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
     DSVGP_LAUNCH_CHECK();
     return 0;

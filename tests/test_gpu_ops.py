@@ -116,7 +116,8 @@ def test_kernel_diag_and_errors(dsvgp, gpu_device):
 
 # ------------------------------------------------------------------ kernel assembly backward
 @pytest.mark.parametrize("n1,n2,d,p,sym", [(11, 23, 5, 2, False), (20, 45, 20, 5, False), (18, 18, 20, 5, True),
-                                           (40, 300, 4, 1, False), (9, 9, 3, 3, True), (6, 10, 6, 0, False)])
+                                           (40, 300, 4, 1, False), (9, 9, 3, 3, True), (6, 10, 6, 0, False),
+                                           (4, 7, 80, 40, False)])       # (q DP = 41 x 84 > 3072: the one-wave tail of the backward)
 def test_kernel_bwd_matches_autograd(dsvgp, gpu_device, n1, n2, d, p, sym):
     ops = dsvgp._ops
     g = torch.Generator().manual_seed(n1 + 31 * n2 + d)
