@@ -95,6 +95,7 @@ SIGNATURES = {
     "dsvgp_kl_terms": (_i, [_p, _p, _p, _l, _i, _d, _p, _p, _p, _l]),
     "dsvgp_phi_symmetrize": (_i, [_p, _p, _i, _l]),
     "dsvgp_transpose_f64": (_i, [_p, _p, _l, _i, _i, _p, _l]),
+    "dsvgp_gemv_f64": (_i, [_p, _i, _p, _l, _i, _i, _p, _p]),
     "dsvgp_transpose_f32": (_i, [_p, _p, _l, _i, _i, _p, _l]),
     "dsvgp_residual_terms": (_i, [_p, _p, _p, _i, _p, _d, _p, _p]),
     "dsvgp_trace_terms": (_i, [_p, _p, _l, _p, _l, _p, _l, _i, _f, _p]),

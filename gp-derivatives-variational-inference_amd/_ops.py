@@ -473,6 +473,18 @@ def phi_symmetrize_(ctx, G):
     check(lib.dsvgp_phi_symmetrize(ctx.h, _ptr(G), G.shape[0], _ld(G)), "dsvgp_phi_symmetrize")
 
 
+def gemv_f64(ctx, A, x, y, trans=False):
+    """y = A x (trans False: A [M, N], x [N], y [M]) or y = A^T x (x [M], y [N]) in fp64"""
+    _req(A, f64, "A", 2)
+    M, N = A.shape
+    _req(x, f64, "x", 1)
+    _req(y, f64, "y", 1)
+    if x.numel() != (M if trans else N) or y.numel() != (N if trans else M):
+        raise ValueError("gemv_f64 shape mismatch")
+    check(lib.dsvgp_gemv_f64(ctx.h, 1 if trans else 0, _ptr(A), _ld(A), M, N, _ptr(x), _ptr(y)), "dsvgp_gemv_f64")
+    return y
+
+
 def transpose_f64(ctx, src, dst):
     check(lib.dsvgp_transpose_f64(ctx.h, _ptr(src), _ld(src), src.shape[0], src.shape[1], _ptr(dst), _ld(dst)),
           "dsvgp_transpose_f64")

@@ -753,6 +753,74 @@ extern "C" int dsvgp_transpose_f32(dsvgp_ctx* ctx, const float* in, int64_t ldi,
     return 0;
 }
 
+// ---- fp64 matrix-vector products of the float64 model mode (_step64.py: mu = A^T m, b = A mu-bar on the [M', B'] panel) ----
+// y = A x: one wave per row, 16-byte loads, butterfly sum.   y = A^T x: a thread per pair of columns, rows in chunks over
+// blockIdx.y, fp64 atomics onto the zeroed y.  (As N = 1 products on the 128 x 128 GEMM kernel they took 0.53 ms each at C4: 1.1 TB/s.)
+__global__ __launch_bounds__(256) void gemv64_rows_kernel(const double* __restrict__ A, int64_t lda, int M, int N,
+                                                          const double* __restrict__ x, double* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const double* a = A + (int64_t)row * lda;
+    double s = 0.0;
+    const bool vec = (lda % 2 == 0) && (((uintptr_t)A % 16) == 0) && (((uintptr_t)x % 16) == 0);
+    if (vec) {
+        const int n2 = N / 2;
+        for (int j = lane; j < n2; j += 64) {
+            const double2 av = *reinterpret_cast<const double2*>(a + 2 * j);
+            const double2 xv = *reinterpret_cast<const double2*>(x + 2 * j);
+            s = fma(av.x, xv.x, s);
+            s = fma(av.y, xv.y, s);
+        }
+        if ((N & 1) && lane == 0) s = fma(a[N - 1], x[N - 1], s);
+    } else {
+        for (int j = lane; j < N; j += 64) s = fma(a[j], x[j], s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) y[row] = s;
+}
+__global__ __launch_bounds__(256) void gemv64_cols_kernel(const double* __restrict__ A, int64_t lda, int M, int N,
+                                                          const double* __restrict__ x, int rows_per_chunk,
+                                                          double* __restrict__ y) {
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const int i0 = blockIdx.y * rows_per_chunk, i1 = min(M, i0 + rows_per_chunk);
+    const bool two = j + 1 < N, vec = two && (lda % 2 == 0) && (((uintptr_t)A % 16) == 0);
+    double s0 = 0.0, s1 = 0.0;
+    if (vec) {
+#pragma unroll 4
+        for (int i = i0; i < i1; ++i) {
+            const double2 av = *reinterpret_cast<const double2*>(A + (int64_t)i * lda + j);
+            const double xi = x[i];
+            s0 = fma(av.x, xi, s0);
+            s1 = fma(av.y, xi, s1);
+        }
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const double xi = x[i];
+            s0 = fma(A[(int64_t)i * lda + j], xi, s0);
+            if (two) s1 = fma(A[(int64_t)i * lda + j + 1], xi, s1);
+        }
+    }
+    atomicAdd(&y[j], s0);
+    if (two) atomicAdd(&y[j + 1], s1);
+}
+extern "C" int dsvgp_gemv_f64(dsvgp_ctx* ctx, int trans, const double* A, int64_t lda, int M, int N, const double* x,
+                              double* y) {
+    if (!ctx || !A || !x || !y || M <= 0 || N <= 0 || lda < N) return DSVGP_EINVAL;
+    if (!trans) {
+        hipLaunchKernelGGL(gemv64_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ctx->stream, A, lda, M, N, x, y);
+    } else {
+        hipError_t e = hipMemsetAsync(y, 0, (size_t)N * sizeof(double), ctx->stream);
+        if (e != hipSuccess) return 1000 + (int)e;
+        int nch = cdiv(M, 64);
+        if (nch > 64) nch = 64;
+        const int rpc = cdiv(M, nch);
+        hipLaunchKernelGGL(gemv64_cols_kernel, dim3(cdiv(N, 512), cdiv(M, rpc)), dim3(256), 0, ctx->stream, A, lda, M, N, x, rpc, y);
+    }
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dsvgp_add_diag(dsvgp_ctx* ctx, double* A, int n, int64_t lda, double delta) {
     if (!ctx || !A || n <= 0) return DSVGP_EINVAL;
     hipLaunchKernelGGL(add_diag_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, A, n, lda, delta);

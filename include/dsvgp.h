@@ -231,6 +231,10 @@ int dsvgp_transpose_f64(dsvgp_ctx* ctx, const double* in, int64_t ldi, int rows,
                         int64_t ldo);
 int dsvgp_transpose_f32(dsvgp_ctx* ctx, const float* in, int64_t ldi, int rows, int cols, float* out,
                         int64_t ldo);
+/* fp64 matrix-vector product on a row-major M x N matrix: trans = 0: y[M] = A x[N];  trans = 1: y[N] = A^T x[M] (sums meet in
+ * fp64 atomics: run-order rounding).  The float64 model mode's predictive mean A^T m and b = A mu-bar
+ * (DirectionalGradVariationalStrategy.py:181-183 under torch.set_default_dtype(torch.float64), experiments/synthetic/exp_script.py:56). */
+int dsvgp_gemv_f64(dsvgp_ctx* ctx, int trans, const double* A, int64_t lda, int M, int N, const double* x, double* y);
 
 /* ---- ELBO-mode fast path.  With mll_type == ELBO, dLoss/dvar_j = 1/(2 noise rows) is the same for every
  * output, so the data term only needs  sum_j (y_j - mu_j)^2  and  sum_j var_j = prior + |L_S^T A|_F^2 - |A|_F^2,

@@ -612,3 +612,19 @@ def test_mfma_rate_probe_reports_a_plausible_roof(dsvgp, gpu_device):
     r32 = dsvgp._ops.mfma_rate(ctx, False, 10)
     assert 39.0 < r64 <= 78.6 * 1.02, r64
     assert 78.0 < r32 <= 157.3 * 1.02, r32
+
+
+@pytest.mark.parametrize("M,N,pad", [(300, 1537, 0), (37, 64, 1), (3000, 2048, 0), (1, 5, 0)])
+def test_gemv_f64_both_orientations(dsvgp, gpu_device, M, N, pad):
+    """dsvgp_gemv_f64 (the float64 model mode's A^T m and A mu-bar): against torch fp64, 1e-13; odd row strides and sizes take
+    the scalar path"""
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, N + pad, generator=g, dtype=torch.float64).to(gpu_device)[:, :N]
+    for trans in (False, True):
+        x = torch.randn(M if trans else N, generator=g, dtype=torch.float64).to(gpu_device)
+        y = torch.full((N if trans else M,), float("nan"), dtype=torch.float64, device=gpu_device)
+        ops.gemv_f64(ctx, A, x, y, trans=trans)
+        ref = (A.t() if trans else A) @ x
+        assert relmax(y, ref) < 1e-13, (M, N, pad, trans, relmax(y, ref))
