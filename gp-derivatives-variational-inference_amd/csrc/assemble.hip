@@ -240,6 +240,9 @@ constexpr int FWD_PAIR_LDT = 52;
 #ifndef FWDP_CHUNK
 #define FWDP_CHUNK 1      // consecutive column tiles per wave (87.7 -> 85.7 us)
 #endif
+#ifndef FWDP_LEAN
+#define FWDP_LEAN 1       // tiles inside the matrix are fetched and staged without predicates (needs FWDP_OVERLAY and a 49th LDS row)
+#endif
 #ifndef FWDP_FAST
 #define FWDP_FAST 1       // interior tiles leave through the T' tile as fully coalesced 16-byte stores
 #endif
@@ -310,8 +313,32 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
     constexpr int NPFP = (48 * 8 + 63) / 64;       // float4 per lane of one prefetched P2 tile (DP <= 32)
     f4 pf[NPFP];
     float pselfv = 0.f;
+    // The packed rows of a column tile are ONE contiguous piece of P2 (T rows of DP floats): float4 number e = lane + 64 u of it
+    // goes to row e / pch of the LDS image.  Per-lane constants: the element index (clamped to the tile for the lanes past its
+    // end) and the LDS offset (those lanes write to a scratch row behind the image) -- a tile that lies inside the matrix is then
+    // fetched and staged without a single predicate (the guarded form below spends ~15 instructions per float4 on masks, zero
+    // fills and 64-bit address arithmetic: PMC, profiles/r03_c_pmc_assemble_fwd_*.txt).
+    int pf_e[NPFP], pf_lds[NPFP];
+#pragma unroll
+    for (int u = 0; u < NPFP; ++u) {
+        const int e = lane + 64 * u;
+        const int ec = min(e, T * pch - 1);
+        const int r = ec / pch, k = (ec - r * pch) * 4;
+        pf_e[u] = ec;
+        pf_lds[u] = (e < T * pch ? r : 48) * LDP + k;
+    }
+    const bool rows_full = row0 + T <= n1q;
     auto prefetch = [&](int ct_) {
         const int c0_ = ct_ * T;
+#if FWDP_LEAN
+        if (c0_ + T <= n2q) {
+            const f4* src = reinterpret_cast<const f4*>(P2 + (int64_t)c0_ * DP);
+#pragma unroll
+            for (int u = 0; u < NPFP; ++u) pf[u] = src[pf_e[u]];
+            pselfv = -self2[c0_ + min(lane, T - 1)];
+            return;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < NPFP; ++u) {
             const int e = lane + 64 * u;
@@ -332,10 +359,23 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
     for (int ct = ct_lo; ct < ct_hi; ct += ct_step) {
         const int col0 = ct * T;
         float s2c0[PPL];
+        const bool full = FWDP_LEAN && rows_full && col0 + T <= n2q;       // (wave-uniform)
+        if (full) {
 #pragma unroll
-        for (int pp = 0; pp < PPL; ++pp) s2c0[pp] = (prow[pp] && col0 + pc0[pp] < n2q) ? self2[col0 + pc0[pp]] : 0.f;
+            for (int pp = 0; pp < PPL; ++pp) s2c0[pp] = self2[col0 + min(pc0[pp], T - 1)];
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) s2c0[pp] = (prow[pp] && col0 + pc0[pp] < n2q) ? self2[col0 + pc0[pp]] : 0.f;
+        }
         __syncthreads();   // single wave: orders the previous tile's LDS reads before the new stores
         if (FWDP_OVERLAY) {
+#if FWDP_LEAN
+#pragma unroll
+            for (int u = 0; u < NPFP; ++u) {           // (lanes past the end of the tile: the scratch row behind the image)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P2s[pf_lds[u] + t] = pf[u][t];
+            }
+#else
 #pragma unroll
             for (int u = 0; u < NPFP; ++u) {
                 const int e = lane + 64 * u;
@@ -345,6 +385,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                     for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
                 }
             }
+#endif
             __syncthreads();
             if (lane < T) {
                 P2s[lane * LDP + K4 + 1] = pselfv;
@@ -1085,6 +1126,9 @@ constexpr int PAIR_WGS = PAIR_WGS_;
 #ifndef BWDP_MINW
 #define BWDP_MINW 2        // waves per SIMD the register allocation leaves room for: 2 (<= 256 VGPRs; the micro-block transform holds
 #endif                     // 36 upstream + 36 T' + 24 A-fragment + 24 accumulator registers); 3 (<= 168) spills: 270 us instead of 157
+#ifndef BWDP_LEAN
+#define BWDP_LEAN 1        // tiles inside the matrix: packed side-2 rows fetched and staged without predicates (142 -> 138 us; the same for
+#endif                     // the upstream micro-block loads measured SLOWER: 167 us)
 #ifndef BWDP_PREFETCH
 #define BWDP_PREFETCH 0    // 1: the next tile's packed side-2 rows travel through registers under the current tile (36 more registers,
 #endif                     //    same time at 8 waves per CU: 157 us either way)
@@ -1102,7 +1146,7 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
     const int LDP = NP + 1;
     // (the A fragments of the wave's 48 side-1 rows stay in registers for the whole sweep: no LDS image of P1')
     float* P2s = smem;                  // [48][LDP]   extended side-2 packs of the current tile
-    float* TT = P2s + 48 * LDP;         // [48][LDT2]  T', then Tbar in place
+    float* TT = P2s + ((49 * LDP + 3) & ~3);      // [48][LDT2]  T', then Tbar in place (16-byte aligned: its 8-byte strips); row 48 of P2s: scratch of the predicate-free staging
     const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
     const int row0 = blockIdx.y * T;
     const int ncoltiles = (n2q + T - 1) / T;
@@ -1131,18 +1175,29 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
     }
     // the packed rows of the NEXT column tile travel through registers under the current tile's work
     constexpr int NPFP = (48 * 8 + 63) / 64;       // float4 per lane of one P2 tile (DP <= 32)
-    int pf_r[NPFP], pf_k[NPFP];
+    // (the packed rows of a column tile are one contiguous piece of P2: see kernel_fwd_pair_kernel)
+    int pf_r[NPFP], pf_k[NPFP], pf_e[NPFP], pf_lds[NPFP];
 #pragma unroll
     for (int u = 0; u < NPFP; ++u) {
         const int e = lane + 64 * u;
         const int r = e / pch;
         pf_r[u] = (e < T * pch) ? r : -1;
         pf_k[u] = (e - r * pch) * 4;
+        const int ec = min(e, T * pch - 1), rc = ec / pch;
+        pf_e[u] = ec;
+        pf_lds[u] = (e < T * pch ? rc : 48) * LDP + (ec - rc * pch) * 4;
     }
     f4 pf[NPFP];
     float pselfv = 0.f;
     auto prefetch = [&](int ct_) {
         const int c0_ = ct_ * T;
+        if (BWDP_LEAN && c0_ + T <= n2q) {               // a tile inside the matrix: no predicates
+            const f4* src = reinterpret_cast<const f4*>(P2 + (int64_t)c0_ * DP);
+#pragma unroll
+            for (int u = 0; u < NPFP; ++u) pf[u] = src[pf_e[u]];
+            pselfv = -self2[c0_ + min(lane, T - 1)];
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NPFP; ++u) {
             pf[u] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1200,11 +1255,9 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
         __syncthreads();   // (single wave: orders the previous tile's MFMA reads of P2s / TT before the new stores)
         if (!BWDP_PREFETCH) prefetch(ct);
 #pragma unroll
-        for (int u = 0; u < NPFP; ++u) {
-            if (pf_r[u] >= 0) {
+        for (int u = 0; u < NPFP; ++u) {               // (lanes past the end of the tile: the scratch row)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) P2s[pf_r[u] * LDP + pf_k[u] + t] = pf[u][t];
-            }
+            for (int t = 0; t < 4; ++t) P2s[pf_lds[u] + t] = pf[u][t];
         }
         __syncthreads();   // the extension columns go on top of the packed zeros
         if (lane < T) {
@@ -1589,7 +1642,7 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
         int ns = FWD_PAIR_WGS_ / rt;
         if (ns < 1) ns = 1;
         if (ns > ctiles) ns = ctiles;
-        const size_t p2w_ = 48 * (size_t)(g.K4 + 5), ttw_ = 48 * (size_t)FWD_PAIR_LDT;
+        const size_t p2w_ = 49 * (size_t)(g.K4 + 5), ttw_ = 48 * (size_t)FWD_PAIR_LDT;        // (49: the scratch row of the predicate-free staging)
         const size_t lds = sizeof(float) * (FWDP_OVERLAY ? (FWDP_AREG ? 0 : 48 * (size_t)(g.K4 + 5)) + (p2w_ > ttw_ ? p2w_ : ttw_)
                                                          : 2 * 48 * (size_t)(g.K4 + 5) + 48 * (size_t)FWD_PAIR_LDT);
         const int esz = out_is_double ? 8 : 4;
@@ -1659,7 +1712,7 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     float* slab = (float*)workspace;
     float* partials = slab + (size_t)ns * n1q * g.NP;
     if (bwd_use_pair(g)) {
-        const size_t lds = sizeof(float) * (48 * (size_t)(g.NP + 1) + 48 * (size_t)PAIR_LDT);
+        const size_t lds = sizeof(float) * (((49 * (size_t)(g.NP + 1) + 3) & ~(size_t)3) + 48 * (size_t)PAIR_LDT);      // (49: the scratch row of the predicate-free staging)
         const int esz = g_is_double ? 8 : 4;
         const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);    // 2-wide loads of the micro-block rows
         dim3 grid(ns, rt);
