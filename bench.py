@@ -87,7 +87,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(cfg, budget_s=150.0, min_steps=3):
+def cpu_baseline(cfg, budget_s=150.0, min_steps=3, fp64=False):
     """The oracle's reference-op-sequence training step (oracle/train_ref.py: DataLoader over the FULL dataset, the four
     kernel assemblies in the reference's matmul / gather / shuffle form, fp64 Cholesky + 2 solves, autograd backward, two
     Adam steps) on this host: 1 untimed warm-up step, then >= 3 timed full-size steps (more while the budget lasts)."""
@@ -96,7 +96,8 @@ def cpu_baseline(cfg, budget_s=150.0, min_steps=3):
     import train_ref
     cores = usable_cpus()
     torch.set_num_threads(cores)
-    st = train_ref.RefTrainer(cfg["N"], cfg["d"], cfg["M"], cfg["p"], cfg["B"], full_gradient=bool(cfg.get("grad")))
+    st = train_ref.RefTrainer(cfg["N"], cfg["d"], cfg["M"], cfg["p"], cfg["B"], full_gradient=bool(cfg.get("grad")),
+                              dtype=torch.float64 if fp64 else torch.float32)
     t0 = time.time()
     st.step()
     first = time.time() - t0
@@ -332,7 +333,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 corrections applied by tools/summarize_pmc.py); only valid for the 1-GPU C4 shape
         traffic = traffic_src = pmc_busy = None
-        if world == 1 and args.config == "c4" and eng.trsm_nb >= Mp:
+        if world == 1 and args.config == "c4" and eng.trsm_nb >= Mp and not args.fp64:
             import glob
             # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
@@ -357,7 +358,9 @@ def main():
                                     note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
                                          "--config c4`, forward-solve launches only; committed profile, not collected by this run")
                     break
-        roof = dict(bound="mfma", kernel="gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)",
+        roof = dict(bound="mfma", kernel=("gemm64_kernel<double> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
+                                           if args.fp64 else
+                                           "gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"),
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                     traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
                     mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
@@ -429,8 +432,8 @@ def main():
                                                probe=coll_probe)
         if cfg.get("ciq"):
             out["config"]["ciq"] = dict(eng.ciq_stats)
-        if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq") and not args.fp64:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq"):
+            out["cpu_baseline"] = cpu_baseline(cfg, fp64=args.fp64)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

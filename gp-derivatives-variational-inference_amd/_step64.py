@@ -445,7 +445,9 @@ class ElboEngine64(ElboEngine):
             Kzx.copy_(full[:, ::p + 1])
         else:
             _ops.kernel_fwd_f64(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        ev = self._event_pair()                         # (bench.py --fp64: the forward solve is the roofline entry of this mode too)
         _ops.trsm(ctx, L, Kzx, False, A, None, self.trsm_nb, ws, reuse_inverse=True)      # A = L^-1 K_ZX
+        self._event_done("solve_fwd", ev)
         mu0 = torch.empty(Bp, dtype=f64, device=dev)
         _ops.gemv_f64(ctx, A, m, mu0, trans=True)                                         # A^T m
         # G = A A^T needs no gradient information, but b = A mu_bar does: the likelihood terms first

@@ -20,16 +20,18 @@ import dsvgp_oracle as O
 
 class RefTrainer:
     def __init__(self, n, d, M, p, B, lr=0.01, num_data_override=None, seed=0, assembly="reference-sequence",
-                 full_gradient=False):
+                 full_gradient=False, dtype=torch.float32):
+        # dtype: torch.float64 = the reference under torch.set_default_dtype(torch.float64) (experiments/synthetic/exp_script.py:56)
         g = torch.Generator().manual_seed(seed)
-        X = torch.rand(n, d, generator=g)
+        X = torch.rand(n, d, generator=g).to(dtype)
         Y = O.testfun(X)
+        self.dtype = dtype
         self.d, self.p, self.full_gradient = d, p, full_gradient
         self.loader = DataLoader(TensorDataset(X, Y), batch_size=B, shuffle=True)
         self.it = iter(self.loader)
         self.num_data = num_data_override or ((d + 1) * n if not full_gradient else n)
-        Z0 = torch.rand(M, d, generator=g) if full_gradient else X[:M].clone()
-        P = O.init_params(Z0, torch.eye(d)[:p].repeat(M, 1), torch.float32, 1e-3, g)
+        Z0 = torch.rand(M, d, generator=g).to(dtype) if full_gradient else X[:M].clone()
+        P = O.init_params(Z0, torch.eye(d, dtype=dtype)[:p].repeat(M, 1), dtype, 1e-3, g)
         self.P = {k: v.requires_grad_(True) for k, v in P.items()}
         if full_gradient:
             self.P["inducing_directions"].requires_grad_(False)       # RBFKernelGrad: fixed canonical directions
@@ -63,7 +65,7 @@ class RefTrainer:
         else:
             idx = sorted(random.sample(range(1, self.d + 1), self.p) + [0])           # select_cols_of_y, :68-90
         yb = yb[:, idx]
-        D = torch.eye(self.d)[np.array(idx[1:]) - 1].repeat(yb.size(0), 1)            # :238
+        D = torch.eye(self.d, dtype=self.dtype)[np.array(idx[1:]) - 1].repeat(yb.size(0), 1)   # :238
         yb = yb.reshape(torch.numel(yb))                                              # :241
         self.opt_v.zero_grad()
         self.opt_h.zero_grad()
@@ -71,4 +73,4 @@ class RefTrainer:
         loss.backward()
         self.opt_v.step(); self.sch_v.step()
         self.opt_h.step(); self.sch_h.step()
-        return float(loss)
+        return float(loss.detach())
