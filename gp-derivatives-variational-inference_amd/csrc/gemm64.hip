@@ -43,11 +43,18 @@ struct G64 {
 #ifndef G64_STORE_SWZ
 #define G64_STORE_SWZ 0     // 1: bank-conflict-free order of the two 16-byte LDS stores of a staged thread (probe)
 #endif
+#ifndef G64_KC
+#define G64_KC 1            // k-contiguous operands taken (A_KC / B_KC staging)
+#endif
 #ifndef G64_BAND
 #define G64_BAND 16         // tile columns per band (probed 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 56.5 / 57.1 / 60.8 / 62.8 / 63.4 / 57.0 / 62.6 / 54.2 TF) of the XCD-local walk
 #endif
 
-template <typename TB>
+// A_KC / B_KC: the operand is K-CONTIGUOUS instead (A stored [M, K] / B stored [N, K], no triangular structure): a thread loads four
+// consecutive k of one row with 16-byte loads and scatters them down a column of the [k][m] LDS image -- the same MFMA loop, so
+// that L-bar = -tril([Q' | a] [G ; b^T]) (row-major [Q' | a]) and the fp64 model mode's Gram / dense products run here too
+// instead of on the 128 x 128 kernel of gemm.hip
+template <typename TB, bool A_KC = false, bool B_KC = false>
 __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     __shared__ double As[BK * LDS_STRIDE];
     __shared__ double Bs[BK * LDS_STRIDE];
@@ -116,17 +123,46 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
     // staging: thread -> (k = tid / 16, 4 consecutive columns at 4 (tid % 16)) of the 16 x 64 stage of each operand
     const int sk = tid >> 4, sc = (tid & 15) * 4;
     const bool hs = (tid >> 2) & 1;
-    const double* __restrict__ Ap = g.A + m0 + sc;
-    const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc;
+    const int kr = tid >> 2, kq = (tid & 3) * 4;           // k-contiguous operand: row kr of the tile, k = kq .. kq + 3 of the stage
+    const double* __restrict__ Ap = A_KC ? g.A + (int64_t)min(m0 + kr, g.M - 1) * g.lda + kq : g.A + m0 + sc;
+    const TB* __restrict__ Bp = B_KC ? (const TB*)g.B + (int64_t)min(n0 + kr, g.N - 1) * g.ldb + kq : (const TB*)g.B + n0 + sc;
     const bool a_in = m0 + T <= g.M, b_in = n0 + T <= g.N;
     double ra[4], rb[4];
     auto fetch = [&](int k0) {
+        if constexpr (A_KC) {
+            const bool rin = m0 + kr < g.M;
+            if (rin && k0 + kq + 3 < g.K) {
+                const double2 v0 = *reinterpret_cast<const double2*>(Ap + k0);
+                const double2 v1 = *reinterpret_cast<const double2*>(Ap + k0 + 2);
+                ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[e] = (rin && k0 + kq + e < g.K) ? Ap[k0 + e] : 0.0;
+            }
+        }
+        if constexpr (B_KC) {
+            const bool rin = n0 + kr < g.N;
+            if (rin && k0 + kq + 3 < g.K) {
+                if (sizeof(TB) == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bp + k0);
+                    rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+                } else {
+                    const double2 v0 = *reinterpret_cast<const double2*>(Bp + k0);
+                    const double2 v1 = *reinterpret_cast<const double2*>(Bp + k0 + 2);
+                    rb[0] = v0.x; rb[1] = v0.y; rb[2] = v1.x; rb[3] = v1.y;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = (rin && k0 + kq + e < g.K) ? (double)Bp[k0 + e] : 0.0;
+            }
+        }
         const int k = k0 + sk;
         const bool kin = k < g.K;
         // interior of the tile / of the triangle: unmasked vector loads; otherwise element-wise with the masks
         const bool a_fast = a_in && kin && (triA == 0 || (triA == 1 ? k0 + BK - 1 <= m0 : k0 >= m0 + T - 1));
         const bool b_fast = b_in && kin && (triB == 0 || (triB == 1 ? k0 + BK - 1 <= n0 : k0 >= n0 + T - 1));
-        if (a_fast) {
+        if constexpr (A_KC) {
+        } else if (a_fast) {
             const double2 v0 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda);
             const double2 v1 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda + 2);
             ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
@@ -140,7 +176,8 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
                 ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
             }
         }
-        if (b_fast) {
+        if constexpr (B_KC) {
+        } else if (b_fast) {
             if (sizeof(TB) == 4) {
                 const float4 v = *reinterpret_cast<const float4*>(Bp + (int64_t)k * g.ldb);
                 rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
@@ -182,10 +219,20 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
                 *reinterpret_cast<double2*>(bs + o1) = hs ? double2{rb[0], rb[1]} : double2{rb[2], rb[3]};
             }
 #else
-            *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
-            *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
-            *reinterpret_cast<double2*>(bs) = double2{rb[0], rb[1]};
-            *reinterpret_cast<double2*>(bs + 2) = double2{rb[2], rb[3]};
+            if constexpr (A_KC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[(kq + e) * LDS_STRIDE + kr] = ra[e];
+            } else {
+                *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
+                *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
+            }
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[(kq + e) * LDS_STRIDE + kr] = rb[e];
+            } else {
+                *reinterpret_cast<double2*>(bs) = double2{rb[0], rb[1]};
+                *reinterpret_cast<double2*>(bs + 2) = double2{rb[2], rb[3]};
+            }
 #endif
             __syncthreads();
             if (k0 + BK < khi) fetch(k0 + BK);               // in flight under the 16 MFMAs of this stage
@@ -263,7 +310,13 @@ void launch_cvt_f64_f32(hipStream_t st, const double* C, int64_t ldc, float* C32
 // returns 1 if the product was taken, 0 if the caller must use gemm.hip, > 1 on a launch error
 int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     const int fl = g.flags;
-    if (!(fl & DSVGP_GEMM_TRANS_A) || (fl & DSVGP_GEMM_TRANS_B)) return 0;        // both operands mn-contiguous only
+    // operand layouts: mn-contiguous (TRANS_A / no TRANS_B) or, without triangular structure, k-contiguous (A_KC / B_KC staging)
+    const bool a_kc = !(fl & DSVGP_GEMM_TRANS_A), b_kc = fl & DSVGP_GEMM_TRANS_B;
+    if (a_kc && (fl & (DSVGP_GEMM_A_LOWER | DSVGP_GEMM_A_UPPER))) return 0;
+    if (b_kc && (fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER))) return 0;
+#if !G64_KC
+    if (a_kc || b_kc) return 0;
+#endif
     if (g.batch != 1 || g.splitk != 1 || g.Cin || g.kscale || (fl & DSVGP_GEMM_KEEP_UPPER)) return 0;
     const bool bf = fl & DSVGP_GEMM_B_IS_FLOAT;
     // 16-byte vector loads: even leading dimensions (multiples of 4 for a float B) and aligned bases
@@ -293,7 +346,16 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
         }
     }
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
-    if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
+    if (a_kc && b_kc) {
+        if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm64_kernel<double, true, true>), grid, dim3(256), 0, st, a);
+    } else if (a_kc) {
+        if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm64_kernel<double, true, false>), grid, dim3(256), 0, st, a);
+    } else if (b_kc) {
+        if (bf) hipLaunchKernelGGL((gemm64_kernel<float, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm64_kernel<double, false, true>), grid, dim3(256), 0, st, a);
+    } else if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
     if (a.slab) {
         hipError_t e0 = hipGetLastError();

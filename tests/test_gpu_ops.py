@@ -628,3 +628,34 @@ def test_gemv_f64_both_orientations(dsvgp, gpu_device, M, N, pad):
         ops.gemv_f64(ctx, A, x, y, trans=trans)
         ref = (A.t() if trans else A) @ x
         assert relmax(y, ref) < 1e-13, (M, N, pad, trans, relmax(y, ref))
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("bfloat", [False, True])
+def test_gemm_f64_k_contiguous_operands_on_the_lean_kernel(dsvgp, gpu_device, ta, tb, bfloat):
+    """fp64 products with >= 1024 tiles of 64 x 64 whose operands are K-contiguous (A stored [M, K] and / or B stored [N, K]) run on
+    gemm64.hip's A_KC / B_KC staging (L-bar of the fp32 step; Gram and dense products of the float64 model mode): ragged M, N and K,
+    a float right operand, OUT_LOWER -- against torch fp64"""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(7 + ta + 2 * tb)
+    M, N, K = 2101, 2050, 301
+    A = torch.randn((K, M) if ta else (M, K + 1), generator=g, dtype=torch.float64)          # (even leading dimension for the row-major case)
+    B = torch.randn((N, K + 3) if tb else (K, N), generator=g, dtype=torch.float64)
+    if not ta:
+        A = A[:, :K]
+    if tb:
+        B = B[:, :K]
+    Bq = B.float().double() if bfloat else B
+    ref = (A.t() if ta else A) @ (Bq.t() if tb else Bq)
+    Ad = A.to(gpu_device) if ta else torch.randn(M, K + 1, dtype=torch.float64).to(gpu_device)[:, :K].copy_(A.to(gpu_device))
+    if tb:
+        Bd = torch.empty(N, K + 3, dtype=torch.float32 if bfloat else torch.float64, device=gpu_device)[:, :K]
+        Bd.copy_(B.to(gpu_device))
+    else:
+        Bd = (B.float() if bfloat else B).to(gpu_device)
+    for lower in (0, L.OUT_LOWER):
+        C = torch.full((M, N), float("nan"), dtype=torch.float64, device=gpu_device)
+        ops.gemm(ctx, (L.TRANS_A if ta else 0) | (L.TRANS_B if tb else 0) | lower, Ad, Bd, C, alpha=-0.5)
+        want = -0.5 * (torch.tril(ref) if lower else ref)
+        assert relmax(C, want) < 1e-13, (ta, tb, bfloat, lower, relmax(C, want))
