@@ -337,7 +337,7 @@ def main():
             import glob
             # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
-                cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith("gemm64_kernel<float>")]
+                cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith(("gemm64w_kernel<float", "gemm64_kernel<float"))]
                 if cands:   # the forward solve is the largest launch of that instantiation
                     traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
                     traffic_src = "profiles/" + os.path.basename(pmc)
@@ -346,7 +346,7 @@ def main():
                 best = None
                 lines = open(pmc).read().splitlines()
                 for i, ln in enumerate(lines[:-1]):
-                    if ln.startswith("gemm64_kernel<float> grid=") and "mfma_busy=" in lines[i + 1]:
+                    if ln.startswith(("gemm64w_kernel<float", "gemm64_kernel<float")) and " grid=" in ln and "mfma_busy=" in lines[i + 1]:
                         grid = int(ln.split("grid=")[1].split()[0])
                         vals = dict(kv.split("=") for kv in lines[i + 1].replace(" GHz", "").split() if "=" in kv)
                         if best is None or grid > best[0]:
@@ -358,9 +358,11 @@ def main():
                                     note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
                                          "--config c4`, forward-solve launches only; committed profile, not collected by this run")
                     break
-        roof = dict(bound="mfma", kernel=("gemm64_kernel<double> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
-                                           if args.fp64 else
-                                           "gemm64_kernel<float> (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"),
+        wide = Mp >= 64 and (Mp + 63) // 64 * ((Bp_local + 63) // 64) >= 8192          # (gemm64.hip: 64 x 192 / 64 x 128 tiles from 8192 tiles of 64 x 64 up)
+        roof = dict(bound="mfma", kernel=("%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
+                                           % ("gemm64w_kernel<double, 128>" if wide else "gemm64_kernel<double>") if args.fp64 else
+                                           "%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"
+                                           % ("gemm64w_kernel<float, 192>" if wide else "gemm64_kernel<float>")),
                     achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                     traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
                     mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)

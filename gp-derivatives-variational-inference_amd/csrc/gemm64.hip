@@ -277,6 +277,135 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
             }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Wide variant for the [M', B'] class (>= 8192 tiles of 64 x 64, no split-K, dense mn-contiguous B, optional triangular A: the
+// forward panel solve A = L^-1 K_ZX): 64 x TW tiles, 4 waves of 32 x TW/2 (2 x TW/32 MFMA tiles), 16-deep stages through one
+// LDS buffer like above.  Against the 64 x 64 tile a stage carries 2-3x the MFMAs between its two barriers, an MFMA needs
+// 3/4 - 2/3 of the LDS fragment reads and the tile 2/3 - 5/9 of the operand bytes per flop; the tile ROW stays 64 so that the
+// K range of a triangular A is trimmed as finely as before.  Measured at C4 on one box (forward solve, ms): 64 x 64 3.72-3.79,
+// TW = 128 (120 VGPRs, 4 workgroups per CU) 3.56-3.62, TW = 192 (164 VGPRs, 3 per CU) 3.51-3.58, TW = 256 (216 VGPRs, 2 per
+// CU) 4.3-4.9; bands of 8 tile columns per XCD (4: +0.03-0.1, 10: +0.4, 16: +0.7).  A float right operand uses TW = 192, a double
+// one (float64 model mode; 168 VGPRs would spill) TW = 128.
+// -------------------------------------------------------------------------------------------------
+#ifndef G64_WIDE
+#define G64_WIDE 1
+#endif
+#ifndef G64W_BAND
+#define G64W_BAND 8
+#endif
+#ifndef G64W_TW
+#define G64W_TW 192
+#endif
+template <typename TB, int TW>
+__global__ __launch_bounds__(256, TW > 128 ? 3 : 4) void gemm64w_kernel(const G64 g) {
+    constexpr int LDS_STRIDE_W = TW + 16, NJ = TW / 32, NB = TW / 16;       // MFMA column tiles per wave; B values staged per thread
+    __shared__ double As[BK * LDS_STRIDE];
+    __shared__ double Bs[BK * LDS_STRIDE_W];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int fl = g.flags;
+    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
+    int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
+    if (t >= g.tiles_m * g.tiles_n) return;
+    const int band = t / (G64W_BAND * g.tiles_m), r = t - band * G64W_BAND * g.tiles_m;
+    const int wcols = min(G64W_BAND, g.tiles_n - band * G64W_BAND);
+    int tm = r / wcols;
+    const int tn = band * G64W_BAND + r - tm * wcols;
+    if (triA == 1) tm = g.tiles_m - 1 - tm;              // longest K ranges first
+    const int m0 = tm * T, n0 = tn * TW;
+    int klo = 0, khi = g.K;
+    if (triA == 1) khi = min(khi, m0 + T);
+    if (triA == 2) klo = max(klo, (m0 / BK) * BK);
+    const int sk = tid >> 4, sc = (tid & 15) * 4, sc8 = (tid & 15) * NB;
+    const double* __restrict__ Ap = g.A + m0 + sc;
+    const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc8;
+    const bool a_in = m0 + T <= g.M, b_in = n0 + TW <= g.N;
+    double ra[4];
+    TB rb[NB];                   // (a float right operand waits in its own width: 12 registers less at TW = 192)
+    auto fetch = [&](int k0) {
+        const int k = k0 + sk;
+        const bool kin = k < g.K;
+        const bool a_fast = a_in && kin && (triA == 0 || (triA == 1 ? k0 + BK - 1 <= m0 : k0 >= m0 + T - 1));
+        if (a_fast) {
+            const double2 v0 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda);
+            const double2 v1 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda + 2);
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + sc + e;
+                bool ok = kin && m < g.M;
+                if (triA == 1) ok = ok && k <= m;
+                if (triA == 2) ok = ok && k >= m;
+                ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
+            }
+        }
+        if (b_in && kin) {
+            if (sizeof(TB) == 4) {
+#pragma unroll
+                for (int e = 0; e < NB; e += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bp + (int64_t)k * g.ldb + e);
+                    rb[e] = (TB)v.x; rb[e + 1] = (TB)v.y; rb[e + 2] = (TB)v.z; rb[e + 3] = (TB)v.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NB; e += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(Bp + (int64_t)k * g.ldb + e);
+                    rb[e] = (TB)v.x; rb[e + 1] = (TB)v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NB; ++e) rb[e] = (kin && n0 + sc8 + e < g.N) ? Bp[(int64_t)k * g.ldb + e] : (TB)0;
+        }
+    };
+    acc4 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+    if (klo < khi) {
+        fetch(klo);
+        for (int k0 = klo; k0 < khi; k0 += BK) {
+            double* as = As + sk * LDS_STRIDE + sc;
+            double* bs = Bs + sk * LDS_STRIDE_W + sc8;
+            *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
+            *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
+#pragma unroll
+            for (int e = 0; e < NB; e += 2) *reinterpret_cast<double2*>(bs + e) = double2{(double)rb[e], (double)rb[e + 1]};
+            __syncthreads();
+            if (k0 + BK < khi) fetch(k0 + BK);               // in flight under the 32 MFMAs of this stage
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                const int kq = kk * 4 + (lane >> 4);
+                double a[2], b[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = As[kq * LDS_STRIDE + wr * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = Bs[kq * LDS_STRIDE_W + wc * (TW / 2) + j * 16 + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * rr;
+                const int n = n0 + wc * (TW / 2) + j * 16 + (lane & 15);
+                if (m >= g.M || n >= g.N) continue;
+                const double v = g.alpha * acc[i][j][rr];
+                if (g.C) g.C[(int64_t)m * g.ldc + n] = v;
+                if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
+            }
+}
+
 // fp32 copy of a split-K result (the atomics accumulate in fp64 only): rows over blockIdx.y, two columns per thread through
 // 16-byte loads / 8-byte stores where the rows allow (no per-element 64-bit division: 78 -> ~25 us for the 3000 x 3001 [Q' | a])
 template <bool VEC>
@@ -345,6 +474,18 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
             if (ez != hipSuccess) return 1000 + (int)ez;
         }
     }
+#if G64_WIDE
+    if (!a.balanced && !a.kchunk && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) &&
+        (bf ? g.ldb % 4 == 0 : true)) {
+        constexpr int TWD = G64W_TW > 128 ? 128 : G64W_TW;          // (double right operand)
+        a.tiles_n = cdiv(g.N, bf ? G64W_TW : TWD);
+        const dim3 gridw(cdiv(a.tiles_m * a.tiles_n, 8) * 8);
+        if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), 0, st, a);
+        hipError_t ew = hipGetLastError();
+        return ew == hipSuccess ? 1 : 1000 + (int)ew;
+    }
+#endif
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
     if (a_kc && b_kc) {
         if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, true>), grid, dim3(256), 0, st, a);
