@@ -336,27 +336,36 @@ def main():
         if world == 1 and args.config == "c4" and eng.trsm_nb >= Mp and not args.fp64:
             import glob
             # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
-            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
-                cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith(("gemm64w_kernel<float", "gemm64_kernel<float"))]
-                if cands:   # the forward solve is the largest launch of that instantiation
-                    traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/" + os.path.basename(pmc)
+            # (the kernel that runs the forward solve NOW decides which committed profile applies: the wide kernel of gemm64.hip first)
+            families = ("gemm64w_kernel<float", "gemm64_kernel<float")
+            for fam in families:
+                for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+                    cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith(fam)]
+                    if cands:   # the forward solve is the largest launch of that instantiation
+                        traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+                        traffic_src = "profiles/" + os.path.basename(pmc)
+                        break
+                if traffic is not None:
                     break
-            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_mfma_busy.txt")), reverse=True):
-                best = None
-                lines = open(pmc).read().splitlines()
-                for i, ln in enumerate(lines[:-1]):
-                    if ln.startswith(("gemm64w_kernel<float", "gemm64_kernel<float")) and " grid=" in ln and "mfma_busy=" in lines[i + 1]:
-                        grid = int(ln.split("grid=")[1].split()[0])
-                        vals = dict(kv.split("=") for kv in lines[i + 1].replace(" GHz", "").split() if "=" in kv)
-                        if best is None or grid > best[0]:
-                            best = (grid, vals, float(ln.split("avg_ms=")[1]))
-                if best:
-                    pmc_busy = dict(mfma_busy=float(best[1]["mfma_busy"]), wait_any_per_wave=float(best[1]["wait_any/wave"]),
-                                    wait_inst_any_per_wave=float(best[1]["wait_inst_any/wave"]), clock_ghz=float(best[1]["clk"]),
-                                    profiled_avg_ms=best[2], source="profiles/" + os.path.basename(pmc),
-                                    note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
-                                         "--config c4`, forward-solve launches only; committed profile, not collected by this run")
+            for fam in families:
+                for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_mfma_busy.txt")), reverse=True):
+                    best = None
+                    lines = open(pmc).read().splitlines()
+                    for i, ln in enumerate(lines[:-1]):
+                        if ln.startswith(fam) and " grid=" in ln and "mfma_busy=" in lines[i + 1]:
+                            vals = dict(kv.split("=") for kv in lines[i + 1].replace(" GHz", "").split() if "=" in kv)
+                            ms = float(ln.split("avg_ms=")[1])
+                            if best is None or ms > best[2]:            # (the forward solve is the longest launch of its family)
+                                best = (ln, vals, ms)
+                    if best:
+                        pmc_busy = dict(kernel=best[0].split(" grid=")[0], mfma_busy=float(best[1]["mfma_busy"]),
+                                        wait_any_per_wave=float(best[1]["wait_any/wave"]),
+                                        wait_inst_any_per_wave=float(best[1]["wait_inst_any/wave"]), clock_ghz=float(best[1]["clk"]),
+                                        profiled_avg_ms=best[2], source="profiles/" + os.path.basename(pmc),
+                                        note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
+                                             "--config c4`, forward-solve launches only; committed profile, not collected by this run")
+                        break
+                if pmc_busy is not None:
                     break
         wide = Mp >= 64 and (Mp + 63) // 64 * ((Bp_local + 63) // 64) >= 8192          # (gemm64.hip: 64 x 192 / 64 x 128 tiles from 8192 tiles of 64 x 64 up)
         roof = dict(bound="mfma", kernel=("%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
