@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
 #ifndef G64W_BAND
 #define G64W_BAND 8
 #endif
+#ifndef G64W_MIN_TILES
+#define G64W_MIN_TILES G64_BALANCED_BELOW       // tiles of 64 x 64 from which the wide kernel takes the product
+#endif
 #ifndef G64W_TW
 #define G64W_TW 192
 #endif
@@ -457,6 +460,18 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     a.tiles_m = cdiv(g.M, T); a.tiles_n = cdiv(g.N, T);
     const int total = a.tiles_m * a.tiles_n;
     a.balanced = total < G64_BALANCED_BELOW;
+#if G64_WIDE
+    if (total >= G64W_MIN_TILES && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) && !g.slab &&
+        (bf ? g.ldb % 4 == 0 : true)) {
+        constexpr int TWD = G64W_TW > 128 ? 128 : G64W_TW;          // (double right operand)
+        a.tiles_n = cdiv(g.N, bf ? G64W_TW : TWD);
+        const dim3 gridw(cdiv(a.tiles_m * a.tiles_n, 8) * 8);
+        if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), 0, st, a);
+        hipError_t ew = hipGetLastError();
+        return ew == hipSuccess ? 1 : 1000 + (int)ew;
+    }
+#endif
     // split-K for the few-tile products with a long K: every tile is resident at once, so the launch lasts as long as its
     // longest tile's chain of K / 16 dependent stages; chunks of G64_KCHUNK accumulate with fp64 atomics onto a zeroed output
     a.kchunk = (G64_KCHUNK > 0 && a.balanced && g.K >= 2 * G64_KCHUNK && g.C) ? G64_KCHUNK : 0;
@@ -474,18 +489,6 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
             if (ez != hipSuccess) return 1000 + (int)ez;
         }
     }
-#if G64_WIDE
-    if (!a.balanced && !a.kchunk && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) &&
-        (bf ? g.ldb % 4 == 0 : true)) {
-        constexpr int TWD = G64W_TW > 128 ? 128 : G64W_TW;          // (double right operand)
-        a.tiles_n = cdiv(g.N, bf ? G64W_TW : TWD);
-        const dim3 gridw(cdiv(a.tiles_m * a.tiles_n, 8) * 8);
-        if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), 0, st, a);
-        hipError_t ew = hipGetLastError();
-        return ew == hipSuccess ? 1 : 1000 + (int)ew;
-    }
-#endif
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
     if (a_kc && b_kc) {
         if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, true>), grid, dim3(256), 0, st, a);
