@@ -461,7 +461,7 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     const int total = a.tiles_m * a.tiles_n;
     a.balanced = total < G64_BALANCED_BELOW;
 #if G64_WIDE
-    if (total >= G64W_MIN_TILES && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) && !g.slab &&
+    if (total >= G64W_MIN_TILES && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) &&      // (no split-K, no atomics: also in deterministic mode)
         (bf ? g.ldb % 4 == 0 : true)) {
         constexpr int TWD = G64W_TW > 128 ? 128 : G64W_TW;          // (double right operand)
         a.tiles_n = cdiv(g.N, bf ? G64W_TW : TWD);
