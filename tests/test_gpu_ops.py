@@ -659,3 +659,35 @@ def test_gemm_f64_k_contiguous_operands_on_the_lean_kernel(dsvgp, gpu_device, ta
         ops.gemm(ctx, (L.TRANS_A if ta else 0) | (L.TRANS_B if tb else 0) | lower, Ad, Bd, C, alpha=-0.5)
         want = -0.5 * (torch.tril(ref) if lower else ref)
         assert relmax(C, want) < 1e-13, (ta, tb, bfloat, lower, relmax(C, want))
+
+
+@pytest.mark.parametrize("tri", [0, 1, 2])
+@pytest.mark.parametrize("bfloat", [False, True])
+def test_gemm_f64_wide_tile_kernel(dsvgp, gpu_device, tri, bfloat):
+    """>= 8192 tiles of 64 x 64 with a dense mn-contiguous right operand: gemm64.hip's 64 x 192 (float B) / 64 x 128 (double B) kernel,
+    the forward panel solve's.  Ragged M, N (not a multiple of the tile width) and K, lower / upper triangular left operand, fp64 and
+    fp32 outputs -- against torch fp64"""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(11 + tri)
+    M, N, K = 601, 64 * 830 + 37, 601
+    A = torch.randn(K, M + 1, generator=g, dtype=torch.float64)[:, :M]            # op(A)[m][k] = A[k][m]
+    if tri == 1:
+        A = torch.triu(A)                          # op(A) lower triangular (A_LOWER)
+    elif tri == 2:
+        A = torch.tril(A)                          # op(A) upper triangular (A_UPPER)
+    B = torch.randn(K, N + (3 if bfloat else 1), generator=g, dtype=torch.float32 if bfloat else torch.float64)[:, :N]
+    Ad = torch.empty(K, M + 1, dtype=torch.float64, device=gpu_device)[:, :M]
+    Ad.copy_(A if tri == 0 else torch.randn(K, M, generator=g, dtype=torch.float64))      # (the masked half must not be read: garbage there)
+    if tri:
+        keep = torch.triu(torch.ones(K, M, dtype=torch.bool)) if tri == 1 else torch.tril(torch.ones(K, M, dtype=torch.bool))
+        Ad.copy_(torch.where(keep.to(gpu_device), A.to(gpu_device), Ad))
+    Bd = torch.empty(K, B.shape[1] + (3 if bfloat else 1), dtype=B.dtype, device=gpu_device)[:, :N]
+    Bd.copy_(B)
+    flags = L.TRANS_A | (L.A_LOWER if tri == 1 else (L.A_UPPER if tri == 2 else 0))
+    C = torch.full((M, N), float("nan"), dtype=torch.float64, device=gpu_device)
+    C32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu_device)
+    ops.gemm(ctx, flags, Ad, Bd, C, alpha=0.75, C32=C32)
+    ref = 0.75 * (A.t().to(gpu_device) @ Bd.double())
+    assert relmax(C, ref) < 1e-13, (tri, bfloat, relmax(C, ref))
+    assert relmax(C32, ref) < 2e-7
