@@ -95,6 +95,11 @@ class ElboEngine:
         # one GPU: the L_S / m gradient kernels (need only G) on the side stream next to the Q' solve and the dense product.
         # Measured: C3 8.26 -> 8.18 ms/step, C4 unchanged (14.01 / 13.97-14.02)
         self.var_overlap = os.environ.get("DSVGP_VAR_OVERLAP", "1") == "1"
+        # one-call step, probe (flag 16 of dsvgp_elbo_step_f32): L-bar and the Cholesky backward (they need [Q' | a] and G only)
+        # behind the variational block on the side stream, under the dense K_ZX-bar product.  Measured (round 4, same box, twice):
+        # C4 13.57-13.65 -> 13.65-13.66 ms, C3 7.79 -> 7.80-7.84, C2 0.60 -> 0.61: the dense product stretches from 3.63 to 5.23 ms
+        # while the 1.6 ms tail runs beside it -- matrix-pipe time is conserved, nothing is recovered.  Off by default.
+        self.tail_side = os.environ.get("DSVGP_TAIL_SIDE", "0") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -1011,7 +1016,8 @@ class ElboEngine:
         timed = self.record_events and self._rec_count % max(1, self.record_every) == 0
         if self.record_events:
             self._rec_count += 1
-        flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if timed else 0)
+        flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if timed else 0) \
+            | (16 if self.tail_side else 0)
         tr = self.host_trace                  # (tools/host_trace.py: where the host's time goes; None in production)
         if tr is not None:
             import time as _t

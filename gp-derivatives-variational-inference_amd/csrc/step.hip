@@ -311,12 +311,36 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
                                         1.f, kl_buf, sums, Ge + (size_t)Mp * Mp, io->dm, io->dLS, io->lddls, B, p, scal);
     };
     // ---- [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64), K_ZX-bar = [Q' | a] [A ; mu_bar^T] (fp32, unscaled)
-    auto solve = [&]() -> int {
-        int rc = dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, Qe64, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
-        if (rc) return rc;
+    auto solve_q = [&]() -> int {
+        return dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, Qe64, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
+    };
+    auto dense = [&]() -> int {
         return dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qe32, ldQ32, A32e, Bp, 0.0, nullptr, 0, Kb32, Bp, nullptr, 0,
                           nullptr);
     };
+    // ---- L-bar = -tril([Q' | a] [G ; b^T]) (fp64); Cholesky backward: K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 through
+    // the explicit inverse, lower halves + mirrors (DGVS.py:72-75 differentiated).  Needs [Q' | a] and [G ; b^T] only.
+    const double* Linv = (const double*)trsm_ws;
+    auto chol_tail = [&]() -> int {
+        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, Qe64, ldQ64, Ge, Mp, 0.0, nullptr, 0,
+                            Lbar, Mp, nullptr, 0, nullptr);
+        if (rc) return rc;
+        rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, L, Mp,
+                        Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
+        if (rc) return rc;
+        rc = dsvgp_phi_symmetrize(ctx, G1, Mp, Mp);
+        if (rc) return rc;
+        rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
+                        nullptr, 0, Yt, Mp, nullptr, 0, nullptr);
+        if (rc) return rc;
+        rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0,
+                        nullptr, 0, Kbar, Mp, nullptr, 0, nullptr);
+        if (rc) return rc;
+        return dsvgp_phi_symmetrize(ctx, Kbar, Mp, Mp);
+    };
+    // tail_side: the whole M'^3 tail (L-bar, Cholesky backward) follows the variational block on the side stream, under the dense
+    // K_ZX-bar product on the main stream (it depends on [Q' | a] and G only); joined before K_ZZ-bar's kernel backward
+    const bool tail_side = overlap && (flags & 16);
     if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork2, main));
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
@@ -324,13 +348,23 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         STEP_CALL(variational());
         STEP_HIP(hipEventRecord(pl->ev_var, side));
         ctx->stream = main;
-        STEP_CALL(solve());
+        STEP_CALL(solve_q());
+        if (tail_side) {
+            STEP_HIP(hipEventRecord(pl->ev_dense, main));           // ([Q' | a] is final)
+            STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
+            ctx->stream = side;
+            STEP_CALL(chol_tail());
+            STEP_HIP(hipEventRecord(pl->ev_zx, side));
+            ctx->stream = main;
+        }
+        STEP_CALL(dense());
     } else {
         STEP_CALL(variational());
-        STEP_CALL(solve());
+        STEP_CALL(solve_q());
+        STEP_CALL(dense());
     }
     // ---- K_ZX-bar's kernel backward: beside the fp64 products that follow when the batch is small against M' (HBM-bound read)
-    const bool zx_side = overlap && Bp <= 2 * Mp;
+    const bool zx_side = overlap && !tail_side && Bp <= 2 * Mp;
     if (zx_side) {
         STEP_HIP(hipEventRecord(pl->ev_dense, main));
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
@@ -341,26 +375,16 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         STEP_HIP(hipEventRecord(pl->ev_zx, side));
         ctx->stream = main;
     }
-    // ---- L-bar = -tril([Q' | a] [G ; b^T]) (fp64), joined with the variational block
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, Qe64, ldQ64, Ge, Mp, 0.0, nullptr, 0,
-                         Lbar, Mp, nullptr, 0, nullptr));
-    if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
+    if (!tail_side) {
+        STEP_CALL(chol_tail());                                     // (its first product does not need the variational block)
+        if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
+    }
     if (!zx_side) {
         STEP_TIME(4);
         STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
         STEP_TIME(5);
     }
-    // ---- Cholesky backward: K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 through the explicit inverse, lower halves + mirrors
-    const double* Linv = (const double*)trsm_ws;
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, L, Mp,
-                         Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));
-    STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
-                         nullptr, 0, Yt, Mp, nullptr, 0, nullptr));
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0,
-                         nullptr, 0, Kbar, Mp, nullptr, 0, nullptr));
-    STEP_CALL(dsvgp_phi_symmetrize(ctx, Kbar, Mp, Mp));
-    if (zx_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
+    if (zx_side || tail_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
     STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
     // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
     STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,

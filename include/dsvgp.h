@@ -361,7 +361,8 @@ int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, fl
  *              flag 8 whenever anything else may have written to the buffer since this plan's last step)
  *   io         device pointers (below); io->flat[0 .. flat_floats) is cleared by the call and must contain every gradient slot
  *   flags      1: overlap on the plan's second stream; 2: include the KL term (data-parallel ranks > 0 leave it out); 4: record
- *              HIP-event timings (dsvgp_elbo_step_timings); 8: the workspace contents are undefined (re-clear the paddings)
+ *              HIP-event timings (dsvgp_elbo_step_timings); 8: the workspace contents are undefined (re-clear the paddings);
+ *              16 (with 1): L-bar and the Cholesky backward on the second stream under the dense K_ZX-bar product
  * Gradients are those of loss = -(sum_j ll_j / global_rows - KL / num_data); a factorisation that fails leaves NaNs in the
  * outputs and a non-zero status word: read it with dsvgp_elbo_step_status (waits for the factorisation only, not for the step)
  * and run the jitter ladder on the piecewise path.  Threading: one host thread per context.                                  */
