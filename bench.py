@@ -145,6 +145,9 @@ def main():
                     help="HIP-graph replay of the step (one rank, ELBO fast path); measured no faster than eager at C2, see DESIGN.md")
     ap.add_argument("--dp-algo", default=os.environ.get("DSVGP_DP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
                     help="(N > 1) collective of the large operand: RCCL all-reduce, or reduce-scatter + all-gather")
+    ap.add_argument("--no-other-configs", action="store_true", help="c4 on one GPU: skip the C2 / C3 / C5 / float64 windows")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="c4 on one GPU: skip the repeated windows, the reporting-step timing and the other BASELINE configurations")
     ap.add_argument("--event-every", type=int, default=0,
                     help="HIP events (dominant-kernel / assembly timings) on every K-th timed step; 0 = every step, except on the "
                          "sub-millisecond configuration c2 where six event records are 5 %% of the step: every 8th there")
@@ -182,29 +185,72 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import dsvgp_amd
+
+    def build(cfg, fp64):
+        """dataset + training loop of one configuration, engine switches applied; returns (loop, engine, batch(k))"""
+        d, N, M, p, B = cfg["d"], cfg["N"], cfg["M"], cfg["p"], cfg["B"]
+        prev = torch.get_default_dtype()
+        if fp64:
+            torch.set_default_dtype(torch.float64)
+        try:
+            X, Y = synthetic_data(N, d, device)
+            if fp64:
+                X, Y = X.double(), Y.double()
+            if cfg.get("grad"):
+                loop = dsvgp_amd.grad_svgp.setup_training(None, d, num_inducing=M, minibatch_size=B, num_epochs=1,
+                                                          learning_rate_hypers=0.01, seed=0, tensors=(X, Y))
+            else:
+                loop = dsvgp_amd.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
+                                                num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True,
+                                                seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
+        finally:
+            torch.set_default_dtype(prev)
+        loop.graph = args.graph == "on"
+        eng = loop.model.engine
+        if args.trsm_nb > 0:
+            eng.trsm_nb = args.trsm_nb
+        if args.no_overlap:
+            eng.overlap = False        # (default None: automatic by problem size)
+        if os.environ.get("DSVGP_OVERLAP") == "1":
+            eng.overlap = True         # diagnostics: the side stream also below M' = 2048
+        eng.fused_inverse = not args.no_fused_inverse
+        eng.lib_dense_gemm = bool(args.lib_gemm)
+        eng.global_gram = not args.no_global_gram
+        eng.pack_reduce = not args.no_pack_reduce
+        if loop.dp is not None:
+            loop.dp.algo = args.dp_algo
+        perm = loop.epoch_permutation()
+        nbatches = N // B
+        return loop, eng, (lambda k: perm[(k % nbatches) * B:(k % nbatches + 1) * B])
+
+    def window(loop, batch, first, steps):
+        """`steps` optimisation steps bracketed by barrier + synchronize on both sides; returns (seconds, last loss)"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            loss, _, _ = loop.step(batch(first + k))
+        loop.finish()                    # (graph replay: the status of the last replayed step is read here)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, loss
+
+    def events_on(eng, every):
+        eng.record_events = True
+        eng.events = []
+        if hasattr(eng, "c_step_timed"):
+            eng.c_step_timed = []
+            eng.record_every, eng._rec_count = every, 0
+
+    def event_durations(eng, names):
+        has_dur = hasattr(eng, "event_durations")
+        return {nm: (eng.event_durations(nm) if has_dur else [s_.elapsed_time(e_) * 1e-3 for (n2, s_, e_) in eng.events if n2 == nm])
+                for nm in names}
+
     d, N, M, p, B = cfg["d"], cfg["N"], cfg["M"], cfg["p"], cfg["B"]
-    X, Y = synthetic_data(N, d, device)
-    if cfg.get("grad"):
-        loop = dsvgp_amd.grad_svgp.setup_training(None, d, num_inducing=M, minibatch_size=B, num_epochs=1,
-                                                  learning_rate_hypers=0.01, seed=0, tensors=(X, Y))
-    else:
-        loop = dsvgp_amd.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p,
-                                        num_epochs=1, learning_rate_hypers=0.01, inducing_data_initialization=True,
-                                        seed=0, tensors=(X, Y), use_ciq=bool(cfg.get("ciq")))
-    loop.graph = args.graph == "on"
-    eng = loop.model.engine
-    if args.trsm_nb > 0:
-        eng.trsm_nb = args.trsm_nb
-    if args.no_overlap:
-        eng.overlap = False        # (default None: automatic by problem size)
-    if os.environ.get("DSVGP_OVERLAP") == "1":
-        eng.overlap = True         # diagnostics: the side stream also below M' = 2048
-    eng.fused_inverse = not args.no_fused_inverse
-    eng.lib_dense_gemm = bool(args.lib_gemm)
-    eng.global_gram = not args.no_global_gram
-    eng.pack_reduce = not args.no_pack_reduce
-    if loop.dp is not None:
-        loop.dp.algo = args.dp_algo
+    loop, eng, batch = build(cfg, args.fp64)
     if args.emulate_world > 1 and world == 1:
         # diagnostics on a one-GPU box: run rank 0's share of the work of a W-rank job with the collectives skipped
         # (use with --config c4shardW; not a measurement of the job, only of one rank's kernels)
@@ -228,31 +274,11 @@ def main():
                 grp["lr"] = 0.0
             if hasattr(sch, "base_lrs"):
                 sch.base_lrs = [0.0] * len(sch.base_lrs)
-    perm = loop.epoch_permutation()
-    nbatches = N // B
-
-    def batch(k):
-        k = k % nbatches
-        return perm[k * B:(k + 1) * B]
 
     for k in range(args.warmup):
         loop.step(batch(k))
-    eng.record_events = True
-    eng.events = []
-    if hasattr(eng, "c_step_timed"):
-        eng.c_step_timed = []
-        eng.record_every, eng._rec_count = args.event_every, 0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        loss, _, _ = loop.step(batch(args.warmup + k))
-    loop.finish()                    # (graph replay: the status of the last replayed step is read here)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    events_on(eng, args.event_every)
+    elapsed, loss = window(loop, batch, args.warmup, args.steps)
     if hasattr(eng, "record_every"):
         eng.record_every = 1             # (the untimed passes below: every step)
     if loop._graphs:
@@ -267,9 +293,8 @@ def main():
         torch.cuda.synchronize()
     # the kernel assembly forward alone on the GPU (it shares the CUs with the Cholesky chain in the step when M' >= 2048):
     # three more untimed steps with the side stream off, HIP events around the same launch
-    has_dur = hasattr(eng, "event_durations")
-    durations = {nm: (eng.event_durations(nm) if has_dur else [s.elapsed_time(e) * 1e-3 for (n2, s, e) in eng.events if n2 == nm])
-                 for nm in ("solve_fwd", "assemble_fwd", "assemble_bwd", "early_reduce_wait", "final_reduce", "ciq_stacked_backward")}
+    EVENT_NAMES = ("solve_fwd", "assemble_fwd", "assemble_bwd", "early_reduce_wait", "final_reduce", "ciq_stacked_backward")
+    durations = event_durations(eng, EVENT_NAMES)
     iso_fwd = None
     if not cfg.get("ciq") and world == 1 and not args.fp64:
         saved = eng.overlap
@@ -279,7 +304,7 @@ def main():
         for k in range(3):
             loop.step(batch(args.warmup + args.steps + 3 + k))
         torch.cuda.synchronize()
-        durs = eng.event_durations("assemble_fwd") if has_dur else [s.elapsed_time(e) * 1e-3 for (nm, s, e) in eng.events if nm == "assemble_fwd"]
+        durs = event_durations(eng, ("assemble_fwd",))["assemble_fwd"]
         iso_fwd = sum(durs) / len(durs) if durs else None
         eng.overlap = saved
     eng.record_events = False
@@ -288,6 +313,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.item())
+
+    # ---- the same window twice more (box-to-box and run-to-run spread of a 0.3 s timed region is +-3 %): min / median / max of the
+    # three, `steps` / `ms_per_step` stay those of the FIRST window
+    repeat_ms = None
+    extras = args.config == "c4" and world == 1 and args.emulate_world == 1 and not args.fp64 and not args.no_extras
+    if extras:
+        ws_ = [elapsed]
+        for r in range(2):
+            e_r, _ = window(loop, batch, args.warmup + args.steps * (r + 1) + 6, args.steps)
+            ws_.append(e_r)
+        ws_ = sorted(1e3 * w / args.steps for w in ws_)
+        repeat_ms = [ws_[0], ws_[1], ws_[2]]
+    # ---- the reference's every-50th-step report (directional_vi.py:255-260: loss.item(), nll of the function values from
+    # output.mean / output.variance of that forward pass): one reporting step costs a host synchronisation (the step pipeline
+    # drains) plus the value-row variances; measured over 5 reporting steps in a row, 1/50 of the extra goes into ms_per_step
+    report_extra_ms = None
+    if extras and hasattr(eng, "value_variances"):
+        q_ = p + 1
+
+        def report_step(k):
+            l_, out_, yb_ = loop.step(batch(args.warmup + 3 * args.steps + 6 + k), need_variance="values")
+            means_ = out_.mean[::q_]
+            stds_ = out_.value_variance.sqrt()
+            nll_ = -torch.distributions.Normal(means_, stds_).log_prob(yb_[::q_]).mean()
+            return "loss: %s, nll: %s" % (l_.item(), nll_.item())
+
+        report_step(0)                   # (untimed: first use of the value-row buffers and of torch.distributions' kernels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(5):
+            report_step(1 + k)
+        torch.cuda.synchronize()
+        report_extra_ms = max(0.0, 1e3 * (time.perf_counter() - t0) / 5 - 1e3 * elapsed / args.steps)
 
     # N > 1: what the collectives this design could use cost on THIS node, measured after the timed region (all ranks take part;
     # priced for the next design step: sharding the replicated M' x M' products would add two 72 MB all-gathers per step)
@@ -316,117 +374,173 @@ def main():
                 coll_probe[name] = e0.elapsed_time(e1) / 10.0
             except Exception as ex:      # (a backend without the collective: report, do not fail the bench line)
                 coll_probe[name] = "unavailable: %s" % type(ex).__name__
-    # dominant kernel: the fp64 MFMA GEMM of the forward panel solve A = L^-1 K_ZX (one launch when nb >= M')
+    def rooflines(cfg, eng, durations, iso_fwd, fp64, cfg_name, headline):
+        """(roofline of the dominant kernel, assembly roofline) of one configuration from its HIP-event durations"""
+        d, N, M, p, B = cfg["d"], cfg["N"], cfg["M"], cfg["p"], cfg["B"]
+        # dominant kernel: the fp64 MFMA GEMM of the forward panel solve A = L^-1 K_ZX (one launch when nb >= M')
+        Mp = M * (p + 1)
+        B_local = B // world
+        Bp_local = B_local * (p + 1)
+
+        def avg(name):
+            durs = durations.get(name, [])
+            return (sum(durs) / len(durs), len(durs)) if durs else (None, 0)
+
+        roof = None
+        t_solve, n_solve = avg("solve_fwd")
+        if t_solve:
+            flops = float(Mp) * Mp * Bp_local           # SURVEY.md 8(d): F_trsm = M'^2 B' per solve
+            ach = flops / t_solve / 1e12
+            # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+            # separate runs, gfx950 corrections applied by tools/summarize_pmc.py); only valid for the 1-GPU C4 shape
+            traffic = traffic_src = pmc_busy = None
+            if world == 1 and cfg_name == "c4" and eng.trsm_nb >= Mp and not fp64 and headline:
+                import glob
+                # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
+                # (the kernel that runs the forward solve NOW decides which committed profile applies: the wide kernel of gemm64.hip first)
+                families = ("gemm64w_kernel<float", "gemm64_kernel<float")
+                for fam in families:
+                    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+                        cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith(fam)]
+                        if cands:   # the forward solve is the largest launch of that instantiation
+                            traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+                            traffic_src = "profiles/" + os.path.basename(pmc)
+                            break
+                    if traffic is not None:
+                        break
+                for fam in families:
+                    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_mfma_busy.txt")), reverse=True):
+                        best = None
+                        lines = open(pmc).read().splitlines()
+                        for i, ln in enumerate(lines[:-1]):
+                            if ln.startswith(fam) and " grid=" in ln and "mfma_busy=" in lines[i + 1]:
+                                vals = dict(kv.split("=") for kv in lines[i + 1].replace(" GHz", "").split() if "=" in kv)
+                                ms = float(ln.split("avg_ms=")[1])
+                                if best is None or ms > best[2]:            # (the forward solve is the longest launch of its family)
+                                    best = (ln, vals, ms)
+                        if best:
+                            pmc_busy = dict(kernel=best[0].split(" grid=")[0], mfma_busy=float(best[1]["mfma_busy"]),
+                                            wait_any_per_wave=float(best[1]["wait_any/wave"]),
+                                            wait_inst_any_per_wave=float(best[1]["wait_inst_any/wave"]), clock_ghz=float(best[1]["clk"]),
+                                            profiled_avg_ms=best[2], source="profiles/" + os.path.basename(pmc),
+                                            note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
+                                                 "--config c4`, forward-solve launches only; committed profile, not collected by this run")
+                            break
+                    if pmc_busy is not None:
+                        break
+            wide = Mp >= 64 and (Mp + 63) // 64 * ((Bp_local + 63) // 64) >= 8192          # (gemm64.hip: 64 x 192 / 64 x 128 tiles from 8192 tiles of 64 x 64 up)
+            roof = dict(bound="mfma", kernel=("%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
+                                               % ("gemm64w_kernel<double, 128>" if wide else "gemm64_kernel<double>") if fp64 else
+                                               "%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"
+                                               % ("gemm64w_kernel<float, 192>" if wide else "gemm64_kernel<float>")),
+                        achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
+                        traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
+                        mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
+            if rank == 0 and headline:
+                # what THIS card sustains on the same instruction with no memory traffic (40 ms of back-to-back MFMAs after the
+                # timed region): `peak` above is the data-sheet figure at 2.4 GHz, which no MI355X of this pool holds under matrix load
+                sus = dsvgp_amd._ops.mfma_rate(dsvgp_amd._ops.Context.get(device), True, 40)
+                roof["sustained"] = dict(measured_mfma_only=sus, unit="TFLOP/s", frac_of_sustained=ach / sus,
+                                         note="v_mfma_f64_16x16x4_f64 from registers on all CUs (dsvgp_mfma_rate)")
+
+        t_ciq, n_ciq = avg("ciq_stacked_backward")
+        if cfg.get("ciq") and t_ciq:
+            # CIQ (BASELINE config 5): the largest launch of the step is the stacked backward product of sqrt_inv_matmul,
+            # K_ZZ-bar = -sym stack_i(U_i)^T stack_i(Z_i): [M', depth] x [depth, M'] in fp32 on v_mfma_f32_32x32x2_f32 (DESIGN.md section 8)
+            depth = float(eng.ciq_stats.get("stacked_depth", 0))
+            flops = 2.0 * Mp * Mp * depth
+            roof = dict(bound="mfma", kernel="gemm32 (stacked backward product of the CIQ step: [M', depth]^T x [depth, M'], fp32 MFMA)",
+                        achieved=flops / t_ciq / 1e12, peak=157.3, unit="TFLOP/s", frac=flops / t_ciq / 1e12 / 157.3, traffic=None,
+                        launches=n_ciq, avg_ms=t_ciq * 1e3, flops_per_launch=flops, depth=depth)
+        # kernel assembly (north_star: HBM GB/s of the assembly): algorithmic bytes per launch (SURVEY.md 8d) =
+        # 4 [M' B' + (M + B) d (p + 1)] -- write the block matrix once (forward) / read its gradient once (backward) plus the
+        # points and directions -- over the live HIP-event duration on the stream the kernel was queued on
+        roof_asm = None
+        t_f, n_f = avg("assemble_fwd")
+        t_b, n_b = avg("assemble_bwd")
+        if t_f and t_b and not cfg.get("ciq"):
+            nbytes = 4.0 * (float(Mp) * Bp_local + (M + B_local) * d * (p + 1))
+            roof_asm = dict(bound="hbm", peak=PEAK_HBM_TBPS, unit="TB/s", bytes_per_launch=nbytes,
+                            forward=dict(kernel="kernel_fwd (K_ZX, %d x %d fp32, interleaved block layout)" % (Mp, Bp_local),
+                                         avg_ms=t_f * 1e3, launches=n_f, achieved=nbytes / t_f / 1e12,
+                                         frac=nbytes / t_f / 1e12 / PEAK_HBM_TBPS,
+                                         note="queued on the side stream under the Cholesky chain when M' >= 2048: shares the CUs",
+                                         alone_avg_ms=iso_fwd * 1e3 if iso_fwd else None,
+                                         alone_achieved=nbytes / iso_fwd / 1e12 if iso_fwd else None,
+                                         alone_frac=nbytes / iso_fwd / 1e12 / PEAK_HBM_TBPS if iso_fwd else None),
+                            backward=dict(kernel="kernel_bwd (reads K_ZX-bar once -> dZ, dV, d ell, d s)", avg_ms=t_b * 1e3,
+                                          launches=n_b, achieved=nbytes / t_b / 1e12, frac=nbytes / t_b / 1e12 / PEAK_HBM_TBPS))
+
+        return roof, roof_asm
+
+    roof, roof_asm = rooflines(cfg, eng, durations, iso_fwd, args.fp64, args.config, True)
     Mp = M * (p + 1)
-    B_local = B // world
-    Bp_local = B_local * (p + 1)
+    hl = (eng.trsm_nb, eng.lib_dense_gemm, bool(getattr(eng, "c_step_used", False)), getattr(eng, "pack_reduce", None),
+          int(getattr(eng, "early_wire_numel", 0) or 0))
+    graph_replay = bool(loop._graphs)
+    ciq_stats = dict(eng.ciq_stats) if cfg.get("ciq") else None
 
-    def avg(name):
-        durs = durations.get(name, [])
-        return (sum(durs) / len(durs), len(durs)) if durs else (None, 0)
+    # ---- every other BASELINE configuration, timed by this same command (one GPU, default run): C2, C3, C5 and the float64 model
+    # mode at C4, each with its own warm-up and ONE timed window of the given number of steps (same bracketing as above)
+    other = None
+    if extras and not args.no_other_configs:
+        other = {}
+        del loop, eng, batch
+        import gc
+        for key, name, fp64_, steps_, warm_ in (("c2", "c2", False, 300, 20), ("c3", "c3", False, 30, 5), ("c5", "c5", False, 8, 3),
+                                                  ("c4_fp64", "c4", True, 10, 3)):
+            gc.collect()
+            torch.cuda.empty_cache()
+            cfg_o = CONFIGS[name]
+            loop_o, eng_o, batch_o = build(cfg_o, fp64_)
+            for k in range(warm_):
+                loop_o.step(batch_o(k))
+            events_on(eng_o, 8 if name == "c2" else 1)
+            e_o, loss_o = window(loop_o, batch_o, warm_, steps_)
+            eng_o.record_events = False
+            roof_o, asm_o = rooflines(cfg_o, eng_o, event_durations(eng_o, EVENT_NAMES), None, fp64_, name, False)
+            other[key] = dict(workload=cfg_o["name"] + (" (float64 model mode)" if fp64_ else ""), steps=steps_, warmup=warm_,
+                              ms_per_step=1e3 * e_o / steps_, steps_per_s=steps_ / e_o, final_loss=float(loss_o.item()),
+                              one_call_step=bool(getattr(eng_o, "c_step_used", False)),
+                              roofline_kernel=(roof_o or {}).get("kernel"), roofline_frac=(roof_o or {}).get("frac"),
+                              roofline_avg_ms=(roof_o or {}).get("avg_ms"),
+                              assembly_fwd_frac=((asm_o or {}).get("forward") or {}).get("frac"),
+                              assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
+            del loop_o, eng_o, batch_o
+        eng = None
 
-    roof = None
-    t_solve, n_solve = avg("solve_fwd")
-    if t_solve:
-        flops = float(Mp) * Mp * Bp_local           # F_trsm = M'^2 B' per solve
-        ach = flops / t_solve / 1e12
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
-        # separate runs, gfx950 corrections applied by tools/summarize_pmc.py); only valid for the 1-GPU C4 shape
-        traffic = traffic_src = pmc_busy = None
-        if world == 1 and args.config == "c4" and eng.trsm_nb >= Mp and not args.fp64:
-            import glob
-            # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
-            # (the kernel that runs the forward solve NOW decides which committed profile applies: the wide kernel of gemm64.hip first)
-            families = ("gemm64w_kernel<float", "gemm64_kernel<float")
-            for fam in families:
-                for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
-                    cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith(fam)]
-                    if cands:   # the forward solve is the largest launch of that instantiation
-                        traffic = max(cands, key=lambda k: k["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
-                        traffic_src = "profiles/" + os.path.basename(pmc)
-                        break
-                if traffic is not None:
-                    break
-            for fam in families:
-                for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_mfma_busy.txt")), reverse=True):
-                    best = None
-                    lines = open(pmc).read().splitlines()
-                    for i, ln in enumerate(lines[:-1]):
-                        if ln.startswith(fam) and " grid=" in ln and "mfma_busy=" in lines[i + 1]:
-                            vals = dict(kv.split("=") for kv in lines[i + 1].replace(" GHz", "").split() if "=" in kv)
-                            ms = float(ln.split("avg_ms=")[1])
-                            if best is None or ms > best[2]:            # (the forward solve is the longest launch of its family)
-                                best = (ln, vals, ms)
-                    if best:
-                        pmc_busy = dict(kernel=best[0].split(" grid=")[0], mfma_busy=float(best[1]["mfma_busy"]),
-                                        wait_any_per_wave=float(best[1]["wait_any/wave"]),
-                                        wait_inst_any_per_wave=float(best[1]["wait_inst_any/wave"]), clock_ghz=float(best[1]["clk"]),
-                                        profiled_avg_ms=best[2], source="profiles/" + os.path.basename(pmc),
-                                        note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over `python3 bench.py "
-                                             "--config c4`, forward-solve launches only; committed profile, not collected by this run")
-                        break
-                if pmc_busy is not None:
-                    break
-        wide = Mp >= 64 and (Mp + 63) // 64 * ((Bp_local + 63) // 64) >= 8192          # (gemm64.hip: 64 x 192 / 64 x 128 tiles from 8192 tiles of 64 x 64 up)
-        roof = dict(bound="mfma", kernel=("%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
-                                           % ("gemm64w_kernel<double, 128>" if wide else "gemm64_kernel<double>") if args.fp64 else
-                                           "%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"
-                                           % ("gemm64w_kernel<float, 192>" if wide else "gemm64_kernel<float>")),
-                    achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
-                    traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
-                    mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
-        if rank == 0:
-            # what THIS card sustains on the same instruction with no memory traffic (40 ms of back-to-back MFMAs after the
-            # timed region): `peak` above is the data-sheet figure at 2.4 GHz, which no MI355X of this pool holds under matrix load
-            sus = dsvgp_amd._ops.mfma_rate(dsvgp_amd._ops.Context.get(device), True, 40)
-            roof["sustained"] = dict(measured_mfma_only=sus, unit="TFLOP/s", frac_of_sustained=ach / sus,
-                                     note="v_mfma_f64_16x16x4_f64 from registers on all CUs (dsvgp_mfma_rate)")
-
-    t_ciq, n_ciq = avg("ciq_stacked_backward")
-    if cfg.get("ciq") and t_ciq:
-        # CIQ (BASELINE config 5): the largest launch of the step is the stacked backward product of sqrt_inv_matmul,
-        # K_ZZ-bar = -sym stack_i(U_i)^T stack_i(Z_i): [M', depth] x [depth, M'] in fp32 on v_mfma_f32_32x32x2_f32
-        depth = float(eng.ciq_stats.get("stacked_depth", 0))
-        flops = 2.0 * Mp * Mp * depth
-        roof = dict(bound="mfma", kernel="gemm32 (stacked backward product of the CIQ step: [M', depth]^T x [depth, M'], fp32 MFMA)",
-                    achieved=flops / t_ciq / 1e12, peak=157.3, unit="TFLOP/s", frac=flops / t_ciq / 1e12 / 157.3, traffic=None,
-                    launches=n_ciq, avg_ms=t_ciq * 1e3, flops_per_launch=flops, depth=depth)
-    # kernel assembly (north_star: HBM GB/s of the assembly): algorithmic bytes per launch =
-    # 4 [M' B' + (M + B) d (p + 1)] -- write the block matrix once (forward) / read its gradient once (backward) plus the
-    # points and directions -- over the live HIP-event duration on the stream the kernel was queued on
-    roof_asm = None
-    t_f, n_f = avg("assemble_fwd")
-    t_b, n_b = avg("assemble_bwd")
-    if t_f and t_b and not cfg.get("ciq"):
-        nbytes = 4.0 * (float(Mp) * Bp_local + (M + B_local) * d * (p + 1))
-        roof_asm = dict(bound="hbm", peak=PEAK_HBM_TBPS, unit="TB/s", bytes_per_launch=nbytes,
-                        forward=dict(kernel="kernel_fwd (K_ZX, %d x %d fp32, interleaved block layout)" % (Mp, Bp_local),
-                                     avg_ms=t_f * 1e3, launches=n_f, achieved=nbytes / t_f / 1e12,
-                                     frac=nbytes / t_f / 1e12 / PEAK_HBM_TBPS,
-                                     note="queued on the side stream under the Cholesky chain when M' >= 2048: shares the CUs",
-                                     alone_avg_ms=iso_fwd * 1e3 if iso_fwd else None,
-                                     alone_achieved=nbytes / iso_fwd / 1e12 if iso_fwd else None,
-                                     alone_frac=nbytes / iso_fwd / 1e12 / PEAK_HBM_TBPS if iso_fwd else None),
-                        backward=dict(kernel="kernel_bwd (reads K_ZX-bar once -> dZ, dV, d ell, d s)", avg_ms=t_b * 1e3,
-                                      launches=n_b, achieved=nbytes / t_b / 1e12, frac=nbytes / t_b / 1e12 / PEAK_HBM_TBPS))
-
+    # ms_per_step = the timed window / steps, plus 1/50 of what a reporting step costs on top of a plain one (the reference reports
+    # on every 50th step, directional_vi.py:255)
+    ms_step = 1e3 * elapsed / args.steps + (report_extra_ms / 50.0 if report_extra_ms is not None else 0.0)
+    trsm_nb_, lib_dense_, c_used_, pack_, early_numel_ = hl
     if rank == 0:
         out = {
             "metric": "ELBO steps/sec, DSVGP d=20 N=1M M=500 p=5" if args.config == "c4" else "ELBO steps/sec, " + cfg["name"],
-            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "value": 1e3 / ms_step, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.fp64 else "f32 (f64 Cholesky/solves)",
             "data": "synthetic",
             "config": {"workload": cfg["name"], "global_batch": B, "per_gpu_batch": B // world, "M_prime": Mp,
-                       "parallelism": "dp%d rows" % world, "trsm_nb": eng.trsm_nb, "final_loss": final_loss,
-                       "graph_replay": bool(loop._graphs),
-                       "one_call_step": bool(getattr(eng, "c_step_used", False)),
+                       "parallelism": "dp%d rows" % world, "trsm_nb": trsm_nb_, "final_loss": final_loss,
+                       "graph_replay": graph_replay,
+                       "one_call_step": c_used_,
                        "kernel_events": "HIP events around the roofline kernels on every %s timed step" % (
                            "single" if args.event_every == 1 else "%d-th" % args.event_every),
-                       "dense_product": "rocBLAS sgemm" if eng.lib_dense_gemm else "hand-written (gemm32.hip, v_mfma_f32_32x32x2_f32)",
-                       "timed_step": "TrainLoop.step(need_variance=False): ELBO fast path every step; the reference's "
-                                     "every-50th-step nll print (per-output path, ~+9 ms once per 50 steps at C4) is "
-                                     "outside the timed region"},
+                       "dense_product": "rocBLAS sgemm" if lib_dense_ else "hand-written (gemm32.hip, v_mfma_f32_32x32x2_f32)",
+                       "timed_window_ms_per_step": 1e3 * elapsed / args.steps,
+                       "reporting_step_extra_ms": report_extra_ms,
+                       "timed_step": "TrainLoop.step(): ELBO fast path every step, timed window = `steps` plain steps; "
+                                     "ms_per_step = timed_window_ms_per_step + reporting_step_extra_ms / 50, where "
+                                     "reporting_step_extra_ms is what the reference's every-50th-step report (loss.item(), nll "
+                                     "from output.mean / output.variance[::p+1] of that forward pass: a host synchronisation + "
+                                     "one [M', M'] x [M', B] product) costs on top of a plain step, measured over 5 reporting "
+                                     "steps in a row after the window" if report_extra_ms is not None else
+                                     "TrainLoop.step(): ELBO fast path every step; the reference's every-50th-step report is "
+                                     "outside the timed region",
+                       "repeat_ms": repeat_ms,
+                       "repeat_note": "min / median / max ms per step of three windows of `steps` steps (the first one is the "
+                                      "headline window)" if repeat_ms else None,
+                       "other_configs": other},
             "roofline": roof,
             "roofline_assembly": roof_asm,
         }
@@ -434,15 +548,15 @@ def main():
             out["rccl_ranks"] = dist.get_world_size()
             t_w, n_w = avg("early_reduce_wait")
             t_r, n_r = avg("final_reduce")
-            out["config"]["collective"] = dict(backend=dist.get_backend(), algo=args.dp_algo, packed_triangle=eng.pack_reduce,
-                                               early_operand_floats=int(eng.early_wire_numel),
+            out["config"]["collective"] = dict(backend=dist.get_backend(), algo=args.dp_algo, packed_triangle=pack_,
+                                               early_operand_floats=early_numel_,
                                                exposed_early_reduce_wait_ms=t_w * 1e3 if t_w else None,
                                                final_reduce_ms=t_r * 1e3 if t_r else None,
                                                note="rank 0, HIP events on the main stream: the time the step stalls for the "
                                                     "[tril(G) | b] sum and the time of the closing gradient all-reduce",
                                                probe=coll_probe)
         if cfg.get("ciq"):
-            out["config"]["ciq"] = dict(eng.ciq_stats)
+            out["config"]["ciq"] = ciq_stats
         if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq"):
             out["cpu_baseline"] = cpu_baseline(cfg, fp64=args.fp64)
         print(json.dumps(out), flush=True)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "dsvgp_elbo_step_f32": (_i, [_p, _p, _p, _p, _z, _i]),
     "dsvgp_elbo_step_status": (_i, [_p, _p, _p]),
     "dsvgp_elbo_step_timings": (_i, [_p, _i, _p]),
+    "dsvgp_elbo_step_timed_count": (C.c_long, [_p]),
+    "dsvgp_elbo_step_locate": (_i, [_p, _i, _p, _p, _p, _p]),
     "dsvgp_version": (C.c_char_p, []),
     "dsvgp_hyp_forward": (_i, [_p, _p, _p, _p, _p]),
     "dsvgp_hyp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),

@@ -105,6 +105,19 @@ class StepPlan:
         check(lib.dsvgp_elbo_step_status(self.h, self._hyp, C.byref(self._info)), "dsvgp_elbo_step_status")
         return int(self._info.value), [float(v) for v in self._hyp]
 
+    def locate(self, workspace, which):
+        """torch view of an intermediate of the step queued last inside ``workspace`` (dsvgp_elbo_step_locate)"""
+        off, rows, cols, ld = C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+        check(lib.dsvgp_elbo_step_locate(self.h, int(which), C.byref(off), C.byref(rows), C.byref(cols), C.byref(ld)),
+              "dsvgp_elbo_step_locate")
+        dt = f32 if which in (0, 1, 4) else torch.float64
+        esz = 4 if dt == f32 else 8
+        flat = workspace[off.value:off.value + rows.value * ld.value * esz].view(dt)
+        return flat.view(rows.value, ld.value)[:, :cols.value]
+
+    def timed_count(self):
+        return int(lib.dsvgp_elbo_step_timed_count(self.h))
+
     def timings(self, back=0):
         """[solve_fwd, assemble_fwd, assemble_bwd] HIP-event durations (ms) of the timed step ``back`` steps before the last"""
         check(lib.dsvgp_elbo_step_timings(self.h, int(back), self._ms), "dsvgp_elbo_step_timings")

@@ -304,11 +304,9 @@ class ElboEngine:
         out = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in self.events if nm == name]
         slot = {"solve_fwd": 0, "assemble_fwd": 1, "assemble_bwd": 2}.get(name)
         if slot is not None and self.c_step_timed:
-            back = {}
-            for plan in reversed(self.c_step_timed):
-                b = back.get(id(plan), 0)
-                back[id(plan)] = b + 1
-                if b < 128:
+            for plan, idx in reversed(self.c_step_timed):      # (absolute index of the timed step in its plan's ring)
+                b = plan.timed_count() - 1 - idx
+                if 0 <= b < 128:
                     out.append(plan.timings(b)[slot] * 1e-3)
         return out
 
@@ -390,6 +388,38 @@ class ElboEngine:
             finally:
                 self._no_middle = False
         return self._predict_chol(ctx, params, x, D, cache)
+
+    @torch.no_grad()
+    def value_variances(self, params):
+        """Predictive variances WITH likelihood noise of the function-value rows ([::p+1]) of the ELBO fast-path step queued
+        last -- what the reference's every-50th-step report reads (``output.variance.sqrt()[::num_directions + 1]``,
+        directional_vi.py:256-258) -- from the A = L^-1 K_ZX that step left in its workspace: W = L_S^T A[:, ::p+1] is one
+        triangular [M', M'] x [M', B] fp32 product (1/(p+1) of the per-output path's W, and none of its U / per-output backward).
+        Valid until the parameters change or the next step is queued: the training loop calls it BEFORE the optimizers step."""
+        lf = getattr(self, "_last_fast", None)
+        if lf is None or "chol_variational_covar" not in params:
+            raise RuntimeError("value_variances needs an ELBO fast-path step of the Cholesky-whitened strategy queued last")
+        ctx = _ops.Context.get(self.device)
+        if lf[0] == "plan":
+            _, plan, ws, p = lf
+            A32 = plan.locate(ws, 0)[:-1]
+            hyp = plan.locate(ws, 4).reshape(-1)
+            q = p + 1
+        else:
+            _, name, hyp, pd = lf
+            A32 = self._buf[name][:-1]
+            q = pd + 1
+        Mp, Bp = A32.shape
+        B = Bp // q
+        Asub = self._get("vv_A", (Mp, B), f32)
+        Asub.copy_(A32[:, ::q])
+        W = self._get("vv_W", (Mp, B), f32)
+        _ops.gemm(ctx, TRANS_A | A_UPPER, params["chol_variational_covar"], Asub, W)          # W = tril(L_S)^T A[:, ::q]
+        mu = torch.empty(B, dtype=f32, device=self.device)
+        var = torch.empty(B, dtype=f32, device=self.device)
+        sws = self._bytes("vv_stats_ws", _lib.lib.dsvgp_stats_workspace_bytes(Mp, B))
+        _ops.predictive_stats(ctx, Asub, W, 0, params["variational_mean"], params["constant"].reshape(-1), hyp, mu, var, sws)
+        return (var + hyp[2]).clamp_min_(1e-6)
 
     @torch.no_grad()
     def predict_joint(self, params, x, D, cache=False):
@@ -996,6 +1026,10 @@ class ElboEngine:
                 raise _lib.DsvgpError("%s must be a float32 GPU tensor with unit inner stride" % name)
         if not (Z.is_contiguous() and x.is_contiguous() and (p == 0 or (V.is_contiguous() and D.is_contiguous()))):
             raise ValueError("points and directions must be contiguous")
+        for name in ("constant", "raw_lengthscale", "raw_outputscale", "raw_noise"):      # (handed over as bare device pointers)
+            t = params[name]
+            if t.dtype != f32 or not t.is_cuda or t.numel() != 1 or not t.is_contiguous():
+                raise _lib.DsvgpError("%s must be a contiguous float32 GPU tensor with one element" % name)
         P = lambda t: t.data_ptr() if t is not None and t.numel() else None
         io = plan.io
         io.Z, io.V, io.m, io.LS, io.ldls = P(Z), P(V), P(params["variational_mean"]), P(LS), _ops._ld(LS)
@@ -1023,6 +1057,7 @@ class ElboEngine:
             import time as _t
             t0 = _t.perf_counter()
         plan.run(ctx, ws, flags)
+        timed_idx = plan.timed_count() - 1 if timed else None
         if tr is not None:
             t1 = _t.perf_counter()
         info, hyp = plan.status()            # waits for the factorisation only; the rest of the step stays queued
@@ -1032,8 +1067,10 @@ class ElboEngine:
         if info != 0:
             raise _Refactored()
         if timed:
-            self.c_step_timed.append(plan)              # bench.py reads plan.timings(back) after its timed region
+            self.c_step_timed.append((plan, timed_idx))  # bench.py reads the plan's HIP events after its timed region (a step whose
+                                                         # factorisation failed is not listed: its events time garbage)
         self.c_step_used = True
+        self._last_fast = ("plan", plan, ws, p)
         self._pending = None
         return loss_out[0], grads, mu, torch.empty(0, dtype=f32, device=self.device)
 
@@ -1041,6 +1078,7 @@ class ElboEngine:
         use_fast = mll_type == "ELBO" and fast
         self._ctx = ctx
         self.c_step_used = False
+        self._last_fast = None
         if self._c_step_eligible(params, x, use_fast, sync):
             pz = params["inducing_directions"].shape[0] // params["inducing_points"].shape[0]
             Bq = x.shape[0] * (pz + 1)
@@ -1217,6 +1255,8 @@ class ElboEngine:
         packX, Kzx, S32e = pro["packX"], pro["Kzx"], pro["S32e"]
         for t in packX:
             t.record_stream(torch.cuda.current_stream(dev))
+        if not self._no_middle and self.whitening == "cholesky":
+            self._last_fast = ("buffers", "A32e", hyp, pd)
         # the fast path consumes only the fp32 copy of A: with the explicit inverse the fp64 result is never stored
         A64 = None if self.trsm_nb >= Mp else self._get("A64", (Mp, Bp), f64)
         A32e = self._get("A32e", (Mp + 1, Bp), f32)          # [A ; mu_bar^T]

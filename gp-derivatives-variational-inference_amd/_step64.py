@@ -315,6 +315,11 @@ class ElboEngine64(ElboEngine):
             loss, grads, mu, varn = self._ciq_call("loss_and_grads", params, x, y, D, num_data, mll_type=mll_type,
                                                    global_rows=global_rows, include_kl=include_kl)
             return loss.double(), {k: g.double() for k, g in grads.items()}, mu.double(), varn.double()
+        if getattr(self, "deterministic", False):
+            # the bitwise-reproducible mode (fixed-order split-K slabs, one stream) is built for the fp32 engine only: the fp64
+            # engine's transposed gemv and split-K products sum through fp64 atomics
+            raise NotImplementedError("deterministic mode covers the float32 engine (ElboEngine); the float64 model mode "
+                                      "(ElboEngine64) sums split-K slices and the transposed gemv with fp64 atomics")
         ctx = _ops.Context.get(self.device)
         params, nat = self._from_natural(ctx, params)
         if self.shared_directions:

@@ -46,6 +46,9 @@ struct G64 {
 #ifndef G64_KC
 #define G64_KC 1            // k-contiguous operands taken (A_KC / B_KC staging)
 #endif
+#if G64_STORE_SWZ && G64_KC
+#error "G64_STORE_SWZ=1 stores ra / rb in the mn-contiguous [k][m] layout only: build the probe with -DG64_KC=0"
+#endif
 #ifndef G64_BAND
 #define G64_BAND 16         // tile columns per band (probed 2 / 4 / 8 / 12 / 16 / 20 / 24 / 32: 56.5 / 57.1 / 60.8 / 62.8 / 63.4 / 57.0 / 62.6 / 54.2 TF) of the XCD-local walk
 #endif

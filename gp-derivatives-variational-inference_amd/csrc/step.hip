@@ -161,6 +161,25 @@ extern "C" int dsvgp_elbo_step_timings(dsvgp_step_plan* pl, int back, float* ms3
 }
 
 extern "C" size_t dsvgp_elbo_step_plan_bytes(const dsvgp_step_plan* pl) { return pl ? pl->bytes : 0; }
+// number of steps queued with flag 4 so far (the step queued last with that flag has index count - 1: callers that keep an index
+// per step read its timings with back = count - 1 - index, whatever was queued in between)
+extern "C" long dsvgp_elbo_step_timed_count(const dsvgp_step_plan* pl) { return pl ? pl->timed_steps : 0; }
+
+// Where an intermediate of the step queued last lies in the caller's workspace (valid until the next step on that workspace):
+//   which = 0: [A ; mu_bar^T] = [L^-1 K_ZX ; residual row], float [M' + 1, B'];  1: K_ZX, float [M', B'];  2: the Cholesky factor L,
+//   double [M', M'] (lower);  3: L^-1, double [M', M'] (lower);  4: {lengthscale, outputscale, noise, 0}, float [1, 4].   Used for the reference's every-50th-step nll print
+//   (directional_vi.py:255-260), which needs the predictive variance of the function-value rows of THAT forward pass.
+extern "C" int dsvgp_elbo_step_locate(const dsvgp_step_plan* pl, int which, size_t* offset_bytes, int* rows, int* cols, int64_t* ld) {
+    if (!pl || !offset_bytes || !rows || !cols || !ld) return DSVGP_EINVAL;
+    switch (which) {
+        case 0: *offset_bytes = pl->o_A32e; *rows = pl->Mp + 1; *cols = pl->Bp; *ld = pl->Bp; return 0;
+        case 1: *offset_bytes = pl->o_Kzx; *rows = pl->Mp; *cols = pl->Bp; *ld = pl->Bp; return 0;
+        case 2: *offset_bytes = pl->o_L; *rows = pl->Mp; *cols = pl->Mp; *ld = pl->Mp; return 0;
+        case 3: *offset_bytes = pl->o_trsm; *rows = pl->Mp; *cols = pl->Mp; *ld = pl->Mp; return 0;
+        case 4: *offset_bytes = pl->o_hyp; *rows = 1; *cols = 4; *ld = 4; return 0;
+        default: return DSVGP_EINVAL;
+    }
+}
 
 // Wait for the factorisation of the step queued last (NOT for the rest of the step) and return its status word (0 = positive
 // definite; k > 0: pivot k failed -- the caller runs psd_safe_cholesky's jitter ladder on the piecewise path) and the constrained

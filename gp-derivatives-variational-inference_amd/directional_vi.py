@@ -149,9 +149,19 @@ class TrainLoop:
 
     def step(self, idx, need_variance=False):
         """One optimisation step on the GLOBAL minibatch ``idx`` (row indices into the dataset).
-        ``need_variance``: the caller will read ``output.variance`` of THIS forward (the reference's
-        every-50-steps nll print, :255-260), so the per-output path is used instead of the ELBO fast path."""
-        self.model.engine.elbo_fast = not need_variance
+        ``need_variance``: True = the caller will read ``output.variance`` of THIS forward, so the per-output path is used
+        instead of the ELBO fast path; "values" = only the function-value rows are read (the reference's every-50-steps nll
+        print, :255-260: ``output.variance.sqrt()[::num_directions + 1]``) -- the step stays on the fast path and
+        ``output.value_variance`` is formed from the A it leaves behind, before the optimizers change the parameters."""
+        eng = self.model.engine
+        self._values_only = False
+        if need_variance == "values":
+            ok = (hasattr(eng, "value_variances") and self.mll.mll_type == "ELBO" and eng.whitening == "cholesky"
+                  and not eng.shared_directions and not self.dfree and not getattr(self, "plain", False)
+                  and hasattr(self.model.variational_strategy._variational_distribution, "chol_variational_covar")
+                  and not self.autograd_protocol)
+            self._values_only, need_variance = ok, not ok
+        eng.elbo_fast = not need_variance
         dim, p, dp = self.dim, self.minibatch_dim, self.dp
         if dp is not None:
             dp.global_batch = idx.shape[0]
@@ -180,6 +190,9 @@ class TrainLoop:
         self._cols_pinned[slot].copy_(torch.tensor(idx_y, dtype=torch.int32))
         cols = self._cols_pinned[slot].to(self.device, non_blocking=True)
         loss, output, y_batch = self._device_step(idx.contiguous(), cols, len(idx_y) - 1)
+        output._value_stride = len(idx_y)
+        if self._values_only and getattr(self.model.engine, "_last_fast", None) is not None:
+            output._value_varn = self.model.engine.value_variances(self.model._param_dict(self.likelihood))
         self.variational_optimizer.step()
         self.variational_scheduler.step()
         self.hyperparameter_optimizer.step()
@@ -478,10 +491,10 @@ def train_gp(train_dataset, num_inducing=128,
         perm = loop.epoch_permutation()
         for start in range(0, n_samples, minibatch_size):
             report = (total_step % 50 == 0) and verbose
-            loss, output, y_batch = loop.step(perm[start:start + minibatch_size], need_variance=report)
+            loss, output, y_batch = loop.step(perm[start:start + minibatch_size], need_variance="values" if report else False)
             if report:
                 means = output.mean[::num_directions + 1]
-                stds = output.variance.sqrt()[::num_directions + 1]
+                stds = output.value_variance.sqrt()          # = output.variance.sqrt()[::num_directions + 1]
                 nll = -torch.distributions.Normal(means, stds).log_prob(y_batch[::num_directions + 1]).mean()
                 print(f"Epoch: {i}; total_step: {total_step}, loss: {loss.item()}, nll: {nll}")
                 sys.stdout.flush()

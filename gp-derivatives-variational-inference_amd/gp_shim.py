@@ -154,7 +154,8 @@ class PredictiveDistribution:
 
     @property
     def mean(self):
-        self._ensure()
+        if self._mu is None:        # (a fast-path training step has left its mean here; only the variance is then on demand)
+            self._ensure()
         return self._mu
 
     loc = mean
@@ -163,6 +164,15 @@ class PredictiveDistribution:
     def variance(self):
         self._ensure()
         return self._varn if self.likelihood is not None else self._var
+
+    @property
+    def value_variance(self):
+        """``variance[::p+1]`` (the function-value rows).  After a training step taken with ``need_variance="values"`` it is
+        the vector the engine formed from that step's own forward pass (ElboEngine.value_variances); otherwise a slice."""
+        v = getattr(self, "_value_varn", None)
+        if v is not None and self.likelihood is not None:
+            return v
+        return self.variance[::getattr(self, "_value_stride", 1)]
 
     @property
     def stddev(self):

@@ -166,10 +166,10 @@ def train_gp(train_dataset, dim, num_inducing=128,
         mini_steps = 0
         for start in range(0, n_samples, minibatch_size):
             report = (total_step % 25 == 0) and verbose
-            loss, output, y_batch = loop.step(perm[start:start + minibatch_size], need_variance=report)
+            loss, output, y_batch = loop.step(perm[start:start + minibatch_size], need_variance="values" if report else False)
             if report:
                 means = output.mean[::dim + 1]
-                stds = output.variance.sqrt()[::dim + 1]
+                stds = output.value_variance.sqrt()          # = output.variance.sqrt()[::dim + 1]
                 nll = -torch.distributions.Normal(means, stds).log_prob(y_batch[::dim + 1]).mean()
                 print(f"Epoch: {i}; total_step: {mini_steps}, loss: {loss.item()}, nll: {nll}")
             mini_steps += 1

@@ -389,9 +389,15 @@ size_t dsvgp_elbo_step_plan_bytes(const dsvgp_step_plan* plan);
 int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_elbo_step_io* io, void* workspace,
                         size_t workspace_bytes, int flags);
 int dsvgp_elbo_step_status(dsvgp_step_plan* plan, float* hyp4, int* info);
+/* Where an intermediate of the step queued last lies inside the caller's workspace (valid until the next step on it): which = 0:
+ * [A ; mu_bar^T], A = L^-1 K_ZX (float [M'+1, B']); 1: K_ZX (float [M', B']); 2: the Cholesky factor L (double [M', M'], lower);
+ * 3: L^-1 (double [M', M'], lower); 4: the constrained {lengthscale, outputscale, noise, 0} (float [1, 4]).  The reference's every-50th-step nll print (directional_vi.py:255-260) reads the predictive
+ * variance of the function-value rows of the forward pass it has just differentiated: W = L_S^T A[:, ::p+1] is all it takes.  */
+int dsvgp_elbo_step_locate(const dsvgp_step_plan* plan, int which, size_t* offset_bytes, int* rows, int* cols, int64_t* ld);
 /* flags & 4 in dsvgp_elbo_step_f32: HIP-event pairs around the forward solve, the K_ZX assembly and K_ZX-bar's kernel backward,
  * each on the stream its kernel runs on; ms3 = their durations in ms (waits for the step) -- bench.py's roofline entries      */
 int dsvgp_elbo_step_timings(dsvgp_step_plan* plan, int steps_back, float* ms3);   /* the plan keeps the last 128 timed steps */
+long dsvgp_elbo_step_timed_count(const dsvgp_step_plan* plan);   /* steps queued with flag 4 so far (index of the last: count - 1) */
 
 /* ---- measurement aid (bench.py `roofline.sustained`): the MFMA rate this card holds with no memory traffic, ~`millis` ms of
  * v_mfma_f64_16x16x4_f64 (is_double = 1) or v_mfma_f32_32x32x2_f32 (0) on every CU; synchronises the stream.

@@ -981,3 +981,42 @@ def test_one_call_step_on_degenerate_shapes(dsvgp, gpu_device, N, d, M, p, B):
             continue
         assert relmax(g1[k], g0[k]) < 2e-5, (k, relmax(g1[k], g0[k]))
         assert relmax(g1[k], g_ref[k]) < 1e-3, (k, relmax(g1[k], g_ref[k]))
+
+
+@pytest.mark.parametrize("c_step", [True, False])
+def test_value_variances_of_the_reporting_step(dsvgp, gpu_device, c_step):
+    """The reference's every-50th-step nll print reads ``output.variance.sqrt()[::p+1]`` of the forward pass it differentiates
+    (directional_vi.py:255-260).  ``TrainLoop.step(need_variance="values")`` keeps that step on the ELBO fast path and forms
+    those rows from the A it leaves behind: held to the oracle's predictive at the parameters the step STARTED from."""
+    torch.manual_seed(1)
+    n, d, M, p, B = 2000, 4, 30, 2, 256
+    X = torch.rand(n, d)
+    Y = O.testfun(X)
+    loop = dsvgp.setup_training(None, num_inducing=M, num_directions=p, minibatch_size=B, minibatch_dim=p, num_epochs=1,
+                                learning_rate_hypers=0.05, seed=3, tensors=(X.to(gpu_device), Y.to(gpu_device)))
+    eng = loop.model.engine
+    eng.c_step = c_step
+    idx = torch.arange(B, device=gpu_device)
+    for _ in range(10):                         # plain steps first: q(u) away from N(0, I), so that W != A matters
+        loop.step(idx)
+    P = {k: v.detach().cpu().clone() for k, v in loop.model._param_dict(loop.likelihood).items()}
+    state = loop.col_rng.getstate()
+    cols = sorted(loop.col_rng.sample(range(1, d + 1), p) + [0])      # the columns the next step will draw (directional_vi.py:68-90)
+    loop.col_rng.setstate(state)
+    loss, output, yb = loop.step(idx, need_variance="values")
+    vv, mean = output.value_variance, output.mean
+    torch.cuda.synchronize()
+    assert getattr(output, "_value_varn", None) is not None and eng.c_step_used == c_step, "the reporting step left the fast path"
+    assert vv.shape == (B,) and mean.shape == (B * (p + 1),)
+    D = torch.eye(d)[[c - 1 for c in cols[1:]]].repeat(B, 1)
+    P64 = {k: v.double() for k, v in P.items()}
+    mu64, var64 = O.predictive(P64, X[:B].double(), D.double())
+    _, _, noise = O.constrained(P64)
+    errs = {"value variance": relmax(vv, (var64 + noise)[::p + 1]), "mean": relmax(mean, mu64),
+            "nll": abs((-torch.distributions.Normal(mean[::p + 1].cpu().double(), vv.cpu().double().sqrt()).log_prob(yb[::p + 1].cpu().double()).mean()
+                        + torch.distributions.Normal(mu64[::p + 1], (var64 + noise)[::p + 1].sqrt()).log_prob(yb[::p + 1].cpu().double()).mean()).item())}
+    _report("reporting step, value rows from the fast path vs float64 oracle (one-call step: %s)" % c_step, errs)
+    assert errs["value variance"] < 2e-5 and errs["mean"] < 4e-5 and errs["nll"] < 1e-6, errs          # observed 1.4e-6 / 4.0e-6 / 3.6e-8
+    # a step whose FULL variance vector is read still takes the per-output path and agrees with its own stride
+    loss, output, yb = loop.step(idx, need_variance=True)
+    assert torch.equal(output.value_variance, output.variance[::p + 1])

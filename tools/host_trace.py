@@ -15,7 +15,7 @@ def init(self, *a, **k):
     self.host_trace = []
     traces.append(self.host_trace)
 _step.ElboEngine.__init__ = init
-sys.argv = ["bench.py", "--config", cfg, "--steps", "400", "--warmup", "30", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--config", cfg, "--steps", "400", "--warmup", "30", "--no-cpu-baseline --no-extras"]
 try:
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 except SystemExit:

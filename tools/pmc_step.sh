@@ -6,7 +6,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r03}; shift || true
-ARGS=${@:---config c4 --steps 4 --warmup 2 --no-cpu-baseline}
+ARGS=${@:---config c4 --steps 4 --warmup 2 --no-cpu-baseline --no-extras}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_s; mkdir -p /tmp/pmc_s

@@ -5,7 +5,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}; shift || true
-ARGS=${@:---config c4 --steps 6 --warmup 2 --no-cpu-baseline}
+ARGS=${@:---config c4 --steps 6 --warmup 2 --no-cpu-baseline --no-extras}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_f /tmp/pmc_w

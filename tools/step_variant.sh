@@ -7,5 +7,5 @@ spec=$1; shift
 $R/tools/build_variant.sh $B "$spec" > /dev/null
 for a in "$@"; do
   case "$a" in *--steps*) st="";; *) st="--steps 30";; esac
-  DSVGP_LIB_PATH=$B/libdsvgp_hip.so python $R/bench.py $a $st --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$spec] $a', round(j['ms_per_step'],3))"
+  DSVGP_LIB_PATH=$B/libdsvgp_hip.so python $R/bench.py $a $st --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$spec] $a', round(j['ms_per_step'],3))"
 done

@@ -6,7 +6,7 @@ for kv in "$@"; do export "$kv"; done
 O=$R/gpurun_out/timeline; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks_$name
-rocprofv3 --kernel-trace --stats -d /tmp/ks_$name -o run -- python3 $R/bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline > /tmp/ks_$name.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ks_$name -o run -- python3 $R/bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-extras > /tmp/ks_$name.log 2>&1
 db=$(find /tmp/ks_$name -name "*.db" | head -1)
 python3 $R/tools/step_timeline.py $db > $O/timeline_$name.txt 2>&1
 python3 $R/tools/kernel_stats.py $db --steps $(($steps + 6)) > $O/kernel_stats_$name.txt 2>&1
