@@ -57,11 +57,8 @@ constexpr int TM = 128, TN = 128;
 #define G32_SK_MINT 0
 #endif
 #ifndef G32_TRI_SB
-#define G32_TRI_SB 8        // lower-triangular outputs: super-block edge (tiles) of the walk; 1 = plain row-major triangle
-#endif
-#ifndef G32_PATTERNS
-#define G32_PATTERNS 1      // 1: diagonal / ragged-row tiles deal only their useful 32 x 32 MFMA tiles to the waves (see gemm32_dma_kernel)
-#endif
+#define G32_TRI_SB 1        // lower-triangular outputs: super-block edge (tiles) of the walk; 1 = plain row-major triangle.  Measured
+#endif                      // (round 4, tools/gemm32_variants.sh, same box): Gram at C4 2.169 (1) / 2.193 (8) / 2.222 ms (4) -- no gain
 #ifndef G32_ABL
 #define G32_ABL 0           // timing ablations (results are WRONG): 1 no global fetch in the loop, 2 no LDS stores, 4 no LDS fragment reads, 8 no barriers
 #endif
@@ -366,48 +363,24 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_a
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-// 2 x 2 tiles of v_mfma_f32_32x32x2_f32 per wave (64 x 64 of the 128 x 128 output tile); lane l = 32 h + r reads chunk 2 j + h of its
-// row per read.  (The same structure on v_mfma_f32_16x16x4_f32 -- twice the fragment reads per flop -- measured 112-116 TF against
-// 117-120 in round 2 and was dropped in round 4.)
-//
-// Work patterns (round 4, G32_PATTERNS).  A workgroup lasts as long as its busiest wave, so tiles with useless MFMA tiles deal the
-// USEFUL ones evenly instead of letting some waves idle:
-//   diagonal tile of a lower-triangular output: 10 of the 16 MFMA tiles lie on or below the diagonal -- waves 0 / 1 take the two
-//     diagonal 64 x 64 corners as L-shapes {(a,a), (b,a), (b,b)} (3 tiles), waves 2 / 3 one row each of the lower-left 64 x 64
-//     block (2 tiles): 3 / 3 / 2 / 2 instead of 3 / 0 / 4 / 3 -- the tile lasts 3/4 of a full one;
-//   ragged last tile row with <= 64 valid rows (M' = 3000: 56): wave w takes MFMA row w / 2, columns 2 (w % 2) + {0, 1}:
-//     2 tiles per wave, the tile lasts half a full one (rows beyond the matrix: nothing).
-// At C4 the Gram product executed 300 full tiles for 274.6 tiles' worth of flops (24 diagonal, 24 in the ragged row) and the dense
-// K_ZX-bar product 4608 for 4512.
-enum { PAT_FULL = 0, PAT_L3 = 1, PAT_ROW2 = 2, PAT_NONE = 3 };
+// Round 4, measured and taken out again (profiles/r04_b_gemm32_patterns.txt): dealing only the USEFUL 32 x 32 MFMA tiles of a
+// diagonal tile of a lower output (10 of 16, as 3 / 3 / 2 / 2 per wave) and of a ragged last tile row (M' = 3000: 56 valid rows -> 2
+// MFMA tiles per wave) through per-wave copies of the K loop.  Ragged rows: Gram 2.077 -> 2.083 ms, dense 3.53 -> 3.55 (nothing:
+// the two workgroups of a CU alternate MFMA and DMA-issue phases in lockstep, a shorter MFMA phase of one does not shorten the
+// period of the pair); diagonal tiles: Gram 2.077 -> 2.124 ms at C4 and 0.633 -> 0.774 ms at C3 (slower); the mere presence of
+// the extra loop copies costs 1-2 % (2.077 -> 2.114 with the patterns switched off at run time).
+// MF = 32: 2 x 2 tiles of v_mfma_f32_32x32x2_f32 per wave;  MF = 16: 4 x 4 tiles of v_mfma_f32_16x16x4_f32 (same 64 x 64 wave tile,
+// same LDS images and DMA; twice the fragment reads per flop, but the smaller shape holds a higher clock under load).
+// Lane l = TS h + r (TS = 32 / 16 rows per tile, h = k slot 0..1 / 0..3) reads chunk (64 / MF) j + h of its row per read.
 template <int MF, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
-    static_assert(MF == 32, "the LDS-DMA kernel is built on v_mfma_f32_32x32x2_f32");
     constexpr int BK = 32, OPW = 128 * BK;                // words per operand image
-    constexpr int NJ = 4;                                 // chunk groups (8 k each) per stage
+    constexpr int TS = MF, NT = 64 / TS, NH = 64 / TS, NJ = 8 / NH;   // tile size, tiles per wave side, k slots, chunk groups / stage
     __shared__ __attribute__((aligned(16))) float lds[2][2 * OPW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    const int h = lane >> 5, r = lane & 31;
+    const int h = lane / TS, r = lane % TS;
     int m0, n0, kbeg, kend;
     if (!pick_unit(g, m0, n0, kbeg, kend)) return;
-
-    // ---- this wave's MFMA tiles inside the 4 x 4 grid of the output tile: rows ar0 / ar1, columns bc0 / bc1 and a pattern
-    int pat = PAT_FULL, ar0 = 2 * wr, ar1 = 2 * wr + 1, bc0 = 2 * wc, bc1 = 2 * wc + 1;
-#if G32_PATTERNS
-    {
-        const int vr = min(4, (g.M - m0 + 31) / 32);      // MFMA tile rows that hold rows of the matrix
-        const int uw = __builtin_amdgcn_readfirstlane(wave);
-        if ((g.flags & DSVGP_GEMM_OUT_LOWER) && m0 == n0) {
-            if (uw == 0) { pat = PAT_L3; ar0 = 0; ar1 = 1; bc0 = 0; bc1 = 1; }
-            else if (uw == 1) { pat = PAT_L3; ar0 = 2; ar1 = 3; bc0 = 2; bc1 = 3; }
-            else { pat = PAT_ROW2; ar0 = uw; ar1 = uw; bc0 = 0; bc1 = 1; }
-            if (ar0 >= vr) pat = PAT_NONE;
-        } else if (vr <= 2) {
-            pat = PAT_ROW2; ar0 = ar1 = uw >> 1; bc0 = 2 * (uw & 1); bc1 = bc0 + 1;
-            if (ar0 >= vr) pat = PAT_NONE;
-        }
-    }
-#endif
 
     // ---- DMA sources: 4 instructions per operand and stage, instruction i of wave w fills the 1 KB block 4 w + i
     const float* asrc[4];
@@ -457,57 +430,47 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
         }
     };
 
-    acc16 acc[2][2];
+    using accT = typename std::conditional<MF == 32, acc16, acc4f>::type;
+    accT acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[i][j][c] = 0.f;
+            for (int c = 0; c < (MF == 32 ? 16 : 4); ++c) acc[i][j][c] = 0.f;
 
-    // per-lane fragment offsets (words) inside an operand image: chunk group j of MFMA tile row / column t
+    // per-lane fragment offsets (words) inside an operand image; tile i of the wave adds i * TS rows / columns
     const int q7 = h ^ ((r >> 1) & 7);
     int aoff[NJ], boff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        aoff[j] = A_KC ? r * BK + 4 * ((2 * j) ^ q7) : (8 * j + 4 * h) * 128 + r;
-        boff[j] = B_KC ? r * BK + 4 * ((2 * j) ^ q7) : (8 * j + 4 * h) * 128 + r;
+        aoff[j] = A_KC ? (wr * 64 + r) * BK + 4 * ((NH * j) ^ q7) : (4 * NH * j + 4 * h) * 128 + wr * 64 + r;
+        boff[j] = B_KC ? (wc * 64 + r) * BK + 4 * ((NH * j) ^ q7) : (4 * NH * j + 4 * h) * 128 + wc * 64 + r;
     }
-    const int at0 = ar0 * 32 * (A_KC ? BK : 1), at1 = ar1 * 32 * (A_KC ? BK : 1);
-    const int bt0 = bc0 * 32 * (B_KC ? BK : 1), bt1 = bc1 * 32 * (B_KC ? BK : 1);
 
-    // fragments of one chunk group j (8 k): 4 k-values per lane for each MFMA tile row / column of the wave
-    struct Frag { float a[2][4], b[2][4]; };
-    auto ldA = [&](const float* As, int off, float (&d)[4]) {
-        if constexpr (A_KC) {
-            const float4 v = *reinterpret_cast<const float4*>(As + off);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        } else {
+    // fragments of one chunk group j (4 NH k): 4 k-values per lane for each of the NT + NT MFMA tiles
+    struct Frag { float a[NT][4], b[NT][4]; };
+    auto load_frag = [&](const float* As, const float* Bs, int j, Frag& f) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = As[off + e * 128];
-        }
-    };
-    auto ldB = [&](const float* Bs, int off, float (&d)[4]) {
-        if constexpr (B_KC) {
-            const float4 v = *reinterpret_cast<const float4*>(Bs + off);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        } else {
+        for (int i = 0; i < NT; ++i) {
+            if constexpr (A_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(As + aoff[j] + i * TS * BK);
+                f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = Bs[off + e * 128];
-        }
-    };
-
-    // the K loop, one copy per pattern (the pattern is fixed per wave; every copy runs the same DMA issue and the same barriers)
-    auto kloop = [&](auto tag) {
-        constexpr int PAT = decltype(tag)::value;
-        auto load_frag = [&](const float* As, const float* Bs, int j, Frag& f) {
-            if constexpr (PAT != PAT_NONE) {
-                ldA(As, aoff[j] + at0, f.a[0]);
-                if constexpr (PAT != PAT_ROW2) ldA(As, aoff[j] + at1, f.a[1]);
-                ldB(Bs, boff[j] + bt0, f.b[0]);
-                ldB(Bs, boff[j] + bt1, f.b[1]);
+                for (int e = 0; e < 4; ++e) f.a[i][e] = As[aoff[j] + e * 128 + i * TS];
             }
-        };
+            if constexpr (B_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(Bs + boff[j] + i * TS * BK);
+                f.b[i][0] = v.x; f.b[i][1] = v.y; f.b[i][2] = v.z; f.b[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.b[i][e] = Bs[boff[j] + e * 128 + i * TS];
+            }
+        }
+    };
+
+    if (kbeg < kend) {
         dma(0, kbeg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // stage 0 has landed for every wave
@@ -531,16 +494,16 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
                 __builtin_amdgcn_sched_barrier(0);         // (hipcc otherwise sinks the reads to just before their use)
                 const Frag& c = f[j & 1];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if constexpr (PAT != PAT_NONE)
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[0][e], c.b[0][e], acc[0][0], 0, 0, 0);
-                    if constexpr (PAT == PAT_FULL || PAT == PAT_ROW2)
-                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[0][e], c.b[1][e], acc[0][1], 0, 0, 0);
-                    if constexpr (PAT == PAT_FULL || PAT == PAT_L3) {
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[1][e], c.b[0][e], acc[1][0], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[1][e], c.b[1][e], acc[1][1], 0, 0, 0);
-                    }
-                }
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < NT; ++jn) {
+                            if constexpr (MF == 32)
+                                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[i][e], c.b[jn][e], acc[i][jn], 0, 0, 0);
+                            else
+                                acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[i][e], c.b[jn][e], acc[i][jn], 0, 0, 0);
+                        }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (G32_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -558,38 +521,29 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
             g32_stamps[0] = d_dma; g32_stamps[1] = d_mfma; g32_stamps[2] = d_vm; g32_stamps[3] = d_bar; g32_stamps[4] = n_st;
         }
 #endif
-    };
-    if (kbeg < kend) {
-        if (pat == PAT_FULL) kloop(std::integral_constant<int, PAT_FULL>{});
-        else if (pat == PAT_L3) kloop(std::integral_constant<int, PAT_L3>{});
-        else if (pat == PAT_ROW2) kloop(std::integral_constant<int, PAT_ROW2>{});
-        else kloop(std::integral_constant<int, PAT_NONE>{});
     }
     G32_DEST();
-    // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (c & 3) + 8 (c >> 2) + 4 (lane >> 5)
-    const bool out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
-    auto store = [&](int ti, int tj, const acc16& a) {
+    if constexpr (MF == 32) {
+        store_tile(g, acc, m0, n0, wr, wc, h, r, Cb, ldcb, atomic_);
+    } else {
+        // C/D layout of the 16 x 16 form: col = lane & 15, row = 4 (lane >> 4) + reg
+        const bool atomic = atomic_, out_lower = g.flags & DSVGP_GEMM_OUT_LOWER;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int m = m0 + ti * 32 + (c & 3) + 8 * (c >> 2) + 4 * h;
-            const int n = n0 + tj * 32 + r;
-            if (m >= g.M || n >= g.N) continue;
-            if (out_lower && n > m) continue;                // (the caller zero-fills m < n)
-            const float v = g.alpha * a[c];
-            float* dst = Cb + (int64_t)m * ldcb + n;
-#ifdef G32_ABL_NOATOMIC          // (timing ablation only: wrong results under split-K)
-            *dst = v;
-#else
-            if (atomic_) atomicAdd(dst, v);
-            else *dst = v;
-#endif
-        }
-    };
-    if (pat != PAT_NONE) store(ar0, bc0, acc[0][0]);
-    if (pat == PAT_FULL || pat == PAT_ROW2) store(ar0, bc1, acc[0][1]);
-    if (pat == PAT_FULL || pat == PAT_L3) { store(ar1, bc0, acc[1][0]); store(ar1, bc1, acc[1][1]); }
-    // (deterministic mode: the fixed-order pass reads every in-matrix entry of a slab, on or below the diagonal for a lower output;
-    //  the patterns leave out only MFMA tiles strictly above the diagonal or beyond the last row, so every such entry is written)
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int m = m0 + wr * 64 + i * 16 + 4 * h + c;
+                    const int n = n0 + wc * 64 + j * 16 + r;
+                    if (m >= g.M || n >= g.N) continue;
+                    if (out_lower && n > m) continue;
+                    const float v = g.alpha * acc[i][j][c];
+                    float* dst = Cb + (int64_t)m * ldcb + n;
+                    if (atomic) atomicAdd(dst, v);
+                    else *dst = v;
+                }
+    }
 }
 
 template <int BK>

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64_kernel(const G64 g) {
                 if (g.kchunk) {
                     if (out_lower && n > m) continue;
                     if (g.slab) g.slab[((int64_t)blockIdx.y * g.M + m) * g.N + n] = v;    // deterministic mode (summed in order afterwards)
+#ifdef G64_ABL_NOATOMIC      // (timing ablation only: wrong results)
+                    else g.C[(int64_t)m * g.ldc + n] = v;
+#else
                     else atomicAdd(&g.C[(int64_t)m * g.ldc + n], v);
+#endif
                     continue;
                 }
                 if (out_lower && n > m) v = 0.0;

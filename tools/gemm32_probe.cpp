@@ -12,6 +12,12 @@
 #ifdef G32_STAMP
 int g32_read_stamps(unsigned long long* out);
 #endif
+// the two helpers of gemm.hip that launch_gemm32 calls (the probe links gemm32.hip alone)
+hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st) {
+    if (ld == N) return hipMemsetAsync(C, 0, (size_t)M * N * esz, st);
+    return hipMemset2DAsync(C, (size_t)ld * esz, 0, (size_t)N * esz, (size_t)M, st);
+}
+int launch_splitk_reduce(hipStream_t, int, const void*, int, int, int, void*, int64_t, float*, int64_t, int, int) { return DSVGP_EINVAL; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d line %d\n", (int)e, __LINE__); exit(1); } } while (0)
 
 static void fill(float* p, size_t n, unsigned seed) {
