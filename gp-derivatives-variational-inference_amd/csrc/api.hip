@@ -4,8 +4,6 @@
 
 #include "common.h"
 
-#include <stdlib.h>
-
 extern "C" const char* dsvgp_version(void) { return "dsvgp-hip 0.1 (gfx950)"; }
 
 extern "C" int dsvgp_create(dsvgp_ctx** out) {
@@ -18,33 +16,8 @@ extern "C" int dsvgp_create(dsvgp_ctx** out) {
     *out = c;
     return 0;
 }
-// stream + events of the hybrid Cholesky chain, created on first use; DSVGP_POTRF_HYBRID=0 in the environment (read once) or
-// ctx->potrf_hybrid = 0 keeps the fused launches
-const PotrfAux* potrf_aux(dsvgp_ctx* ctx) {
-    static const int env_on = [] { const char* e = getenv("DSVGP_POTRF_HYBRID"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!ctx || !ctx->potrf_hybrid || !env_on) return nullptr;
-    PotrfAux& a = ctx->potrf_aux_;
-    if (!a.stream) {
-        bool ok = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            (void)hipGetLastError();
-            if (a.fork) (void)hipEventDestroy(a.fork);
-            if (a.join) (void)hipEventDestroy(a.join);
-            if (a.stream) (void)hipStreamDestroy(a.stream);
-            a = PotrfAux{};
-            ctx->potrf_hybrid = 0;
-            return nullptr;
-        }
-    }
-    return &a;
-}
 extern "C" int dsvgp_destroy(dsvgp_ctx* ctx) {
     if (!ctx) return DSVGP_EINVAL;
-    if (ctx->potrf_aux_.fork) (void)hipEventDestroy(ctx->potrf_aux_.fork);
-    if (ctx->potrf_aux_.join) (void)hipEventDestroy(ctx->potrf_aux_.join);
-    if (ctx->potrf_aux_.stream) (void)hipStreamDestroy(ctx->potrf_aux_.stream);
     if (ctx->blas) rocblas_destroy_handle((rocblas_handle)ctx->blas);
     delete ctx;
     return 0;
@@ -77,7 +50,7 @@ extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* i
     if (!ctx || !A || !info_dev || n <= 0 || lda < n) return DSVGP_EINVAL;
     if (algo == 1) {
         if (!workspace) return DSVGP_EINVAL;
-        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace, nullptr, 0, nullptr, false, potrf_aux(ctx));
+        return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)workspace, nullptr, 0, nullptr);
     }
     if (algo != 0) return DSVGP_EINVAL;
     rocblas_status st = rocsolver_dpotrf((rocblas_handle)ctx->blas, rocblas_fill_upper, n, A, (rocblas_int)lda, info_dev);
@@ -144,7 +117,7 @@ extern "C" int dsvgp_potrf_inverse(dsvgp_ctx* ctx, double* A, int n, int64_t lda
     double* Dinv = (double*)workspace;
     double* DinvT = Dinv + (size_t)n * n;
     // both images of L^-1 come out of the factorisation launches (the inverse tiles are written straight and transposed)
-    return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n, DinvT, ctx->prezeroed, potrf_aux(ctx));
+    return launch_potrf_blocked(ctx->stream, A, n, lda, info_dev, (double*)potrf_workspace, Dinv, n, DinvT, ctx->prezeroed);
 }
 
 // First phase of dsvgp_trsm on its own: Dinv / DinvT of `workspace` from L.  potrf_workspace (may be NULL): the

@@ -6,9 +6,6 @@
 
 #include "dsvgp.h"
 
-// second stream + events of the hybrid Cholesky chain (potrf.hip): the diagonal workgroup runs as a persistent kernel beside the
-// step launches.  Owned by the context, created on first use.
-struct PotrfAux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 struct dsvgp_ctx {
     hipStream_t stream = nullptr;
     void* blas = nullptr;  // rocblas_handle (opaque here so only potrf.hip needs the rocBLAS headers)
@@ -20,11 +17,7 @@ struct dsvgp_ctx {
     // targets, OUT_LOWER blocks, the potrf status word, the residual sums) lies in ONE region the step has cleared with a
     // single memset -- the launchers skip their own clears (a dozen ~5 us fill launches per step at M' = 600)
     bool prezeroed = false;
-    // hybrid Cholesky chain (potrf.hip): stream + events created by potrf_aux() on first use; potrf_hybrid = 0 keeps the fused launches
-    PotrfAux potrf_aux_;
-    int potrf_hybrid = 1;
 };
-const PotrfAux* potrf_aux(dsvgp_ctx* ctx);      // api.hip: nullptr when switched off or when the stream cannot be created
 
 #define DSVGP_LAUNCH_CHECK()                                  \
     do {                                                      \
@@ -76,7 +69,7 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g);     // gemm32.hip (fp32, 3
 // blocked Cholesky (potrf.hip)
 size_t potrf_blocked_workspace_bytes(int n);
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT, bool info_zeroed = false, const PotrfAux* aux = nullptr);
+                         double* YinvT, bool info_zeroed = false);
 // pieces of the one-call step (csrc/step.hip) that fold tiny dependent launches into their neighbours
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp);                                       // assemble.hip

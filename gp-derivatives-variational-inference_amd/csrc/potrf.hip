@@ -52,55 +52,6 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Hybrid chain (round 4): the critical (diagonal) workgroup of every block column leaves the step launches and becomes ONE
-// persistent 8-wave workgroup on a stream of its own (chol_diag_kernel); the step launches keep the update / inverse tiles.
-// The two sides meet in device-memory flags:
-//   wdone      number of diagonal blocks whose X_k = inv(L_kk) and W_k = X_k^T X_k are published; a tile workgroup of launch k
-//              waits for wdone > k before it reads W_k / X_k
-//   rowdone[k] workgroups of launch k that have stored their tiles of tile row k + 2 -- (k+2, k+1) and (k+2, k+2), all the
-//              diagonal workgroup needs for block k + 2 besides its own W_{k+1}
-//   started    the diagonal workgroup is resident (a one-thread gate kernel holds back the first step launch until then: a launch
-//              of spinning workgroups that fills every CU before the workgroup they wait for has a slot would never end)
-//   abort      a wait ran out (cannot happen in a healthy run; bounded so that no wave ever spins for good): everybody leaves,
-//              info = -1
-// Data that crosses between the two kernels while both run (W_k, X_k; the two tiles of row k + 2) is written and read with
-// agent-scope relaxed atomics -- sc1 stores / loads on gfx950: write-through to, and read from, the point all XCDs share --
-// followed by s_waitcnt vmcnt(0) + the flag; the L2-wide write-back / invalidate of a release / acquire fence is not needed.
-// Why: the fused launch costs the diagonal workgroup 51k cycles per block column (loads 6.1k, two 64^3 products 9.5k on four
-// waves, LDS moves 3.3k, factor + inverse 32.2k); on its own it multiplies on eight waves, shares no registers with the tile
-// roles, and its step no longer waits for the slowest tile of the launch.
-// -------------------------------------------------------------------------------------------------
-constexpr int F_WDONE = 0, F_STARTED = 1, F_ABORT = 2, F_ROW = 8;
-#ifndef POTRF_SPIN_LIMIT
-#define POTRF_SPIN_LIMIT (1 << 19)      // polls of ~1 us before a wait gives up
-#endif
-__device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_flag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool SC1> __device__ __forceinline__ void st_any(double* p, double v) { if constexpr (SC1) st_sc1(p, v); else *p = v; }
-// one thread: wait until flags[idx] >= want; false = aborted (info <- -1)
-__device__ __forceinline__ bool wait_flag(int* flags, int idx, int want, int* info) {
-    int spins = 0;
-    while (ld_flag(flags + idx) < want) {
-        if (ld_flag(flags + F_ABORT) || ++spins > POTRF_SPIN_LIMIT) {
-            st_flag(flags + F_ABORT, 1);
-            atomicCAS(info, 0, -1);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return true;
-}
-// strip length of step launch k (shared by the launcher and the diagonal workgroup, which must know how many workgroups cover
-// tile row k + 2 of that launch)
-__host__ __device__ inline int chol_strip(int nblk, int k, bool inv) {
-    const int nt = nblk - (k + 1);
-    const int tiles = (k < 0) ? 1 : nt * (nt + 1) / 2 + (inv ? nt * (k + 1) + (k + 1) : 0);
-    return tiles > POTRF_STRIP_T6 ? POTRF_STRIP_V6 : (tiles > POTRF_STRIP_T4 ? POTRF_STRIP_V4 : (tiles > POTRF_STRIP_T2 ? POTRF_STRIP_V2 : 1));
-}
-
-// -------------------------------------------------------------------------------------------------
 // ONE launch per block column.
 //   With X_k = inv(L_kk) and W_k = X_k^T X_k = inv(A_kk) the rank-64 update of step k needs no solved panel:
 //       A_ij -= L_ik L_jk^T = (A_ik W_k) A_jk^T                  (i >= j > k)
@@ -255,7 +206,6 @@ __device__ __forceinline__ acc4 prod16(const double* Ab, int lda_, const double*
 // chain of the next diagonal sub-block, waves 1..3 do everything that is already final: the other trailing sub-blocks,
 // the global stores of row-block kb of X and column-block kb of L, and the running sum W = X^T X = sum_kb X_kb^T X_kb
 // (lower blocks, mirrored on store) -- so the critical path is 4 x (factor16 + one panel product + one update product).
-template <bool SC1 = false>
 __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT], double (*Xd)[17], double* colbuf,
                                              double* rowbuf, int tid, int* info, int gidx0, int nvalid,
                                              double* __restrict__ Ag, int64_t lda, double* __restrict__ Xg,
@@ -337,7 +287,7 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
             const int t3 = tid - 64;
             for (int e = t3; e < 16 * 64; e += 192) {
                 const int r = o + (e >> 6), c = e & 63;
-                st_any<SC1>(&Xg[r * 64 + c], Y[r][c]);
+                Xg[r * 64 + c] = Y[r][c];
             }
             for (int e = t3; e < (64 - o) * 16; e += 192) {
                 const int r = o + (e >> 4), c = o + (e & 15);
@@ -371,8 +321,8 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mb * 16 + mrow + 4 * q, nn = nb * 16 + ncol;
-                    st_any<SC1>(&Wg[m * 64 + nn], wacc[sI][q]);
-                    st_any<SC1>(&Wg[nn * 64 + m], wacc[sI][q]);
+                    Wg[m * 64 + nn] = wacc[sI][q];
+                    Wg[nn * 64 + m] = wacc[sI][q];
                 }
             }
         }
@@ -385,13 +335,12 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 //   Y-tiles  (j <= k):         Y_kj  = X_k R_kj                        (row block k of L^-1 is final)
 // Row k of R was completed by launch k-1 and is read-only here; these tiles ride on the CUs the latency-bound
 // factorisation chain leaves idle.
-template <int NW = 4, bool HYB = false>
+template <int NW = 4>
 __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n,
                                                   int k, int e, const double* __restrict__ Xws,
                                                   const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
                                                   double* __restrict__ Y, int64_t ldy, int nblk,
-                                                  double* __restrict__ YT, int strip = 1, int* flags = nullptr,
-                                                  int* info = nullptr, int* okflag = nullptr) {
+                                                  double* __restrict__ YT, int strip = 1) {
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;     // column groups of waves, 16-column sub-tiles per wave, rows per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int nt = nblk - (k + 1), spr = (k + strip) / strip, nR = nt * spr;     // strips per tile row of R
@@ -413,16 +362,8 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
         for (int u = 0; u < NU; ++u) {
             const int r = (tid >> 6) + NW * u, c = tid & 63;
             ra[u] = ytile ? 0.0 : A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
-            if constexpr (!HYB) rb[u] = Lk[r * 64 + c];
+            rb[u] = Lk[r * 64 + c];
             rc[u] = (j == k) ? ((r == c) ? 1.0 : 0.0) : Rw[(int64_t)(k0 + r) * ldr + j0 + c];
-        }
-        if constexpr (HYB) {
-            // W_k / X_k come from the diagonal workgroup's kernel: wait for its flag (the loads above are in flight meanwhile)
-            if (tid == 0) *okflag = wait_flag(flags, F_WDONE, k + 1, info) ? 1 : 0;
-            __syncthreads();
-            if (!*okflag) return;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) rb[u] = ld_sc1(Lk + ((tid >> 6) + NW * u) * 64 + (tid & 63));
         }
         if (!ytile && j != k) {              // (R is padded to whole blocks: no clamping)
 #pragma unroll
@@ -542,12 +483,12 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
 #ifndef POTRF_MINW
 #define POTRF_MINW (POTRF_NW / 2)
 #endif
-template <int NW, bool HYB = false>
+template <int NW>
 __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
                                                            double* __restrict__ Xws, double* __restrict__ Wws,
                                                            int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
                                                            double* __restrict__ Yinv, int64_t ldy, int nA,
-                                                           double* __restrict__ YinvT, int strip, int* __restrict__ flags) {
+                                                           double* __restrict__ YinvT, int strip) {
     // TWO 64 x 64 LDS tiles (70 KB with the factorisation scratch): two workgroups share a CU, which halves the rounds
     // the ~1100 update / inverse tiles of a mid-chain launch need.  The second right operand of every tile waits in
     // registers while the first product runs.
@@ -556,12 +497,9 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     __shared__ double colbuf[32], rowbuf[32];      // [16..31]: dummy slots of the non-owner lanes
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
-    __shared__ int okflag;
-    // hybrid chain: the diagonal workgroup (block 0 of the fused launch) lives in chol_diag_kernel; the launch starts at block 1
-    const int b = HYB ? (int)blockIdx.x + 1 : (int)blockIdx.x;
+    const int b = blockIdx.x;
     if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
-        chol_inverse_tile<NW, HYB>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip, flags, info,
-                                   &okflag);
+        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip);
         return;
     }
     // tile row ti holds ti + 1 update tiles, dealt to workgroups in strips of strip block columns (block 0: the diagonal tile
@@ -589,7 +527,7 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                 const int r = (tid >> 6) + NW * u, c = tid & 63;
                 ra[u] = A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
                 rb[u] = A[((j0 + r < n) ? brow0 + u * astep : alast) + k0 + c];
-                if constexpr (!HYB) rw[u] = Wk[r * 64 + c];
+                rw[u] = Wk[r * 64 + c];
             }
             const int m0 = i0 + wr * 32 + (lane >> 4);
             const int64_t crow0 = (int64_t)m0 * lda;
@@ -604,14 +542,6 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                         cv[i][j][q] = A[((m0 + dm < n) ? crow0 + (int64_t)dm * lda : alast) + nn];
                     }
                 }
-            if constexpr (HYB) {
-                // W_k comes from the diagonal workgroup's kernel: wait for its flag (the loads above are in flight meanwhile)
-                if (tid == 0) okflag = wait_flag(flags, F_WDONE, k + 1, info) ? 1 : 0;
-                __syncthreads();
-                if (!okflag) return;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) rw[u] = ld_sc1(Wk + ((tid >> 6) + NW * u) * 64 + (tid & 63));
-            }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int r = (tid >> 6) + NW * u, c = tid & 63;
@@ -700,20 +630,10 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ml = ml0 + i * 16 + 4 * q, nl = nl0 + j * 16;
-                        if (i0 + ml < n && jcur + nl < n && !(diag && nl > ml)) {
-                            if (HYB && ti == 1) st_sc1(&cdst[(int64_t)(i * 16 + 4 * q) * lda + j * 16], acc[i][j][q]);   // (read by the diagonal workgroup)
-                            else cdst[(int64_t)(i * 16 + 4 * q) * lda + j * 16] = acc[i][j][q];
-                        }
+                        if (i0 + ml < n && jcur + nl < n && !(diag && nl > ml))
+                            cdst[(int64_t)(i * 16 + 4 * q) * lda + j * 16] = acc[i][j][q];
                     }
             if (cc + 1 < ncols) __syncthreads();     // every wave is done reading A_jk out of S[1]
-        }
-        if constexpr (HYB) {
-            if (ti == 1) {                           // tile row k + 2 of this launch: what the diagonal workgroup waits for
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(flags + F_ROW + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
         }
         if (b != 0) return;
         __syncthreads();                                            // F aliases the T tile: every wave is done reading it
@@ -729,7 +649,7 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                     F[ml][nl] = in ? acc[i][j][q] : ((ml == nl) ? 1.0 : 0.0);   // identity padding of a ragged last block
                 }
         CHOL_STAMP(9);
-    } else if constexpr (!HYB) {
+    } else {
         double ra[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -743,7 +663,6 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
         }
         __syncthreads();        // (row-wise fill: the leading 16 x 16 block comes from several waves)
     }
-    if constexpr (HYB) return;          // (the diagonal tile is factored by chol_diag_kernel)
     // (update path: wave 0 owns rows / columns 0..31 of F, so the block its first chain reads is its own -- no barrier here)
     CHOL_STAMP(2);
     // ---- factor the diagonal tile kk = k + 1 ----
@@ -753,133 +672,6 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                  Wws + (size_t)kk * 4096);
     CHOL_STAMP(3);
     CHOL_STAMP_FLUSH;
-}
-
-// The diagonal workgroup of the hybrid chain: ONE persistent workgroup of 8 waves walks the diagonal.  Block kk = k + 1:
-//   wait for the two tiles of tile row kk that step launch k - 1 updated, A_{kk,k} and A_{kk,kk};
-//   C = A_{kk,kk} - (A_{kk,k} W_k) A_{kk,k}^T  (two 64^3 products on 8 waves, W_k written by this workgroup one block earlier);
-//   factor + invert C in LDS (factor64_lds: waves 0..3; waves 4..7 only meet its barriers), X_kk / W_kk / L_kk to memory;
-//   publish wdone = kk + 1.
-#ifdef POTRF_DEBUG
-__device__ unsigned long long chol_diag_dbg[256 * 8];      // [block][stamp]: loop top, row tiles seen, operands in LDS, C formed, factored, published
-#define DIAG_STAMP(slot) do { if (tid == 0 && kk < 256) { __builtin_amdgcn_sched_barrier(0); chol_diag_dbg[kk * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define DIAG_STAMP(slot) do { } while (0)
-#endif
-__global__ __launch_bounds__(512, 1) void chol_diag_kernel(double* __restrict__ A, int64_t lda, int n, double* __restrict__ Xws,
-                                                           double* __restrict__ Wws, int* __restrict__ info,
-                                                           int* __restrict__ flags, int has_inv) {
-    constexpr int NW = 8, WC = 4, NU = 64 / NW;
-    __shared__ double S[2][64][LDT];
-    __shared__ double Xd[16][17];
-    __shared__ double colbuf[32], rowbuf[32];
-    __shared__ int okflag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
-    const int nblk = (n + 63) / 64;
-    double (*F)[LDT] = S[0];
-    double (*Y)[LDT] = S[1];
-    if (tid == 0) st_flag(flags + F_STARTED, 1);
-    // ---- block 0: straight from the matrix
-    {
-        double ra[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int r = (tid >> 6) + NW * u, c = tid & 63;
-            ra[u] = A[(int64_t)min(r, n - 1) * lda + min(c, n - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int r = (tid >> 6) + NW * u, c = tid & 63;
-            F[r][c] = (r < n && c <= r) ? ra[u] : ((r == c) ? 1.0 : 0.0);
-        }
-        __syncthreads();
-    }
-    factor64_lds<true>(F, Y, Xd, colbuf, rowbuf, tid, info, 0, n < 64 ? n : 64, A, lda, Xws, Wws);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) st_flag(flags + F_WDONE, 1);
-    const int ml0 = wr * 32 + (lane >> 4), nl0 = wc * 16 + (lane & 15);
-#pragma unroll 1
-    for (int k = 0; k < nblk - 1; ++k) {
-        const int kk = k + 1, r0 = kk * 64, k0 = k * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
-        DIAG_STAMP(0);
-        if (k >= 1) {
-            // tiles (kk, k) and (kk, kk) were last written by the workgroups of tile row 1 of step launch k - 1
-            const int strip = chol_strip(nblk, k - 1, has_inv != 0), need = (1 + strip) / strip;
-            if (tid == 0) okflag = wait_flag(flags, F_ROW + k - 1, need, info) ? 1 : 0;
-            __syncthreads();
-            if (!okflag) return;
-        }
-        DIAG_STAMP(1);
-        double ra[NU], cv[2][4];
-        {
-            double rw[NU];
-            const double* Wk = Wws + (size_t)k * 4096;
-            const int64_t alast = (int64_t)(n - 1) * lda;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {       // (rows past the matrix: clamped to the last row, zeroed on the way to LDS)
-                const int r = (tid >> 6) + NW * u, c = tid & 63;
-                ra[u] = ld_sc1(A + ((r0 + r < n) ? (int64_t)(r0 + r) * lda : alast) + k0 + c);
-                rw[u] = ld_sc1(Wk + r * 64 + c);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = r0 + ml0 + i * 16 + 4 * q, nn = min(r0 + nl0, n - 1);
-                    cv[i][q] = ld_sc1(A + ((m < n) ? (int64_t)m * lda : alast) + nn);
-                }
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int r = (tid >> 6) + NW * u, c = tid & 63;
-                S[0][r][c] = (r0 + r < n) ? ra[u] : 0.0;
-                S[1][r][c] = rw[u];
-            }
-        }
-        __syncthreads();
-        DIAG_STAMP(2);
-        acc4 acc[2][1];
-        tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_{kk,k} W_k   (W symmetric)
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {           // -T to LDS, the accumulators restart from the C tile
-                S[0][ml0 + i * 16 + 4 * q][nl0] = -acc[i][0][q];
-                acc[i][0][q] = cv[i][q];
-            }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int r = (tid >> 6) + NW * u, c = tid & 63;
-            S[1][r][c] = (r0 + r < n) ? ra[u] : 0.0;                    // A_jk = A_ik on the diagonal
-        }
-        __syncthreads();
-        tile_product<true, NW, true>(S[0], S[1], lane, wr, wc, acc);    // C - T A_{kk,k}^T
-        __syncthreads();                                                // F aliases the T tile
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ml = ml0 + i * 16 + 4 * q, nl = nl0;
-                const bool in = r0 + ml < n && r0 + nl < n && nl <= ml;
-                F[ml][nl] = in ? acc[i][0][q] : ((ml == nl) ? 1.0 : 0.0);   // identity padding of a ragged last block
-            }
-        DIAG_STAMP(3);
-        // (wave 0 owns rows 0..31, columns 0..15 of F: the 16 x 16 block its first chain reads is its own -- no barrier here)
-        factor64_lds<true>(F, Y, Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
-                           Wws + (size_t)kk * 4096);
-        DIAG_STAMP(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) st_flag(flags + F_WDONE, kk + 1);
-        DIAG_STAMP(5);
-    }
-}
-
-// holds back the first step launch until the diagonal workgroup is resident (see the flag list above)
-__global__ void chol_gate_kernel(int* __restrict__ flags, int* __restrict__ info) {
-    if (threadIdx.x == 0) wait_flag(flags, F_STARTED, 1, info);
 }
 
 // the last block row of L^-1 (its X is produced by the last step launch): Y_kj = X_k R_kj, j <= k = nblk - 1
@@ -942,16 +734,15 @@ __global__ __launch_bounds__(256) void chol_panels_kernel(double* __restrict__ A
 
 size_t potrf_blocked_workspace_bytes(int n) {
     const size_t nblk = (size_t)cdiv(n, NBC);
-    // X_k, W_k blocks + the flags of the hybrid chain (4 KB) + the working matrix R of the fused inverse (padded to whole blocks)
-    return sizeof(double) * (2 * nblk * NBC * NBC + 512 + nblk * NBC * nblk * NBC);
+    // X_k, W_k blocks + the working matrix R of the fused inverse (padded to whole blocks)
+    return sizeof(double) * (2 * nblk * NBC * NBC + nblk * NBC * nblk * NBC);
 }
 
 // one fused launch per block column + one batched panel launch (see chol_step_kernel).  Yinv != nullptr: also L^-1
 // (lower triangle, leading dimension ldy) by the fused forward elimination, and (YinvT != nullptr) its transpose with the
-// same leading dimension.  aux != nullptr (and st not being captured into a graph): the hybrid chain -- the diagonal workgroup as
-// a persistent kernel on aux->stream, the step launches on st without it (see the flag list at the top of this file).
+// same leading dimension.
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT, bool info_zeroed, const PotrfAux* aux) {
+                         double* YinvT, bool info_zeroed) {
     if (!info_zeroed) {
         hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
         if (e != hipSuccess) return 1000 + (int)e;
@@ -959,48 +750,21 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
     const int nblk = cdiv(n, NBC);
     double* Xws = ws;
     double* Wws = ws + (size_t)nblk * NBC * NBC;
-    int* flags = (int*)(Wws + (size_t)nblk * NBC * NBC);
-    double* Rw = Yinv ? Wws + (size_t)nblk * NBC * NBC + 512 : nullptr;
+    double* Rw = Yinv ? Wws + (size_t)nblk * NBC * NBC : nullptr;
     const int64_t ldr = (int64_t)nblk * NBC;
-    bool hybrid = aux && aux->stream && nblk >= 2 && nblk <= 1000;
-    if (hybrid) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); hybrid = false; }
-    }
-    if (hybrid) {
-        hipError_t e = hipMemsetAsync(flags, 0, 4096, st);
-        if (e == hipSuccess) e = hipEventRecord(aux->fork, st);
-        if (e == hipSuccess) e = hipStreamWaitEvent(aux->stream, aux->fork, 0);
-        if (e != hipSuccess) return 1000 + (int)e;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(512), 0, aux->stream, A, lda, n, Xws, Wws, info, flags, Yinv ? 1 : 0);
-        DSVGP_LAUNCH_CHECK();
-        e = hipEventRecord(aux->join, aux->stream);
-        if (e != hipSuccess) return 1000 + (int)e;
-        hipLaunchKernelGGL(chol_gate_kernel, dim3(1), dim3(64), 0, st, flags, info);
-        DSVGP_LAUNCH_CHECK();
-    }
-    for (int k = hybrid ? 0 : -1; k < nblk - 1; ++k) {
+    for (int k = -1; k < nblk - 1; ++k) {
         const int nt = nblk - (k + 1);
-        const int strip = chol_strip(nblk, k, Yinv != nullptr);
+        const int tiles = (k < 0) ? 1 : nt * (nt + 1) / 2 + (Yinv ? nt * (k + 1) + (k + 1) : 0);
+        const int strip = tiles > POTRF_STRIP_T6 ? POTRF_STRIP_V6 : (tiles > POTRF_STRIP_T4 ? POTRF_STRIP_V4 : (tiles > POTRF_STRIP_T2 ? POTRF_STRIP_V2 : 1));
         int nA = 1;                                  // update tiles, in strips of `strip` block columns per tile row
         if (k >= 0) {
             nA = 0;
             for (int ti = 0; ti < nt; ++ti) nA += (ti + strip) / strip;
         }
         const int nI = (k >= 0 && Yinv) ? nt * ((k + strip) / strip) + (k + 1) : 0;     // R strips + Y tiles
-        if (hybrid) {
-            if (nA - 1 + nI > 0)
-                hipLaunchKernelGGL((chol_step_kernel<POTRF_NW, true>), dim3(nA - 1 + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws,
-                                   info, Rw, ldr, Yinv, ldy, nA, YinvT, strip, flags);
-        } else {
-            hipLaunchKernelGGL((chol_step_kernel<POTRF_NW, false>), dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info,
-                               Rw, ldr, Yinv, ldy, nA, YinvT, strip, (int*)nullptr);
-        }
+        hipLaunchKernelGGL(chol_step_kernel<POTRF_NW>, dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info, Rw,
+                           ldr, Yinv, ldy, nA, YinvT, strip);
         DSVGP_LAUNCH_CHECK();
-    }
-    if (hybrid) {
-        hipError_t e = hipStreamWaitEvent(st, aux->join, 0);       // every X_k / L_kk is in memory
-        if (e != hipSuccess) return 1000 + (int)e;
     }
     const int ny = Yinv ? nblk : 0, npan = nblk * (nblk - 1) / 2;
     if (ny + npan > 0) {
@@ -1012,9 +776,6 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
 }
 
 #ifdef POTRF_DEBUG
-extern "C" int dsvgp_debug_potrf_diag(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_diag_dbg), sizeof(unsigned long long) * 256 * 8);
-}
 extern "C" int dsvgp_debug_potrf_clock(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 32);
 }
