@@ -38,6 +38,12 @@ class ElboStepIO(C.Structure):
                 ("loss", _p), ("mu", _p), ("num_data", _d), ("global_rows", _d), ("kzz_jitter", _f)]
 
 
+class ElboStepDP(C.Structure):
+    """``dsvgp_elbo_step_dp`` of include/dsvgp.h (rank, world and the collective operands of one data-parallel rank)"""
+    _fields_ = [("rank", _i), ("world", _i), ("wire", _p), ("wire_floats", _z), ("q_local", _p), ("q_all", _p),
+                ("lbar_local", _p), ("lbar_all", _p)]
+
+
 # name -> (restype, argtypes); mirrors include/dsvgp.h one to one
 SIGNATURES = {
     "dsvgp_create": (_i, [C.POINTER(_p)]),
@@ -49,6 +55,9 @@ SIGNATURES = {
     "dsvgp_elbo_step_plan_destroy": (_i, [_p]),
     "dsvgp_elbo_step_plan_bytes": (_z, [_p]),
     "dsvgp_elbo_step_f32": (_i, [_p, _p, _p, _p, _z, _i]),
+    "dsvgp_elbo_step_dp_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "dsvgp_elbo_step_dp_plan_create": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p)]),
+    "dsvgp_elbo_step_dp_f32": (_i, [_p, _p, _p, _p, _p, _z, _i, _i]),
     "dsvgp_elbo_step_status": (_i, [_p, _p, _p]),
     "dsvgp_elbo_step_timings": (_i, [_p, _i, _p]),
     "dsvgp_elbo_step_timed_count": (C.c_long, [_p]),

@@ -81,9 +81,15 @@ class Context:
 class StepPlan:
     """``dsvgp_step_plan`` of one (M, d, p, B): host-side object of the one-call ELBO step (csrc/step.hip)"""
 
-    def __init__(self, ctx, M, d, p, B):
+    def __init__(self, ctx, M, d, p, B, world=1):
         h = C.c_void_p()
-        check(lib.dsvgp_elbo_step_plan_create(ctx.h, int(M), int(d), int(p), int(B), C.byref(h)), "dsvgp_elbo_step_plan_create")
+        if world > 1:       # one rank of a data-parallel job (B = this rank's rows)
+            check(lib.dsvgp_elbo_step_dp_plan_create(ctx.h, int(M), int(d), int(p), int(B), int(world), C.byref(h)),
+                  "dsvgp_elbo_step_dp_plan_create")
+            self.dp = _lib.ElboStepDP()
+        else:
+            check(lib.dsvgp_elbo_step_plan_create(ctx.h, int(M), int(d), int(p), int(B), C.byref(h)), "dsvgp_elbo_step_plan_create")
+        self.world = int(world)
         self.h = h
         self.bytes = int(lib.dsvgp_elbo_step_plan_bytes(h))
         self.io = _lib.ElboStepIO()
@@ -99,6 +105,10 @@ class StepPlan:
     def run(self, ctx, workspace, flags):
         check(lib.dsvgp_elbo_step_f32(ctx.h, self.h, C.byref(self.io), _ptr(workspace), workspace.numel(), int(flags)),
               "dsvgp_elbo_step_f32")
+
+    def run_dp(self, ctx, workspace, flags, phase):
+        check(lib.dsvgp_elbo_step_dp_f32(ctx.h, self.h, C.byref(self.io), C.byref(self.dp), _ptr(workspace), workspace.numel(),
+                                         int(flags), int(phase)), "dsvgp_elbo_step_dp_f32 (phase %d)" % phase)
 
     def status(self):
         """(potrf status word, [lengthscale, outputscale, noise]) of the step queued last; waits for its factorisation only"""
@@ -124,7 +134,9 @@ class StepPlan:
         return [float(v) for v in self._ms]
 
 
-def step_supported(M, d, p, B):
+def step_supported(M, d, p, B, world=1):
+    if world > 1:
+        return int(lib.dsvgp_elbo_step_dp_workspace_bytes(int(M), int(d), int(p), int(B), int(world))) > 0
     return int(lib.dsvgp_elbo_step_workspace_bytes(int(M), int(d), int(p), int(B))) > 0
 
 

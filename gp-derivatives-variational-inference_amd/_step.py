@@ -994,13 +994,20 @@ class ElboEngine:
                 and self.data_outputs == "all" and not self.shared_directions and not self._no_middle and self.potrf_algo == 1
                 and self.fused_inverse and self._trsm_nb is None and not self.lib_dense_gemm):
             return False
-        coll = self.collective
-        if coll is not None and coll.world > 1:
-            return False
         Z, V = params["inducing_points"], params["inducing_directions"]
         M, d = Z.shape
         p = V.shape[0] // M if M else 0
-        return M > 0 and x.shape[0] > 0 and M * (p + 1) <= 8192 and _ops.step_supported(M, d, p, x.shape[0])
+        Mp = M * (p + 1)
+        coll = self.collective
+        world = coll.world if coll is not None else 1
+        if world > 1:
+            # a data-parallel rank: dsvgp_elbo_step_dp_f32 covers the global-Gram schedule with the sharded replicated stage and
+            # the packed early operand; every other multi-rank schedule keeps the piecewise path
+            if not (self.global_gram and self._allow_early and self.shard_replicated and self.pack_reduce and M >= world
+                    and hasattr(coll, "all_gather_async") and Mp >= self.shard_min_mp and Mp >= 4 * world
+                    and not self.deterministic):
+                return False
+        return M > 0 and x.shape[0] > 0 and Mp <= 8192 and _ops.step_supported(M, d, p, x.shape[0], world)
 
     def _c_step(self, ctx, params, x, y, D, num_data, rows, include_kl):
         """the whole fast-path step queued by dsvgp_elbo_step_f32 (one ctypes call); raises _Refactored when the
@@ -1011,12 +1018,14 @@ class ElboEngine:
         B = x.shape[0]
         Mp, Bp = M * (p + 1), B * (p + 1)
         self._problem_size(Mp)
-        plan = self._plans.get((M, d, p, B))
+        coll = self.collective
+        world = coll.world if coll is not None else 1
+        plan = self._plans.get((M, d, p, B, world))
         if plan is None:
-            plan = self._plans[(M, d, p, B)] = _ops.StepPlan(ctx, M, d, p, B)
+            plan = self._plans[(M, d, p, B, world)] = _ops.StepPlan(ctx, M, d, p, B, world)
         # one workspace PER plan: a plan clears the pad columns of its fp32 [Q' | a] once per workspace and assumes nobody else
         # writes there (a ragged tail batch has its own plan, layout and buffer)
-        ws = self._bytes("cstep_ws_%d_%d_%d_%d" % (M, d, p, B), plan.bytes)
+        ws = self._bytes("cstep_ws_%d_%d_%d_%d_%d" % (M, d, p, B, world), plan.bytes)
         grads, loss_out, d_hyp = self._alloc_grads(params, PARAM_NAMES, zero=False)
         mu = torch.empty(Bp, dtype=f32, device=self.device)
         LS, dLS = params["chol_variational_covar"], grads["chol_variational_covar"]
@@ -1056,7 +1065,10 @@ class ElboEngine:
         if tr is not None:
             import time as _t
             t0 = _t.perf_counter()
-        plan.run(ctx, ws, flags)
+        if world > 1:
+            self._c_step_dp_phases(ctx, plan, ws, flags, coll, Mp)
+        else:
+            plan.run(ctx, ws, flags)
         timed_idx = plan.timed_count() - 1 if timed else None
         if tr is not None:
             t1 = _t.perf_counter()
@@ -1073,6 +1085,45 @@ class ElboEngine:
         self._last_fast = ("plan", plan, ws, p)
         self._pending = None
         return loss_out[0], grads, mu, torch.empty(0, dtype=f32, device=self.device)
+
+    def _c_step_dp_phases(self, ctx, plan, ws, flags, coll, Mp):
+        """one data-parallel rank: the five pieces of dsvgp_elbo_step_dp_f32 with this rank's collectives between them
+        (include/dsvgp.h; same schedule as the piecewise global-Gram path with the sharded replicated stage below)"""
+        world, dev = coll.world, self.device
+        wq = ((Mp + 1 + world - 1) // world + 3) // 4 * 4
+        wr = (Mp + world - 1) // world
+        used = _ops.tril_packed_numel(Mp, Mp)
+        total = (used + 2047) // 2048 * 2048                # (any world size <= 8 can reduce-scatter it)
+        key = ("dp_bufs", Mp, world)
+        bufs = self._buf.get(key)
+        if bufs is None:
+            bufs = self._buf[key] = dict(wire=torch.zeros(total, dtype=f32, device=dev),
+                                         q_local=torch.zeros(Mp, wq, dtype=f32, device=dev),
+                                         q_all=torch.empty(world, Mp, wq, dtype=f32, device=dev),
+                                         lbar_local=torch.zeros(wr, Mp, dtype=f32, device=dev),
+                                         lbar_all=torch.empty(world * wr, Mp, dtype=f32, device=dev))
+        dp = plan.dp
+        dp.rank, dp.world = coll.rank, world
+        dp.wire, dp.wire_floats = bufs["wire"].data_ptr(), total
+        dp.q_local, dp.q_all = bufs["q_local"].data_ptr(), bufs["q_all"].data_ptr()
+        dp.lbar_local, dp.lbar_all = bufs["lbar_local"].data_ptr(), bufs["lbar_all"].data_ptr()
+        self.early_wire_numel = total
+        plan.run_dp(ctx, ws, flags, 0)
+        h_g = coll.all_reduce_async(bufs["wire"])
+        plan.run_dp(ctx, ws, flags, 1)
+        h_q = coll.all_gather_async(bufs["q_all"], bufs["q_local"])
+        ev_w = self._event_pair()                        # (bench.py: how long the main stream stalls for [G ; b^T])
+        h_g.wait()
+        self._event_done("early_reduce_wait", ev_w)
+        plan.run_dp(ctx, ws, flags, 2)
+        h_l = coll.all_gather_async(bufs["lbar_all"], bufs["lbar_local"])
+        h_q.wait()
+        plan.run_dp(ctx, ws, flags, 3)
+        h_l.wait()
+        plan.run_dp(ctx, ws, flags, 4)
+        self._global_gram = True
+        self.sharded_stage_used = True
+        self.variational_grads_global = True
 
     def _loss_and_grads(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, fast, sync):
         use_fast = mll_type == "ELBO" and fast
@@ -1306,7 +1357,17 @@ class ElboEngine:
             vbar2 = 1.0 / (noise * rows)                     # 2 * vbar
 
         def variational_part():
-            _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)        # 2 vbar tril(G tril(L_S))
+            if coll is not None and not self.deterministic:
+                # global-Gram schedule: every rank forms L_S-bar itself from the same summed G and nobody reduces it again, so
+                # THIS product adds its K slices in a fixed order (slab scratch, dsvgp_set_deterministic around the one call):
+                # the replicas' L_S and Adam moments stay bitwise equal -- no periodic re-broadcast of the variational parameters
+                ctx.set_deterministic(self._bytes("gls_slab", 4 * 4 * Mp * Mp + 4096))
+                try:
+                    _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)
+                finally:
+                    ctx.set_deterministic(None)
+            else:
+                _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LS, dLS, alpha=vbar2)    # 2 vbar tril(G tril(L_S))
             dm.copy_(Ge[Mp])                                 # b = A mu_bar, the data part of m-bar (global under coll)
             # ONE pass over (L_S, tril(G L_S)): trace terms |L_S^T A|_F^2 and tr G, 2 vbar tril(G L_S) where the product ran
             # unscaled (one rank: dev_scale), KL value + gradient.  Global-Gram schedule: m-bar / L_S-bar are not reduced again,
@@ -1352,6 +1413,18 @@ class ElboEngine:
             if c1 > c0:
                 q64 = self._get("Qcols64", (Mp, w), f64)
                 _ops.trsm(ctx, L, S32e[:, c0:c1], True, q64[:, :c1 - c0], loc[:, :c1 - c0], self.trsm_nb, ws, reuse_inverse=True)
+            # this rank's ROWS [r0, r1) of [Q' | a] in fp64: the left operand of its rows of L-bar, so that L-bar is formed with the
+            # arithmetic of the one-GPU step (fp64 [Q' | a] x fp32 [G ; b^T], fp64 accumulation) instead of an fp32 product of the
+            # gathered fp32 copy.  L^-T[r0:r1, :] is zero left of column r0
+            wr = (Mp + Gw - 1) // Gw
+            r0 = min(coll.rank * wr, Mp)
+            r1 = min(r0 + wr, Mp)
+            self._qrows64 = None
+            if r1 > r0:
+                Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
+                qr = self._get("Qrows64", (wr, (Mp + 2) // 2 * 2), f64)[:r1 - r0, :Mp + 1]
+                _ops.gemm(ctx, TRANS_A | A_UPPER, Linv[r0:, r0:r1], S32e[r0:], qr)
+                self._qrows64 = qr
             allq = self._get("Qall32", (Gw, Mp, w), f32)
             return coll.all_gather_async(allq, loc), allq, w
 
@@ -1369,15 +1442,17 @@ class ElboEngine:
             return Qe32
 
         def lbar_sharded(Qe32):
-            """rank g: rows [r0, r1) of L-bar = -2 vbar [Q' | a][G ; b^T] (fp32 MFMA product; only the lower triangle is read later),
-            all-gathered; the Cholesky backward takes the fp32 L-bar as the float operand of its first fp64 product"""
+            """rank g: rows [r0, r1) of L-bar = -2 vbar [Q' | a][G ; b^T] (fp64 rows of [Q' | a] x fp32 [G ; b^T], fp64 accumulation:
+            the one-GPU arithmetic; only the lower triangle is read later), all-gathered as fp32; the Cholesky backward takes the
+            fp32 L-bar as the float operand of its first fp64 product"""
             Gw = coll.world
             wr = (Mp + Gw - 1) // Gw
             r0 = min(coll.rank * wr, Mp)
             r1 = min(r0 + wr, Mp)
             loc = self._get_zeroed("Lrows32", (wr, Mp), f32)
             if r1 > r0:
-                _ops.gemm(ctx, _lib.K_PADDED, Qe32[r0:r1], Ge, loc[:r1 - r0], alpha=-vbar2)
+                l64 = self._get("Lrows64", (wr, Mp), f64)
+                _ops.gemm(ctx, 0, self._qrows64, Ge, l64[:r1 - r0], alpha=-vbar2, C32=loc[:r1 - r0])
             allr = self._get("Lall32", (Gw * wr, Mp), f32)
             h = coll.all_gather_async(allr, loc)
             h.wait()

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void ls_rows_reduce_kernel(const float* __rest
                                                              const float* __restrict__ G, int64_t ldg, int n, float t1_scale,
                                                              float* __restrict__ out_kl, float* __restrict__ sums,
                                                              const float* __restrict__ hyp, int fin_npts, int fin_p, float inv_rows,
-                                                             float* __restrict__ fin_scal) {
+                                                             float* __restrict__ fin_scal, int mute = 0) {
     __shared__ double red[3][256];
     double a = 0, b = 0, c = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -463,8 +463,10 @@ __global__ __launch_bounds__(256) void ls_rows_reduce_kernel(const float* __rest
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (rowkl && out_kl) out_kl[0] = (float)red[0][0];
-        if (rowtr && sums) { sums[2] = t1_scale * (float)red[1][0]; sums[3] = (float)red[2][0]; }
+        // mute: a data-parallel rank whose G is the GLOBAL Gram matrix but which is not the rank that counts the trace terms and the
+        // KL value (they enter the summed loss once; the gradients were formed regardless)
+        if (rowkl && out_kl) out_kl[0] = mute ? 0.f : (float)red[0][0];
+        if (rowtr && sums) { sums[2] = mute ? 0.f : t1_scale * (float)red[1][0]; sums[3] = mute ? 0.f : (float)red[2][0]; }
         if (fin_scal) elbo_fast_finalize_body(sums, hyp, fin_npts, fin_p, inv_rows, fin_scal);   // (one launch fewer in the one-call step)
     }
 }
@@ -1083,12 +1085,13 @@ int launch_variational_terms(hipStream_t st, const float* m, const float* LS, in
                              const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,
                              float* sums, const float* dm_src, float* d_m, float* d_LS, int64_t lddls, int fin_npts, int fin_p,
                              float* fin_scal) {
-    int rc = launch_ls_rows(st, m, LS, ldls, Mp, (float)(1.0 / num_data), flags | 4, hyp, (float)(1.0 / global_rows),
+    // flags bit 3 (8): mute the scalar outputs (trace terms, KL value), see ls_rows_reduce_kernel
+    int rc = launch_ls_rows(st, m, LS, ldls, Mp, (float)(1.0 / num_data), (flags & 3) | 4, hyp, (float)(1.0 / global_rows),
                             kl_out + 1, kl_out + 1 + Mp, d_m, d_LS, lddls, dm_src);
     if (rc) return rc;
     hipLaunchKernelGGL(ls_rows_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)(kl_out + 1),
                        (const float*)(kl_out + 1 + Mp), G, ldg, Mp, t1_scale, kl_out, sums, hyp, fin_npts, fin_p,
-                       (float)(1.0 / global_rows), fin_scal);
+                       (float)(1.0 / global_rows), fin_scal, (flags & 8) ? 1 : 0);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

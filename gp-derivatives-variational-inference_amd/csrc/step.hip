@@ -41,6 +41,10 @@ inline int auto_nb(int Mp) {          // _step.ElboEngine._problem_size: the exp
 
 struct dsvgp_step_plan {
     int M, d, p, B, Mp, Bp, DP, nb;
+    int world = 1;                    // > 1: a data-parallel rank's plan (dsvgp_elbo_step_dp_f32); sizes the buffers below
+    int wq = 0, wr = 0;               // column block of [Q' | a] / row block of L-bar per rank
+    size_t o_Qfull = 0, o_Qrows64 = 0, o_qcol64 = 0, o_cbT = 0, o_cbK = 0, o_slab = 0, slab_bytes = 0, o_lrow64 = 0;
+    hipEvent_t ev_dp = nullptr;
     size_t bytes;
     // workspace offsets (bytes)
     size_t o_zero, zero_bytes;        // region cleared at the start of every step: info, sums, kl_buf
@@ -63,8 +67,8 @@ struct dsvgp_step_plan {
 };
 
 // workspace layout of one (M, d, p, B); returns the total byte count (0: unsupported shape)
-static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl) {
-    if (M <= 0 || d <= 0 || p < 0 || B <= 0) return 0;
+static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int world = 1) {
+    if (M <= 0 || d <= 0 || p < 0 || B <= 0 || world < 1 || world > 64 || (world > 1 && M < world)) return 0;
     const int q = p + 1, Mp = M * q, Bp = B * q, DP = dsvgp_packed_width(d);
     if (DP <= 0 || Mp > 8192 || (int64_t)Mp * Bp >= ((int64_t)1 << 31)) return 0;
     pl->M = M; pl->d = d; pl->p = p; pl->B = B; pl->Mp = Mp; pl->Bp = Bp; pl->DP = DP; pl->nb = auto_nb(Mp);
@@ -102,6 +106,27 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl) {
     pl->o_sums = pl->o_info + 4 * sizeof(int);
     pl->o_klbuf = pl->o_sums + 4 * sizeof(float);
     pl->arena_bytes = c.off - pl->o_arena;            // (T tail of the solve workspace ... head)
+    pl->world = world;
+    if (world > 1) {
+        // data-parallel rank (global-Gram schedule with the replicated M'^3 stage sharded): its columns of
+        // [Q' | a] (fp64 result of the column solve, fp32 copy in the caller's all-gather operand), its ROWS of [Q' | a] in fp64
+        // (left operand of its rows of L-bar), the gathered [Q' | a] in row-major form, the column block of the Cholesky
+        // backward, one fp64 row block of L-bar, and the slab of the fixed-order G L_S product (the replicas' L_S-bar must agree
+        // bit for bit: nobody reduces it again)
+        const int q1 = p + 1;
+        pl->wq = ((Mp + 1 + world - 1) / world + 3) / 4 * 4;
+        pl->wr = (Mp + world - 1) / world;
+        const int wc = ((M + world - 1) / world) * q1;              // widest column block of K_ZZ-bar
+        const int ldQ64 = (Mp + 2) / 2 * 2;
+        pl->o_Qfull = c.take((size_t)Mp * world * pl->wq * 4);
+        pl->o_Qrows64 = c.take((size_t)pl->wr * ldQ64 * 8);
+        pl->o_qcol64 = c.take((size_t)Mp * pl->wq * 8);
+        pl->o_lrow64 = c.take((size_t)pl->wr * Mp * 8);
+        pl->o_cbT = c.take((size_t)Mp * wc * 8);
+        pl->o_cbK = c.take((size_t)Mp * wc * 8);
+        pl->slab_bytes = (size_t)4 * Mp * Mp * 4 + 4096;
+        pl->o_slab = c.take(pl->slab_bytes);
+    }
     pl->bytes = c.off + 256;
     return pl->bytes;
 }
@@ -111,13 +136,18 @@ extern "C" size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B) {
     return step_layout(M, d, p, B, &pl);
 }
 
-extern "C" int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out) {
+extern "C" size_t dsvgp_elbo_step_dp_workspace_bytes(int M, int d, int p, int B, int world) {
+    dsvgp_step_plan pl{};
+    return step_layout(M, d, p, B, &pl, world);
+}
+
+static int plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, dsvgp_step_plan** out) {
     if (!ctx || !out) return DSVGP_EINVAL;
     dsvgp_step_plan* pl = new (std::nothrow) dsvgp_step_plan();
     if (!pl) return DSVGP_EINVAL;
-    if (!step_layout(M, d, p, B, pl)) { delete pl; return DSVGP_EINVAL; }
+    if (!step_layout(M, d, p, B, pl, world)) { delete pl; return DSVGP_EINVAL; }
     bool ok = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) == hipSuccess;
-    hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx};
+    hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx, &pl->ev_dp};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     for (auto& slot : pl->tm_ring) for (hipEvent_t& e : slot) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&pl->host_status, 8 * sizeof(float), hipHostMallocDefault) == hipSuccess;
@@ -134,10 +164,18 @@ extern "C" int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, 
     *out = pl;
     return 0;
 }
+extern "C" int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out) {
+    return plan_create(ctx, M, d, p, B, 1, out);
+}
+// plan of ONE RANK of a `world`-rank data-parallel job (B = this rank's rows of the minibatch): dsvgp_elbo_step_dp_f32
+extern "C" int dsvgp_elbo_step_dp_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, dsvgp_step_plan** out) {
+    if (world < 2) return DSVGP_EINVAL;
+    return plan_create(ctx, M, d, p, B, world, out);
+}
 
 extern "C" int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* pl) {
     if (!pl) return DSVGP_EINVAL;
-    hipEvent_t evs[] = {pl->ev_fork, pl->ev_side, pl->ev_status, pl->ev_fork2, pl->ev_var, pl->ev_dense, pl->ev_zx};
+    hipEvent_t evs[] = {pl->ev_fork, pl->ev_side, pl->ev_status, pl->ev_fork2, pl->ev_var, pl->ev_dense, pl->ev_zx, pl->ev_dp};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& slot : pl->tm_ring) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
     if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -212,45 +250,54 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
 //        bit 2 = record HIP-event timings; bit 3 = the workspace may have been written by somebody else (re-clear the paddings).
 // io->flat .. flat + flat_floats is cleared here (the gradient slots must start from zero); every gradient pointer of io points
 // into it.  All pointers are device pointers; nothing is read back.
-extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace,
-                                   size_t workspace_bytes, int flags) {
+static int step_validate(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace, size_t workspace_bytes) {
     if (!ctx || !pl || !io || !workspace || workspace_bytes < pl->bytes || ((uintptr_t)workspace % 256)) return DSVGP_EINVAL;
     if (!io->Z || !io->m || !io->LS || !io->constant || !io->raw_lengthscale || !io->raw_outputscale || !io->raw_noise || !io->x ||
         !io->y || !io->flat || !io->dZ || !io->dm || !io->dLS || !io->d_hyp || !io->d_constant || !io->d_raw_lengthscale ||
         !io->d_raw_outputscale || !io->d_raw_noise || !io->loss || !io->mu || io->num_data <= 0 || io->global_rows <= 0)
         return DSVGP_EINVAL;
-    const int M = pl->M, d = pl->d, p = pl->p, B = pl->B, Mp = pl->Mp, Bp = pl->Bp, nb = pl->nb;
+    const int p = pl->p, Mp = pl->Mp;
     if (p > 0 && (!io->V || !io->D || !io->dV)) return DSVGP_EINVAL;
     if (io->ldls < Mp || io->lddls < Mp) return DSVGP_EINVAL;
-    char* w = (char*)workspace;
-    int* info = (int*)(w + pl->o_info);
-    float* sums = (float*)(w + pl->o_sums);
-    float* kl_buf = (float*)(w + pl->o_klbuf);
-    float* scal = (float*)(w + pl->o_scal);
-    float* hyp = (float*)(w + pl->o_hyp);
-    float* center = (float*)(w + pl->o_center);
-    float *PZ = (float*)(w + pl->o_PZ), *sZ = (float*)(w + pl->o_sZ), *vZ = (float*)(w + pl->o_vZ);
-    float *PX = (float*)(w + pl->o_PX), *sX = (float*)(w + pl->o_sX), *vX = (float*)(w + pl->o_vX);
-    double* L = (double*)(w + pl->o_L);
-    void* trsm_ws = w + pl->o_trsm;
-    void* potrf_ws = w + pl->o_potrf;
-    float* Kzx = (float*)(w + pl->o_Kzx);
-    float* A32e = (float*)(w + pl->o_A32e);          // [A ; mu_bar^T]
-    float* S32e = (float*)(w + pl->o_S32e);          // [S - I | m / (2 vbar)], rows padded to a multiple of 4 floats
-    float* var0 = (float*)(w + pl->o_var0);
-    void* stats_ws = w + pl->o_stats;
-    float* Ge = (float*)(w + pl->o_Ge);              // [G ; b^T]
-    double* Qe64 = (double*)(w + pl->o_Qe64);        // [Q' | a / (2 vbar)]
-    float* Qe32 = (float*)(w + pl->o_Qe32);
-    float* Kb32 = (float*)(w + pl->o_Kb32);
-    double* Lbar = (double*)(w + pl->o_Lbar);
-    double* G1 = (double*)(w + pl->o_G1);
-    double* Yt = (double*)(w + pl->o_Yt);
-    double* Kbar = (double*)(w + pl->o_Kbar);
-    void* kbwd_ws = w + pl->o_kbwd;
-    void* kbwd_ws2 = w + pl->o_kbwd2;
-    const int ldS = pl->ldS, ldQ32 = pl->ldQ32, ldQ64 = (Mp + 2) / 2 * 2;     // (even fp64 rows: 16-byte loads in the conversion pass)
+    return 0;
+}
+
+#define STEP_LOCALS \
+    const int M = pl->M, d = pl->d, p = pl->p, B = pl->B, Mp = pl->Mp, Bp = pl->Bp, nb = pl->nb; \
+    char* w = (char*)workspace; \
+    int* info = (int*)(w + pl->o_info); \
+    float* sums = (float*)(w + pl->o_sums); \
+    float* kl_buf = (float*)(w + pl->o_klbuf); \
+    float* scal = (float*)(w + pl->o_scal); \
+    float* hyp = (float*)(w + pl->o_hyp); \
+    float* center = (float*)(w + pl->o_center); \
+    float *PZ = (float*)(w + pl->o_PZ), *sZ = (float*)(w + pl->o_sZ), *vZ = (float*)(w + pl->o_vZ); \
+    float *PX = (float*)(w + pl->o_PX), *sX = (float*)(w + pl->o_sX), *vX = (float*)(w + pl->o_vX); \
+    double* L = (double*)(w + pl->o_L); \
+    void* trsm_ws = w + pl->o_trsm; \
+    void* potrf_ws = w + pl->o_potrf; \
+    float* Kzx = (float*)(w + pl->o_Kzx); \
+    float* A32e = (float*)(w + pl->o_A32e); \
+    float* S32e = (float*)(w + pl->o_S32e); \
+    float* var0 = (float*)(w + pl->o_var0); \
+    void* stats_ws = w + pl->o_stats; \
+    float* Ge = (float*)(w + pl->o_Ge); \
+    double* Qe64 = (double*)(w + pl->o_Qe64); \
+    float* Qe32 = (float*)(w + pl->o_Qe32); \
+    float* Kb32 = (float*)(w + pl->o_Kb32); \
+    double* Lbar = (double*)(w + pl->o_Lbar); \
+    double* G1 = (double*)(w + pl->o_G1); \
+    double* Yt = (double*)(w + pl->o_Yt); \
+    double* Kbar = (double*)(w + pl->o_Kbar); \
+    void* kbwd_ws = w + pl->o_kbwd; \
+    void* kbwd_ws2 = w + pl->o_kbwd2; \
+    const int ldS = pl->ldS, ldQ32 = pl->ldQ32, ldQ64 = (Mp + 2) / 2 * 2; \
     const double rows = io->global_rows;
+
+// Everything up to and including the Gram product [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T) of this rank's rows (shared by the
+// one-GPU step and by phase 0 of a data-parallel rank)
+static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace, int flags) {
+    STEP_LOCALS
     const bool overlap = (flags & 1) && !ctx->det_slab;           // (deterministic mode: the scratch serves one stream)
     const bool include_kl = flags & 2, timed = flags & 4;
     pl->timed = timed;
@@ -318,6 +365,24 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // ---- [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), split-K over the minibatch axis; G mirrored
     STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
                          Mp, nullptr, 0, nullptr));
+    return 0;
+}
+
+extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace,
+                                   size_t workspace_bytes, int flags) {
+    if (int rc = step_validate(ctx, pl, io, workspace, workspace_bytes)) return rc;
+    if (pl->world != 1) return DSVGP_EINVAL;          // (a data-parallel rank's plan: dsvgp_elbo_step_dp_f32)
+    STEP_LOCALS
+    const bool overlap = (flags & 1) && !ctx->det_slab;           // (deterministic mode: the scratch serves one stream)
+    const bool include_kl = flags & 2, timed = flags & 4;
+    const hipStream_t main = ctx->stream, side = pl->side;
+    struct PrezeroGuard {               // (the flag must not outlive the call, whatever path returns)
+        dsvgp_ctx* c; bool prev;
+        PrezeroGuard(dsvgp_ctx* c_, bool on) : c(c_), prev(c_->prezeroed) { c->prezeroed = on; }
+        ~PrezeroGuard() { c->prezeroed = prev; }
+    } prezero_guard(ctx, pl->arena_bytes <= ((size_t)48 << 20) && !ctx->det_slab);
+    STEP_CALL(step_front(ctx, pl, io, workspace, flags));
+    float* A32 = A32e;
     STEP_CALL(dsvgp_mirror_lower_f32(ctx, Ge, Mp, Mp));
     // ---- variational block (needs only G): L_S-bar = 2 vbar tril(G L_S) + KL gradient, m-bar = b + KL gradient, trace terms, scalars
     auto variational = [&]() -> int {
@@ -406,6 +471,149 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     if (zx_side || tail_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
     STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
     // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
+    STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,
+                                    kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
+                                    io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// One RANK of a data-parallel job (global-Gram schedule with the replicated M'^3 stage
+// sharded), queued in five pieces with the caller's collectives between them -- the same schedule `_step.ElboEngine` issues
+// through ~120 ctypes calls:
+//   phase 0  everything up to the Gram product of this rank's rows; [tril(G) | b] packed into dp->wire
+//            -> caller: all-reduce(sum) of dp->wire                                                   (18 MB at M' = 3000)
+//   phase 1  this rank's COLUMNS of [Q' | a] = L^-T [S - I | m / (2 vbar)] (fp64 product, fp32 copy in dp->q_local) and its
+//            ROWS of it in fp64 (left operand of its rows of L-bar)                                   (needs L^-1 and S only)
+//            -> caller: all-gather dp->q_local -> dp->q_all                                            (36 MB)
+//   phase 2  (after the all-reduce) G global: mirror; L_S-bar, m-bar, KL, trace terms on the side stream (identical on every rank:
+//            the G L_S product adds its K slices in a fixed order); this rank's rows of L-bar = -[Q' | a][G ; b^T] in fp64
+//            (the arithmetic of the one-GPU step), fp32 copy in dp->lbar_local
+//            -> caller: all-gather dp->lbar_local -> dp->lbar_all                                      (36 MB)
+//   phase 3  (after the first all-gather) [Q' | a] row-major; dense K_ZX-bar of this rank's rows; its kernel backward
+//   phase 4  (after the second all-gather) this rank's column block of K_ZZ-bar = 1/2 L^-T Phi(L^T L-bar) L^-1 and its kernel
+//            backward (row-side gradient doubled by symmetry), scaling by 2 vbar, scalar tail
+//            -> caller: all-reduce(sum) of [Z-bar, V-bar, hyper-parameter gradients, loss]              (0.24 MB)
+// flags as dsvgp_elbo_step_f32 (bit 1: this is the rank that counts the KL value and the trace terms of the global G).
+// -------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const float* __restrict__ src, float* __restrict__ dst, int rowsM, int wq,
+                                                            int world) {
+    // dst[m][g * wq + c] = src[g][m][c]: 16-byte pieces (wq is a multiple of 4)
+    const int per_row = world * (wq / 4);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)rowsM * per_row; e += (int64_t)gridDim.x * 256) {
+        const int m = (int)(e / per_row), r = (int)(e - (int64_t)m * per_row), g = r / (wq / 4), c4 = r - g * (wq / 4);
+        reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[((int64_t)g * rowsM + m) * (wq / 4) + c4];
+    }
+}
+
+extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, const dsvgp_elbo_step_dp* dp,
+                                      void* workspace, size_t workspace_bytes, int flags, int phase) {
+    if (int rc = step_validate(ctx, pl, io, workspace, workspace_bytes)) return rc;
+    if (!dp || pl->world < 2 || dp->world != pl->world || dp->rank < 0 || dp->rank >= dp->world || phase < 0 || phase > 4 ||
+        !dp->wire || !dp->q_local || !dp->q_all || !dp->lbar_local || !dp->lbar_all)
+        return DSVGP_EINVAL;
+    STEP_LOCALS
+    const int world = pl->world, rank = dp->rank, wq = pl->wq, wr = pl->wr, q1 = p + 1;
+    const int64_t wire_used = (int64_t)Mp * (Mp + 1) / 2 + Mp;
+    if ((int64_t)dp->wire_floats < wire_used) return DSVGP_EINVAL;
+    const bool overlap = (flags & 1) && !ctx->det_slab;
+    const bool include_kl = flags & 2, timed = pl->timed;
+    const hipStream_t main = ctx->stream, side = pl->side;
+    float* Qfull = (float*)(w + pl->o_Qfull);
+    double* Qrows64 = (double*)(w + pl->o_Qrows64);
+    double* qcol64 = (double*)(w + pl->o_qcol64);
+    double* lrow64 = (double*)(w + pl->o_lrow64);
+    double* cbT = (double*)(w + pl->o_cbT);
+    double* cbK = (double*)(w + pl->o_cbK);
+    const double* Linv = (const double*)trsm_ws;
+    const int r0 = rank * wr < Mp ? rank * wr : Mp, r1 = r0 + wr < Mp ? r0 + wr : Mp, nrow = r1 - r0;
+    struct PrezeroGuard {
+        dsvgp_ctx* c; bool prev;
+        PrezeroGuard(dsvgp_ctx* c_, bool on) : c(c_), prev(c_->prezeroed) { c->prezeroed = on; }
+        ~PrezeroGuard() { c->prezeroed = prev; }
+    } prezero_guard(ctx, false);             // (the launchers clear their own split-K targets: the arena is not cleared per phase)
+    if (phase == 0) {
+        // (front with flag 8 semantics kept; the arena-wide clear of small problems is off for data-parallel plans)
+        const size_t keep = pl->arena_bytes;
+        pl->arena_bytes = (size_t)1 << 60;
+        const int rc = step_front(ctx, pl, io, workspace, flags);
+        pl->arena_bytes = keep;
+        if (rc) return rc;
+        return dsvgp_tril_pack_f32(ctx, Ge, Mp, Mp, Ge + (size_t)Mp * Mp, Mp, dp->wire);
+    }
+    if (phase == 1) {
+        const int c0 = rank * wq < Mp + 1 ? rank * wq : Mp + 1, c1 = c0 + wq < Mp + 1 ? c0 + wq : Mp + 1;
+        if (c1 > c0)
+            STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e + c0, ldS, 0, c1 - c0, qcol64, wq, dp->q_local, wq, nb, trsm_ws, 1));
+        if (nrow > 0)     // rows [r0, r1) of L^-T [S - I | m / (2 vbar)]: L^-T[r0:r1, :] is zero left of column r0
+            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_IS_FLOAT, nrow, Mp + 1, Mp - r0, 1.0,
+                                 Linv + (size_t)r0 * Mp + r0, Mp, S32e + (size_t)r0 * ldS, ldS, 0.0, nullptr, 0, Qrows64, ldQ64, nullptr, 0,
+                                 nullptr));
+        return 0;
+    }
+    if (phase == 2) {
+        STEP_CALL(dsvgp_tril_unpack_f32(ctx, dp->wire, Mp, Ge, Mp, Ge + (size_t)Mp * Mp, Mp));
+        STEP_CALL(dsvgp_mirror_lower_f32(ctx, Ge, Mp, Mp));
+        auto variational = [&]() -> int {
+            // fixed-order sums for THIS product on every rank: the slab lives in the plan's workspace and serves this stream only
+            void* const keep_slab = ctx->det_slab; const size_t keep_bytes = ctx->det_bytes;
+            ctx->det_slab = w + pl->o_slab; ctx->det_bytes = pl->slab_bytes;
+            int rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, Ge, Mp, io->LS, io->ldls, 0.0, nullptr,
+                                0, io->dLS, io->lddls, nullptr, 0, nullptr);
+            ctx->det_slab = keep_slab; ctx->det_bytes = keep_bytes;
+            if (rc) return rc;
+            // every rank adds the KL gradient (m-bar / L_S-bar are not reduced again); one rank counts the KL value + trace terms
+            return launch_variational_terms(ctx->stream, io->m, io->LS, io->ldls, Mp, io->num_data, 1 | 2 | (include_kl ? 0 : 8), hyp,
+                                            rows, Ge, Mp, 1.f, kl_buf, sums, Ge + (size_t)Mp * Mp, io->dm, io->dLS, io->lddls, B, p, scal);
+        };
+        if (overlap) {
+            STEP_HIP(hipEventRecord(pl->ev_fork2, main));
+            STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
+            ctx->stream = side;
+            STEP_CALL(variational());
+            STEP_HIP(hipEventRecord(pl->ev_var, side));
+            ctx->stream = main;
+        } else {
+            STEP_CALL(variational());
+        }
+        if (nrow > 0)     // rows [r0, r1) of L-bar = -[Q' | a][G ; b^T] (unscaled like every product of the step), fp64 + fp32 copy
+            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_B_IS_FLOAT, nrow, Mp, Mp + 1, -1.0, Qrows64, ldQ64, Ge, Mp, 0.0, nullptr, 0, lrow64, Mp,
+                                 dp->lbar_local, Mp, nullptr));
+        return 0;
+    }
+    if (phase == 3) {
+        {
+            const int64_t n4 = (int64_t)Mp * world * (wq / 4);
+            const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+            hipLaunchKernelGGL(gather_blocks_kernel, dim3(blocks), dim3(256), 0, main, dp->q_all, Qfull, Mp, wq, world);
+            STEP_HIP(hipGetLastError());
+        }
+        STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qfull, (int64_t)world * wq, A32e, Bp, 0.0, nullptr, 0, Kb32,
+                             Bp, nullptr, 0, nullptr));
+        STEP_TIME(4);
+        STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+        STEP_TIME(5);
+        return 0;
+    }
+    // ---- phase 4: this rank's inducing points [m0, m1) = columns [m0 q, m1 q) of the symmetric K_ZZ-bar
+    const int base = M / world, rem = M % world;
+    const int m0 = rank * base + (rank < rem ? rank : rem), m1 = m0 + base + (rank < rem ? 1 : 0);
+    const int c0 = m0 * q1, wcol = (m1 - m0) * q1;
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT,
+                         Mp, Mp, Mp, 1.0, L, Mp, dp->lbar_all, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));       // tril(L^T L-bar)
+    STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));                                                                   // S = Phi(.) + Phi(.)^T
+    if (wcol > 0) {
+        // S L^-1[:, c0 : c0 + wcol]: rows < c0 of that column block of the lower-triangular inverse are zero, the rest is lower
+        // triangular in its own coordinates (S symmetric: read through its transpose)
+        STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER, Mp, wcol, Mp - c0, 1.0, G1 + (size_t)c0 * Mp, Mp,
+                             Linv + (size_t)c0 * Mp + c0, Mp, 0.0, nullptr, 0, cbT, wcol, nullptr, 0, nullptr));
+        STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER, Mp, wcol, Mp, 0.5, Linv, Mp, cbT, wcol, 0.0, nullptr, 0, cbK,
+                             wcol, nullptr, 0, nullptr));
+    }
+    if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
+    if (wcol > 0)
+        STEP_CALL(dsvgp_kernel_bwd(ctx, cbK, wcol, 1, PZ, sZ, vZ, M, PZ + (size_t)c0 * pl->DP, sZ + c0, m1 - m0, d, p, hyp, 1, io->dZ, io->dV,
+                                   io->d_hyp, kbwd_ws));
     STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,
                                     kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
                                     io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));

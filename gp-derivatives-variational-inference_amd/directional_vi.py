@@ -197,11 +197,6 @@ class TrainLoop:
         self.variational_scheduler.step()
         self.hyperparameter_optimizer.step()
         self.hyperparameter_scheduler.step()
-        # (deterministic engines form L_S-bar with fixed-order sums: the replicas stay bitwise equal, nothing to re-broadcast)
-        if dp is not None and self.model.engine.variational_grads_global and not getattr(self.model.engine, "deterministic", False):
-            self._dp_steps = getattr(self, "_dp_steps", 0) + 1
-            if self._dp_steps % dp.resync_every == 0:
-                dp.resync(self.model, (self.variational_optimizer, self.hyperparameter_optimizer))
         return loss, output, y_batch
 
     def _device_step(self, idx, cols, py):

@@ -22,7 +22,6 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.global_batch = None      # set by the training loop before every step
-        self.resync_every = 256       # steps between broadcasts of the variational parameters (see ``resync``)
         # collective algorithm of the large (early) operand: "allreduce" (RCCL picks ring / tree) or "rs_ag"
         # (reduce-scatter + all-gather); DSVGP_DP_ALGO overrides for A/B runs on an 8-GPU node
         import os
@@ -38,21 +37,6 @@ class DataParallel:
         base, rem = divmod(n, self.world)
         lo = self.rank * base + min(self.rank, rem)
         return lo, lo + base + (1 if self.rank < rem else 0)
-
-    def resync(self, model, optimizers):
-        """Under the global-Gram schedule every rank forms L_S-bar itself from the same reduced [G ; b^T]; the split-K
-        atomics of that product sum in a run-dependent order, so the replicas' L_S (and its Adam moments) can differ in the
-        last bit.  Every ``resync_every`` steps rank 0's copies are broadcast (3 x 36 MB at M'=3000, amortised to nothing);
-        Z, V and the hyper-parameters only ever see all-reduced gradients and stay bit-identical by construction."""
-        vs = model.variational_strategy
-        ts = [p.data for p in vs._variational_distribution.parameters()]
-        for opt in optimizers:
-            for p in vs._variational_distribution.parameters():
-                st = opt.state.get(p)
-                if st:
-                    ts += [v for v in st.values() if torch.is_tensor(v)]
-        for t in ts:
-            dist.broadcast(t, self.src0, group=self.group)
 
     def broadcast_floats(self, values, device):
         """rank 0's host scalars on every rank (e.g. the eigenvalue bounds of the CIQ quadrature)"""

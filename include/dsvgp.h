@@ -394,6 +394,34 @@ int dsvgp_elbo_step_status(dsvgp_step_plan* plan, float* hyp4, int* info);
  * 3: L^-1 (double [M', M'], lower); 4: the constrained {lengthscale, outputscale, noise, 0} (float [1, 4]).  The reference's every-50th-step nll print (directional_vi.py:255-260) reads the predictive
  * variance of the function-value rows of the forward pass it has just differentiated: W = L_S^T A[:, ::p+1] is all it takes.  */
 int dsvgp_elbo_step_locate(const dsvgp_step_plan* plan, int which, size_t* offset_bytes, int* rows, int* cols, int64_t* ld);
+/* ---- one RANK of a data-parallel job (the reference is single-process): the same step in five pieces with
+ * the caller's collectives (RCCL through whatever binding the host uses) between them -- global-Gram schedule: the ranks sum
+ * [tril(G) | b] instead of the L_S gradient, every rank forms the identical L_S-bar / m-bar itself, the replicated M'^3 stage
+ * is sharded (columns of [Q' | a], rows of L-bar, column blocks of K_ZZ-bar) and met again by two all-gathers.
+ *   plan      dsvgp_elbo_step_dp_plan_create(M, d, p, B = THIS RANK's rows, world); workspace of dsvgp_elbo_step_dp_workspace_bytes
+ *   io        as above with global_rows = B'(global); io->flat is cleared in phase 0
+ *   dp        rank / world and the collective operands (caller-owned device memory, float):
+ *               wire       [wire_floats >= M'(M'+1)/2 + M'] packed [tril(G) | b]; anything beyond that count is the caller's
+ *                          padding (keep it zero)             phase 0 writes it -> ALL-REDUCE(sum) -> phase 2 reads it
+ *               q_local    [M', wq], wq = roundup4(ceil((M'+1)/world)), ZERO-INITIALISED once (the pad columns stay zero)
+ *                                                              phase 1 writes it -> ALL-GATHER -> q_all [world, M', wq], phase 3 reads
+ *               lbar_local [wr, M'], wr = ceil(M'/world), zero-initialised once
+ *                                                              phase 2 writes it -> ALL-GATHER -> lbar_all [world wr, M'], phase 4 reads
+ *   phase     0 .. 4 in this order, all on the context's stream (the collectives must be ordered against it by the caller);
+ *             after phase 4: ALL-REDUCE(sum) of the slots of io->flat that hold Z-bar, V-bar, the hyper-parameter gradients and
+ *             the loss; m-bar and L_S-bar are final and identical on every rank after phase 2 / 4 (do not reduce them).
+ *   flags     as dsvgp_elbo_step_f32; bit 1 (value 2) on exactly ONE rank (it counts the KL value and the trace terms of the
+ *             global Gram matrix; every rank adds the KL gradient).  Status word as above (dsvgp_elbo_step_status after phase 0).  */
+typedef struct dsvgp_elbo_step_dp {
+    int rank, world;
+    float* wire; size_t wire_floats;
+    float* q_local; const float* q_all;
+    float* lbar_local; const float* lbar_all;
+} dsvgp_elbo_step_dp;
+size_t dsvgp_elbo_step_dp_workspace_bytes(int M, int d, int p, int B, int world);
+int dsvgp_elbo_step_dp_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, dsvgp_step_plan** out);
+int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_elbo_step_io* io, const dsvgp_elbo_step_dp* dp,
+                           void* workspace, size_t workspace_bytes, int flags, int phase);
 /* flags & 4 in dsvgp_elbo_step_f32: HIP-event pairs around the forward solve, the K_ZX assembly and K_ZX-bar's kernel backward,
  * each on the stream its kernel runs on; ms3 = their durations in ms (waits for the step) -- bench.py's roofline entries      */
 int dsvgp_elbo_step_timings(dsvgp_step_plan* plan, int steps_back, float* ms3);   /* the plan keeps the last 128 timed steps */

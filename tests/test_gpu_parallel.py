@@ -63,16 +63,19 @@ def _worker(rank, world, port, out):
     Pg = {k: v.to(dev) for k, v in P.items()}
     xs, ys, Ds = x[lo:hi].to(dev), y[lo * (p + 1):hi * (p + 1)].to(dev), D[lo * p:hi * p].to(dev)
     res = {}
-    for mode, mll in (("global", "ELBO"), ("globalshard", "ELBO"), ("globaldet", "ELBO"), ("early", "ELBO"), ("early", "PLL")):
+    for mode, mll in (("global", "ELBO"), ("globalshard", "ELBO"), ("globalshardpy", "ELBO"), ("globaldet", "ELBO"), ("early", "ELBO"),
+                      ("early", "PLL")):
         eng = dsvgp_amd.ElboEngine(dev)
         eng.global_gram = mode.startswith("global")
-        eng.shard_replicated = mode == "globalshard"        # Q' columns / L-bar rows per rank + two all-gathers
+        eng.shard_replicated = mode.startswith("globalshard")     # Q' columns / L-bar rows per rank + two all-gathers
+        eng.c_step = mode != "globalshardpy"                # "globalshard": the five-piece C entry point (dsvgp_elbo_step_dp_f32)
         eng.shard_min_mp = 0
         eng.deterministic = mode == "globaldet"             # fixed-order sums: the replicas' L_S-bar must be BITWISE equal
         loss, grads, mu, varn = dp.loss_and_grads(eng, Pg, xs, ys, Ds, nd, mll)
         torch.cuda.synchronize()
         assert eng.variational_grads_global == mode.startswith("global"), (mode, mll)
-        assert getattr(eng, "sharded_stage_used", False) == (mode == "globalshard"), mode
+        assert getattr(eng, "sharded_stage_used", False) == mode.startswith("globalshard"), mode
+        assert eng.c_step_used == (mode == "globalshard"), (mode, eng.c_step_used)
         assert eng.collective is None and eng._early_handle is None
         res[mode + mll] = (loss.item(), {k: v.cpu().clone() for k, v in grads.items()})
     for name, flags, P, x, y, D, nd, pdata in _variant_problems():
@@ -112,7 +115,7 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device, dp_resul
     for mll in ("ELBO", "PLL"):
         eng = dsvgp.ElboEngine(gpu_device)
         l1, g1, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, mll)
-        for mode in (("global", "globalshard", "globaldet", "early") if mll == "ELBO" else ("early",)):
+        for mode in (("global", "globalshard", "globalshardpy", "globaldet", "early") if mll == "ELBO" else ("early",)):
             for r in range(3):
                 loss, grads = out[r][mode + mll]
                 assert abs(loss - l1.item()) < 2e-5 * abs(l1.item()), (mode, mll, r, loss, l1.item())
@@ -129,12 +132,14 @@ def test_three_ranks_on_one_gpu_equal_single_process(dsvgp, gpu_device, dp_resul
 
 @pytest.mark.timeout(600)
 def test_deterministic_replicas_are_bitwise_equal(dsvgp, gpu_device, dp_results):
-    """global-Gram schedule under ``ElboEngine.deterministic``: every rank forms L_S-bar / m-bar itself from the same reduced
-    [G ; b^T] with fixed-order sums, so the replicas agree bit for bit (what lets ``DataParallel.resync`` be skipped)"""
+    """global-Gram schedule: every rank forms L_S-bar / m-bar itself from the same reduced [G ; b^T]; the one product behind them
+    (G L_S) adds its K slices in a fixed order on EVERY multi-rank path (round 4; the whole step under ``ElboEngine.deterministic``),
+    so the replicas agree bit for bit and nothing re-broadcasts the variational parameters"""
     out = dp_results
-    for k in ("variational_mean", "chol_variational_covar"):
-        for r in (1, 2):
-            assert torch.equal(out[0]["globaldetELBO"][1][k], out[r]["globaldetELBO"][1][k]), (k, r)
+    for mode in ("global", "globalshard", "globalshardpy", "globaldet"):
+        for k in ("variational_mean", "chol_variational_covar"):
+            for r in (1, 2):
+                assert torch.equal(out[0][mode + "ELBO"][1][k], out[r][mode + "ELBO"][1][k]), (mode, k, r)
 
 
 @pytest.mark.timeout(600)
@@ -298,3 +303,61 @@ def test_multi_rank_schedules_on_an_rccl_communicator(dsvgp, gpu_device):
         assert dl < 1e-5 and dLS < 1e-4 and dm < 1e-4, (gg, res[gg])
     assert res[False][3] < 1e-4            # general schedule: everything is local, so Z-bar is complete too
     assert res["allgather"]
+
+
+# ------------------------------------------------------------------ the sharded replicated stage at the size where it switches on
+def _c4shard_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsvgp_amd
+    from test_gpu_reftext import _errors, _load
+    dev = torch.device("cuda", 0)
+    g, P, x, y, D, nd = _load("c4shard")
+    p = D.shape[0] // x.shape[0]
+    dp = dsvgp_amd.DataParallel()
+    lo, hi = dp.shard_bounds(x.shape[0])
+    dp.global_batch = x.shape[0]
+    Pg = {k: v.to(dev) for k, v in P.items()}
+    xs, ys, Ds = x[lo:hi].to(dev), y[lo * (p + 1):hi * (p + 1)].to(dev), D[lo * p:hi * p].to(dev)
+    res = {}
+    for name, c_step in (("one-call", True), ("piecewise", False)):
+        eng = dsvgp_amd.ElboEngine(dev)
+        eng.c_step = c_step                           # defaults otherwise: global-Gram schedule, sharded stage from M' = 1024 up
+        loss, grads, mu, varn = dp.loss_and_grads(eng, Pg, xs, ys, Ds, nd, "ELBO")
+        torch.cuda.synchronize()
+        assert eng.sharded_stage_used and eng.variational_grads_global and eng.c_step_used == c_step, name
+        res[name] = dict(_errors(g, loss, grads, mu, varn)) if rank == 0 else None
+        res[name + "/LS"] = grads["chol_variational_covar"].double().sum().item()      # (cheap cross-rank identity check)
+        res[name + "/LSabs"] = grads["chol_variational_covar"].double().abs().sum().item()
+        del eng
+        torch.cuda.empty_cache()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sharded_stage_at_c4_shard_geometry_against_reference_text(dsvgp, gpu_device):
+    """The data-parallel step with the replicated M'^3 stage sharded (columns of [Q' | a], fp64 rows of L-bar, column blocks of
+    K_ZZ-bar; two all-gathers) at M' = 3000 -- the size from which it is on by default -- on 2 ranks (one card, gloo), through the
+    five-piece C entry point and through the piecewise path: loss and every gradient against the REFERENCE-TEXT vector of the C4
+    per-rank shard (tests/golden/reftext_c4shard_step.npz), at the tolerances of the one-GPU step."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_c4shard_worker, args=(2, port, out), nprocs=2, join=True)
+    from test_gpu_reftext import TOL32
+    tol_loss, tol_head, tol_grad = TOL32["c4shard"]
+    for name in ("one-call", "piecewise"):
+        errs = out[0][name]
+        print("[parity] reftext c4shard, 2 ranks, sharded stage (%s): %s" % (name, ", ".join("%s %.2e" % kv for kv in errs.items())))
+        for k, v in errs.items():
+            tol = tol_loss if k == "loss" else tol_head if k in ("mu", "varn") else tol_grad
+            assert v < tol, (name, k, v, tol)
+        # L_S-bar is formed by every rank itself: bitwise equal replicas
+        assert out[0][name + "/LS"] == out[1][name + "/LS"] and out[0][name + "/LSabs"] == out[1][name + "/LSabs"], name

@@ -65,6 +65,13 @@ def _errors(g, loss, grads, mu, varn, skip=()):
     return errs
 
 
+# per-case tolerances (loss, predictive head, gradients): a few times the errors measured on MI355X (round 4 GPUTEST log: fp32 C2
+# 5.4e-8 / 4.6e-5 / 2.9e-4 -- the last rows of L_S-bar --, C3 5.6e-8 / 1.3e-5 / 1.5e-4, C4 and its shard 1.7e-7 / 9.3e-7 / 2.4e-6;
+# fp64 C2 2.0e-14 / 3.9e-11 / 9.2e-10, C3 7.9e-16 / 3.7e-13 / 2.4e-11, C4 and its shard 3.2e-16 / 9.8e-15 / 7.2e-14)
+TOL32 = {"c2": (1e-6, 1.5e-4, 1e-3), "c3": (1e-6, 5e-5, 5e-4), "c4shard": (1e-6, 1e-5, 2e-5), "c4": (1e-6, 1e-5, 2e-5)}
+TOL64 = {"c2": (5e-12, 2e-10, 5e-9), "c3": (1e-13, 5e-12, 2e-10), "c4shard": (1e-13, 1e-12, 1e-12), "c4": (1e-13, 1e-12, 1e-12)}
+
+
 def _check(tag, errs, tol_loss, tol_head, tol_grad):
     print("[parity] reftext %s: %s" % (tag, ", ".join("%s %.2e" % kv for kv in errs.items())))
     for k, v in errs.items():
@@ -84,7 +91,7 @@ def test_fp32_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, na
     torch.cuda.synchronize()
     assert grads["chol_variational_covar"].triu(1).abs().max().item() == 0.0
     errs = _errors(g, loss, grads, mu, varn, skip=("inducing_directions",) if name == "c3" else ())
-    _check("%s fp32 %s" % (name, "gram" if fast else "per-output"), errs, 2e-6, 1e-4, 1e-3)
+    _check("%s fp32 %s" % (name, "gram" if fast else "per-output"), errs, *TOL32[name])
 
 
 @pytest.mark.parametrize("fast", [True, False], ids=["gram", "per-output"])
@@ -101,7 +108,7 @@ def test_fp64_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, na
                                                nd, "ELBO", fast=fast)
     torch.cuda.synchronize()
     errs = _errors(g, loss, grads, mu, varn, skip=("inducing_directions",) if name == "c3" else ())
-    _check("%s fp64 %s" % (name, "gram" if fast else "per-output"), errs, 1e-12, 1e-10, 1e-8)
+    _check("%s fp64 %s" % (name, "gram" if fast else "per-output"), errs, *TOL64[name])
 
 
 @pytest.mark.parametrize("name", ["c2pll", "c3pll"])
@@ -118,7 +125,7 @@ def test_pll_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, nam
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
     loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "PLL")
     torch.cuda.synchronize()
-    _check("%s fp32" % name, _errors(g, loss, grads, mu, varn, skip=skip), 2e-6, 1e-4, 1e-3)
+    _check("%s fp32" % name, _errors(g, loss, grads, mu, varn, skip=skip), *TOL32[name[:2]])
     eng64 = ElboEngine64(gpu_device)
     if name.startswith("c3"):
         eng64.chol_jitter = 1e-8
@@ -126,4 +133,4 @@ def test_pll_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, nam
     loss, grads, mu, varn = eng64.loss_and_grads(Pd, x.double().to(gpu_device), y.double().to(gpu_device), D.double().to(gpu_device),
                                                  nd, "PLL")
     torch.cuda.synchronize()
-    _check("%s fp64" % name, _errors(g, loss, grads, mu, varn, skip=skip), 1e-12, 1e-10, 1e-8)
+    _check("%s fp64" % name, _errors(g, loss, grads, mu, varn, skip=skip), *TOL64[name[:2]])
