@@ -1452,7 +1452,8 @@ class ElboEngine:
             loc = self._get_zeroed("Lrows32", (wr, Mp), f32)
             if r1 > r0:
                 l64 = self._get("Lrows64", (wr, Mp), f64)
-                _ops.gemm(ctx, 0, self._qrows64, Ge, l64[:r1 - r0], alpha=-vbar2, C32=loc[:r1 - r0])
+                # (only the lower triangle of L-bar is read: columns [0, r1); the rest of the zero-initialised block stays zero)
+                _ops.gemm(ctx, 0, self._qrows64, Ge[:, :r1], l64[:r1 - r0, :r1], alpha=-vbar2, C32=loc[:r1 - r0, :r1])
             allr = self._get("Lall32", (Gw * wr, Mp), f32)
             h = coll.all_gather_async(allr, loc)
             h.wait()

@@ -576,8 +576,10 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
         } else {
             STEP_CALL(variational());
         }
-        if (nrow > 0)     // rows [r0, r1) of L-bar = -[Q' | a][G ; b^T] (unscaled like every product of the step), fp64 + fp32 copy
-            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_B_IS_FLOAT, nrow, Mp, Mp + 1, -1.0, Qrows64, ldQ64, Ge, Mp, 0.0, nullptr, 0, lrow64, Mp,
+        if (nrow > 0)     // rows [r0, r1) of L-bar = -[Q' | a][G ; b^T] (unscaled like every product of the step), fp64 + fp32 copy;
+            // only the lower triangle of L-bar is ever read: columns [0, r1) (the rest of dp->lbar_local stays zero) -- little work for
+            // the ranks whose rows of [Q' | a] were expensive (L^-T[r0:r1, :] starts at column r0) and vice versa
+            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_B_IS_FLOAT, nrow, r1, Mp + 1, -1.0, Qrows64, ldQ64, Ge, Mp, 0.0, nullptr, 0, lrow64, Mp,
                                  dp->lbar_local, Mp, nullptr));
         return 0;
     }

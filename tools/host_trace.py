@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the HOST's time goes in the one-call step (tools only): per step, seconds between consecutive calls of
 dsvgp_elbo_step_f32, the time inside the call (queueing ~65 launches), the wait for the factorisation status, and the rest of
-the Python loop (gather, model / likelihood / mll wrappers, optimizers, schedulers).  usage: python3 tools/host_trace.py [config]"""
+the Python loop (gather, model / likelihood / mll wrappers, optimizers, schedulers).  usage: python3 tools/host_trace.py [config [more bench.py arguments]]"""
 import os, sys, runpy
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
@@ -15,7 +15,8 @@ def init(self, *a, **k):
     self.host_trace = []
     traces.append(self.host_trace)
 _step.ElboEngine.__init__ = init
-sys.argv = ["bench.py", "--config", cfg, "--steps", "400", "--warmup", "30", "--no-cpu-baseline --no-extras"]
+extra = sys.argv[2:]                 # e.g. --emulate-world 8 with config c4shard8
+sys.argv = ["bench.py", "--config", cfg, "--steps", "400", "--warmup", "30", "--no-cpu-baseline", "--no-extras"] + extra
 try:
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 except SystemExit:
