@@ -97,6 +97,7 @@ SIGNATURES = {
     "dsvgp_trsm": (_i, [_p, _p, _l, _i, _i, _p, _l, _i, _i, _p, _l, _p, _l, _i, _p, _i]),
     "dsvgp_trtri": (_i, [_p, _p, _l, _i, _i, _p, _p]),
     "dsvgp_potrf_inverse": (_i, [_p, _p, _i, _l, _p, _p, _i, _p]),
+    "dsvgp_widen_f32_f64": (_i, [_p, _p, _l, _p, _l, _i, _i]),
     "dsvgp_gemm": (_i, [_p, _i, _i, _i, _i, _i, _d, _p, _l, _p, _l, _d, _p, _l, _p, _l, _p, _l, _p]),
     "dsvgp_stats_workspace_bytes": (_z, [_i, _i]),
     "dsvgp_predictive_stats": (_i, [_p, _p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p]),

@@ -418,6 +418,14 @@ def gemm(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0, Cin=None, C32=None, kscal
     return C_out
 
 
+def widen_f32_f64(ctx, src, dst):
+    """dst (float64) = src (float32), both 2-D with unit inner stride"""
+    M, N = src.shape
+    check(lib.dsvgp_widen_f32_f64(ctx.h, _ptr(_req(src, f32, "src", 2)), _ld(src), _ptr(_req(dst, f64, "dst", 2)), _ld(dst), M, N),
+          "dsvgp_widen_f32_f64")
+    return dst
+
+
 def predictive_stats(ctx, A, W, p, m, constant, hyp, mu, var, workspace=None):
     Mp, nc = A.shape
     nbytes = int(lib.dsvgp_stats_workspace_bytes(Mp, nc))

@@ -948,11 +948,15 @@ class ElboEngine:
                            grads["raw_noise"].reshape(-1), grads["constant"].reshape(-1), loss_out)
         return loss_out[0], grads, mu, varn
 
-    def _chol_backward(self, ctx, L, Lbar, ws, Mp):
+    def _chol_backward(self, ctx, L, Lbar, ws, Mp, phi_arg=False):
         """K-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 (symmetric, fp64) for the lower factor L whose inverted
-        blocks are in ``ws``; L-bar (lower) is destroyed."""
+        blocks are in ``ws``; L-bar (lower) is destroyed.  ``phi_arg``: ``Lbar`` holds tril(L^T L-bar) already (the ELBO fast
+        path forms it as -tril([S - I | m / (2 vbar)][G ; b^T]) without L-bar, see ``_elbo_fast``)."""
         G1 = self._get("G1", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar): Phi reads nothing else
+        if phi_arg:
+            G1.copy_(Lbar)
+        else:
+            _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar): Phi reads nothing else
         _ops.phi_symmetrize_(ctx, G1)                                       # Phi(.) + Phi(.)^T (mirror of the lower part)
         Kbar = G1                                                           # reuse (after the first product has read it)
         if self.trsm_nb >= Mp:
@@ -973,11 +977,15 @@ class ElboEngine:
             Kbar.mul_(0.5)
         return Kbar
 
-    def _chol_backward_cols(self, ctx, L, Lbar, ws, Mp, c0, c1):
+    def _chol_backward_cols(self, ctx, L, Lbar, ws, Mp, c0, c1, phi_arg=False):
         """Columns [c0, c1) of K-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 from the explicit inverse in ``ws``
-        (one rank's share of the Cholesky backward under the global-Gram schedule): 2 M'^2 w flops instead of 3 M'^3."""
+        (one rank's share of the Cholesky backward under the global-Gram schedule): 2 M'^2 w flops instead of 3 M'^3.
+        ``phi_arg``: ``Lbar`` (float32 or float64) holds tril(L^T L-bar) already."""
         G1 = self._get("G1", (Mp, Mp), f64)
-        _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar)
+        if phi_arg:
+            G1.copy_(Lbar)
+        else:
+            _ops.gemm(ctx, TRANS_A | A_UPPER | B_LOWER | OUT_LOWER, L, Lbar, G1)   # tril(L^T L-bar)
         _ops.phi_symmetrize_(ctx, G1)                                       # S = Phi(.) + Phi(.)^T
         Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
         w = c1 - c0
@@ -1236,7 +1244,7 @@ class ElboEngine:
             m0 = coll.rank * base + min(coll.rank, rem)
             m1 = m0 + base + (1 if coll.rank < rem else 0)
             Lb = self._lbar_f32 if getattr(self, "_lbar_f32", None) is not None else Lbar
-            Kcols = self._chol_backward_cols(ctx, L, Lb, self._buf["trsm_ws"], Mp, m0 * q, m1 * q)
+            Kcols = self._chol_backward_cols(ctx, L, Lb, self._buf["trsm_ws"], Mp, m0 * q, m1 * q, phi_arg=use_fast)
             if zx_done is not None:
                 torch.cuda.current_stream(self.device).wait_event(zx_done)
             sub = (packZ[0][m0 * q:m1 * q], packZ[1][m0 * q:m1 * q])
@@ -1244,7 +1252,7 @@ class ElboEngine:
             self.variational_grads_global = True
         else:
             # ---- Cholesky backward (fp64): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1, symmetric kernel backward ----
-            Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp)
+            Kzzbar = self._chol_backward(ctx, L, Lbar, self._buf["trsm_ws"], Mp, phi_arg=use_fast)
             if zx_done is not None:
                 torch.cuda.current_stream(self.device).wait_event(zx_done)
             _ops.kernel_bwd(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, kws)
@@ -1284,7 +1292,10 @@ class ElboEngine:
         _ops.gemm(ctx, A_LOWER | TRANS_B | _lib.B_UPPER | OUT_LOWER | (_lib.BACKGROUND if background else 0), LS, LS, S32)
         _ops.mirror_lower_f32_(ctx, S32, Mp)
         _ops.sminus_i_col_(ctx, S32e, Mp, m.contiguous(), hyp, rows)   # S - I and the column m / (2 vbar), 2 vbar = 1 / (noise rows)
-        return dict(packX=packX, Kzx=Kzx, S32e=S32e)
+        # fp64 copy: the left operand of tril(L^T L-bar) = -2 vbar tril([S - I | m / (2 vbar)][G ; b^T]) (see _elbo_fast)
+        S64e = self._get("S64e", (Mp, (Mp + 2) // 2 * 2), f64)[:, :Mp + 1]
+        _ops.widen_f32_f64(ctx, S32e, S64e)
+        return dict(packX=packX, Kzx=Kzx, S32e=S32e, S64e=S64e)
 
     def _elbo_fast(self, ctx, params, hyp, packZ, L, dims, x, y, D, rows, num_data, include_kl, scal, kl_buf, dm,
                    dLS, Kb32, Lbar, pro):
@@ -1294,6 +1305,9 @@ class ElboEngine:
              K_ZX-bar    = L^-T (m mu_bar^T + 2 vbar (S - I) A) = 2 vbar [Q' | a/(2 vbar)] [A ; mu_bar^T]
              L-bar       = -tril(K_ZX-bar A^T)                  = -2 vbar tril([Q' | a/(2 vbar)] [G ; b^T])
            with Q' = L^-T (S - I), a = L^-T m (fp64 solves on M' x M' data), b = A mu_bar.
+           L-bar itself is never formed (round 4): the Cholesky backward reads only tril(L^T L-bar), where the tril() of L-bar
+           does not matter (row i of the upper-triangular L^T meets rows k >= i of L-bar), and L^T Q' = S - I, L^T a = m:
+             tril(L^T L-bar) = -2 vbar tril([S - I | m/(2 vbar)] [G ; b^T])       (one product, fp64 accumulation)
            Three of the six [M', B'] products of the general path (W, U, the fp64 backward solve and the fp64
            L-bar contraction) are replaced by one fp32 Gram product and one fp32 dense product."""
         M, d, p, Mp = dims
@@ -1303,7 +1317,7 @@ class ElboEngine:
         dev = self.device
         m = params["variational_mean"]
         LS = params["chol_variational_covar"]
-        packX, Kzx, S32e = pro["packX"], pro["Kzx"], pro["S32e"]
+        packX, Kzx, S32e, S64e = pro["packX"], pro["Kzx"], pro["S32e"], pro["S64e"]
         for t in packX:
             t.record_stream(torch.cuda.current_stream(dev))
         if not self._no_middle and self.whitening == "cholesky":
@@ -1413,18 +1427,6 @@ class ElboEngine:
             if c1 > c0:
                 q64 = self._get("Qcols64", (Mp, w), f64)
                 _ops.trsm(ctx, L, S32e[:, c0:c1], True, q64[:, :c1 - c0], loc[:, :c1 - c0], self.trsm_nb, ws, reuse_inverse=True)
-            # this rank's ROWS [r0, r1) of [Q' | a] in fp64: the left operand of its rows of L-bar, so that L-bar is formed with the
-            # arithmetic of the one-GPU step (fp64 [Q' | a] x fp32 [G ; b^T], fp64 accumulation) instead of an fp32 product of the
-            # gathered fp32 copy.  L^-T[r0:r1, :] is zero left of column r0
-            wr = (Mp + Gw - 1) // Gw
-            r0 = min(coll.rank * wr, Mp)
-            r1 = min(r0 + wr, Mp)
-            self._qrows64 = None
-            if r1 > r0:
-                Linv = ws[:Mp * Mp * 8].view(f64).view(Mp, Mp)
-                qr = self._get("Qrows64", (wr, (Mp + 2) // 2 * 2), f64)[:r1 - r0, :Mp + 1]
-                _ops.gemm(ctx, TRANS_A | A_UPPER, Linv[r0:, r0:r1], S32e[r0:], qr)
-                self._qrows64 = qr
             allq = self._get("Qall32", (Gw, Mp, w), f32)
             return coll.all_gather_async(allq, loc), allq, w
 
@@ -1442,9 +1444,9 @@ class ElboEngine:
             return Qe32
 
         def lbar_sharded(Qe32):
-            """rank g: rows [r0, r1) of L-bar = -2 vbar [Q' | a][G ; b^T] (fp64 rows of [Q' | a] x fp32 [G ; b^T], fp64 accumulation:
-            the one-GPU arithmetic; only the lower triangle is read later), all-gathered as fp32; the Cholesky backward takes the
-            fp32 L-bar as the float operand of its first fp64 product"""
+            """rank g: rows [r0, r1) of tril(L^T L-bar) = -2 vbar tril([S - I | m/(2 vbar)][G ; b^T]) (fp64 copy of the left operand x
+            fp32 [G ; b^T], fp64 accumulation: the one-GPU arithmetic), all-gathered as fp32: the argument of Phi in the
+            Cholesky backward"""
             Gw = coll.world
             wr = (Mp + Gw - 1) // Gw
             r0 = min(coll.rank * wr, Mp)
@@ -1452,8 +1454,8 @@ class ElboEngine:
             loc = self._get_zeroed("Lrows32", (wr, Mp), f32)
             if r1 > r0:
                 l64 = self._get("Lrows64", (wr, Mp), f64)
-                # (only the lower triangle of L-bar is read: columns [0, r1); the rest of the zero-initialised block stays zero)
-                _ops.gemm(ctx, 0, self._qrows64, Ge[:, :r1], l64[:r1 - r0, :r1], alpha=-vbar2, C32=loc[:r1 - r0, :r1])
+                # (only the lower triangle is read: columns [0, r1); the rest of the zero-initialised block stays zero)
+                _ops.gemm(ctx, 0, S64e[r0:r1], Ge[:, :r1], l64[:r1 - r0, :r1], alpha=-vbar2, C32=loc[:r1 - r0, :r1])
             allr = self._get("Lall32", (Gw * wr, Mp), f32)
             h = coll.all_gather_async(allr, loc)
             h.wait()
@@ -1532,7 +1534,7 @@ class ElboEngine:
             self._event_done("early_reduce_wait", ev_w)
             _ops.mirror_lower_f32_(ctx, G, Mp)
             variational_part()
-        _ops.gemm(ctx, OUT_LOWER, Qe64, Ge, Lbar, alpha=-vbar2)                 # L-bar (fp64)
+        _ops.gemm(ctx, OUT_LOWER, S64e, Ge, Lbar, alpha=-vbar2)                 # tril(L^T L-bar) (fp64), see the docstring
         if var_done is not None:
             torch.cuda.current_stream(dev).wait_event(var_done)
         return packX, mu

@@ -57,6 +57,13 @@ extern "C" int dsvgp_potrf(dsvgp_ctx* ctx, double* A, int n, int64_t lda, int* i
     return st == rocblas_status_success ? 0 : 2000 + (int)st;
 }
 
+extern "C" int dsvgp_widen_f32_f64(dsvgp_ctx* ctx, const float* src, int64_t ld, double* dst, int64_t ldd, int M, int N) {
+    if (!ctx || !src || !dst || M <= 0 || N <= 0 || ld < N || ldd < N) return DSVGP_EINVAL;
+    launch_widen_f32_f64(ctx->stream, src, ld, dst, ldd, M, N);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N, int K, double alpha, const void* A,
                           int64_t lda, const void* B, int64_t ldb, double beta, const void* Cin, int64_t ldcin, void* C,
                           int64_t ldc, float* C32, int64_t ldc32, const float* kscale) {

@@ -63,6 +63,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
 // own for padded rows (the runtime's pitched 2-D memset runs below 1 TB/s) -- gemm.hip
 hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t st);
 void launch_cvt_f64_f32(hipStream_t st, const double* C, int64_t ldc, float* C32, int64_t ldc32, int M, int N);   // gemm64.hip
+void launch_widen_f32_f64(hipStream_t st, const float* src, int64_t ld, double* dst, int64_t ldd, int M, int N);      // gemm64.hip
 int launch_gemm64(hipStream_t st, const GemmArgs& g);     // gemm64.hip: 1 = taken, 0 = not eligible, > 1 = error
 int launch_gemm32(hipStream_t st, const GemmArgs& g);     // gemm32.hip (fp32, 32x32x2 MFMA): same convention
 

@@ -436,7 +436,26 @@ __global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double* __restri
     }
 }
 
+// dst (double) = src (float), row by row (two columns per thread)
+__global__ __launch_bounds__(256) void widen_f32_f64_kernel(const float* __restrict__ src, int64_t lds_, double* __restrict__ dst,
+                                                            int64_t ldd, int M, int N) {
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (c0 >= N) return;
+    for (int r = blockIdx.y; r < M; r += gridDim.y) {
+        const float* s = src + (int64_t)r * lds_ + c0;
+        double* d = dst + (int64_t)r * ldd + c0;
+        d[0] = (double)s[0];
+        if (c0 + 1 < N) d[1] = (double)s[1];
+    }
+}
+
 }  // namespace
+
+// dst = (double) src for an M x N block
+void launch_widen_f32_f64(hipStream_t st, const float* src, int64_t ld, double* dst, int64_t ldd, int M, int N) {
+    const dim3 grid(cdiv(N, 512), M < 2048 ? M : 2048);
+    hipLaunchKernelGGL(widen_f32_f64_kernel, grid, dim3(256), 0, st, src, ld, dst, ldd, M, N);
+}
 
 // C32 = (float) C: the fp32 copy of a split-K result that was accumulated in fp64
 void launch_cvt_f64_f32(hipStream_t st, const double* C, int64_t ldc, float* C32, int64_t ldc32, int M, int N) {

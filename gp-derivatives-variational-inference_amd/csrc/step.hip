@@ -43,14 +43,14 @@ struct dsvgp_step_plan {
     int M, d, p, B, Mp, Bp, DP, nb;
     int world = 1;                    // > 1: a data-parallel rank's plan (dsvgp_elbo_step_dp_f32); sizes the buffers below
     int wq = 0, wr = 0;               // column block of [Q' | a] / row block of L-bar per rank
-    size_t o_Qfull = 0, o_Qrows64 = 0, o_qcol64 = 0, o_cbT = 0, o_cbK = 0, o_slab = 0, slab_bytes = 0, o_lrow64 = 0;
+    size_t o_Qfull = 0, o_qcol64 = 0, o_cbT = 0, o_cbK = 0, o_slab = 0, slab_bytes = 0, o_lrow64 = 0;
     hipEvent_t ev_dp = nullptr;
     size_t bytes;
     // workspace offsets (bytes)
     size_t o_zero, zero_bytes;        // region cleared at the start of every step: info, sums, kl_buf
     size_t o_info, o_sums, o_klbuf, o_scal, o_hyp, o_center;
     size_t o_PZ, o_sZ, o_vZ, o_PX, o_sX, o_vX;
-    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_Qe32, o_Kb32, o_Lbar, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2;
+    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_S64e, o_Qe32, o_Kb32, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2;
     size_t o_arena, arena_bytes;     // contiguous region of everything a launcher would clear (see step_layout)
     int ldS, ldQ32;
     const void* pad_ready_for = nullptr;          // the workspace whose Qe32 pad columns have been zeroed
@@ -82,6 +82,7 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     pl->o_Kzx = c.take((size_t)Mp * Bp * 4); pl->o_A32e = c.take((size_t)(Mp + 1) * Bp * 4);
     pl->o_var0 = c.take((size_t)Bp * 4); pl->o_stats = c.take(dsvgp_stats_workspace_bytes(Mp, Bp) + 16);
     pl->o_Qe32 = c.take((size_t)Mp * pl->ldQ32 * 4);
+    pl->o_S64e = c.take((size_t)Mp * ((Mp + 2) / 2 * 2) * 8);      // fp64 copy of [S - I | m / (2 vbar)] (rewritten every step)
     const size_t kb = dsvgp_kernel_bwd_workspace_bytes(M, B, d, p), kz = dsvgp_kernel_bwd_workspace_bytes(M, M, d, p);
     pl->o_kbwd = c.take(kb > kz ? kb : kz); pl->o_kbwd2 = c.take(kb);
     // ---- the "arena": every buffer that some launcher clears before use (split-K targets, OUT_LOWER outputs), contiguous, so that
@@ -95,7 +96,7 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     // the trtri scratch `tmp`, which the fused factorisation + inverse never uses: one aligned fill kernel)
     pl->o_S32e = c.take((size_t)Mp * pl->ldS * 4);
     pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 2) * 8 + 64);
-    pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_Lbar = c.take((size_t)Mp * Mp * 8); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
+    pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
     pl->o_Yt = c.take((size_t)Mp * Mp * 8); pl->o_Kbar = c.take((size_t)Mp * Mp * 8);
     // head: hyp[4] | info[4 ints] | sums[4] | kl_buf[2 M' + 1]   (cleared every step; hyp + info go to the host in ONE copy).
     // It closes the arena, so that the small-problem mode clears both with one memset.
@@ -109,9 +110,8 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     pl->world = world;
     if (world > 1) {
         // data-parallel rank (global-Gram schedule with the replicated M'^3 stage sharded): its columns of
-        // [Q' | a] (fp64 result of the column solve, fp32 copy in the caller's all-gather operand), its ROWS of [Q' | a] in fp64
-        // (left operand of its rows of L-bar), the gathered [Q' | a] in row-major form, the column block of the Cholesky
-        // backward, one fp64 row block of L-bar, and the slab of the fixed-order G L_S product (the replicas' L_S-bar must agree
+        // [Q' | a] (fp64 result of the column solve, fp32 copy in the caller's all-gather operand), the gathered [Q' | a] in
+        // row-major form, the column block of the Cholesky backward, one fp64 row block of tril(L^T L-bar), and the slab of the fixed-order G L_S product (the replicas' L_S-bar must agree
         // bit for bit: nobody reduces it again)
         const int q1 = p + 1;
         pl->wq = ((Mp + 1 + world - 1) / world + 3) / 4 * 4;
@@ -119,7 +119,6 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
         const int wc = ((M + world - 1) / world) * q1;              // widest column block of K_ZZ-bar
         const int ldQ64 = (Mp + 2) / 2 * 2;
         pl->o_Qfull = c.take((size_t)Mp * world * pl->wq * 4);
-        pl->o_Qrows64 = c.take((size_t)pl->wr * ldQ64 * 8);
         pl->o_qcol64 = c.take((size_t)Mp * pl->wq * 8);
         pl->o_lrow64 = c.take((size_t)pl->wr * Mp * 8);
         pl->o_cbT = c.take((size_t)Mp * wc * 8);
@@ -283,9 +282,9 @@ static int step_validate(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_s
     void* stats_ws = w + pl->o_stats; \
     float* Ge = (float*)(w + pl->o_Ge); \
     double* Qe64 = (double*)(w + pl->o_Qe64); \
+    double* S64e = (double*)(w + pl->o_S64e); \
     float* Qe32 = (float*)(w + pl->o_Qe32); \
     float* Kb32 = (float*)(w + pl->o_Kb32); \
-    double* Lbar = (double*)(w + pl->o_Lbar); \
     double* G1 = (double*)(w + pl->o_G1); \
     double* Yt = (double*)(w + pl->o_Yt); \
     double* Kbar = (double*)(w + pl->o_Kbar); \
@@ -338,7 +337,11 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
                         (background ? DSVGP_GEMM_BACKGROUND : 0), Mp, Mp, Mp, 1.0, io->LS, io->ldls, io->LS, io->ldls, 0.0, nullptr, 0,
                         S32e, ldS, nullptr, 0, nullptr);
         if (rc) return rc;
-        return launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows);     // mirror + [S - I | m / (2 vbar)]
+        rc = launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows);     // mirror + [S - I | m / (2 vbar)]
+        if (rc) return rc;
+        // its fp64 copy: the left operand of the Cholesky backward's first product, see chol_tail below
+        launch_widen_f32_f64(ctx->stream, S32e, ldS, S64e, ldQ64, Mp, Mp + 1);
+        return hipGetLastError() == hipSuccess ? 0 : 1000 + (int)hipGetLastError();
     };
     if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork, main));
@@ -396,21 +399,26 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     };
     // ---- [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64), K_ZX-bar = [Q' | a] [A ; mu_bar^T] (fp32, unscaled)
     auto solve_q = [&]() -> int {
-        return dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, Qe64, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
+        // (only the fp32 copy of [Q' | a] is read afterwards.  A large solve writes it directly; a small one -- fewer than 1024
+        //  output tiles -- splits K onto an fp64 target: its own, Qe64, not the scratch the forward solve has used already)
+        const bool small = (int64_t)((Mp + 63) / 64) * ((Mp + 1 + 63) / 64) < 1024;
+        return dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, small ? Qe64 : nullptr, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
     };
     auto dense = [&]() -> int {
         return dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qe32, ldQ32, A32e, Bp, 0.0, nullptr, 0, Kb32, Bp, nullptr, 0,
                           nullptr);
     };
-    // ---- L-bar = -tril([Q' | a] [G ; b^T]) (fp64); Cholesky backward: K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 through
-    // the explicit inverse, lower halves + mirrors (DGVS.py:72-75 differentiated).  Needs [Q' | a] and [G ; b^T] only.
+    // ---- Cholesky backward (DGVS.py:72-75 differentiated): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 through the explicit
+    // inverse, lower halves + mirrors.  Phi reads the lower triangle of L^T L-bar only, and there the tril() in
+    // L-bar = -tril(K_ZX-bar A^T) = -tril([Q' | a][G ; b^T]) does not matter (row i of the upper-triangular L^T meets rows k >= i of
+    // L-bar, column j <= i: entries on or below the diagonal), so with L^T Q' = S - I and L^T a = m / (2 vbar)
+    //     tril(L^T L-bar) = -tril([S - I | m / (2 vbar)] [G ; b^T])
+    // -- ONE product of two matrices the step already holds (fp64 accumulation, fp64 copy of the left operand from the prologue)
+    // instead of L-bar (M'^3) followed by L^T L-bar (M'^3 / 3); neither L-bar nor the fp64 [Q' | a] is formed.  (Round 4.)
     const double* Linv = (const double*)trsm_ws;
     auto chol_tail = [&]() -> int {
-        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, Qe64, ldQ64, Ge, Mp, 0.0, nullptr, 0,
-                            Lbar, Mp, nullptr, 0, nullptr);
-        if (rc) return rc;
-        rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, L, Mp,
-                        Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
+        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldQ64, Ge, Mp, 0.0, nullptr, 0,
+                            G1, Mp, nullptr, 0, nullptr);
         if (rc) return rc;
         rc = dsvgp_phi_symmetrize(ctx, G1, Mp, Mp);
         if (rc) return rc;
@@ -483,15 +491,15 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
 // through ~120 ctypes calls:
 //   phase 0  everything up to the Gram product of this rank's rows; [tril(G) | b] packed into dp->wire
 //            -> caller: all-reduce(sum) of dp->wire                                                   (18 MB at M' = 3000)
-//   phase 1  this rank's COLUMNS of [Q' | a] = L^-T [S - I | m / (2 vbar)] (fp64 product, fp32 copy in dp->q_local) and its
-//            ROWS of it in fp64 (left operand of its rows of L-bar)                                   (needs L^-1 and S only)
+//   phase 1  this rank's COLUMNS of [Q' | a] = L^-T [S - I | m / (2 vbar)] (fp64 product, fp32 copy in dp->q_local)
+//                                                                                                     (needs L^-1 and S only)
 //            -> caller: all-gather dp->q_local -> dp->q_all                                            (36 MB)
 //   phase 2  (after the all-reduce) G global: mirror; L_S-bar, m-bar, KL, trace terms on the side stream (identical on every rank:
-//            the G L_S product adds its K slices in a fixed order); this rank's rows of L-bar = -[Q' | a][G ; b^T] in fp64
-//            (the arithmetic of the one-GPU step), fp32 copy in dp->lbar_local
+//            the G L_S product adds its K slices in a fixed order); this rank's rows of tril(L^T L-bar) =
+//            -tril([S - I | m / (2 vbar)][G ; b^T]) (fp64 accumulation: the arithmetic of the one-GPU step), fp32 copy in dp->lbar_local
 //            -> caller: all-gather dp->lbar_local -> dp->lbar_all                                      (36 MB)
 //   phase 3  (after the first all-gather) [Q' | a] row-major; dense K_ZX-bar of this rank's rows; its kernel backward
-//   phase 4  (after the second all-gather) this rank's column block of K_ZZ-bar = 1/2 L^-T Phi(L^T L-bar) L^-1 and its kernel
+//   phase 4  (after the second all-gather) Phi of the gathered matrix; this rank's column block of K_ZZ-bar = 1/2 L^-T Phi(.) L^-1 and its kernel
 //            backward (row-side gradient doubled by symmetry), scaling by 2 vbar, scalar tail
 //            -> caller: all-reduce(sum) of [Z-bar, V-bar, hyper-parameter gradients, loss]              (0.24 MB)
 // flags as dsvgp_elbo_step_f32 (bit 1: this is the rank that counts the KL value and the trace terms of the global G).
@@ -520,7 +528,6 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
     const bool include_kl = flags & 2, timed = pl->timed;
     const hipStream_t main = ctx->stream, side = pl->side;
     float* Qfull = (float*)(w + pl->o_Qfull);
-    double* Qrows64 = (double*)(w + pl->o_Qrows64);
     double* qcol64 = (double*)(w + pl->o_qcol64);
     double* lrow64 = (double*)(w + pl->o_lrow64);
     double* cbT = (double*)(w + pl->o_cbT);
@@ -545,10 +552,6 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
         const int c0 = rank * wq < Mp + 1 ? rank * wq : Mp + 1, c1 = c0 + wq < Mp + 1 ? c0 + wq : Mp + 1;
         if (c1 > c0)
             STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e + c0, ldS, 0, c1 - c0, qcol64, wq, dp->q_local, wq, nb, trsm_ws, 1));
-        if (nrow > 0)     // rows [r0, r1) of L^-T [S - I | m / (2 vbar)]: L^-T[r0:r1, :] is zero left of column r0
-            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_IS_FLOAT, nrow, Mp + 1, Mp - r0, 1.0,
-                                 Linv + (size_t)r0 * Mp + r0, Mp, S32e + (size_t)r0 * ldS, ldS, 0.0, nullptr, 0, Qrows64, ldQ64, nullptr, 0,
-                                 nullptr));
         return 0;
     }
     if (phase == 2) {
@@ -576,11 +579,10 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
         } else {
             STEP_CALL(variational());
         }
-        if (nrow > 0)     // rows [r0, r1) of L-bar = -[Q' | a][G ; b^T] (unscaled like every product of the step), fp64 + fp32 copy;
-            // only the lower triangle of L-bar is ever read: columns [0, r1) (the rest of dp->lbar_local stays zero) -- little work for
-            // the ranks whose rows of [Q' | a] were expensive (L^-T[r0:r1, :] starts at column r0) and vice versa
-            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_B_IS_FLOAT, nrow, r1, Mp + 1, -1.0, Qrows64, ldQ64, Ge, Mp, 0.0, nullptr, 0, lrow64, Mp,
-                                 dp->lbar_local, Mp, nullptr));
+        if (nrow > 0)     // rows [r0, r1) of tril(L^T L-bar) = -tril([S - I | m / (2 vbar)][G ; b^T]) (see chol_tail of the one-GPU step),
+            // columns [0, r1): fp64 accumulation, fp32 copy for the all-gather (the rest of dp->lbar_local stays zero)
+            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_B_IS_FLOAT, nrow, r1, Mp + 1, -1.0, S64e + (size_t)r0 * ldQ64, ldQ64, Ge, Mp, 0.0, nullptr,
+                                 0, lrow64, Mp, dp->lbar_local, Mp, nullptr));
         return 0;
     }
     if (phase == 3) {
@@ -601,8 +603,8 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
     const int base = M / world, rem = M % world;
     const int m0 = rank * base + (rank < rem ? rank : rem), m1 = m0 + base + (rank < rem ? 1 : 0);
     const int c0 = m0 * q1, wcol = (m1 - m0) * q1;
-    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT,
-                         Mp, Mp, Mp, 1.0, L, Mp, dp->lbar_all, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));       // tril(L^T L-bar)
+    launch_widen_f32_f64(main, dp->lbar_all, Mp, G1, Mp, Mp, Mp);                                                       // tril(L^T L-bar), gathered
+    STEP_HIP(hipGetLastError());
     STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));                                                                   // S = Phi(.) + Phi(.)^T
     if (wcol > 0) {
         // S L^-1[:, c0 : c0 + wcol]: rows < c0 of that column block of the lower-triangular inverse are zero, the rest is lower

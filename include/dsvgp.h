@@ -191,6 +191,9 @@ enum {
     DSVGP_GEMM_BACKGROUND = 1024 /* filler product overlapped with a latency-bound chain on another stream: launched with one
                                     workgroup per CU, so that every CU keeps LDS room for a workgroup of the chain */
 };
+/* dst[M, N] (double) = src[M, N] (float): the fp64 copy of [S - I | m / (2 vbar)] that the Cholesky backward multiplies with
+ * [G ; b^T] under fp64 accumulation ("Phi(L^T L-bar) without L-bar")                              */
+int dsvgp_widen_f32_f64(dsvgp_ctx* ctx, const float* src, int64_t ld, double* dst, int64_t ldd, int M, int N);
 int dsvgp_gemm(dsvgp_ctx* ctx, int is_double, int flags, int M, int N, int K, double alpha,
                const void* A, int64_t lda, const void* B, int64_t ldb, double beta, const void* Cin,
                int64_t ldcin, void* C, int64_t ldc, float* C32, int64_t ldc32, const float* kscale);
