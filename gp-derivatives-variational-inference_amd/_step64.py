@@ -401,7 +401,7 @@ class ElboEngine64(ElboEngine):
         self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, scal[2], d_con)
         return loss, grads, mu, varn
 
-    def _kernel_part64(self, ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, dc, d_raw):
+    def _kernel_part64(self, ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, dc, d_raw, phi_arg=False):
         """K_ZX-bar and L-bar -> inducing points / directions and the kernel hyper-parameters (both formulations)"""
         M, d, p, Mp = dims
         dev = self.device
@@ -416,7 +416,7 @@ class ElboEngine64(ElboEngine):
             Kb = full
         scratch = self._get("T_zx", (Mp, B * (p + 1)), f64)
         _ops.kernel_bwd_f64(ctx, Kb, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, scratch)
-        Kzzbar = self._chol_backward(ctx, L, Lbar, ws, Mp)
+        Kzzbar = self._chol_backward(ctx, L, Lbar, ws, Mp, phi_arg=phi_arg)
         scratch = self._get("T_zz", (Mp, Mp), f64)
         _ops.kernel_bwd_f64(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, scratch)
         # softplus chain rule of the kernel hyper-parameters; autograd already holds the likelihood / prior-diagonal parts
@@ -511,12 +511,15 @@ class ElboEngine64(ElboEngine):
             _ops.gemm(ctx, TRANS_A | B_LOWER, Se, Linv, QeT)
             QeT[:Mp].mul_(2.0 * vbar)
             _ops.gemm(ctx, TRANS_A, QeT, Ae, Kb)                                          # K_ZX-bar (the one dense [M', B'] product)
-            _ops.gemm(ctx, TRANS_A | OUT_LOWER, QeT, Ge, Lbar, alpha=-1.0)                # L-bar = -tril([2 vbar Q' | a] [G ; b^T])
         else:
             Qe = self._get("Qe64", (Mp, Mp + 1), f64)
             _ops.trsm(ctx, L, Se, True, Qe, None, self.trsm_nb, ws, reuse_inverse=True)
             Qe[:, :Mp].mul_(2.0 * vbar)
             _ops.gemm(ctx, 0, Qe, Ae, Kb)
-            _ops.gemm(ctx, OUT_LOWER, Qe, Ge, Lbar, alpha=-1.0)
-        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, g[2], g[3:6])
+        # L-bar = -tril([2 vbar Q' | a][G ; b^T]) is not formed: the Cholesky backward reads only tril(L^T L-bar), where the tril() of
+        # L-bar does not matter, and L^T Q' = S - I, L^T a = m (see ElboEngine._elbo_fast):
+        #     tril(L^T L-bar) = -tril([2 vbar (S - I) | m][G ; b^T])            -- one product instead of two
+        Se[:, :Mp].mul_(2.0 * vbar)
+        _ops.gemm(ctx, OUT_LOWER, Se, Ge, Lbar, alpha=-1.0)
+        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, g[2], g[3:6], phi_arg=True)
         return loss.detach(), grads, mu.detach(), torch.empty(0, dtype=f64, device=dev)
