@@ -145,6 +145,9 @@ def main():
                     help="HIP-graph replay of the step (one rank, ELBO fast path); measured no faster than eager at C2, see DESIGN.md")
     ap.add_argument("--dp-algo", default=os.environ.get("DSVGP_DP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
                     help="(N > 1) collective of the large operand: RCCL all-reduce, or reduce-scatter + all-gather")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="OPT-IN: the Gram product and the dense K_ZX-bar product as bf16 x 3 split products on the bf16 matrix pipe "
+                         "(six bf16 MFMA products per fp32 product, fp32 accumulation; csrc/gemm3b.hip) instead of fp32 MFMA")
     ap.add_argument("--no-other-configs", action="store_true", help="c4 on one GPU: skip the C2 / C3 / C5 / float64 windows")
     ap.add_argument("--no-extras", action="store_true",
                     help="c4 on one GPU: skip the repeated windows, the reporting-step timing and the other BASELINE configurations")
@@ -214,6 +217,8 @@ def main():
         if os.environ.get("DSVGP_OVERLAP") == "1":
             eng.overlap = True         # diagnostics: the side stream also below M' = 2048
         eng.fused_inverse = not args.no_fused_inverse
+        if args.split_bf16:
+            eng.split_bf16 = True
         eng.lib_dense_gemm = bool(args.lib_gemm)
         eng.global_gram = not args.no_global_gram
         eng.pack_reduce = not args.no_pack_reduce
@@ -325,6 +330,20 @@ def main():
             ws_.append(e_r)
         ws_ = sorted(1e3 * w / args.steps for w in ws_)
         repeat_ms = [ws_[0], ws_[1], ws_[2]]
+    # ---- second figure (opt-in mode, never the headline): the same window with the two big fp32 products as bf16 x 3 split products
+    split_fig = None
+    if extras and hasattr(eng, "split_bf16") and not eng.split_bf16:
+        eng.split_bf16 = True
+        for k in range(3):
+            loop.step(batch(args.warmup + 3 * args.steps + 20 + k))
+        e_s, loss_s = window(loop, batch, args.warmup + 3 * args.steps + 23, args.steps)
+        eng.split_bf16 = False
+        split_fig = dict(ms_per_step=1e3 * e_s / args.steps, steps=args.steps, final_loss=float(loss_s.item()),
+                         dtype="f32 model; the Gram product and the dense K_ZX-bar product as six bf16 MFMA products per fp32 product "
+                               "(operands split into three bf16 planes, fp32 accumulation, v_mfma_f32_32x32x16_bf16); f64 Cholesky/solves",
+                         note="opt-in (`--split-bf16` / DSVGP_SPLIT_BF16=1); passes every reference-text case at the fp32 path's "
+                              "tolerances, worst error per configuration equal to the fp32 path's, individual scalar gradients up to "
+                              "3-27x further out (<= 1e-5): tests/test_gpu_reftext.py::test_split_bf16_step_*")
     # ---- the reference's every-50th-step report (directional_vi.py:255-260: loss.item(), nll of the function values from
     # output.mean / output.variance of that forward pass): one reporting step costs a host synchronisation (the step pipeline
     # drains) plus the value-row variances; measured over 5 reporting steps in a row, 1/50 of the extra goes into ms_per_step
@@ -518,7 +537,7 @@ def main():
             "metric": "ELBO steps/sec, DSVGP d=20 N=1M M=500 p=5" if args.config == "c4" else "ELBO steps/sec, " + cfg["name"],
             "value": 1e3 / ms_step, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.fp64 else "f32 (f64 Cholesky/solves)",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.fp64 else ("f32 via bf16 x 3 split products (f64 Cholesky/solves)" if args.split_bf16 else "f32 (f64 Cholesky/solves)"),
             "data": "synthetic",
             "config": {"workload": cfg["name"], "global_batch": B, "per_gpu_batch": B // world, "M_prime": Mp,
                        "parallelism": "dp%d rows" % world, "trsm_nb": trsm_nb_, "final_loss": final_loss,
@@ -540,6 +559,7 @@ def main():
                        "repeat_ms": repeat_ms,
                        "repeat_note": "min / median / max ms per step of three windows of `steps` steps (the first one is the "
                                       "headline window)" if repeat_ms else None,
+                       "split_bf16_second_figure": split_fig,
                        "other_configs": other},
             "roofline": roof,
             "roofline_assembly": roof_asm,

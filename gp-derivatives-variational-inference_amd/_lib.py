@@ -35,7 +35,8 @@ class ElboStepIO(C.Structure):
                 ("flat", _p), ("flat_floats", _z),
                 ("dZ", _p), ("dV", _p), ("dm", _p), ("dLS", _p), ("lddls", _l),
                 ("d_hyp", _p), ("d_constant", _p), ("d_raw_lengthscale", _p), ("d_raw_outputscale", _p), ("d_raw_noise", _p),
-                ("loss", _p), ("mu", _p), ("num_data", _d), ("global_rows", _d), ("kzz_jitter", _f)]
+                ("loss", _p), ("mu", _p), ("num_data", _d), ("global_rows", _d), ("kzz_jitter", _f),
+                ("split_ws", _p), ("split_ws_bytes", _z)]
 
 
 class ElboStepDP(C.Structure):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "dsvgp_elbo_step_plan_destroy": (_i, [_p]),
     "dsvgp_elbo_step_plan_bytes": (_z, [_p]),
     "dsvgp_elbo_step_f32": (_i, [_p, _p, _p, _p, _z, _i]),
+    "dsvgp_elbo_step_split_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_elbo_step_dp_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "dsvgp_elbo_step_dp_plan_create": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p)]),
     "dsvgp_elbo_step_dp_f32": (_i, [_p, _p, _p, _p, _p, _z, _i, _i]),
@@ -97,6 +99,10 @@ SIGNATURES = {
     "dsvgp_trsm": (_i, [_p, _p, _l, _i, _i, _p, _l, _i, _i, _p, _l, _p, _l, _i, _p, _i]),
     "dsvgp_trtri": (_i, [_p, _p, _l, _i, _i, _p, _p]),
     "dsvgp_potrf_inverse": (_i, [_p, _p, _i, _l, _p, _p, _i, _p]),
+    "dsvgp_split3_kpad": (_i, [_i]),
+    "dsvgp_split3_bytes": (_z, [_i, _i]),
+    "dsvgp_split3_bf16": (_i, [_p, _p, _l, _i, _i, _i, _p]),
+    "dsvgp_gemm3b": (_i, [_p, _i, _i, _i, _i, _f, _p, _i, _p, _i, _p, _l]),
     "dsvgp_widen_f32_f64": (_i, [_p, _p, _l, _p, _l, _i, _i]),
     "dsvgp_gemm": (_i, [_p, _i, _i, _i, _i, _i, _d, _p, _l, _p, _l, _d, _p, _l, _p, _l, _p, _l, _p]),
     "dsvgp_stats_workspace_bytes": (_z, [_i, _i]),

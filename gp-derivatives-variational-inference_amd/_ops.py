@@ -418,6 +418,26 @@ def gemm(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0, Cin=None, C32=None, kscal
     return C_out
 
 
+def split3_bf16(ctx, src, transpose=False, out=None):
+    """three bf16 planes of the float32 matrix ``src`` [R, C] (or of its transpose): uint8 buffer holding 3 x rows_out x kpad(K) bf16"""
+    _req(src, f32, "src", 2)
+    R, Cc = src.shape
+    rows_out, K = (Cc, R) if transpose else (R, Cc)
+    nbytes = int(lib.dsvgp_split3_bytes(rows_out, K))
+    if out is None or out.numel() < nbytes:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+    check(lib.dsvgp_split3_bf16(ctx.h, _ptr(src), _ld(src), R, Cc, 1 if transpose else 0, _ptr(out)), "dsvgp_split3_bf16")
+    return out
+
+
+def gemm3b(ctx, flags, M, N, K, Aplanes, a_rows, Bplanes, b_rows, C, alpha=1.0):
+    """C[M, N] = alpha A B^T on the bf16 matrix pipe from plane triples (csrc/gemm3b.hip)"""
+    _req(C, f32, "C", 2)
+    check(lib.dsvgp_gemm3b(ctx.h, int(flags), int(M), int(N), int(K), float(alpha), _ptr(Aplanes), int(a_rows), _ptr(Bplanes), int(b_rows),
+                           _ptr(C), _ld(C)), "dsvgp_gemm3b")
+    return C
+
+
 def widen_f32_f64(ctx, src, dst):
     """dst (float64) = src (float32), both 2-D with unit inner stride"""
     M, N = src.shape

@@ -100,6 +100,10 @@ class ElboEngine:
         # C4 13.57-13.65 -> 13.65-13.66 ms, C3 7.79 -> 7.80-7.84, C2 0.60 -> 0.61: the dense product stretches from 3.63 to 5.23 ms
         # while the 1.6 ms tail runs beside it -- matrix-pipe time is conserved, nothing is recovered.  Off by default.
         self.tail_side = os.environ.get("DSVGP_TAIL_SIDE", "0") == "1"
+        # OPT-IN (flag 32 of the one-call step, `bench.py --split-bf16`): the Gram product and the dense K_ZX-bar product as bf16 x 3
+        # split products on the bf16 matrix pipe (six bf16 MFMA products per fp32 product, fp32 accumulation; csrc/gemm3b.hip).
+        # The default computes them on v_mfma_f32_32x32x2_f32.
+        self.split_bf16 = os.environ.get("DSVGP_SPLIT_BF16", "0") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -1069,6 +1073,11 @@ class ElboEngine:
             self._rec_count += 1
         flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if timed else 0) \
             | (16 if self.tail_side else 0)
+        io.split_ws, io.split_ws_bytes = None, 0
+        if self.split_bf16 and Mp >= 256 and Bp >= 256:
+            sws = self._bytes("cstep_split_ws", int(_lib.lib.dsvgp_elbo_step_split_bytes(M, d, p, B)))
+            io.split_ws, io.split_ws_bytes = sws.data_ptr(), sws.numel()
+            flags |= 32
         tr = self.host_trace                  # (tools/host_trace.py: where the host's time goes; None in production)
         if tr is not None:
             import time as _t

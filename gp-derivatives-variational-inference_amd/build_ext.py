@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libdsvgp_hip.so")
-SOURCES = ["gemm.hip", "gemm64.hip", "gemm32.hip", "assemble.hip", "assemble64.hip", "elbo.hip", "potrf.hip", "ciq.hip", "step.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm64.hip", "gemm32.hip", "gemm3b.hip", "assemble.hip", "assemble64.hip", "elbo.hip", "potrf.hip", "ciq.hip", "step.hip", "api.hip"]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 

@@ -130,6 +130,20 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     return pl->bytes;
 }
 
+// flag 32: bf16 plane triples of [A ; mu_bar^T] ((M'+1) x B'), of its transpose (B' x (M'+1)) and of [Q' | a] (M' x (M'+1))
+static size_t split_offsets(int Mp, int Bp, size_t* o_pat, size_t* o_pq) {
+    size_t off = (dsvgp_split3_bytes(Mp + 1, Bp) + 255) / 256 * 256;
+    if (o_pat) *o_pat = off;
+    off += (dsvgp_split3_bytes(Bp, Mp + 1) + 255) / 256 * 256;
+    if (o_pq) *o_pq = off;
+    off += (dsvgp_split3_bytes(Mp, Mp + 1) + 255) / 256 * 256;
+    return off;
+}
+extern "C" size_t dsvgp_elbo_step_split_bytes(int M, int d, int p, int B) {
+    if (M <= 0 || d <= 0 || p < 0 || B <= 0) return 0;
+    return split_offsets(M * (p + 1), B * (p + 1), nullptr, nullptr);
+}
+
 extern "C" size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B) {
     dsvgp_step_plan pl{};
     return step_layout(M, d, p, B, &pl);
@@ -366,6 +380,15 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     STEP_TIME(1);
     STEP_CALL(launch_stats_residual(ctx, A32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var0, stats_ws, io->y, rows, mu_bar, sums));
     // ---- [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), split-K over the minibatch axis; G mirrored
+    if (flags & 32) {
+        // opt-in: six bf16 products per fp32 product on the bf16 matrix pipe (gemm3b.hip); the planes of [A ; mu_bar^T] serve both operands
+        if (!io->split_ws || ((uintptr_t)io->split_ws & 255) || io->split_ws_bytes < split_offsets(Mp, Bp, nullptr, nullptr)) {
+            ctx->stream = main;
+            return DSVGP_EINVAL;
+        }
+        STEP_CALL(dsvgp_split3_bf16(ctx, A32e, Bp, Mp + 1, Bp, 0, io->split_ws));
+        STEP_CALL(dsvgp_gemm3b(ctx, DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.f, io->split_ws, Mp + 1, io->split_ws, Mp + 1, Ge, Mp));
+    } else
     STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
                          Mp, nullptr, 0, nullptr));
     return 0;
@@ -405,6 +428,16 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         return dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, small ? Qe64 : nullptr, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
     };
     auto dense = [&]() -> int {
+        if (flags & 32) {
+            size_t o_pat, o_pq;
+            split_offsets(Mp, Bp, &o_pat, &o_pq);
+            char* sw = (char*)io->split_ws;
+            int rc = dsvgp_split3_bf16(ctx, A32e, Bp, Mp + 1, Bp, 1, sw + o_pat);           // planes of [A ; mu_bar^T]^T: k-contiguous B operand
+            if (rc) return rc;
+            rc = dsvgp_split3_bf16(ctx, Qe32, ldQ32, Mp, Mp + 1, 0, sw + o_pq);
+            if (rc) return rc;
+            return dsvgp_gemm3b(ctx, 0, Mp, Bp, Mp + 1, 1.f, sw + o_pq, Mp, sw + o_pat, Bp, Kb32, Bp);
+        }
         return dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qe32, ldQ32, A32e, Bp, 0.0, nullptr, 0, Kb32, Bp, nullptr, 0,
                           nullptr);
     };
@@ -592,6 +625,14 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
             hipLaunchKernelGGL(gather_blocks_kernel, dim3(blocks), dim3(256), 0, main, dp->q_all, Qfull, Mp, wq, world);
             STEP_HIP(hipGetLastError());
         }
+        if (flags & 32) {
+            size_t o_pat, o_pq;
+            split_offsets(Mp, Bp, &o_pat, &o_pq);
+            char* sw = (char*)io->split_ws;
+            STEP_CALL(dsvgp_split3_bf16(ctx, A32e, Bp, Mp + 1, Bp, 1, sw + o_pat));
+            STEP_CALL(dsvgp_split3_bf16(ctx, Qfull, (int64_t)world * wq, Mp, Mp + 1, 0, sw + o_pq));
+            STEP_CALL(dsvgp_gemm3b(ctx, 0, Mp, Bp, Mp + 1, 1.f, sw + o_pq, Mp, sw + o_pat, Bp, Kb32, Bp));
+        } else
         STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qfull, (int64_t)world * wq, A32e, Bp, 0.0, nullptr, 0, Kb32,
                              Bp, nullptr, 0, nullptr));
         STEP_TIME(4);

@@ -310,6 +310,18 @@ int dsvgp_variational_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int
                             int flags, const float* hyp, double global_rows, const float* G, int64_t ldg,
                             float t1_scale, float* kl_out, float* sums, float* d_m, float* d_LS, int64_t lddls);
 
+/* ---- fp32-equivalent products on the bf16 matrix pipe (round 4, OPT-IN; the default step computes in fp32 MFMA).  An fp32 operand
+ * is cut once into three bf16 planes x = h + m + l (dsvgp_split3_bf16; remainder < 2^-26 |x|) and a product keeps the six terms
+ * down to 2^-16 of (h + m + l)(h' + m' + l') on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/gemm3b.hip).
+ *   planes of a [rows_out, K] operand: 3 x rows_out x dsvgp_split3_kpad(K) bf16, plane after plane (dsvgp_split3_bytes), 16-byte
+ *   aligned; transpose = 1 splits the TRANSPOSE of src[R, Cc] (rows_out = Cc, K = R): both operands of dsvgp_gemm3b are
+ *   k-contiguous.   dsvgp_gemm3b: C[M, N] = alpha A B^T, flags 0 or DSVGP_GEMM_OUT_LOWER (square tile grids).              */
+int dsvgp_split3_kpad(int K);
+size_t dsvgp_split3_bytes(int rows_out, int K);
+int dsvgp_split3_bf16(dsvgp_ctx* ctx, const float* src, int64_t ld, int R, int Cc, int transpose, void* planes);
+int dsvgp_gemm3b(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alpha, const void* Aplanes, int a_rows, const void* Bplanes,
+                 int b_rows, float* C, int64_t ldc);
+
 /* Plain dense fp32 GEMM through rocBLAS (row-major, flags: DSVGP_GEMM_TRANS_A / _TRANS_B only): for products without
  * structure or fused epilogue (the dense K_ZX-bar product of the ELBO fast path); everything else is dsvgp_gemm.      */
 int dsvgp_gemm_lib_f32(dsvgp_ctx* ctx, int flags, int M, int N, int K, float alpha, const float* A, int64_t lda,
@@ -365,7 +377,8 @@ int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, fl
  *   io         device pointers (below); io->flat[0 .. flat_floats) is cleared by the call and must contain every gradient slot
  *   flags      1: overlap on the plan's second stream; 2: include the KL term (data-parallel ranks > 0 leave it out); 4: record
  *              HIP-event timings (dsvgp_elbo_step_timings); 8: the workspace contents are undefined (re-clear the paddings);
- *              16 (with 1): L-bar and the Cholesky backward on the second stream under the dense K_ZX-bar product
+ *              16 (with 1): the Cholesky backward on the second stream under the dense K_ZX-bar product (probe: no gain);
+ *              32: the two big fp32 products as bf16 x 3 split products (io->split_ws; opt-in, see dsvgp_split3_bf16)
  * Gradients are those of loss = -(sum_j ll_j / global_rows - KL / num_data); a factorisation that fails leaves NaNs in the
  * outputs and a non-zero status word: read it with dsvgp_elbo_step_status (waits for the factorisation only, not for the step)
  * and run the jitter ladder on the piecewise path.  Threading: one host thread per context.                                  */
@@ -384,7 +397,12 @@ typedef struct dsvgp_elbo_step_io {
     float* mu;                       /* [B(p+1)] predictive mean of q(f) at the batch (constant mean included)                  */
     double num_data, global_rows;    /* VariationalELBO num_data ((d+1) N); B'(global) of the minibatch                          */
     float kzz_jitter;                /* LazyTensor.add_jitter() default 1e-3 (DGVS.py:144)                                      */
+    /* flag 32 (opt-in): scratch of dsvgp_elbo_step_split_bytes(M, d, p, B) bytes for the bf16 plane triples of [A ; mu_bar^T],
+     * its transpose and [Q' | a] -- the Gram product and the dense K_ZX-bar product then run on the bf16 matrix pipe as six
+     * bf16 products per fp32 product (csrc/gemm3b.hip); NULL / flag clear: v_mfma_f32_32x32x2_f32 (the default)                */
+    void* split_ws; size_t split_ws_bytes;
 } dsvgp_elbo_step_io;
+size_t dsvgp_elbo_step_split_bytes(int M, int d, int p, int B);
 size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B);
 int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out);
 int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* plan);
