@@ -566,8 +566,10 @@ def main():
         }
         if world > 1:
             out["rccl_ranks"] = dist.get_world_size()
-            t_w, n_w = avg("early_reduce_wait")
-            t_r, n_r = avg("final_reduce")
+            def avg_ms(name):
+                durs = durations.get(name, [])
+                return (sum(durs) / len(durs)) if durs else None
+            t_w, t_r = avg_ms("early_reduce_wait"), avg_ms("final_reduce")
             out["config"]["collective"] = dict(backend=dist.get_backend(), algo=args.dp_algo, packed_triangle=pack_,
                                                early_operand_floats=early_numel_,
                                                exposed_early_reduce_wait_ms=t_w * 1e3 if t_w else None,
