@@ -59,10 +59,18 @@ __global__ __launch_bounds__(512, 1) void gemm3b_kernel(const G3 g) {
     const int slice = u / g.ntiles, t = u - slice * g.ntiles;
     int tm, tn;
     if (g.flags & DSVGP_GEMM_OUT_LOWER) {
-        tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-        while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
-        while (tm * (tm + 1) / 2 > t) --tm;
-        tn = t - tm * (tm + 1) / 2;
+        // tiles with tn <= tm, row by row: the triangle while tm < tiles_n, full rows of tiles_n tiles below it (tiles_m > tiles_n:
+        // the extra row b^T of [G ; b^T] opening a tile row of its own when M' is a multiple of 256)
+        const int tri = min(g.tiles_m, g.tiles_n), t0 = tri * (tri + 1) / 2;
+        if (t < t0) {
+            tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+            while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+            while (tm * (tm + 1) / 2 > t) --tm;
+            tn = t - tm * (tm + 1) / 2;
+        } else {
+            tm = tri + (t - t0) / g.tiles_n;
+            tn = (t - t0) % g.tiles_n;
+        }
     } else {                                      // bands of 8 tile columns, row by row inside a band
         const int band = t / (8 * g.tiles_m), q = t - band * 8 * g.tiles_m;
         const int wcols = min(8, g.tiles_n - band * 8);
@@ -248,8 +256,8 @@ extern "C" int dsvgp_gemm3b(dsvgp_ctx* ctx, int flags, int M, int N, int K, floa
     a.tiles_m = cdiv(M, T3); a.tiles_n = cdiv(N, T3);
     const bool out_lower = flags & DSVGP_GEMM_OUT_LOWER;
     if (out_lower) {
-        if (a.tiles_m != a.tiles_n) return DSVGP_EINVAL;
-        a.ntiles = a.tiles_m * (a.tiles_m + 1) / 2;
+        const int tri = a.tiles_m < a.tiles_n ? a.tiles_m : a.tiles_n;
+        a.ntiles = tri * (tri + 1) / 2 + (a.tiles_m > tri ? (a.tiles_m - tri) * a.tiles_n : 0);
     } else {
         a.ntiles = a.tiles_m * a.tiles_n;
     }

@@ -315,7 +315,7 @@ int dsvgp_variational_terms(dsvgp_ctx* ctx, const float* m, const float* LS, int
  * down to 2^-16 of (h + m + l)(h' + m' + l') on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/gemm3b.hip).
  *   planes of a [rows_out, K] operand: 3 x rows_out x dsvgp_split3_kpad(K) bf16, plane after plane (dsvgp_split3_bytes), 16-byte
  *   aligned; transpose = 1 splits the TRANSPOSE of src[R, Cc] (rows_out = Cc, K = R): both operands of dsvgp_gemm3b are
- *   k-contiguous.   dsvgp_gemm3b: C[M, N] = alpha A B^T, flags 0 or DSVGP_GEMM_OUT_LOWER (square tile grids).              */
+ *   k-contiguous.   dsvgp_gemm3b: C[M, N] = alpha A B^T, flags 0 or DSVGP_GEMM_OUT_LOWER.              */
 int dsvgp_split3_kpad(int K);
 size_t dsvgp_split3_bytes(int rows_out, int K);
 int dsvgp_split3_bf16(dsvgp_ctx* ctx, const float* src, int64_t ld, int R, int Cc, int transpose, void* planes);

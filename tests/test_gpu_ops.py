@@ -691,3 +691,58 @@ def test_gemm_f64_wide_tile_kernel(dsvgp, gpu_device, tri, bfloat):
     ref = 0.75 * (A.t().to(gpu_device) @ Bd.double())
     assert relmax(C, ref) < 1e-13, (tri, bfloat, relmax(C, ref))
     assert relmax(C32, ref) < 2e-7
+
+
+# ------------------------------------------------------------------ round 4: bf16 x 3 split products (opt-in), widening copy
+@pytest.mark.parametrize("R,C,transpose", [(700, 1300, False), (257, 33, False), (1300, 700, True), (33, 257, True)])
+def test_split3_planes_reconstruct_the_operand(dsvgp, gpu_device, R, C, transpose):
+    """dsvgp_split3_bf16: x = h + m + l with three bf16 planes, remainder below 2^-24 |x| (the two subtractions are exact), planes
+    K-blocked ((k / 16) rows_out + row) 16 + k % 16, K padded with zeros to a multiple of 16; plain and transposing form"""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(R + C)
+    X = (torch.randn(R, C, generator=g) * torch.exp(3 * torch.randn(R, C, generator=g))).to(gpu_device)      # wide dynamic range
+    buf = ops.split3_bf16(ctx, X, transpose=transpose)
+    torch.cuda.synchronize()
+    rows_out, K = (C, R) if transpose else (R, C)
+    Kp = int(L.lib.dsvgp_split3_kpad(K))
+    assert Kp % 16 == 0 and Kp >= K and Kp - K < 16
+    planes = buf[:3 * rows_out * Kp * 2].view(torch.bfloat16).view(3, Kp // 16, rows_out, 16).float()
+    rec = planes.sum(0).permute(1, 0, 2).reshape(rows_out, Kp)                      # [rows_out, Kp]
+    ref = (X.t() if transpose else X)
+    err = ((rec[:, :K].double() - ref.double()).abs() / ref.double().abs().clamp_min(1e-30)).max().item()
+    assert err < 2.0 ** -24, err
+    assert rec[:, K:].abs().max().item() == 0.0 if Kp > K else True
+    # the first plane is the correctly rounded bf16 of the operand
+    assert torch.equal(planes[0].permute(1, 0, 2).reshape(rows_out, Kp)[:, :K], ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("M,N,K,lower", [(700, 1100, 1300, False), (300, 260, 4097, False), (1001, 1000, 6000, True), (513, 512, 700, True), (300, 600, 520, True)])
+def test_gemm3b_is_an_fp32_grade_product(dsvgp, gpu_device, M, N, K, lower):
+    """csrc/gemm3b.hip: C = alpha A B^T from bf16 plane triples (six bf16 MFMA products per fp32 product, fp32 accumulation) against a
+    float64 product of the same float32 operands: error of the largest entry <= 4e-6 (the fp32 MFMA kernel: 3e-5 bound, ~2e-6
+    measured), ragged edges, K padding, lower-triangular output with split K"""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(gpu_device)
+    B = torch.randn(N, K, generator=g).to(gpu_device)
+    pa, pb = ops.split3_bf16(ctx, A), ops.split3_bf16(ctx, B)
+    C = torch.full((M, N), 5.0, device=gpu_device)
+    ops.gemm3b(ctx, L.OUT_LOWER if lower else 0, M, N, K, pa, M, pb, N, C, alpha=0.75)
+    ref = 0.75 * A.double() @ B.double().t()
+    if lower:
+        ref = ref.tril()
+        assert C.triu(1).abs().max().item() == 0.0
+    err = relmax(C, ref)
+    print("gemm3b M=%d N=%d K=%d lower=%d: rel. error %.2e" % (M, N, K, lower, err))
+    assert err < 4e-6
+
+
+def test_widen_f32_f64(dsvgp, gpu_device):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    X = torch.randn(301, 303, device=gpu_device)
+    out = torch.full((301, 304), 7.0, dtype=torch.float64, device=gpu_device)
+    ops.widen_f32_f64(ctx, X, out[:, :303])
+    assert torch.equal(out[:, :303], X.double()) and (out[:, 303] == 7.0).all()
