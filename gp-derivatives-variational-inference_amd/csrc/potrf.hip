@@ -19,6 +19,9 @@ constexpr int NBC = 64;
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
 #endif
+#ifndef POTRF_FOLD
+#define POTRF_FOLD 0        // 1: both rank-1 updates of factor16_wave through w = a_ij / a_jj (10 instead of 16 fp64 operations per column).
+#endif                      // Measured (round 4): n = 3000 1.400 / 1.406 -> 1.396 / 1.414 ms, n = 600 0.250 -> 0.252: the column is latency-, not issue-bound
 // Update / inverse tiles of one tile row are dealt to workgroups in STRIPS of up to `strip` block columns: T = A_ik W_k is formed
 // once per strip (1 + strip products for strip tiles instead of 2 per tile, A_ik and W_k loaded once).  The launcher picks the
 // strip length per launch from the tile count: long strips only where the launch is bound by its tiles, not by the diagonal
@@ -169,13 +172,25 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
         bad = (bad < 0 && !(d > 0.0)) ? j : bad;
         const double rinv = rsqrt_nr(d);
         const double li = ci * rinv;                                // L[i][j]  (0 above the diagonal, sqrt(a_jj) on it)
-        const double ls = (i == j) ? 0.0 : li;
         ri = (i == j) ? rinv : ri;
+#if POTRF_FOLD
+        // both rank-1 updates through w = L[i][j] / L[j][j] = a_ij / a_jj: ten fp64 operations per column instead of sixteen (the
+        // multiplier is folded once per lane instead of once per element)
+        const double w = li * rinv;
+        const double ws = (i == j) ? 0.0 : w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = fma(-w, cc[t], a[t]);
+            y[t] = fma(-ws, rr[t], y[t]);
+        }
+#else
+        const double ls = (i == j) ? 0.0 : li;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             a[t] = fma(-li, cc[t] * rinv, a[t]);
             y[t] = fma(-ls, rr[t] * rinv, y[t]);
         }
+#endif
         if (g == gj) a[tj] = li;
     }
     if (lane == 0 && bad >= 0 && o + bad < nvalid && *info == 0) *info = gidx0 + o + bad + 1;   // LAPACK convention
