@@ -1108,7 +1108,7 @@ class ElboEngine:
         (include/dsvgp.h; same schedule as the piecewise global-Gram path with the sharded replicated stage below)"""
         world, dev = coll.world, self.device
         wq = ((Mp + 1 + world - 1) // world + 3) // 4 * 4
-        wr = (Mp + world - 1) // world
+        wr = ((Mp + world - 1) // world + 1) // 2 * 2
         used = _ops.tril_packed_numel(Mp, Mp)
         total = (used + 2047) // 2048 * 2048                # (any world size <= 8 can reduce-scatter it)
         key = ("dp_bufs", Mp, world)

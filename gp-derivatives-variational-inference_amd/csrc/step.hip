@@ -82,7 +82,7 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     pl->o_Kzx = c.take((size_t)Mp * Bp * 4); pl->o_A32e = c.take((size_t)(Mp + 1) * Bp * 4);
     pl->o_var0 = c.take((size_t)Bp * 4); pl->o_stats = c.take(dsvgp_stats_workspace_bytes(Mp, Bp) + 16);
     pl->o_Qe32 = c.take((size_t)Mp * pl->ldQ32 * 4);
-    pl->o_S64e = c.take((size_t)Mp * ((Mp + 2) / 2 * 2) * 8);      // fp64 copy of [S - I | m / (2 vbar)] (rewritten every step)
+    pl->o_S64e = c.take((size_t)(Mp + 1) * ((Mp + 1) / 2 * 2) * 8);      // fp64 [S - I ; m^T / (2 vbar)], (M'+1) x M' (rewritten every step)
     const size_t kb = dsvgp_kernel_bwd_workspace_bytes(M, B, d, p), kz = dsvgp_kernel_bwd_workspace_bytes(M, M, d, p);
     pl->o_kbwd = c.take(kb > kz ? kb : kz); pl->o_kbwd2 = c.take(kb);
     // ---- the "arena": every buffer that some launcher clears before use (split-K targets, OUT_LOWER outputs), contiguous, so that
@@ -115,7 +115,7 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
         // bit for bit: nobody reduces it again)
         const int q1 = p + 1;
         pl->wq = ((Mp + 1 + world - 1) / world + 3) / 4 * 4;
-        pl->wr = (Mp + world - 1) / world;
+        pl->wr = ((Mp + world - 1) / world + 1) / 2 * 2;            // (even: 16-byte aligned column offsets into the fp64 [S - I ; m^T])
         const int wc = ((M + world - 1) / world) * q1;              // widest column block of K_ZZ-bar
         const int ldQ64 = (Mp + 2) / 2 * 2;
         pl->o_Qfull = c.take((size_t)Mp * world * pl->wq * 4);
@@ -304,7 +304,7 @@ static int step_validate(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_s
     double* Kbar = (double*)(w + pl->o_Kbar); \
     void* kbwd_ws = w + pl->o_kbwd; \
     void* kbwd_ws2 = w + pl->o_kbwd2; \
-    const int ldS = pl->ldS, ldQ32 = pl->ldQ32, ldQ64 = (Mp + 2) / 2 * 2; \
+    const int ldS = pl->ldS, ldQ32 = pl->ldQ32, ldQ64 = (Mp + 2) / 2 * 2, ldST = (Mp + 1) / 2 * 2; \
     const double rows = io->global_rows;
 
 // Everything up to and including the Gram product [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T) of this rank's rows (shared by the
@@ -353,8 +353,11 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         if (rc) return rc;
         rc = launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows);     // mirror + [S - I | m / (2 vbar)]
         if (rc) return rc;
-        // its fp64 copy: the left operand of the Cholesky backward's first product, see chol_tail below
-        launch_widen_f32_f64(ctx->stream, S32e, ldS, S64e, ldQ64, Mp, Mp + 1);
+        // its fp64 copy, TRANSPOSED -- [S - I ; m^T / (2 vbar)], (M'+1) x M': S - I is symmetric, so its rows are copied as they lie and
+        // only the extra column becomes a row -- the left operand of the Cholesky backward's first product (chol_tail below) then
+        // streams as an mn-contiguous operand (the lean fp64 kernel's faster staging path: 49 against 46 TF)
+        launch_widen_f32_f64(ctx->stream, S32e, ldS, S64e, ldST, Mp, Mp);
+        launch_widen_f32_f64(ctx->stream, S32e + Mp, ldS, S64e + (size_t)Mp * ldST, 1, Mp, 1);
         return hipGetLastError() == hipSuccess ? 0 : 1000 + (int)hipGetLastError();
     };
     if (overlap) {
@@ -450,8 +453,8 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // instead of L-bar (M'^3) followed by L^T L-bar (M'^3 / 3); neither L-bar nor the fp64 [Q' | a] is formed.  (Round 4.)
     const double* Linv = (const double*)trsm_ws;
     auto chol_tail = [&]() -> int {
-        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldQ64, Ge, Mp, 0.0, nullptr, 0,
-                            G1, Mp, nullptr, 0, nullptr);
+        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldST, Ge, Mp,
+                            0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
         if (rc) return rc;
         rc = dsvgp_phi_symmetrize(ctx, G1, Mp, Mp);
         if (rc) return rc;
@@ -614,8 +617,8 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
         }
         if (nrow > 0)     // rows [r0, r1) of tril(L^T L-bar) = -tril([S - I | m / (2 vbar)][G ; b^T]) (see chol_tail of the one-GPU step),
             // columns [0, r1): fp64 accumulation, fp32 copy for the all-gather (the rest of dp->lbar_local stays zero)
-            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_B_IS_FLOAT, nrow, r1, Mp + 1, -1.0, S64e + (size_t)r0 * ldQ64, ldQ64, Ge, Mp, 0.0, nullptr,
-                                 0, lrow64, Mp, dp->lbar_local, Mp, nullptr));
+            STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_IS_FLOAT, nrow, r1, Mp + 1, -1.0, S64e + r0, ldST, Ge, Mp, 0.0,
+                                 nullptr, 0, lrow64, Mp, dp->lbar_local, Mp, nullptr));
         return 0;
     }
     if (phase == 3) {

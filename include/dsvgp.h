@@ -426,7 +426,7 @@ int dsvgp_elbo_step_locate(const dsvgp_step_plan* plan, int which, size_t* offse
  *                          padding (keep it zero)             phase 0 writes it -> ALL-REDUCE(sum) -> phase 2 reads it
  *               q_local    [M', wq], wq = roundup4(ceil((M'+1)/world)), ZERO-INITIALISED once (the pad columns stay zero)
  *                                                              phase 1 writes it -> ALL-GATHER -> q_all [world, M', wq], phase 3 reads
- *               lbar_local [wr, M'], wr = ceil(M'/world), zero-initialised once
+ *               lbar_local [wr, M'], wr = roundup2(ceil(M'/world)), zero-initialised once
  *                                                              phase 2 writes it -> ALL-GATHER -> lbar_all [world wr, M'], phase 4 reads
  *   phase     0 .. 4 in this order, all on the context's stream (the collectives must be ordered against it by the caller);
  *             after phase 4: ALL-REDUCE(sum) of the slots of io->flat that hold Z-bar, V-bar, the hyper-parameter gradients and
