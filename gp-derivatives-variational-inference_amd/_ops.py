@@ -634,14 +634,16 @@ def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2
     n = len(params)
     if n > ADAM_MAX_TENSORS:
         raise ValueError("at most %d tensors per launch" % ADAM_MAX_TENSORS)
+    dt = params[0].dtype if n else f32
     for group in (params, grads, exp_avgs, exp_avg_sqs):
         for t in group:
-            if t.dtype != f32 or not t.is_cuda or not t.is_contiguous():
-                raise ValueError("adam: tensors must be contiguous float32 GPU tensors")
+            if t.dtype != dt or dt not in (f32, f64) or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("adam: tensors must be contiguous GPU tensors of one dtype (float32 or float64)")
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     sizes = (ctypes.c_int64 * n)(*[t.numel() for t in params])
-    check(lib.dsvgp_adam_step_multi(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, float(lr),
-                                    float(beta1), float(beta2), float(eps), int(step)), "dsvgp_adam_step_multi")
+    fn, name = (lib.dsvgp_adam_step_multi_f64, "dsvgp_adam_step_multi_f64") if dt == f64 else (lib.dsvgp_adam_step_multi, "dsvgp_adam_step_multi")
+    check(fn(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, float(lr), float(beta1), float(beta2),
+             float(eps), int(step)), name)
 
 
 def adam_step_(ctx, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):

@@ -853,6 +853,62 @@ extern "C" int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, 
     return 0;
 }
 
+// the float64 model mode's update (the reference's experiment scripts train under torch.set_default_dtype(torch.float64),
+// experiments/synthetic/exp_script.py:56): the same rule in double
+struct AdamTable64 {
+    double* param[DSVGP_ADAM_MAX_TENSORS];
+    const double* grad[DSVGP_ADAM_MAX_TENSORS];
+    double* m[DSVGP_ADAM_MAX_TENSORS];
+    double* v[DSVGP_ADAM_MAX_TENSORS];
+    int64_t n[DSVGP_ADAM_MAX_TENSORS];
+    int first[DSVGP_ADAM_MAX_TENSORS + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void adam_multi_f64_kernel(const AdamTable64 t, double lr, double b1, double b2, double eps,
+                                                             double bc1, double bc2_sqrt) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first[k + 1]) ++k;
+    const int nb = t.first[k + 1] - t.first[k];
+    double* __restrict__ param = t.param[k];
+    const double* __restrict__ grad = t.grad[k];
+    double* __restrict__ m = t.m[k];
+    double* __restrict__ v = t.v[k];
+    const int64_t n = t.n[k];
+    for (int64_t i = (int64_t)(blockIdx.x - t.first[k]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        const double g = grad[i];
+        const double mi = b1 * m[i] + (1.0 - b1) * g;
+        const double vi = b2 * v[i] + (1.0 - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const double denom = sqrt(vi) / bc2_sqrt + eps;
+        param[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+extern "C" int dsvgp_adam_step_multi_f64(dsvgp_ctx* ctx, int count, double* const* params, const double* const* grads,
+                                         double* const* exp_avgs, double* const* exp_avg_sqs, const int64_t* sizes, double lr,
+                                         double beta1, double beta2, double eps, int step) {
+    if (!ctx || count < 0 || count > DSVGP_ADAM_MAX_TENSORS || step < 1) return DSVGP_EINVAL;
+    if (count && (!params || !grads || !exp_avgs || !exp_avg_sqs || !sizes)) return DSVGP_EINVAL;
+    AdamTable64 t{};
+    int nblocks = 0;
+    for (int k = 0; k < count; ++k) {
+        if (sizes[k] < 0 || (sizes[k] > 0 && (!params[k] || !grads[k] || !exp_avgs[k] || !exp_avg_sqs[k]))) return DSVGP_EINVAL;
+        if (sizes[k] == 0) continue;
+        const int c = t.count++;
+        t.param[c] = params[k]; t.grad[c] = grads[k]; t.m[c] = exp_avgs[k]; t.v[c] = exp_avg_sqs[k]; t.n[c] = sizes[k];
+        int b = cdiv(sizes[k], 256);
+        if (b > 2048) b = 2048;
+        t.first[c] = nblocks;
+        nblocks += b;
+    }
+    if (!t.count) return 0;
+    t.first[t.count] = nblocks;
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    hipLaunchKernelGGL(adam_multi_f64_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, t, lr, beta1, beta2, eps, bc1, sqrt(bc2));
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
                                      float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
                                      float beta1, float beta2, float eps, int step) {

@@ -99,29 +99,20 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                key = (st["step"], p.device, float(group["lr"]), float(b1), float(b2), float(group["eps"]))
+                key = (st["step"], p.device, float(group["lr"]), float(b1), float(b2), float(group["eps"]), p.dtype)
                 batch.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
-        for (step, dev, lr, b1, b2, eps), items in batch.items():
+        for (step, dev, lr, b1, b2, eps, dt), items in batch.items():
             ctx = _ops.Context.get(dev)
             for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
                 ps, gs, ms, vs = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
-                if len(ps) == 1:
+                if len(ps) == 1 and dt == torch.float32:
                     _ops.adam_step_(ctx, ps[0], gs[0], ms[0], vs[0], lr, b1, b2, eps, step)
                 else:
-                    _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step)
+                    _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step)       # (float32 or float64 tensors)
         return loss
 
 
 def make_adam(param_groups, lr=1e-3):
-    """torch.optim.Adam(param_groups, lr) of the reference loop (directional_vi.py:189-198): the fused multi-tensor HIP update for
-    the fp32 model, torch's own Adam for the fp64 model mode (``_step64``; the update is O(parameters) elementwise work)."""
-    groups = list(param_groups)
-    tensors = [p for g in groups for p in (g["params"] if isinstance(g, dict) else [g])]
-    if any(p.dtype == torch.float64 for p in tensors):
-        if all(p.is_cuda for p in tensors):
-            try:                    # torch's own multi-tensor kernel (same update rule): one launch per group instead of ~10
-                return torch.optim.Adam(groups, lr=lr, fused=True)
-            except (RuntimeError, ValueError, TypeError):
-                pass
-        return torch.optim.Adam(groups, lr=lr)
-    return FusedAdam(groups, lr=lr)
+    """torch.optim.Adam(param_groups, lr) of the reference loop (directional_vi.py:189-198): the fused multi-tensor HIP update, for
+    the fp32 model and (round 4: ``dsvgp_adam_step_multi_f64``) for the float64 model mode alike."""
+    return FusedAdam(list(param_groups), lr=lr)

@@ -285,6 +285,10 @@ int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_
 int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
                           float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
                           float beta1, float beta2, float eps, int step);
+/* the same update for the float64 model mode (parameters, gradients and moments in double) */
+int dsvgp_adam_step_multi_f64(dsvgp_ctx* ctx, int count, double* const* params, const double* const* grads,
+                              double* const* exp_avgs, double* const* exp_avg_sqs, const int64_t* sizes, double lr,
+                              double beta1, double beta2, double eps, int step);
 
 /* ---- graph-capturable variants (HIP-graph replay of the steady-state step: every per-step scalar lives in device memory)
  * dsvgp_adam_step_multi_dev: dsvgp_adam_step_multi with {lr, step} read from the device float[2] lr_step_dev (the host

@@ -594,3 +594,24 @@ def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, g
             if state == "init" and k == "g_inducing_directions":
                 tol = 2e-3
             assert v < tol, (k, v)
+
+
+def test_fp64_fused_adam_matches_torch_adam(dsvgp, gpu_device):
+    """``optim.make_adam`` hands float64 parameters to the hand-written multi-tensor update (dsvgp_adam_step_multi_f64) since round
+    4: five steps on three tensors against torch.optim.Adam in float64 (the reference's optimizer, directional_vi.py:189-198)."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37, 5), (130,), (64, 64)]
+    p0 = [torch.randn(*s, generator=g, dtype=torch.float64) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone().to(gpu_device)) for t in p0]
+    ref = [torch.nn.Parameter(t.clone().to(gpu_device)) for t in p0]
+    o1 = dsvgp.optim.make_adam([{"params": mine[:2]}, {"params": mine[2:]}], lr=0.01)
+    assert isinstance(o1, dsvgp.optim.FusedAdam)
+    o2 = torch.optim.Adam([{"params": ref[:2]}, {"params": ref[2:]}], lr=0.01)
+    for step in range(5):
+        for a, b in zip(mine, ref):
+            gr = torch.randn(a.shape, generator=g, dtype=torch.float64).to(gpu_device)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o1.step(); o2.step()
+    torch.cuda.synchronize()
+    for a, b in zip(mine, ref):
+        assert (a - b).abs().max().item() < 1e-14, (a - b).abs().max().item()
