@@ -333,6 +333,7 @@ def main():
     # ---- second figure (opt-in mode, never the headline): the same window with the two big fp32 products as bf16 x 3 split products
     split_fig = None
     if extras and hasattr(eng, "split_bf16") and not eng.split_bf16:
+      try:
         eng.split_bf16 = True
         for k in range(3):
             loop.step(batch(args.warmup + 3 * args.steps + 20 + k))
@@ -344,6 +345,9 @@ def main():
                          note="opt-in (`--split-bf16` / DSVGP_SPLIT_BF16=1); passes every reference-text case at the fp32 path's "
                               "tolerances, worst error per configuration equal to the fp32 path's, individual scalar gradients up to "
                               "3-27x further out (<= 1.2e-5): tests/test_gpu_reftext.py::test_split_bf16_step_*")
+      except Exception as ex:                # (an extra must never take the headline line down)
+        eng.split_bf16 = False
+        split_fig = dict(error="%s: %s" % (type(ex).__name__, ex))
     # ---- the reference's every-50th-step report (directional_vi.py:255-260: loss.item(), nll of the function values from
     # output.mean / output.variance of that forward pass): one reporting step costs a host synchronisation (the step pipeline
     # drains) plus the value-row variances; measured over 5 reporting steps in a row, 1/50 of the extra goes into ms_per_step
@@ -358,13 +362,16 @@ def main():
             nll_ = -torch.distributions.Normal(means_, stds_).log_prob(yb_[::q_]).mean()
             return "loss: %s, nll: %s" % (l_.item(), nll_.item())
 
-        report_step(0)                   # (untimed: first use of the value-row buffers and of torch.distributions' kernels)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(5):
-            report_step(1 + k)
-        torch.cuda.synchronize()
-        report_extra_ms = max(0.0, 1e3 * (time.perf_counter() - t0) / 5 - 1e3 * elapsed / args.steps)
+        try:
+            report_step(0)               # (untimed: first use of the value-row buffers and of torch.distributions' kernels)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(5):
+                report_step(1 + k)
+            torch.cuda.synchronize()
+            report_extra_ms = max(0.0, 1e3 * (time.perf_counter() - t0) / 5 - 1e3 * elapsed / args.steps)
+        except Exception:                    # (an extra must never take the headline line down)
+            report_extra_ms = None
 
     # N > 1: what the collectives this design could use cost on THIS node, measured after the timed region (all ranks take part;
     # priced for the next design step: sharding the replicated M' x M' products would add two 72 MB all-gathers per step)
@@ -499,6 +506,22 @@ def main():
     graph_replay = bool(loop._graphs)
     ciq_stats = dict(eng.ciq_stats) if cfg.get("ciq") else None
 
+    def time_other(cfg_o, name, fp64_, steps_, warm_):
+        loop_o, eng_o, batch_o = build(cfg_o, fp64_)
+        for k in range(warm_):
+            loop_o.step(batch_o(k))
+        events_on(eng_o, 8 if name == "c2" else 1)
+        e_o, loss_o = window(loop_o, batch_o, warm_, steps_)
+        eng_o.record_events = False
+        roof_o, asm_o = rooflines(cfg_o, eng_o, event_durations(eng_o, EVENT_NAMES), None, fp64_, name, False)
+        return dict(workload=cfg_o["name"] + (" (float64 model mode)" if fp64_ else ""), steps=steps_, warmup=warm_,
+                    ms_per_step=1e3 * e_o / steps_, steps_per_s=steps_ / e_o, final_loss=float(loss_o.item()),
+                    one_call_step=bool(getattr(eng_o, "c_step_used", False)),
+                    roofline_kernel=(roof_o or {}).get("kernel"), roofline_frac=(roof_o or {}).get("frac"),
+                    roofline_avg_ms=(roof_o or {}).get("avg_ms"),
+                    assembly_fwd_frac=((asm_o or {}).get("forward") or {}).get("frac"),
+                    assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
+
     # ---- every other BASELINE configuration, timed by this same command (one GPU, default run): C2, C3, C5 and the float64 model
     # mode at C4, each with its own warm-up and ONE timed window of the given number of steps (same bracketing as above)
     other = None
@@ -511,21 +534,10 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             cfg_o = CONFIGS[name]
-            loop_o, eng_o, batch_o = build(cfg_o, fp64_)
-            for k in range(warm_):
-                loop_o.step(batch_o(k))
-            events_on(eng_o, 8 if name == "c2" else 1)
-            e_o, loss_o = window(loop_o, batch_o, warm_, steps_)
-            eng_o.record_events = False
-            roof_o, asm_o = rooflines(cfg_o, eng_o, event_durations(eng_o, EVENT_NAMES), None, fp64_, name, False)
-            other[key] = dict(workload=cfg_o["name"] + (" (float64 model mode)" if fp64_ else ""), steps=steps_, warmup=warm_,
-                              ms_per_step=1e3 * e_o / steps_, steps_per_s=steps_ / e_o, final_loss=float(loss_o.item()),
-                              one_call_step=bool(getattr(eng_o, "c_step_used", False)),
-                              roofline_kernel=(roof_o or {}).get("kernel"), roofline_frac=(roof_o or {}).get("frac"),
-                              roofline_avg_ms=(roof_o or {}).get("avg_ms"),
-                              assembly_fwd_frac=((asm_o or {}).get("forward") or {}).get("frac"),
-                              assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
-            del loop_o, eng_o, batch_o
+            try:
+                other[key] = time_other(cfg_o, name, fp64_, steps_, warm_)
+            except Exception as ex:          # (an extra must never take the headline line down)
+                other[key] = dict(workload=cfg_o["name"], error="%s: %s" % (type(ex).__name__, ex))
         eng = None
 
     # ms_per_step = the timed window / steps, plus 1/50 of what a reporting step costs on top of a plain one (the reference reports
