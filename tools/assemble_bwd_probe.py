@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time the kernel-assembly backward (K_ZX-bar at C4 size, fp32 upstream; K_ZZ-bar fp64) for the library named by
-DSVGP_LIB_PATH."""
+"""Time the kernel-assembly backward (K_ZX-bar, fp32 upstream; K_ZZ-bar fp64) for the library named by DSVGP_LIB_PATH.
+Geometry from BWD_GEOM="M,B,d,p" (default C4: 500,4096,20,5; C3: 300,512,10,10)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ import dsvgp_amd
 ops = dsvgp_amd._ops
 dev = torch.device("cuda", 0)
 ctx = ops.Context.get(dev)
-M, B, d, p = 500, 4096, 20, 5
+M, B, d, p = (int(v) for v in os.environ.get("BWD_GEOM", "500,4096,20,5").split(","))
 hyp = torch.tensor([0.69, 0.69, 0.1, 0.0], device=dev)
 Z, V = torch.rand(M, d, device=dev), torch.eye(d, device=dev)[:p].repeat(M, 1)
 X, D = torch.rand(B, d, device=dev), torch.eye(d, device=dev)[:p].repeat(B, 1)
