@@ -523,14 +523,14 @@ def main():
                     assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
 
     # ---- every other BASELINE configuration, timed by this same command (one GPU, default run): C2, C3, C5 and the float64 model
-    # mode at C4, each with its own warm-up and ONE timed window of the given number of steps (same bracketing as above)
+    # mode at C4 and C5 (fp64 msMINRES), each with its own warm-up and ONE timed window of the given number of steps (same bracketing as above)
     other = None
     if extras and not args.no_other_configs:
         other = {}
         del loop, eng, batch
         import gc
         for key, name, fp64_, steps_, warm_ in (("c2", "c2", False, 300, 20), ("c3", "c3", False, 30, 5), ("c5", "c5", False, 8, 3),
-                                                  ("c4_fp64", "c4", True, 10, 3)):
+                                                  ("c4_fp64", "c4", True, 10, 3), ("c5_fp64", "c5", True, 4, 2)):
             gc.collect()
             torch.cuda.empty_cache()
             cfg_o = CONFIGS[name]

@@ -78,6 +78,14 @@ SIGNATURES = {
     "dsvgp_ciq_rowstats": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "dsvgp_ciq_tbar": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dsvgp_sym_average_f32": (_i, [_p, _p, _i, _l, _p, _l]),
+    "dsvgp_ciq_workspace_bytes_f64": (_z, [_i, _i, _i, _i]),
+    "dsvgp_ciq_lanczos_f64": (_i, [_p, _p, _l, _p, _i, _i, _p, _p, _p]),
+    "dsvgp_ciq_solve_f64": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _d, _i, _i, _p, _i, _p, _p, _p, _l, _p, _p]),
+    "dsvgp_ciq_mix_f64": (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _l]),
+    "dsvgp_ciq_cross_f64": (_i, [_p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "dsvgp_ciq_rowstats_f64": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _d, _p, _p, _p, _p]),
+    "dsvgp_ciq_tbar_f64": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "dsvgp_sym_average_f64": (_i, [_p, _p, _i, _l, _p, _l]),
     "dsvgp_packed_width": (_i, [_i]),
     "dsvgp_column_mean": (_i, [_p, _p, _i, _i, _p]),
     "dsvgp_pack_points": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),

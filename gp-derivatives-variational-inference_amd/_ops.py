@@ -668,15 +668,30 @@ def gemm_lib_f32(ctx, flags, A, B, C_out, alpha=1.0, beta=0.0):
 
 
 # ---- contour-integral-quadrature whitening (csrc/ciq.hip) ------------------------------------------------------
+# Every wrapper serves both scalar types: float32 tensors go to dsvgp_ciq_*, float64 tensors (the fp64 model mode) to
+# dsvgp_ciq_*_f64; all tensors of one call must share the type of its first matrix argument.
+def _ciq_fn(name, dt):
+    if dt == f32:
+        return getattr(lib, name)
+    if dt == f64:
+        return getattr(lib, (name[:-4] if name.endswith("_f32") else name) + "_f64")
+    raise TypeError("CIQ kernels are built for float32 and float64 tensors, got %s" % dt)
+
+
+def ciq_workspace_bytes(Q, t, n, cap, dtype=f32):
+    return int(_ciq_fn("dsvgp_ciq_workspace_bytes", dtype)(int(Q), int(t), int(n), int(cap)))
+
+
 def ciq_lanczos(ctx, K, v0, iters):
-    """alpha[iters], beta[iters] of `iters` Lanczos steps with the symmetric fp32 K started at v0."""
-    _req(K, f32, "K", 2)
+    """alpha[iters], beta[iters] of `iters` Lanczos steps with the symmetric K started at v0."""
+    dt = K.dtype
+    _req(K, dt, "K", 2)
     n = K.shape[0]
-    alpha = torch.zeros(iters, dtype=f32, device=K.device)
-    beta = torch.zeros(iters, dtype=f32, device=K.device)
-    ws = torch.empty(3 * n + 8, dtype=f32, device=K.device)
-    check(lib.dsvgp_ciq_lanczos(ctx.h, _ptr(K), _ld(K), _ptr(_req(v0, f32, "v0", 1)), n, int(iters), _ptr(alpha),
-                                _ptr(beta), _ptr(ws)), "dsvgp_ciq_lanczos")
+    alpha = torch.zeros(iters, dtype=dt, device=K.device)
+    beta = torch.zeros(iters, dtype=dt, device=K.device)
+    ws = torch.empty(3 * n + 8, dtype=dt, device=K.device)
+    check(_ciq_fn("dsvgp_ciq_lanczos", dt)(ctx.h, _ptr(K), _ld(K), _ptr(_req(v0, dt, "v0", 1)), n, int(iters), _ptr(alpha),
+                                          _ptr(beta), _ptr(ws)), "dsvgp_ciq_lanczos")
     return alpha, beta
 
 
@@ -689,24 +704,26 @@ def ciq_solve(ctx, K, R, sigma, omega, basis, ycoef, rnorm, out, workspace, tol=
     """out[t,n] = sum_q omega_q (K + sigma_q)^-1 R rows by basis-resident msMINRES: basis[cap+1,t,n] receives the Lanczos
     rows, ycoef[t,cap,QP] the per-shift coefficients (x_q = rnorm * mix(basis, ycoef)), rnorm[t] the row norms of R.
     Returns the iteration count, or None when `cap` iterations were not enough (call again with a larger basis)."""
-    _req(K, f32, "K", 2)
-    _req(R, f32, "R", 2)
+    dt = K.dtype
+    _req(K, dt, "K", 2)
+    _req(R, dt, "R", 2)
     t, n = R.shape
     Q = sigma.shape[0]
     cap = basis.shape[0] - 1
     if (K.shape != (n, n) or basis.shape != (cap + 1, t, n) or cap < 1 or ycoef.shape != (t, cap, ciq_qp(Q)) or
             rnorm.shape != (t,) or out.shape != (t, n) or not basis.is_contiguous() or not ycoef.is_contiguous()):
         raise ValueError("ciq_solve shape mismatch")
-    for a, name in ((basis, "basis"), (ycoef, "ycoef"), (rnorm, "rnorm")):
-        if a.dtype != f32 or not a.is_cuda:
-            raise TypeError("%s must be a float32 GPU tensor" % name)
-    need = int(lib.dsvgp_ciq_workspace_bytes(Q, t, n, cap))
+    for a, name in ((basis, "basis"), (ycoef, "ycoef"), (rnorm, "rnorm"), (out, "out")):
+        if a.dtype != dt or not a.is_cuda:
+            raise TypeError("%s must be a %s GPU tensor" % (name, dt))
+    need = ciq_workspace_bytes(Q, t, n, cap, dt)
     if workspace.numel() * workspace.element_size() < need:
         raise ValueError("ciq workspace too small")
     its = C.c_int(0)
-    rc = lib.dsvgp_ciq_solve(ctx.h, _ptr(K), _ld(K), _ptr(R), _ld(R), t, n, _ptr(_req(sigma, f32, "sigma", 1)),
-                             _ptr(_req(omega, f32, "omega", 1)), Q, float(tol), int(max_iter), int(check_every), _ptr(basis),
-                             cap, _ptr(ycoef), _ptr(rnorm), _ptr(out), _ld(out), _ptr(workspace), C.byref(its))
+    rc = _ciq_fn("dsvgp_ciq_solve", dt)(ctx.h, _ptr(K), _ld(K), _ptr(R), _ld(R), t, n, _ptr(_req(sigma, dt, "sigma", 1)),
+                                        _ptr(_req(omega, dt, "omega", 1)), Q, float(tol), int(max_iter), int(check_every),
+                                        _ptr(basis), cap, _ptr(ycoef), _ptr(rnorm), _ptr(out), _ld(out), _ptr(workspace),
+                                        C.byref(its))
     if rc == _lib.ENOSPACE:
         return None
     check(rc, "dsvgp_ciq_solve")
@@ -717,11 +734,13 @@ def ciq_mix(ctx, basis, J, coef, Kout, rowscale, out):
     """out[k,row,:] = rowscale[row] * sum_{j<J} coef[row,j,k] basis[j,row,:] for k < Kout (coef[t,ldj,KP], KP % 4 == 0)."""
     _, t, n = basis.shape
     ldj, KP = coef.shape[1], coef.shape[2]
+    dt = basis.dtype
     if (coef.shape[0] != t or J > ldj or J > basis.shape[0] or out.shape != (Kout, t, n) or not out.is_contiguous() or
-            not coef.is_contiguous() or not basis.is_contiguous() or basis.dtype != f32 or coef.dtype != f32 or out.dtype != f32):
+            not coef.is_contiguous() or not basis.is_contiguous() or coef.dtype != dt or out.dtype != dt or
+            (rowscale is not None and rowscale.dtype != dt)):
         raise ValueError("ciq_mix shape mismatch")
-    check(lib.dsvgp_ciq_mix(ctx.h, _ptr(basis), int(J), t, n, _ptr(coef), ldj, KP, int(Kout), _ptr(rowscale), _ptr(out), n),
-          "dsvgp_ciq_mix")
+    check(_ciq_fn("dsvgp_ciq_mix", dt)(ctx.h, _ptr(basis), int(J), t, n, _ptr(coef), ldj, KP, int(Kout), _ptr(rowscale), _ptr(out),
+                                      n), "dsvgp_ciq_mix")
     return out
 
 
@@ -730,34 +749,48 @@ def ciq_cross(ctx, ya, Ja, yb, Jb, omega, rn_a, rn_b):
     stack(basisA[:Ja])^T stack(mix(basisB, C)) (A_q = rn_a mix(basisA, ya)_q, B_q likewise)."""
     t = ya.shape[0]
     Q = omega.shape[0]
+    dt = ya.dtype
     if yb.shape[0] != t or ya.shape[2] != ciq_qp(Q) or yb.shape[2] != ciq_qp(Q) or Ja > ya.shape[1] or Jb > yb.shape[1]:
         raise ValueError("ciq_cross shape mismatch")
-    out = torch.empty(t, Jb, ciq_qp(Ja), dtype=f32, device=ya.device)
-    check(lib.dsvgp_ciq_cross(ctx.h, _ptr(ya), int(Ja), ya.shape[1], _ptr(yb), int(Jb), yb.shape[1], _ptr(omega), Q, t,
-                              _ptr(rn_a), _ptr(rn_b), _ptr(out)), "dsvgp_ciq_cross")
+    if any(a.dtype != dt for a in (yb, omega, rn_a, rn_b)):
+        raise TypeError("ciq_cross: every tensor must be %s" % dt)
+    out = torch.empty(t, Jb, ciq_qp(Ja), dtype=dt, device=ya.device)
+    check(_ciq_fn("dsvgp_ciq_cross", dt)(ctx.h, _ptr(ya), int(Ja), ya.shape[1], _ptr(yb), int(Jb), yb.shape[1], _ptr(omega), Q, t,
+                                        _ptr(rn_a), _ptr(rn_b), _ptr(out)), "dsvgp_ciq_cross")
     return out
 
 
 def ciq_rowstats(ctx, T, ST, p, m, constant, hyp, kxx_jitter=0.0):
     t, n = T.shape
     dev = T.device
-    imean, mu, var, live = (torch.empty(t, dtype=f32, device=dev) for _ in range(4))
-    check(lib.dsvgp_ciq_rowstats(ctx.h, _ptr(T), _ptr(ST), t, n, p, _ptr(m), _ptr(constant), _ptr(hyp), float(kxx_jitter), _ptr(imean),
-                                 _ptr(mu), _ptr(var), _ptr(live)), "dsvgp_ciq_rowstats")
+    dt = T.dtype
+    if any(a.dtype != dt for a in (ST, m, constant, hyp)):
+        raise TypeError("ciq_rowstats: every tensor must be %s" % dt)
+    imean, mu, var, live = (torch.empty(t, dtype=dt, device=dev) for _ in range(4))
+    check(_ciq_fn("dsvgp_ciq_rowstats", dt)(ctx.h, _ptr(T), _ptr(ST), t, n, p, _ptr(m), _ptr(constant), _ptr(hyp), float(kxx_jitter),
+                                           _ptr(imean), _ptr(mu), _ptr(var), _ptr(live)), "dsvgp_ciq_rowstats")
     return imean, mu, var, live
 
 
 def ciq_tbar(ctx, T, ST, m, mu_bar, var_bar, live, imean, Tbar, VT):
     t, n = T.shape
-    cvec = torch.empty(t, dtype=f32, device=T.device)
-    check(lib.dsvgp_ciq_tbar(ctx.h, _ptr(T), _ptr(ST), t, n, _ptr(m), _ptr(mu_bar), _ptr(var_bar), _ptr(live),
-                             _ptr(imean), _ptr(Tbar), _ptr(VT), _ptr(cvec)), "dsvgp_ciq_tbar")
+    dt = T.dtype
+    if any(a.dtype != dt for a in (ST, m, mu_bar, var_bar, live, imean, Tbar, VT)):
+        raise TypeError("ciq_tbar: every tensor must be %s" % dt)
+    cvec = torch.empty(t, dtype=dt, device=T.device)
+    check(_ciq_fn("dsvgp_ciq_tbar", dt)(ctx.h, _ptr(T), _ptr(ST), t, n, _ptr(m), _ptr(mu_bar), _ptr(var_bar), _ptr(live),
+                                       _ptr(imean), _ptr(Tbar), _ptr(VT), _ptr(cvec)), "dsvgp_ciq_tbar")
     return cvec
 
 
 def sym_average_f32(ctx, A, out):
     check(lib.dsvgp_sym_average_f32(ctx.h, _ptr(_req(A, f32, "A", 2)), A.shape[0], _ld(A), _ptr(out), _ld(out)),
           "dsvgp_sym_average_f32")
+
+
+def sym_average_f64(ctx, A, out):
+    check(lib.dsvgp_sym_average_f64(ctx.h, _ptr(_req(A, f64, "A", 2)), A.shape[0], _ld(A), _ptr(_req(out, f64, "out", 2)),
+                                    _ld(out)), "dsvgp_sym_average_f64")
 
 
 def mfma_rate(ctx, is_double=True, millis=40):

@@ -133,6 +133,7 @@ class ElboEngine:
         self.ciq_backward_form = None       # stacking of the backward's sum over shifts: None = the shortest of "backward" /
                                             # "forward" (rows of that solve's basis) / "shifts" (the Q materialised solves)
         self.ciq_stats = {}                 # lmin / lmax / iterations of the last CIQ forward + backward
+        self.ciq_eig_bounds = None          # (lmin, lmax) to build the quadrature on instead of the 20-step Lanczos estimate
         self._eval_cache = None
         # True while a step is being captured into / replayed from a HIP graph (directional_vi.TrainLoop): nothing may read
         # device results on the host -- the potrf status is checked by the caller one step later, and the Adam kernels of the
@@ -771,12 +772,12 @@ class ElboEngine:
     # ---- CIQ whitening (CiqDirectionalGradVariationalStrategy.forward with a NaturalVariationalDistribution) ----
     def _ciq_quadrature(self, ctx, K32, v0):
         """Eigenvalue bounds from 20 Lanczos steps (device) and the elliptic-function quadrature (host, scipy) exactly
-        as gpytorch's contour_integral_quad: K^-1/2 ~ sum_q omega_q (K + sigma_q I)^-1."""
-        import math
-        import numpy as np
-        import scipy.special
+        as gpytorch's contour_integral_quad: K^-1/2 ~ sum_q omega_q (K + sigma_q I)^-1.  ``K32``: float32, or float64 for the
+        fp64 model mode (the shifts and weights come back in its type)."""
         n = K32.shape[0]
         iters = min(20, n)
+        if self.ciq_eig_bounds is not None:                 # (tests: the quadrature of a given spectrum interval)
+            return self._ciq_quadrature_from(K32, float(self.ciq_eig_bounds[0]), float(self.ciq_eig_bounds[1]))
         alpha, beta = _ops.ciq_lanczos(ctx, K32, v0.contiguous(), iters)
         a, b = alpha.double().cpu(), beta.double().cpu()              # host sync (40 floats)
         # an invariant subspace was reached at step k (beta_k ~ 0: e.g. a start vector that is an eigenvector of an almost
@@ -799,6 +800,12 @@ class ElboEngine:
             # data parallel: K_ZZ is replicated but the Lanczos start (first row of the LOCAL K_XZ shard) is not; rank 0's
             # start is the single-process one (first row of the global batch), so its bounds define the quadrature for all
             lmin, lmax = coll.broadcast_floats([lmin, lmax], self.device)
+        return self._ciq_quadrature_from(K32, lmin, lmax)
+
+    def _ciq_quadrature_from(self, K32, lmin, lmax):
+        import math
+        import numpy as np
+        import scipy.special
         Q = int(self.ciq_num_quadrature)
         k2 = lmin / lmax
         Kp = scipy.special.ellipk(1.0 - k2)
@@ -808,7 +815,7 @@ class ElboEngine:
         omega = 2.0 * Kp * math.sqrt(lmin) / (math.pi * Q) * dn / cn ** 2
         self.ciq_stats.update(lmin=lmin, lmax=lmax)
         dev = self.device
-        return (torch.tensor(sigma, dtype=f32, device=dev), torch.tensor(omega, dtype=f32, device=dev),
+        return (torch.tensor(sigma, dtype=K32.dtype, device=dev), torch.tensor(omega, dtype=K32.dtype, device=dev),
                 [float(w) for w in omega])
 
     def _ciq_solve(self, ctx, tag, K32, R, sigma, omega, out):
@@ -817,25 +824,27 @@ class ElboEngine:
         iterations; a solve that needs more is run again with twice the room (and the engine keeps the larger size)."""
         t, n = R.shape
         Q = sigma.shape[0]
+        dt = K32.dtype                                      # float32, or float64 (fp64 model mode: the *_f64 entry points)
+        esz = 8 if dt == f64 else 4
         names = ("ciq_basis_" + tag, "ciq_ycoef_" + tag)
         if self.ciq_capacity is None:
-            self.ciq_capacity = max(20, (4 << 30) // (4 * t * n))
+            self.ciq_capacity = max(20, (4 << 30) // (esz * t * n))
         while True:
             cap = min(int(self.ciq_capacity), int(self.ciq_max_iter))
             have = self._buf.get(names[0])
-            if have is not None and have.shape != torch.Size((cap + 1, t, n)):
+            if have is not None and (have.shape != torch.Size((cap + 1, t, n)) or have.dtype != dt):
                 for nm in names:
                     self._buf.pop(nm, None)
                 del have
                 free, _ = torch.cuda.mem_get_info(self.device)
                 cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-                if 4 * (cap + 1) * t * n > free + cached:
+                if esz * (cap + 1) * t * n > free + cached:
                     raise RuntimeError("msMINRES did not converge within the %d Lanczos rows [%d, %d] that fit this GPU's "
                                        "free memory" % (cap, t, n))
-            basis = self._get(names[0], (cap + 1, t, n), f32)
-            ycoef = self._get(names[1], (t, cap, _ops.ciq_qp(Q)), f32)
-            rnorm = self._get("ciq_rnorm_" + tag, (t,), f32)
-            ws = self._bytes("ciq_ws", _lib.lib.dsvgp_ciq_workspace_bytes(Q, t, n, cap))
+            basis = self._get(names[0], (cap + 1, t, n), dt)
+            ycoef = self._get(names[1], (t, cap, _ops.ciq_qp(Q)), dt)
+            rnorm = self._get("ciq_rnorm_" + tag, (t,), dt)
+            ws = self._bytes("ciq_ws", _ops.ciq_workspace_bytes(Q, t, n, cap, dt))
             its = _ops.ciq_solve(ctx, K32, R, sigma, omega, basis, ycoef, rnorm, out, ws, self.ciq_tolerance,
                                  self.ciq_max_iter)
             if its is not None:

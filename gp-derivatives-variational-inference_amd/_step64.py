@@ -16,8 +16,8 @@ does not read the per-output variances, the Gram-matrix formulation (``_elbo_fas
 of six.  q(u) may be a NaturalVariationalDistribution (``train_gp(use_ngd=True)``: natural parameters in, expectation-parameter gradients out).
 It is not the benchmark path (the headline configs run the reference's default fp32 model; ``bench.py --fp64`` times it).  Under ``parallel.DataParallel`` the gradients of the row shards are
 summed by one all-reduce at the end of the step (no early operand).  No CPU fallback: the inputs must be HIP tensors.
-Shared inducing directions run in fp64 (``_shared_step64``); the CIQ strategy of a float64 model runs on the fp32 CIQ kernels
-(``_ciq_call``: see the comment there and DESIGN.md section 9).
+Shared inducing directions run in fp64 (``_shared_step64``), and so does the CIQ strategy of a float64 model (``_ciq_step64``:
+fp64 msMINRES, the ``*_f64`` entry points of csrc/ciq.hip).
 """
 import math
 
@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, _ops
-from ._step import CHOL_TRIES, PARAM_NAMES, _NGD_RENAME, ElboEngine, NotPSDError
+from ._step import CHOL_TRIES, NGD_PARAM_NAMES, PARAM_NAMES, _NGD_RENAME, ElboEngine, NotPSDError
 
 KXX_JITTER = 1e-4       # data_data_covar.add_jitter(1e-4), DGVS.py:202
 MIN_VARIANCE = 1e-6     # MultivariateNormal.variance clamp (gpytorch settings.min_variance)
@@ -58,7 +58,7 @@ class ElboEngine64(ElboEngine):
         if x.dtype != f64 or (D is not None and D.numel() and D.dtype != f64):
             raise TypeError("fp64 model mode: inputs must be float64")
         if self.whitening != "cholesky":
-            raise NotImplementedError("fp64 model mode covers the Cholesky-whitened strategies (and CIQ through the fp32 kernels)")
+            raise NotImplementedError("fp64 model mode: whitening must be 'cholesky' here (CIQ goes through _ciq_step64)")
 
     def _hyp64(self, params, grad=False):
         """(raw leaves, hyp[4] = {lengthscale, outputscale, noise, 0}): gpytorch Positive / GreaterThan(1e-4) softplus constraints"""
@@ -145,30 +145,115 @@ class ElboEngine64(ElboEngine):
             torch.ones(1, dtype=f64, device=like.device)
         return s * row.repeat(B)
 
-    # ---- CIQ whitening under a float64 model (train_gp(use_ciq=True): the bunny / GNN drivers offer it under their fp64 default) ----
-    # msMINRES stops at a mean relative update of 1e-4 and the quadrature itself is a 1e-4-class approximation of K_ZZ^-1/2
-    # (tests/test_ciq.py), so the CIQ strategy of a float64 model runs on the fp32 CIQ kernels (csrc/ciq.hip): parameters, data
-    # and optimizer state stay float64, the step's arithmetic is that of the reference's default (fp32) CIQ model, the
-    # gradients come back as float64.  Stated in DESIGN.md section 9; a float64 msMINRES is not built.
-    _CIQ_ATTRS = ("whitening", "ciq_num_quadrature", "ciq_tolerance", "ciq_max_iter", "ciq_kxx_jitter", "kzz_jitter",
-                  "chol_jitter", "data_outputs", "shared_directions", "collective", "ciq_backward_form")
-
-    def _ciq_delegate(self):
-        e = self.__dict__.get("_ciq32")
-        if e is None:
-            e = self._ciq32 = ElboEngine(self.device)
-        for k in self._CIQ_ATTRS:
-            setattr(e, k, getattr(self, k))
-        return e
-
-    def _ciq_call(self, fn, params, *tensors, **kw):
-        if any(v.dtype != f64 for v in params.values()):
-            raise TypeError("fp64 model mode: parameters must be float64")
-        e = self._ciq_delegate()
-        out = getattr(e, fn)({k: v.float() for k, v in params.items()},
-                             *[t.float() if torch.is_tensor(t) and t.is_floating_point() else t for t in tensors], **kw)
-        self.ciq_stats = e.ciq_stats
-        return out
+    # ---- CIQ whitening under a float64 model (train_gp(use_ciq=True): the bunny / GNN drivers offer it under their fp64 default,
+    #      reference experiments/bunny/exp_bunny.py:66,78) ----
+    def _ciq_step64(self, ctx, params, x, y, D, num_data, mll_type, global_rows, include_kl, want_grads):
+        """The float64 form of ``ElboEngine._ciq_step`` (reference CiqDirectionalGradVariationalStrategy.py:197-295 and its
+        _NgdInterpTerms, :19-123, on a float64 model): fp64 kernel assembly, fp64 msMINRES (the ``*_f64`` entry points of
+        csrc/ciq.hip), every product on the fp64 MFMA GEMM.  Same schedule, same buffers' roles, all tensors float64."""
+        if self.data_outputs != "all":
+            raise NotImplementedError("derivative-free data is built for the Cholesky-whitened strategy only")
+        if "natural_vec" not in params:
+            raise NotImplementedError("the CIQ strategy is built for a NaturalVariationalDistribution (what "
+                                      "train_gp(use_ciq=True) constructs, reference directional_vi.py:164-166)")
+        for k, v in params.items():
+            if v.dtype != f64:
+                raise TypeError("fp64 model mode: parameter %s is %s" % (k, v.dtype))
+            if not v.is_cuda:
+                raise _lib.DsvgpError("%s must live on the GPU: the DSVGP hot path has no CPU fallback" % k)
+        if x.dtype != f64 or (D is not None and D.numel() and D.dtype != f64) or (y is not None and y.dtype != f64):
+            raise TypeError("fp64 model mode: inputs must be float64")
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        Mp = M * (p + 1)
+        B = x.shape[0]
+        Bp = B * (p + 1)
+        dev = self.device
+        rows = float(Bp if global_rows is None else global_rows)
+        nat_vec, nat_mat = params["natural_vec"], params["natural_mat"]
+        _, (ell, s, noise), hyp = self._hyp64(params)
+        self.center = Z.mean(0).contiguous()
+        packZ = _ops.pack_points_f64(ctx, Z.contiguous(), V.contiguous(), p, hyp, self.center)
+        packX = _ops.pack_points_f64(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        K = self._get("ciq_K64", (Mp, Mp), f64)
+        _ops.kernel_fwd_f64(ctx, packZ, M, packZ, M, d, p, hyp, jitter=self.kzz_jitter, out=K)       # :230-234
+        Rrow = self._get("ciq_R64", (Bp, Mp), f64)                                                   # K_XZ, one right-hand side per row
+        _ops.kernel_fwd_f64(ctx, packX, B, packZ, M, d, p, hyp, out=Rrow)
+        sigma, omega, _ = self._ciq_quadrature(ctx, K, Rrow[0])
+        Q = sigma.shape[0]
+        Trow = self._get("ciq_T64", (Bp, Mp), f64)
+        basisF, ycoefF, rnF, its = self._ciq_solve(ctx, "f", K, Rrow, sigma, omega, Trow)           # :255-256
+        self.ciq_stats.update(iterations=its)
+        S64, m64, info = self._natural_moments(ctx, nat_vec, nat_mat)                                # :51-61 as a direct fp64 solve
+        if int(info[0].item()) != 0:
+            raise NotPSDError("natural_mat does not define a positive definite precision")
+        m = m64.reshape(Mp).contiguous()
+        STrow = self._get("ciq_ST64", (Bp, Mp), f64)
+        _ops.gemm(ctx, 0, Trow, S64, STrow)                                                          # (S T)^T = T^T S
+        const = params["constant"].reshape(1).contiguous()
+        imean, mu, var, live = _ops.ciq_rowstats(ctx, Trow, STrow, p, m, const, hyp, self.ciq_kxx_jitter)      # :65-69,265-266
+        if not want_grads:
+            return None, None, mu, (var + noise).clamp_min_(MIN_VARIANCE)
+        # the likelihood launch of the fp64 mode takes (mean without the constant, variance beyond prior diagonal + 1e-4)
+        cs = var - self._prior_diag(B, p, p, ell, s, x) - KXX_JITTER
+        mu, varn, mu_bar, var_bar, scal = _ops.likelihood_terms_f64(ctx, imean, cs, y.contiguous(), const, p, hyp,
+                                                                    0 if mll_type == "ELBO" else 1, rows)
+        loss = -scal[0] / rows                                                                       # (the KL term stays out of the loss, :74)
+        grads = {k: torch.zeros_like(params[k], memory_format=torch.contiguous_format) for k in NGD_PARAM_NAMES}
+        Tbar = self._get("ciq_Tbar64", (Bp, Mp), f64)
+        VT = self._get("ciq_VT64", (Bp, Mp), f64)
+        cvec = _ops.ciq_tbar(ctx, Trow, STrow, m, mu_bar, var_bar, live, imean, Tbar, VT)           # :94-96
+        kl_bar = (1.0 / float(num_data)) if include_kl else 0.0
+        d1 = grads["natural_vec"].reshape(1, Mp)
+        _ops.gemm(ctx, 0, cvec.reshape(1, Bp), Trow, d1)                                             # :102-106
+        d1.add_(nat_vec.reshape(1, Mp), alpha=kl_bar)                                                # :107
+        d2 = grads["natural_mat"]
+        _ops.gemm(ctx, TRANS_A, VT, Trow, d2)                                                        # :115-116: T^T diag(vbar) T
+        d2.add_(nat_mat, alpha=kl_bar)                                                               # kl/2 (I - prec), prec = -2 theta_2
+        d2.diagonal().add_(0.5 * kl_bar)
+        # backward of sqrt_inv_matmul: dR = K^-1/2 Tbar, dK = -sym sum_q omega_q Y_q^T X_q (same quadrature)
+        Rbar = self._get("ciq_Rbar64", (Bp, Mp), f64)
+        basisB, ycoefB, rnB, its_b = self._ciq_solve(ctx, "b", K, Tbar, sigma, omega, Rbar)
+        self.ciq_stats.update(iterations_backward=its_b)
+        dK = self._get("ciq_dK64", (Mp, Mp), f64)
+        form = self.ciq_backward_form
+        if form is None:
+            form = "backward" if its_b <= min(its, Q) else ("forward" if its <= Q else "shifts")
+        kmin = {"backward": its_b, "forward": its, "shifts": Q}[form]
+        if form == "backward":
+            ctab = _ops.ciq_cross(ctx, ycoefB, its_b, ycoefF, its, omega, rnB, rnF)
+            Zs = _ops.ciq_mix(ctx, basisF, its, ctab, its_b, None, self._get("ciq_Z64", (its_b, Bp, Mp), f64))
+            left, right = basisB[:its_b], Zs
+        elif form == "forward":
+            ctab = _ops.ciq_cross(ctx, ycoefF, its, ycoefB, its_b, omega, rnF, rnB)
+            Zs = _ops.ciq_mix(ctx, basisB, its_b, ctab, its, None, self._get("ciq_Z64", (its, Bp, Mp), f64))
+            left, right = Zs, basisF[:its]
+        else:
+            om = torch.zeros(_ops.ciq_qp(Q), dtype=f64, device=dev)
+            om[:Q] = omega
+            right = _ops.ciq_mix(ctx, basisF, its, ycoefF * om, Q, rnF, self._get("ciq_Z64", (Q, Bp, Mp), f64))
+            left = _ops.ciq_mix(ctx, basisB, its_b, ycoefB, Q, rnB, self._get("ciq_Z264", (Q, Bp, Mp), f64))
+        _ops.gemm(ctx, TRANS_A, left.reshape(kmin * Bp, Mp), right.reshape(kmin * Bp, Mp), dK, alpha=-1.0)
+        self.ciq_stats.update(stacked_depth=int(kmin * Bp))
+        Kzzbar = self._get("ciq_Kzzbar64", (Mp, Mp), f64)
+        _ops.sym_average_f64(ctx, dK, Kzzbar)
+        Kb = self._get("Kb64", (Mp, Bp), f64)
+        _ops.transpose_f64(ctx, Rbar, Kb)
+        dZ, dV = grads["inducing_points"], grads["inducing_directions"]
+        d_hyp = torch.zeros(4, dtype=f64, device=dev)
+        scratch = self._get("T_zx", (Mp, Bp), f64)
+        _ops.kernel_bwd_f64(ctx, Kb, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, scratch)
+        scratch = self._get("T_zz", (Mp, Mp), f64)
+        _ops.kernel_bwd_f64(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, scratch)
+        # likelihood / prior-diagonal parts (scal) + kernel parts (d_hyp) through the softplus constraints
+        d_raw = self._raw_grads64(params, scal)
+        sig = [torch.sigmoid(params[k].reshape(())) for k in ("raw_lengthscale", "raw_outputscale")]
+        grads["raw_lengthscale"].add_((d_raw[0] + d_hyp[0] * sig[0]).reshape(grads["raw_lengthscale"].shape))
+        grads["raw_outputscale"].add_((d_raw[1] + d_hyp[1] * sig[1]).reshape(grads["raw_outputscale"].shape))
+        grads["raw_noise"].add_(d_raw[2].reshape(grads["raw_noise"].shape))
+        grads["constant"].add_(scal[2].reshape(grads["constant"].shape))
+        return loss, grads, mu, varn
 
     # ---- NaturalVariationalDistribution (train_gp(use_ngd=True), reference directional_vi.py:35-37,186-187) in fp64 ----
     def _from_natural(self, ctx, params):
@@ -252,10 +337,10 @@ class ElboEngine64(ElboEngine):
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
     def predict(self, params, x, D, cache=False):
-        if self.whitening == "ciq":
-            mu, varn = self._ciq_call("predict", params, x, D, cache=cache)
-            return mu.double(), varn.double()
         ctx = _ops.Context.get(self.device)
+        if self.whitening == "ciq":
+            _, _, mu, varn = self._ciq_step64(ctx, params, x, None, D, 1.0, "ELBO", None, False, False)
+            return mu, varn
         params, _ = self._from_natural(ctx, params)
         if self.shared_directions:
             params = self._shared_predict_params(params)
@@ -277,10 +362,11 @@ class ElboEngine64(ElboEngine):
     def predict_joint(self, params, x, D, cache=False):
         """Mean [B'] and the full predictive covariance [B', B'] (fp64, likelihood noise on the diagonal):
         Sigma = s K_XX + 1e-4 I + W^T W - A^T A + noise I  (DGVS.py:199-208 + likelihood)"""
-        if self.whitening == "ciq":
-            mu, Sigma = self._ciq_call("predict_joint", params, x, D, cache=cache)
-            return mu.double(), Sigma.double()
         ctx = _ops.Context.get(self.device)
+        if self.whitening == "ciq":
+            # NGD-CIQ: the reference's q(f) carries a DIAGONAL covariance (CiqDGVS.py:264-267), see ElboEngine.predict_joint
+            _, _, mu, varn = self._ciq_step64(ctx, params, x, None, D, 1.0, "ELBO", None, False, False)
+            return mu, torch.diag(varn)
         params, _ = self._from_natural(ctx, params)
         if self.shared_directions:
             params = self._shared_predict_params(params)
@@ -310,11 +396,9 @@ class ElboEngine64(ElboEngine):
         """(loss, grads dict, mu, varn), all fp64; see ``ElboEngine.loss_and_grads`` for the arguments.  With natural parameters
         (``natural_vec``, ``natural_mat``) the gradients of those two slots are the expectation-parameter gradients NGD steps along."""
         if self.whitening == "ciq":
-            if x.dtype != f64 or y.dtype != f64:
-                raise TypeError("fp64 model mode: inputs must be float64")
-            loss, grads, mu, varn = self._ciq_call("loss_and_grads", params, x, y, D, num_data, mll_type=mll_type,
-                                                   global_rows=global_rows, include_kl=include_kl)
-            return loss.double(), {k: g.double() for k, g in grads.items()}, mu.double(), varn.double()
+            if mll_type not in ("ELBO", "PLL"):
+                raise ValueError("mll_type must be 'ELBO' or 'PLL'")
+            return self._ciq_step64(_ops.Context.get(self.device), params, x, y, D, num_data, mll_type, global_rows, include_kl, True)
         if getattr(self, "deterministic", False):
             # the bitwise-reproducible mode (fixed-order split-K slabs, one stream) is built for the fp32 engine only: the fp64
             # engine's transposed gemv and split-K products sum through fp64 atomics

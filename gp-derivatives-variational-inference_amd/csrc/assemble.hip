@@ -237,6 +237,9 @@ constexpr int FWD_PAIR_LDT = 52;
 #ifndef FWDP_MINW
 #define FWDP_MINW 1
 #endif
+#ifndef FWDP_LDS_EXTRA
+#define FWDP_LDS_EXTRA 0  // tools only: unused LDS bytes per wave (30720 -> 4 waves per CU = 1 per SIMD: the occupancy ablation)
+#endif
 #ifndef FWDP_CHUNK
 #define FWDP_CHUNK 1      // consecutive column tiles per wave (87.7 -> 85.7 us)
 #endif
@@ -1643,7 +1646,7 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
         if (ns < 1) ns = 1;
         if (ns > ctiles) ns = ctiles;
         const size_t p2w_ = 49 * (size_t)(g.K4 + 5), ttw_ = 48 * (size_t)FWD_PAIR_LDT;        // (49: the scratch row of the predicate-free staging)
-        const size_t lds = sizeof(float) * (FWDP_OVERLAY ? (FWDP_AREG ? 0 : 48 * (size_t)(g.K4 + 5)) + (p2w_ > ttw_ ? p2w_ : ttw_)
+        const size_t lds = FWDP_LDS_EXTRA + sizeof(float) * (FWDP_OVERLAY ? (FWDP_AREG ? 0 : 48 * (size_t)(g.K4 + 5)) + (p2w_ > ttw_ ? p2w_ : ttw_)
                                                          : 2 * 48 * (size_t)(g.K4 + 5) + 48 * (size_t)FWD_PAIR_LDT);
         const int esz = out_is_double ? 8 : 4;
         // bit 0: 2-wide stores of the micro-block rows; bit 1: 16-byte stores of lane pairs (float output, 16-byte aligned rows)

@@ -367,6 +367,27 @@ int dsvgp_ciq_rowstats(dsvgp_ctx* ctx, const float* T, const float* ST, int t, i
 int dsvgp_ciq_tbar(dsvgp_ctx* ctx, const float* T, const float* ST, int t, int n, const float* m, const float* mu_bar,
                    const float* var_bar, const float* live, const float* imean, float* Tbar, float* VT, float* cvec);
 int dsvgp_sym_average_f32(dsvgp_ctx* ctx, const float* A, int n, int64_t lda, float* out, int64_t ldo);
+/* The same entry points in double precision, for a model built under torch.set_default_dtype(torch.float64) with
+ * use_ciq=True (reference experiments/bunny/exp_bunny.py:66,78): every array is double, the arithmetic is the float64
+ * msMINRES of gpytorch run on a float64 LazyTensor; workspace of dsvgp_ciq_lanczos_f64: 3 n + 2 doubles.            */
+size_t dsvgp_ciq_workspace_bytes_f64(int Q, int t, int n, int cap);
+int dsvgp_ciq_lanczos_f64(dsvgp_ctx* ctx, const double* K, int64_t ldk, const double* v0, int n, int iters, double* alpha,
+                          double* beta, void* workspace);
+int dsvgp_ciq_solve_f64(dsvgp_ctx* ctx, const double* K, int64_t ldk, const double* R, int64_t ldr, int t, int n,
+                        const double* sigma, const double* omega, int Q, double tol, int max_iter, int check_every,
+                        double* basis, int cap, double* ycoef, double* rnorm, double* out, int64_t ldo, void* workspace,
+                        int* iters_out);
+int dsvgp_ciq_mix_f64(dsvgp_ctx* ctx, const double* basis, int J, int t, int n, const double* C, int ldj, int KP, int Kout,
+                      const double* rowscale, double* out, int64_t ldo);
+int dsvgp_ciq_cross_f64(dsvgp_ctx* ctx, const double* ya, int Ja, int lda, const double* yb, int Jb, int ldb,
+                        const double* omega, int Q, int t, const double* rn_a, const double* rn_b, double* Cout);
+int dsvgp_ciq_rowstats_f64(dsvgp_ctx* ctx, const double* T, const double* ST, int t, int n, int p, const double* m,
+                           const double* constant, const double* hyp, double kxx_jitter, double* imean, double* mu,
+                           double* var, double* live);
+int dsvgp_ciq_tbar_f64(dsvgp_ctx* ctx, const double* T, const double* ST, int t, int n, const double* m, const double* mu_bar,
+                       const double* var_bar, const double* live, const double* imean, double* Tbar, double* VT,
+                       double* cvec);
+int dsvgp_sym_average_f64(dsvgp_ctx* ctx, const double* A, int n, int64_t lda, double* out, int64_t ldo);
 
 /* ---- the whole ELBO step from ONE host call (round 3; csrc/step.hip)
  * dsvgp_elbo_step_f32 queues forward + backward of one minibatch ELBO evaluation -- `output = model(x, derivative_directions=D);

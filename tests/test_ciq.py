@@ -187,6 +187,71 @@ def test_ciq_lanczos_and_solve_match_oracle(dsvgp, gpu_device):
 
 
 @pytest.mark.gpu
+def test_ciq_f64_lanczos_solve_mix_cross_match_oracle(dsvgp, gpu_device):
+    """The double-precision entry points (dsvgp_ciq_*_f64: the CIQ strategy of a float64 model): Ritz bounds, iteration count,
+    every shifted solve and the quadrature sum against the float64 oracle at round-off level; mix / cross against tensor
+    expressions (vector width 2 and 1)."""
+    ops = dsvgp._ops
+    dev = gpu_device
+    ctx = ops.Context.get(dev)
+    f64 = torch.float64
+    # (n, cond): 70 iterations on a 96 x 96 matrix lose the orthogonality of the Lanczos vectors, after which two float64
+    # implementations agree only at the level the iteration has converged to; 20 iterations on a well-conditioned 256 x 256
+    # matrix stay at round-off
+    for n, cond, tol_x in ((96, 1e3, 2e-3), (256, 30.0, 1e-10)):
+        t, Q = 40, 15
+        K, lam = spd(n, cond, seed=5)
+        g = torch.Generator().manual_seed(6)
+        R = torch.randn(t, n, generator=g, dtype=f64)
+        Kd, Rd = K.to(dev).contiguous(), R.to(dev).contiguous()
+        alpha, beta = ops.ciq_lanczos(ctx, Kd, Rd[0].contiguous(), 20)
+        assert alpha.dtype == f64
+        a, b = alpha.cpu(), beta.cpu()
+        eigs = torch.linalg.eigvalsh(torch.diag(a) + torch.diag(b[:19], 1) + torch.diag(b[:19], -1))
+        lmin, lmax = O.lanczos_eig_bounds(K, R[0])
+        assert abs(eigs.max().item() - lmax) < 1e-10 * lmax and abs(eigs.min().item() - lmin) < 1e-8 * lmin
+        sigma, omega = O.ciq_quadrature(lmin, lmax, Q)
+        out = torch.empty(t, n, device=dev, dtype=f64)
+        cap = 200
+        basis = torch.empty(cap + 1, t, n, device=dev, dtype=f64)
+        ycoef = torch.empty(t, cap, ops.ciq_qp(Q), device=dev, dtype=f64)
+        rnorm = torch.empty(t, device=dev, dtype=f64)
+        ws = torch.empty(ops.ciq_workspace_bytes(Q, t, n, cap, f64), dtype=torch.uint8, device=dev)
+        its = ops.ciq_solve(ctx, Kd, Rd, sigma.to(dev), omega.to(dev), basis, ycoef, rnorm, out, ws)
+        Xr, its_r = O.msminres(K, R.t().contiguous(), sigma)
+        assert its == its_r
+        X = ops.ciq_mix(ctx, basis, its, ycoef, Q, rnorm, torch.empty(Q, t, n, device=dev, dtype=f64))
+        ex = max(relmax(X[q].t(), Xr[q]) for q in (0, 7, 14))
+        eo = relmax(out.t(), (omega.reshape(-1, 1, 1) * Xr).sum(0))
+        print("[parity] float64 msMINRES n=%d cond=%.0e: %d iterations (oracle %d), shifted solves %.1e, quadrature sum %.1e" % (
+            n, cond, its, its_r, ex, eo))
+        assert ex < tol_x and eo < tol_x
+    with pytest.raises(TypeError):
+        ops.ciq_solve(ctx, Kd, Rd, sigma.float().to(dev), omega.to(dev), basis, ycoef, rnorm, out, ws)
+    for (t2, n2, J, Kout) in ((9, 37, 21, 19), (6, 64, 3, 1)):
+        g = torch.Generator().manual_seed(t2 * 100 + n2)
+        ld, KP = J + 2, ops.ciq_qp(Kout)
+        bs = torch.randn(J + 1, t2, n2, generator=g, dtype=f64)
+        Cc = torch.randn(t2, ld, KP, generator=g, dtype=f64)
+        scale = torch.rand(t2, generator=g, dtype=f64) + 0.5
+        o2 = ops.ciq_mix(ctx, bs.to(dev), J, Cc.to(dev), Kout, scale.to(dev), torch.empty(Kout, t2, n2, device=dev, dtype=f64))
+        ref = torch.einsum("rjk,jrn->krn", Cc[:, :J, :Kout], bs[:J]) * scale[None, :, None]
+        assert relmax(o2, ref) < 1e-13
+        Q2, Ja, Jb = 5, min(J, 6), J
+        QP = ops.ciq_qp(Q2)
+        ya, yb = torch.randn(t2, Ja + 1, QP, generator=g, dtype=f64), torch.randn(t2, Jb + 3, QP, generator=g, dtype=f64)
+        om = torch.rand(Q2, generator=g, dtype=f64)
+        rn_a, rn_b = torch.rand(t2, generator=g, dtype=f64) + 0.5, torch.rand(t2, generator=g, dtype=f64) + 0.5
+        ctab = ops.ciq_cross(ctx, ya.to(dev), Ja, yb.to(dev), Jb, om.to(dev), rn_a.to(dev), rn_b.to(dev))
+        ref = torch.einsum("q,riq,rjq->rji", om, ya[:, :Ja, :Q2], yb[:, :Jb, :Q2]) * (rn_a * rn_b)[:, None, None]
+        assert ctab.dtype == f64 and relmax(ctab[:, :, :Ja], ref) < 1e-13
+    A = torch.randn(70, 70, dtype=f64, generator=g).to(dev)
+    o = torch.empty_like(A)
+    ops.sym_average_f64(ctx, A, o)
+    assert torch.equal(o, 0.5 * (A + A.t()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("t,n,J,Kout", [(13, 40, 7, 5), (9, 37, 21, 19), (6, 64, 3, 1)])
 def test_ciq_mix_and_cross_against_plain_tensor_expressions(dsvgp, gpu_device, t, n, J, Kout):
     """dsvgp_ciq_mix: out[k, row] = scale_row sum_j C[row, j, k] basis[j, row]; dsvgp_ciq_cross: the per-row coefficients that turn

@@ -380,8 +380,9 @@ def test_train_gp_with_ngd_under_float64_default(dsvgp, gpu_device):
 
 
 def test_fp64_model_with_ciq_strategy(dsvgp, gpu_device):
-    """train_gp(use_ciq=True) under a float64 default: the CIQ step of a float64 model runs on the fp32 CIQ kernels (msMINRES stops at
-    1e-4) and hands float64 gradients back -- same tolerances against the fp64 oracle as the fp32 model's test"""
+    """train_gp(use_ciq=True) under a float64 default (reference experiments/bunny/exp_bunny.py:66,78): the CIQ step of a float64
+    model runs the float64 msMINRES (csrc/ciq.hip ``*_f64``) on fp64 kernel matrices -- the same iteration count as the float64
+    oracle and its numbers to 1e-8 / 1e-6 (the fp32 CIQ step is held to 1e-3 / 2e-2 against the same oracle)"""
     from torch.utils.data import TensorDataset
     from dsvgp_amd._step64 import ElboEngine64
     from test_ngd import make_ngd_problem
@@ -393,14 +394,45 @@ def test_fp64_model_with_ciq_strategy(dsvgp, gpu_device):
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
     loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
     assert loss.dtype == f64 and all(v.dtype == f64 for v in grads.values()) and mu.dtype == f64
+
+    def errors(loss, grads, mu, varn):
+        e = {"loss": abs(loss.item() - l_ref.item()) / abs(l_ref.item()), "mu": relmax(mu, mu_ref), "var": relmax(varn, var_ref)}
+        for k in O.NGD_PARAM_NAMES:
+            if g_ref[k].numel() and g_ref[k].abs().max() > 0:
+                e["g_" + k] = relmax(grads[k], g_ref[k])
+        return e
+    # (a) as shipped: the spectrum interval from the engine's own 20 Lanczos steps.  The largest Ritz value is converged
+    # (1e-9), the smallest is not (K_ZZ has a cluster of tiny eigenvalues; the 20-step estimate moves by tens of percent with
+    # the rounding of the recurrence), so the two quadratures differ at the quadrature's own accuracy
+    assert abs(eng.ciq_stats["lmax"] - st["lmax"]) < 1e-9 * st["lmax"] and 0.3 * st["lmin"] < eng.ciq_stats["lmin"] < 3 * st["lmin"]
     assert abs(eng.ciq_stats["iterations"] - st["iterations"]) <= 10
-    assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
-    assert relmax(mu, mu_ref) < 5e-3 and relmax(varn, var_ref) < 5e-3
-    for k in O.NGD_PARAM_NAMES:
-        if g_ref[k].numel() and g_ref[k].abs().max() > 0:
-            assert relmax(grads[k], g_ref[k]) < 2e-2, k
+    errs = errors(loss, grads, mu, varn)
+    print("[parity] float64 model, float64 msMINRES vs the float64 oracle (own Lanczos bounds): %s" % ", ".join("%s %.2e" % kv for kv in errs.items()))
+    assert errs["loss"] < 1e-3 and errs["mu"] < 5e-3 and errs["var"] < 5e-3 and all(v < 2e-2 for k, v in errs.items() if k.startswith("g_")), errs
+    # (b) the same step on the oracle's interval: one quadrature, the same iteration count
+    eng.ciq_eig_bounds = (st["lmin"], st["lmax"])
+    loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+    errs = errors(loss, grads, mu, varn)
+    print("[parity] float64 model, float64 msMINRES vs the float64 oracle (oracle's bounds): iterations %d (oracle %d), %s" % (
+        eng.ciq_stats["iterations"], st["iterations"], ", ".join("%s %.2e" % kv for kv in errs.items())))
+    # measured: loss 1.4e-8, mean 1.5e-5, variance 1.1e-6, gradients <= 1.5e-5 -- not round-off: 30 Lanczos steps on a 60 x 60
+    # matrix lose orthogonality, and past that point two float64 recurrences agree to what the iteration has converged to
+    # (tests/test_ciq.py::test_ciq_f64_lanczos_solve_mix_cross_match_oracle shows both regimes: 4e-15 at 20 steps on a
+    # well-conditioned matrix).  The fp32 CIQ step sits at 1e-3 / 2e-2 against the same oracle.
+    assert eng.ciq_stats["iterations"] == st["iterations"]
+    assert errs["loss"] < 1e-6 and errs["mu"] < 1e-4 and errs["var"] < 1e-4, errs
+    assert all(v < 1e-4 for k, v in errs.items() if k.startswith("g_")), errs
     mu_p, var_p = eng.predict(Pg, x.to(gpu_device), D.to(gpu_device))
-    assert mu_p.dtype == f64 and relmax(mu_p, mu_ref) < 5e-3 and relmax(var_p, var_ref) < 5e-3
+    assert mu_p.dtype == f64 and relmax(mu_p, mu_ref) < 1e-4 and relmax(var_p, var_ref) < 1e-4
+    mu_j, Sig_j = eng.predict_joint(Pg, x.to(gpu_device), D.to(gpu_device))
+    assert Sig_j.dtype == f64 and relmax(torch.diagonal(Sig_j), var_ref) < 1e-4 and float((Sig_j - torch.diag(torch.diagonal(Sig_j))).abs().max()) == 0.0
+    for form in ("forward", "shifts"):                       # the other stackings of the backward's sum over shifts: the same matrix
+        eng.ciq_backward_form = form
+        _, g2, _, _ = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd)
+        for k in ("inducing_points", "inducing_directions", "raw_lengthscale", "raw_outputscale"):
+            assert relmax(g2[k], grads[k]) < 1e-9, (form, k, relmax(g2[k], grads[k]))
+    eng.ciq_backward_form = None
+    eng.ciq_eig_bounds = None
     # the harness: a float64 model with the CIQ strategy trains and evaluates
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
@@ -551,12 +583,16 @@ def test_other_harnesses_under_float64_default(dsvgp, gpu_device):
 @pytest.mark.parametrize("state", ["init", "mid"])
 def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, gpu_device, state):
     """The reference's bunny experiment runs ``use_ciq=True`` under ``torch.set_default_dtype(torch.float64)``
-    (experiments/bunny/exp_bunny.py:66,78).  Here the float64 model's CIQ step runs on the fp32 CIQ kernels (csrc/ciq.hip; a
-    float64 msMINRES is not built -- DESIGN.md section 9), so its distance to FLOAT64 arithmetic is MEASURED at BASELINE config 5
-    size (M' = 6144, B' = 3072, Q = 15) against the oracle evaluated in float64 (tests/golden/c5_step_{init,mid}64.npz,
-    oracle/make_c5_fixture.py init64 / mid64; 190 s and 1530 s of 8 CPU cores) and held to: loss 1e-6; ``init`` moments 1e-6,
-    gradients 1e-5 except dZ 2e-2 / dV 2e-3 (the state where 1 / lengthscale^2 = 1e6 amplifies fp32 cancellation in the kernel
-    backward); ``mid`` mean 4e-3, variance 1e-4, gradients 6e-3."""
+    (experiments/bunny/exp_bunny.py:66,78).  Here that is the float64 msMINRES of csrc/ciq.hip (``*_f64``) on fp64 kernel matrices,
+    held at BASELINE config 5 size (M' = 6144, B' = 3072, Q = 15) to the oracle evaluated in float64
+    (tests/golden/c5_step_{init,mid}64.npz, oracle/make_c5_fixture.py init64 / mid64; 190 s and 1530 s of 8 CPU cores), on the
+    oracle's spectrum interval (one quadrature for both).
+    ``init`` (10 iterations): the same count, everything at round-off -- 1e-9 asserted, measured loss / moments 4e-16, dZ 1.5e-11,
+    dV 1.8e-12 (on the fp32 CIQ kernels, through round 3: dZ 7e-3, dV 5e-4, the rest 2e-7).
+    ``mid`` (80-90 iterations): the Lanczos vectors have lost orthogonality long before the stopping test passes, so two float64
+    recurrences agree to what the iteration has converged to (tolerance 1e-4 on the mean relative update; HIP stops at 80, the
+    oracle at 90): measured loss 4e-8, mean 4.6e-4, variance 1.1e-6, gradients <= 1.0e-3 -- asserted 1e-6 / 2e-3 / 1e-5 / 4e-3
+    (fp32 kernels: mean 1.2e-3, gradients 2.2e-3)."""
     import numpy as np
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
     from make_c5_fixture import make_inputs, Q
@@ -566,6 +602,7 @@ def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, g
     eng = ElboEngine64(gpu_device)
     eng.whitening = "ciq"
     eng.ciq_num_quadrature = Q
+    eng.ciq_eig_bounds = (float(g["lmin"]), float(g["lmax"]))        # the oracle's spectrum interval: one quadrature for both
     Pg = {k: v.double().to(gpu_device) for k, v in P.items()}
     loss, grads, mu, varn = eng.loss_and_grads(Pg, x.double().to(gpu_device), y.double().to(gpu_device), D.double().to(gpu_device), nd)
     torch.cuda.synchronize()
@@ -579,21 +616,18 @@ def test_fp64_model_ciq_step_at_c5_size_measured_against_float64_oracle(dsvgp, g
     for k in O.NGD_PARAM_NAMES:
         if k != "natural_mat" and t("g_" + k).numel() and t("g_" + k).abs().max() > 0:
             errs["g_" + k] = relmax(grads[k], t("g_" + k))
-    print("[parity] float64 model, CIQ step on the fp32 CIQ kernels, C5 %s vs the float64 oracle: iterations %d (oracle %d), %s" % (
+    print("[parity] float64 model, float64 msMINRES, C5 %s vs the float64 oracle: iterations %d (oracle %d), %s" % (
         state, eng.ciq_stats["iterations"], int(g["iterations"]), ", ".join("%s %.2e" % kv for kv in errs.items())))
-    # measured (MI355X): init  loss 5e-8, moments 4e-8, dZ 7.0e-3, dV 4.7e-4, every other gradient <= 2.2e-7;
-    #                    mid   loss 6e-8, mu 1.2e-3, var 2.7e-6, gradients <= 2.2e-3 (natural_vec; msMINRES stopped at the same
-    #                          1e-4 mean relative update in both arithmetics, 90 iterations each)
-    tol_loss, tol_mu, tol_var = (1e-6, 1e-6, 1e-6) if state == "init" else (1e-6, 4e-3, 1e-4)
+    if state == "init":
+        assert eng.ciq_stats["iterations"] == int(g["iterations"])
+        tol_loss, tol_mu, tol_var, tol_g = 1e-9, 1e-9, 1e-9, 1e-9
+    else:
+        assert abs(eng.ciq_stats["iterations"] - int(g["iterations"])) <= 10
+        tol_loss, tol_mu, tol_var, tol_g = 1e-6, 2e-3, 1e-5, 4e-3
     assert errs["loss"] < tol_loss and errs["mu"] < tol_mu and errs["var"] < tol_var, errs
     for k, v in errs.items():
         if k.startswith("g_"):
-            tol = 1e-5 if state == "init" else 6e-3
-            if state == "init" and k == "g_inducing_points":
-                tol = 2e-2
-            if state == "init" and k == "g_inducing_directions":
-                tol = 2e-3
-            assert v < tol, (k, v)
+            assert v < tol_g, (k, v)
 
 
 def test_fp64_fused_adam_matches_torch_adam(dsvgp, gpu_device):
