@@ -100,6 +100,7 @@ SIGNATURES = {
     "dsvgp_colstats_f64": (_i, [_p, _p, _l, _p, _l, _p, _i, _i, _p, _p]),
     "dsvgp_abar_f64": (_i, [_p, _p, _l, _p, _l, _p, _p, _p, _i, _i, _p, _l, _p, _l]),
     "dsvgp_likelihood_terms_f64": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _i, _d, _p, _p, _p, _p, _p]),
+    "dsvgp_elbo_fast_tail_f64": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _d, _p, _p, _p]),
     "dsvgp_potrf_workspace_bytes": (_z, [_i, _i]),
     "dsvgp_potrf": (_i, [_p, _p, _i, _l, _p, _i, _p]),
     "dsvgp_add_diag": (_i, [_p, _p, _i, _l, _d]),

@@ -293,6 +293,20 @@ def likelihood_terms_f64(ctx, mu0, cs, y, constant, p, hyp, mll_type, rows):
     return mu, varn, mu_bar, var_bar, scal
 
 
+def elbo_fast_tail_f64(ctx, mu0, y, constant, npts, pd, hyp, tvar, rows):
+    """(mu, mu_bar, scal[8]) of the fp64 ELBO fast path's scalar tail in two launches (see dsvgp.h): scal = {sum ll, d/d noise,
+    d/d constant, d/d outputscale, d/d lengthscale, vbar, sum r^2, sum r}"""
+    n = mu0.shape[0]
+    dev = mu0.device
+    mu, mu_bar = torch.empty(n, dtype=f64, device=dev), torch.empty(n, dtype=f64, device=dev)
+    scal = torch.empty(8, dtype=f64, device=dev)
+    check(lib.dsvgp_elbo_fast_tail_f64(ctx.h, _ptr(_req(mu0, f64, "mu0", 1)), _ptr(_req(y, f64, "y", 1)),
+                                       _ptr(_req(constant, f64, "constant", 1)), n, int(npts), int(pd), _ptr(_req(hyp, f64, "hyp", 1)),
+                                       _ptr(_req(tvar.reshape(1), f64, "tvar", 1)), float(rows), _ptr(mu), _ptr(mu_bar), _ptr(scal)),
+          "dsvgp_elbo_fast_tail_f64")
+    return mu, mu_bar, scal
+
+
 def kernel_diag(ctx, n, p, hyp):
     out = torch.empty(n * (p + 1), dtype=f32, device=hyp.device)
     check(lib.dsvgp_kernel_diag(ctx.h, n, p, _ptr(hyp), _ptr(out)), "dsvgp_kernel_diag")

@@ -8,8 +8,10 @@ and the ELBO are then all fp64.  ``ElboEngine64`` is that mode of ``directional_
   * every O(M'^2 d), O(M' B' d), O(M'^3) and O(M'^2 B') term runs on the library's own HIP kernels -- the fp64 kernel assembly
     (csrc/assemble64.hip: T = P1 P2^T on the fp64 MFMA GEMM + per-pair transforms), the blocked MFMA Cholesky with fused inverse
     (csrc/potrf.hip), the triangular products (csrc/gemm64.hip / gemm.hip) and the column statistics (assemble64.hip);
-  * the O(B') likelihood terms, the O(M'^2) KL term and the softplus constraints are elementwise torch fp64 tensor
-    expressions on the device, differentiated by autograd exactly like the reference does (directional_vi.py:245-249).
+  * the O(B') likelihood terms and the scalar tail are closed-form launches too (dsvgp_likelihood_terms_f64 for the general path,
+    dsvgp_elbo_fast_tail_f64 for the Gram formulation); the O(M'^2) KL term and the softplus slopes are elementwise torch fp64
+    expressions in closed form.  Nothing goes through torch.autograd (the reference differentiates the same expressions by
+    autograd, directional_vi.py:245-249).
 
 Two formulations, as in the fp32 engine: the general (variance-carrying) one covers ELBO and PLL; in ELBO mode, when the caller
 does not read the per-output variances, the Gram-matrix formulation (``_elbo_fast64``) needs three [M', B'] products instead
@@ -19,8 +21,6 @@ summed by one all-reduce at the end of the step (no early operand).  No CPU fall
 Shared inducing directions run in fp64 (``_shared_step64``), and so does the CIQ strategy of a float64 model (``_ciq_step64``:
 fp64 msMINRES, the ``*_f64`` entry points of csrc/ciq.hip).
 """
-import math
-
 import torch
 import torch.nn.functional as F
 
@@ -60,10 +60,9 @@ class ElboEngine64(ElboEngine):
         if self.whitening != "cholesky":
             raise NotImplementedError("fp64 model mode: whitening must be 'cholesky' here (CIQ goes through _ciq_step64)")
 
-    def _hyp64(self, params, grad=False):
-        """(raw leaves, hyp[4] = {lengthscale, outputscale, noise, 0}): gpytorch Positive / GreaterThan(1e-4) softplus constraints"""
-        raw = [params[k].detach().reshape(()).clone().requires_grad_(grad)
-               for k in ("raw_lengthscale", "raw_outputscale", "raw_noise")]
+    def _hyp64(self, params):
+        """(raw values, hyp[4] = {lengthscale, outputscale, noise, 0}): gpytorch Positive / GreaterThan(1e-4) softplus constraints"""
+        raw = [params[k].detach().reshape(()) for k in ("raw_lengthscale", "raw_outputscale", "raw_noise")]
         ell, s, noise = F.softplus(raw[0]), F.softplus(raw[1]), F.softplus(raw[2]) + NOISE_FLOOR
         return raw, (ell, s, noise), torch.stack([ell, s, noise, torch.zeros_like(ell)]).detach().contiguous()
 
@@ -503,7 +502,7 @@ class ElboEngine64(ElboEngine):
         Kzzbar = self._chol_backward(ctx, L, Lbar, ws, Mp, phi_arg=phi_arg)
         scratch = self._get("T_zz", (Mp, Mp), f64)
         _ops.kernel_bwd_f64(ctx, Kzzbar, packZ, M, packZ, M, d, p, hyp, True, dZ, dV, d_hyp, scratch)
-        # softplus chain rule of the kernel hyper-parameters; autograd already holds the likelihood / prior-diagonal parts
+        # softplus chain rule of the kernel hyper-parameters; d_raw already holds the likelihood / prior-diagonal parts
         sig = [torch.sigmoid(params[k].reshape(())) for k in ("raw_lengthscale", "raw_outputscale")]
         grads["raw_lengthscale"].add_((d_raw[0] + d_hyp[0] * sig[0]).reshape(grads["raw_lengthscale"].shape))
         grads["raw_outputscale"].add_((d_raw[1] + d_hyp[1] * sig[1]).reshape(grads["raw_outputscale"].shape))
@@ -549,30 +548,17 @@ class ElboEngine64(ElboEngine):
         Gs = Gs + torch.tril(G, -1).t()                             # the symmetric G
         G.copy_(Gs)
         _ops.gemm(ctx, B_LOWER | OUT_LOWER, G, LSl, H)                                    # tril(G L_S): nothing else of it is read
-        tvar = ((H * LSl).sum() - torch.diagonal(G).sum()).detach()                     # tr(L_S^T G L_S) - tr G
-        with torch.enable_grad():
-            raw, (ell, s, noise), _ = self._hyp64(params, grad=True)
-            mu0_ = mu0.requires_grad_(True)
-            tvar_ = tvar.requires_grad_(True)
-            c_ = params["constant"].detach().reshape(()).clone().requires_grad_(True)
-            m_ = m.detach().clone().requires_grad_(True)
-            LS_ = LS.detach().clone().requires_grad_(True)
-            mu = mu0_ + c_
-            sum_varn = self._prior_diag(B, p, pd, ell, s, x).sum() + Bp * (KXX_JITTER + noise) + tvar_
-            ll = -0.5 * ((((y - mu) ** 2).sum() + sum_varn) / noise + Bp * (torch.log(noise) + math.log(2 * math.pi)))
-            loss = -ll / rows
-            if include_kl:
-                LSt = torch.tril(LS_)
-                kl = 0.5 * ((m_ * m_).sum() + (LSt * LSt).sum() - Mp - torch.log(torch.diagonal(LSt) ** 2).sum())
-                loss = loss + kl / num_data
-            leaves = [mu0_, tvar_, c_, raw[0], raw[1], raw[2]] + ([m_, LS_] if include_kl else [])
-            g = torch.autograd.grad(loss, leaves, allow_unused=True)
-        mu_bar, vbar = g[0].contiguous(), g[1]                      # vbar = 1 / (2 noise rows)
+        tvar = (H * LSl).sum() - torch.diagonal(G).sum()                                # tr(L_S^T G L_S) - tr G
+        # scalar tail in closed form (dsvgp_elbo_fast_tail_f64: two launches; the KL term and the softplus slopes as in the general path)
+        const = params["constant"].reshape(1).contiguous()
+        mu, mu_bar, scal = _ops.elbo_fast_tail_f64(ctx, mu0, y.contiguous(), const, B, pd, hyp, tvar, rows)
+        loss = -scal[0] / rows
+        vbar = scal[5]                                              # d loss / d (sum of variances) = 1 / (2 noise rows)
         grads = {k: torch.zeros_like(params[k]) for k in PARAM_NAMES}
         dm, dLS = grads["variational_mean"], grads["chol_variational_covar"]
         if include_kl:
-            dm.add_(g[6])
-            dLS.add_(g[7])
+            loss = loss + self._kl64(m, LS, Mp, num_data, dm, dLS)
+        d_raw = self._raw_grads64(params, scal)
         dLS.add_(torch.tril(H) * (2.0 * vbar))                                            # 2 vbar tril(G L_S)
         Ae[Mp].copy_(mu_bar)
         b = torch.empty(Mp, dtype=f64, device=dev)
@@ -605,5 +591,5 @@ class ElboEngine64(ElboEngine):
         #     tril(L^T L-bar) = -tril([2 vbar (S - I) | m][G ; b^T])            -- one product instead of two
         Se[:, :Mp].mul_(2.0 * vbar)
         _ops.gemm(ctx, OUT_LOWER, Se, Ge, Lbar, alpha=-1.0)
-        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, g[2], g[3:6], phi_arg=True)
-        return loss.detach(), grads, mu.detach(), torch.empty(0, dtype=f64, device=dev)
+        self._kernel_part64(ctx, params, hyp, packZ, packX, L, Lbar, Kb, dims, ws, B, pd, grads, scal[2], d_raw, phi_arg=True)
+        return loss, grads, mu, torch.empty(0, dtype=f64, device=dev)

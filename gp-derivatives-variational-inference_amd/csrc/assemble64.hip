@@ -289,7 +289,69 @@ __global__ __launch_bounds__(256) void likelihood64_kernel(const double* __restr
     if (threadIdx.x < 5) atomicAdd(&scal[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// Scalar tail of the fp64 ELBO fast path (ElboEngine64._elbo_fast64): the variance enters the ELBO only through its sum, so
+// per output just  mu = mu0 + c,  mu_bar = d loss / d mu0 = -(y - mu) / (noise rows)  and the sums of r^2 and r (scal[6..7]) ...
+__global__ __launch_bounds__(256) void fast_tail64_kernel(const double* __restrict__ mu0, const double* __restrict__ y,
+                                                          const double* __restrict__ constant, int ncols,
+                                                          const double* __restrict__ hyp, double inv_rows,
+                                                          double* __restrict__ mu_out, double* __restrict__ mu_bar,
+                                                          double* __restrict__ scal) {
+    __shared__ double red[2][4];
+    const double noise = hyp[2], c = constant[0];
+    const double k = -inv_rows / noise;
+    double a0 = 0.0, a1 = 0.0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < ncols; j += gridDim.x * 256) {
+        const double mj = mu0[j] + c, r = y[j] - mj;
+        mu_out[j] = mj;
+        mu_bar[j] = k * r;
+        a0 += r * r;
+        a1 += r;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); }
+    if (lane == 0) { red[0][wave] = a0; red[1][wave] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2) atomicAdd(&scal[6 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+// ... and the closed forms (one thread): sum_j var_j + noise = s npts (1 + pd / ell^2) + ncols (1e-4 + noise) + tvar,
+// ll = -1/2 [(sum r^2 + that) / noise + ncols (log noise + log 2 pi)]  (expected_log_prob summed, directional_vi.py:245-246);
+// scal = {ll, d loss / d noise, d / d constant, d / d outputscale, d / d lengthscale, vbar = d loss / d tvar, sum r^2, sum r}
+__global__ void fast_tail64_final_kernel(const double* __restrict__ hyp, const double* __restrict__ tvar, int ncols, int npts,
+                                         int pd, double inv_rows, double* __restrict__ scal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ell = hyp[0], s = hyp[1], noise = hyp[2];
+    const double LOG2PI = 1.8378770664093454835606594728112;
+    const double SS = scal[6], SR = scal[7];
+    const double dgsum = (double)npts * (1.0 + (double)pd / (ell * ell));
+    const double sum_varn = s * dgsum + (double)ncols * (1e-4 + noise) + tvar[0];
+    const double vbar = 0.5 * inv_rows / noise;
+    scal[0] = -0.5 * ((SS + sum_varn) / noise + (double)ncols * (log(noise) + LOG2PI));
+    scal[1] = -(0.5 * (SS + sum_varn) / (noise * noise) - (double)ncols / noise) * inv_rows;
+    scal[2] = -SR * inv_rows / noise;
+    scal[3] = vbar * dgsum;
+    scal[4] = vbar * s * (double)npts * (double)pd * (-2.0 / (ell * ell * ell));
+    scal[5] = vbar;
+}
+
 }  // namespace
+
+extern "C" int dsvgp_elbo_fast_tail_f64(dsvgp_ctx* ctx, const double* mu0, const double* y, const double* constant, int ncols,
+                                        int npts, int pd, const double* hyp, const double* tvar, double rows, double* mu,
+                                        double* mu_bar, double* scal) {
+    if (!ctx || !mu0 || !y || !constant || !hyp || !tvar || !mu || !mu_bar || !scal || ncols <= 0 || npts <= 0 || pd < 0 ||
+        ncols != npts * (pd + 1) || rows <= 0.0)
+        return DSVGP_EINVAL;
+    hipError_t e = hipMemsetAsync(scal, 0, sizeof(double) * 8, ctx->stream);
+    if (e != hipSuccess) return 1000 + (int)e;
+    int blocks = cdiv(ncols, 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(fast_tail64_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mu0, y, constant, ncols, hyp, 1.0 / rows, mu,
+                       mu_bar, scal);
+    DSVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fast_tail64_final_kernel, dim3(1), dim3(64), 0, ctx->stream, hyp, tvar, ncols, npts, pd, 1.0 / rows, scal);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dsvgp_likelihood_terms_f64(dsvgp_ctx* ctx, const double* mu0, const double* cs, const double* y, const double* constant,
                                           int ncols, int p, const double* hyp, int mll_type, double rows, double* mu, double* varn,

@@ -134,6 +134,12 @@ int dsvgp_abar_f64(dsvgp_ctx* ctx, const double* A, int64_t lda, const double* U
 int dsvgp_likelihood_terms_f64(dsvgp_ctx* ctx, const double* mu0, const double* cs, const double* y, const double* constant,
                                int ncols, int p, const double* hyp, int mll_type, double rows, double* mu, double* varn,
                                double* mu_bar, double* var_bar, double* scal);
+/* scalar tail of the fp64 ELBO fast path (the variances enter the ELBO only through their sum: tvar[0] = tr(L_S^T G L_S) - tr G on
+ * the device): mu = mu0 + constant, mu_bar = d loss / d mu0, and scal[8] = {sum ll, d loss / d noise, d / d constant, d / d outputscale,
+ * d / d lengthscale (prior-diagonal parts), vbar = d loss / d tvar = 1 / (2 noise rows), sum r^2, sum r}; ncols = npts (pd + 1) outputs
+ * (GaussianLikelihood.expected_log_prob summed, VariationalELBO: directional_vi.py:217,245-246)                                   */
+int dsvgp_elbo_fast_tail_f64(dsvgp_ctx* ctx, const double* mu0, const double* y, const double* constant, int ncols, int npts, int pd,
+                             const double* hyp, const double* tvar, double rows, double* mu, double* mu_bar, double* scal);
 int dsvgp_kernel_bwd_points_f64(dsvgp_ctx* ctx, const double* dP, const double* P1, const double* vnorm1, int n1, int d,
                                 int p, const double* hyp, int symmetric, double* d_x1, double* d_v1);
 
