@@ -14,7 +14,7 @@ namespace {
 constexpr int NBC = 64;
 
 #ifndef POTRF_NW
-#define POTRF_NW 4          // waves per workgroup of the step launches: 4; 8 (each 64 x 64 tile product split 32 x 16 per wave) measured slower at M' = 3000 (1.78-1.93 vs 1.70 ms), 5 % faster at 600
+#define POTRF_NW 4          // waves per workgroup of the step launches: 4; 8 (each 64 x 64 tile product split 32 x 16 per wave) measured slower at M' = 3000 (1.78-1.93 vs 1.70 ms); at 600 5 % faster in round 2, 28 % slower on the round-4 kernel (0.319 vs 0.249 ms)
 #endif
 #ifndef POTRF_NEWTON
 #define POTRF_NEWTON 2
