@@ -104,6 +104,10 @@ class ElboEngine:
         # split products on the bf16 matrix pipe (six bf16 MFMA products per fp32 product, fp32 accumulation; csrc/gemm3b.hip).
         # The default computes them on v_mfma_f32_32x32x2_f32.
         self.split_bf16 = os.environ.get("DSVGP_SPLIT_BF16", "0") == "1"
+        # flag 64 of the one-call step: tril(L^T L-bar) = -tril([S - I | m'][G ; b^T]) with fp64 accumulation.  Default off: both
+        # operands are fp32 data and G carries sqrt(M') times the error fp32 accumulation adds, so the product runs on the fp32
+        # LDS-DMA kernel and only its result is widened (csrc/step.hip, chol_tail)
+        self.phi_arg_fp64 = os.environ.get("DSVGP_PHI_ARG_FP64", "0") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -1081,7 +1085,7 @@ class ElboEngine:
         if self.record_events:
             self._rec_count += 1
         flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if timed else 0) \
-            | (16 if self.tail_side else 0)
+            | (16 if self.tail_side else 0) | (64 if self.phi_arg_fp64 else 0)
         io.split_ws, io.split_ws_bytes = None, 0
         if self.split_bf16 and Mp >= 256 and Bp >= 256:
             sws = self._bytes("cstep_split_ws", int(_lib.lib.dsvgp_elbo_step_split_bytes(M, d, p, B)))

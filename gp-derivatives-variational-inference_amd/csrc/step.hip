@@ -246,6 +246,9 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
     return 0;
 }
 
+#ifndef STEP_PHI64
+#define STEP_PHI64 0        // 1: tril(L^T L-bar) always with fp64 accumulation (probes; flag 64 of the step does the same at run time)
+#endif
 #define STEP_CALL(expr)                 \
     do {                                \
         const int rc__ = (expr);        \
@@ -328,6 +331,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     else STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
     if (pl->pad_ready_for != workspace || (flags & 8)) {
         STEP_HIP(hipMemsetAsync(Qe32, 0, (size_t)Mp * ldQ32 * sizeof(float), main));
+        STEP_HIP(hipMemsetAsync(S32e, 0, (size_t)Mp * ldS * sizeof(float), main));       // (pad columns of [S - I | m']: a k-contiguous operand of the fp32 kernels)
         pl->pad_ready_for = workspace;
     }
     struct PrezeroGuard {               // (the flag must not outlive the call, whatever path returns)
@@ -452,9 +456,31 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // -- ONE product of two matrices the step already holds (fp64 accumulation, fp64 copy of the left operand from the prologue)
     // instead of L-bar (M'^3) followed by L^T L-bar (M'^3 / 3); neither L-bar nor the fp64 [Q' | a] is formed.  (Round 4.)
     const double* Linv = (const double*)trsm_ws;
-    auto chol_tail = [&]() -> int {
-        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldST, Ge, Mp,
-                            0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
+    // Both operands of that product are fp32 DATA (S = L_S L_S^T and G = A A^T come out of fp32 MFMA products; the fp64 copy of
+    // the left one is a widening), and G carries 2e-6 of its largest entry per element -- sqrt(M') times more than what fp32
+    // accumulation of this product adds.  So the product itself runs on the fp32 LDS-DMA kernel (gemm32.hip, 2x the fp64 rate;
+    // result into the [Q' | a] scratch, free once the dense product has read it) and only its RESULT is widened for the fp64
+    // Cholesky backward.  STEP_PHI64 / flag 64 / shapes gemm32 does not take: the fp64-accumulated form.
+    auto phi_arg = [&](bool qe32_free) -> int {
+#if !STEP_PHI64
+        if (qe32_free && !(flags & 64)) {
+            GemmArgs g{};
+            g.M = Mp; g.N = Mp; g.K = Mp + 1; g.A = S32e; g.lda = ldS; g.B = Ge; g.ldb = Mp; g.C = Qe32; g.ldc = ldQ32;
+            g.alpha = -1.0; g.beta = 0.0; g.flags = DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED; g.batch = 1; g.splitk = 1;
+            g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
+            const int rc = launch_gemm32(ctx->stream, g);          // (clears the output itself: Qe32 is not part of the prezeroed arena)
+            if (rc > 1) return rc;
+            if (rc == 1) {
+                launch_widen_f32_f64(ctx->stream, Qe32, ldQ32, G1, Mp, Mp, Mp);
+                return hipGetLastError() == hipSuccess ? 0 : 1000 + (int)hipGetLastError();
+            }
+        }
+#endif
+        return dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldST, Ge, Mp,
+                          0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
+    };
+    auto chol_tail = [&](bool qe32_free) -> int {
+        int rc = phi_arg(qe32_free);
         if (rc) return rc;
         rc = dsvgp_phi_symmetrize(ctx, G1, Mp, Mp);
         if (rc) return rc;
@@ -481,7 +507,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
             STEP_HIP(hipEventRecord(pl->ev_dense, main));           // ([Q' | a] is final)
             STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
             ctx->stream = side;
-            STEP_CALL(chol_tail());
+            STEP_CALL(chol_tail(false));                            // ([Q' | a] is being read by the dense product beside it)
             STEP_HIP(hipEventRecord(pl->ev_zx, side));
             ctx->stream = main;
         }
@@ -504,7 +530,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         ctx->stream = main;
     }
     if (!tail_side) {
-        STEP_CALL(chol_tail());                                     // (its first product does not need the variational block)
+        STEP_CALL(chol_tail(true));                                 // (its first product does not need the variational block)
         if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
     }
     if (!zx_side) {

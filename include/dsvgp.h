@@ -409,7 +409,9 @@ int dsvgp_sym_average_f64(dsvgp_ctx* ctx, const double* A, int n, int64_t lda, d
  *   flags      1: overlap on the plan's second stream; 2: include the KL term (data-parallel ranks > 0 leave it out); 4: record
  *              HIP-event timings (dsvgp_elbo_step_timings); 8: the workspace contents are undefined (re-clear the paddings);
  *              16 (with 1): the Cholesky backward on the second stream under the dense K_ZX-bar product (probe: no gain);
- *              32: the two big fp32 products as bf16 x 3 split products (io->split_ws; opt-in, see dsvgp_split3_bf16)
+ *              32: the two big fp32 products as bf16 x 3 split products (io->split_ws; opt-in, see dsvgp_split3_bf16);
+ *              64: tril(L^T L-bar) = -tril([S - I | m'][G ; b^T]) with fp64 accumulation (default: both operands are fp32 data, the
+ *              product runs on the fp32 MFMA kernel and its result is widened for the fp64 Cholesky backward)
  * Gradients are those of loss = -(sum_j ll_j / global_rows - KL / num_data); a factorisation that fails leaves NaNs in the
  * outputs and a non-zero status word: read it with dsvgp_elbo_step_status (waits for the factorisation only, not for the step)
  * and run the jitter ladder on the piecewise path.  Threading: one host thread per context.                                  */
