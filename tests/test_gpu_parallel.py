@@ -11,6 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from _mpfiles import FileDict
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -101,10 +103,9 @@ def dp_results(gpu_device):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
-    out = mgr.dict()
+    out = FileDict()
     mp.spawn(_worker, args=(3, port, out), nprocs=3, join=True)
-    return {r: out[r] for r in range(3)}
+    return out.collect(range(3))
 
 
 @pytest.mark.timeout(600)
@@ -223,9 +224,9 @@ def test_every_train_gp_mirror_runs_data_parallel(dsvgp, gpu_device):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
-    out = mgr.dict()
+    out = FileDict()
     mp.spawn(_harness_worker, args=(2, port, out), nprocs=2, join=True)
+    out = out.collect(range(2))
     for name, run in _harness_cases(dsvgp):
         torch.manual_seed(100)
         model, likelihood = run()
@@ -294,9 +295,9 @@ def test_multi_rank_schedules_on_an_rccl_communicator(dsvgp, gpu_device):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
-    out = mgr.dict()
+    out = FileDict()
     mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    out = out.collect(range(1))
     res = out[0]
     for gg in (True, False):
         dl, dLS, dm, dZ = res[gg]
@@ -348,9 +349,9 @@ def test_sharded_stage_at_c4_shard_geometry_against_reference_text(dsvgp, gpu_de
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
-    out = mgr.dict()
+    out = FileDict()
     mp.spawn(_c4shard_worker, args=(2, port, out), nprocs=2, join=True)
+    out = out.collect(range(2))
     from test_gpu_reftext import TOL32
     tol_loss, tol_head, tol_grad = TOL32["c4shard"]
     for name in ("one-call", "piecewise"):

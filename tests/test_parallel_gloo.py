@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from _mpfiles import FileDict
+
 import dsvgp_oracle as O
 
 
@@ -147,9 +149,9 @@ def test_two_rank_gloo_equals_single_process():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mgr = mp.Manager()
-    out = mgr.dict()
+    out = FileDict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    out = out.collect(range(2))
     P, x, y, D, nd, p = _problem()
     l_ref, g_ref, _, _ = O.elbo_loss_and_grads(P, x, y, D, nd)
     assert out[0][2] == (0, 6) and out[1][2] == (6, 11)            # ragged tail goes to the low rank
