@@ -75,7 +75,6 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp);                                       // assemble.hip
 int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows);   // elbo.hip
-int launch_tril_copy_f32(hipStream_t st, const float* src, int64_t lds, float* dst, int64_t ldd, int n);    // elbo.hip: dst = tril(src), zero above
 int launch_variational_terms(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int flags,
                              const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,
                              float* sums, const float* dm_src, float* d_m, float* d_LS, int64_t lddls, int fin_npts, int fin_p,

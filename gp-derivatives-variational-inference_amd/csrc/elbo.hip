@@ -1054,19 +1054,6 @@ __global__ void mirror_sminus_kernel(float* __restrict__ G, int n, int64_t ldg, 
         }
     }
 }
-// dst[i][j] = src[i][j] for j <= i, 0 above the diagonal (n x n; dst rows of ldd floats are written up to column n - 1)
-__global__ __launch_bounds__(256) void tril_copy_f32_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
-                                                            int64_t ldd, int n) {
-    const int i = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < n) dst[(int64_t)i * ldd + j] = j <= i ? src[(int64_t)i * lds + j] : 0.f;
-}
-int launch_tril_copy_f32(hipStream_t st, const float* src, int64_t lds, float* dst, int64_t ldd, int n) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(tril_copy_f32_kernel, dim3(cdiv(n, 256), n), dim3(256), 0, st, src, lds, dst, ldd, n);
-    DSVGP_LAUNCH_CHECK();
-    return 0;
-}
 int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows) {
     const int nb = cdiv(n, 32);
     hipLaunchKernelGGL(mirror_sminus_kernel, dim3(nb, nb), dim3(32, 8), 0, st, A, n, lda, m, hyp, rows);

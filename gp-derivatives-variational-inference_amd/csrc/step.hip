@@ -50,7 +50,7 @@ struct dsvgp_step_plan {
     size_t o_zero, zero_bytes;        // region cleared at the start of every step: info, sums, kl_buf
     size_t o_info, o_sums, o_klbuf, o_scal, o_hyp, o_center;
     size_t o_PZ, o_sZ, o_vZ, o_PX, o_sX, o_vX;
-    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_S64e, o_Qe32, o_Kb32, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2, o_LSl;
+    size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_S64e, o_Qe32, o_Kb32, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2;
     size_t o_arena, arena_bytes;     // contiguous region of everything a launcher would clear (see step_layout)
     int ldS, ldQ32;
     const void* pad_ready_for = nullptr;          // the workspace whose Qe32 pad columns have been zeroed
@@ -83,7 +83,6 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     pl->o_var0 = c.take((size_t)Bp * 4); pl->o_stats = c.take(dsvgp_stats_workspace_bytes(Mp, Bp) + 16);
     pl->o_Qe32 = c.take((size_t)Mp * pl->ldQ32 * 4);
     pl->o_S64e = c.take((size_t)(Mp + 1) * ((Mp + 1) / 2 * 2) * 8);      // fp64 [S - I ; m^T / (2 vbar)], (M'+1) x M' (rewritten every step)
-    pl->o_LSl = c.take((size_t)Mp * pad4(Mp) * 4);                        // tril(L_S), upper triangle zero (rewritten every step)
     const size_t kb = dsvgp_kernel_bwd_workspace_bytes(M, B, d, p), kz = dsvgp_kernel_bwd_workspace_bytes(M, M, d, p);
     pl->o_kbwd = c.take(kb > kz ? kb : kz); pl->o_kbwd2 = c.take(kb);
     // ---- the "arena": every buffer that some launcher clears before use (split-K targets, OUT_LOWER outputs), contiguous, so that
@@ -296,7 +295,6 @@ static int step_validate(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_s
     float* Kzx = (float*)(w + pl->o_Kzx); \
     float* A32e = (float*)(w + pl->o_A32e); \
     float* S32e = (float*)(w + pl->o_S32e); \
-    float* LSl = (float*)(w + pl->o_LSl); \
     float* var0 = (float*)(w + pl->o_var0); \
     void* stats_ws = w + pl->o_stats; \
     float* Ge = (float*)(w + pl->o_Ge); \
@@ -358,10 +356,6 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
                         S32e, ldS, nullptr, 0, nullptr);
         if (rc) return rc;
         rc = launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows);     // mirror + [S - I | m / (2 vbar)]
-        if (rc) return rc;
-        // tril(L_S) with an explicit zero upper triangle: the right operand of tril(G L_S) on the fp32 LDS-DMA kernel, which
-        // takes no triangular-operand flags (the parameter's upper triangle is whatever the optimizer left there)
-        rc = launch_tril_copy_f32(ctx->stream, io->LS, io->ldls, LSl, pad4(Mp), Mp);
         if (rc) return rc;
         // its fp64 copy, TRANSPOSED -- [S - I ; m^T / (2 vbar)], (M'+1) x M': S - I is symmetric, so its rows are copied as they lie and
         // only the extra column becomes a row -- the left operand of the Cholesky backward's first product (chol_tail below) then
@@ -425,22 +419,11 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     STEP_CALL(dsvgp_mirror_lower_f32(ctx, Ge, Mp, Mp));
     // ---- variational block (needs only G): L_S-bar = 2 vbar tril(G L_S) + KL gradient, m-bar = b + KL gradient, trace terms, scalars
     auto variational = [&]() -> int {
-        // tril(G L_S): on the LDS-DMA fp32 kernel where it takes the shape (the whole K range against the zero upper triangle of
-        // the tril(L_S) copy: twice the multiply-adds of the K-trimmed product at five times its rate), into the cleared gradient slot
-        int rc = 0;
-        {
-            GemmArgs g{};
-            g.M = Mp; g.N = Mp; g.K = Mp; g.A = Ge; g.lda = Mp; g.B = LSl; g.ldb = pad4(Mp); g.C = io->dLS; g.ldc = io->lddls;
-            g.alpha = 1.0; g.beta = 0.0; g.flags = DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_C_ZEROED; g.batch = 1; g.splitk = 1;
-            g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
-            rc = launch_gemm32(ctx->stream, g);
-            if (rc > 1) return rc;
-        }
-        if (rc == 0)
-            rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, Ge, Mp, io->LS, io->ldls, 0.0, nullptr, 0,
+        // (tril(G L_S) stays on the K-trimmed register-staged kernel of gemm.hip: on the LDS-DMA kernel -- against a tril-clean copy of
+        //  L_S, twice the multiply-adds at five times the rate -- the step got SLOWER, C4 12.91 -> 13.02 ms, C3 7.20 -> 7.34: this
+        //  product runs beside the [Q' | a] solve, and the DMA kernel's two-per-CU workgroups crowd that solve out of the CUs)
+        int rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, Ge, Mp, io->LS, io->ldls, 0.0, nullptr, 0,
                             io->dLS, io->lddls, nullptr, 0, nullptr);
-        else
-            rc = 0;
         if (rc) return rc;
         // one pass + one reduction launch: m-bar = b + KL gradient (b = row M' of [G ; b^T], copied on the way), trace terms, scaling,
         // KL, and the scalar assembly of dsvgp_elbo_fast_finalize in the reduction's last thread
