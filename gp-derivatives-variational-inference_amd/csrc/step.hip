@@ -521,7 +521,10 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         STEP_CALL(dense());
     }
     // ---- K_ZX-bar's kernel backward: beside the fp64 products that follow when the batch is small against M' (HBM-bound read)
-    const bool zx_side = overlap && !tail_side && Bp <= 2 * Mp;
+#ifndef STEP_ZX_SIDE_MAX
+#define STEP_ZX_SIDE_MAX 2          // K_ZX-bar's kernel backward goes to the side stream when B' <= STEP_ZX_SIDE_MAX * M'
+#endif
+    const bool zx_side = overlap && !tail_side && (int64_t)Bp <= (int64_t)STEP_ZX_SIDE_MAX * Mp;
     if (zx_side) {
         STEP_HIP(hipEventRecord(pl->ev_dense, main));
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
