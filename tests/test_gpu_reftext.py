@@ -137,6 +137,35 @@ def test_pll_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, nam
 
 
 @pytest.mark.parametrize("name", ["c2", "c3", "c4shard", "c4"])
+def test_phi_argument_on_the_fp32_kernel_against_reference_text(dsvgp, gpu_device, name):
+    """DEFAULT since round 4: tril(L^T L-bar) = -tril([S - I | m'][G ; b^T]) -- both operands fp32 data out of fp32 MFMA products -- runs
+    on the fp32 LDS-DMA kernel and its result is widened for the fp64 Cholesky backward; ``ElboEngine.phi_arg_fp64`` (flag 64 of
+    dsvgp_elbo_step_f32) keeps the fp64-accumulated product.  Both forms are held to the reference-text vectors at the same
+    tolerances, and the default may not be further out than the fp64-accumulated form by more than two fp32-accurate evaluations of
+    one step differ by anyway (their split-K sums meet in atomics: run to run a scalar gradient moves between 5e-8 and 4e-6).
+    Measured: C4 inducing_points 1.8e-6 / 1.6e-6, inducing_directions 1.4e-6 / 1.5e-6, C3 inducing_points 2.5e-5 / 2.6e-5."""
+    g, P, x, y, D, nd = _load(name)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    errs = {}
+    for f64 in (False, True):
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.phi_arg_fp64 = f64
+        if name == "c3":
+            eng.chol_jitter = 1e-8
+        loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "ELBO", fast=True)
+        torch.cuda.synchronize()
+        assert eng.c_step_used
+        errs[f64] = _errors(g, loss, grads, mu, varn, skip=("inducing_directions",) if name == "c3" else ())
+        del eng
+    _check("%s tril(L^T L-bar) on the fp32 kernel (default)" % name, errs[False], *TOL32[name])
+    _check("%s tril(L^T L-bar) with fp64 accumulation" % name, errs[True], *TOL32[name])
+    worst = lambda e: max(v for k, v in e.items() if k not in ("loss", "mu", "varn"))
+    assert worst(errs[False]) <= 1.5 * worst(errs[True]) + 2e-7, (name, worst(errs[False]), worst(errs[True]))
+    for k in errs[False]:
+        assert errs[False][k] <= max(3.0 * errs[True][k], 3e-5), (name, k, errs[False][k], errs[True][k])
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4shard", "c4"])
 def test_split_bf16_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, name):
     """OPT-IN mode (``ElboEngine.split_bf16`` / flag 32 of dsvgp_elbo_step_f32): the Gram product and the dense K_ZX-bar product as
     bf16 x 3 split products on the bf16 matrix pipe (six bf16 MFMA products per fp32 product, fp32 accumulation; csrc/gemm3b.hip).
