@@ -514,13 +514,23 @@ def main():
         e_o, loss_o = window(loop_o, batch_o, warm_, steps_)
         eng_o.record_events = False
         roof_o, asm_o = rooflines(cfg_o, eng_o, event_durations(eng_o, EVENT_NAMES), None, fp64_, name, False)
-        return dict(workload=cfg_o["name"] + (" (float64 model mode)" if fp64_ else ""), steps=steps_, warmup=warm_,
-                    ms_per_step=1e3 * e_o / steps_, steps_per_s=steps_ / e_o, final_loss=float(loss_o.item()),
-                    one_call_step=bool(getattr(eng_o, "c_step_used", False)),
-                    roofline_kernel=(roof_o or {}).get("kernel"), roofline_frac=(roof_o or {}).get("frac"),
-                    roofline_avg_ms=(roof_o or {}).get("avg_ms"),
-                    assembly_fwd_frac=((asm_o or {}).get("forward") or {}).get("frac"),
-                    assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
+        res = dict(workload=cfg_o["name"] + (" (float64 model mode)" if fp64_ else ""), steps=steps_, warmup=warm_,
+                   ms_per_step=1e3 * e_o / steps_, steps_per_s=steps_ / e_o, final_loss=float(loss_o.item()),
+                   one_call_step=bool(getattr(eng_o, "c_step_used", False)),
+                   roofline_kernel=(roof_o or {}).get("kernel"), roofline_frac=(roof_o or {}).get("frac"),
+                   roofline_avg_ms=(roof_o or {}).get("avg_ms"),
+                   assembly_fwd_frac=((asm_o or {}).get("forward") or {}).get("frac"),
+                   assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
+        del loop_o, eng_o, batch_o
+        # the same reference-op-sequence CPU port as the headline's cpu_baseline, on a bounded sample (two to ten timed steps) of this configuration;
+        # the CIQ configuration has no CPU training loop to time (the oracle evaluates single steps: 190 s for the C5 `init` state
+        # on 8 cores, tests/golden/c5_step_init64.npz)
+        if not args.no_cpu_baseline and not fp64_ and not cfg_o.get("ciq"):
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg_o, budget_s=10.0, min_steps=2)
+            except Exception as ex:
+                res["cpu_baseline"] = dict(error="%s: %s" % (type(ex).__name__, ex))
+        return res
 
     # ---- every other BASELINE configuration, timed by this same command (one GPU, default run): C2, C3, C5 and the float64 model
     # mode at C4 and C5 (fp64 msMINRES), each with its own warm-up and ONE timed window of the given number of steps (same bracketing as above)
