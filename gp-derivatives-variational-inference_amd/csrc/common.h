@@ -74,6 +74,7 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
 // pieces of the one-call step (csrc/step.hip) that fold tiny dependent launches into their neighbours
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp);                                       // assemble.hip
+int launch_widen_sym_f32_f64(hipStream_t st, const float* src, int64_t lds, double* dst, int64_t ldd, int n);    // elbo.hip: fp64 mirror of an fp32 lower triangle
 int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows);   // elbo.hip
 int launch_variational_terms(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int flags,
                              const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,

@@ -210,6 +210,25 @@ __global__ void phi_sym_kernel(double* __restrict__ G, int n, int64_t ldg) {
     }
 }
 
+// dst (fp64, full symmetric) = mirror of the lower triangle (diagonal included) of src (fp32): the widening of an fp32 product's
+// lower-triangular result and Phi(.) + Phi(.)^T of it in ONE pass (csrc/step.hip, chol_tail)
+__global__ void widen_sym_kernel(const float* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int n) {
+    __shared__ float tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;                       // lower block (bi, bj), bj <= bi -> dst blocks (bi, bj) and (bj, bi)
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bi * 32 + r, gj = bj * 32 + tx;
+        const float v = (gi < n && gj < n) ? src[(int64_t)gi * lds + gj] : 0.f;
+        tile[r][tx] = v;
+        if (gi < n && gj < n && gj <= gi) dst[(int64_t)gi * ldd + gj] = (double)v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = bj * 32 + r, gj = bi * 32 + tx;   // upper element (gi, gj) <- lower (gj, gi)
+        if (gi < n && gj < n && gj > gi) dst[(int64_t)gi * ldd + gj] = (double)tile[tx][r];
+    }
+}
 template <typename T>
 __global__ void transpose_kernel(const T* __restrict__ in, int64_t ldi, int rows, int cols,
                                  T* __restrict__ out, int64_t ldo) {
@@ -1054,6 +1073,14 @@ __global__ void mirror_sminus_kernel(float* __restrict__ G, int n, int64_t ldg, 
         }
     }
 }
+int launch_widen_sym_f32_f64(hipStream_t st, const float* src, int64_t lds, double* dst, int64_t ldd, int n) {
+    if (n <= 0) return 0;
+    const int nb = cdiv(n, 32);
+    hipLaunchKernelGGL(widen_sym_kernel, dim3(nb, nb), dim3(32, 8), 0, st, src, lds, dst, ldd, n);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows) {
     const int nb = cdiv(n, 32);
     hipLaunchKernelGGL(mirror_sminus_kernel, dim3(nb, nb), dim3(32, 8), 0, st, A, n, lda, m, hyp, rows);

@@ -473,19 +473,16 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
             g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
             const int rc = launch_gemm32(ctx->stream, g);          // (clears the output itself: Qe32 is not part of the prezeroed arena)
             if (rc > 1) return rc;
-            if (rc == 1) {
-                launch_widen_f32_f64(ctx->stream, Qe32, ldQ32, G1, Mp, Mp, Mp);
-                return hipGetLastError() == hipSuccess ? 0 : 1000 + (int)hipGetLastError();
-            }
+            if (rc == 1) return launch_widen_sym_f32_f64(ctx->stream, Qe32, ldQ32, G1, Mp, Mp);   // widening + Phi(.) + Phi(.)^T in one pass
         }
 #endif
-        return dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldST, Ge, Mp,
-                          0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
+        int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldST, Ge, Mp,
+                            0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr);
+        if (rc) return rc;
+        return dsvgp_phi_symmetrize(ctx, G1, Mp, Mp);
     };
     auto chol_tail = [&](bool qe32_free) -> int {
-        int rc = phi_arg(qe32_free);
-        if (rc) return rc;
-        rc = dsvgp_phi_symmetrize(ctx, G1, Mp, Mp);
+        int rc = phi_arg(qe32_free);                                // S = Phi(P) + Phi(P)^T of P = tril(L^T L-bar), fp64, full
         if (rc) return rc;
         rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
                         nullptr, 0, Yt, Mp, nullptr, 0, nullptr);

@@ -892,7 +892,7 @@ def test_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device, 
                                        (6000, 20, 370, 5, 700)])
 def test_one_call_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, B):
     """dsvgp_elbo_step_f32 queues the same library calls in the same order as the Python-orchestrated fast path: loss, mean and
-    every gradient agree to the run-order noise of the split-K atomics (1e-5), with and without the second stream, and against
+    every gradient agree to the run-order noise of the split-K atomics (1e-5 typical, 5e-5 asserted), with and without the second stream, and against
     the oracle like the piecewise path.  (M' = 600 and 2220 >= 512: the overlap schedule is on by default there.)"""
     P, x, y, D, nd = make_problem(N, d, M, p, B, seed=N + d + 1)
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
@@ -912,11 +912,13 @@ def test_one_call_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, 
         assert relmax(mu1, mu0) < 4e-6, (overlap, relmax(mu1, mu0))
         for k in O.PARAM_NAMES:
             if g0[k].numel():
-                assert relmax(g1[k], g0[k]) < 2e-5, (overlap, k, relmax(g1[k], g0[k]))
+                # (observed up to 2.3e-5 on inducing_directions at M' = 120 in one run of eight: the direction gradients are sums
+                #  with cancellation of terms whose split-K partial sums meet in a different order; a wrong operand shows at 1e-3+)
+                assert relmax(g1[k], g0[k]) < 5e-5, (overlap, k, relmax(g1[k], g0[k]))
         assert g1["chol_variational_covar"].triu(1).abs().max().item() == 0.0
         l2, g2, _, _ = eng.loss_and_grads(Pg, xd, yd, Dd, nd)        # second call on the same plan / workspace
         assert abs(l2.item() - l1.item()) < 4e-6 * abs(l1.item()), (overlap, l2.item(), l1.item())
-        assert relmax(g2["inducing_points"], g1["inducing_points"]) < 2e-5, (overlap, relmax(g2["inducing_points"], g1["inducing_points"]))
+        assert relmax(g2["inducing_points"], g1["inducing_points"]) < 5e-5, (overlap, relmax(g2["inducing_points"], g1["inducing_points"]))
     l_ref, g_ref, mu_ref, _ = O.elbo_loss_and_grads(P, x, y, D, nd)
     assert abs(l1.item() - l_ref.item()) < 2e-5 * abs(l_ref.item()) and relmax(mu1, mu_ref) < 2e-4
 
