@@ -132,6 +132,95 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
 }
 
+#ifndef POTRF_F16_BLK
+#define POTRF_F16_BLK 1     // 1: the 16-column chain of the diagonal sub-block in four 4-column blocks, rank-4 updates on the fp64 MFMA; 0: column by column
+#endif
+#if POTRF_F16_BLK
+// one wave: Cholesky factor L_d (in place, upper part zeroed) and inverse Xd = L_d^-1 of the 16 x 16 block at F[o.., o..], FOUR
+// COLUMNS PER EXCHANGE, the updates as two v_mfma_f64_16x16x4 per block.
+//   The column-by-column form (POTRF_F16_BLK = 0) publishes one column and one row through LDS per column and applies a rank-1
+//   update from VALU code: 16 write -> read round trips and ~35 instructions per column on the single wave whose chain bounds
+//   every launch of the factorisation.  Here, per block of four columns j0 .. j0+3:
+//     * every lane publishes ONE element of D (column j0 + g of its row) and one of Y', reads the 4 x 4 pivot block (the same ten
+//       numbers in every lane), the four block entries of its own row and the four block rows of Y' in its own column;
+//     * factors the pivot block (four dependent rsqrt), substitutes its own row against it -> M[i][0..3] = L[i][j0..j0+3], and
+//       eliminates the four rows of Y' inside the block -> Z[0..3];
+//     * D -= M M^T and Y' -= (M diag(1/L_kk), strictly below the diagonal) Z are ONE MFMA each, and both take their operands from
+//       the lane's own registers: with a[t] = D[i][4t+g] (i = lane & 15, g = lane >> 4) the 16x16x4 A operand wants lane (m, k)
+//       to hold M[m][k] and the B operand lane (n, k) to hold M[n][k] -- the same register, M[i][g]; its C/D layout (lane (c, g'),
+//       register q <-> element (g' + 4q, c)) is the transposed position of D[c][4q+g'], which a SYMMETRIC update term leaves
+//       correct; Y' is kept as yt[t] = Y'[4t+g][i] (row in (t, g), column on the lane), the C/D layout itself.
+//   Y': forward elimination of the identity with UNSCALED rows (Y'[r] = L_rr X[r]); scaled by 1 / L_rr at the end.
+//   colblk = [16][4] (columns j0 .. j0+3 of D), rowblk = [4][16] (rows j0 .. j0+3 of Y').
+__device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*Xd)[17], double* colblk, double* rowblk,
+                                              int lane, int* info, int gidx0, int nvalid) {
+    const int i = lane & 15, g = lane >> 4;
+    acc4 a, yt;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        a[t] = F[o + i][o + 4 * t + g];
+        yt[t] = (4 * t + g == i) ? 1.0 : 0.0;
+    }
+    double rrow[4];                  // 1 / L_rr of rows r = 4t + g
+    int bad = -1;                    // first non-positive pivot (wave-uniform)
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const int j0 = 4 * jb;
+        colblk[i * 4 + g] = a[jb];                      // D[i][j0 + g]
+        rowblk[g * 16 + i] = yt[jb];                    // Y'[j0 + g][i]
+        __builtin_amdgcn_wave_barrier();
+        const double P00 = colblk[(j0 + 0) * 4 + 0];    // (the same addresses in every lane: broadcast reads)
+        const double P10 = colblk[(j0 + 1) * 4 + 0], P11 = colblk[(j0 + 1) * 4 + 1];
+        const double P20 = colblk[(j0 + 2) * 4 + 0], P21 = colblk[(j0 + 2) * 4 + 1], P22 = colblk[(j0 + 2) * 4 + 2];
+        const double P30 = colblk[(j0 + 3) * 4 + 0], P31 = colblk[(j0 + 3) * 4 + 1], P32 = colblk[(j0 + 3) * 4 + 2],
+                     P33 = colblk[(j0 + 3) * 4 + 3];
+        const double p0 = colblk[i * 4 + 0], p1 = colblk[i * 4 + 1], p2 = colblk[i * 4 + 2], p3 = colblk[i * 4 + 3];
+        const double y0 = rowblk[0 * 16 + i], y1 = rowblk[1 * 16 + i], y2 = rowblk[2 * 16 + i], y3 = rowblk[3 * 16 + i];
+        __builtin_amdgcn_wave_barrier();
+        // the 4 x 4 pivot block
+        const double r0 = rsqrt_nr(P00);
+        const double l10 = P10 * r0, l20 = P20 * r0, l30 = P30 * r0;
+        const double d1 = fma(-l10, l10, P11);
+        const double r1 = rsqrt_nr(d1);
+        const double l21 = fma(-l20, l10, P21) * r1, l31 = fma(-l30, l10, P31) * r1;
+        const double d2 = fma(-l21, l21, fma(-l20, l20, P22));
+        const double r2 = rsqrt_nr(d2);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, P32)) * r2;
+        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, P33)));
+        const double r3 = rsqrt_nr(d3);
+        bad = (bad < 0 && !(P00 > 0.0)) ? j0 : bad;
+        bad = (bad < 0 && !(d1 > 0.0)) ? j0 + 1 : bad;
+        bad = (bad < 0 && !(d2 > 0.0)) ? j0 + 2 : bad;
+        bad = (bad < 0 && !(d3 > 0.0)) ? j0 + 3 : bad;
+        // this lane's row against the pivot block: M[i][0..3] = L[i][j0 .. j0+3]; it keeps column g (zero above the diagonal)
+        const double m0 = p0 * r0;
+        const double m1 = fma(-m0, l10, p1) * r1;
+        const double m2 = fma(-m1, l21, fma(-m0, l20, p2)) * r2;
+        const double m3 = fma(-m2, l32, fma(-m1, l31, fma(-m0, l30, p3))) * r3;
+        const double mraw = (g == 0) ? m0 : ((g == 1) ? m1 : ((g == 2) ? m2 : m3));
+        const double rg = (g == 0) ? r0 : ((g == 1) ? r1 : ((g == 2) ? r2 : r3));
+        const double mg = (i >= j0 + g) ? mraw : 0.0;
+        const double sg = (i > j0 + g) ? mraw * rg : 0.0;       // L[i][j0+g] / L[j0+g][j0+g], strictly below the diagonal
+        // rows j0 .. j0+3 of Y' after the elimination inside the block, in this lane's column; it keeps row g
+        const double w10 = l10 * r0, w20 = l20 * r0, w30 = l30 * r0, w21 = l21 * r1, w31 = l31 * r1, w32 = l32 * r2;
+        const double z1 = fma(-w10, y0, y1);
+        const double z2 = fma(-w21, z1, fma(-w20, y0, y2));
+        const double z3 = fma(-w32, z2, fma(-w31, z1, fma(-w30, y0, y3)));
+        const double zg = (g == 0) ? y0 : ((g == 1) ? z1 : ((g == 2) ? z2 : z3));
+        a = __builtin_amdgcn_mfma_f64_16x16x4f64(-mg, mg, a, 0, 0, 0);          // D -= M M^T (every column; the block's own ...
+        a[jb] = mg;                                                              // ... is final: L)
+        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(-sg, zg, yt, 0, 0, 0);        // Y' -= S Z (rows of the block end up as Z)
+        rrow[jb] = rg;
+    }
+    if (lane == 0 && bad >= 0 && o + bad < nvalid && *info == 0) *info = gidx0 + o + bad + 1;   // LAPACK convention
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g;                                    // column of D held in a[t]; row of Y' held in yt[t]
+        F[o + i][o + c] = (c > i) ? 0.0 : a[t];
+        Xd[c][i] = (i > c) ? 0.0 : yt[t] * rrow[t];
+    }
+}
+#else
 // one wave: Cholesky factor L_d (in place, upper part zeroed) and inverse Xd = L_d^-1 of the 16 x 16 block at F[o.., o..].
 // Lane (i = lane & 15, g = lane >> 4) holds a[t] = D[i][4g+t] and y[t] = Y[i][4g+t] (Y: forward elimination of the
 // identity, row i scaled by 1/L_ii at the end).  The single wave is instruction-issue bound, so per-element predicates
@@ -201,6 +290,8 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
         Xd[i][c] = (c > i) ? 0.0 : y[t] * ri;
     }
 }
+
+#endif      // POTRF_F16_BLK
 
 // 16 x 16 x 16 product on one wave:  P[m][n] = sum_q Aop(m, q) Bop(q, n);  operands through pointers + strides
 //   Aop(m, q) = Ab[m * lda_ + q];   Bop(q, n) = B_NK ? Bb[n * ldb_ + q] : Bb[q * ldb_ + n]
@@ -509,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     // registers while the first product runs.
     __shared__ double S[2][64][LDT];
     __shared__ double Xd[16][17];
-    __shared__ double colbuf[32], rowbuf[32];      // [16..31]: dummy slots of the non-owner lanes
+    __shared__ double colbuf[64], rowbuf[64];      // column-by-column chain: [16..31] dummy slots of the non-owner lanes; 4-column blocks: [16][4] / [4][16]
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int b = blockIdx.x;
@@ -794,4 +885,5 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
 extern "C" int dsvgp_debug_potrf_clock(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 32);
 }
+
 #endif
