@@ -3,7 +3,8 @@
 //
 // rocSOLVER's dpotrf takes 8.1 ms at M' = 3000 (serial single-workgroup panel kernels + many small launches); a first
 // blocked version here (diagonal-block kernel + panel GEMM + trailing GEMM per block column, 141 launches) took 4.5 ms.
-// This version: 48 launches, 1.41 ms at M' = 3000 for the factor WITH the fused inverse (1.66 at 3300, 0.25 at 600; tools/potrf_inv_probe.py; per-launch
+// This version: 48 launches, 1.355 ms at M' = 3000 for the factor WITH the fused inverse (1.62 at 3300, 0.222 at 600; 1.41 / 1.67 / 0.252 with the
+// column-by-column chain of the 16 x 16 diagonal sub-blocks, POTRF_F16_BLK = 0; tools/potrf_inv_probe.py; per-launch
 // trace tools/potrf_inv_trace.sh; in-kernel stamps of the diagonal workgroup tools/potrf_clock.sh; anatomy in DESIGN.md section 5).
 // Measured without effect on the chain (+-1 %, removed again): one Newton step behind v_rsq_f64 instead of two, multipliers folded
 // once per column of the 16-column chain, operand reads of the 64^3 products pipelined in chunks, 8-wave workgroups (POTRF_NW).
