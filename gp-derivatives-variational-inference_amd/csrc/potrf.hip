@@ -153,15 +153,20 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
 //       correct; Y' is kept as yt[t] = Y'[4t+g][i] (row in (t, g), column on the lane), the C/D layout itself.
 //   Y': forward elimination of the identity with UNSCALED rows (Y'[r] = L_rr X[r]); scaled by 1 / L_rr at the end.
 //   colblk = [16][4] (columns j0 .. j0+3 of D), rowblk = [4][16] (rows j0 .. j0+3 of Y').
+//   from_regs (wave-uniform): the block arrives in a_in, a_in[t] = D[i][4t+g] (the critical tile's leading block comes straight out of
+//   the MFMA accumulators of its rank-64 update, see crit_tile_update) instead of from F.
 __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*Xd)[17], double* colblk, double* rowblk,
-                                              int lane, int* info, int gidx0, int nvalid) {
+                                              int lane, int* info, int gidx0, int nvalid, bool from_regs = false,
+                                              acc4 a_in = acc4{0, 0, 0, 0}) {
     const int i = lane & 15, g = lane >> 4;
     acc4 a, yt;
+    if (from_regs) a = a_in;
+    else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        a[t] = F[o + i][o + 4 * t + g];
-        yt[t] = (4 * t + g == i) ? 1.0 : 0.0;
+        for (int t = 0; t < 4; ++t) a[t] = F[o + i][o + 4 * t + g];
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) yt[t] = (4 * t + g == i) ? 1.0 : 0.0;
     double rrow[4];                  // 1 / L_rr of rows r = 4t + g
     int bad = -1;                    // first non-positive pivot (wave-uniform)
 #pragma unroll
@@ -230,7 +235,7 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
 // (rows <= j only collect junk above the diagonal, which is never read), likewise Y[i][:] -= ls * Y[j][:] / L_jj with
 // ls = li for i > j, 0 otherwise.
 __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*Xd)[17], double* colbuf, double* rowbuf,
-                                              int lane, int* info, int gidx0, int nvalid) {
+                                              int lane, int* info, int gidx0, int nvalid, bool = false, acc4 = acc4{0, 0, 0, 0}) {
     const int i = lane & 15, g = lane >> 4;
     double a[4], y[4];
 #pragma unroll
@@ -313,18 +318,23 @@ __device__ __forceinline__ acc4 prod16(const double* Ab, int lda_, const double*
 // chain of the next diagonal sub-block, waves 1..3 do everything that is already final: the other trailing sub-blocks,
 // the global stores of row-block kb of X and column-block kb of L, and the running sum W = X^T X = sum_kb X_kb^T X_kb
 // (lower blocks, mirrored on store) -- so the critical path is 4 x (factor16 + one panel product + one update product).
+//
+// Y is never initialised: its 16 x 16 blocks are ASSIGNED at their first touch (block (ib, kb) of the elimination of the identity
+// starts as -L_{ib,kb} X_{kb,kb}: the identity has nothing there), blocks above the diagonal are never touched and leave as zeros
+// in the stores to Xg.  So Y may alias a tile that other waves are still reading until the barrier behind the first chain
+// (the critical tile's update keeps A_ik there, crit_tile_update).
+// first_from_regs: wave 0 starts the first 16-column chain from a0 (see factor16_wave) instead of from F.
 __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT], double (*Xd)[17], double* colbuf,
                                              double* rowbuf, int tid, int* info, int gidx0, int nvalid,
                                              double* __restrict__ Ag, int64_t lda, double* __restrict__ Xg,
-                                             double* __restrict__ Wg) {
+                                             double* __restrict__ Wg, bool first_from_regs = false,
+                                             acc4 a0 = acc4{0, 0, 0, 0}) {
     const int lane = tid & 63, wave = tid >> 6;
     const int mrow = (lane >> 4), ncol = lane & 15;
     // (written for waves 0..3; in an 8-wave workgroup waves 4..7 only take part in the barriers)
     // No barrier between the caller's writes of F and the first 16-column chain: wave 0 wrote the 16 x 16 block it starts
-    // with ITSELF (the caller guarantees that), so it goes straight on while waves 1..3 finish their parts of F and set Y = I;
-    // the barrier behind the first chain closes both.
-    if (wave >= 1 && wave < 4)
-        for (int e = tid - 64; e < 64 * 64; e += 192) Y[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+    // with ITSELF (the caller guarantees that) or holds it in registers, so it goes straight on while waves 1..3 finish their
+    // parts of F; the barrier behind the first chain closes that.
     acc4 wacc[4];                        // waves 1..3: lower blocks idx = (wave - 1) + 3 s of W
 #pragma unroll
     for (int sI = 0; sI < 4; ++sI) wacc[sI] = acc4{0, 0, 0, 0};
@@ -334,7 +344,7 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 #ifdef POTRF_DEBUG
         if (tid == 0 && kb == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[8] = __builtin_amdgcn_s_memtime();
 #endif
-        if (wave == 0) factor16_wave(F, o, Xd, colbuf, rowbuf, lane, info, gidx0, nvalid);
+        if (wave == 0) factor16_wave(F, o, Xd, colbuf, rowbuf, lane, info, gidx0, nvalid, first_from_regs && kb == 0, a0);
 #ifdef POTRF_DEBUG
         if (tid == 0 && kb == 0 && gidx0 == (POTRF_DEBUG_K + 1) * 64) chol_dbg[9] = __builtin_amdgcn_s_memtime();
 #endif
@@ -386,15 +396,20 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
                 for (int cb = 0; cb <= kb; ++cb) {
                     if (1 + (task++ % 3) != wave) continue;
                     acc4 r = prod16<false>(&F[ib * 16][o], LDT, &Y[o][cb * 16], LDT, lane);
+                    if (cb == kb) {                  // first touch of block (ib, kb): the identity is zero there
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Y[ib * 16 + mrow + 4 * q][cb * 16 + ncol] -= r[q];
+                        for (int q = 0; q < 4; ++q) Y[ib * 16 + mrow + 4 * q][cb * 16 + ncol] = -r[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Y[ib * 16 + mrow + 4 * q][cb * 16 + ncol] -= r[q];
+                    }
                 }
             }
             // final data of this sub-block step: rows o..o+15 of X, columns o..o+15 of L -> global
             const int t3 = tid - 64;
             for (int e = t3; e < 16 * 64; e += 192) {
                 const int r = o + (e >> 6), c = e & 63;
-                Xg[r * 64 + c] = Y[r][c];
+                Xg[r * 64 + c] = (c < o + 16) ? Y[r][c] : 0.0;            // (blocks above the diagonal: never touched)
             }
             for (int e = t3; e < (64 - o) * 16; e += 192) {
                 const int r = o + (e >> 4), c = o + (e & 15);
@@ -587,6 +602,119 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     }
 }
 
+#ifndef POTRF_CRIT_SLIVER
+#define POTRF_CRIT_SLIVER 1     // 1: the critical tile's rank-64 update in 16-row strips out of registers (crit_tile_update); 0: as every other tile
+#endif
+// The critical workgroup's rank-64 update  D = C - (A W) A^T  of the NEXT diagonal tile (A = A_{k+1,k}, W = W_k, C = A_{k+1,k+1}),
+// ordered for the serial chain that follows it instead of for throughput.  Every other tile forms T = A W with four waves of
+// 32 x 32, sends -T through LDS and runs a second 64^3 product (two barriers, ~10.6k cycles + 3.3k of LDS moves) before the
+// factorisation can start.  Here wave w owns the 16-row strip w of the tile:
+//   * U = T_w^T = W A_w^T (64 x 16: four accumulator blocks, K = 64).  Its C/D register layout (lane (c, g), register q <->
+//     U[g + 4q][c] = T_w[c][g + 4q]) IS the A-operand layout of T_w for the next product -- T never goes through LDS;
+//   * D[w][nb] = C[w][nb] - T_w A_nb^T only for the blocks nb <= w on or below the diagonal (16 / 32 / 48 / 64 MFMAs for wave 0..3);
+//   * wave 0 therefore holds the leading 16 x 16 block after 64 + 16 MFMAs and starts the 16-column chain OUT OF ITS REGISTERS
+//     (it loads C transposed, C[n][g + 4q]: the accumulator then holds D^T, whose register layout is the one factor16_wave wants,
+//     lower triangle from valid data); waves 1..3 finish their strips in the shadow of that chain and meet it at its barrier.
+// LDS: S[0] = A (read until the end of the second product, then the inverse's work tile Y -- never initialised, see factor64_lds),
+// S[1] = W (dead after the one barrier between the two products, then F).  Returns wave 0's leading block in a0.
+__device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n, int k,
+                                                 const double* __restrict__ Wk, int tid, acc4& a0
+#ifdef POTRF_DEBUG
+                                                 , unsigned long long* st_
+#endif
+                                                 ) {
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int k0 = k * 64, i0 = (k + 1) * 64;
+    const int64_t alast = (int64_t)(n - 1) * lda;
+    acc4 cacc[4];
+    {
+        double ra[16], rw[16];
+        const int64_t arow0 = (int64_t)(i0 + (tid >> 6)) * lda, astep = (int64_t)4 * lda;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            rw[u] = Wk[r * 64 + c];
+            ra[u] = A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
+        }
+        // this strip's blocks of C, requested behind the operands and consumed after the first product
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb > wave) { cacc[nb] = acc4{0, 0, 0, 0}; continue; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // wave 0 (its one block is the tile's leading diagonal block): transposed, element (row g + 4q, column i) <- C[i][g + 4q]
+                const int rr = (wave == 0) ? i : 16 * wave + g + 4 * q, cc = (wave == 0) ? g + 4 * q : 16 * nb + i;
+                const int gr = min(i0 + rr, n - 1), gc = min(i0 + cc, n - 1);
+                cacc[nb][q] = A[(int64_t)gr * lda + gc];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = (tid >> 6) + 4 * u, c = tid & 63;
+            S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
+            S[1][r][c] = rw[u];
+        }
+    }
+    __syncthreads();
+    CHOL_STAMP(1);
+    // U = W A_w^T: A operand W[16 cb + m][k] (lane (m, k)), B operand A_w[n][k] (lane (n, k)); four independent accumulators
+    acc4 U[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) U[cb] = acc4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int kq = 4 * ks + g;
+        const double bop = S[0][16 * wave + i][kq];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) U[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1][16 * cb + i][kq], bop, U[cb], 0, 0, 0);
+    }
+    CHOL_STAMP(4);
+    __syncthreads();                 // W is dead: S[1] becomes F
+    CHOL_STAMP(5);
+    // D[w][nb] = C[w][nb] - T_w A_nb^T, T_w from the registers of U; the leading block (wave 0) on two accumulators (one
+    // dependent chain of 16 fp64 MFMAs would wait out every instruction's latency)
+    if (wave == 0) {
+        acc4 d0 = cacc[0], d1 = acc4{0, 0, 0, 0};
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double bop = S[0][i][16 * cb + 4 * q + g];
+                if (q & 1) d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[cb][q], bop, d1, 0, 0, 0);
+                else d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[cb][q], bop, d0, 0, 0, 0);
+            }
+        CHOL_STAMP(7);
+        // (symmetric update term: the transposed C makes this D^T) a0[t] = D[i][4t + g] for 4t + g <= i, zero above, identity padding
+        // of a ragged last block
+        const int nr = n - i0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = 4 * t + g;
+            const bool in = i < nr && c <= i;
+            a0[t] = in ? d0[t] + d1[t] : ((i == c && i >= nr) ? 1.0 : 0.0);
+        }
+    } else {
+        double (*F)[LDT] = S[1];
+        const int nr = n - i0;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb > wave) continue;
+            acc4 d = cacc[nb];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[cb][q], S[0][16 * nb + i][16 * cb + 4 * q + g], d, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ml = 16 * wave + g + 4 * q, nl = 16 * nb + i;
+                const bool in = ml < nr && nl <= ml;
+                F[ml][nl] = in ? d[q] : ((ml == nl) ? 1.0 : 0.0);
+            }
+        }
+    }
+}
+
 #ifndef POTRF_MINW
 #define POTRF_MINW (POTRF_NW / 2)
 #endif
@@ -609,6 +737,26 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
         chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip);
         return;
     }
+#if POTRF_CRIT_SLIVER
+    if (NW == 4 && b == 0 && k >= 0) {             // the critical workgroup: update of the next diagonal tile ordered for the chain
+        CHOL_STAMP_DECL;
+        CHOL_STAMP(0);
+        acc4 a0;
+#ifdef POTRF_DEBUG
+        crit_tile_update(S, A, lda, n, k, Wws + (size_t)k * 4096, tid, a0, st_);
+        st_[6] = st_[5];
+#else
+        crit_tile_update(S, A, lda, n, k, Wws + (size_t)k * 4096, tid, a0);
+#endif
+        CHOL_STAMP(2);
+        const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
+        factor64_lds(S[1], S[0], Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
+                     Wws + (size_t)kk * 4096, true, a0);
+        CHOL_STAMP(3);
+        CHOL_STAMP_FLUSH;
+        return;
+    }
+#endif
     // tile row ti holds ti + 1 update tiles, dealt to workgroups in strips of strip block columns (block 0: the diagonal tile
     // of row 0, alone: the critical workgroup)
     int ti = 0, first = 0;
