@@ -1032,7 +1032,17 @@ class ElboEngine:
                     and hasattr(coll, "all_gather_async") and Mp >= self.shard_min_mp and Mp >= 4 * world
                     and not self.deterministic):
                 return False
-        return M > 0 and x.shape[0] > 0 and Mp <= 8192 and _ops.step_supported(M, d, p, x.shape[0], world)
+        rows_local = x.shape[0]
+        if world > 1:
+            # the choice of path must be the SAME on every rank (the two paths issue differently sized collectives): decide it
+            # from global quantities only -- the largest shard of the global minibatch (a shape the smaller shards then fit too),
+            # never from this rank's own row count
+            gb = getattr(coll, "global_batch", None)
+            if gb is not None:
+                if gb < world:
+                    return False
+                rows_local = -(-gb // world)
+        return M > 0 and rows_local > 0 and Mp <= 8192 and _ops.step_supported(M, d, p, rows_local, world)
 
     def _c_step(self, ctx, params, x, y, D, num_data, rows, include_kl):
         """the whole fast-path step queued by dsvgp_elbo_step_f32 (one ctypes call); raises _Refactored when the
@@ -1470,7 +1480,7 @@ class ElboEngine:
             fp32 [G ; b^T], fp64 accumulation: the one-GPU arithmetic), all-gathered as fp32: the argument of Phi in the
             Cholesky backward"""
             Gw = coll.world
-            wr = (Mp + Gw - 1) // Gw
+            wr = ((Mp + Gw - 1) // Gw + 1) // 2 * 2          # (the row block of the five-piece C path: dsvgp_step_plan::wr)
             r0 = min(coll.rank * wr, Mp)
             r1 = min(r0 + wr, Mp)
             loc = self._get_zeroed("Lrows32", (wr, Mp), f32)

@@ -242,11 +242,10 @@ extern "C" int dsvgp_gemm3b(dsvgp_ctx* ctx, int flags, int M, int N, int K, floa
     if (!ctx || !Aplanes || !Bplanes || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N || a_rows < M || b_rows < N ||
         (flags & ~DSVGP_GEMM_OUT_LOWER))
         return DSVGP_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per call: the attribute belongs to the CURRENT device's copy of the kernel (a process-wide "done" flag would leave a second
+        // GPU of the process, or a concurrent first call, without it); a host-side table write, no device work
         hipError_t e = hipFuncSetAttribute((const void*)gemm3b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_NBUF * STAGE3);
         if (e != hipSuccess) return 1000 + (int)e;
-        attr_set = true;
     }
     G3 a{};
     const int Kp = dsvgp_split3_kpad(K);

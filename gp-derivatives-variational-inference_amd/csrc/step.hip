@@ -362,7 +362,8 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         // streams as an mn-contiguous operand (the lean fp64 kernel's faster staging path: 49 against 46 TF)
         launch_widen_f32_f64(ctx->stream, S32e, ldS, S64e, ldST, Mp, Mp);
         launch_widen_f32_f64(ctx->stream, S32e + Mp, ldS, S64e + (size_t)Mp * ldST, 1, Mp, 1);
-        return hipGetLastError() == hipSuccess ? 0 : 1000 + (int)hipGetLastError();
+        const hipError_t e = hipGetLastError();            // (one call: it clears the error it returns)
+        return e == hipSuccess ? 0 : 1000 + (int)e;
     };
     if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork, main));

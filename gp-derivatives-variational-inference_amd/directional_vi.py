@@ -197,7 +197,27 @@ class TrainLoop:
         self.variational_scheduler.step()
         self.hyperparameter_optimizer.step()
         self.hyperparameter_scheduler.step()
+        if dp is not None and dp.check_every > 0:
+            self._check_replicas(dp)
         return loss, output, y_batch
+
+    def _check_replicas(self, dp, force=False):
+        """DSVGP_DP_CHECK (parallel.DataParallel.check_replicas): every N-th step the replicas compare the parameters nobody reduces
+        after the update -- all of them: an Adam step on identical gradients keeps identical replicas identical -- and on a mismatch
+        take rank 0's parameters AND rank 0's Adam moments (a replica that drifted once would otherwise drift again)."""
+        params = [q for opt in (self.variational_optimizer, self.hyperparameter_optimizer)
+                  for g in opt.param_groups for q in g["params"]]
+        same = dp.check_replicas([q.data for q in params], force=force)
+        if not same:
+            import torch.distributed as dist
+            for opt in (self.variational_optimizer, self.hyperparameter_optimizer):
+                for g in opt.param_groups:
+                    for q in g["params"]:
+                        st = opt.state.get(q)
+                        for k in ("exp_avg", "exp_avg_sq"):
+                            if st and k in st:
+                                dist.broadcast(st[k], dp.src0, group=dp.group)
+        return same
 
     def _device_step(self, idx, cols, py):
         """minibatch gather + fused ELBO forward / backward (gradients land in ``.grad``); everything here is stream work"""

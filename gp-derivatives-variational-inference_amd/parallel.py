@@ -31,6 +31,39 @@ class DataParallel:
         # rank 0 OF THE GROUP as a global rank: what dist.broadcast's ``src`` means (a sub-group need not contain global rank 0)
         self.src0 = dist.get_global_rank(group, 0) if group is not None else 0
         self.replicated_step = False  # set by the training loop for a tail minibatch with fewer rows than ranks
+        # Replica consistency of L_S, m (and their Adam moments) rests on the fixed-order G L_S product and on bitwise-identical
+        # all-reduce results; nothing re-broadcasts them.  DSVGP_DP_CHECK=N: every N-th step the replicas compare a checksum of
+        # their variational parameters (one 4-element all-reduce of max / min) and, if they differ, take rank 0's copy and count
+        # the event (``divergences``); 0 / unset: off.
+        try:
+            self.check_every = int(os.environ.get("DSVGP_DP_CHECK", "0"))
+        except ValueError:
+            self.check_every = 0
+        self._check_step = 0
+        self.divergences = 0
+
+    def check_replicas(self, tensors, force=False):
+        """Opt-in divergence check (DSVGP_DP_CHECK): True if the replicas of ``tensors`` agree bit for bit on every rank.
+        A checksum per tensor (sum and sum of squares in float64) goes through ONE all-reduce(max) of [c, -c]: the replicas agree
+        iff max(c) == min(c).  On disagreement every tensor is overwritten with rank 0's copy (broadcast) and ``divergences``
+        is incremented; the caller decides what else to re-synchronise (optimizer moments)."""
+        self._check_step += 1
+        if not force and (self.check_every <= 0 or self._check_step % self.check_every):
+            return True
+        cs = []
+        for t in tensors:
+            t64 = t.detach().to(torch.float64)
+            cs += [t64.sum(), (t64 * t64).sum()]
+        c = torch.stack(cs)
+        both = torch.cat([c, -c])
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
+        n = c.numel()
+        same = bool(torch.equal(both[:n], -both[n:]))
+        if not same:
+            self.divergences += 1
+            for t in tensors:
+                dist.broadcast(t.detach(), self.src0, group=self.group)
+        return same
 
     def shard_bounds(self, n):
         """rows [lo, hi) of a global batch of n rows owned by this rank (ragged tails go to low ranks)."""

@@ -131,7 +131,7 @@ def _worker(rank, world, port, out):
     full = torch.empty(n, world * w)
     full.view(n, world, w).copy_(allq.permute(1, 0, 2))
     assert torch.equal(full[:, :n + 1], Q) and full[:, n + 1:].abs().max().item() == 0.0
-    wr = (n + world - 1) // world
+    wr = ((n + world - 1) // world + 1) // 2 * 2       # (even, as both orchestrations of the sharded stage size it)
     r0 = min(rank * wr, n)
     r1 = min(r0 + wr, n)
     rows = torch.zeros(wr, n)
@@ -139,6 +139,17 @@ def _worker(rank, world, port, out):
     allr = torch.empty(world * wr, n)
     dp.all_gather_async(allr, rows).wait()
     assert torch.equal(allr[:n], Q[:, :n])
+    # opt-in divergence check (DSVGP_DP_CHECK): identical replicas pass; a replica that drifted in ONE element is detected on every
+    # rank and overwritten with rank 0's copy; off by default (every call returns True without a collective)
+    a, b = torch.arange(12.0).reshape(3, 4), torch.linspace(0, 1, 5)
+    assert dp.check_every == 0 and dp.check_replicas([a, b]) is True
+    assert dp.check_replicas([a, b], force=True) is True and dp.divergences == 0
+    if rank == 1:
+        a[2, 3] += 1e-6
+    assert dp.check_replicas([a, b], force=True) is False and dp.divergences == 1
+    assert torch.equal(a, torch.arange(12.0).reshape(3, 4))
+    dp.check_every, dp._check_step = 2, 0
+    assert dp.check_replicas([a, b]) is True and dp.check_replicas([a, b]) is True and dp.divergences == 1
     out[rank] = (loss.item(), {k: v.clone() for k, v in grads.items()}, (lo, hi), mu.shape[0])
     dist.destroy_process_group()
 

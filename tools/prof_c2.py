@@ -1,5 +1,5 @@
 import cProfile, pstats, sys, os
-sys.argv = ["bench.py", "--config", "c2", "--steps", "400", "--warmup", "30", "--no-cpu-baseline --no-extras"]
+sys.argv = ["bench.py", "--config", "c2", "--steps", "400", "--warmup", "30", "--no-cpu-baseline", "--no-extras"]
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import runpy
 pr = cProfile.Profile()
