@@ -108,6 +108,9 @@ class ElboEngine:
         # operands are fp32 data and G carries sqrt(M') times the error fp32 accumulation adds, so the product runs on the fp32
         # LDS-DMA kernel and only its result is widened (csrc/step.hip, chol_tail)
         self.phi_arg_fp64 = os.environ.get("DSVGP_PHI_ARG_FP64", "0") == "1"
+        # flag 128 of the one-call step: the forward solve A = L^-1 K_ZX in row ranges, the first two on the side stream under the
+        # Cholesky chain's later launches (csrc/step.hip, step_front); same arithmetic per output element
+        self.solve_pipe = os.environ.get("DSVGP_SOLVE_PIPE", "0") == "1"
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -1095,7 +1098,7 @@ class ElboEngine:
         if self.record_events:
             self._rec_count += 1
         flags = (1 if overlap and not self.deterministic else 0) | (2 if include_kl else 0) | (4 if timed else 0) \
-            | (16 if self.tail_side else 0) | (64 if self.phi_arg_fp64 else 0)
+            | (16 if self.tail_side else 0) | (64 if self.phi_arg_fp64 else 0) | (128 if self.solve_pipe else 0)
         io.split_ws, io.split_ws_bytes = None, 0
         if self.split_bf16 and Mp >= 256 and Bp >= 256:
             sws = self._bytes("cstep_split_ws", int(_lib.lib.dsvgp_elbo_step_split_bytes(M, d, p, B)))

@@ -44,6 +44,12 @@ struct GemmArgs {
     // deterministic mode: split-K slices store their partial tiles to this scratch ([slice][M][N], packed) and a
     // fixed-order pass adds them (launch_splitk_reduce) instead of meeting in atomics; null = atomics
     void* slab; size_t slab_bytes;
+    // row-range pieces of a product with a triangular A (the forward solve pipelined under the Cholesky chain, step.hip): the
+    // piece's row 0 is row tri_off of the triangle (its K range ends at tri_off + row + 1); wide64: take the 64 x 192 kernel of
+    // gemm64.hip whatever the tile count; lds_pad: extra (unused) dynamic LDS per workgroup, which bounds the workgroups a CU
+    // takes so that another stream's launches keep finding room.  Only gemm64.hip's wide kernel honours these: launch_gemm
+    // refuses (DSVGP_EINVAL) a product with tri_off / wide64 set that it cannot send there.
+    int tri_off, wide64, lds_pad;
 };
 // how many split-K slices fit the slab (>= 2) or 1 (= do not split); esz = bytes per element
 static inline int slab_slices(const GemmArgs& g, int want, size_t esz) {
@@ -69,8 +75,11 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g);     // gemm32.hip (fp32, 3
 
 // blocked Cholesky (potrf.hip)
 size_t potrf_blocked_workspace_bytes(int n);
+// hooks: after the launch that completes block row after_k of L^-1 (rows < 64 (after_k + 1) of Yinv / YinvT are final once it has
+// run) the event is recorded on st -- another stream may then start consuming those rows while the chain goes on
+struct PotrfHook { int after_k; hipEvent_t ev; };
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT, bool info_zeroed = false);
+                         double* YinvT, bool info_zeroed = false, const PotrfHook* hooks = nullptr, int nhooks = 0);
 // pieces of the one-call step (csrc/step.hip) that fold tiny dependent launches into their neighbours
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp);                                       // assemble.hip

@@ -538,6 +538,7 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
         if (rc > 1) return rc;
     }
 #endif
+    if (g.tri_off || g.wide64) return DSVGP_EINVAL;                 // (row-range pieces exist on gemm64.hip's wide kernel only)
 #if GEMM32
     if (!is_double) {
         const int rc = launch_gemm32(st, g);

@@ -20,6 +20,7 @@ struct G64 {
     const double* A; const void* B; double* C; float* C32;
     int64_t lda, ldb, ldc, ldc32;
     int M, N, K, tiles_m, tiles_n, flags, balanced;
+    int tri_off;         // wide kernel, triangular A: row m of this product is row tri_off + m of the triangle
     int kchunk;          // > 0: split-K, blockIdx.y-th chunk of this many k of the tile's (trimmed) range; fp64 atomics onto zeros
     double* slab;        // deterministic mode: chunk y stores its tiles to slab[y][M][N] instead (summed in a fixed order afterwards)
     double alpha;
@@ -322,9 +323,10 @@ __global__ __launch_bounds__(256, TW > 128 ? 3 : 4) void gemm64w_kernel(const G6
     const int tn = band * G64W_BAND + r - tm * wcols;
     if (triA == 1) tm = g.tiles_m - 1 - tm;              // longest K ranges first
     const int m0 = tm * T, n0 = tn * TW;
+    const int toff = g.tri_off;
     int klo = 0, khi = g.K;
-    if (triA == 1) khi = min(khi, m0 + T);
-    if (triA == 2) klo = max(klo, (m0 / BK) * BK);
+    if (triA == 1) khi = min(khi, m0 + toff + T);
+    if (triA == 2) klo = max(klo, ((m0 + toff) / BK) * BK);
     const int sk = tid >> 4, sc = (tid & 15) * 4, sc8 = (tid & 15) * NB;
     const double* __restrict__ Ap = g.A + m0 + sc;
     const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc8;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, TW > 128 ? 3 : 4) void gemm64w_kernel(const G6
     auto fetch = [&](int k0) {
         const int k = k0 + sk;
         const bool kin = k < g.K;
-        const bool a_fast = a_in && kin && (triA == 0 || (triA == 1 ? k0 + BK - 1 <= m0 : k0 >= m0 + T - 1));
+        const bool a_fast = a_in && kin && (triA == 0 || (triA == 1 ? k0 + BK - 1 <= m0 + toff : k0 >= m0 + toff + T - 1));
         if (a_fast) {
             const double2 v0 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda);
             const double2 v1 = *reinterpret_cast<const double2*>(Ap + (int64_t)k * g.lda + 2);
@@ -344,8 +346,8 @@ __global__ __launch_bounds__(256, TW > 128 ? 3 : 4) void gemm64w_kernel(const G6
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + sc + e;
                 bool ok = kin && m < g.M;
-                if (triA == 1) ok = ok && k <= m;
-                if (triA == 2) ok = ok && k >= m;
+                if (triA == 1) ok = ok && k <= m + toff;
+                if (triA == 2) ok = ok && k >= m + toff;
                 ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
             }
         }
@@ -484,20 +486,28 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.ldc; a.ldc32 = g.ldc32;
     a.M = g.M; a.N = g.N; a.K = g.K; a.flags = fl; a.alpha = g.alpha;
     a.tiles_m = cdiv(g.M, T); a.tiles_n = cdiv(g.N, T);
+    a.tri_off = g.tri_off;
     const int total = a.tiles_m * a.tiles_n;
     a.balanced = total < G64_BALANCED_BELOW;
 #if G64_WIDE
-    if (total >= G64W_MIN_TILES && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) &&      // (no split-K, no atomics: also in deterministic mode)
+    if ((total >= G64W_MIN_TILES || g.wide64) && !a_kc && !b_kc && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER)) &&      // (no split-K, no atomics: also in deterministic mode)
         (bf ? g.ldb % 4 == 0 : true)) {
         constexpr int TWD = G64W_TW > 128 ? 128 : G64W_TW;          // (double right operand)
         a.tiles_n = cdiv(g.N, bf ? G64W_TW : TWD);
         const dim3 gridw(cdiv(a.tiles_m * a.tiles_n, 8) * 8);
-        if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), 0, st, a);
+        const int pad = g.lds_pad > 0 ? g.lds_pad : 0;
+        if (pad) {          // (static + dynamic LDS beyond 64 KB needs the attribute; a host-side table write per call)
+            const hipError_t ea = bf ? hipFuncSetAttribute((const void*)gemm64w_kernel<float, G64W_TW>, hipFuncAttributeMaxDynamicSharedMemorySize, pad)
+                                     : hipFuncSetAttribute((const void*)gemm64w_kernel<double, TWD>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+            if (ea != hipSuccess) return 1000 + (int)ea;
+        }
+        if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), pad, st, a);
         hipError_t ew = hipGetLastError();
         return ew == hipSuccess ? 1 : 1000 + (int)ew;
     }
 #endif
+    if (g.tri_off || g.wide64) return DSVGP_EINVAL;                 // (only the wide kernel takes row-range pieces)
     // split-K for the few-tile products with a long K: every tile is resident at once, so the launch lasts as long as its
     // longest tile's chain of K / 16 dependent stages; chunks of G64_KCHUNK accumulate with fp64 atomics onto a zeroed output
     a.kchunk = (G64_KCHUNK > 0 && a.balanced && g.K >= 2 * G64_KCHUNK && g.C) ? G64_KCHUNK : 0;

@@ -997,7 +997,7 @@ size_t potrf_blocked_workspace_bytes(int n) {
 // (lower triangle, leading dimension ldy) by the fused forward elimination, and (YinvT != nullptr) its transpose with the
 // same leading dimension.
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT, bool info_zeroed) {
+                         double* YinvT, bool info_zeroed, const PotrfHook* hooks, int nhooks) {
     if (!info_zeroed) {
         hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
         if (e != hipSuccess) return 1000 + (int)e;
@@ -1020,6 +1020,11 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
         hipLaunchKernelGGL(chol_step_kernel<POTRF_NW>, dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info, Rw,
                            ldr, Yinv, ldy, nA, YinvT, strip);
         DSVGP_LAUNCH_CHECK();
+        for (int h = 0; h < nhooks; ++h)
+            if (hooks[h].after_k == k) {
+                const hipError_t e = hipEventRecord(hooks[h].ev, st);
+                if (e != hipSuccess) return 1000 + (int)e;
+            }
     }
     const int ny = Yinv ? nblk : 0, npan = nblk * (nblk - 1) / 2;
     if (ny + npan > 0) {

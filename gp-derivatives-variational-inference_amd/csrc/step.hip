@@ -15,6 +15,7 @@
 // dsvgp_elbo_step_status and falls back).
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -56,7 +57,7 @@ struct dsvgp_step_plan {
     const void* pad_ready_for = nullptr;          // the workspace whose Qe32 pad columns have been zeroed
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_status = nullptr, ev_fork2 = nullptr, ev_var = nullptr, ev_dense = nullptr,
-               ev_zx = nullptr;
+               ev_zx = nullptr, ev_pipe1 = nullptr, ev_pipe2 = nullptr;
     // timing pairs of the last TM_RING timed steps: forward solve, K_ZX assembly, K_ZX-bar kernel backward
     static constexpr int TM_RING = 128;
     hipEvent_t tm_ring[TM_RING][6] = {};
@@ -160,7 +161,8 @@ static int plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, ds
     if (!pl) return DSVGP_EINVAL;
     if (!step_layout(M, d, p, B, pl, world)) { delete pl; return DSVGP_EINVAL; }
     bool ok = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) == hipSuccess;
-    hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx, &pl->ev_dp};
+    hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx, &pl->ev_dp,
+                         &pl->ev_pipe1, &pl->ev_pipe2};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     for (auto& slot : pl->tm_ring) for (hipEvent_t& e : slot) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&pl->host_status, 8 * sizeof(float), hipHostMallocDefault) == hipSuccess;
@@ -188,7 +190,8 @@ extern "C" int dsvgp_elbo_step_dp_plan_create(dsvgp_ctx* ctx, int M, int d, int 
 
 extern "C" int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* pl) {
     if (!pl) return DSVGP_EINVAL;
-    hipEvent_t evs[] = {pl->ev_fork, pl->ev_side, pl->ev_status, pl->ev_fork2, pl->ev_var, pl->ev_dense, pl->ev_zx, pl->ev_dp};
+    hipEvent_t evs[] = {pl->ev_fork, pl->ev_side, pl->ev_status, pl->ev_fork2, pl->ev_var, pl->ev_dense, pl->ev_zx, pl->ev_dp, pl->ev_pipe1,
+                        pl->ev_pipe2};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& slot : pl->tm_ring) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
     if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -246,6 +249,11 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
     return 0;
 }
 
+#ifndef STEP_PIPE_K1
+#define STEP_PIPE_K1 450    // forward solve under the chain (flag 128): the side stream starts rows [0, r1) after launch k1 = 45 % of the block rows,
+#define STEP_PIPE_K2 750    // rows [r1, r2) after launch k2 = 75 %
+#define STEP_PIPE_PAD 49152 // unused dynamic LDS of the side-stream pieces: one 36 KB + 48 KB workgroup per CU beside one 70 KB chain workgroup
+#endif
 #ifndef STEP_PHI64
 #define STEP_PHI64 0        // 1: tril(L^T L-bar) always with fp64 accumulation (probes; flag 64 of the step does the same at run time)
 #endif
@@ -365,27 +373,76 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         const hipError_t e = hipGetLastError();            // (one call: it clears the error it returns)
         return e == hipSuccess ? 0 : 1000 + (int)e;
     };
+    // ---- the forward solve PIPELINED under the Cholesky chain (flag 128).  Row block i of A = L^-1 K_ZX needs rows i of L^-1 only,
+    // and those are final as soon as the chain's launch i has run (potrf.hip writes row block k of the inverse in launch k);
+    // the chain's later launches are bound by ONE workgroup or by a few hundred latency-bound tiles and leave the matrix pipes
+    // mostly idle.  So the solve is queued in three row ranges: [0, r1) and [r1, r2) on the side stream behind events the chain
+    // records after its launches k1 / k2, one workgroup per CU (LDS padding: the chain's launches must keep finding room), and
+    // the rest on the main stream after the chain as before.  Pieces are row ranges of the SAME product (gemm64.hip's wide kernel
+    // with a row offset into the triangle): the arithmetic of every output element is unchanged.
+    float* A32 = A32e;
+    float* mu_bar = A32e + (size_t)Mp * Bp;
+    static const int pipe_k1 = getenv("DSVGP_PIPE_K1") ? atoi(getenv("DSVGP_PIPE_K1")) : STEP_PIPE_K1;      // (per mille of the block rows)
+    static const int pipe_k2 = getenv("DSVGP_PIPE_K2") ? atoi(getenv("DSVGP_PIPE_K2")) : STEP_PIPE_K2;
+    static const int pipe_pad = getenv("DSVGP_PIPE_PAD") ? atoi(getenv("DSVGP_PIPE_PAD")) : STEP_PIPE_PAD;
+    const int nblk64 = (Mp + 63) / 64;
+    const bool pipe = overlap && (flags & 128) && nb >= Mp && Mp % 2 == 0 && Bp % 4 == 0 && ((uintptr_t)Kzx % 16) == 0 &&
+                      (int64_t)nblk64 * ((Bp + 63) / 64) >= 8192 && nblk64 >= 16;
+    const double* LinvT = (const double*)trsm_ws + (size_t)Mp * Mp;
+    auto solve_rows = [&](int ra, int rb, int pad) -> int {        // rows [ra, rb) of A = L^-1 K_ZX
+        GemmArgs f{};
+        f.batch = 1; f.splitk = 1;
+        f.M = rb - ra; f.N = Bp; f.K = rb; f.tri_off = ra; f.wide64 = 1; f.lds_pad = pad;
+        f.A = LinvT + ra; f.lda = Mp; f.flags = DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_LOWER | DSVGP_GEMM_B_IS_FLOAT;
+        f.B = Kzx; f.ldb = Bp; f.alpha = 1.0; f.beta = 0.0;
+        f.C = nullptr; f.C32 = A32 + (size_t)ra * Bp; f.ldc32 = Bp;
+        return launch_gemm(ctx->stream, 1, f);
+    };
+    int r2 = 0;
     if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork, main));
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork, 0));
         ctx->stream = side;
         STEP_CALL(prologue(true));
-        STEP_HIP(hipEventRecord(pl->ev_side, side));
+        STEP_HIP(hipEventRecord(pl->ev_side, side));              // (K_ZX and [S - I | m'] are final)
         ctx->stream = main;
     }
     // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip)
     STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
+    if (pipe) {
+        const int k1 = nblk64 * pipe_k1 / 1000, k2 = nblk64 * pipe_k2 / 1000;      // launches after which the side stream may start
+        const int r1 = (k1 + 1) * 64;
+        r2 = (k2 + 1) * 64;
+        const PotrfHook hooks[2] = {{k1, pl->ev_pipe1}, {k2, pl->ev_pipe2}};
+        double* Dinv = (double*)trsm_ws;
+        STEP_CALL(launch_potrf_blocked(main, L, Mp, Mp, info, (double*)potrf_ws, Dinv, Mp, Dinv + (size_t)Mp * Mp, ctx->prezeroed, hooks,
+                                       k2 > k1 ? 2 : 1));
+        ctx->stream = side;
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_pipe1, 0));
+        STEP_TIME(0);
+        STEP_CALL(solve_rows(0, r1, pipe_pad));
+        if (k2 > k1) {
+            STEP_HIP(hipStreamWaitEvent(side, pl->ev_pipe2, 0));
+            STEP_CALL(solve_rows(r1, r2, pipe_pad));
+        } else r2 = r1;
+        STEP_TIME(1);
+        STEP_HIP(hipEventRecord(pl->ev_pipe1, side));             // (re-used: the side stream's pieces are done)
+        ctx->stream = main;
+    } else
     STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
     STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));     // hyp[4] | info: contiguous
     STEP_HIP(hipEventRecord(pl->ev_status, main));
     if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_side, 0));
     else STEP_CALL(prologue(false));
     // ---- A = L^-1 K_ZX (fp64 product with the explicit inverse, fp32 result), mu = A^T m + c, residuals (DGVS.py:181-188)
-    float* A32 = A32e;
-    float* mu_bar = A32e + (size_t)Mp * Bp;
-    STEP_TIME(0);
-    STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 0, Kzx, Bp, 0, Bp, nullptr, 0, A32, Bp, nb, trsm_ws, 1));
-    STEP_TIME(1);
+    if (pipe) {
+        STEP_CALL(solve_rows(r2, Mp, 0));
+        STEP_HIP(hipStreamWaitEvent(main, pl->ev_pipe1, 0));      // (the side stream's row ranges: joined behind the main stream's own)
+    } else {
+        STEP_TIME(0);
+        STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 0, Kzx, Bp, 0, Bp, nullptr, 0, A32, Bp, nb, trsm_ws, 1));
+        STEP_TIME(1);
+    }
     STEP_CALL(launch_stats_residual(ctx, A32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var0, stats_ws, io->y, rows, mu_bar, sums));
     // ---- [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), split-K over the minibatch axis; G mirrored
     if (flags & 32) {
