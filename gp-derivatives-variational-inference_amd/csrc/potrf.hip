@@ -88,6 +88,28 @@ __device__ unsigned long long chol_dbg[32];
 #define CHOL_STAMP(slot) do { } while (0)
 #define CHOL_STAMP_FLUSH do { } while (0)
 #endif
+// per-workgroup phase trace of ONE step launch (tools/potrf_wgtrace.py; -DPOTRF_TRACE -DPOTRF_DEBUG_K=k): thread 0 of every workgroup
+// stamps s_memtime into an LDS array at phase boundaries and copies it out on exit; slot 22 = role / strip, slot 23 = hardware id
+#ifdef POTRF_TRACE
+#ifndef POTRF_DEBUG_K
+#define POTRF_DEBUG_K 20
+#endif
+constexpr int TR_SLOTS = 24, TR_MAXWG = 4096;
+__device__ unsigned long long chol_trace[TR_MAXWG * TR_SLOTS];
+#define TR_DECL __shared__ unsigned long long trs_[TR_SLOTS]; if (threadIdx.x < TR_SLOTS) trs_[threadIdx.x] = 0
+#define TR(slot) do { if (k == POTRF_DEBUG_K && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); \
+        trs_[slot] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define TR_VAL(slot, v) do { if (k == POTRF_DEBUG_K && threadIdx.x == 0) trs_[slot] = (unsigned long long)(v); } while (0)
+#define TR_FLUSH do { if (k == POTRF_DEBUG_K && threadIdx.x == 0 && blockIdx.x < TR_MAXWG) { \
+        trs_[23] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
+        trs_[21] = __builtin_amdgcn_s_memtime(); \
+        for (int q_ = 0; q_ < TR_SLOTS; ++q_) chol_trace[(size_t)blockIdx.x * TR_SLOTS + q_] = trs_[q_]; } } while (0)
+#else
+#define TR_DECL
+#define TR(slot) do { } while (0)
+#define TR_VAL(slot, v) do { } while (0)
+#define TR_FLUSH do { } while (0)
+#endif
 constexpr int LDT = 66;                       // LDS row stride of a 64 x 64 tile (doubles)
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -131,6 +153,51 @@ __device__ __forceinline__ void tile_product(const double (*As)[LDT], const doub
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+}
+
+#ifndef POTRF_IL
+#define POTRF_IL 0          // 1: the strip products of the update / inverse tiles issue the NEXT block column's global loads between their MFMAs.
+#endif                      // Measured (round 5, profiles/r05_b_potrf_tile_roles.txt): needs POTRF_MINW = 1 (at two waves per SIMD it spills 23 registers:
+                            // 1.48 ms); with it n = 3000 1.33 -> 1.27 ms, n = 3300 1.60 -> 1.54, but the STEP does not move (C4 12.81 / 12.78 against
+                            // 12.83 / 12.79, C3 7.055 against 7.06: beside the side stream's kernels the launches are bound elsewhere).  Off.
+// The same 64 x 64 x 64 product by 4 waves (acc += / = A B), scheduled for a wave that is ALONE on its SIMD (the tile-bound
+// launches run one strip workgroup per CU): operand fragments are read two k-steps ahead of the MFMAs that use them, and after
+// every k-step (4 MFMAs = 256 cycles of the matrix pipe, of which the SIMD's issue port is busy for ~32) the caller's hook
+// pf(ks), ks = 0 .. 15, issues one sixteenth of the NEXT tile's global loads.  With those 32 loads issued in front of the product
+// (round 2 .. 4) a strip column cost 7.0k cycles against 4.8k for the last column of a strip, which prefetches nothing
+// (profiles/r05_b_potrf_wgtrace_before.txt): the vector-memory issue of one wave, ~70 cycles per load, ran with the matrix pipe idle.
+template <bool B_NK, bool ACC_INIT, typename F>
+__device__ __forceinline__ void tile_product_il(const double (*As)[LDT], const double (*Bs)[LDT], int lane, int wr, int wc,
+                                                acc4 (&acc)[2][2], F&& pf) {
+    if constexpr (!ACC_INIT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+    }
+    const int g = lane >> 4, m = lane & 15;
+    double a[16][2], b[16][2];
+    auto rd = [&](int ks) {
+        const int kq = 4 * ks + g;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[ks][i] = As[wr * 32 + i * 16 + m][kq];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j] = B_NK ? Bs[wc * 32 + j * 16 + m][kq] : Bs[kq][wc * 32 + j * 16 + m];
+    };
+    rd(0);
+    rd(1);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 2 < 16) rd(ks + 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        pf(ks);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the four fragment reads of k-step ks + 2
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // the four MFMAs of k-step ks
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // two of the next tile's global loads
+    }
 }
 
 #ifndef POTRF_F16_BLK
@@ -462,7 +529,11 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                                                   int k, int e, const double* __restrict__ Xws,
                                                   const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
                                                   double* __restrict__ Y, int64_t ldy, int nblk,
-                                                  double* __restrict__ YT, int strip = 1) {
+                                                  double* __restrict__ YT, int strip = 1
+#ifdef POTRF_TRACE
+                                                  , unsigned long long* trs_ = nullptr
+#endif
+                                                  ) {
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;     // column groups of waves, 16-column sub-tiles per wave, rows per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int nt = nblk - (k + 1), spr = (k + strip) / strip, nR = nt * spr;     // strips per tile row of R
@@ -485,6 +556,10 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
             const int r = (tid >> 6) + NW * u, c = tid & 63;
             ra[u] = ytile ? 0.0 : A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
             rb[u] = Lk[r * 64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {           // (behind the operands of the first product)
+            const int r = (tid >> 6) + NW * u, c = tid & 63;
             rc[u] = (j == k) ? ((r == c) ? 1.0 : 0.0) : Rw[(int64_t)(k0 + r) * ldr + j0 + c];
         }
         if (!ytile && j != k) {              // (R is padded to whole blocks: no clamping)
@@ -493,7 +568,11 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
+#ifdef POTRF_ABL_NOC
+                    for (int q = 0; q < 4; ++q) ro[i][jj][q] = 1e-3 * q;
+#else
                     for (int q = 0; q < 4; ++q) ro[i][jj][q] = rdst[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16];
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -510,15 +589,25 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
         }
     }
     __syncthreads();
+#ifdef POTRF_TRACE
+    if (trs_) { TR(1); TR_VAL(20, ((ytile ? 0 : ncols) << 16) | (ytile ? 0xffff : (e / spr))); }
+#endif
     acc4 acc[2][NJ];
     if (!ytile) {
-#ifdef POTRF_ABL_P1
+#if defined(POTRF_ABL_P1) || defined(POTRF_ABL_NOP)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = acc4{1e-3, 1e-3, 1e-3, 1e-3};
 #else
+#if POTRF_IL
+        if constexpr (NW == 4) tile_product_il<true, false>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+        else
+#endif
         tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k
+#endif
+#ifdef POTRF_TRACE
+        if (trs_) TR(2);
 #endif
         __syncthreads();
 #pragma unroll
@@ -543,7 +632,43 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
 #pragma unroll
             for (int u = 0; u < NU; ++u) S[1][(tid >> 6) + NW * u][tid & 63] = rc[u];
             __syncthreads();
+#ifdef POTRF_TRACE
+            if (trs_ && cc < 5) TR(3 + 3 * cc);
+#endif
             double* const rcur = rdst;
+#if POTRF_IL && !defined(POTRF_ABL_NOP) && !defined(POTRF_ABL_NOC)
+            if constexpr (NW == 4) {
+                if (cc + 1 < ncols) {                // next block column: its loads go out BETWEEN the MFMAs of this product
+                    ++j; j0 += 64; rdst += 64;
+                    if (j == k) {                    // (the identity block of R's row k: nothing to load)
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) rc[u] = (((tid >> 6) + NW * u) == (tid & 63)) ? 1.0 : 0.0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) ro[i][jj][q] = 0.0;
+                        tile_product_il<false, true>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+                    } else {
+                        const double* prc = Rw + (int64_t)(k0 + (tid >> 6)) * ldr + j0 + (tid & 63);
+                        const double* pro = rdst;
+                        const int64_t step4 = (int64_t)4 * ldr;
+                        auto pf = [&](int ks) {
+                            rc[ks] = *prc;
+                            prc += step4;
+                            const int t = ks & 7;
+                            ro[t >> 2][ks >> 3][t & 3] = pro[(ks >> 3) * 16];
+                            pro += (t == 7) ? -7 * step4 : step4;
+                        };
+                        tile_product_il<false, true>(S[0], S[1], lane, wr, wc, acc, pf);
+                    }
+                } else {
+                    tile_product_il<false, true>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+                }
+                goto inv_product_done;
+            }
+#endif
             if (cc + 1 < ncols) {                    // next block column: requested now, consumed after this product
                 ++j; j0 += 64; rdst += 64;
 #pragma unroll
@@ -557,18 +682,41 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                     for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
+#ifdef POTRF_ABL_NOC
+                            ro[i][jj][q] = 1e-3 * q;
+#else
                             ro[i][jj][q] = (j == k) ? 0.0 : rdst[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16];
+#endif
             }
+#ifndef POTRF_ABL_NOP
             tile_product<false, NW, true>(S[0], S[1], lane, wr, wc, acc);   // R_ij - T R_kj
+#endif
+#if POTRF_IL && !defined(POTRF_ABL_NOP) && !defined(POTRF_ABL_NOC)
+inv_product_done:
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rcur[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16] = acc[i][jj][q];
+                    for (int q = 0; q < 4; ++q)
+#ifdef POTRF_ABL_NOC
+                        if (acc[i][jj][q] == 123.456)
+#endif
+                        rcur[(int64_t)(i * 16 + 4 * q) * ldr + jj * 16] = acc[i][jj][q];
+#ifdef POTRF_TRACE
+            if (trs_ && cc < 5) TR(4 + 3 * cc);
+#endif
+#ifdef POTRF_TRACE
+            if (trs_ && cc < 5) TR(5 + 3 * cc);
+#endif
             if (cc + 1 < ncols) __syncthreads();     // every wave is done reading R_kj out of S[1]
         }
     } else {
+#if POTRF_IL
+        if constexpr (NW == 4) tile_product_il<false, false>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+        else
+#endif
         tile_product<false, NW>(S[0], S[1], lane, wr, wc, acc);         // X_k R_kj
         if (YT == nullptr) {
 #pragma unroll
@@ -733,8 +881,16 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / WC, wc = wave % WC;
     const int b = blockIdx.x;
+    TR_DECL;
+    TR(0);
     if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
+#ifdef POTRF_TRACE
+        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip, trs_);
+        TR_VAL(22, 2);
+        TR_FLUSH;
+#else
         chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip);
+#endif
         return;
     }
 #if POTRF_CRIT_SLIVER
@@ -749,11 +905,15 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
         crit_tile_update(S, A, lda, n, k, Wws + (size_t)k * 4096, tid, a0);
 #endif
         CHOL_STAMP(2);
+        TR(1);
         const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
         factor64_lds(S[1], S[0], Xd, colbuf, rowbuf, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096,
                      Wws + (size_t)kk * 4096, true, a0);
         CHOL_STAMP(3);
         CHOL_STAMP_FLUSH;
+        TR(2);
+        TR_VAL(22, 0);
+        TR_FLUSH;
         return;
     }
 #endif
@@ -781,8 +941,12 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
             for (int u = 0; u < NU; ++u) {       // (rows past the matrix: clamped to the last row, zeroed on the way to LDS)
                 const int r = (tid >> 6) + NW * u, c = tid & 63;
                 ra[u] = A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
-                rb[u] = A[((j0 + r < n) ? brow0 + u * astep : alast) + k0 + c];
                 rw[u] = Wk[r * 64 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {       // (behind the operands of T = A_ik W_k: the first LDS fill waits for those only)
+                const int r = (tid >> 6) + NW * u, c = tid & 63;
+                rb[u] = A[((j0 + r < n) ? brow0 + u * astep : alast) + k0 + c];
             }
             const int m0 = i0 + wr * 32 + (lane >> 4);
             const int64_t crow0 = (int64_t)m0 * lda;
@@ -794,7 +958,11 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int dm = i * 16 + 4 * q;
+#ifdef POTRF_ABL_NOC
+                        cv[i][j][q] = 1e-3 * dm;
+#else
                         cv[i][j][q] = A[((m0 + dm < n) ? crow0 + (int64_t)dm * lda : alast) + nn];
+#endif
                     }
                 }
 #pragma unroll
@@ -806,8 +974,9 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
         }
         __syncthreads();
         CHOL_STAMP(1);
+        TR(1);
         acc4 acc[2][NJ];
-#ifdef POTRF_ABL_P1     // timing ablation (wrong numbers): every tile but the critical one skips its first product
+#if defined(POTRF_ABL_P1) || defined(POTRF_ABL_NOP)     // timing ablation (wrong numbers): every tile but the critical one skips its first product
         if (b == 0) tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);
         else {
 #pragma unroll
@@ -816,9 +985,14 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
                 for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{1e-3, 1e-3, 1e-3, 1e-3};
         }
 #else
+#if POTRF_IL
+        if constexpr (NW == 4) tile_product_il<true, false>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+        else
+#endif
         tile_product<true, NW>(S[0], S[1], lane, wr, wc, acc);          // T = A_ik W_k   (W symmetric: [n][k] == [k][n])
 #endif
         CHOL_STAMP(4);
+        TR(2);
         __syncthreads();
         CHOL_STAMP(5);
 #pragma unroll
@@ -848,8 +1022,38 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
             }
             __syncthreads();
             CHOL_STAMP(6);
+            if (cc < 5) TR(3 + 3 * cc);
             const bool diag = ti == tj;
             const int jcur = j0;
+#if POTRF_IL && !defined(POTRF_ABL_NOP) && !defined(POTRF_ABL_NOC)
+            if constexpr (NW == 4) {
+                if (b != 0) {
+                    if (cc + 1 < ncols) {            // next block column of the strip: its loads go out BETWEEN the MFMAs of this product
+                        ++tj; j0 += 64;
+                        // two pointers walking down 4 rows per k-step (no per-load 64-bit multiplies in the MFMA stream); in the ragged
+                        // last block row the walk stops at the matrix's last row (those values are never used), and a strip's columns
+                        // lie left of its rows: inside the matrix
+                        const int64_t step4 = (int64_t)4 * lda;
+                        const double* pr = A + (int64_t)min(j0 + (tid >> 6), n - 1) * lda + k * 64 + (tid & 63);
+                        const int cc0 = min(j0 + nl0, n - 1), dc1 = min(j0 + nl0 + 16, n - 1) - cc0;     // (columns clamped like the rows)
+                        const double* pc = A + (int64_t)min(i0 + ml0, n - 1) * lda + cc0;
+                        const int rrow = j0 + (tid >> 6), crow = i0 + ml0;
+                        auto pf = [&](int ks) {
+                            rb[ks] = *pr;
+                            pr += (rrow + 4 * (ks + 1) < n) ? step4 : 0;
+                            const int t = ks & 7;                // rows 4 t of this wave's 32: cv[t >> 2][.][t & 3]
+                            cv[t >> 2][ks >> 3][t & 3] = pc[(ks >> 3) ? dc1 : 0];
+                            if (t == 7) pc = A + (int64_t)min(crow, n - 1) * lda + cc0;
+                            else pc += (crow + 4 * (t + 1) < n) ? step4 : 0;
+                        };
+                        tile_product_il<true, true>(S[0], S[1], lane, wr, wc, acc, pf);
+                    } else {
+                        tile_product_il<true, true>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+                    }
+                    goto product_done;
+                }
+            }
+#endif
             if (cc + 1 < ncols) {                    // next block column of the strip: requested now, consumed after this product
                 ++tj; j0 += 64;
                 const int64_t alast = (int64_t)(n - 1) * lda, astep = (int64_t)NW * lda;
@@ -869,15 +1073,45 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int dm = i * 16 + 4 * q;
+#ifdef POTRF_ABL_NOC
+                            cv[i][j][q] = 1e-3 * dm;
+#else
                             cv[i][j][q] = A[((m0 + dm < n) ? crow0 + (int64_t)dm * lda : alast) + nn];
+#endif
                         }
                     }
             }
+#ifdef POTRF_ABL_NOP
+            if (b == 0)
+#endif
+#if POTRF_IL
+            if constexpr (NW == 4) tile_product_il<true, true>(S[0], S[1], lane, wr, wc, acc, [](int) {});
+            else
+#endif
             tile_product<true, NW, true>(S[0], S[1], lane, wr, wc, acc);    // C - T A_jk^T
+#if POTRF_IL && !defined(POTRF_ABL_NOP) && !defined(POTRF_ABL_NOC)
+product_done:
+#endif
             CHOL_STAMP(7);
             CHOL_STAMP(8);
+            if (cc < 5) TR(4 + 3 * cc);
             if (b == 0) break;                                          // (the critical tile: a strip of one, kept in LDS below)
             double* const cdst = A + (int64_t)(i0 + ml0) * lda + jcur + nl0;
+#ifndef POTRF_ABL_NOC
+            if (POTRF_IL && NW == 4 && !diag) {      // off-diagonal tile (its columns are inside the matrix): one pointer walking down 4 rows per pair of stores
+                double* pd = cdst;
+                const int64_t step4 = (int64_t)4 * lda;
+                const int crow = i0 + ml0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (crow + 4 * t < n) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) pd[j * 16] = acc[t >> 2][j][t & 3];
+                    }
+                    pd += step4;
+                }
+            } else
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -885,12 +1119,21 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ml = ml0 + i * 16 + 4 * q, nl = nl0 + j * 16;
+#ifdef POTRF_ABL_NOC
+                        if (acc[i][j][q] == 123.456)
+#endif
                         if (i0 + ml < n && jcur + nl < n && !(diag && nl > ml))
                             cdst[(int64_t)(i * 16 + 4 * q) * lda + j * 16] = acc[i][j][q];
                     }
+            if (cc < 5) TR(5 + 3 * cc);
             if (cc + 1 < ncols) __syncthreads();     // every wave is done reading A_jk out of S[1]
         }
-        if (b != 0) return;
+        if (b != 0) {
+            TR_VAL(20, (ncols << 16) | ti);
+            TR_VAL(22, 1);
+            TR_FLUSH;
+            return;
+        }
         __syncthreads();                                            // F aliases the T tile: every wave is done reading it
         CHOL_STAMP(10);
 #pragma unroll
@@ -1035,6 +1278,12 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
     return 0;
 }
 
+#ifdef POTRF_TRACE
+extern "C" int dsvgp_debug_potrf_trace(unsigned long long* out, int nwg) {
+    if (nwg > TR_MAXWG) nwg = TR_MAXWG;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_trace), sizeof(unsigned long long) * (size_t)nwg * TR_SLOTS);
+}
+#endif
 #ifdef POTRF_DEBUG
 extern "C" int dsvgp_debug_potrf_clock(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 32);

@@ -77,6 +77,10 @@ class DataParallel:
         dist.broadcast(t, self.src0, group=self.group)
         return [float(v) for v in t.tolist()]
 
+    def all_reduce_sum(self, t):
+        """sum over the ranks, in place, ordered on the current stream (the closing reduction of the step)"""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def all_reduce_async(self, t):
         """sum over the ranks, asynchronously on the collective's own stream; ``.wait()`` orders the current stream after it.
         ``algo = "rs_ag"``: one reduce-scatter + one all-gather (every rank owns 1/world of the buffer: with RCCL's direct
@@ -163,13 +167,13 @@ class DataParallel:
         # (bench.py: HIP events around the final reduction on the main stream = the communication the step does not hide)
         ev = engine._event_pair() if hasattr(engine, "_event_pair") else None
         if views is not None and getattr(engine, "variational_grads_global", False):
-            dist.all_reduce(engine.flat_late, op=dist.ReduceOp.SUM, group=self.group)     # [Z-bar, V-bar, scalars, loss]
+            self.all_reduce_sum(engine.flat_late)     # [Z-bar, V-bar, scalars, loss]
         elif early is not None:
-            dist.all_reduce(engine.flat_late, op=dist.ReduceOp.SUM, group=self.group)
+            self.all_reduce_sum(engine.flat_late)
             early.wait()
             engine._early_handle = None
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.all_reduce_sum(flat)
         if ev is not None:
             engine._event_done("final_reduce", ev)
         if views is not None:

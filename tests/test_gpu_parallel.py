@@ -362,3 +362,53 @@ def test_sharded_stage_at_c4_shard_geometry_against_reference_text(dsvgp, gpu_de
             assert v < tol, (name, k, v, tol)
         # L_S-bar is formed by every rank itself: bitwise equal replicas
         assert out[0][name + "/LS"] == out[1][name + "/LS"] and out[0][name + "/LSabs"] == out[1][name + "/LSabs"], name
+
+
+# ------------------------------------------------------------------ world = 4 and 8 through the five-piece C entry, one process
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,M,p,B", [(8, 48, 2, 51), (8, 20, 5, 67), (4, 30, 2, 33)])
+def test_virtual_ranks_through_the_dp_c_entry(dsvgp, gpu_device, world, M, p, B):
+    """The shard bounds of an 8-rank (and 4-rank) job -- ragged row shards, 5-6 inducing points per rank in the column-split
+    Cholesky backward, the Q' column blocks and L-bar row blocks of the sharded stage, the M' >= 4 world gate -- through
+    ``dsvgp_elbo_step_dp_f32`` (phases 0-4) on ONE card: the GPU box admits at most 6 processes on a card, so the ranks are
+    threads of this process with an in-process transport (tests/_virtual_ranks.py); engines, plans, workspaces and the C entry
+    are the product's.  Loss and gradients against the one-rank step; the replicas' gradients bitwise equal."""
+    from _virtual_ranks import VirtualWorld, make_virtual_dp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_step import make_problem
+    d = 6
+    P, x, y, D, nd = make_problem(500, d, M, p, B, seed=17 + world)
+    dev = gpu_device
+    Pg = {k: v.to(dev) for k, v in P.items()}
+    eng1 = dsvgp.ElboEngine(dev)
+    l1, g1, _, _ = eng1.loss_and_grads(Pg, x.to(dev), y.to(dev), D.to(dev), nd, "ELBO")
+    torch.cuda.synchronize()
+    l1, g1 = l1.item(), {k: v.double().cpu() for k, v in g1.items()}
+    vw = VirtualWorld(world)
+
+    def rank_fn(r, vw_):
+        dp = make_virtual_dp(dsvgp, vw_, r)
+        lo, hi = dp.shard_bounds(B)
+        dp.global_batch = B
+        eng = dsvgp.ElboEngine(dev)
+        eng.global_gram, eng.shard_replicated, eng.c_step, eng.shard_min_mp = True, True, True, 0
+        Pr = {k: v.clone() for k, v in Pg.items()}
+        loss, grads, mu, _ = dp.loss_and_grads(eng, Pr, x[lo:hi].to(dev), y[lo * (p + 1):hi * (p + 1)].to(dev),
+                                               D[lo * p:hi * p].to(dev), nd, "ELBO")
+        torch.cuda.synchronize()
+        assert eng.c_step_used and eng.sharded_stage_used and eng.variational_grads_global, (r, eng.c_step_used)
+        assert mu.shape[0] == (hi - lo) * (p + 1)
+        return loss.item(), {k: v.detach().cpu().clone() for k, v in grads.items()}, (lo, hi)
+
+    out = vw.run(rank_fn)
+    sizes = [hi - lo for _, _, (lo, hi) in out]
+    assert sum(sizes) == B and max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    for r, (loss, grads, _) in enumerate(out):
+        assert abs(loss - l1) < 2e-5 * abs(l1), (world, r, loss, l1)
+        for k, ref in g1.items():
+            if ref.numel() == 0 or ref.abs().max().item() == 0:
+                continue
+            err = (grads[k].double() - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 3e-4, (world, r, k, err)
+        for k in grads:                      # identical replicas: what the un-synchronised Adam steps rely on
+            assert torch.equal(grads[k], out[0][1][k]), (world, r, k)

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out/r05_potrf
+tools/potrf_variants.sh "il1:" "il0:-DPOTRF_IL=0" "il1:" "il0:-DPOTRF_IL=0" > gpurun_out/r05_potrf/il_ab.txt 2>&1; cat gpurun_out/r05_potrf/il_ab.txt
+for k in 5 25; do tools/potrf_wgtrace.sh $k 3000; done > gpurun_out/r05_potrf/wgtrace_il.txt 2>&1; cat gpurun_out/r05_potrf/wgtrace_il.txt
+tools/potrf_inv_trace.sh 3000 > gpurun_out/r05_potrf/trace_3000_il.txt 2>&1; cat gpurun_out/r05_potrf/trace_3000_il.txt
