@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="c4 on one GPU: skip the C2 / C3 / C5 / float64 windows")
     ap.add_argument("--no-extras", action="store_true",
                     help="c4 on one GPU: skip the repeated windows, the reporting-step timing and the other BASELINE configurations")
+    ap.add_argument("--eval-only", action="store_true", help="tools: only the eval_gp throughput figure of --config (other_configs.eval_c4)")
     ap.add_argument("--event-every", type=int, default=0,
                     help="HIP events (dominant-kernel / assembly timings) on every K-th timed step; 0 = every step, except on the "
                          "sub-millisecond configuration c2 where six event records are 5 %% of the step: every 8th there")
@@ -532,6 +533,73 @@ def main():
                 res["cpu_baseline"] = dict(error="%s: %s" % (type(ex).__name__, ex))
         return res
 
+    def time_eval(cfg_e, n_test=100_000, eval_batch=4096):
+        """eval_gp-equivalent throughput (reference directionalvi/directional_vi.py:271-305): predictive mean and
+        variance (with likelihood noise) of all p + 1 outputs of `n_test` test rows in batches of `eval_batch`, eval mode (the
+        Cholesky factor and its inverse cached across batches like the reference's @cached _cholesky_factor, DGVS.py:72), canonical
+        derivative directions tiled per batch (:292-294), every batch's two vectors copied to the host (:297-298).  Forward only."""
+        loop_e, eng_e, _ = build(cfg_e, False)
+        d_, p_, M_ = cfg_e["d"], cfg_e["p"], cfg_e["M"]
+        Mp_ = M_ * (p_ + 1)
+        Xt = torch.rand(n_test, d_, device=device, generator=torch.Generator(device=device).manual_seed(7))
+        params_e = loop_e.model._param_dict(loop_e.likelihood)
+        Dcan = torch.eye(d_, device=device)[:p_]
+        def run(collect):
+            outs = []
+            with torch.no_grad():
+                for s0 in range(0, n_test, eval_batch):
+                    xb = Xt[s0:s0 + eval_batch]
+                    mu_, varn_ = eng_e.predict(params_e, xb, Dcan.repeat(xb.shape[0], 1), cache=True)
+                    if collect:
+                        outs.append((mu_.cpu(), varn_.cpu()))
+            return outs
+        run(False)                                   # warm-up: factorisation + inverse cached, buffers allocated
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(False); e1.record()
+        torch.cuda.synchronize()
+        dev_s = e0.elapsed_time(e1) * 1e-3
+        t0 = time.perf_counter()
+        outs = run(True)
+        torch.cuda.synchronize()
+        wall_s = time.perf_counter() - t0
+        nb_ = (n_test + eval_batch - 1) // eval_batch
+        # the dominant kernel of a batch is the forward solve A = L^-1 K_ZX of the training step (fp64 MFMA, M'^2 B' flop), followed by
+        # the triangular W = L_S^T A (fp32 MFMA, M'^2 B'); roofline of the pair against the mixed peak, as for the step
+        flop_solve = float(Mp_) ** 2 * n_test * (p_ + 1)
+        mixed_s = flop_solve / 78.6e12 + flop_solve / 157.3e12
+        res = dict(workload="eval_gp of %s: %d test rows, batches of %d, cached L^-1" % (cfg_e["name"], n_test, eval_batch),
+                   rows_per_s=n_test / dev_s, outputs_per_s=n_test * (p_ + 1) / dev_s, ms_per_batch=1e3 * dev_s / nb_,
+                   rows_per_s_with_host_copies=n_test / wall_s,
+                   roofline=dict(bound="mfma", note="fp64 solve M'^2 B' + fp32 triangular product M'^2 B' per batch against 78.6 / 157.3 TF",
+                                 achieved_tflops=2 * flop_solve / dev_s / 1e12, frac=mixed_s / dev_s),
+                   mean_finite=bool(all(torch.isfinite(m_).all() for m_, _ in outs)),
+                   variance_min=float(min(v_.min().item() for _, v_ in outs)))
+        if not args.no_cpu_baseline:
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+                import dsvgp_oracle as O_
+                torch.set_num_threads(usable_cpus())
+                Pc = {k: v.detach().cpu() for k, v in params_e.items()}
+                nrows = 1024                                         # bounded sample: one 1024-row batch, factorisation included once
+                xb = Xt[:nrows].cpu()
+                Db = torch.eye(d_)[:p_].repeat(nrows, 1)
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    O_.predictive(Pc, xb, Db, assembly=O_.kernel_matrix_refseq)
+                t1 = time.perf_counter() - t0
+                res["cpu_baseline"] = dict(value=nrows / t1, unit="rows/s", cores=usable_cpus(), kind="port",
+                                           sample="oracle predictive (reference op sequence, fp64 Cholesky + solves) on one %d-row batch, "
+                                                  "factorisation included (the reference caches it across batches): %.2f s" % (nrows, t1))
+            except Exception as ex:
+                res["cpu_baseline"] = dict(error="%s: %s" % (type(ex).__name__, ex))
+        del loop_e, eng_e
+        return res
+
+    if args.eval_only and rank == 0:
+        print(json.dumps(time_eval(cfg)), flush=True)
+        return
+
     # ---- every other BASELINE configuration, timed by this same command (one GPU, default run): C2, C3, C5 and the float64 model
     # mode at C4 and C5 (fp64 msMINRES), each with its own warm-up and ONE timed window of the given number of steps (same bracketing as above)
     other = None
@@ -548,6 +616,12 @@ def main():
                 other[key] = time_other(cfg_o, name, fp64_, steps_, warm_)
             except Exception as ex:          # (an extra must never take the headline line down)
                 other[key] = dict(workload=cfg_o["name"], error="%s: %s" % (type(ex).__name__, ex))
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            other["eval_c4"] = time_eval(CONFIGS["c4"])
+        except Exception as ex:
+            other["eval_c4"] = dict(workload="eval_gp at C4", error="%s: %s" % (type(ex).__name__, ex))
         eng = None
 
     # ms_per_step = the timed window / steps, plus 1/50 of what a reporting step costs on top of a plain one (the reference reports
