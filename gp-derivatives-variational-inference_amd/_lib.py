@@ -56,6 +56,9 @@ SIGNATURES = {
     "dsvgp_elbo_step_plan_destroy": (_i, [_p]),
     "dsvgp_elbo_step_plan_bytes": (_z, [_p]),
     "dsvgp_elbo_step_f32": (_i, [_p, _p, _p, _p, _z, _i]),
+    "dsvgp_elbo_step_po_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "dsvgp_elbo_step_po_plan_create": (_i, [_p, _i, _i, _i, _i, C.POINTER(_p)]),
+    "dsvgp_elbo_step_po_f32": (_i, [_p, _p, _p, _p, _p, _z, _i]),
     "dsvgp_elbo_step_split_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_elbo_step_dp_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "dsvgp_elbo_step_dp_plan_create": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p)]),

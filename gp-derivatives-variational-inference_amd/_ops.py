@@ -81,9 +81,14 @@ class Context:
 class StepPlan:
     """``dsvgp_step_plan`` of one (M, d, p, B): host-side object of the one-call ELBO step (csrc/step.hip)"""
 
-    def __init__(self, ctx, M, d, p, B, world=1):
+    def __init__(self, ctx, M, d, p, B, world=1, per_output=False):
         h = C.c_void_p()
-        if world > 1:       # one rank of a data-parallel job (B = this rank's rows)
+        self.per_output = bool(per_output)
+        if per_output:      # dsvgp_elbo_step_po_f32: PLL objective / per-output variances (one rank)
+            if world != 1:
+                raise ValueError("the per-output step plan is a one-rank plan")
+            check(lib.dsvgp_elbo_step_po_plan_create(ctx.h, int(M), int(d), int(p), int(B), C.byref(h)), "dsvgp_elbo_step_po_plan_create")
+        elif world > 1:     # one rank of a data-parallel job (B = this rank's rows)
             check(lib.dsvgp_elbo_step_dp_plan_create(ctx.h, int(M), int(d), int(p), int(B), int(world), C.byref(h)),
                   "dsvgp_elbo_step_dp_plan_create")
             self.dp = _lib.ElboStepDP()
@@ -105,6 +110,10 @@ class StepPlan:
     def run(self, ctx, workspace, flags):
         check(lib.dsvgp_elbo_step_f32(ctx.h, self.h, C.byref(self.io), _ptr(workspace), workspace.numel(), int(flags)),
               "dsvgp_elbo_step_f32")
+
+    def run_po(self, ctx, workspace, flags, varn):
+        check(lib.dsvgp_elbo_step_po_f32(ctx.h, self.h, C.byref(self.io), _ptr(varn), _ptr(workspace), workspace.numel(), int(flags)),
+              "dsvgp_elbo_step_po_f32")
 
     def run_dp(self, ctx, workspace, flags, phase):
         check(lib.dsvgp_elbo_step_dp_f32(ctx.h, self.h, C.byref(self.io), C.byref(self.dp), _ptr(workspace), workspace.numel(),
@@ -134,7 +143,9 @@ class StepPlan:
         return [float(v) for v in self._ms]
 
 
-def step_supported(M, d, p, B, world=1):
+def step_supported(M, d, p, B, world=1, per_output=False):
+    if per_output:
+        return world == 1 and int(lib.dsvgp_elbo_step_po_workspace_bytes(int(M), int(d), int(p), int(B))) > 0
     if world > 1:
         return int(lib.dsvgp_elbo_step_dp_workspace_bytes(int(M), int(d), int(p), int(B), int(world))) > 0
     return int(lib.dsvgp_elbo_step_workspace_bytes(int(M), int(d), int(p), int(B))) > 0

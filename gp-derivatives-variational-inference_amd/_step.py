@@ -1047,9 +1047,26 @@ class ElboEngine:
                 rows_local = -(-gb // world)
         return M > 0 and rows_local > 0 and Mp <= 8192 and _ops.step_supported(M, d, p, rows_local, world)
 
-    def _c_step(self, ctx, params, x, y, D, num_data, rows, include_kl):
+    def _c_step_po_eligible(self, params, x, sync):
+        """the per-output step (PLL objective, or ELBO with the per-output variances wanted) as ONE C call (dsvgp_elbo_step_po_f32):
+        one rank, Cholesky whitening, every data point with its derivatives, explicit-inverse regime"""
+        if not (self.c_step and not sync and not self.capture_mode and self.whitening == "cholesky" and self.data_outputs == "all"
+                and not self.shared_directions and not self._no_middle and self.potrf_algo == 1 and self.fused_inverse
+                and self._trsm_nb is None and not self.lib_dense_gemm and not self.deterministic):
+            return False
+        coll = self.collective
+        if coll is not None and coll.world > 1:
+            return False
+        Z, V = params["inducing_points"], params["inducing_directions"]
+        M, d = Z.shape
+        p = V.shape[0] // M if M else 0
+        return M > 0 and x.shape[0] > 0 and M * (p + 1) <= 8192 and _ops.step_supported(M, d, p, x.shape[0], 1, per_output=True)
+
+    def _c_step(self, ctx, params, x, y, D, num_data, rows, include_kl, per_output=None):
         """the whole fast-path step queued by dsvgp_elbo_step_f32 (one ctypes call); raises _Refactored when the
-        factorisation failed (the caller then runs the jitter ladder on the piecewise path)"""
+        factorisation failed (the caller then runs the jitter ladder on the piecewise path).
+        ``per_output``: None = the ELBO fast path; "ELBO" / "PLL" = the per-output step (dsvgp_elbo_step_po_f32), which also
+        returns the per-output variances"""
         Z, V = params["inducing_points"], params["inducing_directions"]
         M, d = Z.shape
         p = V.shape[0] // M
@@ -1058,12 +1075,14 @@ class ElboEngine:
         self._problem_size(Mp)
         coll = self.collective
         world = coll.world if coll is not None else 1
-        plan = self._plans.get((M, d, p, B, world))
+        po = per_output is not None
+        pkey = (M, d, p, B, world, po)
+        plan = self._plans.get(pkey)
         if plan is None:
-            plan = self._plans[(M, d, p, B, world)] = _ops.StepPlan(ctx, M, d, p, B, world)
+            plan = self._plans[pkey] = _ops.StepPlan(ctx, M, d, p, B, world, per_output=po)
         # one workspace PER plan: a plan clears the pad columns of its fp32 [Q' | a] once per workspace and assumes nobody else
         # writes there (a ragged tail batch has its own plan, layout and buffer)
-        ws = self._bytes("cstep_ws_%d_%d_%d_%d_%d" % (M, d, p, B, world), plan.bytes)
+        ws = self._bytes("cstep_ws_%d_%d_%d_%d_%d%s" % (M, d, p, B, world, "_po" if po else ""), plan.bytes)
         grads, loss_out, d_hyp = self._alloc_grads(params, PARAM_NAMES, zero=False)
         mu = torch.empty(Bp, dtype=f32, device=self.device)
         LS, dLS = params["chol_variational_covar"], grads["chol_variational_covar"]
@@ -1108,7 +1127,12 @@ class ElboEngine:
         if tr is not None:
             import time as _t
             t0 = _t.perf_counter()
-        if world > 1:
+        varn = None
+        if po:
+            varn = torch.empty(Bp, dtype=f32, device=self.device)
+            plan.run_po(ctx, ws, (flags & 3) | (256 if per_output == "PLL" else 0), varn)
+            timed = False
+        elif world > 1:
             self._c_step_dp_phases(ctx, plan, ws, flags, coll, Mp)
         else:
             plan.run(ctx, ws, flags)
@@ -1125,8 +1149,11 @@ class ElboEngine:
             self.c_step_timed.append((plan, timed_idx))  # bench.py reads the plan's HIP events after its timed region (a step whose
                                                          # factorisation failed is not listed: its events time garbage)
         self.c_step_used = True
-        self._last_fast = ("plan", plan, ws, p)
         self._pending = None
+        if po:
+            self._last_fast = None
+            return loss_out[0], grads, mu, varn
+        self._last_fast = ("plan", plan, ws, p)
         return loss_out[0], grads, mu, torch.empty(0, dtype=f32, device=self.device)
 
     def _c_step_dp_phases(self, ctx, plan, ws, flags, coll, Mp):
@@ -1180,6 +1207,13 @@ class ElboEngine:
                 raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bq)
             return self._c_step(ctx, params, x, y.contiguous(), D, num_data, float(Bq if global_rows is None else global_rows),
                                 include_kl)
+        if not use_fast and mll_type in ("ELBO", "PLL") and self._c_step_po_eligible(params, x, sync):
+            pz = params["inducing_directions"].shape[0] // params["inducing_points"].shape[0]
+            Bq = x.shape[0] * (pz + 1)
+            if y.shape != (Bq,):
+                raise ValueError("y must be the interleaved target vector of length B*(p+1)=%d" % Bq)
+            return self._c_step(ctx, params, x, y.contiguous(), D, num_data, float(Bq if global_rows is None else global_rows),
+                                include_kl, per_output=mll_type)
         Mz = params["inducing_points"].shape[0]
         p = params["inducing_directions"].shape[0] // Mz if Mz else 0
         B = x.shape[0]

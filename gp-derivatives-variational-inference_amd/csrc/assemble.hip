@@ -1552,6 +1552,9 @@ inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int
     const int Trp = (g.Tr + 15) & ~15;
     if (Trp > 48) launch_bwd<GT, 0, BWD_GCH_MAX>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
     else if (g.q == 4) launch_bwd<GT, 4, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
+#ifndef BWD_NO_Q11
+    else if (g.q == 11) launch_bwd<GT, 11, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);   // (full-gradient SVGP at d = 10: BASELINE config 3)
+#endif
     else launch_bwd<GT, 0, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
 }
 

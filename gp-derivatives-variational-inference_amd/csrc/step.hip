@@ -42,6 +42,8 @@ inline int auto_nb(int Mp) {          // _step.ElboEngine._problem_size: the exp
 
 struct dsvgp_step_plan {
     int M, d, p, B, Mp, Bp, DP, nb;
+    bool per_output = false;          // plan of the per-output step (dsvgp_elbo_step_po_f32: PLL objective / per-output variances)
+    size_t o_A64 = 0, o_U32 = 0, o_Abar = 0, o_Kb64 = 0, o_var = 0, o_varbar = 0;
     int world = 1;                    // > 1: a data-parallel rank's plan (dsvgp_elbo_step_dp_f32); sizes the buffers below
     int wq = 0, wr = 0;               // column block of [Q' | a] / row block of L-bar per rank
     size_t o_Qfull = 0, o_qcol64 = 0, o_cbT = 0, o_cbK = 0, o_slab = 0, slab_bytes = 0, o_lrow64 = 0;
@@ -127,6 +129,15 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
         pl->slab_bytes = (size_t)4 * Mp * Mp * 4 + 4096;
         pl->o_slab = c.take(pl->slab_bytes);
     }
+    if (pl->per_output) {
+        // per-output step: the fp64 copy of A = L^-1 K_ZX (left factor of L-bar = -tril(K_ZX-bar A^T)), U = L_S W, A-bar, the fp64 K_ZX-bar, the per-output variance and its gradient; W = L_S^T A reuses the K_ZX buffer (dead after the solve)
+        pl->o_A64 = c.take((size_t)Mp * Bp * 8);
+        pl->o_U32 = c.take((size_t)Mp * Bp * 4);
+        pl->o_Abar = c.take((size_t)Mp * Bp * 4);
+        pl->o_Kb64 = c.take((size_t)Mp * Bp * 8);
+        pl->o_var = c.take((size_t)Bp * 4);
+        pl->o_varbar = c.take((size_t)Bp * 4);
+    }
     pl->bytes = c.off + 256;
     return pl->bytes;
 }
@@ -155,10 +166,11 @@ extern "C" size_t dsvgp_elbo_step_dp_workspace_bytes(int M, int d, int p, int B,
     return step_layout(M, d, p, B, &pl, world);
 }
 
-static int plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, dsvgp_step_plan** out) {
+static int plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, dsvgp_step_plan** out, bool per_output = false) {
     if (!ctx || !out) return DSVGP_EINVAL;
     dsvgp_step_plan* pl = new (std::nothrow) dsvgp_step_plan();
     if (!pl) return DSVGP_EINVAL;
+    pl->per_output = per_output;
     if (!step_layout(M, d, p, B, pl, world)) { delete pl; return DSVGP_EINVAL; }
     bool ok = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) == hipSuccess;
     hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx, &pl->ev_dp,
@@ -186,6 +198,16 @@ extern "C" int dsvgp_elbo_step_plan_create(dsvgp_ctx* ctx, int M, int d, int p, 
 extern "C" int dsvgp_elbo_step_dp_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, dsvgp_step_plan** out) {
     if (world < 2) return DSVGP_EINVAL;
     return plan_create(ctx, M, d, p, B, world, out);
+}
+
+// plan / workspace of the PER-OUTPUT step (dsvgp_elbo_step_po_f32): one rank
+extern "C" int dsvgp_elbo_step_po_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out) {
+    return plan_create(ctx, M, d, p, B, 1, out, true);
+}
+extern "C" size_t dsvgp_elbo_step_po_workspace_bytes(int M, int d, int p, int B) {
+    dsvgp_step_plan pl{};
+    pl.per_output = true;
+    return step_layout(M, d, p, B, &pl);
 }
 
 extern "C" int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* pl) {
@@ -606,6 +628,98 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
                                     kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
                                     io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));
     return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// The PER-OUTPUT step from one host call: the objective reads every output's own predictive variance -- mll_type = "PLL"
+// (PredictiveLogLikelihood, reference directional_vi.py:218-219, what tests/test_grad_svgp.py:19-36 trains with) or the ELBO with
+// per-output variances returned -- so the Gram formulation of dsvgp_elbo_step_f32 does not apply:
+//   A = L^-1 K_ZX (fp64 + fp32 copy), W = L_S^T A, mu / var per output (DGVS.py:181-205), likelihood terms (mu-bar, var-bar),
+//   U = L_S W, A-bar = m mu-bar^T + 2 (U - A) diag(var-bar), L_S-bar = tril(2 A diag(var-bar) W^T) + KL, m-bar = A mu-bar + KL,
+//   K_ZX-bar = L^-T A-bar (fp64 + fp32 copy), L-bar = -tril(K_ZX-bar A^T) (fp64), the Cholesky backward and both kernel backwards.
+// The same library calls as the Python-orchestrated path (`_step.ElboEngine._loss_and_grads`, ~100 ctypes calls: host-bound at the
+// reference's own test sizes), queued here from C.  flags: bit 0 overlap (x pack + K_ZX assembly on the side stream under the
+// Cholesky chain), bit 1 include the KL term, bit 8 (256) PLL objective (clear: ELBO).  varn [B(p+1)]: var + noise per output.
+// -------------------------------------------------------------------------------------------------------------------------
+extern "C" int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, float* varn, void* workspace,
+                                      size_t workspace_bytes, int flags) {
+    if (int rc = step_validate(ctx, pl, io, workspace, workspace_bytes)) return rc;
+    if (pl->world != 1 || !pl->per_output || !varn) return DSVGP_EINVAL;
+    STEP_LOCALS
+    const bool overlap = (flags & 1) && !ctx->det_slab;
+    const bool include_kl = flags & 2;
+    const int mll_type = (flags & 256) ? 1 : 0;
+    const hipStream_t main = ctx->stream, side = pl->side;
+    double* A64 = (double*)(w + pl->o_A64);
+    float* U32 = (float*)(w + pl->o_U32);
+    float* Abar = (float*)(w + pl->o_Abar);
+    double* Kb64 = (double*)(w + pl->o_Kb64);
+    float* var = (float*)(w + pl->o_var);
+    float* var_bar = (float*)(w + pl->o_varbar);
+    float* W32 = Kzx;                                   // (K_ZX is dead once A has been formed)
+    float* A32 = A32e;
+    float* mu_bar = A32e + (size_t)Mp * Bp;
+    double* Lbar = Qe64;                                // [M', M'] fp64 (the fast path's [Q' | a] scratch)
+    pl->timed = false;
+    struct PrezeroGuard {
+        dsvgp_ctx* c; bool prev;
+        PrezeroGuard(dsvgp_ctx* c_) : c(c_), prev(c_->prezeroed) { c->prezeroed = false; }
+        ~PrezeroGuard() { c->prezeroed = prev; }
+    } prezero_guard(ctx);
+    STEP_HIP(hipMemsetAsync(io->flat, 0, io->flat_floats * sizeof(float), main));
+    STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
+    STEP_CALL(launch_column_mean_hyp(main, io->Z, M, d, center, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp));
+    STEP_CALL(dsvgp_pack_points(ctx, io->Z, io->V, M, d, p, hyp, center, PZ, sZ, vZ));
+    auto prologue = [&]() -> int {
+        int rc = dsvgp_pack_points(ctx, io->x, io->D, B, d, p, hyp, center, PX, sX, vX);
+        if (rc) return rc;
+        return dsvgp_kernel_fwd(ctx, PZ, sZ, M, PX, sX, B, d, p, hyp, 0.f, Kzx, Bp, 0);
+    };
+    if (overlap) {
+        STEP_HIP(hipEventRecord(pl->ev_fork, main));
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork, 0));
+        ctx->stream = side;
+        STEP_CALL(prologue());
+        STEP_HIP(hipEventRecord(pl->ev_side, side));
+        ctx->stream = main;
+    }
+    STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
+    STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
+    STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));
+    STEP_HIP(hipEventRecord(pl->ev_status, main));
+    if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_side, 0));
+    else STEP_CALL(prologue());
+    // ---- forward (DGVS.py:181-205)
+    STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 0, Kzx, Bp, 0, Bp, A64, Bp, A32, Bp, nb, trsm_ws, 1));
+    STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER, Mp, Bp, Mp, 1.0, io->LS, io->ldls, A32, Bp, 0.0, nullptr, 0, W32,
+                         Bp, nullptr, 0, nullptr));                                                          // W = tril(L_S)^T A
+    STEP_CALL(dsvgp_predictive_stats(ctx, A32, Bp, W32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var, stats_ws));
+    STEP_CALL(dsvgp_likelihood_terms(ctx, io->mu, var, io->y, Bp, p, hyp, mll_type, rows, mu_bar, var_bar, varn, scal));
+    // ---- variational parameters
+    STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_A_LOWER, Mp, Bp, Mp, 1.0, io->LS, io->ldls, W32, Bp, 0.0, nullptr, 0, U32, Bp, nullptr, 0,
+                         nullptr));                                                                          // U = L_S W
+    STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, 2.0, A32, Bp, W32, Bp, 0.0, nullptr, 0, io->dLS,
+                         io->lddls, nullptr, 0, var_bar));                                                   // tril(2 A diag(var-bar) W^T)
+    STEP_CALL(dsvgp_abar(ctx, A32, Bp, U32, Bp, Mp, Bp, io->m, mu_bar, var_bar, Abar, Bp));
+    STEP_CALL(dsvgp_rowdot(ctx, A32, Bp, Mp, Bp, mu_bar, io->dm));                                            // m-bar += A mu-bar
+    if (include_kl) STEP_CALL(dsvgp_kl_terms(ctx, io->m, io->LS, io->ldls, Mp, io->num_data, kl_buf, io->dm, io->dLS, io->lddls));
+    // ---- through the triangular solve and the Cholesky factor (fp64)
+    STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 1, Abar, Bp, 0, Bp, Kb64, Bp, Kb32, Bp, nb, trsm_ws, 1));            // K_ZX-bar = L^-T A-bar
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, -1.0, Kb64, Bp, A64, Bp, 0.0, nullptr, 0, Lbar, Mp,
+                         nullptr, 0, nullptr));                                                              // L-bar = -tril(K_ZX-bar A^T)
+    STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    const double* Linv = (const double*)trsm_ws;
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, L, Mp,
+                         Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));                            // tril(L^T L-bar)
+    STEP_CALL(dsvgp_phi_symmetrize(ctx, G1, Mp, Mp));
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0, nullptr,
+                         0, Yt, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0, nullptr,
+                         0, Kbar, Mp, nullptr, 0, nullptr));
+    STEP_CALL(dsvgp_phi_symmetrize(ctx, Kbar, Mp, Mp));
+    STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    return dsvgp_step_epilogue(ctx, scal, kl_buf, rows, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
+                               io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss);
 }
 
 // -------------------------------------------------------------------------------------------------------------------------

@@ -443,6 +443,18 @@ size_t dsvgp_elbo_step_plan_bytes(const dsvgp_step_plan* plan);
 int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_elbo_step_io* io, void* workspace,
                         size_t workspace_bytes, int flags);
 int dsvgp_elbo_step_status(dsvgp_step_plan* plan, float* hyp4, int* info);
+/* The PER-OUTPUT step from one host call (round 5): objectives that read every output's own predictive variance -- mll_type = "PLL"
+ * (PredictiveLogLikelihood, reference directionalvi/directional_vi.py:218-219; what tests/test_grad_svgp.py:19-36 trains with) or the
+ * ELBO with the per-output variances returned -- for which the Gram formulation of dsvgp_elbo_step_f32 does not apply: forward
+ * A = L^-1 K_ZX, W = L_S^T A, mu / var per output (DGVS.py:181-205), likelihood terms, and the backward through U = L_S W,
+ * A-bar, K_ZX-bar = L^-T A-bar, L-bar = -tril(K_ZX-bar A^T), the Cholesky factor and both kernel assemblies.  Same io as above;
+ * plan from dsvgp_elbo_step_po_plan_create, workspace of dsvgp_elbo_step_po_workspace_bytes; varn [B(p+1)] (device) receives
+ * var + noise per output (what likelihood(model(x)).variance returns).  flags: bit 0 overlap, bit 1 include the KL term,
+ * bit 8 (256) PLL objective (clear: ELBO).  Status word / jitter ladder as for dsvgp_elbo_step_f32.                            */
+size_t dsvgp_elbo_step_po_workspace_bytes(int M, int d, int p, int B);
+int dsvgp_elbo_step_po_plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, dsvgp_step_plan** out);
+int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_elbo_step_io* io, float* varn, void* workspace,
+                           size_t workspace_bytes, int flags);
 /* Where an intermediate of the step queued last lies inside the caller's workspace (valid until the next step on it): which = 0:
  * [A ; mu_bar^T], A = L^-1 K_ZX (float [M'+1, B']); 1: K_ZX (float [M', B']); 2: the Cholesky factor L (double [M', M'], lower);
  * 3: L^-1 (double [M', M'], lower); 4: the constrained {lengthscale, outputscale, noise, 0} (float [1, 4]).  The reference's every-50th-step nll print (directional_vi.py:255-260) reads the predictive

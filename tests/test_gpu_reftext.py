@@ -125,6 +125,7 @@ def test_pll_step_against_reference_text_at_baseline_size(dsvgp, gpu_device, nam
     Pg = {k: v.to(gpu_device) for k, v in P.items()}
     loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), D.to(gpu_device), nd, "PLL")
     torch.cuda.synchronize()
+    assert eng.c_step_used            # (round 5: the per-output step is ONE C call, dsvgp_elbo_step_po_f32)
     _check("%s fp32" % name, _errors(g, loss, grads, mu, varn, skip=skip), *TOL32[name[:2]])
     eng64 = ElboEngine64(gpu_device)
     if name.startswith("c3"):

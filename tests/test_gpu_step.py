@@ -923,6 +923,41 @@ def test_one_call_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, 
     assert abs(l1.item() - l_ref.item()) < 2e-5 * abs(l_ref.item()) and relmax(mu1, mu_ref) < 2e-4
 
 
+@pytest.mark.parametrize("N,d,M,p,B", [(600, 5, 40, 2, 128), (500, 20, 30, 5, 96), (3000, 5, 200, 2, 512), (400, 6, 300, 6, 64)])
+@pytest.mark.parametrize("mll", ["PLL", "ELBO"])
+def test_one_call_per_output_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, B, mll):
+    """dsvgp_elbo_step_po_f32 (round 5): the per-output step -- mll_type="PLL" (what the reference's tests/test_grad_svgp.py trains
+    with, directional_vi.py:218-219) or the ELBO with per-output variances -- queues the library calls of the Python-orchestrated
+    per-output path from ONE host call: loss, mean, per-output variance and every gradient agree with that path to the run-order
+    noise of the split-K atomics, and with the oracle like it."""
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=N + d + 3)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    xd, yd, Dd = x.to(gpu_device), y.to(gpu_device), D.to(gpu_device)
+    ref = dsvgp.ElboEngine(gpu_device)
+    ref.c_step = False
+    l0, g0, mu0, vn0 = ref.loss_and_grads(Pg, xd, yd, Dd, nd, mll, fast=False)
+    assert not ref.c_step_used and vn0.numel() == B * (p + 1)
+    for overlap in (None, False):
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.overlap = overlap
+        l1, g1, mu1, vn1 = eng.loss_and_grads(Pg, xd, yd, Dd, nd, mll, fast=False)
+        torch.cuda.synchronize()
+        assert eng.c_step_used and vn1.numel() == B * (p + 1)
+        assert abs(l1.item() - l0.item()) < 4e-6 * abs(l0.item()), (overlap, l1.item(), l0.item())
+        assert relmax(mu1, mu0) < 4e-6 and relmax(vn1, vn0) < 4e-6, (overlap, relmax(mu1, mu0), relmax(vn1, vn0))
+        for k in O.PARAM_NAMES:
+            if g0[k].numel():
+                assert relmax(g1[k], g0[k]) < 5e-5, (overlap, k, relmax(g1[k], g0[k]))
+        assert g1["chol_variational_covar"].triu(1).abs().max().item() == 0.0
+        l2, g2, _, _ = eng.loss_and_grads(Pg, xd, yd, Dd, nd, mll, fast=False)        # second call on the same plan / workspace
+        assert abs(l2.item() - l1.item()) < 4e-6 * abs(l1.item())
+    l_ref, g_ref, mu_ref, vn_ref = O.elbo_loss_and_grads(P, x, y, D, nd, mll)
+    assert abs(l1.item() - l_ref.item()) < 2e-5 * abs(l_ref.item()) and relmax(mu1, mu_ref) < 2e-4 and relmax(vn1, vn_ref) < 2e-4
+    for k in O.PARAM_NAMES:
+        if g_ref[k].numel() and g_ref[k].abs().max().item() > 0:
+            assert relmax(g1[k], g_ref[k]) < 3e-3, (k, relmax(g1[k], g_ref[k]))
+
+
 def test_one_call_step_falls_back_to_the_jitter_ladder(dsvgp, gpu_device):
     """a K_ZZ that needs psd_safe_cholesky's retries: the one-call step reports the failed factorisation through its status word and
     the engine redoes the step on the piecewise path (same result as with the one-call path switched off)"""
