@@ -64,6 +64,7 @@ int launch_splitk_reduce(hipStream_t st, int is_double, const void* slab, int ns
                          float* C32, int64_t ldc32, int out_lower, int accumulate);
 constexpr int DSVGP_GEMM_KEEP_UPPER = 1 << 20;   // internal flag (with OUT_LOWER): do not touch m < n
 constexpr int DSVGP_GEMM_C_ZEROED = 1 << 21;     // internal flag: the caller has cleared C / C32 (skip the launcher's own clears)
+constexpr int DSVGP_GEMM_UPPER_UNDEF = 1 << 22;  // internal flag (with OUT_LOWER, gemm32.hip): nobody reads the strict upper triangle -- leave it undefined instead of zero-filling it
 int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g);
 // zero an M x N block (element size esz) with leading dimension ld: linear memset for contiguous rows, a fill kernel of our
 // own for padded rows (the runtime's pitched 2-D memset runs below 1 TB/s) -- gemm.hip

@@ -567,7 +567,7 @@ int g32_read_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(o
 // of work per tile; OUT_LOWER (square tile grids) zero-fills the strict upper triangle like gemm.hip does.
 int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     const int fl = g.flags;
-    if (fl & ~(DSVGP_GEMM_TRANS_A | DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED | DSVGP_GEMM_C_ZEROED)) return 0;
+    if (fl & ~(DSVGP_GEMM_TRANS_A | DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED | DSVGP_GEMM_C_ZEROED | DSVGP_GEMM_UPPER_UNDEF)) return 0;
     if (g.batch != 1 || g.splitk != 1 || g.Cin || g.kscale || g.C32 || !g.C || g.beta != 0.0) return 0;
     if (g.M < 512 || g.N < 512 || g.K < 512) return 0;
     if (g.lda % 4 || g.ldb % 4 || ((uintptr_t)g.A % 16) || ((uintptr_t)g.B % 16)) return 0;     // 16-byte vector loads
@@ -610,7 +610,7 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     a.kslice = cdiv(cdiv(g.K, sk), 32) * 32;
     a.splitk = cdiv(g.K, a.kslice);
     a.slab = (g.slab && a.splitk > 1) ? (float*)g.slab : nullptr;
-    if (!a.slab && (a.splitk > 1 || out_lower) && !(fl & DSVGP_GEMM_C_ZEROED)) {
+    if (!a.slab && (a.splitk > 1 || (out_lower && !(fl & DSVGP_GEMM_UPPER_UNDEF))) && !(fl & DSVGP_GEMM_C_ZEROED)) {
         // atomics accumulate onto zeros / the strict upper triangle is defined as zero
         // (contiguous rows: one linear fill -- the 2-D fill kernel of the runtime takes 104 us for 36 MB, the linear one ~10)
         hipError_t e = zero_block(a.C, sizeof(float), a.ldc, a.M, a.N, st);

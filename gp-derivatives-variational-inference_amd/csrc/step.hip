@@ -452,10 +452,19 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         ctx->stream = main;
     } else
     STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
-    STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));     // hyp[4] | info: contiguous
-    STEP_HIP(hipEventRecord(pl->ev_status, main));
-    if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_side, 0));
-    else STEP_CALL(prologue(false));
+    if (overlap) {
+        // the status word's copy to the host leaves the main stream (a 5 us blit between the chain and the solve at M' = 600): the side
+        // stream makes it behind an event the main stream records after the factorisation
+        STEP_HIP(hipStreamWaitEvent(main, pl->ev_side, 0));
+        STEP_HIP(hipEventRecord(pl->ev_fork2, main));
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
+        STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, side));     // hyp[4] | info: contiguous
+        STEP_HIP(hipEventRecord(pl->ev_status, side));
+    } else {
+        STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));
+        STEP_HIP(hipEventRecord(pl->ev_status, main));
+        STEP_CALL(prologue(false));
+    }
     // ---- A = L^-1 K_ZX (fp64 product with the explicit inverse, fp32 result), mu = A^T m + c, residuals (DGVS.py:181-188)
     if (pipe) {
         STEP_CALL(solve_rows(r2, Mp, 0));
@@ -549,7 +558,8 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         if (qe32_free && !(flags & 64)) {
             GemmArgs g{};
             g.M = Mp; g.N = Mp; g.K = Mp + 1; g.A = S32e; g.lda = ldS; g.B = Ge; g.ldb = Mp; g.C = Qe32; g.ldc = ldQ32;
-            g.alpha = -1.0; g.beta = 0.0; g.flags = DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED; g.batch = 1; g.splitk = 1;
+            g.alpha = -1.0; g.beta = 0.0; g.batch = 1; g.splitk = 1;
+            g.flags = DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED | DSVGP_GEMM_UPPER_UNDEF;     // (the widening below reads the lower triangle only: no zero fill of the rest)
             g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
             const int rc = launch_gemm32(ctx->stream, g);          // (clears the output itself: Qe32 is not part of the prezeroed arena)
             if (rc > 1) return rc;

@@ -412,3 +412,30 @@ def test_virtual_ranks_through_the_dp_c_entry(dsvgp, gpu_device, world, M, p, B)
             assert err < 3e-4, (world, r, k, err)
         for k in grads:                      # identical replicas: what the un-synchronised Adam steps rely on
             assert torch.equal(grads[k], out[0][1][k]), (world, r, k)
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_of_a_four_rank_rehearsal(gpu_device):
+    """`bench.py --gpus 4` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE card over gloo
+    (DSVGP_REHEARSE_GLOO=1; four rank processes + this one stay under the box's six-process limit): the JSON line carries the
+    world size, the collective block (backend, packed early operand, exposed waits) and a finite whole-job figure."""
+    import json
+    import subprocess
+    env = dict(os.environ, DSVGP_REHEARSE_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "c4", "--steps", "4", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extras"]             # (C4: M' = 3000 >= ElboEngine.shard_min_mp, the regime of the five-piece C entry)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 4 and j["rccl_ranks"] == 4 and j["steps"] == 4
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["config"]["per_gpu_batch"] * 4 == j["config"]["global_batch"]
+    coll = j["config"]["collective"]
+    assert coll["backend"] == "gloo" and coll["packed_triangle"] and coll["early_operand_floats"] > 0
+    assert j["config"]["one_call_step"]                     # the five-piece C entry, not the piecewise orchestration
