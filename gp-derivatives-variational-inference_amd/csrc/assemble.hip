@@ -249,7 +249,9 @@ constexpr int FWD_PAIR_LDT = 52;
 #ifndef FWDP_FAST
 #define FWDP_FAST 1       // interior tiles leave through the T' tile as fully coalesced 16-byte stores
 #endif
-template <typename OutT, int Q>
+// KSM: k-steps of the T' product the A fragments are held for: 8 (packed width DP <= 32: d <= 28, the BASELINE configs 2 and 4) or 16
+// (DP <= 64: d <= 60, BASELINE config 5 at d = 50; round 5 -- more registers: one wave per SIMD instead of two)
+template <typename OutT, int Q, int KSM = 8>
 __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const float* __restrict__ P1, const float* __restrict__ self1,
                                                              int n1q, const float* __restrict__ P2,
                                                              const float* __restrict__ self2, int n2q, int K4, int DP,
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
     const float ell = hyp[0], s = hyp[1];
     const float il = 1.f / ell, il2 = il * il;
 
-    float areg[3][8];                   // A fragments: areg[i][ks] = P1'[row0 + 16 i + m16][4 ks + kg]  (KS <= 8 since DP <= 32)
+    float areg[3][KSM];                 // A fragments: areg[i][ks] = P1'[row0 + 16 i + m16][4 ks + kg]  (KS <= KSM since DP <= 4 KSM)
     if (FWDP_AREG) {
         for (int e = lane; e < 48 * LDP; e += 64) P2s[e] = 0.f;
 #pragma unroll
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
             const int a = (i * 16 + m16) % Q;
             const float sf = ok ? self1[gr] : 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < KSM; ++ks) {
                 float v = 0.f;
                 if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
                 else if (ks == K4 / 4 && ok) v = (kg == 1) ? (a == 0 ? 1.f : 0.f) : ((kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f);
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
         s1r0[pp] = prow[pp] ? self1[row0 + pr0[pp]] : 0.f;
     }
 
-    constexpr int NPFP = (48 * 8 + 63) / 64;       // float4 per lane of one prefetched P2 tile (DP <= 32)
+    constexpr int NPFP = (48 * KSM + 63) / 64;     // float4 per lane of one prefetched P2 tile (DP <= 4 KSM)
     f4 pf[NPFP];
     float pselfv = 0.f;
     // The packed rows of a column tile are ONE contiguous piece of P2 (T rows of DP floats): float4 number e = lane + 64 u of it
@@ -448,7 +450,21 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                     case 5: product(std::integral_constant<int, 5>{}); break;
                     case 6: product(std::integral_constant<int, 6>{}); break;
                     case 7: product(std::integral_constant<int, 7>{}); break;
-                    default: product(std::integral_constant<int, 8>{}); break;
+                    case 8: product(std::integral_constant<int, 8>{}); break;
+                    default:
+                        if constexpr (KSM > 8) {
+                            switch (KS) {
+                                case 9: product(std::integral_constant<int, 9>{}); break;
+                                case 10: product(std::integral_constant<int, 10>{}); break;
+                                case 11: product(std::integral_constant<int, 11>{}); break;
+                                case 12: product(std::integral_constant<int, 12>{}); break;
+                                case 13: product(std::integral_constant<int, 13>{}); break;
+                                case 14: product(std::integral_constant<int, 14>{}); break;
+                                case 15: product(std::integral_constant<int, 15>{}); break;
+                                default: product(std::integral_constant<int, 16>{}); break;
+                            }
+                        } else product(std::integral_constant<int, 8>{});
+                        break;
                 }
             } else
             for (int ks = 0; ks < ((FWDP_ABL & 2) ? 1 : KS); ++ks) {
@@ -605,6 +621,181 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                 }
 #pragma unroll
                 for (int b = 0; b < Q; ++b) o[a * ld + b] = (OutT)v[b];
+            }
+        }
+    }
+}
+
+// ---- forward, "split" variant for wide micro-blocks (round 5) ------------------------------------------------------------
+// q = 11 (full-gradient SVGP at d = 10: BASELINE config 3, GradVariationalStrategy.py:89-99) leaves the pair kernel's mapping
+// (one lane per point pair, the Q x Q micro-block in registers) with R^2 = 16 pairs per 44 x 44 tile and 121 values per lane.
+// Here SPL = 64 / R^2 lanes share a pair: lane (pair, sub) takes the micro-block rows a = sub, sub + SPL, ..., reads row 0 of the
+// T' micro-block (w_b; every lane of the pair needs it) and its own rows from LDS, and writes its rows back IN PLACE; the tile
+// then leaves as fully coalesced 16-byte stores (T = 44: every row 176 contiguous bytes) like the pair kernel's interior path.
+// One wave per workgroup, the A fragments of its T side-1 rows in registers for the whole column sweep, T' overlays the packed
+// side-2 rows it was computed from.  Same arithmetic as kernel_fwd_pair_kernel (self terms folded into two extra packed columns).
+template <typename OutT, int Q, int KSM>
+__global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __restrict__ P1, const float* __restrict__ self1, int n1q,
+                                                              const float* __restrict__ P2, const float* __restrict__ self2, int n2q,
+                                                              int K4, int DP, int ovec, const float* __restrict__ hyp, float jitter,
+                                                              OutT* __restrict__ out, int64_t ld) {
+    constexpr int R = 48 / Q, T = R * Q, NPAIR = R * R, SPL = 64 / NPAIR, RPL = (Q + SPL - 1) / SPL;
+    constexpr int LDT2 = FWD_PAIR_LDT;
+    static_assert(NPAIR * SPL <= 64 && SPL >= 2 && T % 4 == 0, "split mapping: R^2 pairs x SPL lanes, 16-byte rows");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP = K4 + 5;
+    float* P2s = smem;                  // [49][LDP]  packed side-2 rows of the tile (+ a scratch row), overlaid by ...
+    float* TT = smem;                   // [48][LDT2] ... the T' tile once every B fragment is in registers
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * T;
+    const int ncoltiles = (n2q + T - 1) / T;
+    const int KS = K4 / 4 + 1, pch = DP / 4;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+
+    float areg[3][KSM];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int lr = i * 16 + m16, gr = row0 + lr;
+        const bool ok = lr < T && gr < n1q;
+        const int a = lr % Q;
+        const float sf = ok ? self1[gr] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            float v = 0.f;
+            if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
+            else if (ks == K4 / 4 && ok) v = (kg == 1) ? (a == 0 ? 1.f : 0.f) : ((kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f);
+            areg[i][ks] = v;
+        }
+    }
+    for (int e = lane; e < 49 * LDP; e += 64) P2s[e] = 0.f;
+    // this lane's share of the tile: pair (pi, pj), rows a = sub + SPL i of its micro-block
+    const int pid = lane / SPL, sub = lane - pid * SPL;
+    const int pi = pid / R, pj = pid - pi * R;
+    const int pr0 = pi * Q, pc0 = pj * Q;
+    const bool pvalid = pid < NPAIR;
+    const bool prow = pvalid && row0 + pr0 < n1q;
+    const float s1r0 = prow ? self1[row0 + pr0] : 0.f;
+    const bool rows_full = row0 + T <= n1q;
+    // consecutive column tiles per wave (as in the pair kernel: neighbouring tiles complete each other's cache lines)
+    const int cper = (ncoltiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ct_lo = blockIdx.x * cper, ct_hi = min(ct_lo + cper, ncoltiles);
+    // the packed rows of a column tile are one contiguous piece of P2 (T rows of DP floats); the NEXT tile's travel through
+    // registers under the current tile's transform and stores
+    constexpr int NPF = (T * KSM + 63) / 64;       // float4 per lane (pch <= KSM)
+    f4 pf[NPF];
+    float pselfv = 0.f;
+    auto prefetch = [&](int ct_) {
+        const int c0_ = ct_ * T;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (e < T * pch && c0_ + r < n2q) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(c0_ + r) * DP + k);
+        }
+        pselfv = (lane < T && c0_ + lane < n2q) ? -self2[c0_ + lane] : 0.f;
+    };
+    if (ct_lo < ct_hi) prefetch(ct_lo);
+    for (int ct = ct_lo; ct < ct_hi; ++ct) {
+        const int col0 = ct * T;
+        const bool colok = prow && col0 + pc0 < n2q;
+        const float s2c0 = colok ? self2[col0 + pc0] : 0.f;
+        __syncthreads();                 // (single wave: the previous tile's LDS reads are done)
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            if (e < T * pch) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
+            }
+        }
+        __syncthreads();
+        if (lane < T) {
+            P2s[lane * LDP + K4 + 1] = pselfv;
+            P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
+        }
+        if (ct + 1 < ct_hi) prefetch(ct + 1);
+        __syncthreads();
+        {
+            f4 t[3][3];
+            const float* pb = P2s + m16 * LDP + kg;
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks) {
+                if (ks < KS) {
+                    float bv[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bv[j] = pb[j * 16 * LDP + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();             // every B fragment has been read: T' may overlay the packed rows
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
+        }
+        __syncthreads();
+        // ---- micro-block transform, rows split over the SPL lanes of a pair
+        float* blk = TT + pr0 * LDT2 + pc0;
+        float t0[Q], ta[RPL][Q];
+        if (pvalid) {
+#pragma unroll
+            for (int b = 0; b < Q; ++b) t0[b] = blk[b];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int a = sub + SPL * i;
+#pragma unroll
+                for (int b = 0; b < Q; ++b) ta[i][b] = (a < Q) ? blk[a * LDT2 + b] : 0.f;
+            }
+        }
+        __syncthreads();                 // row 0 is rewritten by the lane with sub = 0: every lane of the pair has read it
+        const float nn = fmaxf(s1r0 - s2c0 - 2.f * t0[0], 0.f);      // covar_dist clamps at 0
+        const float k = s * expf(-0.5f * nn);                          // postprocess_rbf, ScaleKernel
+        const float kil = k * il, kil2 = k * il2;
+        const int64_t gr0 = (int64_t)row0 + pr0, gc0 = (int64_t)col0 + pc0;
+        const bool fast = sizeof(OutT) == 4 && (ovec & 2) && rows_full && col0 + T <= n2q;     // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int a = sub + SPL * i;
+            float v[Q];
+            if (a == 0) {
+                v[0] = k;
+#pragma unroll
+                for (int b = 1; b < Q; ++b) v[b] = t0[b] * kil;                                  // w_b k / ell
+            } else {
+                v[0] = ta[i][0] * kil;                                                           // -u_a k / ell
+#pragma unroll
+                for (int b = 1; b < Q; ++b) v[b] = (ta[i][b] + ta[i][0] * t0[b]) * kil2;         // (G_ab - u_a w_b) k / ell^2
+            }
+            if (jitter != 0.f && gr0 == gc0) {
+#pragma unroll
+                for (int b = 0; b < Q; ++b) if (b == a) v[b] += jitter;                          // diagonal of the diagonal micro-block
+            }
+            if (!pvalid || a >= Q) continue;
+            if (fast) {
+#pragma unroll
+                for (int b = 0; b < Q; ++b) blk[a * LDT2 + b] = v[b];
+            } else if (colok) {          // edge tiles / double output: the lane stores its own rows
+                OutT* o = out + (gr0 + a) * ld + gc0;
+#pragma unroll
+                for (int b = 0; b < Q; ++b) o[b] = (OutT)v[b];
+            }
+        }
+        if (fast) {
+            __syncthreads();
+            if constexpr (sizeof(OutT) == 4) {
+                float* orow = (float*)out + (int64_t)row0 * ld + col0;
+                constexpr int C4 = T / 4;
+                for (int id = lane; id < T * C4; id += 64) {
+                    const int r = id / C4, c4 = (id - C4 * r) * 4;
+                    *reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4) = *reinterpret_cast<const f4*>(TT + r * LDT2 + c4);
+                }
             }
         }
     }
@@ -1135,8 +1326,9 @@ constexpr int PAIR_WGS = PAIR_WGS_;
 #ifndef BWDP_PREFETCH
 #define BWDP_PREFETCH 0    // 1: the next tile's packed side-2 rows travel through registers under the current tile (36 more registers,
 #endif                     //    same time at 8 waves per CU: 157 us either way)
-template <typename GT, int Q>
-__global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT* __restrict__ G, int64_t ldg,
+// KSM: as for kernel_fwd_pair_kernel (8: DP <= 32, 16: DP <= 64); the dP1 accumulators cover NP = 4 KSM packed columns
+template <typename GT, int Q, int KSM = 8>
+__global__ __launch_bounds__(64, KSM > 8 ? 1 : BWDP_MINW) void kernel_bwd_pair_kernel(const GT* __restrict__ G, int64_t ldg,
                                                              const float* __restrict__ P1, const float* __restrict__ self1,
                                                              int n1q, const float* __restrict__ P2,
                                                              const float* __restrict__ self2, int n2q, int K4, int DP,
@@ -1153,7 +1345,8 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
     const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
     const int row0 = blockIdx.y * T;
     const int ncoltiles = (n2q + T - 1) / T;
-    const int nnp = NP / 16;            // 1 or 2
+    const int nnp = NP / 16;            // 1 .. KSM / 4
+    constexpr int NNP = KSM / 4;
     const int KS = K4 / 4 + 1;
     const int pch = DP / 4;
     const float ell = hyp[0], s = hyp[1];
@@ -1161,7 +1354,7 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
     const bool vec = gvec != 0;
 
     for (int e = lane; e < 48 * LDP; e += 64) P2s[e] = 0.f;
-    float areg[3][8];                   // areg[i][ks] = P1'[row0 + 16 i + m16][4 ks + kg]  (KS <= 8 since DP <= 32)
+    float areg[3][KSM];                 // areg[i][ks] = P1'[row0 + 16 i + m16][4 ks + kg]  (KS <= KSM since DP <= 4 KSM)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int gr = row0 + i * 16 + m16;
@@ -1169,7 +1362,7 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
         const int a = (i * 16 + m16) % Q;
         const float sf = ok ? self1[gr] : 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KSM; ++ks) {
             float v = 0.f;
             if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
             else if (ks == K4 / 4 && ok) v = (kg == 1) ? (a == 0 ? 1.f : 0.f) : ((kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f);
@@ -1177,7 +1370,7 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
         }
     }
     // the packed rows of the NEXT column tile travel through registers under the current tile's work
-    constexpr int NPFP = (48 * 8 + 63) / 64;       // float4 per lane of one P2 tile (DP <= 32)
+    constexpr int NPFP = (48 * KSM + 63) / 64;     // float4 per lane of one P2 tile (DP <= 4 KSM)
     // (the packed rows of a column tile are one contiguous piece of P2: see kernel_fwd_pair_kernel)
     int pf_r[NPFP], pf_k[NPFP], pf_e[NPFP], pf_lds[NPFP];
 #pragma unroll
@@ -1222,9 +1415,11 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
         s1r0[pp] = prow[pp] ? self1[row0 + pr0[pp]] : 0.f;
     }
 
-    f4 acc[3][2];
+    f4 acc[3][NNP];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { acc[i][0] = f4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NNP; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     float sK_sum = 0.f, l_acc = 0.f;
 
     if (BWDP_PREFETCH && (int)blockIdx.x < ncoltiles) prefetch(blockIdx.x);
@@ -1297,7 +1492,21 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
                 case 5: product(std::integral_constant<int, 5>{}); break;
                 case 6: product(std::integral_constant<int, 6>{}); break;
                 case 7: product(std::integral_constant<int, 7>{}); break;
-                default: product(std::integral_constant<int, 8>{}); break;
+                case 8: product(std::integral_constant<int, 8>{}); break;
+                default:
+                    if constexpr (KSM > 8) {
+                        switch (KS) {
+                            case 9: product(std::integral_constant<int, 9>{}); break;
+                            case 10: product(std::integral_constant<int, 10>{}); break;
+                            case 11: product(std::integral_constant<int, 11>{}); break;
+                            case 12: product(std::integral_constant<int, 12>{}); break;
+                            case 13: product(std::integral_constant<int, 13>{}); break;
+                            case 14: product(std::integral_constant<int, 14>{}); break;
+                            case 15: product(std::integral_constant<int, 15>{}); break;
+                            default: product(std::integral_constant<int, 16>{}); break;
+                        }
+                    } else product(std::integral_constant<int, 8>{});
+                    break;
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -1390,15 +1599,16 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
             const float* pb = P2s + kg * LDP + m16;
 #pragma unroll
             for (int kk = 0; kk < 48; kk += 4) {
-                float av[3], bv[2];
+                float av[3], bv[NNP];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) av[i] = pa[i * 16 * LDT2 + kk];
-                bv[0] = pb[kk * LDP];
-                bv[1] = nnp > 1 ? pb[kk * LDP + 16] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NNP; ++j) bv[j] = (j < nnp) ? pb[kk * LDP + 16 * j] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[0], acc[i][0], 0, 0, 0);
-                    if (nnp > 1) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[1], acc[i][1], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NNP; ++j)
+                        if (j < nnp) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -1408,7 +1618,7 @@ __global__ __launch_bounds__(64, BWDP_MINW) void kernel_bwd_pair_kernel(const GT
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NNP; ++j)
             if (j < nnp) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1521,7 +1731,7 @@ inline int make_geom(int d, int p, Geom& g) {
     if (g.NP > 96) return DSVGP_EINVAL;   // d <= 88
     return 0;
 }
-inline bool bwd_use_pair(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 32; }
+inline bool bwd_use_pair(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 64; }     // (NP <= 32: KSM = 8; <= 64: KSM = 16)
 // row-tile height / column-tile width / workgroup budget of the backward variant that will run
 inline void bwd_tiles(const Geom& g, int& tr, int& tc, int& wgs) {
     if (bwd_use_pair(g)) { tr = tc = (48 / g.q) * g.q; wgs = PAIR_WGS; }
@@ -1642,7 +1852,28 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
             return 0;
         }
     }
-    if ((g.q == 6 || g.q == 3) && g.NP <= 32) {
+#ifndef FWD_NO_SPLIT
+    if (g.q == 11 && g.K4 <= 12) {      // full-gradient SVGP at d <= 12 (BASELINE config 3): the split-row kernel
+        const int T = 44;
+        const int rt = cdiv(n1q, T), ctiles = cdiv(n2q, T);
+        int ns = FWD_PAIR_WGS_ / rt;
+        if (ns < 1) ns = 1;
+        if (ns > ctiles) ns = ctiles;
+        const size_t p2w_ = 49 * (size_t)(g.K4 + 5), ttw_ = 48 * (size_t)FWD_PAIR_LDT;
+        const size_t lds = sizeof(float) * (p2w_ > ttw_ ? p2w_ : ttw_);
+        const int ovec = (!out_is_double && ld % 4 == 0 && (uintptr_t)out % 16 == 0) ? 2 : 0;
+        dim3 grid(ns, rt);
+        if (out_is_double)
+            hipLaunchKernelGGL((kernel_fwd_split_kernel<double, 11, 4>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, n2q,
+                               g.K4, g.DP, ovec, hyp, jitter, (double*)out, ld);
+        else
+            hipLaunchKernelGGL((kernel_fwd_split_kernel<float, 11, 4>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, n2q,
+                               g.K4, g.DP, ovec, hyp, jitter, (float*)out, ld);
+        DSVGP_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    if ((g.q == 6 || g.q == 3) && g.NP <= 64) {
         const int T = (48 / g.q) * g.q;
         const int rt = cdiv(n1q, T), ctiles = cdiv(n2q, T);
         int ns = FWD_PAIR_WGS_ / rt;
@@ -1656,11 +1887,16 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
         const int ovec = (((ld % 2 == 0) && ((uintptr_t)out % (2 * esz) == 0)) ? 1 : 0) |
                          ((!out_is_double && ld % 4 == 0 && (uintptr_t)out % 16 == 0 && FWDP_ST16) ? 2 : 0);
         dim3 grid(ns, rt);
-#define DSVGP_FWD_PAIR(OT_, Q_)                                                                                      \
-        hipLaunchKernelGGL((kernel_fwd_pair_kernel<OT_, Q_>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, \
+#define DSVGP_FWD_PAIR(OT_, Q_, KSM_)                                                                                \
+        hipLaunchKernelGGL((kernel_fwd_pair_kernel<OT_, Q_, KSM_>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, \
                            n2q, g.K4, g.DP, ovec, hyp, jitter, (OT_*)out, ld)
-        if (out_is_double) { if (g.q == 6) DSVGP_FWD_PAIR(double, 6); else DSVGP_FWD_PAIR(double, 3); }
-        else { if (g.q == 6) DSVGP_FWD_PAIR(float, 6); else DSVGP_FWD_PAIR(float, 3); }
+        if (g.NP <= 32) {
+            if (out_is_double) { if (g.q == 6) DSVGP_FWD_PAIR(double, 6, 8); else DSVGP_FWD_PAIR(double, 3, 8); }
+            else { if (g.q == 6) DSVGP_FWD_PAIR(float, 6, 8); else DSVGP_FWD_PAIR(float, 3, 8); }
+        } else {
+            if (out_is_double) { if (g.q == 6) DSVGP_FWD_PAIR(double, 6, 16); else DSVGP_FWD_PAIR(double, 3, 16); }
+            else { if (g.q == 6) DSVGP_FWD_PAIR(float, 6, 16); else DSVGP_FWD_PAIR(float, 3, 16); }
+        }
 #undef DSVGP_FWD_PAIR
         DSVGP_LAUNCH_CHECK();
         return 0;
@@ -1722,11 +1958,16 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
         const int esz = g_is_double ? 8 : 4;
         const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);    // 2-wide loads of the micro-block rows
         dim3 grid(ns, rt);
-#define DSVGP_PAIR_LAUNCH(GT_, Q_)                                                                                      \
-        hipLaunchKernelGGL((kernel_bwd_pair_kernel<GT_, Q_>), grid, dim3(64), lds, ctx->stream, (const GT_*)G, ldg, P1, self1, \
+#define DSVGP_PAIR_LAUNCH(GT_, Q_, KSM_)                                                                                \
+        hipLaunchKernelGGL((kernel_bwd_pair_kernel<GT_, Q_, KSM_>), grid, dim3(64), lds, ctx->stream, (const GT_*)G, ldg, P1, self1, \
                            n1q, P2, self2, n2q, g.K4, g.DP, g.NP, gvec, hyp, slab, partials)
-        if (g_is_double) { if (g.q == 6) DSVGP_PAIR_LAUNCH(double, 6); else DSVGP_PAIR_LAUNCH(double, 3); }
-        else { if (g.q == 6) DSVGP_PAIR_LAUNCH(float, 6); else DSVGP_PAIR_LAUNCH(float, 3); }
+        if (g.NP <= 32) {
+            if (g_is_double) { if (g.q == 6) DSVGP_PAIR_LAUNCH(double, 6, 8); else DSVGP_PAIR_LAUNCH(double, 3, 8); }
+            else { if (g.q == 6) DSVGP_PAIR_LAUNCH(float, 6, 8); else DSVGP_PAIR_LAUNCH(float, 3, 8); }
+        } else {
+            if (g_is_double) { if (g.q == 6) DSVGP_PAIR_LAUNCH(double, 6, 16); else DSVGP_PAIR_LAUNCH(double, 3, 16); }
+            else { if (g.q == 6) DSVGP_PAIR_LAUNCH(float, 6, 16); else DSVGP_PAIR_LAUNCH(float, 3, 16); }
+        }
 #undef DSVGP_PAIR_LAUNCH
         DSVGP_LAUNCH_CHECK();
     } else {

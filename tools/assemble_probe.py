@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the kernel-assembly forward (K_ZX at C4 size) for the library named by DSVGP_LIB_PATH."""
+"""Time the kernel-assembly forward (K_ZX; geometry FWD_GEOM="M,B,d,p", default C4: 500,4096,20,5) for the library named by DSVGP_LIB_PATH."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,7 @@ import dsvgp_amd
 ops = dsvgp_amd._ops
 dev = torch.device("cuda", 0)
 ctx = ops.Context.get(dev)
-M, B, d, p = 500, 4096, 20, 5
+M, B, d, p = (int(v) for v in os.environ.get("FWD_GEOM", "500,4096,20,5").split(","))
 hyp = torch.tensor([0.69, 0.69, 0.1, 0.0], device=dev)
 Z, V = torch.rand(M, d, device=dev), torch.eye(d, device=dev)[:p].repeat(M, 1)
 X, D = torch.rand(B, d, device=dev), torch.eye(d, device=dev)[:p].repeat(B, 1)
