@@ -1639,6 +1639,278 @@ __global__ __launch_bounds__(64, KSM > 8 ? 1 : BWDP_MINW) void kernel_bwd_pair_k
     }
 }
 
+// ---- backward, "split" variant for wide micro-blocks (round 5; q = 11: BASELINE config 3) -----------------------------------------
+// The mapping of kernel_fwd_split_kernel applied to kernel_bwd_pair_kernel's data flow: ONE WAVE per workgroup owns R = 48 / Q points
+// of side 1 (T = R Q rows) and sweeps T-column tiles; SPL = 64 / R^2 consecutive lanes share a point pair, lane (pair, sub) takes the
+// micro-block rows a = sub, sub + SPL, ...  The upstream tile arrives through LDS (coalesced 16-byte loads instead of Q x Q scalars
+// per lane), T' = P1' P2'^T from MFMA through LDS; a lane reads row 0 of both micro-blocks and its own rows, the sums that run over
+// ALL rows of the micro-block (gu_b = sum_a g_ab u_a and three scalars) are added across the SPL lanes of the pair by two quad
+// shuffles, and the lane with sub = 0 finishes row 0.  Tbar goes back to the T' tile in place: the A operand of dP1 += Tbar P2ext.
+// Measured at the C3 geometry (M = 300, B = 512, d = 10, q = 11; K_ZX-bar 74 MB, whole dsvgp_kernel_bwd; profiles/r05_c_assemble_c3_c5.txt):
+// generic kernel with runtime q 132 us, its compile-time q = 11 instance 111, this kernel 101-104 at 2048 waves (with or without the
+// register prefetch of the next tile), 93 at 1024 waves; phase ablations at 1024 waves: no transform 75, no dP1 product 61, no T'
+// product 83, no upstream loads 79, none of them 23 -- the phases ADD UP (one wave per SIMD: nothing overlaps them), which is what
+// keeps it at 0.10 of the HBM roof.  Kept because it is the fastest of the three; the backward of wide micro-blocks is an open item.
+#ifndef BWDS_PREFETCH
+#define BWDS_PREFETCH 0
+#endif
+#ifndef BWDS_WGS
+#define BWDS_WGS (256 * 4)
+#endif
+#ifndef BWDS_ABL
+#define BWDS_ABL 0         // tools only (wrong results): bit 0 = no transform, 1 = no dP1 MFMA, 2 = no T' MFMA, 3 = no upstream loads
+#endif
+template <typename GT, int Q, int KSM>
+__global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restrict__ G, int64_t ldg, const float* __restrict__ P1,
+                                                              const float* __restrict__ self1, int n1q, const float* __restrict__ P2,
+                                                              const float* __restrict__ self2, int n2q, int K4, int DP, int NP, int gvec,
+                                                              const float* __restrict__ hyp, float* __restrict__ slab,
+                                                              float* __restrict__ partials) {
+    constexpr int R = 48 / Q, T = R * Q, NPAIR = R * R, SPL = 64 / NPAIR, RPL = (Q + SPL - 1) / SPL;
+    constexpr int LDT2 = PAIR_LDT, LDG = PAIR_LDT, NNP = KSM / 4;      // (row stride 52: 16-byte rows, 20 banks apart)
+    static_assert(NPAIR * SPL == 64 && SPL == 4 && T % 4 == 0, "split mapping: R^2 pairs x 4 lanes (quad shuffles), 16-byte rows");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDP = NP + 1;
+    float* P2s = smem;                                   // [49][LDP]  extended side-2 packs of the tile
+    float* TT = P2s + ((49 * LDP + 3) & ~3);             // [48][LDT2] T', then Tbar in place
+    float* GG = TT + 48 * LDT2;                          // [T][LDG]   upstream tile
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * T;
+    const int ncoltiles = (n2q + T - 1) / T;
+    const int nnp = NP / 16, KS = K4 / 4 + 1, pch = DP / 4;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+
+    for (int e = lane; e < 49 * LDP; e += 64) P2s[e] = 0.f;
+    for (int e = lane; e < 48 * LDT2; e += 64) TT[e] = 0.f;
+    float areg[3][KSM];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int lr = i * 16 + m16, gr = row0 + lr;
+        const bool ok = lr < T && gr < n1q;
+        const int a = lr % Q;
+        const float sf = ok ? self1[gr] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            float v = 0.f;
+            if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
+            else if (ks == K4 / 4 && ok) v = (kg == 1) ? (a == 0 ? 1.f : 0.f) : ((kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f);
+            areg[i][ks] = v;
+        }
+    }
+    const int pid = lane / SPL, sub = lane - pid * SPL;
+    const int pi = pid / R, pj = pid - pi * R;
+    const int pr0 = pi * Q, pc0 = pj * Q;
+    const bool prow = row0 + pr0 < n1q;
+    const float s1r0 = prow ? self1[row0 + pr0] : 0.f;
+    f4 acc[3][NNP];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NNP; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float sK_sum = 0.f, l_acc = 0.f;
+    constexpr int C4 = T / 4;                              // 16-byte pieces per upstream tile row
+
+    // the NEXT tile's upstream rows and packed side-2 rows travel through registers under the current tile's work
+    constexpr int NGF = (T * C4 + 63) / 64, NPF = (T * KSM + 63) / 64;
+    f4 gf[NGF], pf[NPF];
+    auto prefetch = [&](int ct_) {
+        const int c0_ = ct_ * T;
+        const bool interior = row0 + T <= n1q && c0_ + T <= n2q;
+#pragma unroll
+        for (int u = 0; u < NGF; ++u) {
+            const int id = lane + 64 * u, r = id / C4, c = (id - C4 * r) * 4;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (id < T * C4 && !(BWDS_ABL & 8)) {
+                const GT* src = G + (int64_t)(row0 + r) * ldg + c0_ + c;
+                if (interior && gvec) {
+                    if constexpr (sizeof(GT) == 4) {
+                        v = *reinterpret_cast<const f4*>(src);
+                    } else {
+                        using D2 = double __attribute__((ext_vector_type(2)));
+                        const D2 v0 = *reinterpret_cast<const D2*>(src), v1 = *reinterpret_cast<const D2*>(src + 2);
+                        v = f4{(float)v0[0], (float)v0[1], (float)v1[0], (float)v1[1]};
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (row0 + r < n1q && c0_ + c + t < n2q) v[t] = (float)src[t];
+                }
+            }
+            gf[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (e < T * pch && c0_ + r < n2q) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(c0_ + r) * DP + k);
+        }
+    };
+    if (BWDS_PREFETCH && (int)blockIdx.x < ncoltiles) prefetch(blockIdx.x);
+    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
+        const int col0 = ct * T;
+        const bool colok = prow && col0 + pc0 < n2q;
+        const float s2c0 = colok ? self2[col0 + pc0] : 0.f;
+        __syncthreads();                                   // (single wave: the previous tile's MFMA reads of P2s / TT are done)
+        if (!BWDS_PREFETCH) prefetch(ct);
+#pragma unroll
+        for (int u = 0; u < NGF; ++u) {
+            const int id = lane + 64 * u, r = id / C4, c = (id - C4 * r) * 4;
+            if (id < T * C4) *reinterpret_cast<f4*>(GG + r * LDG + c) = gf[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            if (e < T * pch) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
+            }
+        }
+        if (BWDS_PREFETCH && ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);
+        __syncthreads();
+        if (lane < T) {
+            const bool ok = col0 + lane < n2q;
+            P2s[lane * LDP + K4 + 1] = ok ? -self2[col0 + lane] : 0.f;
+            P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (!(BWDS_ABL & 4)) {   // T' = P1' P2'^T
+            f4 t[3][3];
+            const float* pb = P2s + m16 * LDP + kg;
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks) {
+                if (ks < KS) {
+                    float bv[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bv[j] = pb[j * 16 * LDP + ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
+        }
+        __syncthreads();
+        // ---- micro-block transform (kernel_bwd_pair_kernel's arithmetic), rows split over the four lanes of a pair
+        float* blk = TT + pr0 * LDT2 + pc0;
+        const float* gb = GG + pr0 * LDG + pc0;
+        if (!(BWDS_ABL & 1)) {
+        float t0[Q], g0[Q], ta[RPL][Q], ga[RPL][Q];
+#pragma unroll
+        for (int b = 0; b < Q; ++b) { t0[b] = blk[b]; g0[b] = colok ? gb[b] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int a = sub + SPL * i;
+#pragma unroll
+            for (int b = 0; b < Q; ++b) {
+                ta[i][b] = (a < Q) ? blk[a * LDT2 + b] : 0.f;
+                ga[i][b] = (a < Q && colok) ? gb[a * LDG + b] : 0.f;
+            }
+        }
+        __syncthreads();                                   // row 0 of the T' micro-block is rewritten below: every lane has read it
+        const float nn = fmaxf(s1r0 - s2c0 - 2.f * t0[0], 0.f);
+        const float k = s * expf(-0.5f * nn);
+        const float kil = k * il, kil2 = k * il2;
+        float gu[Q];
+#pragma unroll
+        for (int b = 0; b < Q; ++b) gu[b] = 0.f;
+        float second = 0.f, hsum = 0.f, dots = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int a = sub + SPL * i;
+            if (a >= 1 && a < Q) {
+                const float u = -ta[i][0];
+                const float ga0 = ga[i][0];
+                float gw = 0.f, gt = 0.f;
+#pragma unroll
+                for (int b = 1; b < Q; ++b) {
+                    const float gab = ga[i][b];
+                    gw = __builtin_fmaf(gab, t0[b], gw);
+                    gt = __builtin_fmaf(gab, ta[i][b], gt);
+                    gu[b] = __builtin_fmaf(gab, u, gu[b]);
+                    blk[a * LDT2 + b] = kil2 * gab;                                            // Tbar_ab
+                }
+                second = __builtin_fmaf(ga0, u, second);
+                hsum += gt - u * gw;
+                const float ubar = -(kil * ga0 + kil2 * gw);
+                blk[a * LDT2] = -ubar;                                                         // Tbar_a0
+                dots = __builtin_fmaf(ubar, u, dots);
+            }
+        }
+        // sums over all rows of the micro-block: across the four lanes of the pair (consecutive lanes: quad shuffles)
+#pragma unroll
+        for (int b = 1; b < Q; ++b) { gu[b] += __shfl_xor(gu[b], 1); gu[b] += __shfl_xor(gu[b], 2); }
+        second += __shfl_xor(second, 1); second += __shfl_xor(second, 2);
+        hsum += __shfl_xor(hsum, 1); hsum += __shfl_xor(hsum, 2);
+        dots += __shfl_xor(dots, 1); dots += __shfl_xor(dots, 2);
+        if (sub == 0) {
+            float first = 0.f;
+#pragma unroll
+            for (int b = 1; b < Q; ++b) first = __builtin_fmaf(g0[b], t0[b], first);            // sum g0b w_b
+#pragma unroll
+            for (int b = 1; b < Q; ++b) {
+                const float wbar = kil * g0[b] - kil2 * gu[b];
+                blk[b] = wbar;                                                                 // Tbar_0b
+                dots = __builtin_fmaf(wbar, t0[b], dots);
+            }
+            const float e1 = il * (first - second), e2 = il2 * hsum;
+            const float t00 = k * (g0[0] + e1 + e2);                                           // Tbar_00
+            blk[0] = t00;
+            sK_sum += t00;
+            l_acc += k * (e1 + 2.f * e2) - t00 * nn + dots;
+        }
+        }
+        __syncthreads();
+        if (!(BWDS_ABL & 2)) {   // dP1[48, NP] += Tbar[48, 48] . P2ext[48, NP]
+            const float* pa = TT + m16 * LDT2 + kg;
+            const float* pb = P2s + kg * LDP + m16;
+#pragma unroll
+            for (int kk = 0; kk < 48; kk += 4) {
+                float av[3], bv[NNP];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) av[i] = pa[i * 16 * LDT2 + kk];
+#pragma unroll
+                for (int j = 0; j < NNP; ++j) bv[j] = (j < nnp) ? pb[kk * LDP + 16 * j] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < NNP; ++j)
+                        if (j < nnp) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* myslab = slab + ((int64_t)blockIdx.x * n1q) * NP;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NNP; ++j)
+            if (j < nnp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = i * 16 + kg * 4 + r;
+                    const int64_t gr = row0 + rr;
+                    if (rr < T && gr < n1q) myslab[gr * NP + j * 16 + m16] = acc[i][j][r];
+                }
+            }
+    float l_sum = -il * l_acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        sK_sum += __shfl_down(sK_sum, off);
+        l_sum += __shfl_down(l_sum, off);
+    }
+    if (lane == 0) {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        partials[bid * 2] = sK_sum;
+        partials[bid * 2 + 1] = l_sum;
+    }
+}
+
 // one 256-thread block per point: slabs -> d_x1, d_v1 (through the x/ell scaling and the direction normalisation).  Each of the
 // four waves sums every fourth slab (the slabs are 384 KB apart at C4: 32 dependent-latency loads per element on one wave was
 // 21 us for 500 points), the partial sums meet in LDS.  Block 0 also folds the per-workgroup scalar partials into d_hyp (was a
@@ -1732,9 +2004,15 @@ inline int make_geom(int d, int p, Geom& g) {
     return 0;
 }
 inline bool bwd_use_pair(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 64; }     // (NP <= 32: KSM = 8; <= 64: KSM = 16)
+#ifdef BWD_NO_SPLIT
+inline bool bwd_use_split(const Geom&) { return false; }
+#else
+inline bool bwd_use_split(const Geom& g) { return g.q == 11 && g.NP <= 16; }                  // (full-gradient SVGP at d <= 12: BASELINE config 3)
+#endif
 // row-tile height / column-tile width / workgroup budget of the backward variant that will run
 inline void bwd_tiles(const Geom& g, int& tr, int& tc, int& wgs) {
-    if (bwd_use_pair(g)) { tr = tc = (48 / g.q) * g.q; wgs = PAIR_WGS; }
+    if (bwd_use_split(g)) { tr = tc = (48 / g.q) * g.q; wgs = BWDS_WGS; }
+    else if (bwd_use_pair(g)) { tr = tc = (48 / g.q) * g.q; wgs = PAIR_WGS; }
     else { tr = g.Tr; tc = g.T; wgs = BWD_TARGET_WGS; }
 }
 inline int bwd_nsplit(int n1, int n2, const Geom& g) {
@@ -1953,7 +2231,19 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     const int rt = cdiv(n1q, tr_);
     float* slab = (float*)workspace;
     float* partials = slab + (size_t)ns * n1q * g.NP;
-    if (bwd_use_pair(g)) {
+    if (bwd_use_split(g)) {
+        const size_t lds = sizeof(float) * (((49 * (size_t)(g.NP + 1) + 3) & ~(size_t)3) + 48 * (size_t)PAIR_LDT + 44 * (size_t)PAIR_LDT);
+        const int esz = g_is_double ? 8 : 4;
+        const int gvec = (ldg % 4 == 0) && ((uintptr_t)G % (4 * esz) == 0);     // 4-wide loads of the upstream tile rows (tile origins are multiples of 44)
+        dim3 grid(ns, rt);
+        if (g_is_double)
+            hipLaunchKernelGGL((kernel_bwd_split_kernel<double, 11, 4>), grid, dim3(64), lds, ctx->stream, (const double*)G, ldg, P1, self1, n1q,
+                               P2, self2, n2q, g.K4, g.DP, g.NP, gvec, hyp, slab, partials);
+        else
+            hipLaunchKernelGGL((kernel_bwd_split_kernel<float, 11, 4>), grid, dim3(64), lds, ctx->stream, (const float*)G, ldg, P1, self1, n1q,
+                               P2, self2, n2q, g.K4, g.DP, g.NP, gvec, hyp, slab, partials);
+        DSVGP_LAUNCH_CHECK();
+    } else if (bwd_use_pair(g)) {
         const size_t lds = sizeof(float) * (((49 * (size_t)(g.NP + 1) + 3) & ~(size_t)3) + 48 * (size_t)PAIR_LDT);      // (49: the scratch row of the predicate-free staging)
         const int esz = g_is_double ? 8 : 4;
         const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);    // 2-wide loads of the micro-block rows
