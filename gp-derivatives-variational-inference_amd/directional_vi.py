@@ -29,6 +29,7 @@ from .DirectionalGradVariationalStrategy import DirectionalGradVariationalStrate
 from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .gp_shim import (ApproximateGP, CholeskyVariationalDistribution, ConstantMean, GaussianLikelihood,
                       NaturalVariationalDistribution, PredictiveLogLikelihood, ScaleKernel, VariationalELBO)
+from . import optim as _optim
 from .optim import NGD, FusedAdam, make_adam
 from .parallel import DataParallel
 
@@ -193,10 +194,14 @@ class TrainLoop:
         output._value_stride = len(idx_y)
         if self._values_only and getattr(self.model.engine, "_last_fast", None) is not None:
             output._value_varn = self.model.engine.value_variances(self.model._param_dict(self.likelihood))
-        self.variational_optimizer.step()
-        self.variational_scheduler.step()
-        self.hyperparameter_optimizer.step()
-        self.hyperparameter_scheduler.step()
+        if _optim.step_together([self.variational_optimizer, self.hyperparameter_optimizer]):      # both Adam: one multi-tensor launch
+            self.variational_scheduler.step()
+            self.hyperparameter_scheduler.step()
+        else:
+            self.variational_optimizer.step()
+            self.variational_scheduler.step()
+            self.hyperparameter_optimizer.step()
+            self.hyperparameter_scheduler.step()
         if dp is not None and dp.check_every > 0:
             self._check_replicas(dp)
         return loss, output, y_batch

@@ -3,7 +3,11 @@
 (``DataParallel.loss_and_grads`` -> ``ElboEngine`` -> the five-piece C entry ``dsvgp_elbo_step_dp_f32``) with its own engine,
 plan and workspace; only the transport differs: the collectives meet at ``threading.Barrier``s and are computed by torch on the
 one device (all ranks issue on the same stream, so device order = host order).  Sums are taken in rank order, the same on every
-rank: results are bitwise equal across the virtual ranks, as RCCL's are."""
+rank: results are bitwise equal across the virtual ranks, as RCCL's are.
+
+The library's contract is ONE host thread per context (include/dsvgp.h; the one-call step re-points the context's stream while it
+queues its side-stream work), and the ranks of one process share the device's context: the ranks therefore run ONE AT A TIME --
+``VirtualWorld.turn`` is held by the rank that is queueing work and handed over only while it waits inside a collective."""
 import threading
 
 import torch
@@ -20,13 +24,22 @@ class VirtualWorld:
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
         self.errors = []
+        self.turn = threading.Lock()        # held by the one rank that is inside the library
+
+    def wait(self):
+        """barrier; the caller's turn is handed over while it waits"""
+        self.turn.release()
+        try:
+            self.barrier.wait()
+        finally:
+            self.turn.acquire()
 
     def exchange(self, rank, value):
         """every rank deposits ``value``; returns the list of all ranks' values (valid until the next exchange)"""
         self.slots[rank] = value
-        self.barrier.wait()
+        self.wait()
         vals = list(self.slots)
-        self.barrier.wait()
+        self.wait()
         return vals
 
     def run(self, fn):
@@ -34,11 +47,14 @@ class VirtualWorld:
         out = [None] * self.world
 
         def body(r):
+            self.turn.acquire()
             try:
                 out[r] = fn(r, self)
             except BaseException as ex:      # noqa: BLE001  (a failed rank must not leave the others waiting)
                 self.errors.append((r, ex))
                 self.barrier.abort()
+            finally:
+                self.turn.release()
 
         ts = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
         for t in ts:
@@ -66,9 +82,9 @@ def make_virtual_dp(dsvgp_amd, vw, rank):
             total = vals[0].clone()
             for v in vals[1:]:
                 total += v
-            vw.barrier.wait()           # (every rank has read the operands before anyone overwrites its own)
+            vw.wait()                   # (every rank has read the operands before anyone overwrites its own)
             t.copy_(total)
-            vw.barrier.wait()
+            vw.wait()
 
         def all_reduce_async(self, t):
             self.all_reduce_sum(t)
@@ -80,7 +96,7 @@ def make_virtual_dp(dsvgp_amd, vw, rank):
             flat = out.view(-1)
             for r, v in enumerate(vals):
                 flat[r * n:(r + 1) * n].copy_(v.reshape(-1))
-            vw.barrier.wait()
+            vw.wait()
             return _Done()
 
     return VirtualDP()

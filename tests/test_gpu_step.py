@@ -51,9 +51,11 @@ def make_problem(N, d, M, p, B, seed=0, perturb=True):
 
 def run_gpu(dsvgp, dev, P, x, y, D, nd, mll="ELBO", **kw):
     eng = dsvgp.ElboEngine(dev, **{k: v for k, v in kw.items() if k == "trsm_nb"})
+    if "c_step" in kw:                  # (False: the Python-orchestrated path, whose intermediates live in eng._buf)
+        eng.c_step = kw["c_step"]
     Pg = {k: v.to(dev) for k, v in P.items()}
     loss, grads, mu, varn = eng.loss_and_grads(Pg, x.to(dev), y.to(dev), D.to(dev), nd, mll,
-                                               **{k: v for k, v in kw.items() if k != "trsm_nb"})
+                                               **{k: v for k, v in kw.items() if k not in ("trsm_nb", "c_step")})
     torch.cuda.synchronize()
     return loss, grads, mu, varn, eng, Pg
 
@@ -155,8 +157,16 @@ def test_full_size_properties_c4(dsvgp, gpu_device):
     N, d, M, p, B = 20000, 20, 500, 5, 4096
     P, x, y, D, nd = make_problem(N, d, M, p, B, seed=4, perturb=False)
     loss_f, grads_f, _, _, _, _ = run_gpu(dsvgp, dev, P, x, y, D, nd, fast=True)
-    loss, grads, mu, varn, eng, Pg = run_gpu(dsvgp, dev, P, x, y, D, nd, fast=False)
-    assert math.isfinite(loss.item())
+    loss_c, grads_c, mu_c, varn_c, eng_c, _ = run_gpu(dsvgp, dev, P, x, y, D, nd, fast=False)      # one C call (dsvgp_elbo_step_po_f32)
+    assert eng_c.c_step_used
+    del eng_c
+    torch.cuda.empty_cache()
+    # (the Python-orchestrated per-output path: its intermediates L, A64, K_ZX are engine buffers the identities below read)
+    loss, grads, mu, varn, eng, Pg = run_gpu(dsvgp, dev, P, x, y, D, nd, fast=False, c_step=False)
+    assert math.isfinite(loss.item()) and not eng.c_step_used
+    assert abs(loss_c.item() - loss.item()) < 4e-6 * abs(loss.item()) and relmax(varn_c, varn) < 4e-6 and relmax(mu_c, mu) < 4e-6
+    for k in grads:
+        assert relmax(grads_c[k], grads[k]) < 5e-5, k
     # (0) the ELBO fast path (Gram formulation) and the per-output path agree at full size
     assert abs(loss_f.item() - loss.item()) < 2e-5 * abs(loss.item())
     for k in grads:
