@@ -80,7 +80,9 @@ size_t potrf_blocked_workspace_bytes(int n);
 // run) the event is recorded on st -- another stream may then start consuming those rows while the chain goes on
 struct PotrfHook { int after_k; hipEvent_t ev; };
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT, bool info_zeroed = false, const PotrfHook* hooks = nullptr, int nhooks = 0);
+                         double* YinvT, bool info_zeroed = false, const PotrfHook* hooks = nullptr, int nhooks = 0, int pipe_from = 0);
+// pipe_from: first block column whose launch may use the one-workgroup-per-CU pipelined kernel (potrf.hip, PIPE): a caller whose
+// other stream shares the CUs with the first launches of the chain passes the launch index from which the chain is alone
 // pieces of the one-call step (csrc/step.hip) that fold tiny dependent launches into their neighbours
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp);                                       // assemble.hip

@@ -10,6 +10,8 @@
 // once per column of the 16-column chain, operand reads of the 64^3 products pipelined in chunks, 8-wave workgroups (POTRF_NW).
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int NBC = 64;
@@ -104,7 +106,10 @@ __device__ unsigned long long chol_trace[TR_MAXWG * TR_SLOTS];
         trs_[23] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
         trs_[21] = __builtin_amdgcn_s_memtime(); \
         for (int q_ = 0; q_ < TR_SLOTS; ++q_) chol_trace[(size_t)blockIdx.x * TR_SLOTS + q_] = trs_[q_]; } } while (0)
+#define PIPE_TR(slot) do { if (trs && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); \
+        trs[slot] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
+#define PIPE_TR(slot) do { } while (0)
 #define TR_DECL
 #define TR(slot) do { } while (0)
 #define TR_VAL(slot, v) do { } while (0)
@@ -197,6 +202,204 @@ __device__ __forceinline__ void tile_product_il(const double (*As)[LDT], const d
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the four fragment reads of k-step ks + 2
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // the four MFMAs of k-step ks
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // two of the next tile's global loads
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Software-pipelined strip (round 5; the PIPE instantiation of chol_step_kernel: ONE workgroup per CU, three LDS tiles).
+// A tile-bound launch of the chain is one strip workgroup per CU running  T = A_ik W_k  and then, per block column of its strip,
+// C_c -= T B_c^T:  measured (profiles/r05_b_potrf_tile_roles.txt) 9.4k cycles per column of which 4.1k are the product's MFMAs --
+// the next column's 32 loads are issued in front of the product (2.2k), its operand goes to LDS between two barriers (1.5k), the
+// result is stored behind it (0.9k).  Here all of that rides INSIDE the MFMA stream of the product:
+//   product(c)  reads -T (S[0]) and B_c (S[2 - c % 2]); in front of it the wave issues its 8 LDS-DMA instructions of B_{c+1} (into
+//               the other B buffer: global -> LDS, no registers, no ds_write); after each of its first 8 k-steps (4 MFMAs) it
+//               issues two loads of C_{c+1} and two stores of the result of column c - 1;
+//   then ONE drain + barrier closes the column (everything was issued >= 8 k-steps earlier).
+// Register sets rotate by NAME, not by copying (a copy of a register a load is still filling waits for the load): a C set is loaded
+// in stage c - 1, accumulates in stage c, is stored in stage c + 1 -- three sets; with the two B buffers the loop body is six stages.
+// (First version, measured: B rows staged through registers one stage further ahead -- 356 registers, spills whose reloads wait
+// vmcnt(0); selects on loaded values became branches around the loads and cut the scheduling regions.)
+// An LDS-DMA instruction writes 64 x 16 bytes CONTIGUOUSLY (two rows of a tile), so B's LDS image is rows in PAIRS with a stride of
+// 132 doubles per pair, and the 16-byte granules of the odd row of a pair are stored at column c ^ 18 (applied to the SOURCE
+// address): bsw() below; the fragment reads of both operand orientations are then conflict-free (32 lanes, 32 distinct bank pairs).
+// B_NK: B_c given as [n][k] (update role: rows of A_jk) or [k][n] (inverse role: R_kj).  ident_after: the block column BEHIND the
+// ncols pipelined ones has B = I and old C = 0 (inverse role, j == k: always the strip's last): its result is -T itself, stored from
+// LDS at the end, no product.  last_diag: the last column is a diagonal tile (only n <= m is stored).  All 64 rows of every C tile
+// are stored (callers: interior tile rows only), ldB must be even (16-byte source granules).  On entry: T = the product A_ik W_k,
+// S[0] / S[1] still being read by the other waves (the barrier is here), cs[0] = column 0's C elements (requested by the caller),
+// B_0 already in S[2] (pipe_dma_tile, issued by the caller before its own loads).
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* potrf_lds_ptr_t;
+constexpr int BPAIR = 132;                                  // doubles per row pair of a DMA-filled B image (64 x 66 = 32 x 132)
+__device__ __forceinline__ int bsw(int row, int col) { return (row >> 1) * BPAIR + (row & 1) * 64 + (col ^ ((row & 1) * 18)); }
+// One LDS-DMA instruction as an asm statement: no VGPR destination, and WE count it (s_waitcnt vmcnt(0) before the barrier that
+// ends the stage) -- through the builtin hipcc parks a vmcnt(0) in front of the next LDS read (see gemm32.hip).  M0 (the LDS
+// destination base) is compiler-reserved: saved, set and restored inside the statement.
+__device__ __forceinline__ void potrf_lds_dma16(const double* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+// the 64 x 64 tile at Bt (row stride ldB) into the B image Bs: wave w fills row pairs 8 w .. 8 w + 7
+__device__ __forceinline__ void pipe_dma_tile(double (*Bs)[LDT], const double* __restrict__ Bt, int64_t ldB) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int par = lane >> 5, col = ((2 * lane) & 63) ^ (par * 18);
+    const double* src = Bt + (int64_t)(16 * wave_u + par) * ldB + col;
+    const unsigned dst = (unsigned)(uintptr_t)(potrf_lds_ptr_t)&Bs[0][0] + wave_u * (8 * BPAIR * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) potrf_lds_dma16(src + (int64_t)(2 * i) * ldB, dst + i * (BPAIR * 8));
+}
+
+// The lane's two base addresses into a B image (the swizzle folded into them, so that every fragment read of a product is
+// base + compile-time offset):  B_NK: lane (g, m) reads rows wc 32 + 16 j + m, column 4 ks + g -- for an odd row the column is
+// (4 ks) ^ 16 + (g ^ 2): base[0] serves the k-steps with bit 2 clear, base[1] those with it set, + 4 ks + 1056 j doubles;
+// [k][n]: rows 4 ks + g, columns wc 32 + 16 j + m -- for an odd row 16 (j ^ 1) + (m ^ 2): base[j], + 264 ks doubles.
+template <bool B_NK>
+__device__ __forceinline__ void pipe_bases(int lane, int wc, int (&base)[2]) {
+    const int g = lane >> 4, m = lane & 15;
+    if constexpr (B_NK) {
+        const int odd = m & 1, r = ((wc * 32 + m) >> 1) * BPAIR + odd * 64 + (g ^ (2 * odd));
+        base[0] = r + 16 * odd;
+        base[1] = r - 16 * odd;
+    } else {
+        const int odd = g & 1, r = (g >> 1) * BPAIR + odd * 64 + wc * 32 + (m ^ (2 * odd));
+        base[0] = r + 16 * odd;
+        base[1] = r + 16 - 16 * odd;
+    }
+}
+
+template <bool B_NK, bool HAS_PREV, typename F>
+__device__ __forceinline__ void pipe_product(const double (*Ts)[LDT], const double* __restrict__ Bs, const int (&base)[2], int lane,
+                                             int wr, double (&accd)[2][2][4], F&& hook) {
+    const int g = lane >> 4, m = lane & 15;
+    acc4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc4{accd[i][j][0], accd[i][j][1], accd[i][j][2], accd[i][j][3]};
+    const double* ta = &Ts[wr * 32 + m][g];
+    const double* b0 = Bs + base[0];
+    const double* b1 = Bs + base[1];
+    double a[16][2], b[16][2];
+    auto rd = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[ks][i] = ta[i * 16 * LDT + 4 * ks];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j] = B_NK ? ((ks & 4) ? b1 : b0)[4 * ks + j * 8 * BPAIR] : (j ? b1 : b0)[ks * 2 * BPAIR];
+    };
+    rd(0);
+    rd(1);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 2 < 16) rd(ks + 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        if (ks < 8) hook(ks, std::integral_constant<bool, HAS_PREV>{});
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // fragment reads of k-step ks + 2
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // the four MFMAs of k-step ks
+        if (ks < 8) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                  // two loads of C_{c+1}
+            if (HAS_PREV) __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);    // two stores of column c - 1
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accd[i][j][q] = acc[i][j][q];
+}
+
+template <bool B_NK>
+__device__ __forceinline__ void strip_pipe(double (*S)[64][LDT], const double* __restrict__ Bg, int64_t ldB, int64_t dB,
+                                           double* __restrict__ Cg, int64_t ldC, int ncols, bool ident_after, bool last_diag,
+                                           acc4 (&T)[2][2], double (&cs)[3][2][2][4], unsigned long long* trs = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int ml0 = wr * 32 + (lane >> 4), nl0 = wc * 32 + (lane & 15);
+    const int64_t step4C = 4 * ldC;
+    __syncthreads();                                        // every wave is done reading A_ik / W_k for T
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + j * 16 + (lane & 15)] = -T[i][j][q];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): the caller's B_0 (LDS-DMA, not counted by the compiler) and C_0
+    __syncthreads();
+    int base[2];
+    pipe_bases<B_NK>(lane, wc, base);
+    PIPE_TR(2);                                             // (trace: T formed and back in LDS)
+    auto stage = [&](auto s_, int c) {
+        constexpr int s = decltype(s_)::value;
+        double (&acc)[2][2][4] = cs[s % 3];          // (plain doubles, not acc4: element writes into an array of vectors kept it in scratch)
+        double (&nxt)[2][2][4] = cs[(s + 1) % 3];
+        double (&prev)[2][2][4] = cs[(s + 2) % 3];
+        // column c + 1 (clamped to the strip's last column: a harmless re-read at its end)
+        const int c1 = min(c + 1, ncols - 1);
+        pipe_dma_tile(S[1 + (s & 1)], Bg + (int64_t)c1 * dB, ldB);
+        const double* pc = Cg + (int64_t)c1 * 64;
+        double* pd = Cg + (int64_t)(c - 1) * 64;
+        auto hook = [&](int ks, auto has_prev) {            // ks = 0..7 = the row step t of this thread's C elements
+#pragma unroll
+            for (int j = 0; j < 2; ++j) nxt[ks >> 2][j][ks & 3] = pc[j * 16];
+            pc += step4C;
+            if constexpr (decltype(has_prev)::value) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pd[j * 16] = prev[ks >> 2][j][ks & 3];     // (unpredicated: a branch would cut the scheduling region)
+                pd += step4C;
+            }
+        };
+        const double* Bcur = &S[2 - (s & 1)][0][0];
+        if (c < 5) PIPE_TR(3 + 3 * c);
+        if (s != 0 || c > 0) pipe_product<B_NK, true>(S[0], Bcur, base, lane, wr, acc, hook);
+        else pipe_product<B_NK, false>(S[0], Bcur, base, lane, wr, acc, hook);
+        if (c < 5) PIPE_TR(4 + 3 * c);
+        // this wave's share of B_{c+1} has landed (and C_{c+1}, and the stores).  The BUILTIN, not an asm statement: the compiler's own
+        // count of its loads restarts here -- otherwise the next stage's first MFMAs wait "vmcnt(3)" for accumulators that are long
+        // there, and that wait now includes five of the eight DMA instructions just issued.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+        __syncthreads();                                    // B_{c+1} is complete; every wave is done with B_c
+        if (c < 5) PIPE_TR(5 + 3 * c);
+    };
+    // the strip's last column leaves from the stage that computed it (one store loop per register set: choosing the set behind the
+    // loop made its address a phi of three allocas, and the sets stayed in scratch)
+    auto store_last = [&](double (&res)[2][2][4]) {
+        double* pd = Cg + (int64_t)(ncols - 1) * 64;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ml = ml0 + 4 * t, nl = nl0 + j * 16;
+                if (!(last_diag && nl > ml)) pd[j * 16] = res[t >> 2][j][t & 3];
+            }
+            pd += step4C;
+        }
+    };
+    for (int c = 0; c < ncols; c += 6) {
+        stage(std::integral_constant<int, 0>{}, c);
+        if (c + 1 >= ncols) { store_last(cs[0]); break; }
+        stage(std::integral_constant<int, 1>{}, c + 1);
+        if (c + 2 >= ncols) { store_last(cs[1]); break; }
+        stage(std::integral_constant<int, 2>{}, c + 2);
+        if (c + 3 >= ncols) { store_last(cs[2]); break; }
+        stage(std::integral_constant<int, 3>{}, c + 3);
+        if (c + 4 >= ncols) { store_last(cs[0]); break; }
+        stage(std::integral_constant<int, 4>{}, c + 4);
+        if (c + 5 >= ncols) { store_last(cs[1]); break; }
+        stage(std::integral_constant<int, 5>{}, c + 5);
+        if (c + 6 >= ncols) { store_last(cs[2]); break; }
+    }
+    if (ident_after) {                                      // C_ncols = 0 - T I: this thread's elements of -T, back from LDS
+        double* pd = Cg + (int64_t)ncols * 64;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pd[j * 16] = S[0][ml0 + 4 * t][nl0 + j * 16];
+            pd += step4C;
+        }
     }
 }
 
@@ -524,7 +727,7 @@ __device__ __forceinline__ void factor64_lds(double (*F)[LDT], double (*Y)[LDT],
 //   Y-tiles  (j <= k):         Y_kj  = X_k R_kj                        (row block k of L^-1 is final)
 // Row k of R was completed by launch k-1 and is read-only here; these tiles ride on the CUs the latency-bound
 // factorisation chain leaves idle.
-template <int NW = 4>
+template <int NW = 4, bool PIPE = false>
 __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n,
                                                   int k, int e, const double* __restrict__ Xws,
                                                   const double* __restrict__ Wws, double* __restrict__ Rw, int64_t ldr,
@@ -544,6 +747,50 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
     const int i0 = ytile ? k0 : (k + 1 + e / spr) * 64;
     int j0 = j * 64;
     const double* Lk = ytile ? (Xws + (size_t)k * 4096) : (Wws + (size_t)k * 4096);
+    if constexpr (PIPE && NW == 4) {
+        if (!ytile) {                                   // R strip, software-pipelined (R is padded to whole blocks: no clamping there)
+            const int ml0 = wr * 32 + (lane >> 4), nl0 = wc * 32 + (lane & 15);
+            const int64_t rstep = (int64_t)4 * ldr;
+            double cs[3][2][2][4];
+            double* const Cg = Rw + (int64_t)(i0 + ml0) * ldr + j0 + nl0;
+            const double* const Bg = Rw + (int64_t)k0 * ldr + j0;
+            const bool ident_after = k - j < ncols;               // the strip ends with block column j == k: R_kk = I, old R_ik = 0
+            const int np = ident_after ? ncols - 1 : ncols;       // block columns that take a product
+            {
+                double ra[16], rw[16];
+                const int64_t arow0 = (int64_t)(i0 + (tid >> 6)) * lda, alast = (int64_t)(n - 1) * lda, astep = (int64_t)4 * lda;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = (tid >> 6) + 4 * u, c = tid & 63;
+                    ra[u] = A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
+                    rw[u] = Lk[r * 64 + c];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) cs[0][t >> 2][jj][t & 3] = Cg[t * rstep + jj * 16];
+                pipe_dma_tile(S[2], Bg, ldr);                      // B_0 = R_kj of the strip's first column (np == 0: unused); issued last, as above
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = (tid >> 6) + 4 * u;
+                    S[0][r][tid & 63] = (i0 + r < n) ? ra[u] : 0.0;
+                    S[1][r][tid & 63] = rw[u];
+                }
+            }
+            __syncthreads();
+            acc4 acc[2][2];
+#ifdef POTRF_TRACE
+            if (trs_) { TR(1); TR_VAL(20, (ncols << 16) | (e / spr)); }
+#endif
+            tile_product<true, 4>(S[0], S[1], lane, wr, wc, acc);            // T = A_ik W_k (W symmetric: [n][k] == [k][n])
+#ifdef POTRF_TRACE
+            strip_pipe<false>(S, Bg, ldr, (int64_t)64, Cg, ldr, np, ident_after, false, acc, cs, k == POTRF_DEBUG_K ? trs_ : nullptr);
+#else
+            strip_pipe<false>(S, Bg, ldr, (int64_t)64, Cg, ldr, np, ident_after, false, acc, cs);
+#endif
+            return;
+        }
+    }
     // two LDS tiles only (two workgroups per CU): R_kj waits in registers until T = A_ik W_k has been formed
     double rc[NU];
     double ro[2][NJ][4];      // R-tile: the old R_ij, requested with the operands (not as 16 load -> wait -> store round trips at the end)
@@ -866,16 +1113,36 @@ __device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const dou
 #ifndef POTRF_MINW
 #define POTRF_MINW (POTRF_NW / 2)
 #endif
-template <int NW>
-__global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
+#ifndef POTRF_PIPE_MIN_TILES
+#define POTRF_PIPE_MIN_TILES 300    // launches with fewer tiles are bound by the critical workgroup anyway: they keep the two-per-CU kernel
+#endif
+#ifndef POTRF_PIPE_WGS
+#define POTRF_PIPE_WGS 250          // workgroups of a PIPE launch (one per CU; the critical workgroup is one of them)
+#endif
+#ifndef POTRF_PIPE_FROM
+#define POTRF_PIPE_FROM 0           // (A/B builds) first block column that may use the PIPE kernel, on top of the caller's pipe_from
+#endif
+#ifndef POTRF_PIPE_MINW
+#define POTRF_PIPE_MINW 2           // register budget of the PIPE kernel as for two waves per SIMD (256): the MFMAs then keep their accumulators in
+                                    // VGPRs, where the C loads land; with 512 the compiler picks AGPR accumulators and moves the loaded sets
+                                    // to them through scratch (waiting vmcnt(0) for every load).  LDS (101 KB) keeps it at one workgroup per CU.
+#endif
+#ifndef POTRF_PIPE
+#define POTRF_PIPE 1        // 1: launches from `pipe_from` on (launch_potrf_blocked) use the PIPE instantiation: software-pipelined strips (strip_pipe)
+#endif
+// PIPE: three LDS tiles and up to 512 registers -- ONE workgroup per CU -- with the strips of both tile roles software-pipelined
+// (strip_pipe above); strip_e: strip length of the ragged last tile row of the update role, which keeps the two-barrier strip loop
+// (its tiles need clamped addresses) and must not be the launch's longest chain.
+template <int NW, bool PIPE = false>
+__global__ __launch_bounds__(64 * NW, PIPE ? POTRF_PIPE_MINW : POTRF_MINW) void chol_step_kernel(double* __restrict__ A, int64_t lda, int n, int k,
                                                            double* __restrict__ Xws, double* __restrict__ Wws,
                                                            int* __restrict__ info, double* __restrict__ Rw, int64_t ldr,
                                                            double* __restrict__ Yinv, int64_t ldy, int nA,
-                                                           double* __restrict__ YinvT, int strip) {
+                                                           double* __restrict__ YinvT, int strip, int strip_e) {
     // TWO 64 x 64 LDS tiles (70 KB with the factorisation scratch): two workgroups share a CU, which halves the rounds
     // the ~1100 update / inverse tiles of a mid-chain launch need.  The second right operand of every tile waits in
     // registers while the first product runs.
-    __shared__ double S[2][64][LDT];
+    __shared__ double S[PIPE ? 3 : 2][64][LDT];
     __shared__ double Xd[16][17];
     __shared__ double colbuf[64], rowbuf[64];      // column-by-column chain: [16..31] dummy slots of the non-owner lanes; 4-column blocks: [16][4] / [4][16]
     constexpr int WC = NW / 2, NJ = 8 / NW, NU = 64 / NW;
@@ -885,11 +1152,11 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     TR(0);
     if (b >= nA) {                                 // fused-inverse tiles (only launched with k >= 0 and Rw != nullptr)
 #ifdef POTRF_TRACE
-        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip, trs_);
+        chol_inverse_tile<NW, PIPE>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip, trs_);
         TR_VAL(22, 2);
         TR_FLUSH;
 #else
-        chol_inverse_tile<NW>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip);
+        chol_inverse_tile<NW, PIPE>(S, A, lda, n, k, b - nA, Xws, Wws, Rw, ldr, Yinv, ldy, (n + 63) / 64, YinvT, strip);
 #endif
         return;
     }
@@ -920,12 +1187,52 @@ __global__ __launch_bounds__(64 * NW, POTRF_MINW) void chol_step_kernel(double* 
     // tile row ti holds ti + 1 update tiles, dealt to workgroups in strips of strip block columns (block 0: the diagonal tile
     // of row 0, alone: the critical workgroup)
     int ti = 0, first = 0;
-    while (first + (ti + strip) / strip <= b) { first += (ti + strip) / strip; ++ti; }
+    const int ntr = (n + 63) / 64 - (k + 1);        // tile rows of the trailing matrix; the last one may be ragged: strips of strip_e
+    while (ti < ntr - 1 && first + (ti + strip) / strip <= b) { first += (ti + strip) / strip; ++ti; }
+    if (ti == ntr - 1) strip = strip_e;
     int tj = (b - first) * strip;
     const int ncols = min(strip, ti + 1 - tj);
     const int i0 = (k + 1 + ti) * 64;
     int j0 = (k + 1 + tj) * 64;
     double (*F)[LDT] = S[0];
+    if constexpr (PIPE && NW == 4) {
+        if (k >= 0 && b != 0 && i0 + 64 <= n) {        // interior tile row (its strip's columns lie left of it: inside too)
+            const int k0 = k * 64;
+            const double* Wk = Wws + (size_t)k * 4096;
+            const int ml0 = wr * 32 + (lane >> 4), nl0 = wc * 32 + (lane & 15);
+            const int64_t astep = (int64_t)4 * lda;
+            double cs[3][2][2][4];
+            double* const Cg = A + (int64_t)(i0 + ml0) * lda + j0 + nl0;
+            const double* const Bg = A + (int64_t)j0 * lda + k0;
+            {   // the operands of T first; C_0 and B_0 (LDS-DMA, issued LAST: the compiler's count for A_ik / W_k then leaves them
+                // in flight) are only waited for behind the T product (strip_pipe)
+                double ra[16], rw[16];
+                const double* pa = A + (int64_t)(i0 + (tid >> 6)) * lda + k0 + (tid & 63);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { ra[u] = pa[u * astep]; rw[u] = Wk[((tid >> 6) + 4 * u) * 64 + (tid & 63)]; }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) cs[0][t >> 2][j][t & 3] = Cg[t * astep + j * 16];
+                pipe_dma_tile(S[2], Bg, lda);              // B_0 = A_jk of the strip's first column
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { S[0][(tid >> 6) + 4 * u][tid & 63] = ra[u]; S[1][(tid >> 6) + 4 * u][tid & 63] = rw[u]; }
+            }
+            __syncthreads();
+            acc4 acc[2][2];
+            TR(1);
+            tile_product<true, 4>(S[0], S[1], lane, wr, wc, acc);            // T = A_ik W_k (W symmetric: [n][k] == [k][n])
+#ifdef POTRF_TRACE
+            strip_pipe<true>(S, Bg, lda, (int64_t)64 * lda, Cg, lda, ncols, false, ti == tj + ncols - 1, acc, cs, k == POTRF_DEBUG_K ? trs_ : nullptr);
+            TR_VAL(20, (ncols << 16) | ti);
+            TR_VAL(22, 1);
+            TR_FLUSH;
+#else
+            strip_pipe<true>(S, Bg, lda, (int64_t)64 * lda, Cg, lda, ncols, false, ti == tj + ncols - 1, acc, cs);
+#endif
+            return;
+        }
+    }
     CHOL_STAMP_DECL;
     CHOL_STAMP(0);
     if (k >= 0) {
@@ -1240,7 +1547,7 @@ size_t potrf_blocked_workspace_bytes(int n) {
 // (lower triangle, leading dimension ldy) by the fused forward elimination, and (YinvT != nullptr) its transpose with the
 // same leading dimension.
 int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* info, double* ws, double* Yinv, int64_t ldy,
-                         double* YinvT, bool info_zeroed, const PotrfHook* hooks, int nhooks) {
+                         double* YinvT, bool info_zeroed, const PotrfHook* hooks, int nhooks, int pipe_from) {
     if (!info_zeroed) {
         hipError_t e = hipMemsetAsync(info, 0, sizeof(int), st);
         if (e != hipSuccess) return 1000 + (int)e;
@@ -1260,8 +1567,25 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
             for (int ti = 0; ti < nt; ++ti) nA += (ti + strip) / strip;
         }
         const int nI = (k >= 0 && Yinv) ? nt * ((k + strip) / strip) + (k + 1) : 0;     // R strips + Y tiles
-        hipLaunchKernelGGL(chol_step_kernel<POTRF_NW>, dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info, Rw,
-                           ldr, Yinv, ldy, nA, YinvT, strip);
+#if POTRF_PIPE && POTRF_NW == 4
+        if (k >= 0 && k >= pipe_from && k >= POTRF_PIPE_FROM && tiles > POTRF_PIPE_MIN_TILES && lda % 2 == 0) {
+            // one workgroup per CU: the shortest strips that keep the launch within one round of the 256 CUs (the pipelined strip
+            // costs ~13k cycles + 4.7k per column; a second round would cost a whole strip)
+            int sp = 2, nAp = 0, nIp = 0, se = 2;
+            for (;; ++sp) {
+                se = (n % 64 == 0) ? sp : (sp < 2 ? sp : 2);           // the ragged last tile row keeps the two-barrier loop: short strips
+                nAp = 0;
+                for (int ti = 0; ti < nt - 1; ++ti) nAp += (ti + sp) / sp;
+                nAp += (nt - 1 + se) / se;
+                nIp = Yinv ? nt * ((k + sp) / sp) + (k + 1) : 0;
+                if (nAp + nIp <= POTRF_PIPE_WGS || sp >= 12) break;
+            }
+            hipLaunchKernelGGL((chol_step_kernel<4, true>), dim3(nAp + nIp), dim3(256), 0, st, A, lda, n, k, Xws, Wws, info, Rw, ldr, Yinv,
+                               ldy, nAp, YinvT, sp, se);
+        } else
+#endif
+        hipLaunchKernelGGL((chol_step_kernel<POTRF_NW, false>), dim3(nA + nI), dim3(64 * POTRF_NW), 0, st, A, lda, n, k, Xws, Wws, info, Rw,
+                           ldr, Yinv, ldy, nA, YinvT, strip, strip);
         DSVGP_LAUNCH_CHECK();
         for (int h = 0; h < nhooks; ++h)
             if (hooks[h].after_k == k) {

@@ -291,7 +291,7 @@ def _spd(n, g, cond_jitter=1e-3):
 
 
 @pytest.mark.parametrize("algo", [0, 1])
-@pytest.mark.parametrize("n", [64, 100, 333, 700, 1500])
+@pytest.mark.parametrize("n", [64, 100, 333, 700, 1500, 2048, 2100])       # (>= 1700: launches of the pipelined-strip kernel)
 def test_potrf_row_major_lower(dsvgp, gpu_device, n, algo):
     ops = dsvgp._ops
     ctx = ops.Context.get(gpu_device)
@@ -324,10 +324,12 @@ def test_gemm_lib_f32_row_major_convention(dsvgp, gpu_device, ta, tb):
     assert relmax(Cg, ref) < 1e-5
 
 
-@pytest.mark.parametrize("n", [40, 64, 100, 333, 704, 1500])
+@pytest.mark.parametrize("n", [40, 64, 100, 333, 704, 1500, 2048, 2100, 2001])
 def test_potrf_inverse_fused(dsvgp, gpu_device, n):
     """Blocked Cholesky with the fused forward elimination: L and L^-1 from the same launches (ragged last block, one
-    block, several blocks); later solves reuse the inverse."""
+    block, several blocks); later solves reuse the inverse.  n >= 1300: launches with more than 300 tiles run the
+    software-pipelined strip kernel (one workgroup per CU, LDS-DMA operands) -- whole blocks (2048), a ragged last block
+    (2100), and an odd leading dimension (2001), which keeps the two-per-CU kernel (16-byte DMA granules need an even one)."""
     ops = dsvgp._ops
     ctx = ops.Context.get(gpu_device)
     g = torch.Generator().manual_seed(n)
