@@ -765,11 +765,13 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                     ra[u] = A[((i0 + r < n) ? arow0 + u * astep : alast) + k0 + c];
                     rw[u] = Lk[r * 64 + c];
                 }
+#if !POTRF_PIPE_LATE0
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) cs[0][t >> 2][jj][t & 3] = Cg[t * rstep + jj * 16];
                 pipe_dma_tile(S[2], Bg, ldr);                      // B_0 = R_kj of the strip's first column (np == 0: unused); issued last, as above
+#endif
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int r = (tid >> 6) + 4 * u;
@@ -778,6 +780,13 @@ __device__ __forceinline__ void chol_inverse_tile(double (*S)[64][LDT], const do
                 }
             }
             __syncthreads();
+#if POTRF_PIPE_LATE0
+            pipe_dma_tile(S[2], Bg, ldr);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) cs[0][t >> 2][jj][t & 3] = Cg[t * rstep + jj * 16];
+#endif
             acc4 acc[2][2];
 #ifdef POTRF_TRACE
             if (trs_) { TR(1); TR_VAL(20, (ncols << 16) | (e / spr)); }
@@ -1119,6 +1128,9 @@ __device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const dou
 #ifndef POTRF_PIPE_WGS
 #define POTRF_PIPE_WGS 250          // workgroups of a PIPE launch (one per CU; the critical workgroup is one of them)
 #endif
+#ifndef POTRF_PIPE_LATE0
+#define POTRF_PIPE_LATE0 1          // 1: column 0 of a pipelined strip (B_0 by LDS-DMA, C_0) is requested behind the barrier in front of the T product
+#endif
 #ifndef POTRF_PIPE_FROM
 #define POTRF_PIPE_FROM 0           // (A/B builds) first block column that may use the PIPE kernel, on top of the caller's pipe_from
 #endif
@@ -1210,15 +1222,24 @@ __global__ __launch_bounds__(64 * NW, PIPE ? POTRF_PIPE_MINW : POTRF_MINW) void 
                 const double* pa = A + (int64_t)(i0 + (tid >> 6)) * lda + k0 + (tid & 63);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) { ra[u] = pa[u * astep]; rw[u] = Wk[((tid >> 6) + 4 * u) * 64 + (tid & 63)]; }
+#if !POTRF_PIPE_LATE0
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) cs[0][t >> 2][j][t & 3] = Cg[t * astep + j * 16];
                 pipe_dma_tile(S[2], Bg, lda);              // B_0 = A_jk of the strip's first column
+#endif
 #pragma unroll
                 for (int u = 0; u < 16; ++u) { S[0][(tid >> 6) + 4 * u][tid & 63] = ra[u]; S[1][(tid >> 6) + 4 * u][tid & 63] = rw[u]; }
             }
             __syncthreads();
+#if POTRF_PIPE_LATE0
+            pipe_dma_tile(S[2], Bg, lda);                  // B_0, C_0 requested behind the barrier: in flight under the T product
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cs[0][t >> 2][j][t & 3] = Cg[t * astep + j * 16];
+#endif
             acc4 acc[2][2];
             TR(1);
             tile_product<true, 4>(S[0], S[1], lane, wr, wc, acc);            // T = A_ik W_k (W symmetric: [n][k] == [k][n])

@@ -22,8 +22,12 @@ for M, d, p in ((500, 20, 5), (300, 10, 10), (200, 5, 2)):
     ws = ops.trsm_workspace(n, n + 1, nb, dev)
     pws = ops.potrf_workspace(n, dev)
     ts = []
+    pad = int(os.environ.get("PROBE_LDA_PAD", "0"))      # leading dimension rounded up to a multiple of this many doubles (0: n)
+    ldp = (n + pad - 1) // pad * pad if pad else n
+    buf = torch.empty(n, ldp, dtype=torch.float64, device=dev)
     for rep in range(8):
-        A = K.clone()
+        A = buf[:, :n]
+        A.copy_(K)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); ops.potrf_inverse_(ctx, A, info, nb, ws, pws); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
