@@ -418,6 +418,202 @@ __global__ __launch_bounds__(256, TW > 128 ? 3 : 4) void gemm64w_kernel(const G6
             }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Software-pipelined form of the wide kernel (round 5) for a FLOAT right operand: the same 64 x 192 tile, 4 waves of 32 x 96, 16-deep
+// stages -- but the stages that lie entirely inside the operands arrive by LDS-DMA (global_load_lds_dwordx4: no register staging, no
+// ds_write) into TWO stage buffers, one barrier per stage: stage s + 1 is requested right behind the barrier that opens stage s
+// and has that stage's 48 MFMAs per wave to land.  The right operand stays FLOAT in LDS (12 KB per stage instead of 26 KB as
+// doubles) and is widened at the fragment read (v_cvt_f64_f32 beside the MFMAs).  The stages at the diagonal of a triangular A /
+// a ragged K end keep the masked register-staged path of gemm64w_kernel (at most five of a tile's stages).
+// LDS-DMA writes 64 lanes x 16 bytes contiguously, so the images are unpadded and the bank conflicts of the fragment reads
+// are removed through the SOURCE addresses: A image [16][64] doubles, the odd k rows with their 16-double halves of each 32
+// swapped (column c ^ 16); B image [16][192] floats, the odd k rows rotated by 48 columns -- in both, the two k rows that one
+// 32-lane read group touches then fall on disjoint halves of the banks.
+// -------------------------------------------------------------------------------------------------
+#ifndef G64_PIPE
+#define G64_PIPE 1
+#endif
+typedef __attribute__((address_space(3))) void* g64_lds_ptr_t;
+__device__ __forceinline__ void g64_dma16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
+    constexpr int TW = 192, LDS_STRIDE_W = TW + 16, NJ = TW / 32, NB = TW / 16;
+    constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * TW * 4;          // bytes of one DMA stage image: 8 KB + 12 KB
+    // one LDS block: the two DMA stage pairs, or (diagonal stages) the padded images of the register-staged path
+    constexpr int SLOW_BYTES = (BK * LDS_STRIDE + BK * LDS_STRIDE_W) * 8, FAST_BYTES = 2 * (A_STAGE + B_STAGE);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int fl = g.flags;
+    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : 0;               // (the launcher sends no upper-triangular A here)
+    int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
+    if (t >= g.tiles_m * g.tiles_n) return;
+    const int band = t / (G64W_BAND * g.tiles_m), r = t - band * G64W_BAND * g.tiles_m;
+    const int wcols = min(G64W_BAND, g.tiles_n - band * G64W_BAND);
+    int tm = r / wcols;
+    const int tn = band * G64W_BAND + r - tm * wcols;
+    if (triA == 1) tm = g.tiles_m - 1 - tm;              // longest K ranges first
+    const int m0 = tm * T, n0 = tn * TW;
+    const int toff = g.tri_off;
+    int khi = g.K;
+    if (triA == 1) khi = min(khi, m0 + toff + T);
+    // stages [0, nfast) lie inside both operands: k < K, and (lower-triangular A) below the tile's first row
+    int nfast = g.K / BK;
+    if (triA == 1) nfast = min(nfast, (m0 + toff + 1) / BK);
+    // (a DMA piece is 16 bytes: with an odd M / an N that is no multiple of 4 the last piece of a row reaches past the operand's last
+    //  column -- inside the row's leading dimension, except in the very last k row, which then stays with the masked path)
+    if ((g.M & 1) || (g.N & 3)) nfast = min(nfast, (g.K - 1) / BK);
+    const int kfast = nfast * BK;
+
+    acc4 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+
+    const int gq = lane >> 4, ml = lane & 15;
+    if (nfast > 0) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(g64_lds_ptr_t)&lds[0];
+        const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // ---- DMA sources.  A: wave w brings k rows 4 w .. 4 w + 3 of a stage as two 1 KB pieces (two rows each): lane L = 32 par + h
+        // writes doubles 2 h, 2 h + 1 of row 2 piece + par, taken from column (2 h) ^ (16 par).  Columns past M (ragged last tile row)
+        // are clamped to the row's last pair (the one that holds column M - 1): they feed accumulator rows that are never stored.
+        const int par = lane >> 5, hcol = (2 * (lane & 31)) ^ (16 * par);
+        const int acol = min(m0 + hcol, ((g.M - 1) & ~1));
+        const double* asrc = g.A + (int64_t)(4 * wave_u + par) * g.lda + acol;
+        // B: the [16][192] float image is 12 pieces of 1 KB (256 consecutive floats; 192 = 0 mod 4: a lane's four floats never straddle
+        // a row), wave w pieces 3 w .. 3 w + 2: lane L of piece q writes image floats f = 256 q + 4 L .. + 3 = row f / 192, positions
+        // p = f mod 192, taken from column (p - 48 (row & 1)) mod 192; columns past N are clamped likewise.  (global_load_lds_dwordx3
+        // -- one 768-byte row per instruction -- does NOT pack: it writes its 12 bytes at a 16-byte lane stride.)
+        const float* bsrc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = 256 * (3 * wave_u + i) + 4 * lane, row = f / TW, pos = f % TW;
+            const int c = (pos + TW - 48 * (row & 1)) % TW;
+            bsrc[i] = (const float*)g.B + (int64_t)row * g.ldb + min(n0 + c, (g.N - 1) & ~3);
+        }
+        const int64_t a2 = 2 * g.lda, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
+        auto dma = [&](int buf) {
+            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * 3072;
+            g64_dma16(asrc, da);
+            g64_dma16(asrc + a2, da + 1024);
+            g64_dma16(bsrc[0], db);
+            g64_dma16(bsrc[1], db + 1024);
+            g64_dma16(bsrc[2], db + 2048);
+            asrc += astage; bsrc[0] += bstage; bsrc[1] += bstage; bsrc[2] += bstage;
+        };
+        // ---- fragment addresses: lane (gq, ml) reads k row 4 kk + gq; the odd rows' permutation folded into two lane bases each
+        const int odd = gq & 1;
+        const double* abase[2];          // i = 0, 1
+        abase[0] = (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
+        abase[1] = (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
+        const int bpos = wc * (TW / 2) + 48 * odd + ml;                     // + 16 j, mod 192
+        const float* bbase = (const float*)(lds + 2 * A_STAGE) + gq * TW;
+        int boff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) boff[j] = (bpos + 16 * j) % TW;
+        dma(0);
+        for (int s = 0; s < nfast; ++s) {
+            // this wave's pieces of stage s have landed.  An asm statement: the loop holds no memory operation the compiler knows of, and
+            // its wait-count pass drops a builtin s_waitcnt it believes redundant (measured: wrong products from K = 256 on)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                // ... everybody's; and everybody has left stage s - 1's buffer
+            if (s + 1 < nfast) dma((s + 1) & 1);
+            const double* ab0 = abase[0] + (s & 1) * (A_STAGE / 8);
+            const double* ab1 = abase[1] + (s & 1) * (A_STAGE / 8);
+            const float* bb = bbase + (s & 1) * (B_STAGE / 4);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double a[2], b[NJ];
+                a[0] = ab0[kk * 4 * T];
+                a[1] = ab1[kk * 4 * T];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = (double)bb[kk * 4 * TW + boff[j]];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // the DMA images are dead: the padded images of the slow stages take the block
+    }
+    // ---- the remaining stages (diagonal of a triangular A, ragged K end): masked, register-staged, as gemm64w_kernel
+    if (kfast < khi) {
+        double* As = (double*)lds;
+        double* Bs = As + BK * LDS_STRIDE;
+        const int sk = tid >> 4, sc = (tid & 15) * 4, sc8 = (tid & 15) * NB;
+        const double* __restrict__ Ap = g.A + m0 + sc;
+        const float* __restrict__ Bp = (const float*)g.B + n0 + sc8;
+        const bool b_in = n0 + TW <= g.N;
+        double ra[4];
+        float rb[NB];
+        auto fetch = [&](int k0) {
+            const int k = k0 + sk;
+            const bool kin = k < g.K;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + sc + e;
+                bool ok = kin && m < g.M;
+                if (triA == 1) ok = ok && k <= m + toff;
+                ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
+            }
+            if (b_in && kin) {
+#pragma unroll
+                for (int e = 0; e < NB; e += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bp + (int64_t)k * g.ldb + e);
+                    rb[e] = v.x; rb[e + 1] = v.y; rb[e + 2] = v.z; rb[e + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) rb[e] = (kin && n0 + sc8 + e < g.N) ? Bp[(int64_t)k * g.ldb + e] : 0.f;
+            }
+        };
+        fetch(kfast);
+        for (int k0 = kfast; k0 < khi; k0 += BK) {
+            double* as = As + sk * LDS_STRIDE + sc;
+            double* bs = Bs + sk * LDS_STRIDE_W + sc8;
+            *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
+            *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
+#pragma unroll
+            for (int e = 0; e < NB; e += 2) *reinterpret_cast<double2*>(bs + e) = double2{(double)rb[e], (double)rb[e + 1]};
+            __syncthreads();
+            if (k0 + BK < khi) fetch(k0 + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                const int kq = kk * 4 + gq;
+                double a[2], b[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = As[kq * LDS_STRIDE + wr * 32 + i * 16 + ml];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = Bs[kq * LDS_STRIDE_W + wc * (TW / 2) + j * 16 + ml];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wr * 32 + i * 16 + gq + 4 * rr;
+                const int n = n0 + wc * (TW / 2) + j * 16 + ml;
+                if (m >= g.M || n >= g.N) continue;
+                const double v = g.alpha * acc[i][j][rr];
+                if (g.C) g.C[(int64_t)m * g.ldc + n] = v;
+                if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
+            }
+}
+
 // fp32 copy of a split-K result (the atomics accumulate in fp64 only): rows over blockIdx.y, two columns per thread through
 // 16-byte loads / 8-byte stores where the rows allow (no per-element 64-bit division: 78 -> ~25 us for the 3000 x 3001 [Q' | a])
 template <bool VEC>
@@ -501,6 +697,13 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
                                      : hipFuncSetAttribute((const void*)gemm64w_kernel<double, TWD>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
             if (ea != hipSuccess) return 1000 + (int)ea;
         }
+#if G64_PIPE && G64W_TW == 192
+        // (the pipelined form: float right operand, no upper-triangular A, rows of both operands addressable as 16 / 12-byte pieces;
+        //  N >= 4 and M >= 2 for its clamped edge addresses; not as a row-range piece with LDS padding)
+        if (bf && !pad && !(fl & DSVGP_GEMM_A_UPPER) && g.N >= 4 && g.M >= 2)
+            hipLaunchKernelGGL(gemm64p_kernel, gridw, dim3(256), 0, st, a);
+        else
+#endif
         if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), pad, st, a);
         hipError_t ew = hipGetLastError();

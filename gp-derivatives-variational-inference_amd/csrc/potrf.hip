@@ -328,6 +328,7 @@ __device__ __forceinline__ void strip_pipe(double (*S)[64][LDT], const double* _
 #pragma unroll
             for (int q = 0; q < 4; ++q) S[0][wr * 32 + i * 16 + (lane >> 4) + 4 * q][wc * 32 + j * 16 + (lane & 15)] = -T[i][j][q];
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): the caller's B_0 (LDS-DMA, not counted by the compiler) and C_0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int base[2];
     pipe_bases<B_NK>(lane, wc, base);
@@ -361,6 +362,7 @@ __device__ __forceinline__ void strip_pipe(double (*S)[64][LDT], const double* _
         // count of its loads restarts here -- otherwise the next stage's first MFMAs wait "vmcnt(3)" for accumulators that are long
         // there, and that wait now includes five of the eight DMA instructions just issued.
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (and one the wait-count pass cannot weaken: the DMA is invisible to it)
         __syncthreads();                                    // B_{c+1} is complete; every wave is done with B_c
         if (c < 5) PIPE_TR(5 + 3 * c);
     };
