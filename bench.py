@@ -424,8 +424,8 @@ def main():
             if world == 1 and cfg_name == "c4" and eng.trsm_nb >= Mp and not fp64 and headline:
                 import glob
                 # NOT live: both figures are read from the committed rocprofv3 PMC summaries of this same command (profiles/), newest round first
-                # (the kernel that runs the forward solve NOW decides which committed profile applies: the wide kernel of gemm64.hip first)
-                families = ("gemm64w_kernel<float", "gemm64_kernel<float")
+                # (the kernel that runs the forward solve NOW decides which committed profile applies: the pipelined wide kernel of gemm64.hip first)
+                families = ("gemm64p_kernel", "gemm64w_kernel<float", "gemm64_kernel<float")
                 for fam in families:
                     for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
                         cands = [k for k in json.load(open(pmc))["kernels"] if k["kernel"].startswith(fam)]
@@ -459,7 +459,7 @@ def main():
             roof = dict(bound="mfma", kernel=("%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
                                                % ("gemm64w_kernel<double, 128>" if wide else "gemm64_kernel<double>") if fp64 else
                                                "%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"
-                                               % ("gemm64w_kernel<float, 192>" if wide else "gemm64_kernel<float>")),
+                                               % ("gemm64p_kernel (64 x 192 tiles, LDS-DMA stages)" if wide else "gemm64_kernel<float>")),
                         achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                         traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
                         mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)
