@@ -35,6 +35,9 @@ constexpr int TM = 128, TN = 128;
 #ifndef G32_PRIO
 #define G32_PRIO 0
 #endif
+#ifndef G32_DMA_BK
+#define G32_DMA_BK 32       // stage depth of the LDS-DMA kernel (32: two workgroups per CU; 16: three)
+#endif
 #ifndef G32_DMA
 #define G32_DMA 1           // 1: stages by LDS-DMA (gemm32_dma_kernel) where eligible, 0: register staging only
 #endif
@@ -372,26 +375,34 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_a
 // MF = 32: 2 x 2 tiles of v_mfma_f32_32x32x2_f32 per wave;  MF = 16: 4 x 4 tiles of v_mfma_f32_16x16x4_f32 (same 64 x 64 wave tile,
 // same LDS images and DMA; twice the fragment reads per flop, but the smaller shape holds a higher clock under load).
 // Lane l = TS h + r (TS = 32 / 16 rows per tile, h = k slot 0..1 / 0..3) reads chunk (64 / MF) j + h of its row per read.
-template <int MF, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
-    constexpr int BK = 32, OPW = 128 * BK;                // words per operand image
-    constexpr int TS = MF, NT = 64 / TS, NH = 64 / TS, NJ = 8 / NH;   // tile size, tiles per wave side, k slots, chunk groups / stage
+// BK (G32_DMA_BK): 32 -- two 32 KB buffers, two workgroups per CU; 16 -- two 16 KB buffers, LDS and registers (<= 129) leave room for
+// three: a third wave per SIMD fills the matrix pipe while the other two sit in their DMA-issue / barrier phases (round 5).  A
+// k-contiguous image then has 64-byte rows of four 16-byte chunks, chunk c of row R at position c ^ ((R >> 2) & 3) (the four rows
+// of a read group that share R mod 4 -- the same quarter of the 256-byte bank row -- differ in (R >> 2) & 3), 16 rows per 1 KB piece.
+template <int MF, bool A_KC, bool B_KC, int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 3 : 2) void gemm32_dma_kernel(const G32 g) {
+    static_assert(BK == 32 || (BK == 16 && MF == 32), "the 64-byte-row swizzle is derived for the 32 x 32 x 2 shape");
+    constexpr int OPW = 128 * BK;                         // words per operand image
+    constexpr int NP = BK / 8;                            // 1 KB DMA pieces per operand, stage and wave
+    constexpr int CH = BK / 4, RPP = 256 / BK;            // 16-byte chunks per k-contiguous row; rows per piece
+    constexpr int TS = MF, NT = 64 / TS, NH = 64 / TS, NJ = BK / (4 * NH);   // tile size, tiles per wave side, k slots, chunk groups / stage
     __shared__ __attribute__((aligned(16))) float lds[2][2 * OPW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int h = lane / TS, r = lane % TS;
     int m0, n0, kbeg, kend;
     if (!pick_unit(g, m0, n0, kbeg, kend)) return;
 
-    // ---- DMA sources: 4 instructions per operand and stage, instruction i of wave w fills the 1 KB block 4 w + i
-    const float* asrc[4];
-    const float* bsrc[4];
-    int akk[4], bkk[4];                                   // k of the lane's chunk / row inside a stage (for the K tail)
+    // ---- DMA sources: NP instructions per operand and stage, instruction i of wave w fills the 1 KB block NP w + i
+    const float* asrc[NP];
+    const float* bsrc[NP];
+    int akk[NP], bkk[NP];                                 // k of the lane's chunk / row inside a stage (for the K tail)
     const int K4 = (g.K + 3) / 4 * 4;
+    auto swz = [](int R) { return BK == 32 ? ((R >> 1) & 7) : ((R >> 2) & 3); };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int blk = wave * 4 + i;
+    for (int i = 0; i < NP; ++i) {
+        const int blk = wave * NP + i;
         if constexpr (A_KC) {
-            const int R = blk * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7);
+            const int R = blk * RPP + lane / CH, c = (lane % CH) ^ swz(R);
             asrc[i] = g.A + (int64_t)min(m0 + R, g.M - 1) * g.lda + kbeg + 4 * c;
             akk[i] = 4 * c;
         } else {
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
             akk[i] = k;
         }
         if constexpr (B_KC) {
-            const int R = blk * 8 + (lane >> 3), c = (lane & 7) ^ ((R >> 1) & 7);
+            const int R = blk * RPP + lane / CH, c = (lane % CH) ^ swz(R);
             bsrc[i] = g.B + (int64_t)min(n0 + R, g.N - 1) * g.ldb + kbeg + 4 * c;
             bkk[i] = 4 * c;
         } else {
@@ -413,10 +424,10 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)&lds[0][0];
     const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto dma = [&](int buf, int k0) {
-        const unsigned dst = lds_base + (unsigned)buf * (2 * OPW * 4) + wave_u * 4096;     // byte address, wave-uniform
+        const unsigned dst = lds_base + (unsigned)buf * (2 * OPW * 4) + wave_u * (NP * 1024);     // byte address, wave-uniform
         const bool tail = k0 + BK > kend;                 // (only the last stage of the last K slice)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const float* sa = asrc[i];
             const float* sb = bsrc[i];
             if (tail) {
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(const G32 g) {
             for (int c = 0; c < (MF == 32 ? 16 : 4); ++c) acc[i][j][c] = 0.f;
 
     // per-lane fragment offsets (words) inside an operand image; tile i of the wave adds i * TS rows / columns
-    const int q7 = h ^ ((r >> 1) & 7);
+    const int q7 = h ^ swz(r);
     int aoff[NJ], boff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -622,10 +633,10 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
     // LDS-DMA kernel: a k-contiguous operand needs K % 4 == 0 or caller-zeroed padding up to it (the chunk that straddles K
     // is read as it lies in memory)
     if (!((akc || bkc) && g.K % 4 != 0 && !(g.flags & DSVGP_GEMM_K_PADDED))) {
-        if (akc && bkc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, true, true>), grid, dim3(256), 0, st, a);
-        else if (akc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, true, false>), grid, dim3(256), 0, st, a);
-        else if (bkc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, false, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, false, false>), grid, dim3(256), 0, st, a);
+        if (akc && bkc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, true, true, G32_DMA_BK>), grid, dim3(256), 0, st, a);
+        else if (akc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, true, false, G32_DMA_BK>), grid, dim3(256), 0, st, a);
+        else if (bkc) hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, false, true, G32_DMA_BK>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm32_dma_kernel<G32_MF, false, false, G32_DMA_BK>), grid, dim3(256), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return 1000 + (int)e;
     } else
