@@ -207,6 +207,7 @@ extern "C" int dsvgp_trsm(dsvgp_ctx* ctx, const double* L, int64_t ldl, int n, i
         if (rhs_float) f.flags |= DSVGP_GEMM_B_IS_FLOAT;
         f.B = rhs; f.ldb = ldrhs;
         f.alpha = 1.0; f.beta = 0.0;
+        f.lean_classic = ctx->lean_classic ? 1 : 0;
         f.C = X64 ? X64 + (size_t)r0 * ldx64 : nullptr; f.ldc = ldx64;
         if (X32) { f.C32 = X32 + (size_t)r0 * ldx32; f.ldc32 = ldx32; }
         if (!X64 && (int64_t)cdiv(nr, 64) * cdiv(nrhs, 64) < 1024) {

@@ -17,6 +17,11 @@ struct dsvgp_ctx {
     // targets, OUT_LOWER blocks, the potrf status word, the residual sums) lies in ONE region the step has cleared with a
     // single memset -- the launchers skip their own clears (a dozen ~5 us fill launches per step at M' = 600)
     bool prezeroed = false;
+    // hint set by the one-call step around its [Q' | a] solve when a large dense product follows it on the same stream while the
+    // side stream's G L_S product is still running (C4): that solve then keeps the register-staged lean kernel (gemm64.hip) -- on the
+    // pipelined one it finishes 0.2 ms earlier, starves G L_S, and G L_S's tail then collides with the dense product: the step is 0.1 ms
+    // slower (profiles/r05_o_gemm64l_lean.txt)
+    bool lean_classic = false;
 };
 
 #define DSVGP_LAUNCH_CHECK()                                  \
@@ -50,6 +55,7 @@ struct GemmArgs {
     // takes so that another stream's launches keep finding room.  Only gemm64.hip's wide kernel honours these: launch_gemm
     // refuses (DSVGP_EINVAL) a product with tri_off / wide64 set that it cannot send there.
     int tri_off, wide64, lds_pad;
+    int lean_classic;    // 1: gemm64.hip's lean class stays on the register-staged kernel (see dsvgp_ctx::lean_classic)
 };
 // how many split-K slices fit the slab (>= 2) or 1 (= do not split); esz = bytes per element
 static inline int slab_slices(const GemmArgs& g, int want, size_t esz) {

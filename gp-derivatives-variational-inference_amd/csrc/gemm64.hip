@@ -614,6 +614,193 @@ __global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
             }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The lean 64 x 64 kernel in the same software-pipelined form (round 5), for the mid-size [M', B'] solves (C3, the data-parallel
+// shares) and the [Q' | a] solve: float right operand, mn-contiguous operands, optional triangular A (lower OR upper), no
+// triangular B, no split-K.  Stage = A 16 x 64 doubles (8 KB, two DMA pieces per wave) + B 16 x 64 FLOATS (4 KB, one piece per
+// wave); two stage buffers = 24 KB, six workgroups per CU as before; one barrier per 16-MFMA stage instead of two, no ds_write.
+// Images as gemm64p_kernel's (A: odd k rows with the 16-double halves of each 32 swapped; B: odd k rows with column c ^ 16).
+// The K range of a tile is walked as  masked stages | DMA stages | masked stages:  the masked (register-staged) stages are the
+// ones at the diagonal of a triangular A -- at the END of the range for a lower A, at its START for an upper one -- and a ragged
+// K end.
+// -------------------------------------------------------------------------------------------------
+#ifndef G64_LEAN_PIPE
+#define G64_LEAN_PIPE 1
+#endif
+#ifndef G64_LEAN_PIPE_UPPER
+#define G64_LEAN_PIPE_UPPER 1       // 0: an upper-triangular A (the [Q' | a] solve) stays on gemm64_kernel
+#endif
+__global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
+    constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * T * 4;           // 8 KB + 4 KB
+    constexpr int SLOW_BYTES = 2 * BK * LDS_STRIDE * 8, FAST_BYTES = 2 * (A_STAGE + B_STAGE);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int fl = g.flags;
+    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
+    const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
+    int tm, tn;
+    if (g.balanced) {                                       // (the walks of gemm64_kernel, without its triangular-B case)
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int per_row = (g.tiles_n + G64_CHUNK - 1) / G64_CHUNK;
+        const int chunk = (j / G64_CHUNK) * 8 + xcd;
+        if (chunk >= per_row * g.tiles_m) return;
+        const int rr = chunk / per_row, cc = chunk - rr * per_row;
+        tm = (triA == 1) ? g.tiles_m - 1 - rr : rr;
+        tn = cc * G64_CHUNK + j % G64_CHUNK;
+        if (tn >= g.tiles_n) return;
+    } else {
+        int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
+        if (t >= g.tiles_m * g.tiles_n) return;
+        const int band = t / (G64_BAND * g.tiles_m), r = t - band * G64_BAND * g.tiles_m;
+        const int wcols = min(G64_BAND, g.tiles_n - band * G64_BAND);
+        tm = r / wcols;
+        tn = band * G64_BAND + r - tm * wcols;
+        if (triA == 1) tm = g.tiles_m - 1 - tm;
+    }
+    const int m0 = tm * T, n0 = tn * T;
+    if (out_lower && n0 >= m0 + T) {                         // strictly above the diagonal: defined as zero
+        for (int e = tid; e < T * T; e += 256) {
+            const int m = m0 + e / T, n = n0 + e % T;
+            if (m < g.M && n < g.N) {
+                if (g.C) g.C[(int64_t)m * g.ldc + n] = 0.0;
+                if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = 0.f;
+            }
+        }
+        return;
+    }
+    int klo = 0, khi = g.K;
+    if (triA == 1) khi = min(khi, m0 + T);
+    if (triA == 2) klo = max(klo, (m0 / BK) * BK);
+    // DMA stages [f0, f1): k < K (and not the operands' very last k row when a 16-byte piece can reach past their last column),
+    // below the tile's first row (lower A) / from its last row on (upper A)
+    int f1 = (g.K / BK) * BK;
+    if ((g.M & 1) || (g.N & 3)) f1 = min(f1, ((g.K - 1) / BK) * BK);
+    int f0 = klo;
+    if (triA == 1) f1 = min(f1, ((m0 + 1) / BK) * BK);
+    if (triA == 2) f0 = max(f0, ((m0 + T - 1 + BK - 1) / BK) * BK);
+    f1 = min(f1, khi);
+    if (f0 >= f1) { f0 = khi; f1 = khi; }                   // (no DMA stage: one masked range)
+
+    acc4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc4{0, 0, 0, 0};
+    const int gq = lane >> 4, ml = lane & 15;
+
+    // ---- masked, register-staged stages over [ka, kb) (the padded images take the LDS block)
+    auto masked_range = [&](int ka, int kb) {
+        double* As = (double*)lds;
+        double* Bs = As + BK * LDS_STRIDE;
+        const int sk = tid >> 4, sc = (tid & 15) * 4;
+        const double* __restrict__ Ap = g.A + m0 + sc;
+        const float* __restrict__ Bp = (const float*)g.B + n0 + sc;
+        double ra[4];
+        float rb[4];
+        auto fetch = [&](int k0) {
+            const int k = k0 + sk;
+            const bool kin = k < g.K;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + sc + e, n = n0 + sc + e;
+                bool ok = kin && m < g.M;
+                if (triA == 1) ok = ok && k <= m;
+                if (triA == 2) ok = ok && k >= m;
+                ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
+                rb[e] = (kin && n < g.N) ? Bp[(int64_t)k * g.ldb + e] : 0.f;
+            }
+        };
+        fetch(ka);
+        for (int k0 = ka; k0 < kb; k0 += BK) {
+            double* as = As + sk * LDS_STRIDE + sc;
+            double* bs = Bs + sk * LDS_STRIDE + sc;
+            *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
+            *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
+            *reinterpret_cast<double2*>(bs) = double2{(double)rb[0], (double)rb[1]};
+            *reinterpret_cast<double2*>(bs + 2) = double2{(double)rb[2], (double)rb[3]};
+            __syncthreads();
+            if (k0 + BK < kb) fetch(k0 + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                const int kq = kk * 4 + gq;
+                double a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = As[kq * LDS_STRIDE + wr * 32 + i * 16 + ml];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = Bs[kq * LDS_STRIDE + wc * 32 + j * 16 + ml];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    };
+
+    if (klo < f0) masked_range(klo, f0);
+    if (f0 < f1) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(g64_lds_ptr_t)&lds[0];
+        const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // A: wave w brings k rows 4 w .. 4 w + 3 as two 1 KB pieces (gemm64p_kernel); B: ONE 1 KB piece = rows 4 w .. 4 w + 3 of 64
+        // floats: lane L writes floats 4 (L & 15) .. + 3 of row 4 w + (L >> 4), taken from column (4 (L & 15)) ^ (16 (row & 1))
+        const int par = lane >> 5, hcol = (2 * (lane & 31)) ^ (16 * par);
+        const double* asrc = g.A + (int64_t)(f0 + 4 * wave_u + par) * g.lda + min(m0 + hcol, ((g.M - 1) & ~1));
+        const int brow = 4 * wave_u + (lane >> 4), bcol = (4 * (lane & 15)) ^ (16 * (brow & 1));
+        const float* bsrc = (const float*)g.B + (int64_t)(f0 + brow) * g.ldb + min(n0 + bcol, (g.N - 1) & ~3);
+        const int64_t a2 = 2 * g.lda, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
+        auto dma = [&](int buf) {
+            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * 1024;
+            g64_dma16(asrc, da);
+            g64_dma16(asrc + a2, da + 1024);
+            g64_dma16(bsrc, db);
+            asrc += astage; bsrc += bstage;
+        };
+        const int odd = gq & 1;
+        const double* ab0 = (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
+        const double* ab1 = (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
+        const float* bb0 = (const float*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
+        const float* bb1 = (const float*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
+        dma(0);
+        const int nst = (f1 - f0) / BK;
+        for (int st = 0; st < nst; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of stage st have landed (asm: see gemm64p_kernel)
+            __syncthreads();
+            if (st + 1 < nst) dma((st + 1) & 1);
+            const int ao = (st & 1) * (A_STAGE / 8), bo = (st & 1) * (B_STAGE / 4);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double a[2], b[2];
+                a[0] = ab0[ao + kk * 4 * T];
+                a[1] = ab1[ao + kk * 4 * T];
+                b[0] = (double)bb0[bo + kk * 4 * T];
+                b[1] = (double)bb1[bo + kk * 4 * T];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // the DMA images are dead
+    }
+    if (f1 < khi) masked_range(f1, khi);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 32 + i * 16 + gq + 4 * r;
+                const int n = n0 + wc * 32 + j * 16 + ml;
+                if (m >= g.M || n >= g.N) continue;
+                double v = g.alpha * acc[i][j][r];
+                if (out_lower && n > m) v = 0.0;
+                if (g.C) g.C[(int64_t)m * g.ldc + n] = v;
+                if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
+            }
+}
+
 // fp32 copy of a split-K result (the atomics accumulate in fp64 only): rows over blockIdx.y, two columns per thread through
 // 16-byte loads / 8-byte stores where the rows allow (no per-element 64-bit division: 78 -> ~25 us for the 3000 x 3001 [Q' | a])
 template <bool VEC>
@@ -738,7 +925,13 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     } else if (b_kc) {
         if (bf) hipLaunchKernelGGL((gemm64_kernel<float, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm64_kernel<double, false, true>), grid, dim3(256), 0, st, a);
-    } else if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
+    }
+#if G64_LEAN_PIPE
+    // (the pipelined form of the lean kernel: float right operand, no triangular B, no split-K, N >= 4 and M >= 2 for its clamped edge addresses)
+    else if (bf && !a.kchunk && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER)) && g.N >= 4 && g.M >= 2 && !g.lean_classic && (G64_LEAN_PIPE_UPPER || !(fl & DSVGP_GEMM_A_UPPER)))
+        hipLaunchKernelGGL(gemm64l_kernel, grid, dim3(256), 0, st, a);
+#endif
+    else if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);
     if (a.slab) {
         hipError_t e0 = hipGetLastError();

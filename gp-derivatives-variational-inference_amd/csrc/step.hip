@@ -271,6 +271,9 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
     return 0;
 }
 
+#ifndef STEP_Q_CLASSIC_BP
+#define STEP_Q_CLASSIC_BP 16384     // minibatch columns B' from which the [Q' | a] solve of the one-call step keeps the register-staged lean kernel
+#endif
 #ifndef STEP_PIPE_K1
 #define STEP_PIPE_K1 450    // forward solve under the chain (flag 128): the side stream starts rows [0, r1) after launch k1 = 45 % of the block rows,
 #define STEP_PIPE_K2 750    // rows [r1, r2) after launch k2 = 75 %
@@ -524,7 +527,14 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         // (only the fp32 copy of [Q' | a] is read afterwards.  A large solve writes it directly; a small one -- fewer than 1024
         //  output tiles -- splits K onto an fp64 target: its own, Qe64, not the scratch the forward solve has used already)
         const bool small = (int64_t)((Mp + 63) / 64) * ((Mp + 1 + 63) / 64) < 1024;
-        return dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, small ? Qe64 : nullptr, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
+        // (beside the side stream's G L_S and in front of a LARGE dense product -- B' >= STEP_Q_CLASSIC_BP, the C4 geometry -- the solve
+        //  keeps the register-staged lean kernel: see dsvgp_ctx::lean_classic.  Measured: C4 12.31 against 12.42 ms; C3 and the
+        //  8-rank share, whose dense products are small, gain 0.2 % / 1 % on the pipelined kernel.)
+        const bool prev = ctx->lean_classic;
+        ctx->lean_classic = overlap && Bp >= STEP_Q_CLASSIC_BP;
+        const int rc = dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, small ? Qe64 : nullptr, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
+        ctx->lean_classic = prev;
+        return rc;
     };
     auto dense = [&]() -> int {
         if (flags & 32) {
