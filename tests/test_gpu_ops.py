@@ -695,6 +695,44 @@ def test_gemm_f64_wide_tile_kernel(dsvgp, gpu_device, tri, bfloat):
     assert relmax(C32, ref) < 2e-7
 
 
+@pytest.mark.parametrize("tri", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,padA,padB", [(1601, 2947, 1601, 1, 1), (1600, 2944, 1600, 0, 0), (1985, 2050, 1985, 3, 2)])      # (26 x 47, 25 x 46, 32 x 33 tiles)
+def test_gemm_f64_lean_pipelined_kernel(dsvgp, gpu_device, tri, M, N, K, padA, padB):
+    """1024 .. 8191 tiles of 64 x 64 with a FLOAT mn-contiguous right operand: gemm64.hip's lean kernel in its software-pipelined
+    form (LDS-DMA stages; the mid-size panel solves and the [Q' | a] solve): dense / lower / upper triangular left operand with
+    garbage in the masked half, odd and even sizes (16-byte DMA pieces past the last column; the very last k row on the masked path),
+    whole and ragged tiles, OUT_LOWER, fp64 and fp32 outputs -- against torch fp64"""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(23 + tri + M)
+    lda = M + padA + ((M + padA) & 1)                              # (even: 16-byte vector loads)
+    ldb = (N + padB + 3) // 4 * 4
+    A = torch.randn(K, M, generator=g, dtype=torch.float64)        # op(A)[m][k] = A[k][m]
+    keep = None
+    if tri == 1:
+        keep = torch.triu(torch.ones(K, M, dtype=torch.bool))      # op(A) lower triangular (A_LOWER)
+    elif tri == 2:
+        keep = torch.tril(torch.ones(K, M, dtype=torch.bool))      # op(A) upper triangular (A_UPPER)
+    B = torch.randn(K, N, generator=g)
+    Ad = torch.randn(K, lda, generator=g, dtype=torch.float64).to(gpu_device)[:, :M]        # (garbage in the padding too)
+    if keep is None:
+        Ad.copy_(A)
+    else:
+        Ad.copy_(torch.where(keep.to(gpu_device), A.to(gpu_device), Ad))                    # (the masked half must not be read)
+        A = A * keep
+    Bd = torch.randn(K, ldb, generator=g).to(gpu_device)[:, :N]
+    Bd.copy_(B)
+    flags = L.TRANS_A | (L.A_LOWER if tri == 1 else (L.A_UPPER if tri == 2 else 0))
+    ref = 0.75 * (A.t().to(gpu_device) @ Bd.double())
+    for lower in (0, L.OUT_LOWER):
+        C = torch.full((M, N), float("nan"), dtype=torch.float64, device=gpu_device)
+        C32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu_device)
+        ops.gemm(ctx, flags | lower, Ad, Bd, C, alpha=0.75, C32=C32)
+        want = torch.tril(ref) if lower else ref
+        assert relmax(C, want) < 1e-13, (tri, lower, relmax(C, want))
+        assert relmax(C32, want) < 2e-7
+
+
 # ------------------------------------------------------------------ round 4: bf16 x 3 split products (opt-in), widening copy
 @pytest.mark.parametrize("R,C,transpose", [(700, 1300, False), (257, 33, False), (1300, 700, True), (33, 257, True)])
 def test_split3_planes_reconstruct_the_operand(dsvgp, gpu_device, R, C, transpose):
