@@ -457,9 +457,9 @@ def main():
                         break
             wide = Mp >= 64 and (Mp + 63) // 64 * ((Bp_local + 63) // 64) >= 8192          # (gemm64.hip: 64 x 192 / 64 x 128 tiles from 8192 tiles of 64 x 64 up)
             roof = dict(bound="mfma", kernel=("%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp64 K_ZX on v_mfma_f64_16x16x4)"
-                                               % ("gemm64w_kernel<double, 128>" if wide else "gemm64_kernel<double>") if fp64 else
+                                               % ("gemm64p_kernel<double, 128> (64 x 128 tiles, LDS-DMA stages)" if wide else "gemm64_kernel<double>") if fp64 else
                                                "%s (panel solve A = L^-1 K_ZX: lower-triangular fp64 inverse x fp32 K_ZX on v_mfma_f64_16x16x4, fp32 result)"
-                                               % ("gemm64p_kernel (64 x 192 tiles, LDS-DMA stages)" if wide else "gemm64_kernel<float>")),
+                                               % ("gemm64p_kernel<float, 192> (64 x 192 tiles, LDS-DMA stages)" if wide else "gemm64l_kernel (64 x 64 tiles, LDS-DMA stages)")),
                         achieved=ach, peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_MFMA_TFLOPS,
                         traffic=traffic, traffic_source=(traffic_src + " (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes, not live)") if traffic_src else None,
                         mfma_utilisation=pmc_busy, launches=n_solve, avg_ms=t_solve * 1e3, flops_per_launch=flops)

@@ -440,15 +440,22 @@ __device__ __forceinline__ void g64_dma16(const void* gsrc, unsigned lds_byte_ad
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
-    constexpr int TW = 192, LDS_STRIDE_W = TW + 16, NJ = TW / 32, NB = TW / 16;
-    constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * TW * 4;          // bytes of one DMA stage image: 8 KB + 12 KB
-    // one LDS block: the two DMA stage pairs, or (diagonal stages) the padded images of the register-staged path
+// TB = float: TW = 192 (B stage 12 KB, three workgroups per CU by LDS, 156 registers).  TB = double (float64 model mode): TW = 128 -- a k row of
+// the stage is exactly one 1 KB piece, odd k rows with column c ^ 16 like the A image; 48 KB, three workgroups per CU.
+// The K range of a tile is walked as  masked stages | DMA stages | masked stages  (lower A: the diagonal is at the END of the range, upper A:
+// at its START; a ragged K end is masked too).
+template <typename TB, int TW>
+__global__ __launch_bounds__(256, sizeof(TB) == 4 ? 2 : 3) void gemm64p_kernel(const G64 g) {
+    constexpr bool BF = sizeof(TB) == 4;
+    static_assert((BF && TW == 192) || (!BF && TW == 128), "image permutations are derived for these two shapes");
+    constexpr int LDS_STRIDE_W = TW + 16, NJ = TW / 32, NB = TW / 16;
+    constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * TW * (int)sizeof(TB);          // bytes of one DMA stage image
+    // one LDS block: the two DMA stage pairs, or (masked stages) the padded images of the register-staged path
     constexpr int SLOW_BYTES = (BK * LDS_STRIDE + BK * LDS_STRIDE_W) * 8, FAST_BYTES = 2 * (A_STAGE + B_STAGE);
     __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int fl = g.flags;
-    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : 0;               // (the launcher sends no upper-triangular A here)
+    const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
     int t = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
     if (t >= g.tiles_m * g.tiles_n) return;
     const int band = t / (G64W_BAND * g.tiles_m), r = t - band * G64W_BAND * g.tiles_m;
@@ -458,99 +465,35 @@ __global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
     if (triA == 1) tm = g.tiles_m - 1 - tm;              // longest K ranges first
     const int m0 = tm * T, n0 = tn * TW;
     const int toff = g.tri_off;
-    int khi = g.K;
+    int klo = 0, khi = g.K;
     if (triA == 1) khi = min(khi, m0 + toff + T);
-    // stages [0, nfast) lie inside both operands: k < K, and (lower-triangular A) below the tile's first row
-    int nfast = g.K / BK;
-    if (triA == 1) nfast = min(nfast, (m0 + toff + 1) / BK);
-    // (a DMA piece is 16 bytes: with an odd M / an N that is no multiple of 4 the last piece of a row reaches past the operand's last
-    //  column -- inside the row's leading dimension, except in the very last k row, which then stays with the masked path)
-    if ((g.M & 1) || (g.N & 3)) nfast = min(nfast, (g.K - 1) / BK);
-    const int kfast = nfast * BK;
+    if (triA == 2) klo = max(klo, ((m0 + toff) / BK) * BK);
+    // DMA stages [f0, f1): k < K, strictly inside the triangle, and (a DMA piece is 16 bytes: with an odd M / an N that is no multiple of the
+    // piece the last piece of a row reaches past the operand's last column -- inside the row's leading dimension, except in the very last k
+    // row) not the operands' last k row in that case
+    int f0 = klo, f1 = (g.K / BK) * BK;
+    if ((g.M & 1) || (g.N & (BF ? 3 : 1))) f1 = min(f1, ((g.K - 1) / BK) * BK);
+    if (triA == 1) f1 = min(f1, ((m0 + toff + 1) / BK) * BK);
+    if (triA == 2) f0 = max(f0, ((m0 + toff + T - 1 + BK - 1) / BK) * BK);
+    f1 = min(f1, khi);
+    if (f0 >= f1) { f0 = khi; f1 = khi; }                   // (no DMA stage: one masked range)
 
     acc4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = acc4{0, 0, 0, 0};
-
     const int gq = lane >> 4, ml = lane & 15;
-    if (nfast > 0) {
-        const unsigned lds0 = (unsigned)(uintptr_t)(g64_lds_ptr_t)&lds[0];
-        const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
-        // ---- DMA sources.  A: wave w brings k rows 4 w .. 4 w + 3 of a stage as two 1 KB pieces (two rows each): lane L = 32 par + h
-        // writes doubles 2 h, 2 h + 1 of row 2 piece + par, taken from column (2 h) ^ (16 par).  Columns past M (ragged last tile row)
-        // are clamped to the row's last pair (the one that holds column M - 1): they feed accumulator rows that are never stored.
-        const int par = lane >> 5, hcol = (2 * (lane & 31)) ^ (16 * par);
-        const int acol = min(m0 + hcol, ((g.M - 1) & ~1));
-        const double* asrc = g.A + (int64_t)(4 * wave_u + par) * g.lda + acol;
-        // B: the [16][192] float image is 12 pieces of 1 KB (256 consecutive floats; 192 = 0 mod 4: a lane's four floats never straddle
-        // a row), wave w pieces 3 w .. 3 w + 2: lane L of piece q writes image floats f = 256 q + 4 L .. + 3 = row f / 192, positions
-        // p = f mod 192, taken from column (p - 48 (row & 1)) mod 192; columns past N are clamped likewise.  (global_load_lds_dwordx3
-        // -- one 768-byte row per instruction -- does NOT pack: it writes its 12 bytes at a 16-byte lane stride.)
-        const float* bsrc[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int f = 256 * (3 * wave_u + i) + 4 * lane, row = f / TW, pos = f % TW;
-            const int c = (pos + TW - 48 * (row & 1)) % TW;
-            bsrc[i] = (const float*)g.B + (int64_t)row * g.ldb + min(n0 + c, (g.N - 1) & ~3);
-        }
-        const int64_t a2 = 2 * g.lda, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
-        auto dma = [&](int buf) {
-            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * 3072;
-            g64_dma16(asrc, da);
-            g64_dma16(asrc + a2, da + 1024);
-            g64_dma16(bsrc[0], db);
-            g64_dma16(bsrc[1], db + 1024);
-            g64_dma16(bsrc[2], db + 2048);
-            asrc += astage; bsrc[0] += bstage; bsrc[1] += bstage; bsrc[2] += bstage;
-        };
-        // ---- fragment addresses: lane (gq, ml) reads k row 4 kk + gq; the odd rows' permutation folded into two lane bases each
-        const int odd = gq & 1;
-        const double* abase[2];          // i = 0, 1
-        abase[0] = (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
-        abase[1] = (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
-        const int bpos = wc * (TW / 2) + 48 * odd + ml;                     // + 16 j, mod 192
-        const float* bbase = (const float*)(lds + 2 * A_STAGE) + gq * TW;
-        int boff[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) boff[j] = (bpos + 16 * j) % TW;
-        dma(0);
-        for (int s = 0; s < nfast; ++s) {
-            // this wave's pieces of stage s have landed.  An asm statement: the loop holds no memory operation the compiler knows of, and
-            // its wait-count pass drops a builtin s_waitcnt it believes redundant (measured: wrong products from K = 256 on)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                // ... everybody's; and everybody has left stage s - 1's buffer
-            if (s + 1 < nfast) dma((s + 1) & 1);
-            const double* ab0 = abase[0] + (s & 1) * (A_STAGE / 8);
-            const double* ab1 = abase[1] + (s & 1) * (A_STAGE / 8);
-            const float* bb = bbase + (s & 1) * (B_STAGE / 4);
-#pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                double a[2], b[NJ];
-                a[0] = ab0[kk * 4 * T];
-                a[1] = ab1[kk * 4 * T];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = (double)bb[kk * 4 * TW + boff[j]];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();                                    // the DMA images are dead: the padded images of the slow stages take the block
-    }
-    // ---- the remaining stages (diagonal of a triangular A, ragged K end): masked, register-staged, as gemm64w_kernel
-    if (kfast < khi) {
+
+    // ---- masked, register-staged stages over [ka, kb), as gemm64w_kernel (the padded images take the LDS block)
+    auto masked_range = [&](int ka, int kb) {
         double* As = (double*)lds;
         double* Bs = As + BK * LDS_STRIDE;
         const int sk = tid >> 4, sc = (tid & 15) * 4, sc8 = (tid & 15) * NB;
         const double* __restrict__ Ap = g.A + m0 + sc;
-        const float* __restrict__ Bp = (const float*)g.B + n0 + sc8;
-        const bool b_in = n0 + TW <= g.N;
+        const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc8;
         double ra[4];
-        float rb[NB];
+        TB rb[NB];
         auto fetch = [&](int k0) {
             const int k = k0 + sk;
             const bool kin = k < g.K;
@@ -559,21 +502,14 @@ __global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
                 const int m = m0 + sc + e;
                 bool ok = kin && m < g.M;
                 if (triA == 1) ok = ok && k <= m + toff;
+                if (triA == 2) ok = ok && k >= m + toff;
                 ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
             }
-            if (b_in && kin) {
 #pragma unroll
-                for (int e = 0; e < NB; e += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(Bp + (int64_t)k * g.ldb + e);
-                    rb[e] = v.x; rb[e + 1] = v.y; rb[e + 2] = v.z; rb[e + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < NB; ++e) rb[e] = (kin && n0 + sc8 + e < g.N) ? Bp[(int64_t)k * g.ldb + e] : 0.f;
-            }
+            for (int e = 0; e < NB; ++e) rb[e] = (kin && n0 + sc8 + e < g.N) ? Bp[(int64_t)k * g.ldb + e] : (TB)0;
         };
-        fetch(kfast);
-        for (int k0 = kfast; k0 < khi; k0 += BK) {
+        fetch(ka);
+        for (int k0 = ka; k0 < kb; k0 += BK) {
             double* as = As + sk * LDS_STRIDE + sc;
             double* bs = Bs + sk * LDS_STRIDE_W + sc8;
             *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
@@ -581,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
 #pragma unroll
             for (int e = 0; e < NB; e += 2) *reinterpret_cast<double2*>(bs + e) = double2{(double)rb[e], (double)rb[e + 1]};
             __syncthreads();
-            if (k0 + BK < khi) fetch(k0 + BK);
+            if (k0 + BK < kb) fetch(k0 + BK);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 const int kq = kk * 4 + gq;
@@ -598,7 +534,84 @@ __global__ __launch_bounds__(256, 2) void gemm64p_kernel(const G64 g) {
             }
             __syncthreads();
         }
+    };
+
+    if (klo < f0) masked_range(klo, f0);
+    if (f0 < f1) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(g64_lds_ptr_t)&lds[0];
+        const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // ---- DMA sources.  A: wave w brings k rows 4 w .. 4 w + 3 of a stage as two 1 KB pieces (two rows each): lane L = 32 par + h
+        // writes doubles 2 h, 2 h + 1 of row 2 piece + par, taken from column (2 h) ^ (16 par).  Columns past M (ragged last tile row)
+        // are clamped to the row's last pair (the one that holds column M - 1): they feed accumulator rows that are never stored.
+        const int par = lane >> 5, hcol = (2 * (lane & 31)) ^ (16 * par);
+        const int acol = min(m0 + hcol, ((g.M - 1) & ~1));
+        const double* asrc = g.A + (int64_t)(f0 + 4 * wave_u + par) * g.lda + acol;
+        // B, float: the [16][192] float image is 12 pieces of 1 KB (256 consecutive floats; 192 = 0 mod 4: a lane's four floats never straddle
+        // a row), wave w pieces 3 w .. 3 w + 2: lane L of piece q writes image floats f = 256 q + 4 L .. + 3 = row f / 192, positions
+        // p = f mod 192, taken from column (p - 48 (row & 1)) mod 192; columns past N are clamped likewise.  (global_load_lds_dwordx3
+        // -- one 768-byte row per instruction -- does NOT pack: it writes its 12 bytes at a 16-byte lane stride.)
+        // B, double: the [16][128] image is one 1 KB piece per k row, wave w rows 4 w .. 4 w + 3: lane L writes doubles 2 L, 2 L + 1, taken
+        // from column (2 L) ^ (16 (row & 1)).
+        constexpr int NBP = BF ? 3 : 4;
+        const TB* bsrc[NBP];
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) {
+            if constexpr (BF) {
+                const int f = 256 * (3 * wave_u + i) + 4 * lane, row = f / TW, pos = f % TW;
+                const int c = (pos + TW - 48 * (row & 1)) % TW;
+                bsrc[i] = (const TB*)g.B + (int64_t)(f0 + row) * g.ldb + min(n0 + c, (g.N - 1) & ~3);
+            } else {
+                const int row = 4 * wave_u + i, c = (2 * lane) ^ (16 * (row & 1));
+                bsrc[i] = (const TB*)g.B + (int64_t)(f0 + row) * g.ldb + min(n0 + c, (g.N - 1) & ~1);
+            }
+        }
+        const int64_t a2 = 2 * g.lda, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
+        auto dma = [&](int buf) {
+            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * (NBP * 1024);
+            g64_dma16(asrc, da);
+            g64_dma16(asrc + a2, da + 1024);
+#pragma unroll
+            for (int i = 0; i < NBP; ++i) { g64_dma16(bsrc[i], db + i * 1024); bsrc[i] += bstage; }
+            asrc += astage;
+        };
+        // ---- fragment addresses: lane (gq, ml) reads k row 4 kk + gq; the odd rows' permutation folded into lane bases
+        const int odd = gq & 1;
+        const double* abase[2];          // i = 0, 1
+        abase[0] = (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
+        abase[1] = (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
+        const TB* bbase = (const TB*)(lds + 2 * A_STAGE) + gq * TW;
+        int boff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            boff[j] = BF ? (wc * (TW / 2) + 48 * odd + ml + 16 * j) % TW : ((wc * (TW / 2) + 16 * j + ml) ^ (16 * odd));
+        dma(0);
+        const int nst = (f1 - f0) / BK;
+        for (int s = 0; s < nst; ++s) {
+            // this wave's pieces of stage s have landed.  An asm statement: the loop holds no memory operation the compiler knows of, and
+            // its wait-count pass drops a builtin s_waitcnt it believes redundant (measured: wrong products from K = 256 on)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                // ... everybody's; and everybody has left stage s - 1's buffer
+            if (s + 1 < nst) dma((s + 1) & 1);
+            const double* ab0 = abase[0] + (s & 1) * (A_STAGE / 8);
+            const double* ab1 = abase[1] + (s & 1) * (A_STAGE / 8);
+            const TB* bb = bbase + (s & 1) * (B_STAGE / (int)sizeof(TB));
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double a[2], b[NJ];
+                a[0] = ab0[kk * 4 * T];
+                a[1] = ab1[kk * 4 * T];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = (double)bb[kk * 4 * TW + boff[j]];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // the DMA images are dead: the padded images of the masked stages take the block
     }
+    if (f1 < khi) masked_range(f1, khi);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -885,11 +898,12 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
             if (ea != hipSuccess) return 1000 + (int)ea;
         }
 #if G64_PIPE && G64W_TW == 192
-        // (the pipelined form: float right operand, no upper-triangular A, rows of both operands addressable as 16 / 12-byte pieces;
-        //  N >= 4 and M >= 2 for its clamped edge addresses; not as a row-range piece with LDS padding)
-        if (bf && !pad && !(fl & DSVGP_GEMM_A_UPPER) && g.N >= 4 && g.M >= 2)
-            hipLaunchKernelGGL(gemm64p_kernel, gridw, dim3(256), 0, st, a);
-        else
+        // (the pipelined form: rows of both operands addressable as 16-byte pieces -- checked above; N >= 4 and M >= 2 for its clamped edge
+        //  addresses; not as a row-range piece with LDS padding)
+        if (!pad && g.N >= 4 && g.M >= 2) {
+            if (bf) hipLaunchKernelGGL((gemm64p_kernel<float, 192>), gridw, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm64p_kernel<double, 128>), gridw, dim3(256), 0, st, a);
+        } else
 #endif
         if (bf) hipLaunchKernelGGL((gemm64w_kernel<float, G64W_TW>), gridw, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((gemm64w_kernel<double, TWD>), gridw, dim3(256), pad, st, a);
