@@ -640,25 +640,43 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? 2 : 3) void gemm64p_kernel(c
 #ifndef G64_LEAN_PIPE
 #define G64_LEAN_PIPE 1
 #endif
+#ifndef G64_LEAN_PIPE_D
+#define G64_LEAN_PIPE_D 1           // 1: a double right operand too (the Cholesky backward's products; the float64 model mode)
+#endif
 #ifndef G64_LEAN_PIPE_UPPER
 #define G64_LEAN_PIPE_UPPER 1       // 0: an upper-triangular A (the [Q' | a] solve) stays on gemm64_kernel
 #endif
-__global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
-    constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * T * 4;           // 8 KB + 4 KB
+// TB = double (round 5, the Cholesky backward's products and the float64 model mode): the B image is built like the A image (16 KB per stage, 32 KB:
+// five workgroups per CU).  A triangular B trims / masks the K range by the tile COLUMN the same way; split-K (kchunk) walks its chunk of the range
+// and accumulates with fp64 atomics (or stores to the deterministic slab) as gemm64_kernel does.
+template <typename TB>
+__global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_kernel(const G64 g) {
+    constexpr bool BF = sizeof(TB) == 4;
+    constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * T * (int)sizeof(TB);          // 8 KB + 4 / 8 KB
     constexpr int SLOW_BYTES = 2 * BK * LDS_STRIDE * 8, FAST_BYTES = 2 * (A_STAGE + B_STAGE);
     __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int fl = g.flags;
     const int triA = (fl & DSVGP_GEMM_A_LOWER) ? 1 : ((fl & DSVGP_GEMM_A_UPPER) ? 2 : 0);
+    const int triB = (fl & DSVGP_GEMM_B_LOWER) ? 2 : ((fl & DSVGP_GEMM_B_UPPER) ? 1 : 0);
     const bool out_lower = fl & DSVGP_GEMM_OUT_LOWER;
     int tm, tn;
-    if (g.balanced) {                                       // (the walks of gemm64_kernel, without its triangular-B case)
+    if (g.balanced) {                                       // (the walks of gemm64_kernel)
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int per_row = (g.tiles_n + G64_CHUNK - 1) / G64_CHUNK;
         const int chunk = (j / G64_CHUNK) * 8 + xcd;
         if (chunk >= per_row * g.tiles_m) return;
-        const int rr = chunk / per_row, cc = chunk - rr * per_row;
-        tm = (triA == 1) ? g.tiles_m - 1 - rr : rr;
+        int rr, cc;
+        if (triB && !triA) {
+            const int cr = chunk / g.tiles_m;
+            rr = chunk - cr * g.tiles_m;
+            cc = (triB == 2) ? cr : per_row - 1 - cr;
+            tm = rr;
+        } else {
+            rr = chunk / per_row;
+            cc = chunk - rr * per_row;
+            tm = (triA == 1) ? g.tiles_m - 1 - rr : rr;
+        }
         tn = cc * G64_CHUNK + j % G64_CHUNK;
         if (tn >= g.tiles_n) return;
     } else {
@@ -672,6 +690,7 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
     }
     const int m0 = tm * T, n0 = tn * T;
     if (out_lower && n0 >= m0 + T) {                         // strictly above the diagonal: defined as zero
+        if (g.kchunk) return;                                // (split-K: the caller zeroed the whole output)
         for (int e = tid; e < T * T; e += 256) {
             const int m = m0 + e / T, n = n0 + e % T;
             if (m < g.M && n < g.N) {
@@ -684,15 +703,24 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
     int klo = 0, khi = g.K;
     if (triA == 1) khi = min(khi, m0 + T);
     if (triA == 2) klo = max(klo, (m0 / BK) * BK);
+    if (triB == 2) klo = max(klo, (n0 / BK) * BK);
+    if (triB == 1) khi = min(khi, n0 + T);
+    if (g.kchunk) {
+        klo += (int)blockIdx.y * g.kchunk;                   // (klo is a multiple of BK, kchunk too)
+        khi = min(khi, klo + g.kchunk);
+        if (klo >= khi && !g.slab) return;                   // (deterministic mode: an empty chunk still stores its zeros to the slab)
+    }
     // DMA stages [f0, f1): k < K (and not the operands' very last k row when a 16-byte piece can reach past their last column),
-    // below the tile's first row (lower A) / from its last row on (upper A)
+    // strictly inside the triangles: below the tile's first row / column (lower A, upper B), from its last row / column on (upper A, lower B)
     int f1 = (g.K / BK) * BK;
-    if ((g.M & 1) || (g.N & 3)) f1 = min(f1, ((g.K - 1) / BK) * BK);
+    if ((g.M & 1) || (g.N & (BF ? 3 : 1))) f1 = min(f1, ((g.K - 1) / BK) * BK);
     int f0 = klo;
     if (triA == 1) f1 = min(f1, ((m0 + 1) / BK) * BK);
     if (triA == 2) f0 = max(f0, ((m0 + T - 1 + BK - 1) / BK) * BK);
+    if (triB == 1) f1 = min(f1, ((n0 + 1) / BK) * BK);
+    if (triB == 2) f0 = max(f0, ((n0 + T - 1 + BK - 1) / BK) * BK);
     f1 = min(f1, khi);
-    if (f0 >= f1) { f0 = khi; f1 = khi; }                   // (no DMA stage: one masked range)
+    if (f0 >= f1) { f0 = max(klo, khi); f1 = f0; }          // (no DMA stage: one masked range)
 
     acc4 acc[2][2];
 #pragma unroll
@@ -707,9 +735,9 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
         double* Bs = As + BK * LDS_STRIDE;
         const int sk = tid >> 4, sc = (tid & 15) * 4;
         const double* __restrict__ Ap = g.A + m0 + sc;
-        const float* __restrict__ Bp = (const float*)g.B + n0 + sc;
+        const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc;
         double ra[4];
-        float rb[4];
+        TB rb[4];
         auto fetch = [&](int k0) {
             const int k = k0 + sk;
             const bool kin = k < g.K;
@@ -720,7 +748,10 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
                 if (triA == 1) ok = ok && k <= m;
                 if (triA == 2) ok = ok && k >= m;
                 ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
-                rb[e] = (kin && n < g.N) ? Bp[(int64_t)k * g.ldb + e] : 0.f;
+                bool okb = kin && n < g.N;
+                if (triB == 1) okb = okb && k <= n;
+                if (triB == 2) okb = okb && k >= n;
+                rb[e] = okb ? Bp[(int64_t)k * g.ldb + e] : (TB)0;
             }
         };
         fetch(ka);
@@ -751,36 +782,42 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
         }
     };
 
-    if (klo < f0) masked_range(klo, f0);
+    if (klo < f0) masked_range(klo, min(f0, khi));
     if (f0 < f1) {
         const unsigned lds0 = (unsigned)(uintptr_t)(g64_lds_ptr_t)&lds[0];
         const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
-        // A: wave w brings k rows 4 w .. 4 w + 3 as two 1 KB pieces (gemm64p_kernel); B: ONE 1 KB piece = rows 4 w .. 4 w + 3 of 64
-        // floats: lane L writes floats 4 (L & 15) .. + 3 of row 4 w + (L >> 4), taken from column (4 (L & 15)) ^ (16 (row & 1))
+        // A (and a double B): wave w brings k rows 4 w .. 4 w + 3 as two 1 KB pieces (gemm64p_kernel); a float B: ONE 1 KB piece = rows
+        // 4 w .. 4 w + 3 of 64 floats: lane L writes floats 4 (L & 15) .. + 3 of row 4 w + (L >> 4), taken from column (4 (L & 15)) ^ (16 (row & 1))
         const int par = lane >> 5, hcol = (2 * (lane & 31)) ^ (16 * par);
         const double* asrc = g.A + (int64_t)(f0 + 4 * wave_u + par) * g.lda + min(m0 + hcol, ((g.M - 1) & ~1));
-        const int brow = 4 * wave_u + (lane >> 4), bcol = (4 * (lane & 15)) ^ (16 * (brow & 1));
-        const float* bsrc = (const float*)g.B + (int64_t)(f0 + brow) * g.ldb + min(n0 + bcol, (g.N - 1) & ~3);
-        const int64_t a2 = 2 * g.lda, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
+        const TB* bsrc;
+        if constexpr (BF) {
+            const int brow = 4 * wave_u + (lane >> 4), bcol = (4 * (lane & 15)) ^ (16 * (brow & 1));
+            bsrc = (const TB*)g.B + (int64_t)(f0 + brow) * g.ldb + min(n0 + bcol, (g.N - 1) & ~3);
+        } else {
+            bsrc = (const TB*)g.B + (int64_t)(f0 + 4 * wave_u + par) * g.ldb + min(n0 + hcol, ((g.N - 1) & ~1));
+        }
+        const int64_t a2 = 2 * g.lda, b2 = 2 * g.ldb, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
         auto dma = [&](int buf) {
-            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * 1024;
+            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * (BF ? 1024 : 2048);
             g64_dma16(asrc, da);
             g64_dma16(asrc + a2, da + 1024);
             g64_dma16(bsrc, db);
+            if constexpr (!BF) g64_dma16(bsrc + b2, db + 1024);
             asrc += astage; bsrc += bstage;
         };
         const int odd = gq & 1;
         const double* ab0 = (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
         const double* ab1 = (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
-        const float* bb0 = (const float*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
-        const float* bb1 = (const float*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
+        const TB* bb0 = (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
+        const TB* bb1 = (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
         dma(0);
         const int nst = (f1 - f0) / BK;
         for (int st = 0; st < nst; ++st) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of stage st have landed (asm: see gemm64p_kernel)
             __syncthreads();
             if (st + 1 < nst) dma((st + 1) & 1);
-            const int ao = (st & 1) * (A_STAGE / 8), bo = (st & 1) * (B_STAGE / 4);
+            const int ao = (st & 1) * (A_STAGE / 8), bo = (st & 1) * (B_STAGE / (int)sizeof(TB));
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double a[2], b[2];
@@ -797,7 +834,7 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
         }
         __syncthreads();                                    // the DMA images are dead
     }
-    if (f1 < khi) masked_range(f1, khi);
+    if (f1 < khi) masked_range(max(f1, klo), khi);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -808,6 +845,12 @@ __global__ __launch_bounds__(256, G64_MINW) void gemm64l_kernel(const G64 g) {
                 const int n = n0 + wc * 32 + j * 16 + ml;
                 if (m >= g.M || n >= g.N) continue;
                 double v = g.alpha * acc[i][j][r];
+                if (g.kchunk) {
+                    if (out_lower && n > m) continue;
+                    if (g.slab) g.slab[((int64_t)blockIdx.y * g.M + m) * g.N + n] = v;    // deterministic mode (summed in order afterwards)
+                    else atomicAdd(&g.C[(int64_t)m * g.ldc + n], v);
+                    continue;
+                }
                 if (out_lower && n > m) v = 0.0;
                 if (g.C) g.C[(int64_t)m * g.ldc + n] = v;
                 if (g.C32) g.C32[(int64_t)m * g.ldc32 + n] = (float)v;
@@ -941,9 +984,11 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
         else hipLaunchKernelGGL((gemm64_kernel<double, false, true>), grid, dim3(256), 0, st, a);
     }
 #if G64_LEAN_PIPE
-    // (the pipelined form of the lean kernel: float right operand, no triangular B, no split-K, N >= 4 and M >= 2 for its clamped edge addresses)
-    else if (bf && !a.kchunk && !(fl & (DSVGP_GEMM_B_LOWER | DSVGP_GEMM_B_UPPER)) && g.N >= 4 && g.M >= 2 && !g.lean_classic && (G64_LEAN_PIPE_UPPER || !(fl & DSVGP_GEMM_A_UPPER)))
-        hipLaunchKernelGGL(gemm64l_kernel, grid, dim3(256), 0, st, a);
+    // (the pipelined form of the lean kernel: mn-contiguous operands, N >= 4 and M >= 2 for its clamped edge addresses; G64_LEAN_PIPE_D: a double B too)
+    else if (g.N >= 4 && g.M >= 2 && !g.lean_classic && (bf || G64_LEAN_PIPE_D) && (G64_LEAN_PIPE_UPPER || !(fl & DSVGP_GEMM_A_UPPER))) {
+        if (bf) hipLaunchKernelGGL(gemm64l_kernel<float>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(gemm64l_kernel<double>, grid, dim3(256), 0, st, a);
+    }
 #endif
     else if (bf) hipLaunchKernelGGL(gemm64_kernel<float>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm64_kernel<double>, grid, dim3(256), 0, st, a);

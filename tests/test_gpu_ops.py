@@ -733,6 +733,41 @@ def test_gemm_f64_lean_pipelined_kernel(dsvgp, gpu_device, tri, M, N, K, padA, p
         assert relmax(C32, want) < 2e-7
 
 
+@pytest.mark.parametrize("tri_a,tri_b", [(0, 2), (2, 0), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("M,K", [(1985, 1985), (2048, 1536), (1985, 3201)])
+def test_gemm_f64_lean_pipelined_kernel_double_operands(dsvgp, gpu_device, tri_a, tri_b, M, K):
+    """the same kernel with a DOUBLE right operand, a triangular right operand (K range trimmed by the tile column) and split-K (K >= 1536 with
+    an fp64 target: chunks of 768 with fp64 atomics) -- the Cholesky backward's products  G1^T L^-1 (B_LOWER)  and  L^-T Y^T (A_UPPER),
+    both OUT_LOWER -- against torch fp64"""
+    ops, L = dsvgp._ops, dsvgp._lib
+    ctx = ops.Context.get(gpu_device)
+    g = torch.Generator().manual_seed(41 + 3 * tri_a + tri_b + M + K)
+    N = M if (tri_a or tri_b) else M + 130
+    def masked(rows, cols, tri):             # tri 1: keep k <= col (op upper of B / "A_LOWER" of op(A)); 2: keep k >= col
+        if tri == 0:
+            return None
+        ones = torch.ones(rows, cols, dtype=torch.bool)
+        return torch.triu(ones) if tri == 1 else torch.tril(ones)
+    A = torch.randn(K, M, generator=g, dtype=torch.float64)
+    B = torch.randn(K, N, generator=g, dtype=torch.float64)
+    ka, kb = masked(K, M, tri_a), masked(K, N, tri_b)
+    Ad = torch.randn(K, M + (M & 1), generator=g, dtype=torch.float64).to(gpu_device)[:, :M]
+    Bd = torch.randn(K, N + (N & 1), generator=g, dtype=torch.float64).to(gpu_device)[:, :N]
+    Ad.copy_(A if ka is None else torch.where(ka.to(gpu_device), A.to(gpu_device), Ad))
+    Bd.copy_(B if kb is None else torch.where(kb.to(gpu_device), B.to(gpu_device), Bd))
+    if ka is not None:
+        A = A * ka
+    if kb is not None:
+        B = B * kb
+    flags = L.TRANS_A | (L.A_LOWER if tri_a == 1 else (L.A_UPPER if tri_a == 2 else 0)) | (L.B_UPPER if tri_b == 1 else (L.B_LOWER if tri_b == 2 else 0))
+    ref = -0.5 * (A.t().to(gpu_device) @ B.to(gpu_device))
+    for lower in ((L.OUT_LOWER,) if N == M else (0,)):
+        C = torch.full((M, N), float("nan"), dtype=torch.float64, device=gpu_device)
+        ops.gemm(ctx, flags | lower, Ad, Bd, C, alpha=-0.5)
+        want = torch.tril(ref) if lower else ref
+        assert relmax(C, want) < 1e-13, (tri_a, tri_b, M, K, lower, relmax(C, want))
+
+
 # ------------------------------------------------------------------ round 4: bf16 x 3 split products (opt-in), widening copy
 @pytest.mark.parametrize("R,C,transpose", [(700, 1300, False), (257, 33, False), (1300, 700, True), (33, 257, True)])
 def test_split3_planes_reconstruct_the_operand(dsvgp, gpu_device, R, C, transpose):
