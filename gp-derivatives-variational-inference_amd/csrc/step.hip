@@ -271,6 +271,12 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
     return 0;
 }
 
+#ifndef STEP_VAR_LATE
+#define STEP_VAR_LATE 2             // 1: (B' >= STEP_Q_CLASSIC_BP) / 2: (always) the variational block behind the dense product, see dsvgp_elbo_step_f32
+#endif
+#ifndef STEP_VAR_LATE_MP
+#define STEP_VAR_LATE_MP 1536       // ... from this M' on (at M' = 600 the Cholesky backward is too short to hide it: 0.549 -> 0.560 ms)
+#endif
 #ifndef STEP_Q_CLASSIC_BP
 #define STEP_Q_CLASSIC_BP 16384     // minibatch columns B' from which the [Q' | a] solve of the one-call step keeps the register-staged lean kernel
 #endif
@@ -523,6 +529,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
                                         1.f, kl_buf, sums, Ge + (size_t)Mp * Mp, io->dm, io->dLS, io->lddls, B, p, scal);
     };
     // ---- [Q' | a / (2 vbar)] = L^-T [S - I | m / (2 vbar)] (fp64), K_ZX-bar = [Q' | a] [A ; mu_bar^T] (fp32, unscaled)
+    const bool var_late = overlap && !(flags & 16) && Mp >= STEP_VAR_LATE_MP && (STEP_VAR_LATE == 2 || (STEP_VAR_LATE == 1 && Bp >= STEP_Q_CLASSIC_BP));
     auto solve_q = [&]() -> int {
         // (only the fp32 copy of [Q' | a] is read afterwards.  A large solve writes it directly; a small one -- fewer than 1024
         //  output tiles -- splits K onto an fp64 target: its own, Qe64, not the scratch the forward solve has used already)
@@ -531,7 +538,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         //  keeps the register-staged lean kernel: see dsvgp_ctx::lean_classic.  Measured: C4 12.31 against 12.42 ms; C3 and the
         //  8-rank share, whose dense products are small, gain 0.2 % / 1 % on the pipelined kernel.)
         const bool prev = ctx->lean_classic;
-        ctx->lean_classic = overlap && Bp >= STEP_Q_CLASSIC_BP;
+        ctx->lean_classic = overlap && !var_late && Bp >= STEP_Q_CLASSIC_BP;
         const int rc = dsvgp_trsm(ctx, L, Mp, Mp, 1, S32e, ldS, 0, Mp + 1, small ? Qe64 : nullptr, ldQ64, Qe32, ldQ32, nb, trsm_ws, 1);
         ctx->lean_classic = prev;
         return rc;
@@ -595,7 +602,18 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // tail_side: the whole M'^3 tail (L-bar, Cholesky backward) follows the variational block on the side stream, under the dense
     // K_ZX-bar product on the main stream (it depends on [Q' | a] and G only); joined before K_ZZ-bar's kernel backward
     const bool tail_side = overlap && (flags & 16);
-    if (overlap) {
+    if (overlap && var_late) {
+        // the variational block (G L_S, the trace / KL pass) BEHIND the dense product, beside the Cholesky backward's few-tile fp64 products,
+        // instead of beside the [Q' | a] solve: that solve then runs alone, on the pipelined lean kernel (STEP_VAR_LATE)
+        STEP_CALL(solve_q());
+        STEP_CALL(dense());
+        STEP_HIP(hipEventRecord(pl->ev_fork2, main));
+        STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
+        ctx->stream = side;
+        STEP_CALL(variational());
+        STEP_HIP(hipEventRecord(pl->ev_var, side));
+        ctx->stream = main;
+    } else if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork2, main));
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
         ctx->stream = side;
