@@ -573,8 +573,28 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
 
 // 16 x 16 x 16 product on one wave:  P[m][n] = sum_q Aop(m, q) Bop(q, n);  operands through pointers + strides
 //   Aop(m, q) = Ab[m * lda_ + q];   Bop(q, n) = B_NK ? Bb[n * ldb_ + q] : Bb[q * ldb_ + n]
+#ifndef POTRF_PROD16_SPLIT
+#define POTRF_PROD16_SPLIT 1
+#endif
 template <bool B_NK>
 __device__ __forceinline__ acc4 prod16(const double* Ab, int lda_, const double* Bb, int ldb_, int lane) {
+#if POTRF_PROD16_SPLIT
+    // two accumulators: one dependent chain of four fp64 MFMAs waits out every instruction's latency (these 16 x 16 x 16 products sit on the
+    // serial path of factor64_lds: the panel block and the next diagonal block's update of wave 0)
+    acc4 acc0{0, 0, 0, 0}, acc1{0, 0, 0, 0};
+    double a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kq = 4 * t + (lane >> 4), r = lane & 15;
+        a[t] = Ab[r * lda_ + kq];
+        b[t] = B_NK ? Bb[r * ldb_ + kq] : Bb[kq * ldb_ + r];
+    }
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+    return acc0 + acc1;
+#else
     acc4 acc{0, 0, 0, 0};
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4) {
@@ -584,6 +604,7 @@ __device__ __forceinline__ acc4 prod16(const double* Ab, int lda_, const double*
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     return acc;
+#endif
 }
 
 // Factor F (64 x 64, lower, in LDS) -> L in place; Y <- X = L^-1.  256 threads.  While wave 0 runs the serial 16-column
