@@ -640,6 +640,9 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? 2 : 3) void gemm64p_kernel(c
 #ifndef G64_LEAN_PIPE
 #define G64_LEAN_PIPE 1
 #endif
+#ifndef G64_LEAN_PIPE_KC
+#define G64_LEAN_PIPE_KC 1          // 1: k-contiguous operands too (double right operand; the float64 model mode's Gram / dense products)
+#endif
 #ifndef G64_LEAN_PIPE_D
 #define G64_LEAN_PIPE_D 1           // 1: a double right operand too (the Cholesky backward's products; the float64 model mode)
 #endif
@@ -649,9 +652,14 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? 2 : 3) void gemm64p_kernel(c
 // TB = double (round 5, the Cholesky backward's products and the float64 model mode): the B image is built like the A image (16 KB per stage, 32 KB:
 // five workgroups per CU).  A triangular B trims / masks the K range by the tile COLUMN the same way; split-K (kchunk) walks its chunk of the range
 // and accumulates with fp64 atomics (or stores to the deterministic slab) as gemm64_kernel does.
-template <typename TB>
+// A_KC / B_KC (double operands, no triangular structure: the float64 model mode's Gram and dense products): the operand is K-CONTIGUOUS
+// (stored [M, K] / [N, K]); its stage image is [64 rows][16 k] doubles -- 128-byte rows of eight 16-byte chunks, chunk c of row R at position
+// c ^ ((R >> 1) & 7) (a 1 KB piece = 8 rows; the 16 rows of a read group then fall on 16 distinct slots of the 256-byte bank row) -- and a
+// stage advances along the rows (+ 16 doubles) instead of down the matrix.
+template <typename TB, bool A_KC = false, bool B_KC = false>
 __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_kernel(const G64 g) {
     constexpr bool BF = sizeof(TB) == 4;
+    static_assert(!B_KC || !BF, "a k-contiguous float operand stays on gemm64_kernel (its 64-byte rows read 2-way conflicted)");
     constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * T * (int)sizeof(TB);          // 8 KB + 4 / 8 KB
     constexpr int SLOW_BYTES = 2 * BK * LDS_STRIDE * 8, FAST_BYTES = 2 * (A_STAGE + B_STAGE);
     __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES];
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
     // DMA stages [f0, f1): k < K (and not the operands' very last k row when a 16-byte piece can reach past their last column),
     // strictly inside the triangles: below the tile's first row / column (lower A, upper B), from its last row / column on (upper A, lower B)
     int f1 = (g.K / BK) * BK;
-    if ((g.M & 1) || (g.N & (BF ? 3 : 1))) f1 = min(f1, ((g.K - 1) / BK) * BK);
+    if ((!A_KC && (g.M & 1)) || (!B_KC && (g.N & (BF ? 3 : 1)))) f1 = min(f1, ((g.K - 1) / BK) * BK);
     int f0 = klo;
     if (triA == 1) f1 = min(f1, ((m0 + 1) / BK) * BK);
     if (triA == 2) f0 = max(f0, ((m0 + T - 1 + BK - 1) / BK) * BK);
@@ -734,8 +742,9 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
         double* As = (double*)lds;
         double* Bs = As + BK * LDS_STRIDE;
         const int sk = tid >> 4, sc = (tid & 15) * 4;
-        const double* __restrict__ Ap = g.A + m0 + sc;
-        const TB* __restrict__ Bp = (const TB*)g.B + n0 + sc;
+        const int kr = tid >> 2, kq4 = (tid & 3) * 4;       // k-contiguous operand: row kr of the tile, k = kq4 .. kq4 + 3 of the stage
+        const double* __restrict__ Ap = A_KC ? g.A + (int64_t)min(m0 + kr, g.M - 1) * g.lda + kq4 : g.A + m0 + sc;
+        const TB* __restrict__ Bp = B_KC ? (const TB*)g.B + (int64_t)min(n0 + kr, g.N - 1) * g.ldb + kq4 : (const TB*)g.B + n0 + sc;
         double ra[4];
         TB rb[4];
         auto fetch = [&](int k0) {
@@ -743,25 +752,44 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
             const bool kin = k < g.K;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int m = m0 + sc + e, n = n0 + sc + e;
-                bool ok = kin && m < g.M;
-                if (triA == 1) ok = ok && k <= m;
-                if (triA == 2) ok = ok && k >= m;
-                ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
-                bool okb = kin && n < g.N;
-                if (triB == 1) okb = okb && k <= n;
-                if (triB == 2) okb = okb && k >= n;
-                rb[e] = okb ? Bp[(int64_t)k * g.ldb + e] : (TB)0;
+                if constexpr (A_KC) {
+                    ra[e] = (m0 + kr < g.M && k0 + kq4 + e < g.K) ? Ap[k0 + e] : 0.0;
+                } else {
+                    const int m = m0 + sc + e;
+                    bool ok = kin && m < g.M;
+                    if (triA == 1) ok = ok && k <= m;
+                    if (triA == 2) ok = ok && k >= m;
+                    ra[e] = ok ? Ap[(int64_t)k * g.lda + e] : 0.0;
+                }
+                if constexpr (B_KC) {
+                    rb[e] = (n0 + kr < g.N && k0 + kq4 + e < g.K) ? Bp[k0 + e] : (TB)0;
+                } else {
+                    const int n = n0 + sc + e;
+                    bool okb = kin && n < g.N;
+                    if (triB == 1) okb = okb && k <= n;
+                    if (triB == 2) okb = okb && k >= n;
+                    rb[e] = okb ? Bp[(int64_t)k * g.ldb + e] : (TB)0;
+                }
             }
         };
         fetch(ka);
         for (int k0 = ka; k0 < kb; k0 += BK) {
             double* as = As + sk * LDS_STRIDE + sc;
             double* bs = Bs + sk * LDS_STRIDE + sc;
-            *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
-            *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
-            *reinterpret_cast<double2*>(bs) = double2{(double)rb[0], (double)rb[1]};
-            *reinterpret_cast<double2*>(bs + 2) = double2{(double)rb[2], (double)rb[3]};
+            if constexpr (A_KC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[(kq4 + e) * LDS_STRIDE + kr] = ra[e];
+            } else {
+                *reinterpret_cast<double2*>(as) = double2{ra[0], ra[1]};
+                *reinterpret_cast<double2*>(as + 2) = double2{ra[2], ra[3]};
+            }
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[(kq4 + e) * LDS_STRIDE + kr] = (double)rb[e];
+            } else {
+                *reinterpret_cast<double2*>(bs) = double2{(double)rb[0], (double)rb[1]};
+                *reinterpret_cast<double2*>(bs + 2) = double2{(double)rb[2], (double)rb[3]};
+            }
             __syncthreads();
             if (k0 + BK < kb) fetch(k0 + BK);
 #pragma unroll
@@ -789,28 +817,49 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
         // A (and a double B): wave w brings k rows 4 w .. 4 w + 3 as two 1 KB pieces (gemm64p_kernel); a float B: ONE 1 KB piece = rows
         // 4 w .. 4 w + 3 of 64 floats: lane L writes floats 4 (L & 15) .. + 3 of row 4 w + (L >> 4), taken from column (4 (L & 15)) ^ (16 (row & 1))
         const int par = lane >> 5, hcol = (2 * (lane & 31)) ^ (16 * par);
-        const double* asrc = g.A + (int64_t)(f0 + 4 * wave_u + par) * g.lda + min(m0 + hcol, ((g.M - 1) & ~1));
+        // (k-contiguous operand: wave w brings tile rows 16 w .. 16 w + 15 as two 1 KB pieces of 8 rows: lane L writes chunk position L & 7 of
+        //  row 16 w + 8 piece + (L >> 3), taken from chunk (L & 7) ^ ((row >> 1) & 7) of that row; rows past the operand's last: clamped)
+        const int krow = 16 * wave_u + (lane >> 3), kch = (lane & 7) ^ ((krow >> 1) & 7), kch2 = (lane & 7) ^ (((krow + 8) >> 1) & 7);
+        const double* asrc;
+        const double* asrc2;
+        if constexpr (A_KC) {
+            asrc = g.A + (int64_t)min(m0 + krow, g.M - 1) * g.lda + f0 + 2 * kch;
+            asrc2 = g.A + (int64_t)min(m0 + krow + 8, g.M - 1) * g.lda + f0 + 2 * kch2;
+        } else {
+            asrc = g.A + (int64_t)(f0 + 4 * wave_u + par) * g.lda + min(m0 + hcol, ((g.M - 1) & ~1));
+            asrc2 = asrc + 2 * g.lda;
+        }
         const TB* bsrc;
-        if constexpr (BF) {
+        const TB* bsrc2 = nullptr;
+        if constexpr (B_KC) {
+            bsrc = (const TB*)g.B + (int64_t)min(n0 + krow, g.N - 1) * g.ldb + f0 + 2 * kch;
+            bsrc2 = (const TB*)g.B + (int64_t)min(n0 + krow + 8, g.N - 1) * g.ldb + f0 + 2 * kch2;
+        } else if constexpr (BF) {
             const int brow = 4 * wave_u + (lane >> 4), bcol = (4 * (lane & 15)) ^ (16 * (brow & 1));
             bsrc = (const TB*)g.B + (int64_t)(f0 + brow) * g.ldb + min(n0 + bcol, (g.N - 1) & ~3);
         } else {
             bsrc = (const TB*)g.B + (int64_t)(f0 + 4 * wave_u + par) * g.ldb + min(n0 + hcol, ((g.N - 1) & ~1));
+            bsrc2 = bsrc + 2 * g.ldb;
         }
-        const int64_t a2 = 2 * g.lda, b2 = 2 * g.ldb, astage = (int64_t)BK * g.lda, bstage = (int64_t)BK * g.ldb;
+        const int64_t astage = A_KC ? (int64_t)BK : (int64_t)BK * g.lda, bstage = B_KC ? (int64_t)BK : (int64_t)BK * g.ldb;
         auto dma = [&](int buf) {
             const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * (BF ? 1024 : 2048);
             g64_dma16(asrc, da);
-            g64_dma16(asrc + a2, da + 1024);
+            g64_dma16(asrc2, da + 1024);
             g64_dma16(bsrc, db);
-            if constexpr (!BF) g64_dma16(bsrc + b2, db + 1024);
-            asrc += astage; bsrc += bstage;
+            if constexpr (!BF) { g64_dma16(bsrc2, db + 1024); bsrc2 += bstage; }
+            asrc += astage; asrc2 += astage; bsrc += bstage;
         };
         const int odd = gq & 1;
-        const double* ab0 = (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
-        const double* ab1 = (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
-        const TB* bb0 = (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
-        const TB* bb1 = (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
+        // fragment addresses (elements into a stage image): mn-contiguous -- row 4 kk + gq at + kk * 4 * T; k-contiguous -- row m of 16 doubles,
+        // chunk (2 kk + (gq >> 1)) ^ ((ml >> 1) & 7), half gq & 1: four lane offsets koff[kk]
+        int koff[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) koff[kk] = 2 * ((2 * kk + (gq >> 1)) ^ ((ml >> 1) & 7)) + (gq & 1);
+        const double* ab0 = A_KC ? (const double*)lds + (wr * 32 + ml) * BK : (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
+        const double* ab1 = A_KC ? (const double*)lds + (wr * 32 + 16 + ml) * BK : (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
+        const TB* bb0 = B_KC ? (const TB*)(lds + 2 * A_STAGE) + (wc * 32 + ml) * BK : (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
+        const TB* bb1 = B_KC ? (const TB*)(lds + 2 * A_STAGE) + (wc * 32 + 16 + ml) * BK : (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
         dma(0);
         const int nst = (f1 - f0) / BK;
         for (int st = 0; st < nst; ++st) {
@@ -821,10 +870,10 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double a[2], b[2];
-                a[0] = ab0[ao + kk * 4 * T];
-                a[1] = ab1[ao + kk * 4 * T];
-                b[0] = (double)bb0[bo + kk * 4 * T];
-                b[1] = (double)bb1[bo + kk * 4 * T];
+                a[0] = ab0[ao + (A_KC ? koff[kk] : kk * 4 * T)];
+                a[1] = ab1[ao + (A_KC ? koff[kk] : kk * 4 * T)];
+                b[0] = (double)bb0[bo + (B_KC ? koff[kk] : kk * 4 * T)];
+                b[1] = (double)bb1[bo + (B_KC ? koff[kk] : kk * 4 * T)];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -973,14 +1022,21 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
         }
     }
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
+    // (k-contiguous operands: the pipelined form takes them when the right operand is double -- G64_LEAN_PIPE_KC -- and the rows are
+    //  16-byte addressable: even leading dimensions and aligned bases, checked above)
+    const bool lkc = G64_LEAN_PIPE && G64_LEAN_PIPE_KC && !g.lean_classic && g.N >= 4 && g.M >= 2;
     if (a_kc && b_kc) {
         if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, true>), grid, dim3(256), 0, st, a);
+        else if (lkc) hipLaunchKernelGGL((gemm64l_kernel<double, true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm64_kernel<double, true, true>), grid, dim3(256), 0, st, a);
     } else if (a_kc) {
-        if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, false>), grid, dim3(256), 0, st, a);
+        if (lkc && bf) hipLaunchKernelGGL((gemm64l_kernel<float, true, false>), grid, dim3(256), 0, st, a);
+        else if (lkc) hipLaunchKernelGGL((gemm64l_kernel<double, true, false>), grid, dim3(256), 0, st, a);
+        else if (bf) hipLaunchKernelGGL((gemm64_kernel<float, true, false>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm64_kernel<double, true, false>), grid, dim3(256), 0, st, a);
     } else if (b_kc) {
         if (bf) hipLaunchKernelGGL((gemm64_kernel<float, false, true>), grid, dim3(256), 0, st, a);
+        else if (lkc) hipLaunchKernelGGL((gemm64l_kernel<double, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm64_kernel<double, false, true>), grid, dim3(256), 0, st, a);
     }
 #if G64_LEAN_PIPE

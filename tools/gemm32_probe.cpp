@@ -38,6 +38,8 @@ int main(int argc, char** argv) {
         {"C4 dense  Kzx-bar [3000x3001]x[3001x24576] A k-contig", 0, 3000, 24576, 3001, 3004, 24576, 2.0 * 3000 * 3001 * 24576.0},
         {"C4 dense  transposed A copy   (A m-contig)           ", TA, 3000, 24576, 3001, 3000, 24576, 2.0 * 3000 * 3001 * 24576.0},
         {"C4 Gram   tril([A;mu]A^T) K=24576 (both k-contig)    ", TB | OL, 3001, 3000, 24576, 24576, 24576, 1.0 * 3001 * 3000 * 24576.0},
+        {"C4 Gram   from a transposed copy (both m-contig)     ", TA | OL, 3001, 3000, 24576, 3004, 3000, 1.0 * 3001 * 3000 * 24576.0},
+        {"C4 Gram   A k-contig, transposed copy as B (m-contig)", OL, 3001, 3000, 24576, 24576, 3000, 1.0 * 3001 * 3000 * 24576.0},
         {"C4/8 dense N=3072                                    ", 0, 3000, 3072, 3001, 3004, 3072, 2.0 * 3000 * 3001 * 3072.0},
         {"C4/8 Gram  K=3072                                    ", TB | OL, 3001, 3000, 3072, 3072, 3072, 1.0 * 3001 * 3000 * 3072.0},
         {"C3 dense  [3300x3301]x[3301x5632]                    ", 0, 3300, 5632, 3301, 3304, 5632, 2.0 * 3300 * 3301 * 5632.0},
