@@ -9,6 +9,16 @@
 // (the M' x M' x M' class, ~1.5 rounds over the resident workgroups) are dealt in chunks ordered by decreasing K range so
 // that every XCD gets the same mix of long and short tiles.
 // Measured at C4 (M' = 3000): forward solve 3.58 ms = 61.9 TF (0.79 of the fp64 MFMA peak; 4.09 ms on gemm.hip).
+//
+// Kernels of this file (round 5: the register-staged ones are the fallbacks of the software-pipelined LDS-DMA forms):
+//   gemm64_kernel<TB, A_KC, B_KC>   64 x 64 tiles, register-staged, one LDS buffer, two barriers per stage: what the pipelined form does not take
+//                                   (a K-contiguous FLOAT right operand, odd leading dimensions / unaligned bases, dsvgp_ctx::lean_classic)
+//   gemm64w_kernel<TB, TW>          64 x TW tiles, register-staged: row-range pieces with LDS padding (the flag-128 experiment)
+//   gemm64p_kernel<TB, TW>          64 x 192 (float B) / 64 x 128 (double B) tiles, LDS-DMA stages into two buffers, one barrier per stage:
+//                                   the [M', B'] class from 8192 tiles of 64 x 64 up -- the forward solve: 3.30 ms = 67.0 TF at C4 (0.85 of the
+//                                   data-sheet peak, 1.00 of the card's sustained rate)
+//   gemm64l_kernel<TB, A_KC, B_KC>  64 x 64 tiles, LDS-DMA stages, six / five workgroups per CU: the mid-size solves, [Q' | a], the Cholesky
+//                                   backward's products, the float64 model mode's Gram / dense products
 #include "common.h"
 
 namespace {
