@@ -469,6 +469,10 @@ def main():
                 sus = dsvgp_amd._ops.mfma_rate(dsvgp_amd._ops.Context.get(device), True, 40)
                 roof["sustained"] = dict(measured_mfma_only=sus, unit="TFLOP/s", frac_of_sustained=ach / sus,
                                          note="v_mfma_f64_16x16x4_f64 from registers on all CUs (dsvgp_mfma_rate)")
+                if not fp64:
+                    # the same for the fp32 shape of the step's other two large products (dense K_ZX-bar, Gram: gemm32.hip), for the reader of
+                    # profiles/*kernel_stats_c4.txt: their 125 / 108 TF are to be read against this figure, not against 157.3
+                    roof["sustained"]["fp32_mfma_only"] = dsvgp_amd._ops.mfma_rate(dsvgp_amd._ops.Context.get(device), False, 40)
 
         t_ciq, n_ciq = avg("ciq_stacked_backward")
         if cfg.get("ciq") and t_ciq:
