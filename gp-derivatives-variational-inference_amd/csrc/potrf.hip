@@ -1158,9 +1158,8 @@ __device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const dou
 #define POTRF_PIPE_FROM 0           // (A/B builds) first block column that may use the PIPE kernel, on top of the caller's pipe_from
 #endif
 #ifndef POTRF_PIPE_MINW
-#define POTRF_PIPE_MINW 2           // register budget of the PIPE kernel as for two waves per SIMD (256): the MFMAs then keep their accumulators in
-                                    // VGPRs, where the C loads land; with 512 the compiler picks AGPR accumulators and moves the loaded sets
-                                    // to them through scratch (waiting vmcnt(0) for every load).  LDS (101 KB) keeps it at one workgroup per CU.
+#define POTRF_PIPE_MINW 1           // the PIPE instantiation: 101 KB of LDS, one workgroup per CU whatever the registers (asking for 2 here to get a
+                                    // 256-register budget does not take: the compiler sees the LDS size and budgets for one wave per SIMD anyway)
 #endif
 #ifndef POTRF_PIPE
 #define POTRF_PIPE 1        // 1: launches from `pipe_from` on (launch_potrf_blocked) use the PIPE instantiation: software-pipelined strips (strip_pipe)
