@@ -55,6 +55,7 @@ struct GemmArgs {
     // takes so that another stream's launches keep finding room.  Only gemm64.hip's wide kernel honours these: launch_gemm
     // refuses (DSVGP_EINVAL) a product with tri_off / wide64 set that it cannot send there.
     int tri_off, wide64, lds_pad;
+    int small64;         // (set by launch_gemm) a few-tile fp64 product offered to gemm64.hip's four-buffer pipelined form
     int lean_classic;    // 1: gemm64.hip's lean class stays on the register-staged kernel (see dsvgp_ctx::lean_classic)
 };
 // how many split-K slices fit the slab (>= 2) or 1 (= do not split); esz = bytes per element

@@ -524,6 +524,12 @@ hipError_t zero_block(void* C, size_t esz, int64_t ld, int M, int N, hipStream_t
 #ifndef GEMM64_MIN_TILES
 #define GEMM64_MIN_TILES 1024      // (below: 128 x 128 tiles + split-K of this file)
 #endif
+#ifndef GEMM64_SMALL
+#define GEMM64_SMALL 1
+#endif
+#ifndef GEMM64_SMALL_MIN_TILES
+#define GEMM64_SMALL_MIN_TILES 200     // (from 200 tiles: the forward solve of a small problem, 240 tiles at C2, 48 -> 37 us; the 100-tile M'^3 products are FASTER on split-K here: C2 0.545 -> 0.574 ms with them on the pipelined form)
+#endif
 #ifndef GEMM64_MIN_K
 #define GEMM64_MIN_K 256
 #endif
@@ -534,6 +540,18 @@ int launch_gemm(hipStream_t st, int is_double, const GemmArgs& g) {
 #if GEMM64
     if (is_double && (g.C || g.C32) && (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) >= GEMM64_MIN_TILES && g.K >= GEMM64_MIN_K) {
         const int rc = launch_gemm64(st, g);
+        if (rc == 1) return 0;
+        if (rc > 1) return rc;
+    }
+#endif
+#if GEMM64 && GEMM64_SMALL
+    // small problems (M' of a few hundred): 64 .. 1023 tiles with a K chain of >= 256 -- the four-buffer pipelined kernel of gemm64.hip (the chain runs at
+    // the pace of its MFMAs) instead of split-K over fp64 atomics + a conversion pass here
+    if (is_double && (g.C || g.C32) && !g.slab && !g.tri_off && !g.wide64 && (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) >= GEMM64_SMALL_MIN_TILES &&
+        g.K >= GEMM64_MIN_K && g.K <= 2048) {
+        GemmArgs s_ = g;
+        s_.small64 = 1;
+        const int rc = launch_gemm64(st, s_);
         if (rc == 1) return 0;
         if (rc > 1) return rc;
     }

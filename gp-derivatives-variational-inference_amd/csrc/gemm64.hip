@@ -650,6 +650,9 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? 2 : 3) void gemm64p_kernel(c
 #ifndef G64_LEAN_PIPE
 #define G64_LEAN_PIPE 1
 #endif
+#ifndef G64_SMALL_PIPE
+#define G64_SMALL_PIPE 1            // 1: products with 64 .. 1023 tiles (small problems) on the four-buffer form of gemm64l_kernel instead of gemm.hip's split-K
+#endif
 #ifndef G64_LEAN_PIPE_KC
 #define G64_LEAN_PIPE_KC 1          // 1: k-contiguous operands too (double right operand; the float64 model mode's Gram / dense products)
 #endif
@@ -666,12 +669,19 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? 2 : 3) void gemm64p_kernel(c
 // (stored [M, K] / [N, K]); its stage image is [64 rows][16 k] doubles -- 128-byte rows of eight 16-byte chunks, chunk c of row R at position
 // c ^ ((R >> 1) & 7) (a 1 KB piece = 8 rows; the 16 rows of a read group then fall on 16 distinct slots of the 256-byte bank row) -- and a
 // stage advances along the rows (+ 16 doubles) instead of down the matrix.
-template <typename TB, bool A_KC = false, bool B_KC = false>
-__global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_kernel(const G64 g) {
+// NBUF = 4 (the FEW-tile products of small problems, M' of a few hundred: at most one workgroup per CU, nothing beside it to hide a stage's
+// latency): four stage buffers, the DMA of stage s + 3 is requested when stage s opens, so that a tile's chain of K / 16 dependent stages runs
+// at the pace of its MFMAs instead of at the pace of a global load -- what split-K over fp64 atomics bought these products before.  A fifth
+// buffer takes the dummy requests that keep the count of DMA instructions in flight constant at the end of the range (the counted wait,
+// vmcnt((NBUF - 2) x pieces), would otherwise fall through before the last stages have landed).
+template <typename TB, bool A_KC = false, bool B_KC = false, int NBUF = 2>
+__global__ __launch_bounds__(256, NBUF > 2 ? 1 : (sizeof(TB) == 4 ? G64_MINW : 5)) void gemm64l_kernel(const G64 g) {
     constexpr bool BF = sizeof(TB) == 4;
     static_assert(!B_KC || !BF, "a k-contiguous float operand stays on gemm64_kernel (its 64-byte rows read 2-way conflicted)");
+    static_assert(NBUF == 2 || NBUF == 4, "two stage buffers, or four + a dummy");
+    constexpr int NBT = NBUF > 2 ? NBUF + 1 : NBUF;                 // buffers in LDS (the last one: dummy target)
     constexpr int A_STAGE = BK * T * 8, B_STAGE = BK * T * (int)sizeof(TB);          // 8 KB + 4 / 8 KB
-    constexpr int SLOW_BYTES = 2 * BK * LDS_STRIDE * 8, FAST_BYTES = 2 * (A_STAGE + B_STAGE);
+    constexpr int SLOW_BYTES = 2 * BK * LDS_STRIDE * 8, FAST_BYTES = NBT * (A_STAGE + B_STAGE);
     __shared__ __attribute__((aligned(16))) unsigned char lds[FAST_BYTES > SLOW_BYTES ? FAST_BYTES : SLOW_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int fl = g.flags;
@@ -853,12 +863,24 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
         }
         const int64_t astage = A_KC ? (int64_t)BK : (int64_t)BK * g.lda, bstage = B_KC ? (int64_t)BK : (int64_t)BK * g.ldb;
         auto dma = [&](int buf) {
-            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + 2 * A_STAGE + buf * B_STAGE + wave_u * (BF ? 1024 : 2048);
+            const unsigned da = lds0 + buf * A_STAGE + wave_u * 2048, db = lds0 + NBT * A_STAGE + buf * B_STAGE + wave_u * (BF ? 1024 : 2048);
             g64_dma16(asrc, da);
             g64_dma16(asrc2, da + 1024);
             g64_dma16(bsrc, db);
             if constexpr (!BF) { g64_dma16(bsrc2, db + 1024); bsrc2 += bstage; }
             asrc += astage; asrc2 += astage; bsrc += bstage;
+        };
+        // (NBUF > 2) the first stage's sources: what a dummy request re-reads, into the dummy buffer
+        const double* const asrc_0 = asrc;
+        const double* const asrc2_0 = asrc2;
+        const TB* const bsrc_0 = bsrc;
+        const TB* const bsrc2_0 = bsrc2;
+        auto dma_dummy = [&]() {
+            const unsigned da = lds0 + (NBT - 1) * A_STAGE + wave_u * 2048, db = lds0 + NBT * A_STAGE + (NBT - 1) * B_STAGE + wave_u * (BF ? 1024 : 2048);
+            g64_dma16(asrc_0, da);
+            g64_dma16(asrc2_0, da + 1024);
+            g64_dma16(bsrc_0, db);
+            if constexpr (!BF) g64_dma16(bsrc2_0, db + 1024);
         };
         const int odd = gq & 1;
         // fragment addresses (elements into a stage image): mn-contiguous -- row 4 kk + gq at + kk * 4 * T; k-contiguous -- row m of 16 doubles,
@@ -868,15 +890,22 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
         for (int kk = 0; kk < 4; ++kk) koff[kk] = 2 * ((2 * kk + (gq >> 1)) ^ ((ml >> 1) & 7)) + (gq & 1);
         const double* ab0 = A_KC ? (const double*)lds + (wr * 32 + ml) * BK : (const double*)lds + gq * T + wr * 32 + 16 * odd + ml;
         const double* ab1 = A_KC ? (const double*)lds + (wr * 32 + 16 + ml) * BK : (const double*)lds + gq * T + wr * 32 + 16 - 16 * odd + ml;
-        const TB* bb0 = B_KC ? (const TB*)(lds + 2 * A_STAGE) + (wc * 32 + ml) * BK : (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
-        const TB* bb1 = B_KC ? (const TB*)(lds + 2 * A_STAGE) + (wc * 32 + 16 + ml) * BK : (const TB*)(lds + 2 * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
-        dma(0);
+        const TB* bb0 = B_KC ? (const TB*)(lds + NBT * A_STAGE) + (wc * 32 + ml) * BK : (const TB*)(lds + NBT * A_STAGE) + gq * T + wc * 32 + 16 * odd + ml;
+        const TB* bb1 = B_KC ? (const TB*)(lds + NBT * A_STAGE) + (wc * 32 + 16 + ml) * BK : (const TB*)(lds + NBT * A_STAGE) + gq * T + wc * 32 + 16 - 16 * odd + ml;
         const int nst = (f1 - f0) / BK;
+        constexpr int DEPTH = NBUF - 1, NI = BF ? 3 : 4;     // stages in flight; DMA instructions per stage and wave
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) {
+            if (q < nst) dma(q);
+            else dma_dummy();
+        }
         for (int st = 0; st < nst; ++st) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of stage st have landed (asm: see gemm64p_kernel)
+            // this wave's pieces of stage st have landed: all but the (DEPTH - 1) younger stages' instructions (asm: see gemm64p_kernel)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1) * NI) : "memory");
             __syncthreads();
-            if (st + 1 < nst) dma((st + 1) & 1);
-            const int ao = (st & 1) * (A_STAGE / 8), bo = (st & 1) * (B_STAGE / (int)sizeof(TB));
+            if (st + DEPTH < nst) dma((st + DEPTH) % NBUF);      // (the buffer of stage st - 1: everybody has left it)
+            else if (NBUF > 2) dma_dummy();
+            const int ao = (st % NBUF) * (A_STAGE / 8), bo = (st % NBUF) * (B_STAGE / (int)sizeof(TB));
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double a[2], b[2];
@@ -891,6 +920,7 @@ __global__ __launch_bounds__(256, sizeof(TB) == 4 ? G64_MINW : 5) void gemm64l_k
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+        if (NBUF > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (dummy requests still in flight)
         __syncthreads();                                    // the DMA images are dead
     }
     if (f1 < khi) masked_range(max(f1, klo), khi);
@@ -976,6 +1006,7 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     if (a_kc || b_kc) return 0;
 #endif
     if (g.batch != 1 || g.splitk != 1 || g.Cin || g.kscale || (fl & DSVGP_GEMM_KEEP_UPPER)) return 0;
+    if (g.small64 && (a_kc || b_kc || g.N < 4 || g.M < 2 || g.slab)) return 0;            // (the few-tile form: mn-contiguous operands only, not in deterministic mode)
     const bool bf = fl & DSVGP_GEMM_B_IS_FLOAT;
     // 16-byte vector loads: even leading dimensions (multiples of 4 for a float B) and aligned bases
     if (g.lda % 2 || ((uintptr_t)g.A % 16) || (bf ? (g.ldb % 4 || (uintptr_t)g.B % 16) : (g.ldb % 2 || (uintptr_t)g.B % 16))) return 0;
@@ -1016,7 +1047,7 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
     if (g.tri_off || g.wide64) return DSVGP_EINVAL;                 // (only the wide kernel takes row-range pieces)
     // split-K for the few-tile products with a long K: every tile is resident at once, so the launch lasts as long as its
     // longest tile's chain of K / 16 dependent stages; chunks of G64_KCHUNK accumulate with fp64 atomics onto a zeroed output
-    a.kchunk = (G64_KCHUNK > 0 && a.balanced && g.K >= 2 * G64_KCHUNK && g.C) ? G64_KCHUNK : 0;
+    a.kchunk = (G64_KCHUNK > 0 && a.balanced && g.K >= 2 * G64_KCHUNK && g.C && !g.small64) ? G64_KCHUNK : 0;
     int ysplit = 1;
     a.slab = nullptr;
     if (a.kchunk) {
@@ -1032,6 +1063,14 @@ int launch_gemm64(hipStream_t st, const GemmArgs& g) {
         }
     }
     const dim3 grid(a.balanced ? 8 * G64_CHUNK * cdiv(a.tiles_m * cdiv(a.tiles_n, G64_CHUNK), 8) : cdiv(total, 8) * 8, ysplit);
+#if G64_SMALL_PIPE
+    if (g.small64) {          // (few tiles: the four-buffer form; the caller -- launch_gemm -- has checked the layouts it takes)
+        if (bf) hipLaunchKernelGGL((gemm64l_kernel<float, false, false, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm64l_kernel<double, false, false, 4>), grid, dim3(256), 0, st, a);
+        hipError_t es = hipGetLastError();
+        return es == hipSuccess ? 1 : 1000 + (int)es;
+    }
+#endif
     // (k-contiguous operands: the pipelined form takes them when the right operand is double -- G64_LEAN_PIPE_KC -- and the rows are
     //  16-byte addressable: even leading dimensions and aligned bases, checked above)
     const bool lkc = G64_LEAN_PIPE && G64_LEAN_PIPE_KC && !g.lean_classic && g.N >= 4 && g.M >= 2;
