@@ -573,6 +573,9 @@ __device__ __forceinline__ void factor16_wave(double (*F)[LDT], int o, double (*
 
 // 16 x 16 x 16 product on one wave:  P[m][n] = sum_q Aop(m, q) Bop(q, n);  operands through pointers + strides
 //   Aop(m, q) = Ab[m * lda_ + q];   Bop(q, n) = B_NK ? Bb[n * ldb_ + q] : Bb[q * ldb_ + n]
+#ifndef POTRF_CRIT_PFORM
+#define POTRF_CRIT_PFORM 1     // 1: the critical tile's rank-64 update through P = A_ik X_k^T (40 + 16 MFMAs on wave 0's path instead of 64 + 16)
+#endif
 #ifndef POTRF_PROD16_SPLIT
 #define POTRF_PROD16_SPLIT 1
 #endif
@@ -1085,6 +1088,8 @@ __device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const dou
     __syncthreads();
     CHOL_STAMP(1);
     // U = W A_w^T: A operand W[16 cb + m][k] (lane (m, k)), B operand A_w[n][k] (lane (n, k)); four independent accumulators
+    // (POTRF_CRIT_PFORM: S[1] holds X_k instead -- A_ik W_k A_ik^T = (A_ik X_k^T)(A_ik X_k^T)^T -- and U = X A_w^T = P_w^T: X_k is lower
+    //  triangular, so column block cb of P needs the k blocks 0 .. cb only: 40 MFMAs instead of 64)
     acc4 U[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) U[cb] = acc4{0, 0, 0, 0};
@@ -1093,10 +1098,22 @@ __device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const dou
         const int kq = 4 * ks + g;
         const double bop = S[0][16 * wave + i][kq];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) U[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1][16 * cb + i][kq], bop, U[cb], 0, 0, 0);
+        for (int cb = 0; cb < 4; ++cb) {
+            if (POTRF_CRIT_PFORM && cb < (ks >> 2)) continue;
+            U[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1][16 * cb + i][kq], bop, U[cb], 0, 0, 0);
+        }
     }
     CHOL_STAMP(4);
     __syncthreads();                 // W is dead: S[1] becomes F
+#if POTRF_CRIT_PFORM
+    // P replaces A in S[0] (every wave is done with A): strip w's rows from this wave's accumulators (register q of lane (i, g) = P[16 w + i][16 cb + 4 q + g]);
+    // the second products below then read P_nb where they read A_nb
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[0][16 * wave + i][16 * cb + 4 * q + g] = U[cb][q];
+    __syncthreads();
+#endif
     CHOL_STAMP(5);
     // D[w][nb] = C[w][nb] - T_w A_nb^T, T_w from the registers of U; the leading block (wave 0) on two accumulators (one
     // dependent chain of 16 fp64 MFMAs would wait out every instruction's latency)
@@ -1200,10 +1217,10 @@ __global__ __launch_bounds__(64 * NW, PIPE ? POTRF_PIPE_MINW : POTRF_MINW) void 
         CHOL_STAMP(0);
         acc4 a0;
 #ifdef POTRF_DEBUG
-        crit_tile_update(S, A, lda, n, k, Wws + (size_t)k * 4096, tid, a0, st_);
+        crit_tile_update(S, A, lda, n, k, (POTRF_CRIT_PFORM ? Xws : Wws) + (size_t)k * 4096, tid, a0, st_);
         st_[6] = st_[5];
 #else
-        crit_tile_update(S, A, lda, n, k, Wws + (size_t)k * 4096, tid, a0);
+        crit_tile_update(S, A, lda, n, k, (POTRF_CRIT_PFORM ? Xws : Wws) + (size_t)k * 4096, tid, a0);
 #endif
         CHOL_STAMP(2);
         TR(1);
