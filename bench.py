@@ -225,6 +225,10 @@ def main():
         eng.pack_reduce = not args.no_pack_reduce
         if loop.dp is not None:
             loop.dp.algo = args.dp_algo
+            # replica check on by default under the bench (every 64 steps; DSVGP_DP_CHECK=N / 0 overrides): the replicas' L_S, m and Adam
+            # moments are never re-broadcast, so the first run on real multi-GPU hardware reports whether they stayed bitwise equal
+            if os.environ.get("DSVGP_DP_CHECK") is None:
+                loop.dp.check_every = 64
         perm = loop.epoch_permutation()
         nbatches = N // B
         return loop, eng, (lambda k: perm[(k % nbatches) * B:(k % nbatches + 1) * B])
@@ -284,7 +288,26 @@ def main():
     for k in range(args.warmup):
         loop.step(batch(k))
     events_on(eng, args.event_every)
+    if (world > 1 or args.emulate_world > 1) and hasattr(eng, "dp_host_trace"):
+        eng.dp_host_trace = []           # host time stamps of the five C calls + collectives of every rank step in the window
     elapsed, loss = window(loop, batch, args.warmup, args.steps)
+    dp_trace, replica_check = None, None
+    if getattr(eng, "dp_host_trace", None):
+        tr_ = eng.dp_host_trace
+        names_ = ("phase0_front_gram", "issue_allreduce_G", "phase1_q_columns", "issue_allgather_q", "wait_allreduce_G", "phase2_variational_lbar_rows",
+                  "issue_allgather_lbar", "wait_allgather_q", "phase3_dense_kernel_bwd", "wait_allgather_lbar", "phase4_chol_backward_tail")
+        n_ = len(tr_)
+        dp_trace = dict(steps=n_, unit="us of host time per rank step (rank 0), mean over the timed window",
+                        total=1e6 * sum(t_[-1] - t_[0] for t_ in tr_) / n_,
+                        **{nm_: 1e6 * sum(t_[i_ + 1] - t_[i_] for t_ in tr_) / n_ for i_, nm_ in enumerate(names_)})
+    if hasattr(eng, "dp_host_trace"):
+        eng.dp_host_trace = None
+    if loop.dp is not None:
+        if loop.dp.check_every > 0:
+            loop._check_replicas(loop.dp, force=True)       # one more check at the end of the window, whatever the step count
+        replica_check = dict(every=loop.dp.check_every, checks=loop.dp.checks, divergences=loop.dp.divergences,
+                             note="bitwise checksum of every parameter across the ranks after the Adam step (parallel.DataParallel.check_replicas); "
+                                  "a divergence re-broadcasts rank 0's parameters and Adam moments")
     if hasattr(eng, "record_every"):
         eng.record_every = 1             # (the untimed passes below: every step)
     if loop._graphs:
@@ -299,7 +322,7 @@ def main():
         torch.cuda.synchronize()
     # the kernel assembly forward alone on the GPU (it shares the CUs with the Cholesky chain in the step when M' >= 2048):
     # three more untimed steps with the side stream off, HIP events around the same launch
-    EVENT_NAMES = ("solve_fwd", "assemble_fwd", "assemble_bwd", "early_reduce_wait", "final_reduce", "ciq_stacked_backward")
+    EVENT_NAMES = ("solve_fwd", "assemble_fwd", "assemble_bwd", "gram", "dense", "early_reduce_wait", "final_reduce", "ciq_stacked_backward")
     durations = event_durations(eng, EVENT_NAMES)
     iso_fwd = None
     if not cfg.get("ciq") and world == 1 and not args.fp64:
@@ -473,6 +496,43 @@ def main():
                     # the same for the fp32 shape of the step's other two large products (dense K_ZX-bar, Gram: gemm32.hip), for the reader of
                     # profiles/*kernel_stats_c4.txt: their 125 / 108 TF are to be read against this figure, not against 157.3
                     roof["sustained"]["fp32_mfma_only"] = dsvgp_amd._ops.mfma_rate(dsvgp_amd._ops.Context.get(device), False, 40)
+                    # ... and the probe in the hardware guide's own form (ONE wave per SIMD; MI355X_MICROARCH.md: 155 TF fp32), with the rate of
+                    # its first ~2 ms launch from a cooler card and the in-kernel clock of its last launch: the gap between the data-sheet
+                    # peak (2.4 GHz) and what a 40 ms run holds is the clock, not the instruction stream
+                    try:
+                        ctx_ = dsvgp_amd._ops.Context.get(device)
+                        probes = {}
+                        for nm_, dbl_, one_ in (("fp32_one_wave_per_simd", False, True), ("fp32_four_waves_per_simd", False, False),
+                                                ("fp64_one_wave_per_simd", True, True), ("fp64_four_waves_per_simd", True, False)):
+                            r_, b_, c_ = dsvgp_amd._ops.mfma_rate2(ctx_, dbl_, one_, 40)
+                            peak_ = PEAK_F64_MFMA_TFLOPS if dbl_ else 157.3
+                            probes[nm_] = dict(sustained_tflops=r_, first_launch_tflops=b_, clock_ghz_last_launch=c_,
+                                               tflops_at_2p4_ghz=(r_ * 2.4 / c_) if c_ > 0 else None,
+                                               frac_of_peak_at_that_clock=(r_ / (peak_ * c_ / 2.4)) if c_ > 0 else None)
+                        roof["sustained"]["probes"] = probes
+                    except Exception as ex:            # (an extra must never take the headline line down)
+                        roof["sustained"]["probes"] = dict(error="%s: %s" % (type(ex).__name__, ex))
+
+        # the step's two fp32 [M', B'] products, HIP events of the one-call step (csrc/step.hip, dsvgp_elbo_step_timings5): the dense product
+        # K_ZX-bar = [Q' | a][A ; mu_bar^T] (2 M' (M'+1) B' flop) and the Gram product [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T) (its lower
+        # triangle: (M'+1) M' B' flop), both on v_mfma_f32_32x32x2_f32 (gemm32.hip); peak 157.3 TF (MI355X_MICROARCH.md)
+        roof_dense = roof_gram = None
+        t_dense, n_dense = avg("dense")
+        t_gram, n_gram = avg("gram")
+        if t_dense and not fp64:
+            fl = 2.0 * Mp * (Mp + 1) * Bp_local
+            roof_dense = dict(bound="mfma", kernel="gemm32_dma_kernel<32,true,false,32> (dense K_ZX-bar = [Q' | a][A ; mu_bar^T], fp32 MFMA, LDS-DMA stages)",
+                              achieved=fl / t_dense / 1e12, peak=157.3, unit="TFLOP/s", frac=fl / t_dense / 1e12 / 157.3, launches=n_dense,
+                              avg_ms=t_dense * 1e3, flops_per_launch=fl,
+                              note="HIP events around the launch on its stream; includes the launch's own clear of nothing (no split-K)")
+        if t_gram and not fp64:
+            fl = float(Mp + 1) * Mp * Bp_local
+            roof_gram = dict(bound="mfma", kernel="gemm32_dma_kernel<32,true,true,32> (Gram [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), fp32 MFMA, split-K, fp32 atomics)",
+                             achieved=fl / t_gram / 1e12, peak=157.3, unit="TFLOP/s", frac=fl / t_gram / 1e12 / 157.3, launches=n_gram,
+                             avg_ms=t_gram * 1e3, flops_per_launch=fl,
+                             note="lower-triangle flops only; the event pair also spans the clear of the split-K target when the launcher makes one")
+        if roof is not None:
+            roof["dense"], roof["gram"] = roof_dense, roof_gram
 
         t_ciq, n_ciq = avg("ciq_stacked_backward")
         if cfg.get("ciq") and t_ciq:
@@ -524,6 +584,8 @@ def main():
                    one_call_step=bool(getattr(eng_o, "c_step_used", False)),
                    roofline_kernel=(roof_o or {}).get("kernel"), roofline_frac=(roof_o or {}).get("frac"),
                    roofline_avg_ms=(roof_o or {}).get("avg_ms"),
+                   dense_frac=((roof_o or {}).get("dense") or {}).get("frac"), dense_avg_ms=((roof_o or {}).get("dense") or {}).get("avg_ms"),
+                   gram_frac=((roof_o or {}).get("gram") or {}).get("frac"), gram_avg_ms=((roof_o or {}).get("gram") or {}).get("avg_ms"),
                    assembly_fwd_frac=((asm_o or {}).get("forward") or {}).get("frac"),
                    assembly_bwd_frac=((asm_o or {}).get("backward") or {}).get("frac"))
         del loop_o, eng_o, batch_o
@@ -662,8 +724,19 @@ def main():
                        "split_bf16_second_figure": split_fig,
                        "other_configs": other},
             "roofline": roof,
+            "roofline_dense": (roof or {}).get("dense"),
+            "roofline_gram": (roof or {}).get("gram"),
             "roofline_assembly": roof_asm,
         }
+        if roof:
+            # which launch of the step is the largest (the `roofline` entry keeps the forward solve, the kernel north_star names)
+            cands = [("forward solve (roofline)", roof.get("avg_ms")), ("dense K_ZX-bar product (roofline_dense)", (roof.get("dense") or {}).get("avg_ms")),
+                     ("Gram product (roofline_gram)", (roof.get("gram") or {}).get("avg_ms"))]
+            cands = [c for c in cands if c[1]]
+            if cands:
+                out["config"]["largest_launch"] = dict(name=max(cands, key=lambda c: c[1])[0], avg_ms={n_: t_ for n_, t_ in cands})
+            roof.pop("dense", None)
+            roof.pop("gram", None)
         if world > 1:
             out["rccl_ranks"] = dist.get_world_size()
             def avg_ms(name):
@@ -676,7 +749,10 @@ def main():
                                                final_reduce_ms=t_r * 1e3 if t_r else None,
                                                note="rank 0, HIP events on the main stream: the time the step stalls for the "
                                                     "[tril(G) | b] sum and the time of the closing gradient all-reduce",
-                                               probe=coll_probe)
+                                               probe=coll_probe if coll_probe is not None else ("skipped: gloo rehearsal on one card" if rehearse else None),
+                                               replica_check=replica_check, host_us_per_rank_step=dp_trace)
+        elif dp_trace is not None:
+            out["config"]["host_us_per_rank_step"] = dp_trace
         if cfg.get("ciq"):
             out["config"]["ciq"] = ciq_stats
         if world == 1 and not args.no_cpu_baseline and not cfg.get("ciq"):

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dsvgp_elbo_step_dp_f32": (_i, [_p, _p, _p, _p, _p, _z, _i, _i]),
     "dsvgp_elbo_step_status": (_i, [_p, _p, _p]),
     "dsvgp_elbo_step_timings": (_i, [_p, _i, _p]),
+    "dsvgp_elbo_step_timings5": (_i, [_p, _i, _p]),
     "dsvgp_elbo_step_timed_count": (C.c_long, [_p]),
     "dsvgp_elbo_step_locate": (_i, [_p, _i, _p, _p, _p, _p]),
     "dsvgp_version": (C.c_char_p, []),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "dsvgp_ciq_lanczos": (_i, [_p, _p, _l, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_solve": (_i, [_p, _p, _l, _p, _l, _i, _i, _p, _p, _i, _f, _i, _i, _p, _i, _p, _p, _p, _l, _p, _p]),
     "dsvgp_mfma_rate": (_i, [_p, _i, _i, _p, _p]),
+    "dsvgp_mfma_rate2": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "dsvgp_ciq_mix": (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _l]),
     "dsvgp_ciq_cross": (_i, [_p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _p, _p, _p]),
     "dsvgp_ciq_rowstats": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),

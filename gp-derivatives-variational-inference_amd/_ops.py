@@ -100,7 +100,7 @@ class StepPlan:
         self.io = _lib.ElboStepIO()
         self._hyp = (C.c_float * 4)()
         self._info = C.c_int(0)
-        self._ms = (C.c_float * 3)()
+        self._ms = (C.c_float * 5)()
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -138,8 +138,8 @@ class StepPlan:
         return int(lib.dsvgp_elbo_step_timed_count(self.h))
 
     def timings(self, back=0):
-        """[solve_fwd, assemble_fwd, assemble_bwd] HIP-event durations (ms) of the timed step ``back`` steps before the last"""
-        check(lib.dsvgp_elbo_step_timings(self.h, int(back), self._ms), "dsvgp_elbo_step_timings")
+        """[solve_fwd, assemble_fwd, assemble_bwd, gram, dense] HIP-event durations (ms) of the timed step ``back`` steps before the last"""
+        check(lib.dsvgp_elbo_step_timings5(self.h, int(back), self._ms), "dsvgp_elbo_step_timings5")
         return [float(v) for v in self._ms]
 
 
@@ -825,3 +825,13 @@ def mfma_rate(ctx, is_double=True, millis=40):
     out = C.c_double(0.0)
     check(lib.dsvgp_mfma_rate(ctx.h, 1 if is_double else 0, int(millis), _ptr(scratch), C.byref(out)), "dsvgp_mfma_rate")
     return out.value
+
+
+def mfma_rate2(ctx, is_double=True, one_wave_per_simd=False, millis=40):
+    """(sustained TFLOP/s, TFLOP/s of the first ~2 ms launch, in-kernel clock in GHz of the last launch) of the same probe with four
+    waves per SIMD or one (the form the hardware guide's 155 TF fp32 figure was measured in)."""
+    scratch = torch.empty(2 << 20, dtype=torch.uint8, device=ctx.device)
+    out, burst, clk = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    check(lib.dsvgp_mfma_rate2(ctx.h, (1 if is_double else 0) | (2 if one_wave_per_simd else 0), int(millis), _ptr(scratch),
+                               C.byref(out), C.byref(burst), C.byref(clk)), "dsvgp_mfma_rate2")
+    return out.value, burst.value, clk.value

@@ -16,6 +16,7 @@ repeated (A_t == A); everything else keeps the reference's arithmetic precision:
 Cholesky / triangular solves.
 """
 import os
+import time
 
 import torch
 
@@ -111,6 +112,7 @@ class ElboEngine:
         # flag 128 of the one-call step: the forward solve A = L^-1 K_ZX in row ranges, the first two on the side stream under the
         # Cholesky chain's later launches (csrc/step.hip, step_front); same arithmetic per output element
         self.solve_pipe = os.environ.get("DSVGP_SOLVE_PIPE", "0") == "1"
+        self.dp_host_trace = None           # list: host time stamps of every data-parallel rank step's phases (_c_step_dp_phases)
         self._side_done = None
         # K_ZX assembly + S = L_S L_S^T on a second stream under the Cholesky chain.  None = automatic: only from M' = 2048 up
         # (at M' = 600 the fork / join costs more than the overlap returns: 0.88 vs 0.76 ms per step; +0.05 ms gain at M' = 3000)
@@ -314,7 +316,7 @@ class ElboEngine:
         """durations (seconds) recorded for ``name`` (solve_fwd / assemble_fwd / assemble_bwd / ...) since ``events`` /
         ``c_step_timed`` were last cleared: torch events of the piecewise path and the plan's HIP events of the one-call path"""
         out = [s.elapsed_time(e) * 1e-3 for (nm, s, e) in self.events if nm == name]
-        slot = {"solve_fwd": 0, "assemble_fwd": 1, "assemble_bwd": 2}.get(name)
+        slot = {"solve_fwd": 0, "assemble_fwd": 1, "assemble_bwd": 2, "gram": 3, "dense": 4}.get(name)
         if slot is not None and self.c_step_timed:
             for plan, idx in reversed(self.c_step_timed):      # (absolute index of the timed step in its plan's ring)
                 b = plan.timed_count() - 1 - idx
@@ -1178,19 +1180,26 @@ class ElboEngine:
         dp.q_local, dp.q_all = bufs["q_local"].data_ptr(), bufs["q_all"].data_ptr()
         dp.lbar_local, dp.lbar_all = bufs["lbar_local"].data_ptr(), bufs["lbar_all"].data_ptr()
         self.early_wire_numel = total
-        plan.run_dp(ctx, ws, flags, 0)
-        h_g = coll.all_reduce_async(bufs["wire"])
-        plan.run_dp(ctx, ws, flags, 1)
-        h_q = coll.all_gather_async(bufs["q_all"], bufs["q_local"])
+        # dp_host_trace (bench.py --gpus N / tools/host_trace.py; None in production): host time stamps around the five C calls and
+        # the collectives issued / waited for between them -- what the HOST spends per data-parallel rank step, phase by phase
+        tr = self.dp_host_trace
+        now = time.perf_counter if tr is not None else (lambda: 0.0)
+        t = [now()]
+        plan.run_dp(ctx, ws, flags, 0); t.append(now())
+        h_g = coll.all_reduce_async(bufs["wire"]); t.append(now())
+        plan.run_dp(ctx, ws, flags, 1); t.append(now())
+        h_q = coll.all_gather_async(bufs["q_all"], bufs["q_local"]); t.append(now())
         ev_w = self._event_pair()                        # (bench.py: how long the main stream stalls for [G ; b^T])
         h_g.wait()
-        self._event_done("early_reduce_wait", ev_w)
-        plan.run_dp(ctx, ws, flags, 2)
-        h_l = coll.all_gather_async(bufs["lbar_all"], bufs["lbar_local"])
-        h_q.wait()
-        plan.run_dp(ctx, ws, flags, 3)
-        h_l.wait()
-        plan.run_dp(ctx, ws, flags, 4)
+        self._event_done("early_reduce_wait", ev_w); t.append(now())
+        plan.run_dp(ctx, ws, flags, 2); t.append(now())
+        h_l = coll.all_gather_async(bufs["lbar_all"], bufs["lbar_local"]); t.append(now())
+        h_q.wait(); t.append(now())
+        plan.run_dp(ctx, ws, flags, 3); t.append(now())
+        h_l.wait(); t.append(now())
+        plan.run_dp(ctx, ws, flags, 4); t.append(now())
+        if tr is not None:
+            tr.append(t)
         self._global_gram = True
         self.sharded_stage_used = True
         self.variational_grads_global = True

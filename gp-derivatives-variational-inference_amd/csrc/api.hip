@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void mfma_rate_f64_kernel(double* out, int ite
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = d4v{0, 0, 0, 0};
     const double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -245,7 +246,12 @@ __global__ __launch_bounds__(256) void mfma_rate_f64_kernel(double* out, int ite
     double s = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    // thread 0 of a workgroup: shader cycles and 100 MHz ticks spent in the loop (the in-kernel clock = their ratio x 100 MHz), in the slots
+    // of threads 1 / 2, which write nothing
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double* o = out + (size_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) { o[0] = s; o[1] = (double)(c1 - c0); o[2] = (double)(r1 - r0); }
+    else if (threadIdx.x > 2) o[threadIdx.x] = s;
 }
 
 __global__ __launch_bounds__(256) void mfma_rate_f32_kernel(float* out, int iters) {
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(256) void mfma_rate_f32_kernel(float* out, int iter
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
     const float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -266,16 +273,24 @@ __global__ __launch_bounds__(256) void mfma_rate_f32_kernel(float* out, int iter
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += acc[i][k];
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float* o = out + (size_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) { o[0] = s; o[1] = (float)(c1 - c0); o[2] = (float)(r1 - r0); }
+    else if (threadIdx.x > 2) o[threadIdx.x] = s;
 }
 }  // namespace
 
-// is_double: 1 = v_mfma_f64_16x16x4_f64, 0 = v_mfma_f32_32x32x2_f32.  Runs ~`millis` ms of launches on the context's stream
-// (synchronises it) and returns the rate of the second half in *tflops.  scratch: 256 * 1024 * 8 bytes.
-extern "C" int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* scratch, double* tflops) {
-    if (!ctx || !scratch || !tflops || millis < 2 || millis > 2000) return DSVGP_EINVAL;
+// mode bit 0: 1 = v_mfma_f64_16x16x4_f64, 0 = v_mfma_f32_32x32x2_f32; bit 1: ONE wave per SIMD (one 256-thread workgroup per CU: the form the
+// hardware guide's 155 TF fp32 figure was measured in) instead of four.  Runs ~`millis` ms of launches on the context's stream (synchronises
+// it) and returns the rate of the second half in *tflops; burst_tflops (may be null): the rate of the very FIRST launch (~2 ms from an idle
+// card, before the power management has lowered the clock); clock_ghz (may be null): the in-kernel clock of the last launch, median over
+// workgroups of delta s_memtime / delta s_memrealtime x 100 MHz.  scratch: 256 * 1024 * 8 bytes.
+static int mfma_rate_impl(dsvgp_ctx* ctx, int mode, int millis, void* scratch, double* tflops, double* burst_tflops, double* clock_ghz) {
+    if (!ctx || !scratch || !tflops || millis < 2 || millis > 2000 || mode < 0 || mode > 3) return DSVGP_EINVAL;
+    const bool is_double = mode & 1;
     hipStream_t st = ctx->stream;
-    const int grid = 256 * 4, iters = 2000;                      // 4 workgroups (16 waves) per CU; ~1.7 ms (f64) per launch
+    const int per_cu = (mode & 2) ? 1 : 4;
+    const int grid = 256 * per_cu, iters = 2000 * (4 / per_cu);  // 4 workgroups (16 waves) or 1 (4 waves) per CU; ~1.7 ms (f64) per launch
     const double flop_per_launch = is_double ? (double)grid * 4 * iters * 32 * 2048.0 : (double)grid * 4 * iters * 32 * 4096.0;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1000 + (int)hipGetLastError();
@@ -288,6 +303,7 @@ extern "C" int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* 
     if (hipEventSynchronize(e1) != hipSuccess) return 1000 + (int)hipGetLastError();
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
+    if (burst_tflops) *burst_tflops = flop_per_launch / ((ms > 1e-3f ? ms : 1e-3f) * 1e-3) / 1e12;
     int n = (int)(0.5 * millis / (ms > 1e-3f ? ms : 1e-3f));
     n = n < 1 ? 1 : (n > 2000 ? 2000 : n);
     for (int i = 0; i < n; ++i) launch();
@@ -300,5 +316,34 @@ extern "C" int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (e != hipSuccess) return 1000 + (int)e;
     *tflops = flop_per_launch * n / (ms * 1e-3) / 1e12;
+    if (clock_ghz) {
+        // (grid <= 1024 workgroups: the stamps of all of them; median of the ratios)
+        double ratio[1024];
+        const size_t esz = is_double ? 8 : 4;
+        char* host = (char*)malloc((size_t)grid * 256 * esz);
+        if (!host) return DSVGP_EINVAL;
+        e = hipMemcpy(host, scratch, (size_t)grid * 256 * esz, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(host); return 1000 + (int)e; }
+        for (int b = 0; b < grid; ++b) {
+            const double cyc = is_double ? ((double*)host)[(size_t)b * 256 + 1] : (double)((float*)host)[(size_t)b * 256 + 1];
+            const double tck = is_double ? ((double*)host)[(size_t)b * 256 + 2] : (double)((float*)host)[(size_t)b * 256 + 2];
+            ratio[b] = tck > 0 ? cyc / tck : 0.0;
+        }
+        free(host);
+        for (int i = 1; i < grid; ++i) {                         // (insertion sort: 1024 values, once per probe)
+            const double v = ratio[i];
+            int j = i - 1;
+            while (j >= 0 && ratio[j] > v) { ratio[j + 1] = ratio[j]; --j; }
+            ratio[j + 1] = v;
+        }
+        *clock_ghz = ratio[grid / 2] * 0.1;                      // cycles per 10 ns tick -> GHz
+    }
     return 0;
+}
+extern "C" int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* scratch, double* tflops) {
+    if (is_double != 0 && is_double != 1) return DSVGP_EINVAL;
+    return mfma_rate_impl(ctx, is_double, millis, scratch, tflops, nullptr, nullptr);
+}
+extern "C" int dsvgp_mfma_rate2(dsvgp_ctx* ctx, int mode, int millis, void* scratch, double* tflops, double* burst_tflops, double* clock_ghz) {
+    return mfma_rate_impl(ctx, mode, millis, scratch, tflops, burst_tflops, clock_ghz);
 }

@@ -1628,7 +1628,8 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
         }
         const int nI = (k >= 0 && Yinv) ? nt * ((k + strip) / strip) + (k + 1) : 0;     // R strips + Y tiles
 #if POTRF_PIPE && POTRF_NW == 4
-        if (k >= 0 && k >= pipe_from && k >= POTRF_PIPE_FROM && tiles > POTRF_PIPE_MIN_TILES && lda % 2 == 0) {
+        if (k >= 0 && k >= pipe_from && k >= POTRF_PIPE_FROM && tiles > POTRF_PIPE_MIN_TILES && lda % 2 == 0 && ((uintptr_t)A % 16) == 0 &&
+            (!Rw || ((uintptr_t)Rw % 16) == 0)) {      // (the B tiles arrive by 16-byte LDS-DMA pieces: base and row stride 16-byte aligned)
             // one workgroup per CU: the shortest strips that keep the launch within one round of the 256 CUs (the pipelined strip
             // costs ~13k cycles + 4.7k per column; a second round would cost a whole strip)
             int sp = 2, nAp = 0, nIp = 0, se = 2;

@@ -60,9 +60,9 @@ struct dsvgp_step_plan {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_status = nullptr, ev_fork2 = nullptr, ev_var = nullptr, ev_dense = nullptr,
                ev_zx = nullptr, ev_pipe1 = nullptr, ev_pipe2 = nullptr;
-    // timing pairs of the last TM_RING timed steps: forward solve, K_ZX assembly, K_ZX-bar kernel backward
-    static constexpr int TM_RING = 128;
-    hipEvent_t tm_ring[TM_RING][6] = {};
+    // timing pairs of the last TM_RING timed steps: forward solve, K_ZX assembly, K_ZX-bar kernel backward, Gram product, dense K_ZX-bar product
+    static constexpr int TM_RING = 128, TM_PAIRS = 5;
+    hipEvent_t tm_ring[TM_RING][2 * TM_PAIRS] = {};
     hipEvent_t* tm = tm_ring[0];
     long timed_steps = 0;
     bool timed = false;
@@ -225,16 +225,21 @@ extern "C" int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* pl) {
 // HIP-event durations (ms) of a step queued with flag 4 -- `back` steps before the most recent one (the plan keeps the last 128) --
 // each measured on the stream its kernel ran on: ms[0] forward panel solve A = L^-1 K_ZX, ms[1] K_ZX assembly, ms[2] K_ZX-bar
 // kernel backward.  Waits for that step.
-extern "C" int dsvgp_elbo_step_timings(dsvgp_step_plan* pl, int back, float* ms3) {
-    if (!pl || !ms3 || back < 0 || back >= dsvgp_step_plan::TM_RING || back >= pl->timed_steps) return DSVGP_EINVAL;
+static int step_timings(dsvgp_step_plan* pl, int back, float* ms, int n) {
+    if (!pl || !ms || n < 1 || n > dsvgp_step_plan::TM_PAIRS || back < 0 || back >= dsvgp_step_plan::TM_RING || back >= pl->timed_steps)
+        return DSVGP_EINVAL;
     hipEvent_t* tm = pl->tm_ring[(pl->timed_steps - 1 - back) % dsvgp_step_plan::TM_RING];
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < n; ++k) {
         hipError_t e = hipEventSynchronize(tm[2 * k + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms3[k], tm[2 * k], tm[2 * k + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[k], tm[2 * k], tm[2 * k + 1]);
         if (e != hipSuccess) return 1000 + (int)e;
     }
     return 0;
 }
+extern "C" int dsvgp_elbo_step_timings(dsvgp_step_plan* pl, int back, float* ms3) { return step_timings(pl, back, ms3, 3); }
+// ... and the two fp32 [M', B'] products of the step as well: ms5[3] the Gram product [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), ms5[4] the dense
+// product K_ZX-bar = [Q' | a][A ; mu_bar^T] (bench.py: roofline_gram / roofline_dense)
+extern "C" int dsvgp_elbo_step_timings5(dsvgp_step_plan* pl, int back, float* ms5) { return step_timings(pl, back, ms5, 5); }
 
 extern "C" size_t dsvgp_elbo_step_plan_bytes(const dsvgp_step_plan* pl) { return pl ? pl->bytes : 0; }
 // number of steps queued with flag 4 so far (the step queued last with that flag has index count - 1: callers that keep an index
@@ -417,8 +422,13 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     static const int pipe_k2 = getenv("DSVGP_PIPE_K2") ? atoi(getenv("DSVGP_PIPE_K2")) : STEP_PIPE_K2;
     static const int pipe_pad = getenv("DSVGP_PIPE_PAD") ? atoi(getenv("DSVGP_PIPE_PAD")) : STEP_PIPE_PAD;
     const int nblk64 = (Mp + 63) / 64;
+    // launches after which the side stream may start its two row ranges: the chain's launches are k = -1 .. nblk64 - 2, so an event is only
+    // ever recorded for k <= nblk64 - 2 (a wait on a never-recorded event does not wait), and the last range [r2, M') must not be empty;
+    // values outside 0 <= k1 <= k2 <= nblk64 - 2 (DSVGP_PIPE_K1 / K2 are per mille of the block rows, read with atoi) fall back to the serial solve
+    const int pk1 = (int)((int64_t)nblk64 * pipe_k1 / 1000), pk2 = (int)((int64_t)nblk64 * pipe_k2 / 1000);
     const bool pipe = overlap && (flags & 128) && nb >= Mp && Mp % 2 == 0 && Bp % 4 == 0 && ((uintptr_t)Kzx % 16) == 0 &&
-                      (int64_t)nblk64 * ((Bp + 63) / 64) >= 8192 && nblk64 >= 16;
+                      (int64_t)nblk64 * ((Bp + 63) / 64) >= 8192 && nblk64 >= 16 && pipe_k1 >= 0 && pk1 <= pk2 && pk2 <= nblk64 - 2 &&
+                      pipe_pad >= 0 && pipe_pad <= 98304;
     const double* LinvT = (const double*)trsm_ws + (size_t)Mp * Mp;
     auto solve_rows = [&](int ra, int rb, int pad) -> int {        // rows [ra, rb) of A = L^-1 K_ZX
         GemmArgs f{};
@@ -441,8 +451,8 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip)
     STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
     if (pipe) {
-        const int k1 = nblk64 * pipe_k1 / 1000, k2 = nblk64 * pipe_k2 / 1000;      // launches after which the side stream may start
-        const int r1 = (k1 + 1) * 64;
+        const int k1 = pk1, k2 = pk2;
+        const int r1 = (k1 + 1) * 64;                                              // (< M': k <= nblk64 - 2)
         r2 = (k2 + 1) * 64;
         const PotrfHook hooks[2] = {{k1, pl->ev_pipe1}, {k2, pl->ev_pipe2}};
         double* Dinv = (double*)trsm_ws;
@@ -485,6 +495,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     }
     STEP_CALL(launch_stats_residual(ctx, A32, Bp, Mp, Bp, p, io->m, io->constant, hyp, io->mu, var0, stats_ws, io->y, rows, mu_bar, sums));
     // ---- [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T), split-K over the minibatch axis; G mirrored
+    STEP_TIME(6);
     if (flags & 32) {
         // opt-in: six bf16 products per fp32 product on the bf16 matrix pipe (gemm3b.hip); the planes of [A ; mu_bar^T] serve both operands
         if (!io->split_ws || ((uintptr_t)io->split_ws & 255) || io->split_ws_bytes < split_offsets(Mp, Bp, nullptr, nullptr)) {
@@ -496,6 +507,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     } else
     STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
                          Mp, nullptr, 0, nullptr));
+    STEP_TIME(7);
     return 0;
 }
 
@@ -543,7 +555,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         ctx->lean_classic = prev;
         return rc;
     };
-    auto dense = [&]() -> int {
+    auto dense_product = [&]() -> int {
         if (flags & 32) {
             size_t o_pat, o_pq;
             split_offsets(Mp, Bp, &o_pat, &o_pq);
@@ -556,6 +568,13 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         }
         return dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qe32, ldQ32, A32e, Bp, 0.0, nullptr, 0, Kb32, Bp, nullptr, 0,
                           nullptr);
+    };
+    auto dense = [&]() -> int {
+        if (timed && hipEventRecord(pl->tm[8], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
+        const int rc = dense_product();
+        if (rc) return rc;
+        if (timed && hipEventRecord(pl->tm[9], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
+        return 0;
     };
     // ---- Cholesky backward (DGVS.py:72-75 differentiated): K_ZZ-bar = 1/2 L^-T (Phi(L^T L-bar) + Phi(.)^T) L^-1 through the explicit
     // inverse, lower halves + mirrors.  Phi reads the lower triangle of L^T L-bar only, and there the tril() in
@@ -867,6 +886,7 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
             hipLaunchKernelGGL(gather_blocks_kernel, dim3(blocks), dim3(256), 0, main, dp->q_all, Qfull, Mp, wq, world);
             STEP_HIP(hipGetLastError());
         }
+        STEP_TIME(8);
         if (flags & 32) {
             size_t o_pat, o_pq;
             split_offsets(Mp, Bp, &o_pat, &o_pq);
@@ -877,6 +897,7 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
         } else
         STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_K_PADDED, Mp, Bp, Mp + 1, 1.0, Qfull, (int64_t)world * wq, A32e, Bp, 0.0, nullptr, 0, Kb32,
                              Bp, nullptr, 0, nullptr));
+        STEP_TIME(9);
         STEP_TIME(4);
         STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
         STEP_TIME(5);

@@ -127,13 +127,18 @@ def step_together(optimizers):
     (variational parameters, then hyper-parameters: directional_vi.py:251-254) whose settings and step counts coincide, so their
     tensors share a multi-tensor launch (one ~4 us launch fewer per step: visible at BASELINE config 2).  The two updates touch
     disjoint parameters and each reads its own learning rate, so the order against the schedulers' steps does not matter.
-    Returns False (and does nothing) unless every optimizer is a FusedAdam."""
+    Returns False (and does nothing) unless every optimizer is a FusedAdam without registered step hooks."""
     if not optimizers or not all(isinstance(o, FusedAdam) for o in optimizers):
+        return False
+    # Optimizer.step() is bypassed here: an optimizer that carries step hooks (``register_step_pre_hook`` / ``_post_hook``) keeps the
+    # separate ``step()`` calls, which run them
+    if any(getattr(o, "_optimizer_step_pre_hooks", None) or getattr(o, "_optimizer_step_post_hooks", None) for o in optimizers):
         return False
     batch = {}
     for o in optimizers:
         o._collect(batch)
-        o._opt_called = True             # (what the LR schedulers' step-order check looks at)
+        o._opt_called = True             # (what the LR schedulers' step-order check looks at ...
+        o._step_count = getattr(o, "_step_count", 0) + 1      # ... and the wrapped step counter older schedulers read)
     _launch_batches(batch)
     return True
 

@@ -33,27 +33,38 @@ class DataParallel:
         self.replicated_step = False  # set by the training loop for a tail minibatch with fewer rows than ranks
         # Replica consistency of L_S, m (and their Adam moments) rests on the fixed-order G L_S product and on bitwise-identical
         # all-reduce results; nothing re-broadcasts them.  DSVGP_DP_CHECK=N: every N-th step the replicas compare a checksum of
-        # their variational parameters (one 4-element all-reduce of max / min) and, if they differ, take rank 0's copy and count
+        # their parameters' bit patterns (one small all-reduce of max / min) and, if they differ, take rank 0's copy and count
         # the event (``divergences``); 0 / unset: off.
         try:
             self.check_every = int(os.environ.get("DSVGP_DP_CHECK", "0"))
         except ValueError:
             self.check_every = 0
         self._check_step = 0
+        self.checks = 0
         self.divergences = 0
 
     def check_replicas(self, tensors, force=False):
-        """Opt-in divergence check (DSVGP_DP_CHECK): True if the replicas of ``tensors`` agree bit for bit on every rank.
-        A checksum per tensor (sum and sum of squares in float64) goes through ONE all-reduce(max) of [c, -c]: the replicas agree
-        iff max(c) == min(c).  On disagreement every tensor is overwritten with rank 0's copy (broadcast) and ``divergences``
-        is incremented; the caller decides what else to re-synchronise (optimizer moments)."""
+        """Divergence check (DSVGP_DP_CHECK=N, ``check_every``): True if the replicas of ``tensors`` agree bit for bit on every rank.
+        Two checksums per tensor over its BIT PATTERN (the words viewed as int32: their int64 sum, and their sum weighted by
+        1 + position mod 65521 -- a flipped bit, a NaN payload or two swapped entries all change it; NaNs compare like any other
+        bits, so a NaN that every replica holds is not a divergence) go through ONE all-reduce(max) of [c, -c]: the replicas agree
+        iff max(c) == min(c).  On disagreement every tensor is overwritten with rank 0's copy (broadcast) and ``divergences`` is
+        incremented; the caller decides what else to re-synchronise (optimizer moments).  Runs on the eager step; a graph-replayed
+        step is never data-parallel (TrainLoop._graph_eligible), so there is no replayed variant to cover."""
         self._check_step += 1
         if not force and (self.check_every <= 0 or self._check_step % self.check_every):
             return True
+        self.checks += 1
         cs = []
         for t in tensors:
-            t64 = t.detach().to(torch.float64)
-            cs += [t64.sum(), (t64 * t64).sum()]
+            w = t.detach().contiguous().view(-1)
+            if w.numel() == 0:
+                continue
+            bits = w.view(torch.int32).to(torch.int64)          # (float64: two words per element)
+            pos = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64).remainder_(65521).add_(1)
+            cs += [bits.sum(), (bits * pos).sum()]
+        if not cs:
+            return True
         c = torch.stack(cs)
         both = torch.cat([c, -c])
         dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)

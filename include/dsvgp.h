@@ -491,6 +491,10 @@ int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_el
 /* flags & 4 in dsvgp_elbo_step_f32: HIP-event pairs around the forward solve, the K_ZX assembly and K_ZX-bar's kernel backward,
  * each on the stream its kernel runs on; ms3 = their durations in ms (waits for the step) -- bench.py's roofline entries      */
 int dsvgp_elbo_step_timings(dsvgp_step_plan* plan, int steps_back, float* ms3);   /* the plan keeps the last 128 timed steps */
+/* the same three durations plus ms5[3]: the Gram product [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T) and ms5[4]: the dense product
+ * K_ZX-bar = [Q' | a][A ; mu_bar^T] (the two fp32 [M', B'] products of the step; no counterpart in the reference, whose autograd runs
+ * them inside DGVS.py:192-205's backward) */
+int dsvgp_elbo_step_timings5(dsvgp_step_plan* plan, int steps_back, float* ms5);
 long dsvgp_elbo_step_timed_count(const dsvgp_step_plan* plan);   /* steps queued with flag 4 so far (index of the last: count - 1) */
 
 /* ---- measurement aid (bench.py `roofline.sustained`): the MFMA rate this card holds with no memory traffic, ~`millis` ms of
@@ -498,6 +502,10 @@ long dsvgp_elbo_step_timed_count(const dsvgp_step_plan* plan);   /* steps queued
  * scratch: 2 MiB of device memory.  Not part of the reference's interface (SURVEY.md 8d asks for achieved-vs-peak; the
  * data-sheet peak is at 2.4 GHz, which the card does not hold under matrix load).                                        */
 int dsvgp_mfma_rate(dsvgp_ctx* ctx, int is_double, int millis, void* scratch, double* tflops);
+/* mode bit 0 = is_double, bit 1 = ONE wave per SIMD (one 256-thread workgroup per CU; four otherwise); burst_tflops (may be NULL): the rate
+ * of the very first ~2 ms launch from an idle card, before the power management lowers the clock; clock_ghz (may be NULL): the in-kernel clock
+ * of the last launch (delta s_memtime / delta s_memrealtime x 100 MHz, median over workgroups).                                            */
+int dsvgp_mfma_rate2(dsvgp_ctx* ctx, int mode, int millis, void* scratch, double* tflops, double* burst_tflops, double* clock_ghz);
 
 #ifdef __cplusplus
 }

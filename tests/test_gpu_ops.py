@@ -63,7 +63,9 @@ def test_kernel_fwd_matches_reference_golden_vectors(dsvgp, gpu_device, path):
 
 
 @pytest.mark.parametrize("n1,n2,d,p", [(37, 53, 5, 2), (16, 16, 20, 5), (33, 70, 20, 5), (9, 130, 3, 0),
-                                       (20, 11, 10, 10), (7, 40, 45, 1), (130, 7, 2, 1)])
+                                       (20, 11, 10, 10), (7, 40, 45, 1), (130, 7, 2, 1),
+                                       # several tiles of the split-row kernel (q = 11) and of the KSM = 16 pair kernels (q = 6 / 3, 28 < d <= 60)
+                                       (50, 95, 10, 10), (30, 60, 50, 5), (20, 70, 40, 2)])
 def test_kernel_fwd_random_shapes(dsvgp, gpu_device, n1, n2, d, p):
     g = torch.Generator().manual_seed(n1 * 1000 + n2)
     x1, x2 = torch.rand(n1, d, generator=g), torch.rand(n2, d, generator=g)
@@ -117,7 +119,9 @@ def test_kernel_diag_and_errors(dsvgp, gpu_device):
 # ------------------------------------------------------------------ kernel assembly backward
 @pytest.mark.parametrize("n1,n2,d,p,sym", [(11, 23, 5, 2, False), (20, 45, 20, 5, False), (18, 18, 20, 5, True),
                                            (40, 300, 4, 1, False), (9, 9, 3, 3, True), (6, 10, 6, 0, False),
-                                           (4, 7, 80, 40, False)])       # (q DP = 41 x 84 > 3072: the one-wave tail of the backward)
+                                           (4, 7, 80, 40, False),        # (q DP = 41 x 84 > 3072: the one-wave tail of the backward)
+                                           # kernel_bwd_split_kernel<., 11, 4> (q = 11) and kernel_bwd_pair_kernel with KSM = 16 over several tiles
+                                           (50, 95, 10, 10, False), (45, 45, 10, 10, True), (30, 60, 50, 5, False), (20, 70, 40, 2, False)])
 def test_kernel_bwd_matches_autograd(dsvgp, gpu_device, n1, n2, d, p, sym):
     ops = dsvgp._ops
     g = torch.Generator().manual_seed(n1 + 31 * n2 + d)
@@ -359,6 +363,28 @@ def test_potrf_inverse_fused(dsvgp, gpu_device, n):
     bad = bad.to(gpu_device)
     ops.potrf_inverse_(ctx, bad, info, nb, ws)
     assert int(info.item()) == n // 2 + 1
+
+
+def test_potrf_inverse_base_not_16_byte_aligned(dsvgp, gpu_device):
+    """dsvgp_potrf_inverse takes any double*: a matrix that starts 8 bytes into an allocation (a torch view at an odd element
+    offset) with an even leading dimension must not reach the pipelined-strip kernel, whose B tiles arrive by 16-byte LDS-DMA
+    pieces -- the launcher's gate sends it to the two-per-CU kernel; n = 1800: launches with more than 300 tiles."""
+    ops = dsvgp._ops
+    ctx = ops.Context.get(gpu_device)
+    n, ld = 1800, 1802
+    K = _spd(n, torch.Generator().manual_seed(77))
+    buf = torch.zeros(n * ld + 1, dtype=torch.float64, device=gpu_device)
+    A = buf[1:].view(n, ld)[:, :n]
+    assert A.data_ptr() % 16 == 8
+    A.copy_(K.to(gpu_device))
+    info = torch.zeros(1, dtype=torch.int32, device=gpu_device)
+    ws = ops.trsm_workspace(n, n, 4096, gpu_device)
+    ops.potrf_inverse_(ctx, A, info, 4096, ws)
+    assert int(info.item()) == 0
+    L = torch.tril(A).cpu()
+    assert (L @ L.t() - K).abs().max() < 1e-10 * K.abs().max()
+    Linv = torch.tril(ws[:n * n * 8].view(torch.float64).view(n, n)).cpu()
+    assert (Linv @ L - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-9
 
 
 @pytest.mark.parametrize("n,nrhs,nb", [(100, 37, 64), (333, 500, 128), (700, 260, 256), (700, 260, 1024), (520, 129, 512)])

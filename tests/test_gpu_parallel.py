@@ -439,3 +439,33 @@ def test_bench_line_of_a_four_rank_rehearsal(gpu_device):
     coll = j["config"]["collective"]
     assert coll["backend"] == "gloo" and coll["packed_triangle"] and coll["early_operand_floats"] > 0
     assert j["config"]["one_call_step"]                     # the five-piece C entry, not the piecewise orchestration
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launch_of_a_four_rank_rehearsal(gpu_device):
+    """`python bench.py --gpus 4` from a plain invocation: bench.py starts ONE child launcher (`torch.distributed.run --standalone`)
+    before anything in that process touches the GPU, relays its output and exits with its status -- rehearsed on one card over gloo.
+    The line must carry what the first run on real multi-GPU hardware is to report: the replica check (on by default under the bench,
+    no divergence), the host time of a rank step phase by phase, and the collective block."""
+    import json
+    import subprocess
+    env = dict(os.environ, DSVGP_REHEARSE_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DSVGP_DP_CHECK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "c4", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 4 and j["rccl_ranks"] == 4 and j["steps"] == 3 and j["value"] > 0
+    coll = j["config"]["collective"]
+    assert coll["backend"] == "gloo" and j["config"]["one_call_step"]
+    rc = coll["replica_check"]
+    assert rc["every"] == 64 and rc["checks"] >= 1 and rc["divergences"] == 0, rc
+    host = coll["host_us_per_rank_step"]
+    assert host["steps"] == 3 and host["total"] > 0
+    for k in ("phase0_front_gram", "phase1_q_columns", "phase2_variational_lbar_rows", "phase3_dense_kernel_bwd", "phase4_chol_backward_tail",
+              "wait_allreduce_G", "wait_allgather_q", "wait_allgather_lbar"):
+        assert host[k] >= 0, (k, host)
+    print("[dp] host us per rank step (4 gloo ranks on one card):", {k: round(v, 1) for k, v in host.items() if k not in ("unit",)})

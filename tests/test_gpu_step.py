@@ -67,7 +67,7 @@ CASES = [
     (500, 20, 30, 5, 96),      # C4 geometry (d=20, p=5), small M/B
     (300, 4, 25, 4, 50),       # p == d (full gradient)
     (300, 6, 70, 0, 64),       # p = 0: plain SVGP special case
-    (400, 50, 20, 5, 40),      # C5 geometry (d = 50): packed rows wider than the register-resident pair kernels take
+    (400, 50, 20, 5, 40),      # C5 geometry (d = 50): packed rows of 56 floats, the KSM = 16 instances of the pair kernels
     (300, 7, 18, 3, 33),       # q = 4, odd sizes: the generic tiled kernels
 ]
 
@@ -931,6 +931,35 @@ def test_one_call_step_equals_the_piecewise_step(dsvgp, gpu_device, N, d, M, p, 
         assert relmax(g2["inducing_points"], g1["inducing_points"]) < 5e-5, (overlap, relmax(g2["inducing_points"], g1["inducing_points"]))
     l_ref, g_ref, mu_ref, _ = O.elbo_loss_and_grads(P, x, y, D, nd)
     assert abs(l1.item() - l_ref.item()) < 2e-5 * abs(l_ref.item()) and relmax(mu1, mu_ref) < 2e-4
+
+
+def test_one_call_step_with_the_solve_in_row_ranges_under_the_chain(dsvgp, gpu_device):
+    """Flag 128 of dsvgp_elbo_step_f32 (DSVGP_SOLVE_PIPE; measured and left off by default): the forward solve A = L^-1 K_ZX queued as
+    three row ranges, two of them on the side stream behind events the Cholesky chain records after its launches k1 / k2.  Every piece is
+    a row range of the SAME triangular product (tri_off pieces of gemm64.hip's wide kernel), so [A ; mu-bar^T] must equal the serial
+    schedule's BIT FOR BIT (the solve has no split-K), and loss / gradients to the run-order noise of the later atomics.  Geometry:
+    M' = 1024 (16 block rows), B' = 32768 -> 8192 tiles of 64 x 64, the smallest the flag accepts."""
+    N, d, M, p, B = 9000, 6, 256, 3, 8192
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=31)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    xd, yd, Dd = x.to(gpu_device), y.to(gpu_device), D.to(gpu_device)
+    res = []
+    for pipe in (False, True):
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.solve_pipe = pipe
+        l1, g1, mu1, _ = eng.loss_and_grads(Pg, xd, yd, Dd, nd)
+        torch.cuda.synchronize()
+        assert eng.c_step_used
+        _, plan, ws, _ = eng._last_fast
+        res.append((l1.item(), {k: v.clone() for k, v in g1.items()}, mu1.clone(), plan.locate(ws, 0).clone()))
+    (l0, g0, mu0, A0), (l1, g1, mu1, A1) = res
+    assert A0.shape == (M * (p + 1) + 1, B * (p + 1)) and torch.isfinite(A0).all()
+    assert torch.equal(A0[:-1], A1[:-1])                         # rows of A: the same product, piece by piece
+    assert relmax(A1[-1], A0[-1]) < 4e-6 and relmax(mu1, mu0) < 4e-6
+    assert abs(l1 - l0) < 4e-6 * abs(l0), (l1, l0)
+    for k in O.PARAM_NAMES:
+        if g0[k].numel():
+            assert relmax(g1[k], g0[k]) < 5e-5, (k, relmax(g1[k], g0[k]))
 
 
 @pytest.mark.parametrize("N,d,M,p,B", [(600, 5, 40, 2, 128), (500, 20, 30, 5, 96), (3000, 5, 200, 2, 512), (400, 6, 300, 6, 64)])

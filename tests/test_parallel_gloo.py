@@ -150,6 +150,14 @@ def _worker(rank, world, port, out):
     assert torch.equal(a, torch.arange(12.0).reshape(3, 4))
     dp.check_every, dp._check_step = 2, 0
     assert dp.check_replicas([a, b]) is True and dp.check_replicas([a, b]) is True and dp.divergences == 1
+    # the checksum is over the bit pattern: two swapped entries (equal sum and sum of squares) are a divergence, a NaN every replica
+    # holds is not (it must not trigger a re-broadcast on every check), float64 and 0-dim tensors are taken as they are
+    c = torch.arange(8.0)
+    if rank == 1:
+        c[[2, 5]] = c[[5, 2]]
+    assert dp.check_replicas([c], force=True) is False and dp.divergences == 2 and torch.equal(c, torch.arange(8.0))
+    e, f = torch.tensor([1.0, float("nan"), 3.0]), torch.tensor(0.5, dtype=torch.float64)
+    assert dp.check_replicas([e, f, torch.zeros(0)], force=True) is True and dp.divergences == 2 and dp.checks >= 4
     out[rank] = (loss.item(), {k: v.clone() for k, v in grads.items()}, (lo, hi), mu.shape[0])
     dist.destroy_process_group()
 

@@ -4,10 +4,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05_pipe; mkdir -p $O
 cd $R
-run() {  # name, env...
-  name=$1; shift
-  for cfg in "c4 20" "c3 30"; do set -- $cfg "${@:3}"; done
-}
 one() { # label cfg steps env-assignments...
   label=$1; cfg=$2; steps=$3; shift 3
   env "$@" python3 bench.py --config $cfg --steps $steps --warmup 4 --no-cpu-baseline --no-extras > $O/b_${cfg}_$label.json 2>$O/err_${cfg}_$label.txt \

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools only (round 5): whole-step A/B of potrf.hip variants, alternating, one box: usage tools/r05_step_ab.sh "<defs A>" "<defs B>"
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+ARG_A=$1; ARG_B=$2
 BA=$(mktemp -d /tmp/sa_XXXX); BB=$(mktemp -d /tmp/sb_XXXX)
 tools/build_variant.sh $BA "potrf.hip:$1" > /dev/null 2>&1 &
 tools/build_variant.sh $BB "potrf.hip:$2" > /dev/null 2>&1 &
