@@ -77,14 +77,19 @@ using acc4 = double __attribute__((ext_vector_type(4)));
 #ifndef POTRF_DEBUG_K
 #define POTRF_DEBUG_K 20      // block column whose critical workgroup is stamped
 #endif
-__device__ unsigned long long chol_dbg[32];
+#if !defined(POTRF_CRIT_STRIPS) || POTRF_CRIT_STRIPS
+#define CHOL_STRIPS_STAMPS 1  // (slots 16 .. 27 belong to the strips chain's own stamps)
+#else
+#define CHOL_STRIPS_STAMPS 0
+#endif
+__device__ unsigned long long chol_dbg[64];
 // stamps pinned in place (the scalar s_memtime would otherwise be scheduled ahead of the MFMAs it is meant to follow) and kept
 // in registers until the end of the kernel (a global store per stamp would sit in vmcnt and stretch the waits that follow it)
 #define CHOL_STAMP_DECL unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define CHOL_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[slot]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define CHOL_STAMP_FLUSH do { if (b == 0 && k == POTRF_DEBUG_K) { if (tid == 0) { for (int q_ = 0; q_ < 8; ++q_) chol_dbg[q_] = st_[q_]; } \
-        if ((tid & 63) == 0) { chol_dbg[16 + (tid >> 6)] = st_[8]; chol_dbg[20 + (tid >> 6)] = st_[9]; chol_dbg[24 + (tid >> 6)] = st_[10]; } } } while (0)
+        if ((tid & 63) == 0 && !CHOL_STRIPS_STAMPS) { chol_dbg[16 + (tid >> 6)] = st_[8]; chol_dbg[20 + (tid >> 6)] = st_[9]; chol_dbg[24 + (tid >> 6)] = st_[10]; } } } while (0)
 #else
 #define CHOL_STAMP_DECL
 #define CHOL_STAMP(slot) do { } while (0)
@@ -1159,6 +1164,713 @@ __device__ __forceinline__ void crit_tile_update(double (*S)[64][LDT], const dou
     }
 }
 
+#ifndef POTRF_CRIT_STRIPS
+#define POTRF_CRIT_STRIPS 1     // 1: the critical workgroup keeps the diagonal tile in REGISTERS, one 16-row strip per wave (factor64_strips below); 0: round 5's factor64_lds
+#endif
+#if POTRF_CRIT_STRIPS
+// -------------------------------------------------------------------------------------------------
+// Round 6: the critical workgroup's factorisation with the diagonal tile in registers and the inverse OFF the serial chain.
+//
+// Round 5 (factor64_lds): per 16-column block, ONE wave factors AND inverts the 16 x 16 diagonal block (factor16_wave, 4.4-4.7k cycles),
+// then two barrier phases form the panel L_{ib,kb} = F_{ib,kb} X_d^T and the next diagonal block's update -- 6.7k cycles per block,
+// 26.5k for the tile (of the critical workgroup's 37.6k).  The panel needed X_d only because it was written as an MFMA product.
+// Here wave w owns rows 16 w .. 16 w + 15 of the tile for the WHOLE factorisation, in the register image
+//     a[cb][t] = D[16 w + i][16 cb + 4 t + g]      (i = lane & 15, g = lane >> 4;  cb <= w)
+// and block column kb is processed by all waves w >= kb together, four columns at a time:
+//   * the DIAGONAL wave (w = kb) publishes the 16 x 4 column block of its strip, factors the 4 x 4 pivot block (four dependent
+//     rsqrt), substitutes its rows against it and applies the rank-4 update D -= M M^T with ONE MFMA out of its own registers
+//     (as factor16_wave did) -- but runs no forward elimination of the identity beside it: L only;
+//   * the FOLLOWERS (w > kb) read the published block, redo the pivot factorisation (the same ten numbers in every lane), substitute
+//     their own rows AND the diagonal block's rows (the B / A operands of the update D_w -= M_w M_d^T, computed transposed so that the
+//     accumulator IS the a image), one block behind the diagonal wave and never waited for by it: the panel L_{w,kb} comes out of
+//     the same substitution the diagonal block gets -- no inverse on the path;
+//   * after the 16 columns wave w holds L_{w,kb}; it publishes the block (LDS, register image as it stands: readers use the same
+//     lane map), applies  D_{w,cb} -= L_{w,kb} L_{cb,kb}^T  for cb = kb + 1 .. w (own block: both operands are its own registers),
+//     and wave kb + 1 goes straight on as the next diagonal wave.
+// Critical path: 4 x (16-column chain + 4 MFMAs), hopping from wave to wave.  X = L^-1 and W = X^T X are formed by the waves that
+// are done with the chain: wave w inverts its diagonal block from registers (invert16_regs: the forward elimination of the old
+// chain, now beside the NEXT wave's chain), wave c < r forms T_{r,c} = sum_j L_{r,j} X_{j,c} as soon as its inputs exist and
+// X_{r,c} = -X_rr T_{r,c} when wave r has published X_rr; every wave accumulates its own blocks of W row by row.
+// Synchronisation: LDS flags (one writer each, polled), no workgroup barrier after the update phase.  LDS: xs (packed lower
+// blocks of X, row stride XB) and cpub (published column blocks) in the tile that held X_k; lpub (published L blocks) in the tile
+// that holds P = A X_k^T, written only once every wave has left the update phase (FL_P flags).
+// tools/crit_chain_emulator.py replays this routine lane by lane on the host (index algebra check).
+// -------------------------------------------------------------------------------------------------
+#ifndef POTRF_SPIN_SLEEP
+#define POTRF_SPIN_SLEEP 1      // s_sleep argument between two polls of a flag word (0: none; measured: n = 600 0.194 -> 0.188 ms with 1, nothing more with 4)
+#endif
+constexpr int XB = 17;                                        // row stride (doubles) of a 16 x 16 block of X in LDS
+constexpr int FL_C = 0, FL_P = 4, FL_L = 8, FL_X = 24, FL_N = 40;      // flag words: cflag[kb], pdone[w], lflag[r][j], xflag[r][c]
+// (explicit LDS pointers: through generic pointers the volatile flag words became FLAT stores / loads with a vmcnt(0) wait behind each)
+typedef __attribute__((address_space(3))) double LD;
+typedef __attribute__((address_space(3))) volatile int LVI;
+struct CritLds {
+    LD* xs;               // 10 x 16 x XB
+    LD* cpub;         // [4 kb][4 jb][80]: the pivot factors (10 words) and, from word 16, the block M of the diagonal wave, per 4-column block
+    LD* lpub;             // [6][4 t][64 lanes]
+    LD* own;              // [4 waves][64]
+    LVI* fl;              // FL_N words, zeroed before use
+#ifdef POTRF_DEBUG
+    int dbg_gidx0;
+    __attribute__((address_space(3))) unsigned long long* dbg;      // 64 stamp words (LDS: a stamp is one s_memtime + one ds_write of lane 0), copied to chol_dbg at the end
+#endif
+};
+#ifdef POTRF_DEBUG
+#define STRIPS_STAMP(slot) do { if (gidx0 == (POTRF_DEBUG_K + 1) * 64) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0) S.dbg[slot] = t__; } } while (0)
+#else
+#define STRIPS_STAMP(slot) do { } while (0)
+#endif
+__device__ __forceinline__ int xblk(int r, int c) { return 16 * XB * (r * (r + 1) / 2 + c); }
+__device__ __forceinline__ int lblk(int r, int j) { return 256 * (r * (r - 1) / 2 + j); }
+// one writer per flag; LDS executes a wave's instructions in order, so the flag store behind the data stores needs no wait
+__device__ __forceinline__ void fl_set(LVI* f, int v, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) *f = v;
+}
+__device__ __forceinline__ void fl_wait(LVI* f, int v, int* info) {
+    int n = 0;
+    while (*f < v) {
+        if (++n > (1 << 22)) {            // (never in a correct run: every flag is set unconditionally; a bounded spin cannot hang the card)
+            if (info) *info = -777;
+            break;
+        }
+#if POTRF_SPIN_SLEEP
+        __builtin_amdgcn_s_sleep(POTRF_SPIN_SLEEP);
+#endif
+    }
+    asm volatile("" ::: "memory");
+}
+struct Piv4 { double r0, r1, r2, r3, l10, l20, l30, l21, l31, l32; };
+#ifndef POTRF_RSQ_HALLEY
+#define POTRF_RSQ_HALLEY 1      // 1: v_rsq_f64 + ONE third-order step (5 instructions); 0: two Newton steps (8 instructions, rsqrt_nr)
+#endif
+// 1 / sqrt(d) for the serial chain.  A single wave issues one fp64 instruction per ~5 cycles and a dependent one waits no longer than that
+// (tools/lat_probe.cpp: dependent v_fma_f64 5.3, v_rsq_f64 16 cycles): the chain is bound by its INSTRUCTION COUNT.  v_rsq_f64 is good to
+// 2.5e-8, so with e = 1 - d y^2 the step y (1 + e / 2 + 3 e^2 / 8) leaves 5 e^3 / 16 ~ 5e-24: full accuracy from five instructions.
+__device__ __forceinline__ double rsqrt_chain(double d) {
+#if POTRF_RSQ_HALLEY
+    const double y = __builtin_amdgcn_rsq(d);
+    const double gq = d * y;
+    const double e = fma(-gq, y, 1.0);
+    const double pq = fma(e, 0.375, 0.5);
+    const double ye = y * e;
+    return fma(ye, pq, y);
+#else
+    return rsqrt_nr(d);
+#endif
+}
+// the 4 x 4 pivot block (lower entries P_rc): reciprocal square roots of the pivots and the block's L entries
+template <bool CHECK>
+__device__ __forceinline__ Piv4 pivot4(double P00, double P10, double P11, double P20, double P21, double P22, double P30, double P31, double P32,
+                                       double P33, int j0, int& bad) {
+    Piv4 v;
+    v.r0 = rsqrt_chain(P00);
+    v.l10 = P10 * v.r0; v.l20 = P20 * v.r0; v.l30 = P30 * v.r0;
+    const double d1 = fma(-v.l10, v.l10, P11);
+    v.r1 = rsqrt_chain(d1);
+    v.l21 = fma(-v.l20, v.l10, P21) * v.r1; v.l31 = fma(-v.l30, v.l10, P31) * v.r1;
+    const double d2 = fma(-v.l21, v.l21, fma(-v.l20, v.l20, P22));
+    v.r2 = rsqrt_chain(d2);
+    v.l32 = fma(-v.l31, v.l21, fma(-v.l30, v.l20, P32)) * v.r2;
+    const double d3 = fma(-v.l32, v.l32, fma(-v.l31, v.l31, fma(-v.l30, v.l30, P33)));
+    v.r3 = rsqrt_chain(d3);
+    if constexpr (CHECK) {
+        bad = (bad < 0 && !(P00 > 0.0)) ? j0 : bad;
+        bad = (bad < 0 && !(d1 > 0.0)) ? j0 + 1 : bad;
+        bad = (bad < 0 && !(d2 > 0.0)) ? j0 + 2 : bad;
+        bad = (bad < 0 && !(d3 > 0.0)) ? j0 + 3 : bad;
+    }
+    return v;
+}
+// one row's four block entries against the pivot block: M[row][0..3]; returns column g
+__device__ __forceinline__ double subst4(double p0, double p1, double p2, double p3, const Piv4& v, int g) {
+    const double m0 = p0 * v.r0;
+    const double m1 = fma(-m0, v.l10, p1) * v.r1;
+    const double m2 = fma(-m1, v.l21, fma(-m0, v.l20, p2)) * v.r2;
+    const double m3 = fma(-m2, v.l32, fma(-m1, v.l31, fma(-m0, v.l30, p3))) * v.r3;
+    asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));      // (all four in every lane: left to itself hipcc sinks them under nested exec-mask branches on g)
+    return (g == 0) ? m0 : ((g == 1) ? m1 : ((g == 2) ? m2 : m3));
+}
+typedef double __attribute__((ext_vector_type(2))) d2v;      // (a builtin vector: HIP's double2 class cannot be copied out of address space 3 in the host pass)
+typedef __attribute__((address_space(3))) d2v LD2;
+// The diagonal wave of block column kb (ONE copy of this code serves the four block columns: the wave that runs it for kb + 1 finds it in
+// the instruction cache -- as four template instances every chain started with ~1k cycles of instruction fetch, profiles/r06_a_*).
+// cur = D_kk -> L_kk (zero above the diagonal), rks[jb] = the four 1 / L_cc of block jb (the same in every lane).  Per 4-column block: the
+// strip's column block goes through the wave's own LDS words once (row i's four entries for the substitution; rows j0 .. j0+3 are the pivot
+// block, read as broadcasts), P_00 alone comes by v_readlane so that the first 1 / sqrt starts at once; the pivot factors (cpub[kb][jb][0..9])
+// and the block M (the followers' A operand, lane for lane: cpub[..][16 + lane]) are published with ONE flag per block (cflag = jb + 1),
+// behind the MFMA of the rank-4 update (the publication rides under its latency).
+__device__ __forceinline__ void strips_diag(const CritLds& S, int kb, acc4& cur, acc4 (&rks)[4], int lane, int* info, int gidx0, int nvalid) {
+    const int i = lane & 15, g = lane >> 4;
+    LD* own = S.own + 64 * kb;
+    int unused = -1;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const int j0 = 4 * jb;
+        LD* cb = S.cpub + (kb * 4 + jb) * 80;
+        own[i * 4 + g] = cur[jb];                                    // D[i][j0 + g]
+        __builtin_amdgcn_wave_barrier();
+        const double P00 = readlane_f64(cur[jb], j0);
+        const d2v p01 = *(const LD2*)(own + i * 4), p23 = *(const LD2*)(own + i * 4 + 2);
+        const d2v R1 = *(const LD2*)(own + (j0 + 1) * 4), R2 = *(const LD2*)(own + (j0 + 2) * 4), R3 = *(const LD2*)(own + (j0 + 3) * 4),
+                      R3b = *(const LD2*)(own + (j0 + 3) * 4 + 2);
+        const double P22 = own[(j0 + 2) * 4 + 2];
+        __builtin_amdgcn_sched_barrier(0);                           // (the exchange is issued HERE: its latency rides under the first 1 / sqrt)
+        const Piv4 v = pivot4<false>(P00, R1.x, R1.y, R2.x, R2.y, P22, R3.x, R3.y, R3b.x, R3b.y, j0, unused);
+        if (lane == 0) {
+            cb[0] = v.r0; cb[1] = v.r1; cb[2] = v.r2; cb[3] = v.r3; cb[4] = v.l10; cb[5] = v.l20; cb[6] = v.l30; cb[7] = v.l21; cb[8] = v.l31;
+            cb[9] = v.l32;
+        }
+        const double mraw = subst4(p01.x, p01.y, p23.x, p23.y, v, g);
+        const double mg = (i >= j0 + g) ? mraw : 0.0;
+        if (jb < 3) cur = __builtin_amdgcn_mfma_f64_16x16x4f64(-mg, mg, cur, 0, 0, 0);      // D -= M M^T (the last block has nothing behind it)
+        cb[16 + lane] = mg;
+        fl_set(S.fl + FL_C + kb, jb + 1, lane);
+        cur[jb] = mg;
+        rks[jb] = acc4{v.r0, v.r1, v.r2, v.r3};
+        STRIPS_STAMP(32 + 4 * kb + jb);                              // (end of block jb)
+    }
+    // a pivot <= 0 (or NaN) makes its 1 / sqrt and everything behind it NaN: ONE test of the last one per chain; the column is looked up only then
+    const double rl = rks[3][3];
+    if (!(rl < 1.7e308)) {
+        int bad = 15;
+#pragma unroll
+        for (int jb = 3; jb >= 0; --jb)
+#pragma unroll
+            for (int q = 3; q >= 0; --q)
+                if (!(rks[jb][q] < 1.7e308)) bad = 4 * jb + q;
+        if (lane == 0 && 16 * kb + bad < nvalid && *info == 0) *info = gidx0 + 16 * kb + bad + 1;      // LAPACK convention
+    }
+}
+// A follower of block column kb: cur = D_{w,kb} -> L_{w,kb}; dg = this wave's own diagonal block D_ww.  It substitutes its own rows against the
+// published pivot factors and applies, per 4-column block,
+//   D_w^T -= M_d M_w^T   (A operand lane (m, k) = M_d[m][k]: the published block, lane for lane; B operand lane (n, k) = M_w[n][k]; register q of
+//                         lane (n, g') receives row g' + 4 q of M_d against row n of M_w = the update of D_w[n][4 q + g']: the a image)
+//   D_ww  -= M_w M_w^T   (both operands the same register; the trailing update of the wave's own diagonal block, four columns at a time: when
+//                         the sixteenth column is in, the next diagonal wave starts its chain after ONE more MFMA)
+// The flag poll and the factor reads of block jb + 1 are issued behind the MFMAs of block jb, in front of the exchange of the updated column
+// block (which has to wait for them): a follower that has caught up is ~250 cycles behind the publication it waits for.
+__device__ __forceinline__ void strips_follow(const CritLds& S, int kb, acc4& cur, acc4& dg, int wave, int lane, int* info) {
+    const int i = lane & 15, g = lane >> 4;
+    LD* own = S.own + 64 * wave;
+    own[i * 4 + g] = cur[0];                                         // this wave's D[i][j0 + g], exchanged inside the wave
+    __builtin_amdgcn_wave_barrier();
+    d2v p01 = *(const LD2*)(own + i * 4), p23 = *(const LD2*)(own + i * 4 + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    const LD* cb = S.cpub + kb * 4 * 80;
+    d2v f0, f1, f2, f3, f4;
+    double ng;
+    // the flag word and what it guards in ONE LDS round trip: the reads are issued behind the flag read and LDS executes a wave's instructions in
+    // order, so values read behind a flag that reads "set" are the published ones; otherwise the whole batch is repeated
+    auto fetch = [&](int want) {
+        int n = 0;
+        for (;;) {
+            const int fv = *(S.fl + FL_C + kb);
+            asm volatile("" ::: "memory");
+            f0 = *(const LD2*)(cb + 0); f1 = *(const LD2*)(cb + 2); f2 = *(const LD2*)(cb + 4); f3 = *(const LD2*)(cb + 6); f4 = *(const LD2*)(cb + 8);
+            ng = cb[16 + lane];
+            asm volatile("" ::: "memory");
+            if (fv >= want || ++n > (1 << 22)) break;
+#if POTRF_SPIN_SLEEP
+            __builtin_amdgcn_s_sleep(POTRF_SPIN_SLEEP);
+#endif
+        }
+    };
+    fetch(1);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+#ifdef POTRF_DEBUG
+        if (kb == 1 && wave == 2) { const int gidx0 = S.dbg_gidx0; STRIPS_STAMP(16 + jb); }      // (factors of block jb read)
+#endif
+        Piv4 v;
+        v.r0 = f0.x; v.r1 = f0.y; v.r2 = f1.x; v.r3 = f1.y; v.l10 = f2.x; v.l20 = f2.y; v.l30 = f3.x; v.l21 = f3.y; v.l31 = f4.x; v.l32 = f4.y;
+        const double mw = subst4(p01.x, p01.y, p23.x, p23.y, v, g);  // M_w[i][g]
+        if (jb < 3) cur = __builtin_amdgcn_mfma_f64_16x16x4f64(-ng, mw, cur, 0, 0, 0);
+        dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-mw, mw, dg, 0, 0, 0);
+        if (jb < 3) {
+            cb += 80;
+            fetch(jb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur[jb] = mw;
+        if (jb < 3) {
+            own[i * 4 + g] = cur[jb + 1];
+            __builtin_amdgcn_wave_barrier();
+            p01 = *(const LD2*)(own + i * 4); p23 = *(const LD2*)(own + i * 4 + 2);
+        }
+#ifdef POTRF_DEBUG
+        if (kb == 1 && wave == 2) { const int gidx0 = S.dbg_gidx0; STRIPS_STAMP(20 + jb); }      // (block jb done)
+#endif
+    }
+}
+// The inverse of the diagonal block of column kb, formed by an IDLE wave one 4-column block behind the diagonal wave (round 5 ran this
+// forward elimination of the identity inside the chain; as a pass of its own behind the last chain it was 2.8k cycles of the tile's tail):
+// Y' -= (M diag(1 / L_cc), strictly below the diagonal) Z per block, M and the pivot factors as the diagonal wave published them;
+// returns x[t] = X[4 t + g][i], the MFMA result layout.
+__device__ __forceinline__ acc4 strips_invfollow(const CritLds& S, int kb, int wave, int lane, int* info) {
+    const int i = lane & 15, g = lane >> 4;
+    LD* own = S.own + 64 * wave;
+    acc4 yt, rrx;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) yt[t] = (4 * t + g == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const int j0 = 4 * jb;
+        own[g * 16 + i] = yt[jb];                                    // Y'[j0 + g][i]
+        __builtin_amdgcn_wave_barrier();
+        const double y0 = own[0 * 16 + i], y1 = own[1 * 16 + i], y2 = own[2 * 16 + i], y3 = own[3 * 16 + i];
+        __builtin_amdgcn_sched_barrier(0);
+        const LD* cb = S.cpub + (kb * 4 + jb) * 80;
+        fl_wait(S.fl + FL_C + kb, jb + 1, info);
+        const d2v f0 = *(const LD2*)(cb + 0), f1 = *(const LD2*)(cb + 2), f2 = *(const LD2*)(cb + 4), f3 = *(const LD2*)(cb + 6), f4 = *(const LD2*)(cb + 8);
+        const double mgv = cb[16 + lane];                            // M[i][g] = L[i][j0 + g] (zero above the diagonal)
+        const double r0 = f0.x, r1 = f0.y, r2 = f1.x, r3 = f1.y;
+        const double w10 = f2.x * r0, w20 = f2.y * r0, w30 = f3.x * r0, w21 = f3.y * r1, w31 = f4.x * r1, w32 = f4.y * r2;
+        const double z1 = fma(-w10, y0, y1);
+        const double z2 = fma(-w21, z1, fma(-w20, y0, y2));
+        const double z3 = fma(-w32, z2, fma(-w31, z1, fma(-w30, y0, y3)));
+        asm volatile("" :: "v"(z1), "v"(z2), "v"(z3));
+        const double zg = (g == 0) ? y0 : ((g == 1) ? z1 : ((g == 2) ? z2 : z3));
+        const double rg = (g == 0) ? r0 : ((g == 1) ? r1 : ((g == 2) ? r2 : r3));
+        const double sg = (i > j0 + g) ? mgv * rg : 0.0;             // L[i][j0+g] / L[j0+g][j0+g], strictly below the diagonal
+        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(-sg, zg, yt, 0, 0, 0);
+        rrx[jb] = rg;
+    }
+    acc4 x;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = (i > 4 * t + g) ? 0.0 : yt[t] * rrx[t];
+    return x;
+}
+// X_ww = L_ww^-1 from the register image of L_ww (a[t] = L[i][4 t + g], zero above the diagonal; rr[t] = 1 / L_cc, c = 4 t + g):
+// forward elimination of the identity with unscaled rows, four rows per exchange (the Y' half of factor16_wave); returns
+// x[t] = X[4 t + g][i], the MFMA result layout
+__device__ __forceinline__ acc4 invert16_regs(LD* own, const acc4& a, const acc4& rr, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    acc4 yt;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) yt[t] = (4 * t + g == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const int j0 = 4 * jb;
+        own[g * 16 + i] = yt[jb];                                    // Y'[j0 + g][i]
+        __builtin_amdgcn_wave_barrier();
+        const double y0 = own[0 * 16 + i], y1 = own[1 * 16 + i], y2 = own[2 * 16 + i], y3 = own[3 * 16 + i];
+        __builtin_amdgcn_wave_barrier();
+        // L[j0 + r][j0 + c] sits in a[jb] of lane (i = j0 + r, g = c); 1 / L_cc of column j0 + k in rr[jb] of lane (., g = k)
+        const double l10 = readlane_f64(a[jb], j0 + 1), l20 = readlane_f64(a[jb], j0 + 2), l30 = readlane_f64(a[jb], j0 + 3);
+        const double l21 = readlane_f64(a[jb], j0 + 2 + 16), l31 = readlane_f64(a[jb], j0 + 3 + 16), l32 = readlane_f64(a[jb], j0 + 3 + 32);
+        const double r0 = readlane_f64(rr[jb], 0), r1 = readlane_f64(rr[jb], 16), r2 = readlane_f64(rr[jb], 32);
+        const double w10 = l10 * r0, w20 = l20 * r0, w30 = l30 * r0, w21 = l21 * r1, w31 = l31 * r1, w32 = l32 * r2;
+        const double z1 = fma(-w10, y0, y1);
+        const double z2 = fma(-w21, z1, fma(-w20, y0, y2));
+        const double z3 = fma(-w32, z2, fma(-w31, z1, fma(-w30, y0, y3)));
+        const double zg = (g == 0) ? y0 : ((g == 1) ? z1 : ((g == 2) ? z2 : z3));
+        const double sg = (i > j0 + g) ? a[jb] * rr[jb] : 0.0;       // L[i][j0+g] / L[j0+g][j0+g], strictly below the diagonal
+        yt = __builtin_amdgcn_mfma_f64_16x16x4f64(-sg, zg, yt, 0, 0, 0);
+    }
+    acc4 x;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = (i > 4 * t + g) ? 0.0 : yt[t] * rr[t];
+    return x;
+}
+// block (r, c) of X from its result-layout registers: LDS image [row][XB] and the 64 x 64 row-major tile in global memory
+__device__ __forceinline__ void put_x(const CritLds& S, double* __restrict__ Xg, int r, int c, const acc4& x, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    LD* b = S.xs + xblk(r, c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        b[(g + 4 * q) * XB + i] = x[q];
+        Xg[(16 * r + g + 4 * q) * 64 + 16 * c + i] = x[q];
+    }
+    fl_set(S.fl + FL_X + 4 * r + c, 1, lane);
+}
+// one block column: the diagonal wave factors, the waves below follow, publish their panel block and update their trailing blocks
+// (kb is a run-time value: one copy of the code; the strip's blocks are read and written as WHOLE vectors under wave-uniform branches --
+// element writes into an array of vectors keep it in scratch)
+__device__ __forceinline__ void strips_step(const CritLds& S, int kb, acc4 (&a)[4], acc4 (&rks)[4], int wave, int lane, int* info, int gidx0,
+                                            int nvalid) {
+    if (wave < kb) return;
+    acc4 cur = a[0];
+    if (kb == 1) cur = a[1];
+    if (kb == 2) cur = a[2];
+    if (kb == 3) cur = a[3];
+    if (wave == kb) {
+        STRIPS_STAMP(48 + kb);                                       // (this chain starts)
+        strips_diag(S, kb, cur, rks, lane, info, gidx0, nvalid);
+        STRIPS_STAMP(12 + kb);
+    } else {
+        acc4 dg = (wave == 1) ? a[1] : ((wave == 2) ? a[2] : a[3]);  // this wave's own diagonal block
+        strips_follow(S, kb, cur, dg, wave, lane, info);
+        if (wave == 1) a[1] = dg;
+        else if (wave == 2) a[2] = dg;
+        else a[3] = dg;
+        if (wave == kb + 1) STRIPS_STAMP(52 + kb);                   // (the next diagonal wave has its panel block and its updated diagonal block)
+        if (kb == 0) {                                               // lpub lives in the P tile: every wave must have left the update phase
+            typedef int __attribute__((ext_vector_type(4))) i4v;
+            typedef __attribute__((address_space(3))) volatile i4v LVI4;
+            int n = 0;
+            for (;;) {                                               // (the four FL_P words in one read)
+                const i4v pd = *(LVI4*)(S.fl + FL_P);
+                if ((pd.x & pd.y & pd.z & pd.w) != 0 || ++n > (1 << 22)) break;
+            }
+            asm volatile("" ::: "memory");
+        }
+        LD* lp = S.lpub + lblk(wave, kb);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lp[t * 64 + lane] = cur[t];
+        fl_set(S.fl + FL_L + 4 * wave + kb, 1, lane);
+        if (kb == 1 && wave == 2) STRIPS_STAMP(24);                  // (panel block published)
+        // the blocks between: D_{w,cb} -= L_{w,kb} L_{cb,kb}^T for kb < cb < wave, in the a image: A operand = L_{cb,kb} (published image), B
+        // operand = the own L_{w,kb}; two accumulators per block (dependent fp64 MFMAs wait out their latency)
+#pragma unroll
+        for (int cb = 1; cb < 3; ++cb) {
+            if (cb <= kb || cb >= wave) continue;
+            fl_wait(S.fl + FL_L + 4 * cb + kb, 1, info);
+            const LD* lq = S.lpub + lblk(cb, kb);
+            acc4 d0 = a[cb], d1 = acc4{0, 0, 0, 0};
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[0 * 64 + lane], -cur[0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[1 * 64 + lane], -cur[1], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[2 * 64 + lane], -cur[2], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[3 * 64 + lane], -cur[3], d1, 0, 0, 0);
+            a[cb] = d0 + d1;
+        }
+    }
+    if (kb == 0) a[0] = cur;
+    else if (kb == 1) a[1] = cur;
+    else if (kb == 2) a[2] = cur;
+    else a[3] = cur;
+}
+// the W blocks (mb >= nb) a wave accumulates: rows of X at or below its own only (wave v's blocks have mb >= v)
+__device__ __forceinline__ void w_block(int wave, int s, int& mb, int& nb) {
+    //  wave 0: (0,0) (1,0) (3,0)    wave 1: (1,1) (2,0) (3,1)    wave 2: (2,1) (2,2)    wave 3: (3,2) (3,3)
+    mb = -1; nb = 0;
+    if (wave == 0) { mb = (s == 0) ? 0 : ((s == 1) ? 1 : 3); nb = 0; }
+    else if (wave == 1) { mb = (s == 0) ? 1 : ((s == 1) ? 2 : 3); nb = (s == 1) ? 0 : 1; }
+    else if (wave == 2) { if (s < 2) { mb = 2; nb = 1 + s; } }
+    else { if (s < 2) { mb = 3; nb = 2 + s; } }
+}
+// The whole tile: a[cb] (cb <= wave) = this wave's strip of the updated diagonal tile (identity padding of a ragged tile), 256 threads.
+// Ag: the tile's place in the matrix (lower triangle of its nvalid valid rows stored), Xg / Wg: X = L^-1 and W = X^T X, 64 x 64 each.
+__device__ __forceinline__ void factor64_strips(const CritLds& S, acc4 (&a)[4], int tid, int* info, int gidx0, int nvalid,
+                                                double* __restrict__ Ag, int64_t lda, double* __restrict__ Xg, double* __restrict__ Wg) {
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    acc4 rks[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rks[t] = acc4{1, 1, 1, 1};
+    if (wave == 0) STRIPS_STAMP(8);
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) strips_step(S, kb, a, rks, wave, lane, info, gidx0, nvalid);
+    // ---- the rest of the tile's work, in the order of urgency for the waves that wait on it.  Wave 0 inverts its own diagonal block (nobody
+    // is idle beside its chain); wave w < 3 forms the inverse of the NEXT diagonal block one 4-column block behind that chain.
+    if (wave == 0) {
+        acc4 rr;                                                  // rr[t] = 1 / L_cc of column c = 4 t + g
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rr[t] = (g == 0) ? rks[t][0] : ((g == 1) ? rks[t][1] : ((g == 2) ? rks[t][2] : rks[t][3]));
+        const acc4 xw = invert16_regs(S.own, a[0], rr, lane);
+        put_x(S, Xg, 0, 0, xw, lane);
+    }
+    // the zero blocks of X to the right of this wave's diagonal block, and COLUMN block `wave` of L: the diagonal block from the registers,
+    // the blocks below it from the images their waves published (those waves are busy with the next chains; wave 3 has only its own block,
+    // stored at the very end)
+    auto store_l = [&](acc4 lv, int rb, int cbk) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = 16 * rb + i, c = 16 * cbk + 4 * t + g;
+            if (r < nvalid && c <= r) Ag[(int64_t)r * lda + c] = lv[t];
+        }
+    };
+    if (wave < 3) {
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            if (c <= wave) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xg[(16 * wave + g + 4 * q) * 64 + 16 * c + i] = 0.0;
+        }
+        // (the diagonal block picked under wave-uniform branches with compile-time block indices: a block picked at run time -- a select of
+        //  references, or of the loaded vectors -- puts the whole array in memory)
+        if (wave == 0) store_l(a[0], 0, 0);
+        else if (wave == 1) store_l(a[1], 1, 1);
+        else store_l(a[2], 2, 2);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            if (r <= wave) continue;
+            fl_wait(S.fl + FL_L + 4 * r + wave, 1, info);
+            const LD* lq = S.lpub + lblk(r, wave);
+            acc4 lv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) lv[t] = lq[t * 64 + lane];
+            store_l(lv, r, wave);
+        }
+        // T_{w+1,w} = L_{w+1,w} X_ww BEFORE the inverse of the next diagonal block is followed (both operands exist soon after this wave's own
+        // chain; for wave 2 this is T_{3,2}: X_{3,2} then leaves four MFMAs after X_33, not 2k cycles)
+        fl_wait(S.fl + FL_X + 5 * wave, 1, info);                    // X_ww (wave w - 1 formed it; wave 0 its own)
+        fl_wait(S.fl + FL_L + 4 * (wave + 1) + wave, 1, info);
+        acc4 tn0 = acc4{0, 0, 0, 0}, tn1 = acc4{0, 0, 0, 0};
+        {
+            const LD* lq = S.lpub + lblk(wave + 1, wave);
+            const LD* xq = S.xs + xblk(wave, wave);
+            tn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[0 * 64 + lane], xq[(0 + g) * XB + i], tn0, 0, 0, 0);
+            tn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[1 * 64 + lane], xq[(4 + g) * XB + i], tn1, 0, 0, 0);
+            tn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[2 * 64 + lane], xq[(8 + g) * XB + i], tn0, 0, 0, 0);
+            tn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[3 * 64 + lane], xq[(12 + g) * XB + i], tn1, 0, 0, 0);
+        }
+        const acc4 Tn = tn0 + tn1;
+        if (wave == 2) STRIPS_STAMP(58);                             // (T_{3,2} formed)
+        const acc4 xn = strips_invfollow(S, wave + 1, wave, lane, info);
+        put_x(S, Xg, wave + 1, wave + 1, xn, lane);
+        if (wave == 2) STRIPS_STAMP(9);
+        {   // X_{w+1,w} = -X_{w+1,w+1} Tn
+            const LD* xr = S.xs + xblk(wave + 1, wave + 1);
+            acc4 x0 = acc4{0, 0, 0, 0}, x1 = acc4{0, 0, 0, 0};
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 0 + g], Tn[0], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 4 + g], Tn[1], x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 8 + g], Tn[2], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 12 + g], Tn[3], x1, 0, 0, 0);
+            put_x(S, Xg, wave + 1, wave, x0 + x1, lane);
+            if (wave == 2) STRIPS_STAMP(57);                         // (X_{3,2} published)
+        }
+    }
+    // ---- X_{r,w} for the rows below (what the other waves wait for): T_{r,c} = sum_{j = c}^{r-1} L_{r,j} X_{j,c} (A operand lane (m, k) =
+    // L_{r,j}[m][4 t + k], the published register image; B operand lane (n, k) = X_{j,c}[4 t + k][n]), then X_{r,c} = -X_rr T (A operand lane
+    // (m, k) = X_rr[m][4 t + k], B operand = register t of T: its result layout).  Rows 1, 2 in full; of row 3 first T only -- X_33 is the last
+    // thing the tile produces, the blocks of W that do not need it come in between.
+    acc4 wacc[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wacc[s] = acc4{0, 0, 0, 0};
+    auto w_row = [&](int r) {       // W_{mb,nb} += X_{r,mb}^T X_{r,nb} for this wave's blocks with mb <= r: ONE poll for the row (xflag[r][0..3] in one
+                                    // read: a poll is an LDS round trip, ~100 cycles), the blocks' MFMAs interleaved (independent accumulators)
+        typedef int __attribute__((ext_vector_type(4))) i4v;
+        typedef __attribute__((address_space(3))) volatile i4v LVI4;
+        int n = 0;
+        for (;;) {
+            const i4v xf = *(LVI4*)(S.fl + FL_X + 4 * r);
+            const int have = (xf.x != 0) + (r >= 1 ? (xf.y != 0) : 1) + (r >= 2 ? (xf.z != 0) : 1) + (r >= 3 ? (xf.w != 0) : 1);
+            if (have == 4 || ++n > (1 << 22)) break;
+#if POTRF_SPIN_SLEEP
+            __builtin_amdgcn_s_sleep(POTRF_SPIN_SLEEP);
+#endif
+        }
+        asm volatile("" ::: "memory");
+        double wa[3][4], wb[3][4];
+        bool on[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int mb, nb;
+            w_block(wave, s, mb, nb);
+            on[s] = mb >= 0 && mb <= r;
+            const LD* xa = S.xs + xblk(r, on[s] ? mb : 0);
+            const LD* xb = S.xs + xblk(r, on[s] ? nb : 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                wa[s][t] = xa[(4 * t + g) * XB + i];
+                wb[s][t] = xb[(4 * t + g) * XB + i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (on[s]) wacc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s][t], wb[s][t], wacc[s], 0, 0, 0);      // (wave-uniform)
+    };
+#pragma unroll
+    for (int r = 2; r < 4; ++r) {
+        if (r <= wave + 1) continue;                                 // (row wave + 1: above)
+        const int c = wave;
+        acc4 t0 = acc4{0, 0, 0, 0}, t1 = acc4{0, 0, 0, 0};
+        {   // ONE poll for the panel blocks L_{r,c..r-1} (lflag[r][0..3] in one read); X_{j,c}, j > c, are this wave's own earlier rows
+            typedef int __attribute__((ext_vector_type(4))) i4v;
+            typedef __attribute__((address_space(3))) volatile i4v LVI4;
+            int n = 0;
+            for (;;) {
+                const i4v lf = *(LVI4*)(S.fl + FL_L + 4 * r);
+                const int have = ((c > 0) | (lf.x != 0)) + ((c > 1 || r <= 1) | (lf.y != 0)) + ((r <= 2) | (lf.z != 0));
+                if (have == 3 || ++n > (1 << 22)) break;
+            }
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < c || j >= r) continue;
+            const LD* lq = S.lpub + lblk(r, j);
+            const LD* xq = S.xs + xblk(j, c);
+            t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[0 * 64 + lane], xq[(0 + g) * XB + i], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[1 * 64 + lane], xq[(4 + g) * XB + i], t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[2 * 64 + lane], xq[(8 + g) * XB + i], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lq[3 * 64 + lane], xq[(12 + g) * XB + i], t1, 0, 0, 0);
+        }
+        const acc4 T = t0 + t1;
+        if (r == 3) {
+            if (wave == 0) STRIPS_STAMP(60);                         // (T_{3,0} formed)
+            if (wave == 1) STRIPS_STAMP(59);
+#pragma unroll
+            for (int rr_ = 0; rr_ < 3; ++rr_) if (rr_ >= wave) w_row(rr_);      // (waves 0, 1: the rows of W that do not need X_33, while chain 3 runs)
+        }
+        fl_wait(S.fl + FL_X + 4 * r + r, 1, info);
+        if (r == 3 && wave == 0) STRIPS_STAMP(61);                   // (X_33 seen)
+        const LD* xr = S.xs + xblk(r, r);
+        acc4 x0 = acc4{0, 0, 0, 0}, x1 = acc4{0, 0, 0, 0};
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 0 + g], T[0], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 4 + g], T[1], x1, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 8 + g], T[2], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr[i * XB + 12 + g], T[3], x1, 0, 0, 0);
+        put_x(S, Xg, r, c, x0 + x1, lane);
+        if (r == 3 && wave == 0) STRIPS_STAMP(62);                   // (X_{3,0} published)
+        if (r == 3 && wave == 1) STRIPS_STAMP(56);
+    }
+    if (wave == 2) w_row(2);
+    if (wave == 3) STRIPS_STAMP(25);
+    w_row(3);
+    if (wave == 0) STRIPS_STAMP(63);                                 // (row 3 of W taken by wave 0)
+    if (wave == 3) STRIPS_STAMP(26);                                 // (... by wave 3)
+    if (wave == 3) STRIPS_STAMP(27);                                 // (wave 3: its W blocks accumulated)
+    // W blocks -> the 64 x 64 tile, both triangles.  The mirrored block goes through LDS (the cpub words are free now: every reader of them is
+    // behind the row-3 flags), so that its stores run along rows too -- stored from the registers, one instruction touched 64 cache lines and
+    // the 12 of them were ~2k cycles at the very end of the critical workgroup
+    LD* tw = S.cpub + 272 * wave;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int mb, nb;
+        w_block(wave, s, mb, nb);
+        if (mb < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = 16 * mb + g + 4 * q, nn = 16 * nb + i;
+            Wg[m * 64 + nn] = wacc[s][q];
+            tw[(g + 4 * q) * XB + i] = wacc[s][q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mb != nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Wg[(16 * nb + g + 4 * q) * 64 + 16 * mb + i] = tw[i * XB + g + 4 * q];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (wave == 3) {
+        const acc4 l33 = a[3];
+        store_l(l33, 3, 3);
+    }
+    STRIPS_STAMP(28 + wave);                                         // this wave is done
+#ifdef POTRF_DEBUG
+    if (gidx0 == (POTRF_DEBUG_K + 1) * 64) {                         // the stamp words of this wave's slots -> chol_dbg (slots 8 .. 63; 0 .. 7 belong to CHOL_STAMP)
+        __syncthreads();
+        if (tid >= 8 && tid < 64) chol_dbg[tid] = S.dbg[tid];
+    }
+#endif
+}
+
+// The update phase for factor64_strips: as crit_tile_update (P = A X_k^T strip by strip, P back to LDS, D = C - P P^T), but EVERY wave's
+// blocks come out in the a image: block (w, nb) as the transposed product  D^T = C^T - P_nb P_w^T  (A operand: P_nb out of LDS, B operand:
+// the registers of U = P_w^T), C loaded in the a image.  k < 0: the first tile of the matrix, loaded as it is.
+__device__ __forceinline__ void crit_strips_update(double (*S)[64][LDT], const double* __restrict__ A, int64_t lda, int n, int k,
+                                                   const double* __restrict__ Xk, int tid, acc4 (&a)[4], LVI* fl
+#ifdef POTRF_DEBUG
+                                                   , unsigned long long* st_
+#endif
+                                                   ) {
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int i0 = (k + 1) * 64, nr = n - i0;
+    if (tid < FL_N) fl[tid] = 0;
+    // this strip's blocks of C in the a image (clamped addresses, masked below): requested BEHIND the operands of the first product
+    // (loads return in order: in front of them they held up the LDS fill by 1.5k cycles)
+    auto load_c = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb > wave) { a[nb] = acc4{0, 0, 0, 0}; continue; }
+            acc4 cv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gr = min(i0 + 16 * wave + i, n - 1), gc = min(i0 + 16 * nb + 4 * q + g, n - 1);
+                cv[q] = A[(int64_t)gr * lda + gc];
+            }
+            a[nb] = cv;
+        }
+    };
+    if (k >= 0) {
+        const int k0 = k * 64;
+        {
+            double ra[16], rw[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {           // (rows past the matrix: clamped row index, zeroed on the way to LDS -- no branch per load)
+                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+                rw[u] = Xk[r * 64 + c];
+                ra[u] = A[(int64_t)min(i0 + r, n - 1) * lda + k0 + c];
+            }
+            load_c();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = (tid >> 6) + 4 * u, c = tid & 63;
+                S[0][r][c] = (i0 + r < n) ? ra[u] : 0.0;
+                S[1][r][c] = rw[u];
+            }
+        }
+        __syncthreads();
+        CHOL_STAMP(1);
+        // U = X_k A_w^T = P_w^T (X_k lower triangular: column block cb of P needs the k blocks 0 .. cb only)
+        acc4 U[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) U[cb] = acc4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int kq = 4 * ks + g;
+            const double bop = S[0][16 * wave + i][kq];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                if (cb < (ks >> 2)) continue;
+                U[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1][16 * cb + i][kq], bop, U[cb], 0, 0, 0);
+            }
+        }
+        CHOL_STAMP(4);
+        __syncthreads();                 // X_k is dead: its tile becomes xs / cpub
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[0][16 * wave + i][16 * cb + 4 * q + g] = U[cb][q];
+        __syncthreads();
+        CHOL_STAMP(5);
+        if (wave == 0) {                 // one block: two accumulators
+            acc4 d1 = acc4{0, 0, 0, 0};
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double aop = S[0][i][16 * cb + 4 * q + g];
+                    if (q & 1) d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, -U[cb][q], d1, 0, 0, 0);
+                    else a[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, -U[cb][q], a[0], 0, 0, 0);
+                }
+            a[0] += d1;
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        if (nb > wave) continue;
+                        a[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0][16 * nb + i][16 * cb + 4 * q + g], -U[cb][q], a[nb], 0, 0, 0);
+                    }
+        }
+        CHOL_STAMP(7);
+    } else {
+        load_c();
+        __syncthreads();                 // (the flag words are zero for every wave)
+    }
+    fl_set(fl + FL_P + wave, 1, lane);   // this wave is done with the P tile
+    // identity padding of a ragged tile, zero above the diagonal
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb > wave) continue;
+        acc4 mv = a[nb];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * wave + i, c = 16 * nb + 4 * q + g;
+            const bool in = r < nr && c <= r;
+            mv[q] = in ? mv[q] : ((r == c) ? 1.0 : 0.0);
+        }
+        a[nb] = mv;
+    }
+}
+#endif      // POTRF_CRIT_STRIPS
+
 #ifndef POTRF_MINW
 #define POTRF_MINW (POTRF_NW / 2)
 #endif
@@ -1211,7 +1923,42 @@ __global__ __launch_bounds__(64 * NW, PIPE ? POTRF_PIPE_MINW : POTRF_MINW) void 
 #endif
         return;
     }
-#if POTRF_CRIT_SLIVER
+#if POTRF_CRIT_STRIPS && POTRF_CRIT_PFORM
+    if (NW == 4 && b == 0) {                       // the critical workgroup (k = -1: the matrix's first tile, a launch of its own)
+        CHOL_STAMP_DECL;
+        CHOL_STAMP(0);
+        acc4 a[4];
+        CritLds cl;
+        cl.xs = (LD*)&S[1][0][0];                  // (the X_k tile: dead after the first product of the update)
+        cl.cpub = cl.xs + 10 * 16 * XB;
+        cl.lpub = (LD*)&S[0][0][0];                // (the P tile: written only behind the FL_P flags)
+        cl.own = (LD*)&Xd[0][0];
+        cl.fl = (LVI*)colbuf;
+#ifdef POTRF_DEBUG
+        cl.dbg = (__attribute__((address_space(3))) unsigned long long*)rowbuf;
+        if (tid < 64) cl.dbg[tid] = 0;
+        cl.dbg_gidx0 = (k + 1) * 64;
+#endif
+        static_assert(10 * 16 * XB + 16 * 80 <= 64 * LDT && 4 * 272 <= 16 * 80 && 6 * 256 <= 64 * LDT && 4 * 64 <= 16 * 17 && FL_N * sizeof(int) <= 64 * sizeof(double),
+                      "LDS views of the critical workgroup");
+#ifdef POTRF_DEBUG
+        crit_strips_update(S, A, lda, n, k, Xws + (size_t)(k < 0 ? 0 : k) * 4096, tid, a, cl.fl, st_);
+        st_[6] = st_[5];
+#else
+        crit_strips_update(S, A, lda, n, k, Xws + (size_t)(k < 0 ? 0 : k) * 4096, tid, a, cl.fl);
+#endif
+        CHOL_STAMP(2);
+        TR(1);
+        const int kk = k + 1, r0 = kk * 64, nr = (n - r0 < 64) ? (n - r0) : 64;
+        factor64_strips(cl, a, tid, info, r0, nr, A + (int64_t)r0 * lda + r0, lda, Xws + (size_t)kk * 4096, Wws + (size_t)kk * 4096);
+        CHOL_STAMP(3);
+        CHOL_STAMP_FLUSH;
+        TR(2);
+        TR_VAL(22, 0);
+        TR_FLUSH;
+        return;
+    }
+#elif POTRF_CRIT_SLIVER
     if (NW == 4 && b == 0 && k >= 0) {             // the critical workgroup: update of the next diagonal tile ordered for the chain
         CHOL_STAMP_DECL;
         CHOL_STAMP(0);
@@ -1671,7 +2418,7 @@ extern "C" int dsvgp_debug_potrf_trace(unsigned long long* out, int nwg) {
 #endif
 #ifdef POTRF_DEBUG
 extern "C" int dsvgp_debug_potrf_clock(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 32);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chol_dbg), sizeof(unsigned long long) * 64);
 }
 
 #endif
