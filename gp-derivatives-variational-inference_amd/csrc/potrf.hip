@@ -1298,7 +1298,8 @@ typedef __attribute__((address_space(3))) d2v LD2;
 // cur = D_kk -> L_kk (zero above the diagonal), rks[jb] = the four 1 / L_cc of block jb (the same in every lane).  Per 4-column block: the
 // strip's column block goes through the wave's own LDS words once (row i's four entries for the substitution; rows j0 .. j0+3 are the pivot
 // block, read as broadcasts), P_00 alone comes by v_readlane so that the first 1 / sqrt starts at once; the pivot factors (cpub[kb][jb][0..9])
-// and the block M (the followers' A operand, lane for lane: cpub[..][16 + lane]) are published with ONE flag per block (cflag = jb + 1),
+// and the block M (the followers' A operand, lane for lane: cpub[..][16 + lane]) are published with ONE flag per block (cflag = jb + 1; the last block:
+// 4 behind the factors, 5 behind M),
 // behind the MFMA of the rank-4 update (the publication rides under its latency).
 __device__ __forceinline__ void strips_diag(const CritLds& S, int kb, acc4& cur, acc4 (&rks)[4], int lane, int* info, int gidx0, int nvalid) {
     const int i = lane & 15, g = lane >> 4;
@@ -1321,11 +1322,12 @@ __device__ __forceinline__ void strips_diag(const CritLds& S, int kb, acc4& cur,
             cb[0] = v.r0; cb[1] = v.r1; cb[2] = v.r2; cb[3] = v.r3; cb[4] = v.l10; cb[5] = v.l20; cb[6] = v.l30; cb[7] = v.l21; cb[8] = v.l31;
             cb[9] = v.l32;
         }
+        if (jb == 3) fl_set(S.fl + FL_C + kb, 4, lane);              // (the followers' last block needs the factors only: the next chain starts ~0.4k earlier)
         const double mraw = subst4(p01.x, p01.y, p23.x, p23.y, v, g);
         const double mg = (i >= j0 + g) ? mraw : 0.0;
         if (jb < 3) cur = __builtin_amdgcn_mfma_f64_16x16x4f64(-mg, mg, cur, 0, 0, 0);      // D -= M M^T (the last block has nothing behind it)
         cb[16 + lane] = mg;
-        fl_set(S.fl + FL_C + kb, jb + 1, lane);
+        fl_set(S.fl + FL_C + kb, jb < 3 ? jb + 1 : 5, lane);         // (5: the last M block is out too -- the wave that forms the inverse reads it)
         cur[jb] = mg;
         rks[jb] = acc4{v.r0, v.r1, v.r2, v.r3};
         STRIPS_STAMP(32 + 4 * kb + jb);                              // (end of block jb)
@@ -1421,7 +1423,7 @@ __device__ __forceinline__ acc4 strips_invfollow(const CritLds& S, int kb, int w
         const double y0 = own[0 * 16 + i], y1 = own[1 * 16 + i], y2 = own[2 * 16 + i], y3 = own[3 * 16 + i];
         __builtin_amdgcn_sched_barrier(0);
         const LD* cb = S.cpub + (kb * 4 + jb) * 80;
-        fl_wait(S.fl + FL_C + kb, jb + 1, info);
+        fl_wait(S.fl + FL_C + kb, jb < 3 ? jb + 1 : 5, info);
         const d2v f0 = *(const LD2*)(cb + 0), f1 = *(const LD2*)(cb + 2), f2 = *(const LD2*)(cb + 4), f3 = *(const LD2*)(cb + 6), f4 = *(const LD2*)(cb + 8);
         const double mgv = cb[16 + lane];                            // M[i][g] = L[i][j0 + g] (zero above the diagonal)
         const double r0 = f0.x, r1 = f0.y, r2 = f1.x, r3 = f1.y;
