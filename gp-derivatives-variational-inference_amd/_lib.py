@@ -95,9 +95,11 @@ SIGNATURES = {
     "dsvgp_column_mean": (_i, [_p, _p, _i, _i, _p]),
     "dsvgp_pack_points": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dsvgp_kernel_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _f, _p, _l, _i]),
+    "dsvgp_kernel_fwd_canon": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _l]),
     "dsvgp_kernel_diag": (_i, [_p, _i, _i, _p, _p]),
     "dsvgp_kernel_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_kernel_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "dsvgp_kernel_bwd_canon": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     "dsvgp_pack_points_f64": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dsvgp_kernel_transform_f64": (_i, [_p, _p, _l, _p, _i, _p, _i, _i, _p, _d]),
     "dsvgp_kernel_bwd_transform_f64": (_i, [_p, _p, _l, _p, _l, _p, _i, _p, _i, _i, _p, _p]),

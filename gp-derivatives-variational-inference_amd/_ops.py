@@ -222,6 +222,38 @@ def kernel_fwd(ctx, pack1, n1, pack2, n2, d, p, hyp, jitter=0.0, out=None, dtype
     return out
 
 
+def canon_supported(d, p):
+    """geometries the canonical-direction assembly kernels take (csrc/assemble.hip): p + 1 in {3, 6}, packed width <= 32"""
+    return (p + 1) in (3, 6) and ((d + 3) // 4 * 4 + 4 + 15) // 16 * 16 <= 32
+
+
+def kernel_fwd_canon(ctx, pack1, n1, pack2, n2, d, p, dir_idx, idx_base, hyp, out=None):
+    """K(x1, x2; v1, E[dir_idx - idx_base]) with canonical (one-hot) directions on side 2 shared by all its points (the reference's K_ZX:
+    directional_vi.py:81-88, 238, 292-294).  dir_idx: int32 device tensor with p entries."""
+    q = p + 1
+    if out is None:
+        out = torch.empty(n1 * q, n2 * q, dtype=f32, device=pack1[0].device)
+    _req(out, f32, "out", 2)
+    if dir_idx.dtype != torch.int32 or not dir_idx.is_cuda or dir_idx.numel() != p or not dir_idx.is_contiguous():
+        raise ValueError("dir_idx must be a contiguous int32 GPU tensor with p entries")
+    check(lib.dsvgp_kernel_fwd_canon(ctx.h, _ptr(pack1[0]), _ptr(pack1[1]), n1, _ptr(pack2[0]), _ptr(pack2[1]), n2, d, p, _ptr(dir_idx),
+                                     int(idx_base), _ptr(hyp), _ptr(out), _ld(out)), "dsvgp_kernel_fwd_canon")
+    return out
+
+
+def kernel_bwd_canon(ctx, G, pack1, n1, pack2, n2, d, p, dir_idx, idx_base, hyp, d_x1, d_v1, d_hyp, workspace=None):
+    P1, s1, vn1 = pack1
+    isd = G.dtype == f64
+    _req(G, f64 if isd else f32, "G", 2)
+    nbytes = int(lib.dsvgp_kernel_bwd_workspace_bytes(n1, n2, d, p))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=G.device)
+    check(lib.dsvgp_kernel_bwd_canon(ctx.h, _ptr(G), _ld(G), 1 if isd else 0, _ptr(P1), _ptr(s1), _ptr(vn1), n1, _ptr(pack2[0]),
+                                     _ptr(pack2[1]), n2, d, p, _ptr(dir_idx), int(idx_base), _ptr(hyp), _ptr(d_x1), _ptr(d_v1), _ptr(d_hyp),
+                                     _ptr(workspace)), "dsvgp_kernel_bwd_canon")
+    return workspace
+
+
 # ---- fp64 model mode (csrc/assemble64.hip) ---------------------------------------------------------------------
 def pack_points_f64(ctx, x, v, p, hyp, center=None):
     """-> (P[n(p+1), DP], self[n(p+1)], vnorm[n p]) in double precision"""

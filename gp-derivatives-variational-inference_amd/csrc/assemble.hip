@@ -2046,7 +2046,584 @@ inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int
     else launch_bwd<GT, 0, BWD_GCH>(st, grid, lds, G, ldg, P1, self1, n1q, P2, self2, n2q, g, gvec, hyp, slab, partials);
 }
 
+// =================================================================================================
+// Canonical (one-hot) directions on side 2, the same for every point of side 2 (round 6).
+// The reference's callers guarantee this structure for K_ZX: at training time the data directions are the canonical vectors of the
+// sampled derivative columns, tiled over the minibatch (directional_vi.py:81-88, 238), at evaluation time eye(d)[:p] (:292-294).
+// With v2_b = e_{c_b} the inner products of the general formulation collapse:
+//     T0b = x1~ . v2_b = x1~[c_b],   beta_b = x2~ . v2_b = x2~[c_b]      =>  w_b = x1~[c_b] - x2~[c_b]
+//     Tab = v1_a . v2_b = v1_a[c_b]                                        (the same for every point of side 2)
+// so only T00 = x1~ . x2~ and Ta0 = v1_a . x2~ are products: U = P1' X2'^T with ONE column per point of side 2 (not q) -- 1/q of
+// the MFMA work and of the fragment traffic of T' = P1' P2'^T, and no T' round trip through LDS for (q - 1) / q of the columns.
+// Backward: Tbar's direction columns contract with one-hot rows, i.e. they are COLUMN SUMS into packed column c_b (accumulated per
+// lane over the sweep, reduced across the lanes of a point once per workgroup); only its value columns go through the MFMA
+// (dP1 += Tbar[:, c0] X2', K = points of the tile instead of 48).
+// One wave per workgroup, 48-row tiles of side 1 x 48-column tiles of the output, lane <-> point pair(s), as the pair kernels.
+// q in {3, 6}, packed width <= 32 (d <= 28: BASELINE configs 2 and 4), float output / float or double upstream.
+// dir_idx[p] (device memory): coordinate of direction b is dir_idx[b] - idx_base.
+// =================================================================================================
+constexpr int CAN_LDT = 52;            // row stride of the 48 x 48 output / upstream tile in LDS (even: 8-byte strips; 16-byte aligned rows)
+#ifndef CAN_FWD_WGS
+#define CAN_FWD_WGS (256 * 12)
+#endif
+#ifndef CAN_BWD_WGS
+#define CAN_BWD_WGS (256 * 8)
+#endif
+#ifndef CAN_ABL
+#define CAN_ABL 0                      // tools only (results wrong): 1 = no global stores (forward), 2 = no U product
+#endif
+
+// what both kernels share: the A fragments of the wave's 48 side-1 rows (self terms folded as in the pair kernels: column K4 + 2 of P1' =
+// -alpha_a for a > 0 against a 1 in the value rows of side 2, so that U[ra, j] = v1_a . x2~_j - alpha_a = -u_a), and U for one column tile
+template <int Q>
+struct CanTile {
+    static constexpr int R = 48 / Q, PPL = (R * R + 63) / 64;
+};
+
+template <int Q>
+__global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __restrict__ P1, const float* __restrict__ self1, int n1q,
+                                                              const float* __restrict__ P2, const float* __restrict__ self2, int n2,
+                                                              int K4, int DP, const int* __restrict__ dir_idx, int idx_base, int ovec,
+                                                              const float* __restrict__ hyp, float* __restrict__ out, int64_t ld) {
+    constexpr int R = 48 / Q, T = 48, PPL = CanTile<Q>::PPL, NPAIR = R * R, KSM = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDX = K4 + 5;                 // row stride of the staged side-2 value rows [16][LDX]: columns K4 + 2 = 1, K4 + 3 = |x2~|^2
+    float* Xs = smem;                       // [16][LDX]
+    float* TT = smem + ((16 * LDX + 3) & ~3);     // [48][CAN_LDT]: U^T ([point][row], rows 0 .. R-1) first, then the output tile
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * T;
+    const int n2q = n2 * Q;
+    const int ncoltiles = (n2 + R - 1) / R;
+    const int KS = K4 / 4 + 1;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+    int cidx[Q];                            // coordinate of direction b (b >= 1)
+#pragma unroll
+    for (int b = 1; b < Q; ++b) cidx[b] = dir_idx[b - 1] - idx_base;
+    cidx[0] = 0;
+
+    float areg[3][KSM];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int gr = row0 + i * 16 + m16;
+        const bool ok = gr < n1q;
+        const int a = (i * 16 + m16) % Q;
+        const float sf = ok ? self1[gr] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            float v = 0.f;
+            if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
+            else if (ks == K4 / 4 && ok) v = (kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f;
+            areg[i][ks] = v;
+        }
+    }
+    // per-pair constants of side 1: |x1~|^2, x1~[c_b], v1_a[c_b]
+    int pi_[PPL], pj_[PPL];
+    bool prow[PPL];
+    float nrm1[PPL], zc[PPL][Q], gc[PPL][Q][Q];
+#pragma unroll
+    for (int pp = 0; pp < PPL; ++pp) {
+        const int pid = lane + 64 * pp;
+        pi_[pp] = pid / R; pj_[pp] = pid - pi_[pp] * R;
+        const int r0 = row0 + pi_[pp] * Q;
+        prow[pp] = pid < NPAIR && r0 < n1q;
+        nrm1[pp] = prow[pp] ? self1[r0] : 0.f;
+#pragma unroll
+        for (int b = 1; b < Q; ++b) {
+            zc[pp][b] = prow[pp] ? P1[(int64_t)r0 * DP + cidx[b]] : 0.f;
+#pragma unroll
+            for (int a = 1; a < Q; ++a) gc[pp][a][b] = prow[pp] ? P1[(int64_t)(r0 + a) * DP + cidx[b]] : 0.f;
+        }
+    }
+    for (int e = lane; e < 16 * LDX; e += 64) Xs[e] = 0.f;
+    const int pch = DP / 4;                 // float4 per packed row
+    const bool rows_full = row0 + T <= n1q;
+
+    const int cper = (ncoltiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ct_lo = blockIdx.x * cper, ct_hi = min(ct_lo + cper, ncoltiles);
+    // the tile's R value rows of P2: float4 number e = lane (< R pch <= 128: two per lane at most) of [R][DP]
+    f4 pf[2];
+    float pnrm = 0.f;
+    auto prefetch = [&](int ct_) {
+        const int j0 = ct_ * R;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (e < R * pch && j0 + r < n2) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(j0 + r) * Q * DP + k);
+        }
+        pnrm = (lane < R && j0 + lane < n2) ? self2[(int64_t)(j0 + lane) * Q] : 0.f;
+    };
+    if (ct_lo < ct_hi) prefetch(ct_lo);
+    for (int ct = ct_lo; ct < ct_hi; ++ct) {
+        const int j0 = ct * R, col0 = j0 * Q;
+        __syncthreads();                    // (single wave: the previous tile's LDS reads are behind us)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            if (e < R * pch) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Xs[r * LDX + k + t] = pf[u][t];
+            }
+        }
+        __syncthreads();                    // (the extension columns go on top of the packed row's own columns K4 ..)
+        if (lane < R) {
+            Xs[lane * LDX + K4 + 1] = 0.f;
+            Xs[lane * LDX + K4 + 2] = (j0 + lane < n2) ? 1.f : 0.f;
+            Xs[lane * LDX + K4 + 3] = pnrm;
+        }
+        if (ct + 1 < ct_hi) prefetch(ct + 1);
+        __syncthreads();
+        // U = P1' X2'^T: 3 row tiles x (one 16-column tile of which R columns are points), K = K4 + 4
+        f4 t[3];
+        {
+            const float* pb = Xs + m16 * LDX + kg;
+            auto product = [&](auto ksc) {
+                constexpr int KS_ = decltype(ksc)::value;
+#pragma unroll
+                for (int ks = 0; ks < KS_; ++ks) {
+                    const float bv = pb[ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        t[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv, ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i], 0, 0, 0);
+                }
+            };
+            switch ((CAN_ABL & 2) ? 1 : KS) {
+                case 1: product(std::integral_constant<int, 1>{}); break;
+                case 2: product(std::integral_constant<int, 2>{}); break;
+                case 3: product(std::integral_constant<int, 3>{}); break;
+                case 4: product(std::integral_constant<int, 4>{}); break;
+                case 5: product(std::integral_constant<int, 5>{}); break;
+                case 6: product(std::integral_constant<int, 6>{}); break;
+                case 7: product(std::integral_constant<int, 7>{}); break;
+                default: product(std::integral_constant<int, 8>{}); break;
+            }
+        }
+        // U^T -> LDS: lane (point m16, kg) holds rows 16 i + 4 kg .. + 3 of column m16: four consecutive floats of row m16 of [point][row]
+        if (m16 < R) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f4*>(TT + m16 * CAN_LDT + i * 16 + kg * 4) = t[i];
+        }
+        __syncthreads();
+        float v[PPL][Q][Q];
+        bool mine[PPL];
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            float uq[Q], xc[Q];
+            const float* up = TT + pj_[pp] * CAN_LDT + pi_[pp] * Q;
+            const float* xp = Xs + pj_[pp] * LDX;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) uq[a] = up[a];
+#pragma unroll
+            for (int b = 1; b < Q; ++b) xc[b] = xp[cidx[b]];
+            const float nrm2 = xp[K4 + 3];
+            mine[pp] = prow[pp] && j0 + pj_[pp] < n2;
+            const float nn = fmaxf(nrm1[pp] + nrm2 - 2.f * uq[0], 0.f);     // covar_dist clamps at 0
+            const float k = s * expf(-0.5f * nn);                             // postprocess_rbf, ScaleKernel
+            const float kil = k * il, kil2 = k * il2;
+            v[pp][0][0] = k;
+#pragma unroll
+            for (int b = 1; b < Q; ++b) v[pp][0][b] = (zc[pp][b] - xc[b]) * kil;                                  // w_b k / ell
+#pragma unroll
+            for (int a = 1; a < Q; ++a) {
+                v[pp][a][0] = uq[a] * kil;                                                                          // -u_a k / ell
+#pragma unroll
+                for (int b = 1; b < Q; ++b) v[pp][a][b] = (gc[pp][a][b] + uq[a] * (zc[pp][b] - xc[b])) * kil2;      // (G_ab - u_a w_b) k / ell^2
+            }
+        }
+        __syncthreads();                    // every lane has read its U values: the output tile may overlay them
+        const bool full = rows_full && col0 + T <= n2q && (ovec & 2);
+        if (full) {
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) {
+                if (lane + 64 * pp < NPAIR) {
+                    float* blk = TT + pi_[pp] * Q * CAN_LDT + pj_[pp] * Q;
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) {
+                        if constexpr (Q % 2 == 0) {
+                            using F2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int b = 0; b < Q; b += 2) *reinterpret_cast<F2*>(blk + a * CAN_LDT + b) = F2{v[pp][a][b], v[pp][a][b + 1]};
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < Q; ++b) blk[a * CAN_LDT + b] = v[pp][a][b];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            float* orow = out + (int64_t)row0 * ld + col0;
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {   // the tile leaves as nine fully coalesced 16-byte store instructions (rows of 192 bytes)
+                const int id = lane + 64 * u, r = id / 12, c4 = (id - 12 * r) * 4;
+                const f4 x = *reinterpret_cast<const f4*>(TT + r * CAN_LDT + c4);
+                if (!(CAN_ABL & 1)) *reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4) = x;
+            }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) {
+                if (!mine[pp]) continue;
+                float* o = out + (int64_t)(row0 + pi_[pp] * Q) * ld + col0 + pj_[pp] * Q;
+#pragma unroll
+                for (int a = 0; a < Q; ++a)
+#pragma unroll
+                    for (int b = 0; b < Q; ++b) o[a * ld + b] = v[pp][a][b];
+            }
+        }
+    }
+}
+
+// backward: upstream micro-blocks HBM -> registers, the pair kernel's transform with (w_b, -u_a, G_ab) from the canonical sources;
+// Tbar's value columns -> LDS as the A operand of dP1 += Tbar[:, c0] X2' (K = the R points of the tile), its direction columns ->
+// per-lane column sums S[a][b]; at the end of the sweep S is added across the lanes of a point and lands in packed column c_b.
+template <typename GT, int Q>
+__global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __restrict__ G, int64_t ldg, const float* __restrict__ P1,
+                                                                 const float* __restrict__ self1, int n1q, const float* __restrict__ P2,
+                                                                 const float* __restrict__ self2, int n2, int K4, int DP, int NP,
+                                                                 const int* __restrict__ dir_idx, int idx_base, int gvec,
+                                                                 const float* __restrict__ hyp, float* __restrict__ slab,
+                                                                 float* __restrict__ partials) {
+    constexpr int R = 48 / Q, T = 48, PPL = CanTile<Q>::PPL, NPAIR = R * R, KSM = 8, KP = (R + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LDX = NP + 1;                 // row stride of the staged side-2 value rows [16][LDX] (B operand of the dP1 product: NP columns)
+    float* Xs = smem;                       // [16][LDX]
+    float* TT = smem + ((16 * LDX + 3) & ~3);     // [16][CAN_LDT]: U^T ([point][row]), then Tbar's value columns as [point][row] (the A operand, read transposed)
+    float* CS = TT + 16 * CAN_LDT;          // [48][8]: column sums at the end of the sweep
+    const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.y * T;
+    const int n2q = n2 * Q;
+    const int ncoltiles = (n2 + R - 1) / R;
+    const int nnp = NP / 16;                // 1 or 2
+    const int KS = K4 / 4 + 1;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+    const bool vec = gvec != 0;
+    int cidx[Q];
+#pragma unroll
+    for (int b = 1; b < Q; ++b) cidx[b] = dir_idx[b - 1] - idx_base;
+    cidx[0] = 0;
+
+    float areg[3][KSM];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int gr = row0 + i * 16 + m16;
+        const bool ok = gr < n1q;
+        const int a = (i * 16 + m16) % Q;
+        const float sf = ok ? self1[gr] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            float v = 0.f;
+            if (ks < K4 / 4) v = ok ? P1[(int64_t)gr * DP + ks * 4 + kg] : 0.f;
+            else if (ks == K4 / 4 && ok) v = (kg == 2) ? (a == 0 ? 0.f : -sf) : 0.f;
+            areg[i][ks] = v;
+        }
+    }
+    int pi_[PPL], pj_[PPL];
+    bool prow[PPL];
+    float nrm1[PPL], zc[PPL][Q], gc[PPL][Q][Q], S[PPL][Q][Q];
+#pragma unroll
+    for (int pp = 0; pp < PPL; ++pp) {
+        const int pid = lane + 64 * pp;
+        pi_[pp] = pid / R; pj_[pp] = pid - pi_[pp] * R;
+        const int r0 = row0 + pi_[pp] * Q;
+        prow[pp] = pid < NPAIR && r0 < n1q;
+        nrm1[pp] = prow[pp] ? self1[r0] : 0.f;
+#pragma unroll
+        for (int a = 0; a < Q; ++a)
+#pragma unroll
+            for (int b = 0; b < Q; ++b) S[pp][a][b] = 0.f;
+#pragma unroll
+        for (int b = 1; b < Q; ++b) {
+            zc[pp][b] = prow[pp] ? P1[(int64_t)r0 * DP + cidx[b]] : 0.f;
+#pragma unroll
+            for (int a = 1; a < Q; ++a) gc[pp][a][b] = prow[pp] ? P1[(int64_t)(r0 + a) * DP + cidx[b]] : 0.f;
+        }
+    }
+    for (int e = lane; e < 16 * LDX; e += 64) Xs[e] = 0.f;
+    for (int e = lane; e < 16 * CAN_LDT; e += 64) TT[e] = 0.f;
+    const int pch = DP / 4;
+    f4 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    float sK_sum = 0.f, l_acc = 0.f;
+
+    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
+        const int j0 = ct * R, col0 = j0 * Q;
+        // upstream micro-blocks straight into registers (consumed after the U product)
+        float g[PPL][Q][Q];
+        bool mine[PPL];
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            mine[pp] = prow[pp] && j0 + pj_[pp] < n2;
+            const GT* src = G + (int64_t)(row0 + pi_[pp] * Q) * ldg + col0 + pj_[pp] * Q;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                if constexpr (Q % 2 == 0) {
+                    if (mine[pp] && vec) {
+                        using V2 = GT __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) {
+                            const V2 x = *reinterpret_cast<const V2*>(src + a * ldg + b);
+                            g[pp][a][b] = (float)x[0]; g[pp][a][b + 1] = (float)x[1];
+                        }
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < Q; ++b) g[pp][a][b] = mine[pp] ? (float)src[a * ldg + b] : 0.f;
+            }
+        }
+        __syncthreads();
+        // the tile's R value rows of P2 (packed columns 0 .. DP-1; column K4 is the indicator: row sums of Tbar's value columns)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
+            if (e < R * pch) {
+                f4 x = f4{0.f, 0.f, 0.f, 0.f};
+                if (j0 + r < n2) x = *reinterpret_cast<const f4*>(P2 + (int64_t)(j0 + r) * Q * DP + k);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Xs[r * LDX + k + t] = x[t];
+            }
+        }
+        __syncthreads();
+        if (lane < R) {
+            const bool ok = j0 + lane < n2;
+            Xs[lane * LDX + K4 + 1] = 0.f;
+            Xs[lane * LDX + K4 + 2] = ok ? 1.f : 0.f;
+            Xs[lane * LDX + K4 + 3] = ok ? self2[(int64_t)(j0 + lane) * Q] : 0.f;
+        }
+        __syncthreads();
+        f4 t[3];
+        {
+            const float* pb = Xs + m16 * LDX + kg;
+            auto product = [&](auto ksc) {
+                constexpr int KS_ = decltype(ksc)::value;
+#pragma unroll
+                for (int ks = 0; ks < KS_; ++ks) {
+                    const float bv = pb[ks * 4];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        t[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv, ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i], 0, 0, 0);
+                }
+            };
+            switch (KS) {
+                case 1: product(std::integral_constant<int, 1>{}); break;
+                case 2: product(std::integral_constant<int, 2>{}); break;
+                case 3: product(std::integral_constant<int, 3>{}); break;
+                case 4: product(std::integral_constant<int, 4>{}); break;
+                case 5: product(std::integral_constant<int, 5>{}); break;
+                case 6: product(std::integral_constant<int, 6>{}); break;
+                case 7: product(std::integral_constant<int, 7>{}); break;
+                default: product(std::integral_constant<int, 8>{}); break;
+            }
+        }
+        if (m16 < R) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f4*>(TT + m16 * CAN_LDT + i * 16 + kg * 4) = t[i];
+        }
+        __syncthreads();
+        float tv[PPL][Q];                   // Tbar's value column of this pair: Tbar[(i, a)][(j, 0)]
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            float uq[Q], w[Q];
+            const float* up = TT + pj_[pp] * CAN_LDT + pi_[pp] * Q;
+            const float* xp = Xs + pj_[pp] * LDX;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) uq[a] = up[a];
+#pragma unroll
+            for (int b = 1; b < Q; ++b) w[b] = zc[pp][b] - xp[cidx[b]];
+            const float nrm2 = xp[K4 + 3];
+            const float nn = fmaxf(nrm1[pp] + nrm2 - 2.f * uq[0], 0.f);
+            const float k = mine[pp] ? s * expf(-0.5f * nn) : 0.f;
+            const float kil = k * il, kil2 = k * il2;
+            float first = 0.f, second = 0.f, hsum = 0.f, dots = 0.f;
+            float gu[Q];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) gu[b] = 0.f;
+#pragma unroll
+            for (int b = 1; b < Q; ++b) first = __builtin_fmaf(g[pp][0][b], w[b], first);                 // sum g0b w_b
+#pragma unroll
+            for (int a = 1; a < Q; ++a) {
+                const float u = -uq[a];
+                const float ga0 = g[pp][a][0];
+                float gw = 0.f, gt = 0.f;
+#pragma unroll
+                for (int b = 1; b < Q; ++b) {
+                    const float gab = g[pp][a][b];
+                    gw = __builtin_fmaf(gab, w[b], gw);
+                    gt = __builtin_fmaf(gab, gc[pp][a][b], gt);
+                    gu[b] = __builtin_fmaf(gab, u, gu[b]);
+                    S[pp][a][b] = __builtin_fmaf(kil2, gab, S[pp][a][b]);                               // Tbar_ab, summed over the points of side 2
+                }
+                second = __builtin_fmaf(ga0, u, second);
+                hsum += gt - u * gw;
+                const float ubar = -(kil * ga0 + kil2 * gw);
+                tv[pp][a] = -ubar;                                                                      // Tbar_a0
+                dots = __builtin_fmaf(ubar, u, dots);
+            }
+#pragma unroll
+            for (int b = 1; b < Q; ++b) {
+                const float wbar = kil * g[pp][0][b] - kil2 * gu[b];
+                S[pp][0][b] += wbar;                                                                    // Tbar_0b
+                dots = __builtin_fmaf(wbar, w[b], dots);
+            }
+            const float e1 = il * (first - second), e2 = il2 * hsum;
+            const float t00 = k * (g[pp][0][0] + e1 + e2);                                              // Tbar_00
+            tv[pp][0] = t00;
+            sK_sum += t00;
+            l_acc += k * (e1 + 2.f * e2) - t00 * nn + dots;
+        }
+        __syncthreads();                    // every lane has read its U values: Tbar's value columns take their place, [point][row]
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            if (lane + 64 * pp < NPAIR) {
+                float* tp = TT + pj_[pp] * CAN_LDT + pi_[pp] * Q;
+#pragma unroll
+                for (int a = 0; a < Q; ++a) tp[a] = tv[pp][a];
+            }
+        }
+        __syncthreads();
+        // dP1[48, NP] += Tbar[:, value columns][48, R] . X2'[R, NP]:  A operand lane (m, k) = Tbar[row m][point k] = TT[k][m]
+        {
+#pragma unroll
+            for (int kk = 0; kk < 4 * KP; kk += 4) {
+                float av[3], bv[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) av[i] = TT[(kk + kg) * CAN_LDT + i * 16 + m16];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = (j < nnp) ? Xs[(kk + kg) * LDX + 16 * j + m16] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (j < nnp) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the column sums of Tbar's direction columns: across the R lanes of a point (pj = pid % R: xor steps below R), then into
+    // packed column c_b of the point's rows through a small LDS table
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < PPL; ++pp)
+#pragma unroll
+        for (int a = 0; a < Q; ++a)
+#pragma unroll
+            for (int b = 1; b < Q; ++b) {
+                float x = S[pp][a][b];
+#pragma unroll
+                for (int off = 1; off < R; off <<= 1) x += __shfl_xor(x, off);
+                S[pp][a][b] = x;
+            }
+#pragma unroll
+    for (int pp = 0; pp < PPL; ++pp) {
+        if (lane + 64 * pp < NPAIR && pj_[pp] == 0) {
+#pragma unroll
+            for (int a = 0; a < Q; ++a)
+#pragma unroll
+                for (int b = 1; b < Q; ++b) CS[(pi_[pp] * Q + a) * 8 + b] = S[pp][a][b];
+        }
+    }
+    __syncthreads();
+    float* myslab = slab + ((int64_t)blockIdx.x * n1q) * NP;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < nnp) {
+                const int col = j * 16 + m16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = i * 16 + kg * 4 + r;
+                    const int64_t gr = row0 + rr;
+                    float x = acc[i][j][r];
+#pragma unroll
+                    for (int b = 1; b < Q; ++b) x += (cidx[b] == col) ? CS[rr * 8 + b] : 0.f;
+                    if (gr < n1q) myslab[gr * NP + col] = x;
+                }
+            }
+    float l_sum = -il * l_acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        sK_sum += __shfl_down(sK_sum, off);
+        l_sum += __shfl_down(l_sum, off);
+    }
+    if (lane == 0) {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        partials[bid * 2] = sK_sum;
+        partials[bid * 2 + 1] = l_sum;
+    }
+}
+
+inline bool canon_ok(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 32; }
+
 }  // namespace
+
+// K_ZX with canonical (one-hot) directions on side 2, shared by all its points: see the block comment above kernel_fwd_canon_kernel.
+// P2 / self2: the packed rows of side 2 as dsvgp_pack_points leaves them (only the value rows are read).  DSVGP_EINVAL for a geometry the
+// canonical kernels do not take (q not in {3, 6} or packed width > 32): the caller uses dsvgp_kernel_fwd.
+extern "C" int dsvgp_kernel_fwd_canon(dsvgp_ctx* ctx, const float* P1, const float* self1, int n1, const float* P2, const float* self2,
+                                      int n2, int d, int p, const int* dir_idx, int idx_base, const float* hyp, float* out, int64_t ld) {
+    if (!ctx || !P1 || !self1 || !P2 || !self2 || !hyp || !out || !dir_idx || n1 < 0 || n2 < 0) return DSVGP_EINVAL;
+    Geom g;
+    if (int rc = make_geom(d, p, g)) return rc;
+    if (!canon_ok(g)) return DSVGP_EINVAL;
+    if (n1 == 0 || n2 == 0) return 0;
+    const int n1q = n1 * g.q, n2q = n2 * g.q, R = 48 / g.q;
+    if (ld < n2q) return DSVGP_EINVAL;
+    const int rt = cdiv(n1q, 48), ctiles = cdiv(n2, R);
+    int ns = CAN_FWD_WGS / rt;
+    if (ns < 1) ns = 1;
+    if (ns > ctiles) ns = ctiles;
+    const size_t lds = sizeof(float) * (((16 * (size_t)(g.K4 + 5) + 3) & ~(size_t)3) + 48 * (size_t)CAN_LDT);
+    const int ovec = (ld % 4 == 0 && (uintptr_t)out % 16 == 0) ? 2 : 0;
+    dim3 grid(ns, rt);
+    if (g.q == 6)
+        hipLaunchKernelGGL((kernel_fwd_canon_kernel<6>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, n2, g.K4, g.DP, dir_idx,
+                           idx_base, ovec, hyp, out, ld);
+    else
+        hipLaunchKernelGGL((kernel_fwd_canon_kernel<3>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, n2, g.K4, g.DP, dir_idx,
+                           idx_base, ovec, hyp, out, ld);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of dsvgp_kernel_fwd_canon w.r.t. (x1, v1, lengthscale, outputscale): accumulates (+=) like dsvgp_kernel_bwd with symmetric = 0;
+// workspace: dsvgp_kernel_bwd_workspace_bytes(n1, n2, d, p) bytes.
+extern "C" int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double, const float* P1, const float* self1,
+                                      const float* vnorm1, int n1, const float* P2, const float* self2, int n2, int d, int p,
+                                      const int* dir_idx, int idx_base, const float* hyp, float* d_x1, float* d_v1, float* d_hyp,
+                                      void* workspace) {
+    if (!ctx || !G || !P1 || !self1 || !P2 || !self2 || !hyp || !d_x1 || !d_hyp || !workspace || !dir_idx || p < 1 || !vnorm1 || !d_v1)
+        return DSVGP_EINVAL;
+    Geom g;
+    if (int rc = make_geom(d, p, g)) return rc;
+    if (!canon_ok(g)) return DSVGP_EINVAL;
+    if (n1 <= 0 || n2 <= 0) return 0;
+    const int n1q = n1 * g.q, n2q = n2 * g.q, R = 48 / g.q;
+    if (ldg < n2q) return DSVGP_EINVAL;
+    const int rt = cdiv(n1q, 48), ctiles = cdiv(n2, R);
+    int ns = bwd_nsplit(n1, n2, g);               // (the slab count the workspace was sized for: the pair kernels' tiling)
+    if (ns > ctiles) ns = ctiles;
+    float* slab = (float*)workspace;
+    float* partials = slab + (size_t)bwd_nsplit(n1, n2, g) * n1q * g.NP;
+    const size_t lds = sizeof(float) * (((16 * (size_t)(g.NP + 1) + 3) & ~(size_t)3) + 16 * (size_t)CAN_LDT + 48 * 8);
+    const int esz = g_is_double ? 8 : 4;
+    const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);
+    dim3 grid(ns, rt);
+#define DSVGP_CANON_BWD(GT_, Q_)                                                                                                        \
+    hipLaunchKernelGGL((kernel_bwd_canon_kernel<GT_, Q_>), grid, dim3(64), lds, ctx->stream, (const GT_*)G, ldg, P1, self1, n1q, P2, self2, \
+                       n2, g.K4, g.DP, g.NP, dir_idx, idx_base, gvec, hyp, slab, partials)
+    if (g_is_double) { if (g.q == 6) DSVGP_CANON_BWD(double, 6); else DSVGP_CANON_BWD(double, 3); }
+    else { if (g.q == 6) DSVGP_CANON_BWD(float, 6); else DSVGP_CANON_BWD(float, 3); }
+#undef DSVGP_CANON_BWD
+    DSVGP_LAUNCH_CHECK();
+    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;
+    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), ctx->stream,
+                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, 1.f, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dsvgp_packed_width(int d) { return ((d + 3) & ~3) + 4; }
 

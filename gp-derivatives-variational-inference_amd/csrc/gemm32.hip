@@ -62,6 +62,9 @@ constexpr int TM = 128, TN = 128;
 #ifndef G32_TRI_SB
 #define G32_TRI_SB 1        // lower-triangular outputs: super-block edge (tiles) of the walk; 1 = plain row-major triangle.  Measured
 #endif                      // (round 4, tools/gemm32_variants.sh, same box): Gram at C4 2.169 (1) / 2.193 (8) / 2.222 ms (4) -- no gain
+#ifndef G32_XCDK
+#define G32_XCDK 0          // 1: (probe) lower-triangular split-K products in eight K slices, one per XCD -- measured, not kept
+#endif
 #ifndef G32_ABL
 #define G32_ABL 0           // timing ablations (results are WRONG): 1 no global fetch in the loop, 2 no LDS stores, 4 no LDS fragment reads, 8 no barriers
 #endif
@@ -138,10 +141,20 @@ struct FetchMC {
 
 // which (tile, K slice) this workgroup takes: consecutive blocks of one XCD (b, b + 8, ...) get consecutive units
 __device__ __forceinline__ bool pick_unit(const G32& g, int& m0, int& n0, int& kbeg, int& kend) {
+#if G32_XCDK
+    // probe (round 6, profiles/r06_b_gemm32_gram_xcd.txt): a lower-triangular split-K product with EIGHT K slices, slice = the XCD the workgroup
+    // lands on (blocks b, b + 8, ... share one): every XCD's L2 then sees one K slice of the operands only
+    const bool xk = (g.flags & DSVGP_GEMM_OUT_LOWER) && g.splitk == 8;
+    const int u = xk ? 0 : (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
+    if (xk ? (int)(blockIdx.x >> 3) >= g.ntiles : u >= g.ntiles * g.splitk) return false;
+    const int slice = xk ? (int)(blockIdx.x & 7) : u / g.ntiles;
+    const int t = xk ? (int)(blockIdx.x >> 3) : u - slice * g.ntiles;
+#else
     const int u = (blockIdx.x >> 3) + (blockIdx.x & 7) * ((gridDim.x + 7) >> 3);
     if (u >= g.ntiles * g.splitk) return false;
     const int slice = u / g.ntiles;
     const int t = u - slice * g.ntiles;
+#endif
     int tm, tn;
     if (g.flags & DSVGP_GEMM_OUT_LOWER) {
         // tiles with tn <= tm, row by row: the triangle t = tm (tm + 1) / 2 + tn while tm < tiles_n, full rows of
@@ -613,6 +626,9 @@ int launch_gemm32(hipStream_t st, const GemmArgs& g) {
             if (tcost < best * 0.999) { best = tcost; sk = c; }
         }
     }
+#if G32_XCDK
+    if (out_lower && sk > 1 && g.K >= 8 * 512) sk = 8;
+#endif
 #ifdef G32_SK      // probe: fixed slice count for the products of G32_SK_MINT..G32_SK_BELOW tiles
     if (a.ntiles < G32_SK_BELOW && a.ntiles >= G32_SK_MINT && g.K >= 1024 && g.K < 16384) sk = G32_SK;
 #endif

@@ -94,6 +94,14 @@ int dsvgp_pack_points(dsvgp_ctx* ctx, const float* x, const float* v, int n, int
 int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* self1, int n1, const float* P2,
                      const float* self2, int n2, int d, int p, const float* hyp, float jitter,
                      void* out, int64_t ld, int out_is_double);
+/* The same product when the directions of side 2 are CANONICAL unit vectors shared by all its points -- what the reference's callers
+ * pass for K_ZX: select_cols_of_y's E_canonical[idx - 1] tiled over the minibatch (directional_vi.py:81-88, 238), eye(d)[:p] tiled in
+ * eval_gp (:292-294).  dir_idx[p] (device memory): direction b is the unit vector of coordinate dir_idx[b] - idx_base (idx_base = 1 takes
+ * idx_y[1:] of select_cols_of_y as it stands).  P2 / self2: the packed rows of side 2 (only the value rows are read).  float output, no
+ * jitter.  Returns DSVGP_EINVAL for geometries the canonical kernels do not take (p + 1 not in {3, 6} or d > 28): use dsvgp_kernel_fwd. */
+int dsvgp_kernel_fwd_canon(dsvgp_ctx* ctx, const float* P1, const float* self1, int n1, const float* P2,
+                           const float* self2, int n2, int d, int p, const int* dir_idx, int idx_base,
+                           const float* hyp, float* out, int64_t ld);
 /* diag=True branch (:110-119): out[n*(p+1)] = outputscale * [1, 1/ell^2, ...]                    */
 int dsvgp_kernel_diag(dsvgp_ctx* ctx, int n, int p, const float* hyp, float* out);
 
@@ -105,6 +113,11 @@ int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double
                      const float* self1, const float* vnorm1, int n1, const float* P2,
                      const float* self2, int n2, int d, int p, const float* hyp, int symmetric,
                      float* d_x1, float* d_v1, float* d_hyp, void* workspace);
+/* backward of dsvgp_kernel_fwd_canon (symmetric = 0 semantics; same workspace size as dsvgp_kernel_bwd) */
+int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double, const float* P1,
+                           const float* self1, const float* vnorm1, int n1, const float* P2,
+                           const float* self2, int n2, int d, int p, const int* dir_idx, int idx_base,
+                           const float* hyp, float* d_x1, float* d_v1, float* d_hyp, void* workspace);
 
 /* ---- fp64 model mode (the reference's experiments set torch.set_default_dtype(torch.float64),
  * experiments/synthetic/exp_script.py:56): RBFKernelDirectionalGrad.forward / backward in double precision.

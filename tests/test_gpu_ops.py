@@ -77,6 +77,107 @@ def test_kernel_fwd_random_shapes(dsvgp, gpu_device, n1, n2, d, p):
     assert relmax(K, ref) < 2e-5
 
 
+# ------------------------------------------------------------------ canonical (one-hot, shared) directions on side 2: K_ZX as the reference's callers build it
+def _canon_case(dsvgp, dev, x1, x2, v1, idx, ell, s, idx_base):
+    """packs (x1, v1) and (x2, E[idx] tiled); returns ctx, hyp, packs and the device index list (+ idx_base)"""
+    ops = dsvgp._ops
+    ctx = ops.Context.get(dev)
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    p = len(idx)
+    hyp = _hyp(dev, ell, s)
+    x1d = x1.float().to(dev).contiguous()
+    center = ops.column_mean(ctx, x1d)
+    v2 = torch.eye(d)[idx].repeat(n2, 1)
+    p1 = ops.pack_points(ctx, x1d, v1.float().to(dev).contiguous(), p, hyp, center)
+    p2 = ops.pack_points(ctx, x2.float().to(dev).contiguous(), v2.to(dev).contiguous(), p, hyp, center)
+    di = (torch.tensor(idx, dtype=torch.int32) + idx_base).to(dev)
+    return ops, ctx, hyp, p1, p2, di, v2
+
+
+@pytest.mark.parametrize("name", ["kernel_c_onehot", "kernel_e_c2shape", "kernel_g_c4tiles", "kernel_h_c2tiles"])
+def test_kernel_fwd_canon_matches_reference_golden_vectors(dsvgp, gpu_device, name):
+    """the golden vectors of the reference's kernel file whose v2 is one-hot and the same for every point of side 2, through the
+    canonical-direction kernel (index list instead of a direction matrix): same 2e-6 as the general kernel"""
+    path = [q for q in GOLDEN if os.path.basename(q) == name + ".npz"][0]
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(g[k])
+    x2, v2 = t("x2"), t("v2")
+    n2, d = x2.shape
+    p = v2.shape[0] // n2
+    idx = v2.reshape(n2, p, d).argmax(2)
+    assert bool((idx == idx[0]).all()) and bool(((v2 == 0) | (v2 == 1)).all())
+    ops, ctx, hyp, p1, p2, di, _ = _canon_case(dsvgp, gpu_device, t("x1"), x2, t("v1"), idx[0].tolist(), float(g["lengthscale"]), 1.0, 1)
+    K = ops.kernel_fwd_canon(ctx, p1, g["x1"].shape[0], p2, n2, d, p, di, 1, hyp)
+    e_sub, e_sum = kernel_error(K, g)
+    print("kernel_fwd_canon %s: HIP fp32 error %.2e (row/col sums %s)" % (name, e_sub, "%.2e" % e_sum if e_sum is not None else "-"))
+    assert e_sub < 2e-6 and (e_sum is None or e_sum < 2e-6)
+
+
+@pytest.mark.parametrize("n1,n2,d,p,base", [(37, 53, 5, 2, 0), (16, 16, 20, 5, 1), (33, 70, 20, 5, 0), (130, 7, 5, 2, 1), (9, 300, 28, 5, 1),
+                                            (50, 131, 9, 2, 0), (24, 8, 20, 5, 1)])
+def test_kernel_fwd_canon_equals_the_general_kernel(dsvgp, gpu_device, n1, n2, d, p, base):
+    g = torch.Generator().manual_seed(n1 * 1000 + n2 + d)
+    x1, x2 = torch.rand(n1, d, generator=g), torch.rand(n2, d, generator=g)
+    v1 = torch.randn(n1 * p, d, generator=g)
+    idx = sorted(torch.randperm(d, generator=g)[:p].tolist())
+    ell, s = 0.9, 1.7
+    ops, ctx, hyp, p1, p2, di, v2 = _canon_case(dsvgp, gpu_device, x1, x2, v1, idx, ell, s, base)
+    assert ops.canon_supported(d, p)
+    Kc = ops.kernel_fwd_canon(ctx, p1, n1, p2, n2, d, p, di, base, hyp)
+    Kg = ops.kernel_fwd(ctx, p1, n1, p2, n2, d, p, hyp)
+    ref = s * O.kernel_matrix(x1.double(), x2.double(), v1.double(), v2.double(), ell)
+    assert relmax(Kc, ref) < 2e-5 and relmax(Kc, Kg) < 5e-6, (relmax(Kc, ref), relmax(Kc, Kg))
+    # a view with a padded leading dimension (rows not 16-byte aligned: the per-lane store path)
+    buf = torch.zeros(n1 * (p + 1), n2 * (p + 1) + 3, device=gpu_device)
+    Kv = ops.kernel_fwd_canon(ctx, p1, n1, p2, n2, d, p, di, base, hyp, out=buf[:, 1:n2 * (p + 1) + 1])
+    assert torch.equal(Kv, Kc) and buf[:, 0].abs().max().item() == 0.0 and buf[:, -2:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("n1,n2,d,p", [(11, 23, 5, 2), (20, 45, 20, 5), (40, 300, 20, 5), (70, 130, 5, 2), (9, 9, 28, 5), (64, 64, 12, 2)])
+def test_kernel_bwd_canon_matches_autograd_and_the_general_kernel(dsvgp, gpu_device, n1, n2, d, p):
+    g = torch.Generator().manual_seed(n1 + 31 * n2 + d)
+    x1, x2 = torch.rand(n1, d, generator=g), torch.rand(n2, d, generator=g)
+    v1 = torch.randn(n1 * p, d, generator=g)
+    idx = sorted(torch.randperm(d, generator=g)[:p].tolist())
+    ell, s = 0.8, 1.3
+    q = p + 1
+    G = torch.randn(n1 * q, n2 * q, generator=g, dtype=torch.float64)
+    dev = gpu_device
+    ops, ctx, hyp, p1, p2, di, v2 = _canon_case(dsvgp, dev, x1, x2, v1, idx, ell, s, 1)
+    x1r = x1.double().requires_grad_(True)
+    v1r = v1.double().requires_grad_(True)
+    ellr = torch.tensor(ell, dtype=torch.float64, requires_grad=True)
+    sr = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+    (sr * O.kernel_matrix(x1r, x2.double(), v1r, v2.double(), ellr) * G).sum().backward()
+    for Gd in (G.to(dev), G.float().to(dev)):                 # double and float upstream gradients
+        res = []
+        for canon in (True, False):
+            dx = torch.zeros(n1, d, device=dev)
+            dv = torch.zeros(n1 * p, d, device=dev)
+            dh = torch.zeros(4, device=dev)
+            if canon:
+                ops.kernel_bwd_canon(ctx, Gd.contiguous(), p1, n1, p2, n2, d, p, di, 1, hyp, dx, dv, dh)
+            else:
+                ops.kernel_bwd(ctx, Gd.contiguous(), p1, n1, p2, n2, d, p, hyp, False, dx, dv, dh)
+            res.append((dx, dv, dh))
+        (dx, dv, dh), (gx, gv, gh) = res
+        assert relmax(dx, x1r.grad) < 2e-4 and relmax(dv, v1r.grad) < 2e-4, (relmax(dx, x1r.grad), relmax(dv, v1r.grad))
+        assert abs(dh[0].item() - ellr.grad.item()) < 2e-4 * max(1.0, abs(ellr.grad.item()))
+        assert abs(dh[1].item() - sr.grad.item()) < 2e-4 * max(1.0, abs(sr.grad.item()))
+        assert relmax(dx, gx) < 1e-4 and relmax(dv, gv) < 1e-4
+
+
+def test_kernel_canon_rejects_geometries_it_does_not_take(dsvgp, gpu_device):
+    ops = dsvgp._ops
+    assert not ops.canon_supported(50, 5) and not ops.canon_supported(10, 10) and ops.canon_supported(28, 5) and ops.canon_supported(5, 2)
+    g = torch.Generator().manual_seed(1)
+    x1, x2, v1 = torch.rand(6, 10, generator=g), torch.rand(7, 10, generator=g), torch.randn(6 * 3, 10, generator=g)
+    o, ctx, hyp, p1, p2, di, _ = _canon_case(dsvgp, gpu_device, x1, x2, v1, [0, 4, 7], 0.7, 1.0, 0)
+    with pytest.raises(dsvgp._lib.DsvgpError):
+        o.kernel_fwd_canon(ctx, p1, 6, p2, 7, 10, 3, di, 0, hyp)       # q = 4
+
+
 def test_kernel_fwd_symmetric_double_with_jitter_and_exact_diagonal(dsvgp, gpu_device):
     g = torch.Generator().manual_seed(3)
     M, d, p = 50, 20, 5

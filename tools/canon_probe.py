@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""tools only (round 6): kernel assembly forward / backward of K_ZX with canonical data directions -- the general kernels (direction matrix) against
+the canonical-direction kernels (index list) at a geometry CANON_GEOM="M,B,d,p" (default C4: 500,4096,20,5), for the library named by DSVGP_LIB_PATH."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import dsvgp_amd
+ops = dsvgp_amd._ops
+dev = torch.device("cuda", 0)
+ctx = ops.Context.get(dev)
+for geom in os.environ.get("CANON_GEOM", "500,4096,20,5;200,512,5,2;500,512,20,5").split(";"):
+    M, B, d, p = (int(v) for v in geom.split(","))
+    q = p + 1
+    hyp = torch.tensor([0.69, 0.69, 0.1, 0.0], device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    Z, V = torch.rand(M, d, device=dev, generator=g), torch.randn(M * p, d, device=dev, generator=g)
+    idx = sorted(torch.randperm(d)[:p].tolist())
+    X, D = torch.rand(B, d, device=dev, generator=g), torch.eye(d, device=dev)[idx].repeat(B, 1)
+    center = ops.column_mean(ctx, Z)
+    pz, px = ops.pack_points(ctx, Z, V, p, hyp, center), ops.pack_points(ctx, X, D, p, hyp, center)
+    di = (torch.tensor(idx, dtype=torch.int32) + 1).to(dev)
+    out = torch.empty(M * q, B * q, device=dev)
+    G = torch.randn(M * q, B * q, device=dev, generator=g)
+    nbytes = out.numel() * 4 + (M + B) * d * q * 4
+
+    def timeit(fn, n=10):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    dx, dv, dh = torch.zeros(M, d, device=dev), torch.zeros(M * p, d, device=dev), torch.zeros(4, device=dev)
+    ws = torch.empty(int(dsvgp_amd._lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p)), dtype=torch.uint8, device=dev)
+    t_fg = timeit(lambda: ops.kernel_fwd(ctx, pz, M, px, B, d, p, hyp, out=out))
+    Kg = out.clone()
+    t_fc = timeit(lambda: ops.kernel_fwd_canon(ctx, pz, M, px, B, d, p, di, 1, hyp, out=out))
+    err = ((out - Kg).abs().max() / Kg.abs().max()).item()
+    t_bg = timeit(lambda: ops.kernel_bwd(ctx, G, pz, M, px, B, d, p, hyp, False, dx, dv, dh, ws))
+    t_bc = timeit(lambda: ops.kernel_bwd_canon(ctx, G, pz, M, px, B, d, p, di, 1, hyp, dx, dv, dh, ws))
+    tb = lambda ms: nbytes / ms / 1e9
+    print("M=%d B=%d d=%d p=%d (%.1f MB): fwd general %.1f us (%.2f TB/s = %.2f of 8)  canonical %.1f us (%.2f TB/s = %.2f)  |diff| %.1e ;  "
+          "bwd general %.1f us (%.2f = %.2f)  canonical %.1f us (%.2f TB/s = %.2f)"
+          % (M, B, d, p, nbytes / 1e6, t_fg * 1e3, tb(t_fg), tb(t_fg) / 8, t_fc * 1e3, tb(t_fc), tb(t_fc) / 8, err, t_bg * 1e3, tb(t_bg), tb(t_bg) / 8,
+             t_bc * 1e3, tb(t_bc), tb(t_bc) / 8))
