@@ -23,6 +23,21 @@
 #define ASM_ABLATE 0      // tools only: 1 = no global stores, 2 = stores of a constant (no MFMA / epilogue math)
 #endif
 
+// One-wave workgroups (64 threads) exchange through LDS, which serves a wave's instructions in issue order: all they need between a write
+// and another lane's read is that the COMPILER keeps the order.  __syncthreads() would add "s_waitcnt vmcnt(0)" (its fence covers global
+// memory too), i.e. drain the tile's global stores and the next tile's prefetch at every exchange (profiles/r06_c_*).
+// ASM_WAVE_SYNC = 0 restores the workgroup barrier (tools/assemble_variants.sh).
+#ifndef ASM_WAVE_SYNC
+#define ASM_WAVE_SYNC 1
+#endif
+#if ASM_WAVE_SYNC
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define WAVE_SYNC() __syncthreads()
+#endif
+
+
 namespace {
 
 constexpr int TMAX = 96;   // tile rows/cols of the interleaved matrix handled per workgroup
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
         }
     } else {
     for (int e = lane; e < 48 * LDP; e += 64) { P1s[e] = 0.f; P2s[e] = 0.f; }
-    __syncthreads();
+    WAVE_SYNC();
     for (int e = lane; e < T * K4; e += 64) {
         const int r = e / K4, k = e - r * K4;
         if (row0 + r < n1q) P1s[r * LDP + k] = P1[(int64_t)(row0 + r) * DP + k];
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
 #pragma unroll
             for (int pp = 0; pp < PPL; ++pp) s2c0[pp] = (prow[pp] && col0 + pc0[pp] < n2q) ? self2[col0 + pc0[pp]] : 0.f;
         }
-        __syncthreads();   // single wave: orders the previous tile's LDS reads before the new stores
+        WAVE_SYNC();   // single wave: orders the previous tile's LDS reads before the new stores
         if (FWDP_OVERLAY) {
 #if FWDP_LEAN
 #pragma unroll
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                 }
             }
 #endif
-            __syncthreads();
+            WAVE_SYNC();
             if (lane < T) {
                 P2s[lane * LDP + K4 + 1] = pselfv;
                 P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
 #pragma unroll
             for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = v[t];
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < T) {
             const int gr = col0 + lane;
             const bool ok = gr < n2q;
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
             P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
         }
         }
-        __syncthreads();
+        WAVE_SYNC();
         {
             f4 t[3][3];
             if (!FWDP_AREG) {
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
 #pragma unroll
                     for (int j = 0; j < 3; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
             }
-            if (FWDP_OVERLAY) __syncthreads();          // every P2 fragment has been read: T' may overlay the image
+            if (FWDP_OVERLAY) WAVE_SYNC();          // every P2 fragment has been read: T' may overlay the image
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
 #pragma unroll
                     for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
         }
-        __syncthreads();
+        WAVE_SYNC();
 #if FWDP_FAST
         // Interior tile, float output, 16-byte aligned rows: the micro-blocks go back to the T' tile IN PLACE (every lane rewrites
         // only what it read) and the tile leaves as nine fully coalesced store instructions -- every row 192 contiguous bytes,
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
                         }
                     }
                 }
-                __syncthreads();
+                WAVE_SYNC();
                 float* orow = (float*)out + (int64_t)row0 * ld + col0;
 #pragma unroll
                 for (int u = 0; u < 9; ++u) {
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __res
         const int col0 = ct * T;
         const bool colok = prow && col0 + pc0 < n2q;
         const float s2c0 = colok ? self2[col0 + pc0] : 0.f;
-        __syncthreads();                 // (single wave: the previous tile's LDS reads are done)
+        WAVE_SYNC();                 // (single wave: the previous tile's LDS reads are done)
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
@@ -709,13 +724,13 @@ __global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __res
                 for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < T) {
             P2s[lane * LDP + K4 + 1] = pselfv;
             P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
         }
         if (ct + 1 < ct_hi) prefetch(ct + 1);
-        __syncthreads();
+        WAVE_SYNC();
         {
             f4 t[3][3];
             const float* pb = P2s + m16 * LDP + kg;
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __res
                             t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i][ks], bv[j], ks == 0 ? f4{0.f, 0.f, 0.f, 0.f} : t[i][j], 0, 0, 0);
                 }
             }
-            __syncthreads();             // every B fragment has been read: T' may overlay the packed rows
+            WAVE_SYNC();             // every B fragment has been read: T' may overlay the packed rows
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -740,7 +755,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __res
 #pragma unroll
                     for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
         }
-        __syncthreads();
+        WAVE_SYNC();
         // ---- micro-block transform, rows split over the SPL lanes of a pair
         float* blk = TT + pr0 * LDT2 + pc0;
         float t0[Q], ta[RPL][Q];
@@ -754,7 +769,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __res
                 for (int b = 0; b < Q; ++b) ta[i][b] = (a < Q) ? blk[a * LDT2 + b] : 0.f;
             }
         }
-        __syncthreads();                 // row 0 is rewritten by the lane with sub = 0: every lane of the pair has read it
+        WAVE_SYNC();                 // row 0 is rewritten by the lane with sub = 0: every lane of the pair has read it
         const float nn = fmaxf(s1r0 - s2c0 - 2.f * t0[0], 0.f);      // covar_dist clamps at 0
         const float k = s * expf(-0.5f * nn);                          // postprocess_rbf, ScaleKernel
         const float kil = k * il, kil2 = k * il2;
@@ -788,7 +803,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_split_kernel(const float* __res
             }
         }
         if (fast) {
-            __syncthreads();
+            WAVE_SYNC();
             if constexpr (sizeof(OutT) == 4) {
                 float* orow = (float*)out + (int64_t)row0 * ld + col0;
                 constexpr int C4 = T / 4;
@@ -838,7 +853,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_run_kernel(const float* __restr
     const float il = 1.f / ell, il2 = il * il;
 
     for (int e = lane; e < 48 * LDP; e += 64) P1s[e] = 0.f;
-    __syncthreads();
+    WAVE_SYNC();
     for (int e = lane; e < 48 * K4; e += 64) {
         const int r = e / K4, k = e - r * K4;
         if (row0 + r < n1q) P1s[r * LDP + k] = P1[(int64_t)(row0 + r) * DP + k];
@@ -874,7 +889,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_run_kernel(const float* __restr
     if (ct < ncoltiles) prefetch(ct);
     for (; ct < ncoltiles; ct += gridDim.x) {
         const int col0 = ct * TC;
-        __syncthreads();                                // the previous tile's T' reads are done: the overlay may be rewritten
+        WAVE_SYNC();                                // the previous tile's T' reads are done: the overlay may be rewritten
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int e = lane + 64 * u;
@@ -884,7 +899,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_run_kernel(const float* __restr
                 for (int t = 0; t < 4; ++t) P2s[r * LDP + k + t] = pf[u][t];
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < TC) {
             P2s[lane * LDP + K4 + 1] = pself;
             P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
@@ -897,7 +912,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_run_kernel(const float* __restr
 #pragma unroll
         for (int pp = 0; pp < PPR; ++pp) s2v[pp] = (col0 + pc0 + pp * Q < n2q) ? self2[col0 + pc0 + pp * Q] : 0.f;
         if (ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);       // in flight under everything below
-        __syncthreads();
+        WAVE_SYNC();
         f4 t[3][NCT];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -918,14 +933,14 @@ __global__ __launch_bounds__(64) void kernel_fwd_run_kernel(const float* __restr
                     for (int j = 0; j < NCT; ++j) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], t[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();                                // every P2 fragment has been read: T' may overlay the image
+        WAVE_SYNC();                                // every P2 fragment has been read: T' may overlay the image
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < NCT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDTT + j * 16 + m16] = t[i][j][r];
-        __syncthreads();
+        WAVE_SYNC();
         if (rowok && col0 + pc0 < n2q) {
             float tq[Q][12];
 #pragma unroll
@@ -1450,20 +1465,20 @@ __global__ __launch_bounds__(64, KSM > 8 ? 1 : BWDP_MINW) void kernel_bwd_pair_k
                 for (int b = 0; b < Q; ++b) g[pp][a][b] = ok ? (float)src[a * ldg + b] : 0.f;
             }
         }
-        __syncthreads();   // (single wave: orders the previous tile's MFMA reads of P2s / TT before the new stores)
+        WAVE_SYNC();   // (single wave: orders the previous tile's MFMA reads of P2s / TT before the new stores)
         if (!BWDP_PREFETCH) prefetch(ct);
 #pragma unroll
         for (int u = 0; u < NPFP; ++u) {               // (lanes past the end of the tile: the scratch row)
 #pragma unroll
             for (int t = 0; t < 4; ++t) P2s[pf_lds[u] + t] = pf[u][t];
         }
-        __syncthreads();   // the extension columns go on top of the packed zeros
+        WAVE_SYNC();   // the extension columns go on top of the packed zeros
         if (lane < T) {
             P2s[lane * LDP + K4 + 1] = pselfv;
             P2s[lane * LDP + K4 + 2] = (col0 + lane < n2q && lane % Q == 0) ? 1.f : 0.f;
         }
         if (BWDP_PREFETCH && ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);      // in flight under the rest of this tile
-        __syncthreads();
+        WAVE_SYNC();
 
         // T' = P1' P2'^T : 3 x 3 tiles of 16 x 16, K = K4 + 4  (one straight-line copy per K depth: no per-step branches, the
         // first product starts from the inline zero)
@@ -1515,7 +1530,7 @@ __global__ __launch_bounds__(64, KSM > 8 ? 1 : BWDP_MINW) void kernel_bwd_pair_k
 #pragma unroll
                     for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
         }
-        __syncthreads();
+        WAVE_SYNC();
 
         // micro-block transform in registers
 #pragma unroll
@@ -1591,7 +1606,7 @@ __global__ __launch_bounds__(64, KSM > 8 ? 1 : BWDP_MINW) void kernel_bwd_pair_k
                 }
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
 
         // dP1[48, NP] += Tbar[48, 48] . P2ext[48, NP]
         if (!(PAIR_ABLATE & 2)) {
@@ -1751,7 +1766,7 @@ __global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restri
         const int col0 = ct * T;
         const bool colok = prow && col0 + pc0 < n2q;
         const float s2c0 = colok ? self2[col0 + pc0] : 0.f;
-        __syncthreads();                                   // (single wave: the previous tile's MFMA reads of P2s / TT are done)
+        WAVE_SYNC();                                   // (single wave: the previous tile's MFMA reads of P2s / TT are done)
         if (!BWDS_PREFETCH) prefetch(ct);
 #pragma unroll
         for (int u = 0; u < NGF; ++u) {
@@ -1767,13 +1782,13 @@ __global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restri
             }
         }
         if (BWDS_PREFETCH && ct + (int)gridDim.x < ncoltiles) prefetch(ct + gridDim.x);
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < T) {
             const bool ok = col0 + lane < n2q;
             P2s[lane * LDP + K4 + 1] = ok ? -self2[col0 + lane] : 0.f;
             P2s[lane * LDP + K4 + 2] = (ok && lane % Q == 0) ? 1.f : 0.f;
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (!(BWDS_ABL & 4)) {   // T' = P1' P2'^T
             f4 t[3][3];
             const float* pb = P2s + m16 * LDP + kg;
@@ -1797,7 +1812,7 @@ __global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restri
 #pragma unroll
                     for (int r = 0; r < 4; ++r) TT[(i * 16 + kg * 4 + r) * LDT2 + j * 16 + m16] = t[i][j][r];
         }
-        __syncthreads();
+        WAVE_SYNC();
         // ---- micro-block transform (kernel_bwd_pair_kernel's arithmetic), rows split over the four lanes of a pair
         float* blk = TT + pr0 * LDT2 + pc0;
         const float* gb = GG + pr0 * LDG + pc0;
@@ -1814,7 +1829,7 @@ __global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restri
                 ga[i][b] = (a < Q && colok) ? gb[a * LDG + b] : 0.f;
             }
         }
-        __syncthreads();                                   // row 0 of the T' micro-block is rewritten below: every lane has read it
+        WAVE_SYNC();                                   // row 0 of the T' micro-block is rewritten below: every lane has read it
         const float nn = fmaxf(s1r0 - s2c0 - 2.f * t0[0], 0.f);
         const float k = s * expf(-0.5f * nn);
         const float kil = k * il, kil2 = k * il2;
@@ -1867,7 +1882,7 @@ __global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restri
             l_acc += k * (e1 + 2.f * e2) - t00 * nn + dots;
         }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (!(BWDS_ABL & 2)) {   // dP1[48, NP] += Tbar[48, 48] . P2ext[48, NP]
             const float* pa = TT + m16 * LDT2 + kg;
             const float* pb = P2s + kg * LDP + m16;
@@ -2069,6 +2084,12 @@ constexpr int CAN_LDT = 52;            // row stride of the 48 x 48 output / ups
 #ifndef CAN_BWD_WGS
 #define CAN_BWD_WGS (256 * 8)
 #endif
+#ifndef CAN_BWD_DMA
+#define CAN_BWD_DMA 1                  // 0: the backward kernel reads the upstream micro-blocks straight into registers (tools: the A/B)
+#endif
+#ifndef CAN_FWD_MINW
+#define CAN_FWD_MINW 2                 // waves per SIMD the forward kernel's registers are budgeted for
+#endif
 #ifndef CAN_ABL
 #define CAN_ABL 0                      // tools only (results wrong): 1 = no global stores (forward), 2 = no U product
 #endif
@@ -2081,7 +2102,7 @@ struct CanTile {
 };
 
 template <int Q>
-__global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __restrict__ P1, const float* __restrict__ self1, int n1q,
+__global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(const float* __restrict__ P1, const float* __restrict__ self1, int n1q,
                                                               const float* __restrict__ P2, const float* __restrict__ self2, int n2,
                                                               int K4, int DP, const int* __restrict__ dir_idx, int idx_base, int ovec,
                                                               const float* __restrict__ hyp, float* __restrict__ out, int64_t ld) {
@@ -2145,35 +2166,45 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __res
     f4 pf[2];
     float pnrm = 0.f;
     auto prefetch = [&](int ct_) {
+        // (loads without branches, from clamped addresses: with straight-line code the compiler counts the tile's stores issued behind
+        //  them and waits with vmcnt(stores), not vmcnt(0) -- the stores of a tile drain under the next tile's work)
         const int j0 = ct_ * R;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
-            pf[u] = f4{0.f, 0.f, 0.f, 0.f};
-            if (e < R * pch && j0 + r < n2) pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)(j0 + r) * Q * DP + k);
+            const int e = min(lane + 64 * u, R * pch - 1), r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)min(j0 + r, n2 - 1) * Q * DP + k);      // (zeroed past n2 where it is used)
         }
-        pnrm = (lane < R && j0 + lane < n2) ? self2[(int64_t)(j0 + lane) * Q] : 0.f;
+        pnrm = self2[(int64_t)min(j0 + min(lane, R - 1), n2 - 1) * Q];
     };
-    if (ct_lo < ct_hi) prefetch(ct_lo);
-    for (int ct = ct_lo; ct < ct_hi; ++ct) {
+    if (ct_lo >= ct_hi) return;
+    prefetch(ct_lo);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the prologue's loads are in -- said once, so that no wait inside the loop is charged to them
+    // the sweep in two instances: FULL = whole 48 x 48 tiles leaving through LDS as nine 16-byte stores per lane -- straight-line code, so the
+    // wait for the next tile's operands is vmcnt(9 + ..) and the stores drain under the next tile -- and the general one (edge rows, the last
+    // partial column tile, outputs that are not 16-byte aligned)
+    auto sweep = [&](auto fullc, int lo, int hi) {
+    constexpr bool FULL = decltype(fullc)::value;
+    for (int ct = lo; ct < hi; ++ct) {
         const int j0 = ct * R, col0 = j0 * Q;
-        __syncthreads();                    // (single wave: the previous tile's LDS reads are behind us)
+        WAVE_SYNC();                    // (single wave: the previous tile's LDS reads are behind us)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
             if (e < R * pch) {
+                const bool in = j0 + r < n2;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) Xs[r * LDX + k + t] = pf[u][t];
+                for (int t = 0; t < 4; ++t) Xs[r * LDX + k + t] = in ? pf[u][t] : 0.f;
             }
         }
-        __syncthreads();                    // (the extension columns go on top of the packed row's own columns K4 ..)
+        WAVE_SYNC();                    // (the extension columns go on top of the packed row's own columns K4 ..)
         if (lane < R) {
+            const bool in = j0 + lane < n2;
             Xs[lane * LDX + K4 + 1] = 0.f;
-            Xs[lane * LDX + K4 + 2] = (j0 + lane < n2) ? 1.f : 0.f;
-            Xs[lane * LDX + K4 + 3] = pnrm;
+            Xs[lane * LDX + K4 + 2] = in ? 1.f : 0.f;
+            Xs[lane * LDX + K4 + 3] = in ? pnrm : 0.f;
         }
-        if (ct + 1 < ct_hi) prefetch(ct + 1);
-        __syncthreads();
+        prefetch(min(ct + 1, ncoltiles - 1));       // (unconditional: one harmless reload at the end of the range)
+        WAVE_SYNC();
         // U = P1' X2'^T: 3 row tiles x (one 16-column tile of which R columns are points), K = K4 + 4
         f4 t[3];
         {
@@ -2204,7 +2235,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < 3; ++i) *reinterpret_cast<f4*>(TT + m16 * CAN_LDT + i * 16 + kg * 4) = t[i];
         }
-        __syncthreads();
+        WAVE_SYNC();
         float v[PPL][Q][Q];
         bool mine[PPL];
 #pragma unroll
@@ -2231,9 +2262,8 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __res
                 for (int b = 1; b < Q; ++b) v[pp][a][b] = (gc[pp][a][b] + uq[a] * (zc[pp][b] - xc[b])) * kil2;      // (G_ab - u_a w_b) k / ell^2
             }
         }
-        __syncthreads();                    // every lane has read its U values: the output tile may overlay them
-        const bool full = rows_full && col0 + T <= n2q && (ovec & 2);
-        if (full) {
+        WAVE_SYNC();                    // every lane has read its U values: the output tile may overlay them
+        if constexpr (FULL) {
 #pragma unroll
             for (int pp = 0; pp < PPL; ++pp) {
                 if (lane + 64 * pp < NPAIR) {
@@ -2251,7 +2281,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __res
                     }
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
             float* orow = out + (int64_t)row0 * ld + col0;
 #pragma unroll
             for (int u = 0; u < 9; ++u) {   // the tile leaves as nine fully coalesced 16-byte store instructions (rows of 192 bytes)
@@ -2271,12 +2301,28 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon_kernel(const float* __res
             }
         }
     }
+    };
+    const int nfull = (rows_full && (ovec & 2)) ? min(ct_hi, n2q / T) : ct_lo;    // tiles [ct_lo, nfull) are whole
+    sweep(std::true_type{}, ct_lo, nfull);
+    sweep(std::false_type{}, max(nfull, ct_lo), ct_hi);
+}
+
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4), as gemm32.hip's: an asm statement, so that WE count it (s_waitcnt vmcnt) and the
+// compiler does not park a vmcnt(0) in front of every later LDS read; M0 (the LDS destination base; lane l lands at base + 16 l) is saved,
+// set and restored inside the statement.
+__device__ __forceinline__ void can_dma16(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
 // backward: upstream micro-blocks HBM -> registers, the pair kernel's transform with (w_b, -u_a, G_ab) from the canonical sources;
 // Tbar's value columns -> LDS as the A operand of dP1 += Tbar[:, c0] X2' (K = the R points of the tile), its direction columns ->
 // per-lane column sums S[a][b]; at the end of the sweep S is added across the lanes of a point and lands in packed column c_b.
-template <typename GT, int Q>
+// DMA (float upstream, 16-byte aligned rows): the upstream tile of the NEXT column tile comes in by LDS-DMA as nine fully coalesced 1 KB
+// pieces ([48][48] floats, dense) while this tile is worked on -- no registers held for it, no 8-byte strided loads; a last, partial
+// column tile goes through the register path.
+template <typename GT, int Q, bool DMA>
 __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __restrict__ G, int64_t ldg, const float* __restrict__ P1,
                                                                  const float* __restrict__ self1, int n1q, const float* __restrict__ P2,
                                                                  const float* __restrict__ self2, int n2, int K4, int DP, int NP,
@@ -2289,6 +2335,7 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
     float* Xs = smem;                       // [16][LDX]
     float* TT = smem + ((16 * LDX + 3) & ~3);     // [16][CAN_LDT]: U^T ([point][row]), then Tbar's value columns as [point][row] (the A operand, read transposed)
     float* CS = TT + 16 * CAN_LDT;          // [48][8]: column sums at the end of the sweep
+    float* Gs = CS + 48 * 8;                // DMA: [48][48] upstream tile
     const int lane = threadIdx.x, m16 = lane & 15, kg = lane >> 4;
     const int row0 = blockIdx.y * T;
     const int n2q = n2 * Q;
@@ -2348,12 +2395,62 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     float sK_sum = 0.f, l_acc = 0.f;
+    // the tile's R value rows of P2, one tile ahead, in registers (clamped addresses, no branches; zeroed past n2 where they are used)
+    f4 pf[2];
+    float pnrm = 0.f;
+    auto prefetch = [&](int ct_) {
+        const int j0 = ct_ * R;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(lane + 64 * u, R * pch - 1), r = e / pch, k = (e - r * pch) * 4;
+            pf[u] = *reinterpret_cast<const f4*>(P2 + (int64_t)min(j0 + r, n2 - 1) * Q * DP + k);
+        }
+        pnrm = self2[(int64_t)min(j0 + min(lane, R - 1), n2 - 1) * Q];
+    };
+    const unsigned gs_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Gs;
+    auto dma_tile = [&](int ct_) {           // (whole column tiles only)
+        if constexpr (DMA) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const int id = lane + 64 * u, r = id / 12, c4 = (id - 12 * r) * 4;
+                can_dma16(reinterpret_cast<const float*>(G) + (int64_t)min(row0 + r, n1q - 1) * ldg + ct_ * T + c4, gs_addr + u * 1024);
+            }
+        }
+    };
+    if ((int)blockIdx.x >= ncoltiles) return;       // (never: the launcher's grid is at most the number of column tiles)
+    prefetch(blockIdx.x);
+    if (DMA && (int)blockIdx.x * T + T <= n2q) dma_tile(blockIdx.x);
 
     for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
         const int j0 = ct * R, col0 = j0 * Q;
-        // upstream micro-blocks straight into registers (consumed after the U product)
         float g[PPL][Q][Q];
         bool mine[PPL];
+        const bool from_lds = DMA && col0 + T <= n2q;
+        if (from_lds) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this tile's DMA (and P2 rows) are in
+            asm volatile("" ::: "memory");
+            using V2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) {
+                mine[pp] = prow[pp] && j0 + pj_[pp] < n2;
+                const float* src = Gs + (pi_[pp] * Q) * T + pj_[pp] * Q;
+#pragma unroll
+                for (int a = 0; a < Q; ++a) {
+                    if constexpr (Q % 2 == 0) {
+#pragma unroll
+                        for (int b = 0; b < Q; b += 2) {
+                            const V2 x = *reinterpret_cast<const V2*>(src + a * T + b);
+                            g[pp][a][b] = mine[pp] ? x[0] : 0.f; g[pp][a][b + 1] = mine[pp] ? x[1] : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < Q; ++b) g[pp][a][b] = (mine[pp] && lane + 64 * pp < NPAIR) ? src[a * T + b] : 0.f;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done: the buffer may take the next tile
+        } else {
+        // upstream micro-blocks straight into registers (consumed after the U product)
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) {
             mine[pp] = prow[pp] && j0 + pj_[pp] < n2;
@@ -2375,26 +2472,31 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
                 for (int b = 0; b < Q; ++b) g[pp][a][b] = mine[pp] ? (float)src[a * ldg + b] : 0.f;
             }
         }
-        __syncthreads();
+        }
+        WAVE_SYNC();
         // the tile's R value rows of P2 (packed columns 0 .. DP-1; column K4 is the indicator: row sums of Tbar's value columns)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = lane + 64 * u, r = e / pch, k = (e - r * pch) * 4;
             if (e < R * pch) {
-                f4 x = f4{0.f, 0.f, 0.f, 0.f};
-                if (j0 + r < n2) x = *reinterpret_cast<const f4*>(P2 + (int64_t)(j0 + r) * Q * DP + k);
+                const bool in = j0 + r < n2;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) Xs[r * LDX + k + t] = x[t];
+                for (int t = 0; t < 4; ++t) Xs[r * LDX + k + t] = in ? pf[u][t] : 0.f;
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < R) {
             const bool ok = j0 + lane < n2;
             Xs[lane * LDX + K4 + 1] = 0.f;
             Xs[lane * LDX + K4 + 2] = ok ? 1.f : 0.f;
-            Xs[lane * LDX + K4 + 3] = ok ? self2[(int64_t)(j0 + lane) * Q] : 0.f;
+            Xs[lane * LDX + K4 + 3] = ok ? pnrm : 0.f;
         }
-        __syncthreads();
+        {   // the next tile of this workgroup: its P2 rows into registers, its upstream tile into LDS, under the work on this one
+            const int ctn = ct + (int)gridDim.x;
+            prefetch(min(ctn, ncoltiles - 1));
+            if (DMA && ctn < ncoltiles && ctn * T + T <= n2q) dma_tile(ctn);
+        }
+        WAVE_SYNC();
         f4 t[3];
         {
             const float* pb = Xs + m16 * LDX + kg;
@@ -2423,7 +2525,7 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
 #pragma unroll
             for (int i = 0; i < 3; ++i) *reinterpret_cast<f4*>(TT + m16 * CAN_LDT + i * 16 + kg * 4) = t[i];
         }
-        __syncthreads();
+        WAVE_SYNC();
         float tv[PPL][Q];                   // Tbar's value column of this pair: Tbar[(i, a)][(j, 0)]
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) {
@@ -2475,7 +2577,7 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
             sK_sum += t00;
             l_acc += k * (e1 + 2.f * e2) - t00 * nn + dots;
         }
-        __syncthreads();                    // every lane has read its U values: Tbar's value columns take their place, [point][row]
+        WAVE_SYNC();                    // every lane has read its U values: Tbar's value columns take their place, [point][row]
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) {
             if (lane + 64 * pp < NPAIR) {
@@ -2484,7 +2586,7 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
                 for (int a = 0; a < Q; ++a) tp[a] = tv[pp][a];
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         // dP1[48, NP] += Tbar[:, value columns][48, R] . X2'[R, NP]:  A operand lane (m, k) = Tbar[row m][point k] = TT[k][m]
         {
 #pragma unroll
@@ -2504,7 +2606,7 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
     }
     // ---- the column sums of Tbar's direction columns: across the R lanes of a point (pj = pid % R: xor steps below R), then into
     // packed column c_b of the point's rows through a small LDS table
-    __syncthreads();
+    WAVE_SYNC();
 #pragma unroll
     for (int pp = 0; pp < PPL; ++pp)
 #pragma unroll
@@ -2525,7 +2627,7 @@ __global__ __launch_bounds__(64, 2) void kernel_bwd_canon_kernel(const GT* __res
                 for (int b = 1; b < Q; ++b) CS[(pi_[pp] * Q + a) * 8 + b] = S[pp][a][b];
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
     float* myslab = slab + ((int64_t)blockIdx.x * n1q) * NP;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -2607,15 +2709,17 @@ extern "C" int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg
     if (ns > ctiles) ns = ctiles;
     float* slab = (float*)workspace;
     float* partials = slab + (size_t)bwd_nsplit(n1, n2, g) * n1q * g.NP;
-    const size_t lds = sizeof(float) * (((16 * (size_t)(g.NP + 1) + 3) & ~(size_t)3) + 16 * (size_t)CAN_LDT + 48 * 8);
     const int esz = g_is_double ? 8 : 4;
     const int gvec = (ldg % 2 == 0) && ((uintptr_t)G % (2 * esz) == 0);
+    const bool dma = CAN_BWD_DMA && !g_is_double && ldg % 4 == 0 && (uintptr_t)G % 16 == 0;       // (16-byte pieces of the upstream rows)
+    const size_t lds = sizeof(float) * (((16 * (size_t)(g.NP + 1) + 3) & ~(size_t)3) + 16 * (size_t)CAN_LDT + 48 * 8 + (dma ? 48 * 48 : 0));
     dim3 grid(ns, rt);
-#define DSVGP_CANON_BWD(GT_, Q_)                                                                                                        \
-    hipLaunchKernelGGL((kernel_bwd_canon_kernel<GT_, Q_>), grid, dim3(64), lds, ctx->stream, (const GT_*)G, ldg, P1, self1, n1q, P2, self2, \
-                       n2, g.K4, g.DP, g.NP, dir_idx, idx_base, gvec, hyp, slab, partials)
-    if (g_is_double) { if (g.q == 6) DSVGP_CANON_BWD(double, 6); else DSVGP_CANON_BWD(double, 3); }
-    else { if (g.q == 6) DSVGP_CANON_BWD(float, 6); else DSVGP_CANON_BWD(float, 3); }
+#define DSVGP_CANON_BWD(GT_, Q_, DMA_)                                                                                                  \
+    hipLaunchKernelGGL((kernel_bwd_canon_kernel<GT_, Q_, DMA_>), grid, dim3(64), lds, ctx->stream, (const GT_*)G, ldg, P1, self1, n1q, P2, \
+                       self2, n2, g.K4, g.DP, g.NP, dir_idx, idx_base, gvec, hyp, slab, partials)
+    if (g_is_double) { if (g.q == 6) DSVGP_CANON_BWD(double, 6, false); else DSVGP_CANON_BWD(double, 3, false); }
+    else if (dma) { if (g.q == 6) DSVGP_CANON_BWD(float, 6, true); else DSVGP_CANON_BWD(float, 3, true); }
+    else { if (g.q == 6) DSVGP_CANON_BWD(float, 6, false); else DSVGP_CANON_BWD(float, 3, false); }
 #undef DSVGP_CANON_BWD
     DSVGP_LAUNCH_CHECK();
     const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;

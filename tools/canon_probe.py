@@ -42,6 +42,10 @@ for geom in os.environ.get("CANON_GEOM", "500,4096,20,5;200,512,5,2;500,512,20,5
     t_bg = timeit(lambda: ops.kernel_bwd(ctx, G, pz, M, px, B, d, p, hyp, False, dx, dv, dh, ws))
     t_bc = timeit(lambda: ops.kernel_bwd_canon(ctx, G, pz, M, px, B, d, p, di, 1, hyp, dx, dv, dh, ws))
     tb = lambda ms: nbytes / ms / 1e9
+    if os.environ.get("CANON_FILL", "1") == "1":       # what streaming writes of the same buffer cost on this box (the forward's floor)
+        t_z = timeit(lambda: out.zero_()); t_c = timeit(lambda: out.copy_(G))
+        print("  fill of the %d x %d result: %.1f us (%.2f TB/s written)   copy: %.1f us (%.2f TB/s read + written)"
+              % (M * q, B * q, t_z * 1e3, out.numel() * 4 / t_z / 1e9, t_c * 1e3, out.numel() * 8 / t_c / 1e9))
     print("M=%d B=%d d=%d p=%d (%.1f MB): fwd general %.1f us (%.2f TB/s = %.2f of 8)  canonical %.1f us (%.2f TB/s = %.2f)  |diff| %.1e ;  "
           "bwd general %.1f us (%.2f = %.2f)  canonical %.1f us (%.2f TB/s = %.2f)"
           % (M, B, d, p, nbytes / 1e6, t_fg * 1e3, tb(t_fg), tb(t_fg) / 8, t_fc * 1e3, tb(t_fc), tb(t_fc) / 8, err, t_bg * 1e3, tb(t_bg), tb(t_bg) / 8,
