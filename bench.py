@@ -324,7 +324,7 @@ def main():
     # three more untimed steps with the side stream off, HIP events around the same launch
     EVENT_NAMES = ("solve_fwd", "assemble_fwd", "assemble_bwd", "gram", "dense", "early_reduce_wait", "final_reduce", "ciq_stacked_backward")
     durations = event_durations(eng, EVENT_NAMES)
-    iso_fwd = None
+    iso_fwd = iso_bwd = None
     if not cfg.get("ciq") and world == 1 and not args.fp64:
         saved = eng.overlap
         eng.overlap, eng.events = False, []
@@ -333,8 +333,11 @@ def main():
         for k in range(3):
             loop.step(batch(args.warmup + args.steps + 3 + k))
         torch.cuda.synchronize()
-        durs = event_durations(eng, ("assemble_fwd",))["assemble_fwd"]
+        iso = event_durations(eng, ("assemble_fwd", "assemble_bwd"))
+        durs = iso["assemble_fwd"]
         iso_fwd = sum(durs) / len(durs) if durs else None
+        durs = iso["assemble_bwd"]
+        iso_bwd = sum(durs) / len(durs) if durs else None
         eng.overlap = saved
     eng.record_events = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -424,7 +427,7 @@ def main():
                 coll_probe[name] = e0.elapsed_time(e1) / 10.0
             except Exception as ex:      # (a backend without the collective: report, do not fail the bench line)
                 coll_probe[name] = "unavailable: %s" % type(ex).__name__
-    def rooflines(cfg, eng, durations, iso_fwd, fp64, cfg_name, headline):
+    def rooflines(cfg, eng, durations, iso_fwd, fp64, cfg_name, headline, iso_bwd=None):
         """(roofline of the dominant kernel, assembly roofline) of one configuration from its HIP-event durations"""
         d, N, M, p, B = cfg["d"], cfg["N"], cfg["M"], cfg["p"], cfg["B"]
         # dominant kernel: the fp64 MFMA GEMM of the forward panel solve A = L^-1 K_ZX (one launch when nb >= M')
@@ -551,20 +554,27 @@ def main():
         t_b, n_b = avg("assemble_bwd")
         if t_f and t_b and not cfg.get("ciq"):
             nbytes = 4.0 * (float(Mp) * Bp_local + (M + B_local) * d * (p + 1))
+            # (the training loop states its one-hot directions as an index list: the canonical-direction kernels where they take (d, p))
+            canon = "_canon" if dsvgp_amd._ops.canon_supported(d, p) and not cfg.get("dfree_values") else ""
             roof_asm = dict(bound="hbm", peak=PEAK_HBM_TBPS, unit="TB/s", bytes_per_launch=nbytes,
-                            forward=dict(kernel="kernel_fwd (K_ZX, %d x %d fp32, interleaved block layout)" % (Mp, Bp_local),
+                            forward=dict(kernel="kernel_fwd%s (K_ZX, %d x %d fp32, interleaved block layout)" % (canon, Mp, Bp_local),
                                          avg_ms=t_f * 1e3, launches=n_f, achieved=nbytes / t_f / 1e12,
                                          frac=nbytes / t_f / 1e12 / PEAK_HBM_TBPS,
                                          note="queued on the side stream under the Cholesky chain when M' >= 2048: shares the CUs",
                                          alone_avg_ms=iso_fwd * 1e3 if iso_fwd else None,
                                          alone_achieved=nbytes / iso_fwd / 1e12 if iso_fwd else None,
                                          alone_frac=nbytes / iso_fwd / 1e12 / PEAK_HBM_TBPS if iso_fwd else None),
-                            backward=dict(kernel="kernel_bwd (reads K_ZX-bar once -> dZ, dV, d ell, d s)", avg_ms=t_b * 1e3,
-                                          launches=n_b, achieved=nbytes / t_b / 1e12, frac=nbytes / t_b / 1e12 / PEAK_HBM_TBPS))
+                            backward=dict(kernel="kernel_bwd%s + kernel_bwd_points (reads K_ZX-bar once -> dZ, dV, d ell, d s)" % canon,
+                                          avg_ms=t_b * 1e3,
+                                          launches=n_b, achieved=nbytes / t_b / 1e12, frac=nbytes / t_b / 1e12 / PEAK_HBM_TBPS,
+                                          note="queued on the side stream beside the Cholesky backward's tail when the second stream is on",
+                                          alone_avg_ms=iso_bwd * 1e3 if iso_bwd else None,
+                                          alone_achieved=nbytes / iso_bwd / 1e12 if iso_bwd else None,
+                                          alone_frac=nbytes / iso_bwd / 1e12 / PEAK_HBM_TBPS if iso_bwd else None))
 
         return roof, roof_asm
 
-    roof, roof_asm = rooflines(cfg, eng, durations, iso_fwd, args.fp64, args.config, True)
+    roof, roof_asm = rooflines(cfg, eng, durations, iso_fwd, args.fp64, args.config, True, iso_bwd)
     Mp = M * (p + 1)
     hl = (eng.trsm_nb, eng.lib_dense_gemm, bool(getattr(eng, "c_step_used", False)), getattr(eng, "pack_reduce", None),
           int(getattr(eng, "early_wire_numel", 0) or 0))

@@ -5,6 +5,7 @@ dtype and contiguity, then hands raw device pointers to libdsvgp_hip.so.  There 
 """
 import ctypes as C
 
+import os
 import torch
 
 from . import _lib
@@ -224,7 +225,34 @@ def kernel_fwd(ctx, pack1, n1, pack2, n2, d, p, hyp, jitter=0.0, out=None, dtype
 
 def canon_supported(d, p):
     """geometries the canonical-direction assembly kernels take (csrc/assemble.hip): p + 1 in {3, 6}, packed width <= 32"""
-    return (p + 1) in (3, 6) and ((d + 3) // 4 * 4 + 4 + 15) // 16 * 16 <= 32
+    return p >= 1 and bool(lib.dsvgp_kernel_canon_supported(int(d), int(p)))
+
+
+def state_directions(D, idx, base=0):
+    """The caller's statement that the direction matrix ``D`` [B p, d] is one-hot and shared by all points: row j p + b = e_{idx[b] - base}
+    for every j (what the reference's training step and evaluation build: directional_vi.py:81-88, 238, 292-294).  ``idx``: int32
+    tensor [p] on D's device.  The statement travels with the tensor (``model(x, derivative_directions=D)`` is unchanged); the step
+    then assembles K_ZX and its backward on the canonical-direction kernels where they take the geometry.  Returns D."""
+    if D is not None and idx is not None:
+        D._dsvgp_dir_idx = (idx, int(base))
+    return D
+
+
+def stated_directions(D, d, p):
+    """(idx, base) when ``D`` carries a usable statement (state_directions) for a geometry the canonical kernels take, else None.
+    DSVGP_CHECK_DIRS=1: verify the statement against D (a device read: tests / debugging)."""
+    st = getattr(D, "_dsvgp_dir_idx", None) if D is not None else None
+    if st is None or p < 1 or not canon_supported(d, p):
+        return None
+    idx, base = st
+    if not (torch.is_tensor(idx) and idx.dtype == torch.int32 and idx.is_cuda and idx.numel() == p and idx.is_contiguous()
+            and idx.device == D.device):
+        return None
+    if os.environ.get("DSVGP_CHECK_DIRS") == "1":
+        E = torch.eye(d, device=D.device, dtype=D.dtype)[(idx.long() - base)]
+        if not torch.equal(D.reshape(-1, p, d), E.expand(D.shape[0] // p, p, d)):
+            raise _lib.DsvgpError("state_directions: D is not the one-hot matrix the index list states")
+    return idx, int(base)
 
 
 def kernel_fwd_canon(ctx, pack1, n1, pack2, n2, d, p, dir_idx, idx_base, hyp, out=None):

@@ -161,6 +161,7 @@ class ElboEngine:
         # piecewise path below.  DSVGP_C_STEP=0 switches it off (A/B runs).
         self.c_step = os.environ.get("DSVGP_C_STEP", "1") == "1"
         self._plans = {}
+        self._zx_dirs = None                    # (idx, base) of the batch in flight when its directions were stated one-hot (_ops.state_directions)
         self.c_step_used = False        # whether the last step ran through the one-call path
         self.c_step_timed = []          # plans of the steps queued with record_events on, in order
         self.record_every = 1           # bench.py: HIP events on every record_every-th one-call step only (an event record costs the
@@ -308,7 +309,11 @@ class ElboEngine:
             return Kzx
         Kzx = self._get("Kzx", (Mp, B * (p + 1)), f32)
         ev = self._event_pair()                          # (on whichever stream the assembly is queued: main or side)
-        _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
+        st = self._zx_dirs
+        if st is not None:                               # one-hot shared directions stated by the caller (_ops.state_directions)
+            _ops.kernel_fwd_canon(ctx, packZ, M, packX, B, d, p, st[0], st[1], hyp, out=Kzx)
+        else:
+            _ops.kernel_fwd(ctx, packZ, M, packX, B, d, p, hyp, out=Kzx)
         self._event_done("assemble_fwd", ev)
         return Kzx
 
@@ -343,7 +348,11 @@ class ElboEngine:
             full[:, ::p + 1] = Kb32                      # derivative columns carry no gradient
             Kb32 = full
         ev = self._event_pair()
-        _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
+        st = self._zx_dirs if self.data_outputs != "values" else None
+        if st is not None:
+            _ops.kernel_bwd_canon(ctx, Kb32, packZ, M, packX, B, d, p, st[0], st[1], hyp, dZ, dV, d_hyp, kws)
+        else:
+            _ops.kernel_bwd(ctx, Kb32, packZ, M, packX, B, d, p, hyp, False, dZ, dV, d_hyp, kws)
         self._event_done("assemble_bwd", ev)
 
     def _interp(self, ctx, params, hyp, packZ, L, dims, x, D, reuse_inverse=False):
@@ -353,6 +362,7 @@ class ElboEngine:
         pd = self._pd(p)
         Bp = B * (pd + 1)
         packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        self._zx_dirs = _ops.stated_directions(D, d, p) if p > 0 else None
         Kzx = self._assemble_kzx(ctx, packZ, M, packX, B, d, p, hyp, Mp)
         A64 = self._get("A64", (Mp, Bp), f64)
         A32 = self._get("A32", (Mp, Bp), f32)
@@ -1104,6 +1114,8 @@ class ElboEngine:
         io.constant, io.raw_lengthscale = P(params["constant"]), P(params["raw_lengthscale"])
         io.raw_outputscale, io.raw_noise = P(params["raw_outputscale"]), P(params["raw_noise"])
         io.x, io.y, io.D = P(x), P(y), P(D)
+        st = _ops.stated_directions(D, d, p)            # (one-hot shared directions stated by the caller: the canonical assembly kernels)
+        io.dir_idx, io.dir_idx_base = (st[0].data_ptr(), st[1]) if st is not None else (None, 0)
         full = self._flat_full
         io.flat, io.flat_floats = full.data_ptr(), full.numel()
         io.dZ, io.dV, io.dm = P(grads["inducing_points"]), P(grads["inducing_directions"]), P(grads["variational_mean"])
@@ -1357,6 +1369,7 @@ class ElboEngine:
         LS = params["chol_variational_covar"]
         packZ = self._pending_packZ
         packX = _ops.pack_points(ctx, x.contiguous(), D.contiguous() if p > 0 else None, p, hyp, self.center)
+        self._zx_dirs = _ops.stated_directions(D, d, p) if p > 0 else None
         Kzx = self._assemble_kzx(ctx, packZ, M, packX, B, d, p, hyp, Mp)
         # [S - I | m / (2 vbar)]: one solve gives [Q' | a / (2 vbar)].  Rows padded to a multiple of 4 floats: the lean fp64
         # kernel (gemm64.hip) streams a float right-hand side with 16-byte loads

@@ -2661,6 +2661,12 @@ inline bool canon_ok(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 3
 
 }  // namespace
 
+extern "C" int dsvgp_kernel_canon_supported(int d, int p) {
+    Geom g;
+    if (p < 1 || make_geom(d, p, g)) return 0;
+    return canon_ok(g) ? 1 : 0;
+}
+
 // K_ZX with canonical (one-hot) directions on side 2, shared by all its points: see the block comment above kernel_fwd_canon_kernel.
 // P2 / self2: the packed rows of side 2 as dsvgp_pack_points leaves them (only the value rows are read).  DSVGP_EINVAL for a geometry the
 // canonical kernels do not take (q not in {3, 6} or packed width > 32): the caller uses dsvgp_kernel_fwd.

@@ -310,6 +310,22 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
 //        bit 2 = record HIP-event timings; bit 3 = the workspace may have been written by somebody else (re-clear the paddings).
 // io->flat .. flat + flat_floats is cleared here (the gradient slots must start from zero); every gradient pointer of io points
 // into it.  All pointers are device pointers; nothing is read back.
+// K_ZX and its backward: on the canonical-direction kernels when the caller states the minibatch's directions as an index list
+// (io->dir_idx, include/dsvgp.h) and they take the geometry, on the general kernels otherwise
+static inline bool zx_canon(const dsvgp_elbo_step_io* io, int d, int p) { return io->dir_idx && dsvgp_kernel_canon_supported(d, p); }
+static int zx_fwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const float* PZ, const float* sZ, int M, const float* PX, const float* sX,
+                  int B, int d, int p, const float* hyp, float* Kzx, int64_t ld) {
+    if (zx_canon(io, d, p)) return dsvgp_kernel_fwd_canon(ctx, PZ, sZ, M, PX, sX, B, d, p, io->dir_idx, io->dir_idx_base, hyp, Kzx, ld);
+    return dsvgp_kernel_fwd(ctx, PZ, sZ, M, PX, sX, B, d, p, hyp, 0.f, Kzx, ld, 0);
+}
+static int zx_bwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const float* Kb32, int64_t ld, const float* PZ, const float* sZ,
+                  const float* vZ, int M, const float* PX, const float* sX, int B, int d, int p, const float* hyp, void* ws) {
+    if (zx_canon(io, d, p))
+        return dsvgp_kernel_bwd_canon(ctx, Kb32, ld, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, io->dir_idx, io->dir_idx_base, hyp, io->dZ, io->dV,
+                                      io->d_hyp, ws);
+    return dsvgp_kernel_bwd(ctx, Kb32, ld, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, ws);
+}
+
 static int step_validate(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace, size_t workspace_bytes) {
     if (!ctx || !pl || !io || !workspace || workspace_bytes < pl->bytes || ((uintptr_t)workspace % 256)) return DSVGP_EINVAL;
     if (!io->Z || !io->m || !io->LS || !io->constant || !io->raw_lengthscale || !io->raw_outputscale || !io->raw_noise || !io->x ||
@@ -391,7 +407,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         int rc = dsvgp_pack_points(ctx, io->x, io->D, B, d, p, hyp, center, PX, sX, vX);
         if (rc) return rc;
         if (timed && hipEventRecord(pl->tm[2], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
-        rc = dsvgp_kernel_fwd(ctx, PZ, sZ, M, PX, sX, B, d, p, hyp, 0.f, Kzx, Bp, 0);
+        rc = zx_fwd(ctx, io, PZ, sZ, M, PX, sX, B, d, p, hyp, Kzx, Bp);
         if (rc) return rc;
         if (timed && hipEventRecord(pl->tm[3], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
         // S = tril(L_S) tril(L_S)^T: lower triangle + mirror (n^3 / 6 multiply-adds), as a one-workgroup-per-CU filler beside the chain
@@ -664,7 +680,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
         ctx->stream = side;
         STEP_TIME(4);
-        STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws2));
+        STEP_CALL(zx_bwd(ctx, io, Kb32, Bp, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, kbwd_ws2));
         STEP_TIME(5);
         STEP_HIP(hipEventRecord(pl->ev_zx, side));
         ctx->stream = main;
@@ -675,7 +691,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     }
     if (!zx_side) {
         STEP_TIME(4);
-        STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+        STEP_CALL(zx_bwd(ctx, io, Kb32, Bp, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, kbwd_ws));
         STEP_TIME(5);
     }
     if (zx_side || tail_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
@@ -730,7 +746,7 @@ extern "C" int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
     auto prologue = [&]() -> int {
         int rc = dsvgp_pack_points(ctx, io->x, io->D, B, d, p, hyp, center, PX, sX, vX);
         if (rc) return rc;
-        return dsvgp_kernel_fwd(ctx, PZ, sZ, M, PX, sX, B, d, p, hyp, 0.f, Kzx, Bp, 0);
+        return zx_fwd(ctx, io, PZ, sZ, M, PX, sX, B, d, p, hyp, Kzx, Bp);
     };
     if (overlap) {
         STEP_HIP(hipEventRecord(pl->ev_fork, main));
@@ -764,7 +780,7 @@ extern "C" int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
     STEP_CALL(dsvgp_trsm(ctx, L, Mp, Mp, 1, Abar, Bp, 0, Bp, Kb64, Bp, Kb32, Bp, nb, trsm_ws, 1));            // K_ZX-bar = L^-T A-bar
     STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Bp, -1.0, Kb64, Bp, A64, Bp, 0.0, nullptr, 0, Lbar, Mp,
                          nullptr, 0, nullptr));                                                              // L-bar = -tril(K_ZX-bar A^T)
-    STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    STEP_CALL(zx_bwd(ctx, io, Kb32, Bp, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, kbwd_ws));
     const double* Linv = (const double*)trsm_ws;
     STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, L, Mp,
                          Lbar, Mp, 0.0, nullptr, 0, G1, Mp, nullptr, 0, nullptr));                            // tril(L^T L-bar)
@@ -899,7 +915,7 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
                              Bp, nullptr, 0, nullptr));
         STEP_TIME(9);
         STEP_TIME(4);
-        STEP_CALL(dsvgp_kernel_bwd(ctx, Kb32, Bp, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, 0, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+        STEP_CALL(zx_bwd(ctx, io, Kb32, Bp, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, kbwd_ws));
         STEP_TIME(5);
         return 0;
     }

@@ -224,6 +224,12 @@ class TrainLoop:
                                 dist.broadcast(st[k], dp.src0, group=dp.group)
         return same
 
+    def _arange_p(self, p):
+        t = getattr(self, "_arange_cache", None)
+        if t is None or t.numel() != p:
+            t = self._arange_cache = torch.arange(p, dtype=torch.int32, device=self.device)
+        return t
+
     def _device_step(self, idx, cols, py):
         """minibatch gather + fused ELBO forward / backward (gradients land in ``.grad``); everything here is stream work"""
         dim, p, dev = self.dim, self.minibatch_dim, self.device
@@ -242,14 +248,16 @@ class TrainLoop:
             _ops.gather_batch(self.ctx, self.X, self.Y, idx, cols, py, x_batch, y_batch,  # interleaved y, :241
                               self.E_canonical if fused_dirs else None, Db)              # + the directions, :238
         kwargs = {}
+        # (the directions are rows of E_canonical, the same p of them for every point: said to the engine as an index list next to
+        #  the matrix itself -- _ops.state_directions -- so that K_ZX runs on the canonical-direction assembly kernels)
         if self.dfree:                          # dfree_directional_vi.py:224-227
-            kwargs["derivative_directions"] = self.E_canonical[:p].repeat(nb, 1)
+            kwargs["derivative_directions"] = _ops.state_directions(self.E_canonical[:p].repeat(nb, 1), self._arange_p(p), 0)
         elif not self.full_gradient:
             if Db is not None:
-                kwargs["derivative_directions"] = Db
+                kwargs["derivative_directions"] = _ops.state_directions(Db, cols[1:], 1)
             else:
                 derivative_directions = self.E_canonical.index_select(0, cols[1:].long() - 1)
-                kwargs["derivative_directions"] = derivative_directions.repeat(nb, 1)   # :238
+                kwargs["derivative_directions"] = _ops.state_directions(derivative_directions.repeat(nb, 1), cols[1:], 1)   # :238
 
         self.variational_optimizer.zero_grad()
         self.hyperparameter_optimizer.zero_grad()
@@ -552,6 +560,8 @@ def eval_gp(test_dataset, model, likelihood,
             # redo derivative directions b/c batch size is not consistent
             derivative_directions = torch.eye(dim, device=device)[:num_directions]
             derivative_directions = derivative_directions.repeat(len(x_batch), 1)
+            if derivative_directions.is_cuda:   # eye(d)[:p] tiled: one-hot and shared (canonical-direction assembly)
+                _ops.state_directions(derivative_directions, torch.arange(num_directions, dtype=torch.int32, device=device), 0)
             preds = likelihood(model(x_batch, derivative_directions=derivative_directions))
             means.append(preds.mean.cpu())
             variances.append(preds.variance.cpu())

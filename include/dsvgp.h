@@ -113,6 +113,8 @@ int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double
                      const float* self1, const float* vnorm1, int n1, const float* P2,
                      const float* self2, int n2, int d, int p, const float* hyp, int symmetric,
                      float* d_x1, float* d_v1, float* d_hyp, void* workspace);
+/* 1 when dsvgp_kernel_fwd_canon / _bwd_canon take the geometry (d, p), 0 otherwise */
+int dsvgp_kernel_canon_supported(int d, int p);
 /* backward of dsvgp_kernel_fwd_canon (symmetric = 0 semantics; same workspace size as dsvgp_kernel_bwd) */
 int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double, const float* P1,
                            const float* self1, const float* vnorm1, int n1, const float* P2,
@@ -447,6 +449,13 @@ typedef struct dsvgp_elbo_step_io {
      * its transpose and [Q' | a] -- the Gram product and the dense K_ZX-bar product then run on the bf16 matrix pipe as six
      * bf16 products per fp32 product (csrc/gemm3b.hip); NULL / flag clear: v_mfma_f32_32x32x2_f32 (the default)                */
     void* split_ws; size_t split_ws_bytes;
+    /* optional (NULL: not stated): the minibatch's derivative directions as an INDEX LIST.  The reference's training step builds D as
+     * E_canonical[idx - 1] tiled over the minibatch (directional_vi.py:81-88, 238: the same p coordinates for every point), its
+     * evaluation as eye(d)[:p] tiled (:292-294).  dir_idx [p] (device, int32): row j p + b of D is e_{dir_idx[b] - dir_idx_base}
+     * for every point j -- the caller's statement about D (which is still read: the packed rows).  K_ZX and its backward then run
+     * on the canonical-direction kernels (dsvgp_kernel_fwd_canon / _bwd_canon) where those take the geometry (p + 1 in {3, 6},
+     * d <= 28), on the general ones otherwise.  Appended in round 6: callers that zero-initialise the struct keep the old meaning. */
+    const int* dir_idx; int dir_idx_base;
 } dsvgp_elbo_step_io;
 size_t dsvgp_elbo_step_split_bytes(int M, int d, int p, int B);
 size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B);

@@ -897,6 +897,68 @@ def test_step_matches_autograd_through_the_reference_forward(dsvgp, gpu_device, 
     assert errs["loss"] < 2e-5 and max(errs[k] for k in PARAM_KEYS) < 2e-3, errs
 
 
+# ------------------------------------------------------------------ directions stated as an index list (canonical-direction assembly)
+def _stated(dsvgp, D, cols, dev):
+    """the batch's direction matrix on the device with the caller's statement attached (what TrainLoop._device_step does):
+    row j p + b = e_{cols[b + 1] - 1}"""
+    idx = torch.tensor(cols, dtype=torch.int32, device=dev)
+    return dsvgp._ops.state_directions(D.to(dev), idx[1:], 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d,M,p,B", [(600, 5, 40, 2, 128), (500, 20, 30, 5, 96), (700, 20, 30, 5, 131), (3000, 5, 200, 2, 512), (900, 28, 17, 5, 77)])
+@pytest.mark.parametrize("path", ["one-call", "piecewise", "per-output", "PLL"])
+def test_step_with_stated_one_hot_directions(dsvgp, gpu_device, monkeypatch, N, d, M, p, B, path):
+    """K_ZX and its backward on the canonical-direction kernels (io->dir_idx / _ops.state_directions) against the same step on the
+    general kernels (same inputs, the statement left out) and against the float64 oracle at the tolerance of test_step_matches_oracle.
+    DSVGP_CHECK_DIRS=1: the statement itself is checked against D."""
+    monkeypatch.setenv("DSVGP_CHECK_DIRS", "1")
+    assert dsvgp._ops.canon_supported(d, p)
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=N + d + 3)
+    cols = [0] + [int(r.argmax()) + 1 for r in D[:p]]        # (make_problem drew the columns from its generator: read them off D)
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    xd, yd = x.to(gpu_device), y.to(gpu_device)
+    mll = "PLL" if path == "PLL" else "ELBO"
+    fast = path in ("one-call", "piecewise")
+    out = {}
+    for stated in (False, True):
+        eng = dsvgp.ElboEngine(gpu_device)
+        eng.c_step = path != "piecewise"
+        Dd = _stated(dsvgp, D, cols, gpu_device) if stated else D.to(gpu_device)
+        out[stated] = eng.loss_and_grads(Pg, xd, yd, Dd, nd, mll, fast=fast)
+        torch.cuda.synchronize()
+        assert (eng._zx_dirs is not None or eng.c_step_used) if stated else eng._zx_dirs is None
+    (l0, g0, mu0, v0), (l1, g1, mu1, v1) = out[False], out[True]
+    errs = {"loss": abs(l1.item() - l0.item()) / abs(l0.item()), "mu": relmax(mu1, mu0)}
+    # (two assemblies of K_ZX that differ in the last bits of its entries -- 2e-7 -- seen through L^-1: observed 1.4e-5 on mu at M' = 600,
+    #  1e-5 on the inducing-point gradients; a wrong operand shows at 1e-3+.  The float64 oracle below is the bound that counts.)
+    assert errs["loss"] < 4e-6 and errs["mu"] < 1e-4, errs
+    if not fast:
+        errs["varn"] = relmax(v1, v0)
+        assert errs["varn"] < 1e-4, errs
+    for k in O.PARAM_NAMES:
+        errs[k] = relmax(g1[k], g0[k])
+        assert errs[k] < 2e-4, (k, errs[k])
+    P64 = {k: v.double() for k, v in P.items()}
+    _, g64, _, _ = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), nd, mll)
+    for k in O.PARAM_NAMES:
+        e = relmax(g1[k], g64[k])
+        errs[k + "(f64 oracle)"] = e
+        assert e < GRAD_TOL_FP64, (k, e)
+    _report("stated directions N=%d d=%d M=%d p=%d B=%d %s" % (N, d, M, p, B, path), errs)
+
+
+@pytest.mark.gpu
+def test_a_wrong_statement_about_the_directions_is_caught_by_the_check(dsvgp, gpu_device, monkeypatch):
+    monkeypatch.setenv("DSVGP_CHECK_DIRS", "1")
+    P, x, y, D, nd = make_problem(600, 5, 40, 2, 128, seed=11)
+    cols = [0] + [int(r.argmax()) + 1 for r in D[:2]]
+    cols[1] = cols[1] % 5 + 1 if cols[1] % 5 + 1 != cols[2] else (cols[1] + 1) % 5 + 1
+    Pg = {k: v.to(gpu_device) for k, v in P.items()}
+    with pytest.raises(dsvgp._lib.DsvgpError):
+        dsvgp.ElboEngine(gpu_device).loss_and_grads(Pg, x.to(gpu_device), y.to(gpu_device), _stated(dsvgp, D, cols, gpu_device), nd)
+
+
 # ------------------------------------------------------------------ the whole step from one host call (csrc/step.hip)
 @pytest.mark.parametrize("N,d,M,p,B", [(600, 5, 40, 2, 128), (500, 20, 30, 5, 96), (300, 6, 70, 0, 64), (3000, 5, 200, 2, 512),
                                        (6000, 20, 370, 5, 700)])
