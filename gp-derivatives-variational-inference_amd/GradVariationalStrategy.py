@@ -9,6 +9,7 @@ Differences honoured here: no learnable directions, ``psd_safe_cholesky`` defaul
 """
 import torch
 
+from . import _ops
 from .gp_shim import PredictiveDistribution
 
 
@@ -47,6 +48,8 @@ class GradVariationalStrategy(torch.nn.Module):
         if x.size(-1) != dim:
             raise RuntimeError("input dimension %d does not match the inducing points (%d)" % (x.size(-1), dim))
         D = torch.eye(dim, device=x.device, dtype=x.dtype).repeat(x.size(-2), 1)     # RBFKernelGrad: all d partials
+        if D.is_cuda:        # (said to the engine as an index list too: the both-sides one-hot assembly kernels, _ops.state_directions)
+            _ops.state_directions(D, _ops.index_range(D.device, dim), 0)
         return PredictiveDistribution(self.model, x, D)
 
     def __call__(self, x, prior=False, **kwargs):

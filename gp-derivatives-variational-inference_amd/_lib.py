@@ -36,7 +36,7 @@ class ElboStepIO(C.Structure):
                 ("dZ", _p), ("dV", _p), ("dm", _p), ("dLS", _p), ("lddls", _l),
                 ("d_hyp", _p), ("d_constant", _p), ("d_raw_lengthscale", _p), ("d_raw_outputscale", _p), ("d_raw_noise", _p),
                 ("loss", _p), ("mu", _p), ("num_data", _d), ("global_rows", _d), ("kzz_jitter", _f),
-                ("split_ws", _p), ("split_ws_bytes", _z), ("dir_idx", _p), ("dir_idx_base", _i)]
+                ("split_ws", _p), ("split_ws_bytes", _z), ("dir_idx", _p), ("dir_idx_base", _i), ("v_one_hot", _i)]
 
 
 class ElboStepDP(C.Structure):
@@ -100,6 +100,9 @@ SIGNATURES = {
     "dsvgp_kernel_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "dsvgp_kernel_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
     "dsvgp_kernel_canon_supported": (_i, [_i, _i]),
+    "dsvgp_kernel_canon2_supported": (_i, [_i, _i]),
+    "dsvgp_kernel_fwd_canon2": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i, _p, _f, _p, _l, _i]),
+    "dsvgp_kernel_bwd_canon2": (_i, [_p, _p, _l, _i, _p, _p, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "dsvgp_kernel_bwd_canon": (_i, [_p, _p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     "dsvgp_pack_points_f64": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dsvgp_kernel_transform_f64": (_i, [_p, _p, _l, _p, _i, _p, _i, _i, _p, _d]),

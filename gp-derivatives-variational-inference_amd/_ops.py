@@ -238,11 +238,40 @@ def state_directions(D, idx, base=0):
     return D
 
 
-def stated_directions(D, d, p):
+_RANGES = {}
+_NO_CANON = os.environ.get("DSVGP_NO_CANON") == "1"      # tools: ignore the statements (the general assembly kernels everywhere: A/B runs)
+
+
+def index_range(device, n):
+    """the cached int32 tensor [0, 1, .., n - 1] on ``device`` (ONE object per device and length: statements that name all coordinates in
+    order -- eye(d)[:p] tiled -- can be recognised as equal by identity)"""
+    key = (str(device), int(n))
+    t = _RANGES.get(key)
+    if t is None:
+        t = _RANGES[key] = torch.arange(int(n), dtype=torch.int32, device=device)
+    return t
+
+
+def same_statement(st_a, st_b):
+    """whether two (idx, base) statements name the same list without reading device memory: the same tensor object / storage and base"""
+    return (st_a is not None and st_b is not None and st_a[1] == st_b[1] and st_a[0].data_ptr() == st_b[0].data_ptr()
+            and st_a[0].numel() == st_b[0].numel())
+
+
+def detach_keep(t):
+    """``t.detach()`` with the caller's statement about a direction matrix (state_directions) carried over to the new tensor object"""
+    out = t.detach()
+    st = getattr(t, "_dsvgp_dir_idx", None)
+    if st is not None:
+        out._dsvgp_dir_idx = st
+    return out
+
+
+def stated_directions(D, d, p, supported=None):
     """(idx, base) when ``D`` carries a usable statement (state_directions) for a geometry the canonical kernels take, else None.
     DSVGP_CHECK_DIRS=1: verify the statement against D (a device read: tests / debugging)."""
     st = getattr(D, "_dsvgp_dir_idx", None) if D is not None else None
-    if st is None or p < 1 or not canon_supported(d, p):
+    if st is None or p < 1 or _NO_CANON or not (supported or canon_supported)(d, p):
         return None
     idx, base = st
     if not (torch.is_tensor(idx) and idx.dtype == torch.int32 and idx.is_cuda and idx.numel() == p and idx.is_contiguous()
@@ -253,6 +282,42 @@ def stated_directions(D, d, p):
         if not torch.equal(D.reshape(-1, p, d), E.expand(D.shape[0] // p, p, d)):
             raise _lib.DsvgpError("state_directions: D is not the one-hot matrix the index list states")
     return idx, int(base)
+
+
+def canon2_supported(d, p):
+    """geometries the both-sides one-hot assembly kernels take (csrc/assemble.hip: p + 1 = 11, d <= 12 -- the full-gradient SVGP at d = 10)"""
+    return p >= 1 and bool(lib.dsvgp_kernel_canon2_supported(int(d), int(p)))
+
+
+def _req_idx(dir_idx, p):
+    if dir_idx.dtype != torch.int32 or not dir_idx.is_cuda or dir_idx.numel() != p or not dir_idx.is_contiguous():
+        raise ValueError("dir_idx must be a contiguous int32 GPU tensor with p entries")
+
+
+def kernel_fwd_canon2(ctx, pack1, n1, pack2, n2, d, p, dir_idx, idx_base, hyp, jitter=0.0, out=None, dtype=None):
+    """K(x1, x2; E, E), E = the unit vectors e_{dir_idx - idx_base}, on both sides (GradVariationalStrategy.py:89-99 for dir_idx = 0..d-1)"""
+    q = p + 1
+    if out is None:
+        out = torch.empty(n1 * q, n2 * q, dtype=dtype or f32, device=pack1[0].device)
+    if out.dtype not in (f32, torch.float64) or out.dim() != 2 or out.stride(1) != 1 or not out.is_cuda:
+        raise ValueError("out must be a float32 / float64 GPU matrix with unit inner stride")
+    _req_idx(dir_idx, p)
+    check(lib.dsvgp_kernel_fwd_canon2(ctx.h, _ptr(pack1[0]), n1, _ptr(pack2[0]), n2, d, p, _ptr(dir_idx), int(idx_base), _ptr(hyp),
+                                      float(jitter), _ptr(out), _ld(out), 1 if out.dtype == torch.float64 else 0), "dsvgp_kernel_fwd_canon2")
+    return out
+
+
+def kernel_bwd_canon2(ctx, G, pack1, n1, pack2, n2, d, p, dir_idx, idx_base, hyp, symmetric, d_x1, d_v1, d_hyp, workspace=None):
+    """backward of kernel_fwd_canon2: += d_x1, d_hyp[0..1] (d_v1 untouched: the directions are fixed)"""
+    isd = G.dtype == torch.float64
+    if G.dtype not in (f32, torch.float64) or G.dim() != 2 or G.stride(1) != 1 or not G.is_cuda:
+        raise ValueError("G must be a float32 / float64 GPU matrix with unit inner stride")
+    _req_idx(dir_idx, p)
+    if workspace is None:
+        workspace = torch.empty(int(lib.dsvgp_kernel_bwd_workspace_bytes(n1, n2, d, p)), dtype=torch.uint8, device=G.device)
+    check(lib.dsvgp_kernel_bwd_canon2(ctx.h, _ptr(G), _ld(G), 1 if isd else 0, _ptr(pack1[0]), _ptr(pack1[2]), n1, _ptr(pack2[0]), n2, d, p,
+                                      _ptr(dir_idx), int(idx_base), _ptr(hyp), 1 if symmetric else 0, _ptr(d_x1), _ptr(d_v1), _ptr(d_hyp),
+                                      _ptr(workspace)), "dsvgp_kernel_bwd_canon2")
 
 
 def kernel_fwd_canon(ctx, pack1, n1, pack2, n2, d, p, dir_idx, idx_base, hyp, out=None):

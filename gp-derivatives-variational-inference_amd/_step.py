@@ -1114,8 +1114,12 @@ class ElboEngine:
         io.constant, io.raw_lengthscale = P(params["constant"]), P(params["raw_lengthscale"])
         io.raw_outputscale, io.raw_noise = P(params["raw_outputscale"]), P(params["raw_noise"])
         io.x, io.y, io.D = P(x), P(y), P(D)
-        st = _ops.stated_directions(D, d, p)            # (one-hot shared directions stated by the caller: the canonical assembly kernels)
+        # (one-hot shared directions stated by the caller: the canonical assembly kernels; the same statement on the inducing directions --
+        #  the full-gradient SVGP -- the both-sides kernels)
+        st = _ops.stated_directions(D, d, p, lambda d_, p_: _ops.canon_supported(d_, p_) or _ops.canon2_supported(d_, p_))
         io.dir_idx, io.dir_idx_base = (st[0].data_ptr(), st[1]) if st is not None else (None, 0)
+        io.v_one_hot = 1 if (st is not None and _ops.canon2_supported(d, p)
+                             and _ops.same_statement(st, _ops.stated_directions(V, d, p, _ops.canon2_supported))) else 0
         full = self._flat_full
         io.flat, io.flat_floats = full.data_ptr(), full.numel()
         io.dZ, io.dV, io.dm = P(grads["inducing_points"]), P(grads["inducing_directions"]), P(grads["variational_mean"])

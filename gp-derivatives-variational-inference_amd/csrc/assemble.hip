@@ -2735,6 +2735,329 @@ extern "C" int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg
     return 0;
 }
 
+
+// =================================================================================================
+// One-hot directions on BOTH sides, the same index list for every point of both (round 6): the full-gradient SVGP (reference
+// GradVariationalStrategy.py:89-99: RBFKernelGrad over cat([Z, x]) = the directional kernel with p = d and I_d at every inducing and data
+// point; BASELINE config 3), or any model whose inducing directions are FIXED to the canonical columns of its data.
+// With v1_a = e_{c_a} and v2_b = e_{c_b}:  u_a = delta[c_a], w_b = delta[c_b], G_ab = [a == b], delta = x1~ - x2~ -- every block is an
+// elementwise function of (k, delta_c), no products:
+//     K00 = k;   K0b = k delta_b / ell;   Ka0 = -k delta_a / ell;   Kab = k ([a == b] - delta_a delta_b) / ell^2;   k = s exp(-|delta|^2 / 2)
+// One wave per workgroup, ONE PAIR OF POINTS PER LANE: tile = 4 points of side 1 x 16 (float) / 8 (double upstream) points of side 2.  The
+// tile passes through LDS ([4 Q][16 Q] floats, dense: 256 Q^2 bytes) so that it leaves (forward) as whole 16-byte pieces of its rows and
+// arrives (backward) by LDS-DMA, one tile ahead; a lane's accesses to its Q x Q block are bank-conflict free for Q = 11 (11 j + 16 i mod 64
+// are 64 different banks).
+// Backward: with Gm = G : K / k = G00 + (r0 - c0) / ell + (tr - quad) / ell^2  (r0 = sum_b G0b delta_b, c0 = sum_a Ga0 delta_a,
+// tr = sum_a Gaa, quad = delta^T G' delta) the gradient w.r.t. the difference vector is
+//     d delta_m = -k Gm delta_m  (all d coordinates, through k)  +  [m = c_c]  k ((G0c - Gc0) / ell - ((G' delta)_c + (G'^T delta)_c) / ell^2)
+// The first part is the general kernels' T00-bar mechanism (w_ij = k Gm: dP1[value row] += sum_j w_ij x2~_j, its indicator column collects
+// sum_j w_ij; kernel_bwd_points_kernel turns that into -sum_j w_ij x1~); the second lands in packed column c_c of the value row.  The
+// direction rows of the slab are written as zeros: the directions are not parameters here (d_v1 += 0).
+// Instantiated for Q = 11 (d = p = 10 <= 12); other geometries return DSVGP_EINVAL and the caller uses the general kernels.
+// =================================================================================================
+template <int Q, typename OT>
+__global__ __launch_bounds__(64) void kernel_fwd_canon2_kernel(const float* __restrict__ P1, int n1, const float* __restrict__ P2, int n2,
+                                                               int d, int DP, const int* __restrict__ dir_idx, int idx_base,
+                                                               const float* __restrict__ hyp, float jitter, OT* __restrict__ out,
+                                                               int64_t ld, int ovec) {
+    constexpr int RP = 4, CP = 16, W = CP * Q, H = RP * Q, CPR = W / 4, NCH = H * CPR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ts = smem;                       // [H][W]
+    float* X1s = Ts + H * W;                // [RP][DP] value rows of the tile's points of side 1
+    float* X2s = X1s + RP * DP;             // [CP][DP]
+    const int lane = threadIdx.x, i = lane >> 4, j = lane & 15;
+    const int p0 = blockIdx.y * RP, j0 = blockIdx.x * CP;
+    for (int e = lane; e < RP * DP; e += 64) {
+        const int r = e / DP, k = e - r * DP;
+        X1s[e] = (p0 + r < n1) ? P1[(int64_t)(p0 + r) * Q * DP + k] : 0.f;
+    }
+    for (int e = lane; e < CP * DP; e += 64) {
+        const int r = e / DP, k = e - r * DP;
+        X2s[e] = (j0 + r < n2) ? P2[(int64_t)(j0 + r) * Q * DP + k] : 0.f;
+    }
+    WAVE_SYNC();
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+    float dl[Q];
+    dl[0] = 0.f;
+#pragma unroll
+    for (int b = 1; b < Q; ++b) {
+        const int c = dir_idx[b - 1] - idx_base;
+        dl[b] = X1s[i * DP + c] - X2s[j * DP + c];
+    }
+    float nn = 0.f;
+    for (int k = 0; k < d; ++k) {
+        const float t = X1s[i * DP + k] - X2s[j * DP + k];
+        nn = __builtin_fmaf(t, t, nn);
+    }
+    const bool valid = p0 + i < n1 && j0 + j < n2;
+    const float kv = valid ? s * expf(-0.5f * nn) : 0.f;                // postprocess_rbf, ScaleKernel
+    const float kil = kv * il, kil2 = kv * il2;
+    const float jd = (valid && p0 + i == j0 + j) ? jitter : 0.f;        // the global diagonal
+    float* blk = Ts + (i * Q) * W + j * Q;
+#pragma unroll
+    for (int a = 0; a < Q; ++a)
+#pragma unroll
+        for (int b = 0; b < Q; ++b) {
+            float v;
+            if (a == 0) v = (b == 0) ? kv : dl[b] * kil;
+            else if (b == 0) v = -dl[a] * kil;
+            else v = ((a == b) ? kil2 : 0.f) - dl[a] * dl[b] * kil2;
+            if (a == b) v += jd;
+            blk[a * W + b] = v;
+        }
+    WAVE_SYNC();
+    const int64_t row0 = (int64_t)p0 * Q, col0 = (int64_t)j0 * Q;
+    const int64_t n1q = (int64_t)n1 * Q, n2q = (int64_t)n2 * Q;
+    const bool full = ovec && row0 + H <= n1q && col0 + W <= n2q;
+    OT* obase = out + row0 * ld + col0;
+    for (int id = lane; id < NCH; id += 64) {
+        const int r = id / CPR, c4 = (id - r * CPR) * 4;
+        const f4 x = *reinterpret_cast<const f4*>(Ts + r * W + c4);
+        OT* o = obase + (int64_t)r * ld + c4;
+        if (full) {
+            if constexpr (sizeof(OT) == 4) *reinterpret_cast<f4*>(o) = x;
+            else {
+                using d2 = double __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<d2*>(o) = d2{(double)x[0], (double)x[1]};
+                *reinterpret_cast<d2*>(o + 2) = d2{(double)x[2], (double)x[3]};
+            }
+        } else if (row0 + r < n1q) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (col0 + c4 + t < n2q) o[t] = (OT)x[t];
+        }
+    }
+}
+
+template <int Q, typename GT>
+__global__ __launch_bounds__(64) void kernel_bwd_canon2_kernel(const GT* __restrict__ G, int64_t ldg, const float* __restrict__ P1, int n1,
+                                                               const float* __restrict__ P2, int n2, int d, int K4, int DP, int NP,
+                                                               const int* __restrict__ dir_idx, int idx_base,
+                                                               const float* __restrict__ hyp, float* __restrict__ slab,
+                                                               float* __restrict__ partials) {
+    constexpr int RP = 4, CP = 64 / (int)sizeof(GT), W = CP * Q, H = RP * Q, EPC = 16 / (int)sizeof(GT), CPR = W / EPC, NCH = H * CPR;
+    constexpr int NDMA = (NCH + 63) / 64;   // 1 KB pieces of the tile (the last one partly past it: the buffer is that long)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    GT* Ts = reinterpret_cast<GT*>(smem);   // [H][W], dense
+    float* X1s = smem + NDMA * 256;         // [RP][DP]
+    float* X2s = X1s + RP * DP;             // [CP][DP]
+    float* Wt = X2s + CP * DP;              // [RP][CP] w_ij of the tile
+    float* rowbuf = Wt + RP * CP;           // [RP][NP] the value rows of the slab at the end
+    const int lane = threadIdx.x, i = lane / CP, j = lane - i * CP;
+    const bool lane_on = i < RP;            // (double upstream: 32 pairs per tile)
+    const int ii = lane_on ? i : 0;
+    const int p0 = blockIdx.y * RP;
+    const int64_t n1q = (int64_t)n1 * Q, n2q = (int64_t)n2 * Q;
+    const int ncoltiles = (n2 + CP - 1) / CP;
+    const float ell = hyp[0], s = hyp[1];
+    const float il = 1.f / ell, il2 = il * il;
+    int cidx[Q];
+#pragma unroll
+    for (int b = 1; b < Q; ++b) cidx[b] = dir_idx[b - 1] - idx_base;
+    cidx[0] = 0;
+    for (int e = lane; e < RP * DP; e += 64) {
+        const int r = e / DP, k = e - r * DP;
+        X1s[e] = (p0 + r < n1) ? P1[(int64_t)(p0 + r) * Q * DP + k] : 0.f;
+    }
+    const unsigned ts_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Ts;
+    const int64_t ldg_last = (ldg / EPC) * EPC - EPC;       // the last whole 16-byte piece of a row
+    auto dma_tile = [&](int ct_) {
+        const int64_t c0 = (int64_t)ct_ * W;
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) {
+            const int id = min(lane + 64 * u, NCH - 1), r = id / CPR, ch = id - r * CPR;
+            const GT* src = G + min((int64_t)p0 * Q + r, n1q - 1) * ldg + min(c0 + (int64_t)ch * EPC, ldg_last);
+            can_dma16(reinterpret_cast<const float*>(src), ts_addr + u * 1024);
+        }
+    };
+    // lane (im, m): column m <= K4 of the value row of point im accumulates sum_j w_ij X2'[j][m] (column K4 of a value row is 1)
+    const int im = lane >> 4, m = lane & 15;
+    float accm = 0.f, E[Q], sK_sum = 0.f, l_acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < Q; ++b) E[b] = 0.f;
+    dma_tile(blockIdx.x);
+    for (int ct = blockIdx.x; ct < ncoltiles; ct += gridDim.x) {
+        const int j0 = ct * CP;
+        WAVE_SYNC();
+        for (int e = lane; e < CP * DP; e += 64) {
+            const int r = e / DP, k = e - r * DP;
+            X2s[e] = (j0 + r < n2) ? P2[(int64_t)(j0 + r) * Q * DP + k] : 0.f;
+        }
+        WAVE_SYNC();
+        float dl[Q];
+        dl[0] = 0.f;
+#pragma unroll
+        for (int b = 1; b < Q; ++b) dl[b] = X1s[ii * DP + cidx[b]] - X2s[j * DP + cidx[b]];
+        float nn = 0.f;
+        for (int k = 0; k < d; ++k) {
+            const float t = X1s[ii * DP + k] - X2s[j * DP + k];
+            nn = __builtin_fmaf(t, t, nn);
+        }
+        const bool valid = lane_on && p0 + i < n1 && j0 + j < n2;
+        const float kv = valid ? s * expf(-0.5f * nn) : 0.f;
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): this tile's DMA is in
+        asm volatile("" ::: "memory");
+        const GT* blk = Ts + (ii * Q) * W + j * Q;
+        float r0 = 0.f, c0 = 0.f, tr = 0.f, quad = 0.f, Et[Q], colv[Q];
+#pragma unroll
+        for (int b = 0; b < Q; ++b) { Et[b] = 0.f; colv[b] = 0.f; }
+        float g00 = 0.f;
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            float rowv = 0.f;
+#pragma unroll
+            for (int b = 0; b < Q; ++b) {
+                const float g = (float)blk[a * W + b];
+                if (a == 0 && b == 0) g00 = g;
+                else if (a == 0) { r0 = __builtin_fmaf(g, dl[b], r0); Et[b] = __builtin_fmaf(il, g, Et[b]); }
+                else if (b == 0) { c0 = __builtin_fmaf(g, dl[a], c0); Et[a] = __builtin_fmaf(-il, g, Et[a]); }
+                else {
+                    if (a == b) tr += g;
+                    rowv = __builtin_fmaf(g, dl[b], rowv);
+                    colv[b] = __builtin_fmaf(g, dl[a], colv[b]);
+                }
+            }
+            if (a > 0) { quad = __builtin_fmaf(dl[a], rowv, quad); Et[a] = __builtin_fmaf(-il2, rowv, Et[a]); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads are done: the buffer may take the next tile
+        if (ct + (int)gridDim.x < ncoltiles) dma_tile(ct + (int)gridDim.x);
+        const float e1 = il * (r0 - c0), e2 = il2 * (tr - quad);
+        const float w = kv * (g00 + e1 + e2);                       // w_ij = k Gm = T00-bar
+        float dots = 0.f;
+#pragma unroll
+        for (int b = 1; b < Q; ++b) {
+            const float ec = kv * __builtin_fmaf(-il2, colv[b], Et[b]);
+            E[b] += ec;
+            dots = __builtin_fmaf(ec, dl[b], dots);
+        }
+        sK_sum += w;
+        l_acc += kv * (e1 + 2.f * e2) - w * nn + dots;
+        if (lane_on) Wt[i * CP + j] = w;
+        WAVE_SYNC();
+        if (m <= K4) {
+#pragma unroll
+            for (int jj = 0; jj < CP; ++jj) accm = __builtin_fmaf(Wt[im * CP + jj], X2s[jj * DP + m], accm);
+        }
+    }
+    // ---- the value rows of this workgroup's slab: columns 0 .. K4 from accm, the one-hot columns take the sums of E over the lanes of a point
+    WAVE_SYNC();
+    for (int e = lane; e < RP * NP; e += 64) rowbuf[e] = 0.f;
+    WAVE_SYNC();
+    if (m <= K4) rowbuf[im * NP + m] = accm;
+#pragma unroll
+    for (int b = 1; b < Q; ++b) {
+        float x = E[b];
+#pragma unroll
+        for (int off = 1; off < CP; off <<= 1) x += __shfl_xor(x, off);
+        E[b] = x;
+    }
+    WAVE_SYNC();
+    if (lane_on && j == 0) {
+#pragma unroll
+        for (int b = 1; b < Q; ++b) rowbuf[i * NP + cidx[b]] += E[b];
+    }
+    WAVE_SYNC();
+    float* myslab = slab + (int64_t)blockIdx.x * n1q * NP;
+    for (int e = lane; e < H * NP; e += 64) {
+        const int r = e / NP, col = e - r * NP;
+        const int pt = r / Q, a = r - pt * Q;
+        if ((int64_t)p0 * Q + r < n1q) myslab[((int64_t)p0 * Q + r) * NP + col] = (a == 0) ? rowbuf[pt * NP + col] : 0.f;
+    }
+    float l_sum = -il * l_acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        sK_sum += __shfl_down(sK_sum, off);
+        l_sum += __shfl_down(l_sum, off);
+    }
+    if (lane == 0) {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        partials[bid * 2] = sK_sum;
+        partials[bid * 2 + 1] = l_sum;
+    }
+}
+
+#ifndef CAN2_BWD_WGS
+#define CAN2_BWD_WGS (256 * 5)
+#endif
+inline bool canon2_ok(const Geom& g) { return g.q == 11 && g.K4 <= 12; }
+
+extern "C" int dsvgp_kernel_canon2_supported(int d, int p) {
+    Geom g;
+    if (p < 1 || make_geom(d, p, g)) return 0;
+    return canon2_ok(g) ? 1 : 0;
+}
+
+// K(x1, x2) with one-hot directions e_{dir_idx[a] - idx_base} on BOTH sides (see the block comment above); float or double output, jitter on
+// the global diagonal as dsvgp_kernel_fwd.  Only the value rows of the packs are read.
+extern "C" int dsvgp_kernel_fwd_canon2(dsvgp_ctx* ctx, const float* P1, int n1, const float* P2, int n2, int d, int p, const int* dir_idx,
+                                       int idx_base, const float* hyp, float jitter, void* out, int64_t ld, int out_is_double) {
+    if (!ctx || !P1 || !P2 || !hyp || !out || !dir_idx || n1 < 0 || n2 < 0 || p < 1) return DSVGP_EINVAL;
+    Geom g;
+    if (int rc = make_geom(d, p, g)) return rc;
+    if (!canon2_ok(g)) return DSVGP_EINVAL;
+    if (n1 == 0 || n2 == 0) return 0;
+    if (ld < (int64_t)n2 * g.q) return DSVGP_EINVAL;
+    const int ovec = out_is_double ? (ld % 2 == 0 && (uintptr_t)out % 16 == 0) : (ld % 4 == 0 && (uintptr_t)out % 16 == 0);
+    const size_t lds = sizeof(float) * (64 * (size_t)g.q * g.q + 20 * (size_t)g.DP);
+    dim3 grid(cdiv(n2, 16), cdiv(n1, 4));
+    if (out_is_double)
+        hipLaunchKernelGGL((kernel_fwd_canon2_kernel<11, double>), grid, dim3(64), lds, ctx->stream, P1, n1, P2, n2, d, g.DP, dir_idx, idx_base,
+                           hyp, jitter, (double*)out, ld, ovec);
+    else
+        hipLaunchKernelGGL((kernel_fwd_canon2_kernel<11, float>), grid, dim3(64), lds, ctx->stream, P1, n1, P2, n2, d, g.DP, dir_idx, idx_base,
+                           hyp, jitter, (float*)out, ld, ovec);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of dsvgp_kernel_fwd_canon2 w.r.t. (x1, lengthscale, outputscale): accumulates (+=) like dsvgp_kernel_bwd (symmetric != 0: x1 == x2
+// and G symmetric -- the K_ZZ case -- point gradients doubled); d_v1 receives nothing (the directions are fixed).  G's rows must be 16-byte
+// pieces (ldg a multiple of 4 floats / 2 doubles, base 16-byte aligned): DSVGP_EINVAL otherwise -- the caller uses dsvgp_kernel_bwd.
+// workspace: dsvgp_kernel_bwd_workspace_bytes(n1, n2, d, p).
+extern "C" int dsvgp_kernel_bwd_canon2(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double, const float* P1, const float* vnorm1,
+                                       int n1, const float* P2, int n2, int d, int p, const int* dir_idx, int idx_base, const float* hyp,
+                                       int symmetric, float* d_x1, float* d_v1, float* d_hyp, void* workspace) {
+    if (!ctx || !G || !P1 || !P2 || !hyp || !d_x1 || !d_hyp || !workspace || !dir_idx || p < 1 || !vnorm1 || !d_v1) return DSVGP_EINVAL;
+    Geom g;
+    if (int rc = make_geom(d, p, g)) return rc;
+    if (!canon2_ok(g)) return DSVGP_EINVAL;
+    if (n1 <= 0 || n2 <= 0) return 0;
+    const int64_t n1q = (int64_t)n1 * g.q, n2q = (int64_t)n2 * g.q;
+    const int epc = g_is_double ? 2 : 4;
+    if (ldg < n2q || ldg % epc != 0 || (uintptr_t)G % 16 != 0) return DSVGP_EINVAL;
+    const int cp = g_is_double ? 8 : 16;
+    const int rt = cdiv(n1, 4), ctiles = cdiv(n2, cp);
+    // the slab count and the partial slots the workspace was sized for (the general kernels' tiling: dsvgp_kernel_bwd_workspace_bytes)
+    const int cap_ns = bwd_nsplit(n1, n2, g);
+    int tr_, tc_, wgs_;
+    bwd_tiles(g, tr_, tc_, wgs_);
+    const int64_t cap_part = (int64_t)cap_ns * cdiv(n1q, tr_);
+    int ns = CAN2_BWD_WGS / rt;
+    if (ns < 1) ns = 1;
+    if (ns > ctiles) ns = ctiles;
+    if (ns > cap_ns) ns = cap_ns;
+    if ((int64_t)ns * rt > cap_part) ns = (int)(cap_part / rt);
+    if (ns < 1) return DSVGP_EINVAL;
+    float* slab = (float*)workspace;
+    float* partials = slab + (size_t)cap_ns * n1q * g.NP;
+    const int nch = 16 * g.q * g.q, ndma = (nch + 63) / 64;
+    const size_t lds = sizeof(float) * ((size_t)ndma * 256 + (4 + cp) * (size_t)g.DP + 4 * cp + 4 * (size_t)g.NP);
+    dim3 grid(ns, rt);
+    if (g_is_double)
+        hipLaunchKernelGGL((kernel_bwd_canon2_kernel<11, double>), grid, dim3(64), lds, ctx->stream, (const double*)G, ldg, P1, n1, P2, n2, d,
+                           g.K4, g.DP, g.NP, dir_idx, idx_base, hyp, slab, partials);
+    else
+        hipLaunchKernelGGL((kernel_bwd_canon2_kernel<11, float>), grid, dim3(64), lds, ctx->stream, (const float*)G, ldg, P1, n1, P2, n2, d,
+                           g.K4, g.DP, g.NP, dir_idx, idx_base, hyp, slab, partials);
+    DSVGP_LAUNCH_CHECK();
+    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;
+    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), ctx->stream,
+                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, symmetric ? 2.f : 1.f, d_x1, d_v1, (const float*)partials, ns * rt,
+                       d_hyp);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dsvgp_packed_width(int d) { return ((d + 3) & ~3) + 4; }
 
 // column means + the constrained hyper-parameters (dsvgp_hyp_forward) in one launch: block 0 also writes hyp

@@ -313,13 +313,37 @@ extern "C" int dsvgp_elbo_step_status(dsvgp_step_plan* pl, float* hyp4, int* inf
 // K_ZX and its backward: on the canonical-direction kernels when the caller states the minibatch's directions as an index list
 // (io->dir_idx, include/dsvgp.h) and they take the geometry, on the general kernels otherwise
 static inline bool zx_canon(const dsvgp_elbo_step_io* io, int d, int p) { return io->dir_idx && dsvgp_kernel_canon_supported(d, p); }
+// ... and the both-sides one-hot kernels (dsvgp_kernel_fwd_canon2 / _bwd_canon2) when the caller also states that the inducing directions are
+// the same unit vectors (io->v_one_hot: the full-gradient SVGP) -- K_ZZ and K_ZX, forward and backward
+static inline bool zz_canon2(const dsvgp_elbo_step_io* io, int d, int p) {
+    return io->dir_idx && io->v_one_hot && dsvgp_kernel_canon2_supported(d, p);
+}
+static inline bool rows_in_16_byte_pieces(const void* G, int64_t ldg, int esz) { return ldg % (16 / esz) == 0 && (uintptr_t)G % 16 == 0; }
+static int zz_fwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const float* PZ, const float* sZ, int M, int d, int p, const float* hyp,
+                  double* L, int64_t ld) {
+    if (zz_canon2(io, d, p))
+        return dsvgp_kernel_fwd_canon2(ctx, PZ, M, PZ, M, d, p, io->dir_idx, io->dir_idx_base, hyp, io->kzz_jitter, L, ld, 1);
+    return dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, ld, 1);
+}
+// K_ZZ-bar (double, symmetric) or a column block of it (data-parallel phase 4: P2 / s2 / n2 name the block's points)
+static int zz_bwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const double* Kbar, int64_t ld, const float* PZ, const float* sZ,
+                  const float* vZ, int M, const float* P2, const float* s2, int n2, int d, int p, const float* hyp, void* ws) {
+    if (zz_canon2(io, d, p) && rows_in_16_byte_pieces(Kbar, ld, 8))
+        return dsvgp_kernel_bwd_canon2(ctx, Kbar, ld, 1, PZ, vZ, M, P2, n2, d, p, io->dir_idx, io->dir_idx_base, hyp, 1, io->dZ, io->dV,
+                                       io->d_hyp, ws);
+    return dsvgp_kernel_bwd(ctx, Kbar, ld, 1, PZ, sZ, vZ, M, P2, s2, n2, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, ws);
+}
 static int zx_fwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const float* PZ, const float* sZ, int M, const float* PX, const float* sX,
                   int B, int d, int p, const float* hyp, float* Kzx, int64_t ld) {
+    if (zz_canon2(io, d, p)) return dsvgp_kernel_fwd_canon2(ctx, PZ, M, PX, B, d, p, io->dir_idx, io->dir_idx_base, hyp, 0.f, Kzx, ld, 0);
     if (zx_canon(io, d, p)) return dsvgp_kernel_fwd_canon(ctx, PZ, sZ, M, PX, sX, B, d, p, io->dir_idx, io->dir_idx_base, hyp, Kzx, ld);
     return dsvgp_kernel_fwd(ctx, PZ, sZ, M, PX, sX, B, d, p, hyp, 0.f, Kzx, ld, 0);
 }
 static int zx_bwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const float* Kb32, int64_t ld, const float* PZ, const float* sZ,
                   const float* vZ, int M, const float* PX, const float* sX, int B, int d, int p, const float* hyp, void* ws) {
+    if (zz_canon2(io, d, p) && rows_in_16_byte_pieces(Kb32, ld, 4))
+        return dsvgp_kernel_bwd_canon2(ctx, Kb32, ld, 0, PZ, vZ, M, PX, B, d, p, io->dir_idx, io->dir_idx_base, hyp, 0, io->dZ, io->dV,
+                                       io->d_hyp, ws);
     if (zx_canon(io, d, p))
         return dsvgp_kernel_bwd_canon(ctx, Kb32, ld, 0, PZ, sZ, vZ, M, PX, sX, B, d, p, io->dir_idx, io->dir_idx_base, hyp, io->dZ, io->dV,
                                       io->d_hyp, ws);
@@ -465,7 +489,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         ctx->stream = main;
     }
     // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip)
-    STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
+    STEP_CALL(zz_fwd(ctx, io, PZ, sZ, M, d, p, hyp, L, Mp));
     if (pipe) {
         const int k1 = pk1, k2 = pk2;
         const int r1 = (k1 + 1) * 64;                                              // (< M': k <= nblk64 - 2)
@@ -695,7 +719,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         STEP_TIME(5);
     }
     if (zx_side || tail_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
-    STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    STEP_CALL(zz_bwd(ctx, io, Kbar, Mp, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, kbwd_ws));
     // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
     STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,
                                     kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
@@ -756,7 +780,7 @@ extern "C" int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
         STEP_HIP(hipEventRecord(pl->ev_side, side));
         ctx->stream = main;
     }
-    STEP_CALL(dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, Mp, 1));
+    STEP_CALL(zz_fwd(ctx, io, PZ, sZ, M, d, p, hyp, L, Mp));
     STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
     STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));
     STEP_HIP(hipEventRecord(pl->ev_status, main));
@@ -790,7 +814,7 @@ extern "C" int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
     STEP_CALL(dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0, nullptr,
                          0, Kbar, Mp, nullptr, 0, nullptr));
     STEP_CALL(dsvgp_phi_symmetrize(ctx, Kbar, Mp, Mp));
-    STEP_CALL(dsvgp_kernel_bwd(ctx, Kbar, Mp, 1, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, 1, io->dZ, io->dV, io->d_hyp, kbwd_ws));
+    STEP_CALL(zz_bwd(ctx, io, Kbar, Mp, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, kbwd_ws));
     return dsvgp_step_epilogue(ctx, scal, kl_buf, rows, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
                                io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss);
 }
@@ -936,8 +960,7 @@ extern "C" int dsvgp_elbo_step_dp_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const
     }
     if (overlap) STEP_HIP(hipStreamWaitEvent(main, pl->ev_var, 0));
     if (wcol > 0)
-        STEP_CALL(dsvgp_kernel_bwd(ctx, cbK, wcol, 1, PZ, sZ, vZ, M, PZ + (size_t)c0 * pl->DP, sZ + c0, m1 - m0, d, p, hyp, 1, io->dZ, io->dV,
-                                   io->d_hyp, kbwd_ws));
+        STEP_CALL(zz_bwd(ctx, io, cbK, wcol, PZ, sZ, vZ, M, PZ + (size_t)c0 * pl->DP, sZ + c0, m1 - m0, d, p, hyp, kbwd_ws));
     STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,
                                     kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
                                     io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));

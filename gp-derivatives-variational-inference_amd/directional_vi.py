@@ -92,7 +92,7 @@ class GPModel(ApproximateGP):
         return NGD_PARAM_NAMES if ngd else PARAM_NAMES
 
     def _param_dict(self, likelihood=None):
-        return {k: v.detach() for k, v in zip(self._param_names(), self._param_list(likelihood))}
+        return {k: _ops.detach_keep(v) for k, v in zip(self._param_names(), self._param_list(likelihood))}
 
 
 def select_cols_of_y(y_batch, minibatch_dim, dim):

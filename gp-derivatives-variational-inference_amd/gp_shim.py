@@ -8,6 +8,7 @@ and route the arithmetic to the HIP engine (``_step.ElboEngine``).  They contain
 """
 import torch
 
+from . import _ops
 from ._step import ElboEngine, NGD_PARAM_NAMES, PARAM_NAMES
 
 
@@ -112,7 +113,7 @@ class _ElboFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, x, y, D, num_data, mll_type, dp, names, *params):
-        pd = dict(zip(names, [p.detach() for p in params]))
+        pd = dict(zip(names, [_ops.detach_keep(p) for p in params]))
         if dp is not None:
             loss, grads, mu, varn = dp.loss_and_grads(engine, pd, x, y, D, num_data, mll_type)
         else:
@@ -253,7 +254,7 @@ class _ApproximateMLL(torch.nn.Module):
         model = output.model
         plist = model._param_list(self.likelihood)
         names = model._param_names()
-        pd = dict(zip(names, [p.detach() for p in plist]))
+        pd = dict(zip(names, [_ops.detach_keep(p) for p in plist]))
         dp = getattr(model, "data_parallel", None)
         if dp is not None:
             loss, grads, mu, varn = dp.loss_and_grads(model.engine, pd, output.x, target, output.D, float(self.num_data),

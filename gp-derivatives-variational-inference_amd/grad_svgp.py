@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _ops
 from .GradVariationalStrategy import GradVariationalStrategy
 from .RBFKernelDirectionalGrad import RBFKernelDirectionalGrad
 from .directional_vi import TrainLoop, _dataset_tensors
@@ -58,7 +59,10 @@ class GPModel(ApproximateGP):
                      else torch.zeros(1, device=vs.inducing_points.device))
         q = ([vd.natural_vec, vd.natural_mat] if isinstance(vd, NaturalVariationalDistribution)
              else [vd.variational_mean, vd.chol_variational_covar])
-        return [vs.inducing_points, self._canonical_directions] + q + [
+        V = self._canonical_directions
+        if V.is_cuda:        # (fixed unit vectors, the same at every inducing point: stated as an index list, _ops.state_directions)
+            _ops.state_directions(V, _ops.index_range(V.device, V.shape[1]), 0)
+        return [vs.inducing_points, V] + q + [
             self.mean_module.constant, self.covar_module.raw_outputscale,
             self.covar_module.base_kernel.raw_lengthscale, raw_noise]
 
@@ -68,7 +72,7 @@ class GPModel(ApproximateGP):
         return NGD_PARAM_NAMES if ngd else PARAM_NAMES
 
     def _param_dict(self, likelihood=None):
-        return {k: v.detach() for k, v in zip(self._param_names(), self._param_list(likelihood))}
+        return {k: _ops.detach_keep(v) for k, v in zip(self._param_names(), self._param_list(likelihood))}
 
 
 def setup_training(train_dataset, dim, num_inducing=128, minibatch_size=1, num_epochs=1, use_ngd=False, use_ciq=False,

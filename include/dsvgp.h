@@ -121,6 +121,23 @@ int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_
                            const float* self2, int n2, int d, int p, const int* dir_idx, int idx_base,
                            const float* hyp, float* d_x1, float* d_v1, float* d_hyp, void* workspace);
 
+/* One-hot directions on BOTH sides, the same index list for every point of both: the full-gradient SVGP (reference
+ * directionalvi/GradVariationalStrategy.py:89-99 builds RBFKernelGrad over cat([Z, x]) -- the directional kernel with p = d and the
+ * directions I_d at every inducing and data point; BASELINE config 3) or inducing directions fixed to the data's canonical columns.
+ * Every block is then an elementwise function of x1 - x2 (no products): K00 = k, K0b = k delta_b / ell, Ka0 = -k delta_a / ell,
+ * Kab = k ([a == b] - delta_a delta_b) / ell^2.  P1 / P2: packed rows (only the value rows are read); dir_idx / idx_base as above.
+ * _supported: 1 for the geometries taken (p + 1 = 11, d <= 12), else 0 -- the entry points return DSVGP_EINVAL and the caller uses the
+ * general kernels.  fwd: float / double output, jitter on the global diagonal as dsvgp_kernel_fwd.  bwd: accumulates (+=) d_x1,
+ * d_hyp[0..1] as dsvgp_kernel_bwd (symmetric != 0: K_ZZ, point gradients doubled); d_v1 receives nothing (fixed directions); G's rows
+ * must consist of 16-byte pieces (ldg % 4 == 0 floats / % 2 == 0 doubles, base 16-byte aligned), DSVGP_EINVAL otherwise; workspace of
+ * dsvgp_kernel_bwd_workspace_bytes(n1, n2, d, p).                                                                                   */
+int dsvgp_kernel_canon2_supported(int d, int p);
+int dsvgp_kernel_fwd_canon2(dsvgp_ctx* ctx, const float* P1, int n1, const float* P2, int n2, int d, int p, const int* dir_idx,
+                            int idx_base, const float* hyp, float jitter, void* out, int64_t ld, int out_is_double);
+int dsvgp_kernel_bwd_canon2(dsvgp_ctx* ctx, const void* G, int64_t ldg, int g_is_double, const float* P1, const float* vnorm1, int n1,
+                            const float* P2, int n2, int d, int p, const int* dir_idx, int idx_base, const float* hyp, int symmetric,
+                            float* d_x1, float* d_v1, float* d_hyp, void* workspace);
+
 /* ---- fp64 model mode (the reference's experiments set torch.set_default_dtype(torch.float64),
  * experiments/synthetic/exp_script.py:56): RBFKernelDirectionalGrad.forward / backward in double precision.
  * Same packed-row formulation as the fp32 assembly; the two contractions T = P1 P2^T and dP1 = Tbar P2 go through
@@ -456,6 +473,10 @@ typedef struct dsvgp_elbo_step_io {
      * on the canonical-direction kernels (dsvgp_kernel_fwd_canon / _bwd_canon) where those take the geometry (p + 1 in {3, 6},
      * d <= 28), on the general ones otherwise.  Appended in round 6: callers that zero-initialise the struct keep the old meaning. */
     const int* dir_idx; int dir_idx_base;
+    /* non-zero: the inducing directions V are the SAME unit vectors (row m p + a of V is e_{dir_idx[a] - dir_idx_base} for every
+     * inducing point m) and are not parameters -- the full-gradient SVGP (reference GradVariationalStrategy.py:89-99).  K_ZZ, K_ZX
+     * and their backwards then run on dsvgp_kernel_fwd_canon2 / _bwd_canon2 where those take the geometry; dV is left zero.        */
+    int v_one_hot;
 } dsvgp_elbo_step_io;
 size_t dsvgp_elbo_step_split_bytes(int M, int d, int p, int B);
 size_t dsvgp_elbo_step_workspace_bytes(int M, int d, int p, int B);

@@ -178,6 +178,137 @@ def test_kernel_canon_rejects_geometries_it_does_not_take(dsvgp, gpu_device):
         o.kernel_fwd_canon(ctx, p1, 6, p2, 7, 10, 3, di, 0, hyp)       # q = 4
 
 
+# ------------------------------------------------------------------ one-hot directions on both sides (the full-gradient SVGP, BASELINE config 3)
+def _rbf_grad_closed_form(x1, x2, ell, s):
+    """gpytorch RBFKernelGrad's closed form in the interleaved layout (reference GradVariationalStrategy.py:89-99 uses it on
+    cat([Z, x])): block (i, j) = k [[1, delta^T / ell], [-delta / ell, (I - delta delta^T) / ell^2]], delta = (x1_i - x2_j) / ell"""
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    dl = (x1[:, None, :] - x2[None, :, :]) / ell
+    k = s * torch.exp(-0.5 * (dl ** 2).sum(-1))
+    K = torch.zeros(n1, d + 1, n2, d + 1, dtype=x1.dtype)
+    K[:, 0, :, 0] = k
+    K[:, 0, :, 1:] = k[..., None] * dl / ell
+    K[:, 1:, :, 0] = (-k[..., None] * dl / ell).permute(0, 2, 1)
+    blk = (torch.eye(d, dtype=x1.dtype)[None, None] - dl[..., :, None] * dl[..., None, :]) * (k / ell ** 2)[..., None, None]
+    K[:, 1:, :, 1:] = blk.permute(0, 2, 1, 3)
+    return K.reshape(n1 * (d + 1), n2 * (d + 1))
+
+
+def _canon2_case(dsvgp, dev, x1, x2, ell, s, base):
+    ops = dsvgp._ops
+    ctx = ops.Context.get(dev)
+    d = x1.shape[1]
+    hyp = _hyp(dev, ell, s)
+    x1d, x2d = x1.float().to(dev).contiguous(), x2.float().to(dev).contiguous()
+    center = ops.column_mean(ctx, x1d)
+    E1, E2 = torch.eye(d).repeat(x1.shape[0], 1).to(dev), torch.eye(d).repeat(x2.shape[0], 1).to(dev)
+    p1, p2 = ops.pack_points(ctx, x1d, E1, d, hyp, center), ops.pack_points(ctx, x2d, E2, d, hyp, center)
+    di = (torch.arange(d, dtype=torch.int32) + base).to(dev)
+    return ops, ctx, hyp, p1, p2, di
+
+
+@pytest.mark.parametrize("n1,n2,base", [(4, 16, 0), (40, 52, 1), (37, 131, 0), (3, 5, 1), (300, 64, 0), (9, 17, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_kernel_fwd_canon2_matches_the_closed_form_and_the_general_kernel(dsvgp, gpu_device, n1, n2, base, dtype):
+    d = p = 10
+    g = torch.Generator().manual_seed(7 * n1 + n2)
+    x1, x2 = torch.rand(n1, d, generator=g), torch.rand(n2, d, generator=g)
+    ell, s = 0.83, 1.4
+    ops, ctx, hyp, p1, p2, di = _canon2_case(dsvgp, gpu_device, x1, x2, ell, s, base)
+    assert ops.canon2_supported(d, p) and not ops.canon2_supported(20, 5) and not ops.canon2_supported(13, 10)
+    K2 = ops.kernel_fwd_canon2(ctx, p1, n1, p2, n2, d, p, di, base, hyp, dtype=dtype)
+    Kg = ops.kernel_fwd(ctx, p1, n1, p2, n2, d, p, hyp, dtype=dtype)
+    ref = _rbf_grad_closed_form(x1.double(), x2.double(), ell, s)
+    assert K2.dtype == dtype
+    assert relmax(K2, ref) < 2e-6 and relmax(K2, Kg) < 2e-6, (relmax(K2, ref), relmax(K2, Kg))
+    # padded leading dimension / rows that are not 16-byte aligned: the bounds-checked store path
+    buf = torch.zeros(n1 * (p + 1), n2 * (p + 1) + 3, device=gpu_device, dtype=dtype)
+    Kv = ops.kernel_fwd_canon2(ctx, p1, n1, p2, n2, d, p, di, base, hyp, out=buf[:, 1:n2 * (p + 1) + 1])
+    assert torch.equal(Kv, K2) and buf[:, 0].abs().max().item() == 0.0 and buf[:, -2:].abs().max().item() == 0.0
+
+
+def test_kernel_fwd_canon2_symmetric_with_jitter(dsvgp, gpu_device):
+    d = p = 10
+    M = 45
+    Z = torch.rand(M, d, generator=torch.Generator().manual_seed(5))
+    ops, ctx, hyp, p1, _, di = _canon2_case(dsvgp, gpu_device, Z, Z, 0.7, 0.9, 0)
+    K2 = ops.kernel_fwd_canon2(ctx, p1, M, p1, M, d, p, di, 0, hyp, jitter=1e-3, dtype=torch.float64)
+    Kg = ops.kernel_fwd(ctx, p1, M, p1, M, d, p, hyp, jitter=1e-3, dtype=torch.float64)
+    ref = _rbf_grad_closed_form(Z.double(), Z.double(), 0.7, 0.9) + 1e-3 * torch.eye(M * (p + 1), dtype=torch.float64)
+    assert relmax(K2, ref) < 2e-6 and relmax(K2, Kg) < 2e-6
+    Kc = K2.cpu()
+    assert (Kc - Kc.t()).abs().max().item() < 1e-6 and torch.equal(Kc, Kc.float().double())
+    torch.linalg.cholesky(Kc)
+
+
+@pytest.mark.parametrize("n1,n2,sym", [(4, 16, False), (40, 52, False), (37, 131, False), (3, 5, False), (61, 61, True), (300, 300, True)])
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.float64])
+def test_kernel_bwd_canon2_matches_autograd_and_the_general_kernel(dsvgp, gpu_device, n1, n2, sym, gdtype):
+    d = p = 10
+    q = p + 1
+    g = torch.Generator().manual_seed(n1 + 13 * n2)
+    x1 = torch.rand(n1, d, generator=g)
+    x2 = x1 if sym else torch.rand(n2, d, generator=g)
+    ell, s = 0.9, 1.2
+    G = torch.randn(n1 * q, n2 * q, generator=g, dtype=torch.float64)
+    if sym:
+        G = 0.5 * (G + G.t())
+    dev = gpu_device
+    ops, ctx, hyp, p1, p2, di = _canon2_case(dsvgp, dev, x1, x2, ell, s, 1)
+    if sym:
+        p2 = p1
+    x1r = x1.double().requires_grad_(True)
+    ellr = torch.tensor(ell, dtype=torch.float64, requires_grad=True)
+    sr = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+    (_rbf_grad_closed_form_ad(x1r, x1r if sym else x2.double(), ellr, sr) * G).sum().backward()
+    ldp = (n2 * q + 3) // 4 * 4                               # (rows of whole 16-byte pieces: what the DMA path asks for)
+    buf = torch.zeros(n1 * q, ldp, dtype=gdtype, device=dev)
+    buf[:, :n2 * q] = G.to(gdtype).to(dev)
+    Gd = buf[:, :n2 * q]
+    res = []
+    for two in (True, False):
+        dx, dv, dh = torch.zeros(n1, d, device=dev), torch.zeros(n1 * p, d, device=dev), torch.zeros(4, device=dev)
+        if two:
+            ops.kernel_bwd_canon2(ctx, Gd, p1, n1, p2, n2, d, p, di, 1, hyp, sym, dx, dv, dh)
+            assert dv.abs().max().item() == 0.0
+        else:
+            ops.kernel_bwd(ctx, Gd, p1, n1, p2, n2, d, p, hyp, sym, dx, dv, dh)
+        res.append((dx, dh))
+    (dx, dh), (gx, gh) = res
+    assert relmax(dx, x1r.grad) < 2e-4, relmax(dx, x1r.grad)
+    assert abs(dh[0].item() - ellr.grad.item()) < 2e-4 * max(1.0, abs(ellr.grad.item())), (dh[0].item(), ellr.grad.item())
+    assert abs(dh[1].item() - sr.grad.item()) < 2e-4 * max(1.0, abs(sr.grad.item()))
+    assert relmax(dx, gx) < 1e-4 and abs(dh[0].item() - gh[0].item()) < 1e-4 * max(1.0, abs(gh[0].item()))
+    # a second call accumulates (+=)
+    dx2, dv2, dh2 = dx.clone(), torch.zeros(n1 * p, d, device=dev), dh.clone()
+    ops.kernel_bwd_canon2(ctx, Gd, p1, n1, p2, n2, d, p, di, 1, hyp, sym, dx2, dv2, dh2)
+    assert relmax(dx2, 2 * dx) < 1e-5
+
+
+def _rbf_grad_closed_form_ad(x1, x2, ell, s):
+    """the same closed form, differentiable in (x1, ell, s) (x2 = x1 passes the same tensor: the symmetric case)"""
+    n1, d = x1.shape
+    n2 = x2.shape[0]
+    dl = (x1[:, None, :] - x2[None, :, :]) / ell
+    k = s * torch.exp(-0.5 * (dl ** 2).sum(-1))
+    top = torch.cat([k[..., None, None], (k[..., None] * dl / ell)[..., None, :]], -1)                       # [n1, n2, 1, d+1]
+    blk = (torch.eye(d, dtype=x1.dtype) - dl[..., :, None] * dl[..., None, :]) * (k / ell ** 2)[..., None, None]
+    bot = torch.cat([(-k[..., None] * dl / ell)[..., :, None], blk], -1)                                    # [n1, n2, d, d+1]
+    K = torch.cat([top, bot], -2)                                                                             # [n1, n2, d+1, d+1]
+    return K.permute(0, 2, 1, 3).reshape(n1 * (d + 1), n2 * (d + 1))
+
+
+def test_kernel_bwd_canon2_rejects_rows_that_are_not_16_byte_pieces(dsvgp, gpu_device):
+    d = p = 10
+    x1, x2 = torch.rand(5, d), torch.rand(6, d)
+    ops, ctx, hyp, p1, p2, di = _canon2_case(dsvgp, gpu_device, x1, x2, 0.8, 1.0, 0)
+    buf = torch.randn(5 * 11, 6 * 11 + 1, device=gpu_device)
+    dx, dv, dh = torch.zeros(5, d, device=gpu_device), torch.zeros(50, d, device=gpu_device), torch.zeros(4, device=gpu_device)
+    with pytest.raises(dsvgp._lib.DsvgpError):
+        ops.kernel_bwd_canon2(ctx, buf[:, :66], p1, 5, p2, 6, d, p, di, 0, hyp, False, dx, dv, dh)
+
+
 def test_kernel_fwd_symmetric_double_with_jitter_and_exact_diagonal(dsvgp, gpu_device):
     g = torch.Generator().manual_seed(3)
     M, d, p = 50, 20, 5

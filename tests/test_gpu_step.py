@@ -949,6 +949,54 @@ def test_step_with_stated_one_hot_directions(dsvgp, gpu_device, monkeypatch, N, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,M,B", [(900, 37, 96), (2000, 100, 131), (3000, 300, 512)])
+@pytest.mark.parametrize("path", ["one-call", "per-output", "PLL"])
+def test_full_gradient_step_with_unit_directions_stated_on_both_sides(dsvgp, gpu_device, monkeypatch, N, M, B, path):
+    """the full-gradient SVGP (d = p = 10, V = I_d at every inducing point, D = I_d at every data point: reference
+    GradVariationalStrategy.py:89-99) with both direction sets stated as the index list 0 .. d-1: K_ZZ, K_ZX and their backwards on the
+    both-sides one-hot kernels (io->v_one_hot) against the same step on the general kernels and against the float64 oracle."""
+    monkeypatch.setenv("DSVGP_CHECK_DIRS", "1")
+    d = p = 10
+    ops = dsvgp._ops
+    P, x, y, D, nd = make_problem(N, d, M, p, B, seed=N + M)
+    P["inducing_directions"] = torch.eye(d).repeat(M, 1)
+    assert torch.equal(D, torch.eye(d).repeat(B, 1))
+    xd, yd = x.to(gpu_device), y.to(gpu_device)
+    mll = "PLL" if path == "PLL" else "ELBO"
+    fast = path == "one-call"
+    out = {}
+    for stated in (False, True):
+        Pg = {k: v.to(gpu_device) for k, v in P.items()}
+        Dd = D.to(gpu_device)
+        if stated:
+            rng = ops.index_range(gpu_device, d)
+            ops.state_directions(Dd, rng, 0)
+            ops.state_directions(Pg["inducing_directions"], rng, 0)
+        eng = dsvgp.ElboEngine(gpu_device)
+        out[stated] = eng.loss_and_grads(Pg, xd, yd, Dd, nd, mll, fast=fast)
+        torch.cuda.synchronize()
+        assert eng.c_step_used
+        plan = list(eng._plans.values())[0]
+        assert bool(plan.io.v_one_hot) == stated and bool(plan.io.dir_idx) == stated
+    (l0, g0, mu0, v0), (l1, g1, mu1, v1) = out[False], out[True]
+    errs = {"loss": abs(l1.item() - l0.item()) / abs(l0.item()), "mu": relmax(mu1, mu0)}
+    assert errs["loss"] < 4e-6 and errs["mu"] < 1e-4, errs
+    # (fixed directions: no gradient is formed -- unless an upstream matrix's rows are not 16-byte pieces, M' odd or B' not a multiple of 4:
+    #  that backward then runs on the general kernel, which forms one)
+    if (M * (p + 1)) % 2 == 0 and (B * (p + 1)) % 4 == 0:
+        assert g1["inducing_directions"].abs().max().item() == 0.0
+    P64 = {k: v.double() for k, v in P.items()}
+    _, g64, _, _ = O.elbo_loss_and_grads(P64, x.double(), y.double(), D.double(), nd, mll)
+    for k in O.PARAM_NAMES:
+        if k == "inducing_directions":
+            continue
+        errs[k] = relmax(g1[k], g0[k])
+        errs[k + "(f64 oracle)"] = relmax(g1[k], g64[k])
+        assert errs[k] < 2e-4 and errs[k + "(f64 oracle)"] < GRAD_TOL_FP64, (k, errs[k], errs[k + "(f64 oracle)"])
+    _report("full gradient, stated N=%d M=%d B=%d %s" % (N, M, B, path), errs)
+
+
+@pytest.mark.gpu
 def test_a_wrong_statement_about_the_directions_is_caught_by_the_check(dsvgp, gpu_device, monkeypatch):
     monkeypatch.setenv("DSVGP_CHECK_DIRS", "1")
     P, x, y, D, nd = make_problem(600, 5, 40, 2, 128, seed=11)
