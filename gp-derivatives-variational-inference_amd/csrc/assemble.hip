@@ -64,15 +64,12 @@ __global__ void column_mean_kernel(const float* __restrict__ x, int n, int d, fl
     if (threadIdx.x == 0) out[k] = (float)(part[0] / (double)n);
 }
 
-__global__ void pack_points_kernel(const float* __restrict__ x, const float* __restrict__ v, int n, int d,
-                                   int p, const float* __restrict__ hyp, const float* __restrict__ center,
-                                   float* __restrict__ P,
-                                   float* __restrict__ self, float* __restrict__ vnorm, int K4, int DP) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+// one packed row (value row a = 0 / direction row a >= 1 of point i); center: global or LDS, null = no shift
+__device__ __forceinline__ void pack_row(const float* __restrict__ x, const float* __restrict__ v, int row, int d, int p, float ell,
+                                         const float* center, float* __restrict__ P, float* __restrict__ self,
+                                         float* __restrict__ vnorm, int K4, int DP) {
     const int q = p + 1;
-    if (row >= n * q) return;
     const int i = row / q, a = row - i * q;
-    const float ell = hyp[0];
     float* Pr = P + (int64_t)row * DP;
     const float* xi = x + (int64_t)i * d;
     if (a == 0) {
@@ -99,6 +96,52 @@ __global__ void pack_points_kernel(const float* __restrict__ x, const float* __r
         for (int k = d; k < DP; ++k) Pr[k] = 0.f;
         self[row] = acc;
         vnorm[(int64_t)i * p + (a - 1)] = nrm;
+    }
+}
+
+__global__ void pack_points_kernel(const float* __restrict__ x, const float* __restrict__ v, int n, int d,
+                                   int p, const float* __restrict__ hyp, const float* __restrict__ center,
+                                   float* __restrict__ P,
+                                   float* __restrict__ self, float* __restrict__ vnorm, int K4, int DP) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n * (p + 1)) return;
+    pack_row(x, v, row, d, p, hyp[0], center, P, self, vnorm, K4, DP);
+}
+
+// The one-call step's first launch (round 6): column_mean_hyp_kernel + pack_points_kernel of the inducing set + pack_points_kernel of the
+// minibatch in ONE.  Every workgroup forms the centre (column means of Z: one wave per column, lanes over the rows, double sums, the
+// wave's lanes added in a fixed order -- the same in every workgroup) and the constrained hyper-parameters for itself, workgroup 0
+// publishes them (centre, hyp: later launches read them), and each packs 256 rows of Z (workgroups < nbz) or of x.
+__global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ Z, const float* __restrict__ V, int M,
+                                                        const float* __restrict__ X, const float* __restrict__ Dm, int B, int d, int p,
+                                                        const float* rl, const float* rs, const float* rn, float* __restrict__ hyp,
+                                                        float* __restrict__ center, float* __restrict__ PZ, float* __restrict__ sZ,
+                                                        float* __restrict__ vZ, float* __restrict__ PX, float* __restrict__ sX,
+                                                        float* __restrict__ vX, int K4, int DP, int nbz) {
+    extern __shared__ float cs[];           // [d] centre, then ell
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int k = wave; k < d; k += 4) {
+        double acc = 0.0;
+        for (int i = lane; i < M; i += 64) acc += Z[(int64_t)i * d + k];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) cs[k] = (float)(acc / (double)M);
+    }
+    if (t == 0) {       // softplus constraints of gpytorch Positive / GreaterThan(1e-4) (csrc/elbo.hip: hyp_forward_kernel)
+        auto sp = [](float v) { return v > 20.f ? v : log1pf(expf(v)); };
+        const float ell = sp(rl[0]);
+        cs[d] = ell;
+        if (blockIdx.x == 0) { hyp[0] = ell; hyp[1] = sp(rs[0]); hyp[2] = sp(rn[0]) + 1e-4f; hyp[3] = 0.f; }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int k = t; k < d; k += 256) center[k] = cs[k];
+    const int q = p + 1;
+    if ((int)blockIdx.x < nbz) {
+        const int row = blockIdx.x * 256 + t;
+        if (row < M * q) pack_row(Z, V, row, d, p, cs[d], cs, PZ, sZ, vZ, K4, DP);
+    } else {
+        const int row = ((int)blockIdx.x - nbz) * 256 + t;
+        if (row < B * q) pack_row(X, Dm, row, d, p, cs[d], cs, PX, sX, vX, K4, DP);
     }
 }
 
@@ -1931,13 +1974,24 @@ __global__ __launch_bounds__(64) void kernel_bwd_split_kernel(const GT* __restri
 // 21 us for 500 points), the partial sums meet in LDS.  Block 0 also folds the per-workgroup scalar partials into d_hyp (was a
 // launch of its own).
 constexpr int PTS_NT = 256;
+// (round 6) a SECOND slab set (slab2 / nsplit2 / sym2 / partials2; null: none) is added on the way -- everything below is linear in
+// the slab, so K_ZX-bar's and K_ZZ-bar's backwards share one launch -- and `tail` (scal != null) folds in the one-call step's scalar
+// tail (scale_epilogue_kernel of elbo.hip: 2 vbar = 1 / (noise rows) on the point / direction gradients, the chain rule of the
+// constrained hyper-parameters, the loss): d_x1 / d_v1 / d_hyp must then hold no other contribution that wants scaling later.
+struct PointsTail {
+    const float* scal; const float* kl0; float inv_rows, inv_num_data;
+    const float *rl, *rs, *rn; float *drl, *drs, *drn, *dconst, *loss;
+};
 __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* __restrict__ slab, int nsplit,
                                                                    const float* __restrict__ P1,
                                                                    const float* __restrict__ vnorm1, int n1, int d, int p,
                                                                    int K4, int DP, int NP, const float* __restrict__ hyp,
                                                                    float sym, float* __restrict__ d_x1,
                                                                    float* __restrict__ d_v1, const float* __restrict__ partials,
-                                                                   int nblocks, float* __restrict__ d_hyp) {
+                                                                   int nblocks, float* __restrict__ d_hyp,
+                                                                   const float* __restrict__ slab2 = nullptr, int nsplit2 = 0, float sym2 = 0.f,
+                                                                   const float* __restrict__ partials2 = nullptr, int nblocks2 = 0,
+                                                                   PointsTail tail = PointsTail{}) {
     extern __shared__ float dPs[];          // [q][DP] summed over the split slabs, then [q + 1] dots, then [waves - 1][q][DP] wave partials
     const int i = blockIdx.x, t = threadIdx.x, w = t >> 6, l = t & 63;
     const int nth = blockDim.x, nw = nth >> 6;          // 4 waves; 1 when the partials would not fit into LDS (q DP > 3072)
@@ -1950,6 +2004,12 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
         const float* src = slab + ((int64_t)i * q + a) * NP + col;
         float sum = 0.f;
         for (int sp = w; sp < nsplit; sp += nw) sum += src[(int64_t)sp * n1q * NP];
+        if (slab2) {        // (both sets weighted here; `sym` below is then 1)
+            const float* src2 = slab2 + ((int64_t)i * q + a) * NP + col;
+            float sum2 = 0.f;
+            for (int sp = w; sp < nsplit2; sp += nw) sum2 += src2[(int64_t)sp * n1q * NP];
+            sum = sum * sym + sum2 * sym2;
+        }
         if (w == 0) dPs[e] = sum; else part[(w - 1) * qd + e] = sum;
     }
     __syncthreads();
@@ -1972,6 +2032,8 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
         dots[a] = dot;
     }
     __syncthreads();
+    if (slab2) sym = 1.f;
+    if (tail.scal) sym *= tail.inv_rows / hyp[2];
     const float nbar = -0.5f * dPs[K4];
     for (int k = t; k < d; k += nth) {
         // x~bar = dP[0,:] + 2 nbar x~ + sum_a alphabar_a vhat_a
@@ -1990,6 +2052,7 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
         __shared__ double r0[PTS_NT], r1[PTS_NT];
         double a = 0, b = 0;
         for (int j = t; j < nblocks; j += nth) { a += partials[2 * j]; b += partials[2 * j + 1]; }
+        for (int j = t; j < nblocks2; j += nth) { a += partials2[2 * j]; b += partials2[2 * j + 1]; }
         r0[t] = a; r1[t] = b;
         for (int j = nth + t; j < PTS_NT; j += nth) { r0[j] = 0; r1[j] = 0; }
         __syncthreads();
@@ -2000,6 +2063,18 @@ __global__ __launch_bounds__(PTS_NT) void kernel_bwd_points_kernel(const float* 
         if (t == 0) {
             d_hyp[1] += (float)(r0[0] / (double)hyp[1]);   // d outputscale = sum(G o K)/s
             d_hyp[0] += (float)r1[0];                       // d lengthscale
+            if (tail.scal) {                                // scale_epilogue_kernel's first thread (elbo.hip)
+                const float sc = tail.inv_rows / hyp[2];
+                const float* scal = tail.scal;
+                const float d0 = d_hyp[0] * sc + scal[4], d1 = d_hyp[1] * sc + scal[3], d2 = d_hyp[2] + scal[1];
+                d_hyp[0] = d0; d_hyp[1] = d1; d_hyp[2] = d2;
+                auto sigm = [](float v) { return 1.f / (1.f + expf(-v)); };
+                tail.drl[0] += d0 * sigm(tail.rl[0]);
+                tail.drs[0] += d1 * sigm(tail.rs[0]);
+                tail.drn[0] += d2 * sigm(tail.rn[0]);
+                tail.dconst[0] += scal[2];
+                tail.loss[0] = -scal[0] * tail.inv_rows + tail.kl0[0] * tail.inv_num_data;
+            }
         }
     }
 }
@@ -2018,6 +2093,28 @@ inline int make_geom(int d, int p, Geom& g) {
     if (g.NP > 96) return DSVGP_EINVAL;   // d <= 88
     return 0;
 }
+
+inline int launch_points(hipStream_t st, const Geom& g, const float* slab, int ns, const float* P1, const float* vnorm1, int n1, int d, int p,
+                         const float* hyp, float sym, float* d_x1, float* d_v1, const float* partials, int nparts, float* d_hyp,
+                         const float* slab2 = nullptr, int ns2 = 0, float sym2 = 0.f, const float* partials2 = nullptr, int nparts2 = 0,
+                         PointsTail tail = PointsTail{}) {
+    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;       // (wave partials: <= 48 KB of LDS)
+    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), st, slab, ns,
+                       P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1, partials, nparts, d_hyp, slab2, ns2, sym2, partials2, nparts2,
+                       tail);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+// the last launch of every kernel backward: queued now, or noted in the context for dsvgp_kernel_bwd_points_flush (common.h: defer_points)
+inline int finish_points(dsvgp_ctx* ctx, const Geom& g, const float* slab, int ns, const float* P1, const float* vnorm1, int n1, int d, int p,
+                         const float* hyp, float sym, float* d_x1, float* d_v1, const float* partials, int nparts, float* d_hyp) {
+    if (ctx->defer_points && ctx->n_deferred < 2) {
+        ctx->deferred[ctx->n_deferred++] = dsvgp_ctx::PointsJob{slab, ns, partials, nparts, sym};
+        return 0;
+    }
+    return launch_points(ctx->stream, g, slab, ns, P1, vnorm1, n1, d, p, hyp, sym, d_x1, d_v1, partials, nparts, d_hyp);
+}
+
 inline bool bwd_use_pair(const Geom& g) { return (g.q == 6 || g.q == 3) && g.NP <= 64; }     // (NP <= 32: KSM = 8; <= 64: KSM = 16)
 #ifdef BWD_NO_SPLIT
 inline bool bwd_use_split(const Geom&) { return false; }
@@ -2728,11 +2825,7 @@ extern "C" int dsvgp_kernel_bwd_canon(dsvgp_ctx* ctx, const void* G, int64_t ldg
     else { if (g.q == 6) DSVGP_CANON_BWD(float, 6, false); else DSVGP_CANON_BWD(float, 3, false); }
 #undef DSVGP_CANON_BWD
     DSVGP_LAUNCH_CHECK();
-    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;
-    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), ctx->stream,
-                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, 1.f, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
-    DSVGP_LAUNCH_CHECK();
-    return 0;
+    return finish_points(ctx, g, slab, ns, P1, vnorm1, n1, d, p, hyp, 1.f, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
 }
 
 
@@ -3050,12 +3143,27 @@ extern "C" int dsvgp_kernel_bwd_canon2(dsvgp_ctx* ctx, const void* G, int64_t ld
         hipLaunchKernelGGL((kernel_bwd_canon2_kernel<11, float>), grid, dim3(64), lds, ctx->stream, (const float*)G, ldg, P1, n1, P2, n2, d,
                            g.K4, g.DP, g.NP, dir_idx, idx_base, hyp, slab, partials);
     DSVGP_LAUNCH_CHECK();
-    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;
-    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), ctx->stream,
-                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, symmetric ? 2.f : 1.f, d_x1, d_v1, (const float*)partials, ns * rt,
-                       d_hyp);
-    DSVGP_LAUNCH_CHECK();
-    return 0;
+    return finish_points(ctx, g, slab, ns, P1, vnorm1, n1, d, p, hyp, symmetric ? 2.f : 1.f, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
+}
+
+// One kernel_bwd_points launch over the slab sets the kernel backwards have noted while ctx->defer_points was set (at most two: the one-call
+// step's K_ZX-bar and K_ZZ-bar), with the step's scalar tail folded in when `scal` is given (PointsTail above).  Internal (csrc/step.hip).
+int kernel_bwd_points_flush(dsvgp_ctx* ctx, const float* P1, const float* vnorm1, int n1, int d, int p, const float* hyp, float* d_x1,
+                            float* d_v1, float* d_hyp, const float* scal, const float* kl0, double rows, double num_data, const float* rl,
+                            const float* rs, const float* rn, float* drl, float* drs, float* drn, float* dconst, float* loss) {
+    Geom g;
+    if (int rc = make_geom(d, p, g)) return rc;
+    const int n = ctx->n_deferred;
+    ctx->n_deferred = 0;
+    if (n < 1) return DSVGP_EINVAL;
+    PointsTail tail{};
+    if (scal) tail = PointsTail{scal, kl0, (float)(1.0 / rows), (float)(1.0 / num_data), rl, rs, rn, drl, drs, drn, dconst, loss};
+    const dsvgp_ctx::PointsJob& a = ctx->deferred[0];
+    if (n == 1) return launch_points(ctx->stream, g, a.slab, a.ns, P1, vnorm1, n1, d, p, hyp, a.sym, d_x1, d_v1, a.partials, a.nparts, d_hyp,
+                                     nullptr, 0, 0.f, nullptr, 0, tail);
+    const dsvgp_ctx::PointsJob& b = ctx->deferred[1];
+    return launch_points(ctx->stream, g, a.slab, a.ns, P1, vnorm1, n1, d, p, hyp, a.sym, d_x1, d_v1, a.partials, a.nparts, d_hyp, b.slab, b.ns,
+                         b.sym, b.partials, b.nparts, tail);
 }
 
 extern "C" int dsvgp_packed_width(int d) { return ((d + 3) & ~3) + 4; }
@@ -3081,6 +3189,19 @@ __global__ void column_mean_hyp_kernel(const float* __restrict__ x, int n, int d
         }
     }
 }
+// centre + constrained hyper-parameters + the packed rows of (Z, V) and of (x, D) in one launch (pack_both_kernel)
+int launch_pack_both(hipStream_t st, const float* Z, const float* V, int M, const float* X, const float* D, int B, int d, int p,
+                     const float* rl, const float* rs, const float* rn, float* hyp, float* center, float* PZ, float* sZ, float* vZ,
+                     float* PX, float* sX, float* vX) {
+    Geom g;
+    if (int rc = make_geom(d, p, g)) return rc;
+    const int nbz = cdiv((int64_t)M * g.q, 256), nbx = cdiv((int64_t)B * g.q, 256);
+    hipLaunchKernelGGL(pack_both_kernel, dim3(nbz + nbx), dim3(256), sizeof(float) * (d + 1), st, Z, V, M, X, D, B, d, p, rl, rs, rn, hyp,
+                       center, PZ, sZ, vZ, PX, sX, vX, g.K4, g.DP, nbz);
+    DSVGP_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp) {
     hipLaunchKernelGGL(column_mean_hyp_kernel, dim3(d), dim3(256), 0, st, x, n, d, center, rl, rs, rn, hyp);
@@ -3284,9 +3405,5 @@ extern "C" int dsvgp_kernel_bwd(dsvgp_ctx* ctx, const void* G, int64_t ldg, int 
     DSVGP_LAUNCH_CHECK();
     }
     const float sym = symmetric ? 2.f : 1.f;
-    const int pts_waves = (g.q * g.DP > 3072) ? 1 : PTS_NT / 64;       // (wave partials: <= 48 KB of LDS)
-    hipLaunchKernelGGL(kernel_bwd_points_kernel, dim3(n1), dim3(64 * pts_waves), sizeof(float) * (pts_waves * g.q * g.DP + g.q + 1), ctx->stream,
-                       slab, ns, P1, vnorm1, n1, d, p, g.K4, g.DP, g.NP, hyp, sym, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
-    DSVGP_LAUNCH_CHECK();
-    return 0;
+    return finish_points(ctx, g, slab, ns, P1, vnorm1, n1, d, p, hyp, sym, d_x1, d_v1, (const float*)partials, ns * rt, d_hyp);
 }

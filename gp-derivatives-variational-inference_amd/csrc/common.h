@@ -22,6 +22,13 @@ struct dsvgp_ctx {
     // pipelined one it finishes 0.2 ms earlier, starves G L_S, and G L_S's tail then collides with the dense product: the step is 0.1 ms
     // slower (profiles/r05_o_gemm64l_lean.txt)
     bool lean_classic = false;
+    // set by dsvgp_elbo_step_f32 around its two kernel backwards (K_ZX-bar, K_ZZ-bar): their last launch -- kernel_bwd_points_kernel,
+    // which adds the tile kernels' slabs into d_x1 / d_v1 / d_hyp -- is not queued but noted here, and dsvgp_kernel_bwd_points_flush runs
+    // ONE such launch over both slab sets, with the step's scalar tail folded in (round 6: three ~5 us launches fewer at M' = 600)
+    struct PointsJob { const float* slab; int ns; const float* partials; int nparts; float sym; };
+    bool defer_points = false;
+    int n_deferred = 0;
+    PointsJob deferred[2];
 };
 
 #define DSVGP_LAUNCH_CHECK()                                  \
@@ -91,10 +98,17 @@ int launch_potrf_blocked(hipStream_t st, double* A, int n, int64_t lda, int* inf
 // pipe_from: first block column whose launch may use the one-workgroup-per-CU pipelined kernel (potrf.hip, PIPE): a caller whose
 // other stream shares the CUs with the first launches of the chain passes the launch index from which the chain is alone
 // pieces of the one-call step (csrc/step.hip) that fold tiny dependent launches into their neighbours
+int launch_pack_both(hipStream_t st, const float* Z, const float* V, int M, const float* X, const float* D, int B, int d, int p,
+                     const float* rl, const float* rs, const float* rn, float* hyp, float* center, float* PZ, float* sZ, float* vZ,
+                     float* PX, float* sX, float* vX);
+int kernel_bwd_points_flush(dsvgp_ctx* ctx, const float* P1, const float* vnorm1, int n1, int d, int p, const float* hyp, float* d_x1,
+                            float* d_v1, float* d_hyp, const float* scal, const float* kl0, double rows, double num_data, const float* rl,
+                            const float* rs, const float* rn, float* drl, float* drs, float* drn, float* dconst, float* loss);
 int launch_column_mean_hyp(hipStream_t st, const float* x, int n, int d, float* center, const float* rl, const float* rs,
                            const float* rn, float* hyp);                                       // assemble.hip
 int launch_widen_sym_f32_f64(hipStream_t st, const float* src, int64_t lds, double* dst, int64_t ldd, int n);    // elbo.hip: fp64 mirror of an fp32 lower triangle
-int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows);   // elbo.hip
+int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows, double* W = nullptr,
+                               int64_t ldw = 0);   // elbo.hip
 int launch_variational_terms(hipStream_t st, const float* m, const float* LS, int64_t ldls, int Mp, double num_data, int flags,
                              const float* hyp, double global_rows, const float* G, int64_t ldg, float t1_scale, float* kl_out,
                              float* sums, const float* dm_src, float* d_m, float* d_LS, int64_t lddls, int fin_npts, int fin_p,

@@ -1050,26 +1050,35 @@ extern "C" int dsvgp_sminus_i_col(dsvgp_ctx* ctx, float* A, int n, int64_t lda, 
 
 // mirror the lower triangle of A[n, n] onto its upper triangle AND A[i][i] -= 1, A[i][n] = m[i] noise rows: dsvgp_mirror_lower_f32
 // + dsvgp_sminus_i_col in one launch (the diagonal blocks do the extra work after their mirror)
+// W (optional, round 6): the fp64 copy [S - I ; m^T noise rows], (n + 1) x n with row stride ldw, written on the way (S - I is symmetric:
+// its rows go as they lie, the extra column becomes row n) -- two widening launches fewer per step
 __global__ void mirror_sminus_kernel(float* __restrict__ G, int n, int64_t ldg, const float* __restrict__ m,
-                                     const float* __restrict__ hyp, float rows) {
+                                     const float* __restrict__ hyp, float rows, double* __restrict__ W, int64_t ldw) {
     __shared__ float tile[32][33];
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
     const int tx = threadIdx.x, ty = threadIdx.y;
     for (int r = ty; r < 32; r += 8) {
         const int gi = bj * 32 + r, gj = bi * 32 + tx;
-        tile[r][tx] = (gi < n && gj < n) ? G[(int64_t)gi * ldg + gj] : 0.f;
+        const float v = (gi < n && gj < n) ? G[(int64_t)gi * ldg + gj] : 0.f;
+        tile[r][tx] = v;
+        if (W && gi < n && gj < n && gj <= gi) W[(int64_t)gi * ldw + gj] = (double)(gi == gj ? v - 1.f : v);     // the lower tile as it lies
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int gi = bi * 32 + r, gj = bj * 32 + tx;
-        if (gi < n && gj < n && gj > gi) G[(int64_t)gi * ldg + gj] = tile[tx][r];
+        if (gi < n && gj < n && gj > gi) {
+            G[(int64_t)gi * ldg + gj] = tile[tx][r];
+            if (W) W[(int64_t)gi * ldw + gj] = (double)tile[tx][r];
+        }
     }
     if (bi == bj && ty == 0) {
         const int i = bi * 32 + tx;
         if (i < n) {
+            const float col = m[i] * (hyp[2] * rows);
             G[(int64_t)i * ldg + i] -= 1.f;
-            G[(int64_t)i * ldg + n] = m[i] * (hyp[2] * rows);
+            G[(int64_t)i * ldg + n] = col;
+            if (W) W[(int64_t)n * ldw + i] = (double)col;
         }
     }
 }
@@ -1081,9 +1090,10 @@ int launch_widen_sym_f32_f64(hipStream_t st, const float* src, int64_t lds, doub
     return 0;
 }
 
-int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows) {
+int launch_mirror_sminus_i_col(hipStream_t st, float* A, int n, int64_t lda, const float* m, const float* hyp, float rows, double* W,
+                               int64_t ldw) {
     const int nb = cdiv(n, 32);
-    hipLaunchKernelGGL(mirror_sminus_kernel, dim3(nb, nb), dim3(32, 8), 0, st, A, n, lda, m, hyp, rows);
+    hipLaunchKernelGGL(mirror_sminus_kernel, dim3(nb, nb), dim3(32, 8), 0, st, A, n, lda, m, hyp, rows, W, ldw);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -53,6 +53,7 @@ struct dsvgp_step_plan {
     size_t o_zero, zero_bytes;        // region cleared at the start of every step: info, sums, kl_buf
     size_t o_info, o_sums, o_klbuf, o_scal, o_hyp, o_center;
     size_t o_PZ, o_sZ, o_vZ, o_PX, o_sX, o_vX;
+    size_t o_phi32 = 0; bool phi32_own = false;
     size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_S64e, o_Qe32, o_Kb32, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2;
     size_t o_arena, arena_bytes;     // contiguous region of everything a launcher would clear (see step_layout)
     int ldS, ldQ32;
@@ -101,6 +102,11 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     pl->o_Ge = c.take((size_t)(Mp + 1) * Mp * 4); pl->o_Qe64 = c.take((size_t)Mp * (Mp + 2) * 8 + 64);
     pl->o_Kb32 = c.take((size_t)Mp * Bp * 4); pl->o_G1 = c.take((size_t)Mp * Mp * 8);
     pl->o_Yt = c.take((size_t)Mp * Mp * 8); pl->o_Kbar = c.take((size_t)Mp * Mp * 8);
+    // small problems: the fp32 argument of Phi (tril([S - I | m'] [G ; b^T]), a split-K / OUT_LOWER target) gets its own place INSIDE the arena
+    // -- cleared by the step's one memset -- instead of the [Q' | a] scratch, which would need a clearing launch between the dense product
+    // that reads it and this product (round 6: 5 us of the M' = 600 step)
+    pl->phi32_own = (size_t)Mp * pl->ldQ32 * 4 <= ((size_t)8 << 20);
+    pl->o_phi32 = pl->phi32_own ? c.take((size_t)Mp * pl->ldQ32 * 4) : 0;
     // head: hyp[4] | info[4 ints] | sums[4] | kl_buf[2 M' + 1]   (cleared every step; hyp + info go to the host in ONE copy).
     // It closes the arena, so that the small-problem mode clears both with one memset.
     pl->o_zero = c.off;
@@ -424,12 +430,12 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         ~PrezeroGuard() { c->prezeroed = prev; }
     } prezero_guard(ctx, prezero);
     // ---- hyper-parameters + centre (one launch), packed inducing rows (DGVS.py:128-149 via RBFKernelDirectionalGrad.py:57-107)
-    STEP_CALL(launch_column_mean_hyp(main, io->Z, M, d, center, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp));
-    STEP_CALL(dsvgp_pack_points(ctx, io->Z, io->V, M, d, p, hyp, center, PZ, sZ, vZ));
-    // ---- prologue that does not depend on L: pack x, K_ZX, [S - I | m / (2 vbar)] -- on the side stream under the Cholesky chain
+    // (round 6: ONE launch -- centre, hyper-parameters, the packed rows of both point sets; three launches before)
+    STEP_CALL(launch_pack_both(main, io->Z, io->V, M, io->x, io->D, B, d, p, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp,
+                               center, PZ, sZ, vZ, PX, sX, vX));
+    // ---- prologue that does not depend on L: K_ZX, [S - I | m / (2 vbar)] -- on the side stream under the Cholesky chain
     auto prologue = [&](bool background) -> int {
-        int rc = dsvgp_pack_points(ctx, io->x, io->D, B, d, p, hyp, center, PX, sX, vX);
-        if (rc) return rc;
+        int rc = 0;
         if (timed && hipEventRecord(pl->tm[2], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
         rc = zx_fwd(ctx, io, PZ, sZ, M, PX, sX, B, d, p, hyp, Kzx, Bp);
         if (rc) return rc;
@@ -439,13 +445,11 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
                         (background ? DSVGP_GEMM_BACKGROUND : 0), Mp, Mp, Mp, 1.0, io->LS, io->ldls, io->LS, io->ldls, 0.0, nullptr, 0,
                         S32e, ldS, nullptr, 0, nullptr);
         if (rc) return rc;
-        rc = launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows);     // mirror + [S - I | m / (2 vbar)]
+        // mirror + [S - I | m / (2 vbar)] AND its fp64 copy, TRANSPOSED -- [S - I ; m^T / (2 vbar)], (M'+1) x M': S - I is symmetric, so its
+        // rows are copied as they lie and only the extra column becomes a row -- the left operand of the Cholesky backward's first product
+        // (chol_tail below) then streams as an mn-contiguous operand (the lean fp64 kernel's faster staging path: 49 against 46 TF)
+        rc = launch_mirror_sminus_i_col(ctx->stream, S32e, Mp, ldS, io->m, hyp, (float)rows, S64e, ldST);
         if (rc) return rc;
-        // its fp64 copy, TRANSPOSED -- [S - I ; m^T / (2 vbar)], (M'+1) x M': S - I is symmetric, so its rows are copied as they lie and
-        // only the extra column becomes a row -- the left operand of the Cholesky backward's first product (chol_tail below) then
-        // streams as an mn-contiguous operand (the lean fp64 kernel's faster staging path: 49 against 46 TF)
-        launch_widen_f32_f64(ctx->stream, S32e, ldS, S64e, ldST, Mp, Mp);
-        launch_widen_f32_f64(ctx->stream, S32e + Mp, ldS, S64e + (size_t)Mp * ldST, 1, Mp, 1);
         const hipError_t e = hipGetLastError();            // (one call: it clears the error it returns)
         return e == hipSuccess ? 0 : 1000 + (int)e;
     };
@@ -631,15 +635,18 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // Cholesky backward.  STEP_PHI64 / flag 64 / shapes gemm32 does not take: the fp64-accumulated form.
     auto phi_arg = [&](bool qe32_free) -> int {
 #if !STEP_PHI64
-        if (qe32_free && !(flags & 64)) {
+        const bool own = ctx->prezeroed && pl->phi32_own;          // (its own, already cleared place in the arena: step_layout)
+        if ((qe32_free || own) && !(flags & 64)) {
             GemmArgs g{};
-            g.M = Mp; g.N = Mp; g.K = Mp + 1; g.A = S32e; g.lda = ldS; g.B = Ge; g.ldb = Mp; g.C = Qe32; g.ldc = ldQ32;
+            float* P32 = own ? (float*)(w + pl->o_phi32) : Qe32;
+            g.M = Mp; g.N = Mp; g.K = Mp + 1; g.A = S32e; g.lda = ldS; g.B = Ge; g.ldb = Mp; g.C = P32; g.ldc = ldQ32;
             g.alpha = -1.0; g.beta = 0.0; g.batch = 1; g.splitk = 1;
-            g.flags = DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED | DSVGP_GEMM_UPPER_UNDEF;     // (the widening below reads the lower triangle only: no zero fill of the rest)
+            g.flags = DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_K_PADDED | DSVGP_GEMM_UPPER_UNDEF |     // (the widening below reads the lower triangle only: no zero fill of the rest)
+                      (own ? DSVGP_GEMM_C_ZEROED : 0);
             g.slab = ctx->det_slab; g.slab_bytes = ctx->det_bytes;
-            const int rc = launch_gemm32(ctx->stream, g);          // (clears the output itself: Qe32 is not part of the prezeroed arena)
+            const int rc = launch_gemm32(ctx->stream, g);          // (clears the output itself when it is the [Q' | a] scratch: not part of the prezeroed arena)
             if (rc > 1) return rc;
-            if (rc == 1) return launch_widen_sym_f32_f64(ctx->stream, Qe32, ldQ32, G1, Mp, Mp);   // widening + Phi(.) + Phi(.)^T in one pass
+            if (rc == 1) return launch_widen_sym_f32_f64(ctx->stream, P32, ldQ32, G1, Mp, Mp);   // widening + Phi(.) + Phi(.)^T in one pass
         }
 #endif
         int rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_OUT_LOWER | DSVGP_GEMM_B_IS_FLOAT, Mp, Mp, Mp + 1, -1.0, S64e, ldST, Ge, Mp,
@@ -699,6 +706,13 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
 #define STEP_ZX_SIDE_MAX 2          // K_ZX-bar's kernel backward goes to the side stream when B' <= STEP_ZX_SIDE_MAX * M'
 #endif
     const bool zx_side = overlap && !tail_side && (int64_t)Bp <= (int64_t)STEP_ZX_SIDE_MAX * Mp;
+    // (round 6) the two kernel backwards leave their slabs (K_ZX-bar's in the second workspace, whichever stream it runs on) and ONE
+    // kernel_bwd_points launch adds both, scales by 2 vbar and does the scalar tail: kernel_bwd_points x 2 + scale_epilogue before
+    struct DeferGuard {
+        dsvgp_ctx* c;
+        DeferGuard(dsvgp_ctx* c_) : c(c_) { c->defer_points = true; c->n_deferred = 0; }
+        ~DeferGuard() { c->defer_points = false; c->n_deferred = 0; }
+    } defer_guard(ctx);
     if (zx_side) {
         STEP_HIP(hipEventRecord(pl->ev_dense, main));
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_dense, 0));
@@ -715,15 +729,16 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     }
     if (!zx_side) {
         STEP_TIME(4);
-        STEP_CALL(zx_bwd(ctx, io, Kb32, Bp, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, kbwd_ws));
+        STEP_CALL(zx_bwd(ctx, io, Kb32, Bp, PZ, sZ, vZ, M, PX, sX, B, d, p, hyp, kbwd_ws2));
         STEP_TIME(5);
     }
     if (zx_side || tail_side) STEP_HIP(hipStreamWaitEvent(main, pl->ev_zx, 0));
     STEP_CALL(zz_bwd(ctx, io, Kbar, Mp, PZ, sZ, vZ, M, PZ, sZ, M, d, p, hyp, kbwd_ws));
-    // ---- 2 vbar = 1 / (noise rows) on the kernel gradients (the products above ran unscaled), scalar tail
-    STEP_CALL(launch_scale_epilogue(ctx, io->dZ, (int64_t)M * d, p > 0 ? io->dV : nullptr, p > 0 ? (int64_t)M * p * d : 0, hyp, rows, scal,
-                                    kl_buf, io->num_data, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_hyp,
-                                    io->d_raw_lengthscale, io->d_raw_outputscale, io->d_raw_noise, io->d_constant, io->loss));
+    // ---- both slab sets -> Z-bar, V-bar, the kernel hyper-parameter gradients; 2 vbar = 1 / (noise rows) on them (the products above ran
+    // unscaled) and the scalar tail, in the same launch
+    STEP_CALL(kernel_bwd_points_flush(ctx, PZ, vZ, M, d, p, hyp, io->dZ, io->dV, io->d_hyp, scal, kl_buf, rows, io->num_data,
+                                      io->raw_lengthscale, io->raw_outputscale, io->raw_noise, io->d_raw_lengthscale, io->d_raw_outputscale,
+                                      io->d_raw_noise, io->d_constant, io->loss));
     return 0;
 }
 

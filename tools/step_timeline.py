@@ -10,7 +10,7 @@ if args[:1] == ["--back"]:
     back = int(args[1]); args = args[2:]
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name,start,end,stream_id,grid_x,workgroup_x from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if 'hyp_forward' in r[0] or 'column_mean_hyp' in r[0]]
+idx = [i for i, r in enumerate(rows) if 'hyp_forward' in r[0] or 'column_mean_hyp' in r[0] or 'pack_both' in r[0]]     # (a step's first launch)
 back = min(back, len(idx) - 2)
 a, b = idx[-2 - back], idx[-1 - back]
 t0 = rows[a][1]
