@@ -778,8 +778,10 @@ def gather_batch(ctx, X, Y, idx, cols, p, xb, yb, E=None, Db=None):
 ADAM_MAX_TENSORS = 16
 
 
-def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
-    """torch.optim.Adam update of several tensors that share (lr, betas, eps, step) in one launch."""
+def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step, tril=None):
+    """torch.optim.Adam update of several tensors that share (lr, betas, eps, step) in one launch.  ``tril[k]`` true: params[k] is a square
+    matrix of which only the lower triangle is a parameter (its gradient and moments are zero above the diagonal): the strict upper
+    triangle is left alone (float32 only)."""
     import ctypes
     n = len(params)
     if n > ADAM_MAX_TENSORS:
@@ -790,7 +792,10 @@ def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2
             if t.dtype != dt or dt not in (f32, f64) or not t.is_cuda or not t.is_contiguous():
                 raise ValueError("adam: tensors must be contiguous GPU tensors of one dtype (float32 or float64)")
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-    sizes = (ctypes.c_int64 * n)(*[t.numel() for t in params])
+    sz = [t.numel() for t in params]
+    if tril is not None and dt == f32:
+        sz = [-t.shape[0] if (tr and t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] > 1) else k for t, k, tr in zip(params, sz, tril)]
+    sizes = (ctypes.c_int64 * n)(*sz)
     fn, name = (lib.dsvgp_adam_step_multi_f64, "dsvgp_adam_step_multi_f64") if dt == f64 else (lib.dsvgp_adam_step_multi, "dsvgp_adam_step_multi")
     check(fn(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, float(lr), float(beta1), float(beta2),
              float(eps), int(step)), name)

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
     float* __restrict__ m = t.m[k];
     float* __restrict__ v = t.v[k];
     const int64_t n = t.n[k];
-    for (int64_t i = (int64_t)(blockIdx.x - t.first[k]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+    auto update = [&](int64_t i) {
         const float g = grad[i];
         const float mi = b1 * m[i] + (1.f - b1) * g;
         const float vi = b2 * v[i] + (1.f - b2) * g * g;
@@ -302,7 +302,17 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, floa
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         param[i] -= (lr / bc1) * (mi / denom);
+    };
+    if (n < 0) {
+        // a square matrix of which only the lower triangle is a parameter (chol_variational_covar: the reference masks the rest in its
+        // forward, gradient and both moments are exactly zero there and the update is exactly zero): rows dealt cyclically to the
+        // workgroups (the triangular row lengths balance), the strict upper triangle is not touched -- half the traffic of this launch
+        const int64_t dim = -n;
+        for (int64_t r = blockIdx.x - t.first[k]; r < dim; r += nb)
+            for (int64_t c = threadIdx.x; c <= r; c += 256) update(r * dim + c);
+        return;
     }
+    for (int64_t i = (int64_t)(blockIdx.x - t.first[k]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) update(i);
 }
 
 // Graph-capturable variants: every per-step scalar comes from device memory.
@@ -936,11 +946,12 @@ extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* pa
     AdamTable t{};
     int nblocks = 0;
     for (int k = 0; k < count; ++k) {
-        if (sizes[k] < 0 || (sizes[k] > 0 && (!params[k] || !grads[k] || !exp_avgs[k] || !exp_avg_sqs[k]))) return DSVGP_EINVAL;
+        if (sizes[k] != 0 && (!params[k] || !grads[k] || !exp_avgs[k] || !exp_avg_sqs[k])) return DSVGP_EINVAL;
         if (sizes[k] == 0) continue;
         const int c = t.count++;
         t.param[c] = params[k]; t.grad[c] = grads[k]; t.m[c] = exp_avgs[k]; t.v[c] = exp_avg_sqs[k]; t.n[c] = sizes[k];
-        int b = cdiv(sizes[k], 256);
+        // (sizes[k] = -n: an n x n matrix whose lower triangle is the parameter: one workgroup per row, cyclically)
+        int b = sizes[k] < 0 ? (int)(-sizes[k] < 2048 ? -sizes[k] : 2048) : cdiv(sizes[k], 256);
         if (b > 2048) b = 2048;
         t.first[c] = nblocks;
         nblocks += b;

@@ -484,16 +484,22 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         return launch_gemm(ctx->stream, 1, f);
     };
     int r2 = 0;
-    if (overlap) {
-        STEP_HIP(hipEventRecord(pl->ev_fork, main));
+    if (overlap) STEP_HIP(hipEventRecord(pl->ev_fork, main));
+    // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip).  K_ZZ's assembly AND the chain
+    // are QUEUED ahead of the side stream's prologue (round 6): the host needs 20-40 us to queue those three launches and their events,
+    // and the main stream -- the step's critical path from here to the end of the chain -- sat idle for that long at M' = 600; behind the
+    // chain's launches the host is ahead of the device and the prologue still starts under the chain's first launches
+    STEP_CALL(zz_fwd(ctx, io, PZ, sZ, M, d, p, hyp, L, Mp));
+    auto side_prologue = [&]() -> int {      // (queued BEHIND the chain's launches on the host, see above; it only waits for ev_fork on the device)
+        if (!overlap) return 0;
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork, 0));
         ctx->stream = side;
-        STEP_CALL(prologue(true));
-        STEP_HIP(hipEventRecord(pl->ev_side, side));              // (K_ZX and [S - I | m'] are final)
+        const int rc = prologue(true);
         ctx->stream = main;
-    }
-    // ---- K_ZZ + jitter (fp32 values widened, DGVS.py:74,144), Cholesky with the fused inverse (potrf.hip)
-    STEP_CALL(zz_fwd(ctx, io, PZ, sZ, M, d, p, hyp, L, Mp));
+        if (rc) return rc;
+        STEP_HIP(hipEventRecord(pl->ev_side, side));              // (K_ZX and [S - I | m'] are final)
+        return 0;
+    };
     if (pipe) {
         const int k1 = pk1, k2 = pk2;
         const int r1 = (k1 + 1) * 64;                                              // (< M': k <= nblk64 - 2)
@@ -502,6 +508,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         double* Dinv = (double*)trsm_ws;
         STEP_CALL(launch_potrf_blocked(main, L, Mp, Mp, info, (double*)potrf_ws, Dinv, Mp, Dinv + (size_t)Mp * Mp, ctx->prezeroed, hooks,
                                        k2 > k1 ? 2 : 1));
+        STEP_CALL(side_prologue());
         ctx->stream = side;
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_pipe1, 0));
         STEP_TIME(0);
@@ -513,8 +520,10 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         STEP_TIME(1);
         STEP_HIP(hipEventRecord(pl->ev_pipe1, side));             // (re-used: the side stream's pieces are done)
         ctx->stream = main;
-    } else
-    STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
+    } else {
+        STEP_CALL(dsvgp_potrf_inverse(ctx, L, Mp, Mp, info, potrf_ws, nb, trsm_ws));
+        STEP_CALL(side_prologue());
+    }
     if (overlap) {
         // the status word's copy to the host leaves the main stream (a 5 us blit between the chain and the solve at M' = 600): the side
         // stream makes it behind an event the main stream records after the factorisation

@@ -78,6 +78,9 @@ class CholeskyVariationalDistribution(_VariationalDistribution):
         self.mean_init_std = mean_init_std
         self.register_parameter("variational_mean", torch.nn.Parameter(torch.zeros(num_inducing_points)))
         self.register_parameter("chol_variational_covar", torch.nn.Parameter(torch.eye(num_inducing_points)))
+        # (only the lower triangle is a parameter -- forward() masks the rest, its gradient is exactly zero there: optim.FusedAdam then
+        #  walks the lower triangle only, half the traffic of the update's largest tensor)
+        self.chol_variational_covar._dsvgp_tril = True
 
     def initialize_variational_distribution(self):
         """prior N(0, I): mean <- 0 + mean_init_std * randn, chol <- I (first training call in gpytorch)."""

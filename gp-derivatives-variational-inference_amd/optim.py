@@ -107,18 +107,19 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 key = (st["step"], p.device, float(group["lr"]), float(b1), float(b2), float(group["eps"]), p.dtype)
-                batch.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+                batch.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"], bool(getattr(p, "_dsvgp_tril", False))))
 
 
 def _launch_batches(batch):
     for (step, dev, lr, b1, b2, eps, dt), items in batch.items():
         ctx = _ops.Context.get(dev)
         for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
-            ps, gs, ms, vs = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
-            if len(ps) == 1 and dt == torch.float32:
+            ps, gs, ms, vs, tr = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
+            if len(ps) == 1 and dt == torch.float32 and not tr[0]:
                 _ops.adam_step_(ctx, ps[0], gs[0], ms[0], vs[0], lr, b1, b2, eps, step)
             else:
-                _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step)       # (float32 or float64 tensors)
+                # (float32 or float64 tensors; a lower-triangular parameter -- chol_variational_covar -- is walked below its diagonal only)
+                _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step, tril=tr)
 
 
 @torch.no_grad()

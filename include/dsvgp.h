@@ -318,7 +318,10 @@ int dsvgp_adam_step(dsvgp_ctx* ctx, float* param, const float* grad, float* exp_
                     int step);
 
 /* the same update for up to DSVGP_ADAM_MAX_TENSORS tensors that share (lr, betas, eps, step) in ONE launch: the parameter
- * groups of one torch.optim.Adam (directional_vi.py:193-199); the arrays are HOST arrays of device pointers / element counts */
+ * groups of one torch.optim.Adam (directional_vi.py:193-199); the arrays are HOST arrays of device pointers / element counts
+ * (round 6) sizes[k] = -n names an n x n row-major matrix of which only the LOWER TRIANGLE is a parameter (chol_variational_covar: the
+ * reference masks the rest in its forward -- variational_strategy / CholeskyVariationalDistribution -- so gradient, both moments and the
+ * update are exactly zero there): the strict upper triangle is then not read or written (dsvgp_adam_step_multi only).             */
 #define DSVGP_ADAM_MAX_TENSORS 16
 int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
                           float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,

@@ -723,6 +723,39 @@ def test_kl_terms_phi_transpose_adddiag(dsvgp, gpu_device):
     assert relmax(Gd, Phi + Phi.t() + 0.25 * torch.eye(Mp, dtype=torch.float64)) < 1e-15
 
 
+@pytest.mark.parametrize("n", [2, 37, 600, 1031])
+def test_fused_adam_walks_only_the_lower_triangle_of_a_flagged_square_parameter(dsvgp, gpu_device, n):
+    """a parameter flagged ``_dsvgp_tril`` (chol_variational_covar: gradient exactly zero above the diagonal) is updated below and on
+    the diagonal exactly as by the dense launch / torch.optim.Adam; what lies above the diagonal -- parameter, moments -- is not touched"""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(n)
+    w0, v0 = torch.randn(n, n, generator=g), torch.randn(n, generator=g)         # (garbage above the diagonal stays where it is)
+    pt = [w0.clone().requires_grad_(True), v0.clone().requires_grad_(True)]
+    pa = [torch.nn.Parameter(w0.clone().to(dev)), torch.nn.Parameter(v0.clone().to(dev))]
+    pb = [torch.nn.Parameter(w0.clone().to(dev)), torch.nn.Parameter(v0.clone().to(dev))]
+    pa[0]._dsvgp_tril = True
+    ot, oa, ob = torch.optim.Adam(pt, lr=0.03), dsvgp.FusedAdam(pa, lr=0.03), dsvgp.FusedAdam(pb, lr=0.03)
+    for k in range(4):
+        gw, gv = torch.randn(n, n, generator=g).tril(), torch.randn(n, generator=g)
+        for ps in (pt, pa, pb):
+            ps[0].grad = gw.clone().to(ps[0].device)
+            ps[1].grad = gv.clone().to(ps[1].device)
+        ot.step(); oa.step(); ob.step()
+    assert torch.equal(pa[0].detach(), pb[0].detach()) and torch.equal(pa[1].detach(), pb[1].detach())       # bit-identical to the dense walk
+    assert relmax(pa[0].detach(), pt[0].detach()) < 2e-6
+    assert torch.equal(pa[0].detach().cpu().triu(1), w0.triu(1))
+    st = oa.state[pa[0]]
+    assert st["exp_avg"].triu(1).abs().max().item() == 0.0 and st["exp_avg_sq"].triu(1).abs().max().item() == 0.0
+    # the flag alone on the single-tensor path
+    pc = torch.nn.Parameter(w0.clone().to(dev))
+    pc._dsvgp_tril = True
+    oc, od = dsvgp.FusedAdam([pc], lr=0.03), dsvgp.FusedAdam([torch.nn.Parameter(w0.clone().to(dev))], lr=0.03)
+    gw = torch.randn(n, n, generator=g).tril().to(dev)
+    pc.grad = gw.clone(); od.param_groups[0]["params"][0].grad = gw.clone()
+    oc.step(); od.step()
+    assert torch.equal(pc.detach(), od.param_groups[0]["params"][0].detach())
+
+
 def test_gather_batch_and_fused_adam(dsvgp, gpu_device):
     ops = dsvgp._ops
     dev = gpu_device
