@@ -60,7 +60,7 @@ struct dsvgp_step_plan {
     const void* pad_ready_for = nullptr;          // the workspace whose Qe32 pad columns have been zeroed
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_status = nullptr, ev_fork2 = nullptr, ev_var = nullptr, ev_dense = nullptr,
-               ev_zx = nullptr, ev_pipe1 = nullptr, ev_pipe2 = nullptr;
+               ev_zx = nullptr, ev_pipe1 = nullptr, ev_pipe2 = nullptr, ev_s = nullptr;
     // timing pairs of the last TM_RING timed steps: forward solve, K_ZX assembly, K_ZX-bar kernel backward, Gram product, dense K_ZX-bar product
     static constexpr int TM_RING = 128, TM_PAIRS = 5;
     hipEvent_t tm_ring[TM_RING][2 * TM_PAIRS] = {};
@@ -71,6 +71,10 @@ struct dsvgp_step_plan {
 };
 
 // workspace layout of one (M, d, p, B); returns the total byte count (0: unsupported shape)
+#ifndef STEP_S_LATE
+#define STEP_S_LATE 2               // [S - I | m'] behind the chain, beside the forward solve: 1 as a one-workgroup-per-CU filler, 2 at full grid
+#define STEP_S_LATE_MP 1024         // ... from this M' up (below: under the chain, as in rounds 2-5)
+#endif
 static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int world = 1) {
     if (M <= 0 || d <= 0 || p < 0 || B <= 0 || world < 1 || world > 64 || (world > 1 && M < world)) return 0;
     const int q = p + 1, Mp = M * q, Bp = B * q, DP = dsvgp_packed_width(d);
@@ -180,7 +184,7 @@ static int plan_create(dsvgp_ctx* ctx, int M, int d, int p, int B, int world, ds
     if (!step_layout(M, d, p, B, pl, world)) { delete pl; return DSVGP_EINVAL; }
     bool ok = hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) == hipSuccess;
     hipEvent_t* evs[] = {&pl->ev_fork, &pl->ev_side, &pl->ev_status, &pl->ev_fork2, &pl->ev_var, &pl->ev_dense, &pl->ev_zx, &pl->ev_dp,
-                         &pl->ev_pipe1, &pl->ev_pipe2};
+                         &pl->ev_pipe1, &pl->ev_pipe2, &pl->ev_s};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     for (auto& slot : pl->tm_ring) for (hipEvent_t& e : slot) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&pl->host_status, 8 * sizeof(float), hipHostMallocDefault) == hipSuccess;
@@ -219,7 +223,7 @@ extern "C" size_t dsvgp_elbo_step_po_workspace_bytes(int M, int d, int p, int B)
 extern "C" int dsvgp_elbo_step_plan_destroy(dsvgp_step_plan* pl) {
     if (!pl) return DSVGP_EINVAL;
     hipEvent_t evs[] = {pl->ev_fork, pl->ev_side, pl->ev_status, pl->ev_fork2, pl->ev_var, pl->ev_dense, pl->ev_zx, pl->ev_dp, pl->ev_pipe1,
-                        pl->ev_pipe2};
+                        pl->ev_pipe2, pl->ev_s};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& slot : pl->tm_ring) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
     if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -434,16 +438,20 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     STEP_CALL(launch_pack_both(main, io->Z, io->V, M, io->x, io->D, B, d, p, io->raw_lengthscale, io->raw_outputscale, io->raw_noise, hyp,
                                center, PZ, sZ, vZ, PX, sX, vX));
     // ---- prologue that does not depend on L: K_ZX, [S - I | m / (2 vbar)] -- on the side stream under the Cholesky chain
-    auto prologue = [&](bool background) -> int {
-        int rc = 0;
-        if (timed && hipEventRecord(pl->tm[2], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
-        rc = zx_fwd(ctx, io, PZ, sZ, M, PX, sX, B, d, p, hyp, Kzx, Bp);
-        if (rc) return rc;
-        if (timed && hipEventRecord(pl->tm[3], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
-        // S = tril(L_S) tril(L_S)^T: lower triangle + mirror (n^3 / 6 multiply-adds), as a one-workgroup-per-CU filler beside the chain
-        rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_A_LOWER | DSVGP_GEMM_TRANS_B | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER |
-                        (background ? DSVGP_GEMM_BACKGROUND : 0), Mp, Mp, Mp, 1.0, io->LS, io->ldls, io->LS, io->ldls, 0.0, nullptr, 0,
-                        S32e, ldS, nullptr, 0, nullptr);
+    // (round 6) with the second stream, [S - I | m'] is formed BEHIND the chain, beside the forward solve, not under the chain's first
+    // launches: it is not needed before the [Q' | a] solve, and under the chain its product -- even as a one-workgroup-per-CU filler --
+    // shares the critical workgroup's CU: the chain's launches 1 .. 5 took 41 / 80 / 72 / 63 / 36 us instead of 24 at M' = 3000 (175 us
+    // of the step's critical path; profiles/r06_*_timeline_c4.txt).  K_ZX's assembly stays under the chain: the solve needs it.
+    // Measured (one box, alternating; profiles/r06_d_s_late.txt): C4 12.006 / 12.038 ms under the chain, 11.967 / 11.982 late as a filler,
+    // 11.948 / 11.925 late at full grid; C3 6.32 / 6.36 / 6.29; C2 (M' = 600: the chain's launches are short either way) unchanged within
+    // its run-to-run spread -- small problems keep the old place.
+    static const int s_late_env = getenv("DSVGP_S_LATE") ? atoi(getenv("DSVGP_S_LATE")) : -1;     // 0: under the chain (rounds 2-5); 1: late, filler; 2: late, full grid
+    const int s_late = !overlap ? 0 : s_late_env >= 0 ? s_late_env : (Mp >= STEP_S_LATE_MP ? STEP_S_LATE : 0);
+    auto prologue_s = [&](bool background) -> int {
+        // S = tril(L_S) tril(L_S)^T: lower triangle + mirror (n^3 / 6 multiply-adds)
+        int rc = dsvgp_gemm(ctx, 0, DSVGP_GEMM_A_LOWER | DSVGP_GEMM_TRANS_B | DSVGP_GEMM_B_UPPER | DSVGP_GEMM_OUT_LOWER |
+                            (background ? DSVGP_GEMM_BACKGROUND : 0), Mp, Mp, Mp, 1.0, io->LS, io->ldls, io->LS, io->ldls, 0.0, nullptr, 0,
+                            S32e, ldS, nullptr, 0, nullptr);
         if (rc) return rc;
         // mirror + [S - I | m / (2 vbar)] AND its fp64 copy, TRANSPOSED -- [S - I ; m^T / (2 vbar)], (M'+1) x M': S - I is symmetric, so its
         // rows are copied as they lie and only the extra column becomes a row -- the left operand of the Cholesky backward's first product
@@ -452,6 +460,15 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         if (rc) return rc;
         const hipError_t e = hipGetLastError();            // (one call: it clears the error it returns)
         return e == hipSuccess ? 0 : 1000 + (int)e;
+    };
+    auto prologue = [&](bool background) -> int {
+        int rc = 0;
+        if (timed && hipEventRecord(pl->tm[2], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
+        rc = zx_fwd(ctx, io, PZ, sZ, M, PX, sX, B, d, p, hyp, Kzx, Bp);
+        if (rc) return rc;
+        if (timed && hipEventRecord(pl->tm[3], ctx->stream) != hipSuccess) return 1000 + (int)hipGetLastError();
+        if (s_late) return 0;
+        return prologue_s(background);
     };
     // ---- the forward solve PIPELINED under the Cholesky chain (flag 128).  Row block i of A = L^-1 K_ZX needs rows i of L^-1 only,
     // and those are final as soon as the chain's launch i has run (potrf.hip writes row block k of the inverse in launch k);
@@ -532,6 +549,13 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
         STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, side));     // hyp[4] | info: contiguous
         STEP_HIP(hipEventRecord(pl->ev_status, side));
+        if (s_late) {           // [S - I | m'] beside the forward solve (see prologue_s above)
+            ctx->stream = side;
+            const int rc = prologue_s(s_late == 1);
+            ctx->stream = main;
+            if (rc) return rc;
+            STEP_HIP(hipEventRecord(pl->ev_s, side));
+        }
     } else {
         STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, main));
         STEP_HIP(hipEventRecord(pl->ev_status, main));
@@ -561,6 +585,7 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
                          Mp, nullptr, 0, nullptr));
     STEP_TIME(7);
+    if (s_late) STEP_HIP(hipStreamWaitEvent(main, pl->ev_s, 0));       // ([S - I | m'] is final: every later reader is behind this point)
     return 0;
 }
 
