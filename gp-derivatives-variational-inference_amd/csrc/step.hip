@@ -739,7 +739,8 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
 #ifndef STEP_ZX_SIDE_MAX
 #define STEP_ZX_SIDE_MAX 2          // K_ZX-bar's kernel backward goes to the side stream when B' <= STEP_ZX_SIDE_MAX * M'
 #endif
-    const bool zx_side = overlap && !tail_side && (int64_t)Bp <= (int64_t)STEP_ZX_SIDE_MAX * Mp;
+    static const int zx_side_max = getenv("DSVGP_ZX_SIDE_MAX") ? atoi(getenv("DSVGP_ZX_SIDE_MAX")) : STEP_ZX_SIDE_MAX;
+    const bool zx_side = overlap && !tail_side && (int64_t)Bp <= (int64_t)zx_side_max * Mp;
     // (round 6) the two kernel backwards leave their slabs (K_ZX-bar's in the second workspace, whichever stream it runs on) and ONE
     // kernel_bwd_points launch adds both, scales by 2 vbar and does the scalar tail: kernel_bwd_points x 2 + scale_epilogue before
     struct DeferGuard {
