@@ -2176,7 +2176,7 @@ inline void dispatch_bwd(hipStream_t st, dim3 grid, size_t lds, const GT* G, int
 // =================================================================================================
 constexpr int CAN_LDT = 52;            // row stride of the 48 x 48 output / upstream tile in LDS (even: 8-byte strips; 16-byte aligned rows)
 #ifndef CAN_FWD_WGS
-#define CAN_FWD_WGS (256 * 12)
+#define CAN_FWD_WGS (256 * 32)          // (probed with the result NOT in the memory-side cache: 12 / 24 / 32 / 48 / 64 per CU: 88 / 75 / 75 / 83 / 90 us at C4)
 #endif
 #ifndef CAN_BWD_WGS
 #define CAN_BWD_WGS (256 * 8)
@@ -2184,11 +2184,14 @@ constexpr int CAN_LDT = 52;            // row stride of the 48 x 48 output / ups
 #ifndef CAN_BWD_DMA
 #define CAN_BWD_DMA 1                  // 0: the backward kernel reads the upstream micro-blocks straight into registers (tools: the A/B)
 #endif
+#ifndef CAN_FWD_STRIDED
+#define CAN_FWD_STRIDED 1
+#endif
 #ifndef CAN_FWD_MINW
 #define CAN_FWD_MINW 2                 // waves per SIMD the forward kernel's registers are budgeted for
 #endif
 #ifndef CAN_ABL
-#define CAN_ABL 0                      // tools only (results wrong): 1 = no global stores (forward), 2 = no U product
+#define CAN_ABL 0                      // tools only (results wrong): 1 = no global stores (forward), 2 = no U product, 4 = whole cache lines only (2/3 of the bytes)
 #endif
 
 // what both kernels share: the A fragments of the wave's 48 side-1 rows (self terms folded as in the pair kernels: column K4 + 2 of P1' =
@@ -2257,8 +2260,15 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
     const int pch = DP / 4;                 // float4 per packed row
     const bool rows_full = row0 + T <= n1q;
 
+    // Column tiles of a workgroup: blockIdx.x, + gridDim.x, ... (CAN_FWD_STRIDED = 1: at any moment the workgroups of a row tile write
+    // ADJACENT 192-byte pieces of the same 48 rows -- whole cache lines and DRAM pages fill up together; in contiguous chunks per workgroup
+    // the pieces written at one time lie 2 KB apart, which costs nothing while the result is still in the memory-side cache from the launch
+    // before (what a probe that rewrites one buffer sees: 62 us) and a third of the rate when it is not (the step: 87 us) --
+    // profiles/r06_c_canon_assembly.txt)
     const int cper = (ncoltiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int ct_lo = blockIdx.x * cper, ct_hi = min(ct_lo + cper, ncoltiles);
+    const int ct_step = CAN_FWD_STRIDED ? (int)gridDim.x : 1;
+    const int ct_lo = CAN_FWD_STRIDED ? (int)blockIdx.x : (int)blockIdx.x * cper;
+    const int ct_hi = CAN_FWD_STRIDED ? ncoltiles : min(ct_lo + cper, ncoltiles);
     // the tile's R value rows of P2: float4 number e = lane (< R pch <= 128: two per lane at most) of [R][DP]
     f4 pf[2];
     float pnrm = 0.f;
@@ -2281,7 +2291,7 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
     // partial column tile, outputs that are not 16-byte aligned)
     auto sweep = [&](auto fullc, int lo, int hi) {
     constexpr bool FULL = decltype(fullc)::value;
-    for (int ct = lo; ct < hi; ++ct) {
+    for (int ct = lo; ct < hi; ct += ct_step) {
         const int j0 = ct * R, col0 = j0 * Q;
         WAVE_SYNC();                    // (single wave: the previous tile's LDS reads are behind us)
 #pragma unroll
@@ -2300,7 +2310,7 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
             Xs[lane * LDX + K4 + 2] = in ? 1.f : 0.f;
             Xs[lane * LDX + K4 + 3] = in ? pnrm : 0.f;
         }
-        prefetch(min(ct + 1, ncoltiles - 1));       // (unconditional: one harmless reload at the end of the range)
+        prefetch(min(ct + ct_step, ncoltiles - 1)); // (unconditional: one harmless reload at the end of the range)
         WAVE_SYNC();
         // U = P1' X2'^T: 3 row tiles x (one 16-column tile of which R columns are points), K = K4 + 4
         f4 t[3];
@@ -2384,6 +2394,7 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
             for (int u = 0; u < 9; ++u) {   // the tile leaves as nine fully coalesced 16-byte store instructions (rows of 192 bytes)
                 const int id = lane + 64 * u, r = id / 12, c4 = (id - 12 * r) * 4;
                 const f4 x = *reinterpret_cast<const f4*>(TT + r * CAN_LDT + c4);
+                if ((CAN_ABL & 4) && ((ct & 1) ? c4 < 16 : c4 >= 32)) continue;   // (tools: only the whole 128-byte line of each row piece)
                 if (!(CAN_ABL & 1)) *reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4) = x;
             }
         } else {
@@ -2399,9 +2410,10 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
         }
     }
     };
-    const int nfull = (rows_full && (ovec & 2)) ? min(ct_hi, n2q / T) : ct_lo;    // tiles [ct_lo, nfull) are whole
+    const int nfull = (rows_full && (ovec & 2)) ? min(ct_hi, n2q / T) : ct_lo;    // this workgroup's tiles below nfull are whole
     sweep(std::true_type{}, ct_lo, nfull);
-    sweep(std::false_type{}, max(nfull, ct_lo), ct_hi);
+    const int g0 = nfull > ct_lo ? ct_lo + (nfull - ct_lo + ct_step - 1) / ct_step * ct_step : ct_lo;     // its first tile that is not
+    sweep(std::false_type{}, g0, ct_hi);
 }
 
 // LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4), as gemm32.hip's: an asm statement, so that WE count it (s_waitcnt vmcnt) and the

@@ -19,8 +19,16 @@ for geom in os.environ.get("CANON_GEOM", "500,4096,20,5;200,512,5,2;500,512,20,5
     center = ops.column_mean(ctx, Z)
     pz, px = ops.pack_points(ctx, Z, V, p, hyp, center), ops.pack_points(ctx, X, D, p, hyp, center)
     di = (torch.tensor(idx, dtype=torch.int32) + 1).to(dev)
-    out = torch.empty(M * q, B * q, device=dev)
-    G = torch.randn(M * q, B * q, device=dev, generator=g)
+    # CANON_ROT output / upstream buffers used in turn (default 5: 1.5 GB at C4, well past the 256 MB memory-side cache -- every launch then
+    # writes / reads memory that is not cached from the launch before, as in the step; CANON_ROT=1: the same buffer again and again)
+    ROT = int(os.environ.get("CANON_ROT", "5"))
+    outs = [torch.empty(M * q, B * q, device=dev) for _ in range(ROT)]
+    Gs = [torch.randn(M * q, B * q, device=dev, generator=g) for _ in range(ROT)]
+    out, G = outs[0], Gs[0]
+    turn = [0]
+    def nxt(lst):
+        turn[0] += 1
+        return lst[turn[0] % ROT]
     nbytes = out.numel() * 4 + (M + B) * d * q * 4
 
     def timeit(fn, n=10):
@@ -35,15 +43,17 @@ for geom in os.environ.get("CANON_GEOM", "500,4096,20,5;200,512,5,2;500,512,20,5
 
     dx, dv, dh = torch.zeros(M, d, device=dev), torch.zeros(M * p, d, device=dev), torch.zeros(4, device=dev)
     ws = torch.empty(int(dsvgp_amd._lib.lib.dsvgp_kernel_bwd_workspace_bytes(M, B, d, p)), dtype=torch.uint8, device=dev)
-    t_fg = timeit(lambda: ops.kernel_fwd(ctx, pz, M, px, B, d, p, hyp, out=out))
+    t_fg = timeit(lambda: ops.kernel_fwd(ctx, pz, M, px, B, d, p, hyp, out=nxt(outs)))
+    ops.kernel_fwd(ctx, pz, M, px, B, d, p, hyp, out=out)
     Kg = out.clone()
-    t_fc = timeit(lambda: ops.kernel_fwd_canon(ctx, pz, M, px, B, d, p, di, 1, hyp, out=out))
+    t_fc = timeit(lambda: ops.kernel_fwd_canon(ctx, pz, M, px, B, d, p, di, 1, hyp, out=nxt(outs)))
+    ops.kernel_fwd_canon(ctx, pz, M, px, B, d, p, di, 1, hyp, out=out)
     err = ((out - Kg).abs().max() / Kg.abs().max()).item()
-    t_bg = timeit(lambda: ops.kernel_bwd(ctx, G, pz, M, px, B, d, p, hyp, False, dx, dv, dh, ws))
-    t_bc = timeit(lambda: ops.kernel_bwd_canon(ctx, G, pz, M, px, B, d, p, di, 1, hyp, dx, dv, dh, ws))
+    t_bg = timeit(lambda: ops.kernel_bwd(ctx, nxt(Gs), pz, M, px, B, d, p, hyp, False, dx, dv, dh, ws))
+    t_bc = timeit(lambda: ops.kernel_bwd_canon(ctx, nxt(Gs), pz, M, px, B, d, p, di, 1, hyp, dx, dv, dh, ws))
     tb = lambda ms: nbytes / ms / 1e9
     if os.environ.get("CANON_FILL", "1") == "1":       # what streaming writes of the same buffer cost on this box (the forward's floor)
-        t_z = timeit(lambda: out.zero_()); t_c = timeit(lambda: out.copy_(G))
+        t_z = timeit(lambda: nxt(outs).zero_()); t_c = timeit(lambda: nxt(outs).copy_(nxt(Gs)))
         print("  fill of the %d x %d result: %.1f us (%.2f TB/s written)   copy: %.1f us (%.2f TB/s read + written)"
               % (M * q, B * q, t_z * 1e3, out.numel() * 4 / t_z / 1e9, t_c * 1e3, out.numel() * 8 / t_c / 1e9))
     print("M=%d B=%d d=%d p=%d (%.1f MB): fwd general %.1f us (%.2f TB/s = %.2f of 8)  canonical %.1f us (%.2f TB/s = %.2f)  |diff| %.1e ;  "
