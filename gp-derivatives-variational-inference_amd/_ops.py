@@ -233,7 +233,7 @@ def state_directions(D, idx, base=0):
     for every j (what the reference's training step and evaluation build: directional_vi.py:81-88, 238, 292-294).  ``idx``: int32
     tensor [p] on D's device.  The statement travels with the tensor (``model(x, derivative_directions=D)`` is unchanged); the step
     then assembles K_ZX and its backward on the canonical-direction kernels where they take the geometry.  Returns D."""
-    if D is not None and idx is not None:
+    if D is not None and idx is not None and not _NO_CANON:
         D._dsvgp_dir_idx = (idx, int(base))
     return D
 
