@@ -150,6 +150,7 @@ SIGNATURES = {
     "dsvgp_gather_batch": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
     "dsvgp_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _i]),
     "dsvgp_adam_step_multi": (_i, [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i]),
+    "dsvgp_adam_step_multi_guarded": (_i, [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _p]),
     "dsvgp_adam_step_multi_f64": (_i, [_p, _i, _p, _p, _p, _p, _p, _d, _d, _d, _d, _i]),
 }
 

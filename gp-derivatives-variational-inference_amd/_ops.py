@@ -130,8 +130,8 @@ class StepPlan:
         off, rows, cols, ld = C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int64(0)
         check(lib.dsvgp_elbo_step_locate(self.h, int(which), C.byref(off), C.byref(rows), C.byref(cols), C.byref(ld)),
               "dsvgp_elbo_step_locate")
-        dt = f32 if which in (0, 1, 4) else torch.float64
-        esz = 4 if dt == f32 else 8
+        dt = torch.int32 if which == 5 else f32 if which in (0, 1, 4) else torch.float64
+        esz = 4 if dt in (f32, torch.int32) else 8
         flat = workspace[off.value:off.value + rows.value * ld.value * esz].view(dt)
         return flat.view(rows.value, ld.value)[:, :cols.value]
 
@@ -778,7 +778,7 @@ def gather_batch(ctx, X, Y, idx, cols, p, xb, yb, E=None, Db=None):
 ADAM_MAX_TENSORS = 16
 
 
-def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step, tril=None):
+def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step, tril=None, guard=None):
     """torch.optim.Adam update of several tensors that share (lr, betas, eps, step) in one launch.  ``tril[k]`` true: params[k] is a square
     matrix of which only the lower triangle is a parameter (its gradient and moments are zero above the diagonal): the strict upper
     triangle is left alone (float32 only)."""
@@ -796,6 +796,12 @@ def adam_step_multi_(ctx, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2
     if tril is not None and dt == f32:
         sz = [-t.shape[0] if (tr and t.dim() == 2 and t.shape[0] == t.shape[1] and t.shape[0] > 1) else k for t, k, tr in zip(params, sz, tril)]
     sizes = (ctypes.c_int64 * n)(*sz)
+    if guard is not None:       # (``guard``: int32 device tensor, the update is skipped on the device while guard[0] != 0; float32 only)
+        if dt != f32 or guard.dtype != torch.int32 or not guard.is_cuda:
+            raise ValueError("adam: a guarded update takes float32 tensors and an int32 GPU guard word")
+        check(lib.dsvgp_adam_step_multi_guarded(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, float(lr), float(beta1),
+                                                float(beta2), float(eps), int(step), _ptr(guard)), "dsvgp_adam_step_multi_guarded")
+        return
     fn, name = (lib.dsvgp_adam_step_multi_f64, "dsvgp_adam_step_multi_f64") if dt == f64 else (lib.dsvgp_adam_step_multi, "dsvgp_adam_step_multi")
     check(fn(ctx.h, n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, float(lr), float(beta1), float(beta2),
              float(eps), int(step)), name)

@@ -161,6 +161,11 @@ class ElboEngine:
         # piecewise path below.  DSVGP_C_STEP=0 switches it off (A/B runs).
         self.c_step = os.environ.get("DSVGP_C_STEP", "1") == "1"
         self._plans = {}
+        # deferred status (round 6, TrainLoop._eager_step): the one-call step returns WITHOUT waiting for the factorisation's status; the caller
+        # queues its parameter update guarded on the device by the status word (deferred_guard) and reads the status before the next step
+        # (deferred_check): the ~100 us the host waited per step at M' = 600 leave its critical path
+        self.defer_status = False
+        self._deferred = None                   # (plan, workspace) of a step whose status has not been read yet
         self._zx_dirs = None                    # (idx, base) of the batch in flight when its directions were stated one-hot (_ops.state_directions)
         self.c_step_used = False        # whether the last step ran through the one-call path
         self.c_step_timed = []          # plans of the steps queued with record_events on, in order
@@ -1157,12 +1162,17 @@ class ElboEngine:
         timed_idx = plan.timed_count() - 1 if timed else None
         if tr is not None:
             t1 = _t.perf_counter()
-        info, hyp = plan.status()            # waits for the factorisation only; the rest of the step stays queued
-        if tr is not None:
-            tr.append((t0, t1, _t.perf_counter()))
-        self._hyp_host = hyp[:3]
-        if info != 0:
-            raise _Refactored()
+        if self.defer_status and world == 1 and not timed:
+            self._deferred = (plan, ws)          # (status unread: deferred_check / deferred_guard)
+            if tr is not None:
+                tr.append((t0, t1, t1))
+        else:
+            info, hyp = plan.status()            # waits for the factorisation only; the rest of the step stays queued
+            if tr is not None:
+                tr.append((t0, t1, _t.perf_counter()))
+            self._hyp_host = hyp[:3]
+            if info != 0:
+                raise _Refactored()
         if timed:
             self.c_step_timed.append((plan, timed_idx))  # bench.py reads the plan's HIP events after its timed region (a step whose
                                                          # factorisation failed is not listed: its events time garbage)
@@ -1173,6 +1183,23 @@ class ElboEngine:
             return loss_out[0], grads, mu, varn
         self._last_fast = ("plan", plan, ws, p)
         return loss_out[0], grads, mu, torch.empty(0, dtype=f32, device=self.device)
+
+    def deferred_guard(self):
+        """int32 device tensor [1]: the status word of the deferred step (0 = the factorisation went through); None when nothing is deferred"""
+        if self._deferred is None:
+            return None
+        plan, ws = self._deferred
+        return plan.locate(ws, 5).reshape(-1)
+
+    def deferred_check(self):
+        """reads the status of the deferred step (waits for its factorisation only); returns the status word, 0 when nothing was deferred"""
+        if self._deferred is None:
+            return 0
+        plan, _ = self._deferred
+        self._deferred = None
+        info, hyp = plan.status()
+        self._hyp_host = hyp[:3]
+        return info
 
     def _c_step_dp_phases(self, ctx, plan, ws, flags, coll, Mp):
         """one data-parallel rank: the five pieces of dsvgp_elbo_step_dp_f32 with this rank's collectives between them

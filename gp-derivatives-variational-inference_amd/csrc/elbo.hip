@@ -285,7 +285,8 @@ struct AdamTable {
     int count;
 };
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, float lr, float b1, float b2, float eps,
-                                                         float bc1, float bc2_sqrt) {
+                                                         float bc1, float bc2_sqrt, const int* __restrict__ guard) {
+    if (guard && *guard != 0) return;       // (the Cholesky status word of the step whose gradients these are: a failed factorisation must not touch the parameters)
     int k = 0;
     while (k + 1 < t.count && (int)blockIdx.x >= t.first[k + 1]) ++k;
     const int nb = t.first[k + 1] - t.first[k];
@@ -938,9 +939,24 @@ extern "C" int dsvgp_adam_step_multi_f64(dsvgp_ctx* ctx, int count, double* cons
     return 0;
 }
 
+static int adam_step_multi_impl(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                float* const* exp_avg_sqs, const int64_t* sizes, float lr, float beta1, float beta2, float eps, int step,
+                                const int* guard_dev);
 extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
                                      float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
                                      float beta1, float beta2, float eps, int step) {
+    return adam_step_multi_impl(ctx, count, params, grads, exp_avgs, exp_avg_sqs, sizes, lr, beta1, beta2, eps, step, nullptr);
+}
+// the same update skipped ON THE DEVICE while *guard_dev != 0 (round 6): guard_dev = the status word of the one-call step that produced the
+// gradients (dsvgp_elbo_step_locate which = 5) -- the host then need not wait for that status before it queues the update
+extern "C" int dsvgp_adam_step_multi_guarded(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
+                                             float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
+                                             float beta1, float beta2, float eps, int step, const int* guard_dev) {
+    return adam_step_multi_impl(ctx, count, params, grads, exp_avgs, exp_avg_sqs, sizes, lr, beta1, beta2, eps, step, guard_dev);
+}
+static int adam_step_multi_impl(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                float* const* exp_avg_sqs, const int64_t* sizes, float lr, float beta1, float beta2, float eps, int step,
+                                const int* guard_dev) {
     if (!ctx || count < 0 || count > DSVGP_ADAM_MAX_TENSORS || step < 1) return DSVGP_EINVAL;
     if (count && (!params || !grads || !exp_avgs || !exp_avg_sqs || !sizes)) return DSVGP_EINVAL;
     AdamTable t{};
@@ -960,7 +976,7 @@ extern "C" int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* pa
     t.first[t.count] = nblocks;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, t, lr, beta1, beta2, eps, (float)bc1,
-                       (float)sqrt(bc2));
+                       (float)sqrt(bc2), guard_dev);
     DSVGP_LAUNCH_CHECK();
     return 0;
 }

@@ -268,6 +268,7 @@ extern "C" int dsvgp_elbo_step_locate(const dsvgp_step_plan* pl, int which, size
         case 2: *offset_bytes = pl->o_L; *rows = pl->Mp; *cols = pl->Mp; *ld = pl->Mp; return 0;
         case 3: *offset_bytes = pl->o_trsm; *rows = pl->Mp; *cols = pl->Mp; *ld = pl->Mp; return 0;
         case 4: *offset_bytes = pl->o_hyp; *rows = 1; *cols = 4; *ld = 4; return 0;
+        case 5: *offset_bytes = pl->o_info; *rows = 1; *cols = 1; *ld = 1; return 0;     // the factorisation's status word (int32; 0 = positive definite)
         default: return DSVGP_EINVAL;
     }
 }

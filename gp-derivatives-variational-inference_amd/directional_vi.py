@@ -144,6 +144,8 @@ class TrainLoop:
         self.E_canonical = torch.eye(self.dim, device=self.device, dtype=X.dtype)
         self.graph = None                       # HIP-graph replay of the step: True = on (also DSVGP_GRAPH=1), None / False = eager
         self._graphs, self._graph_seen, self._graph_pending = {}, {}, None
+        self._deferred_pending = None       # (idx, idx_y, learning rates) of an eager step whose factorisation status has not been read yet
+        self.defer_status = None            # None: DSVGP_DEFER_STATUS (default off); True / False
 
     def epoch_permutation(self):
         return torch.randperm(self.X.shape[0], device=self.device, generator=self.perm_gen)   # DataLoader(shuffle=True)
@@ -176,13 +178,65 @@ class TrainLoop:
         else:
             idx_y = list(range(dim + 1)) if self.full_gradient else sorted(self.col_rng.sample(range(1, dim + 1), p) + [0])
         if self._graph_eligible(need_variance):
+            self._deferred_check_previous()
             return self._graph_step(idx, idx_y)
         if self._graph_pending is not None:
             self._graph_check_previous()
-        return self._eager_step(idx, idx_y)
+        self._deferred_check_previous()
+        return self._eager_step(idx, idx_y, defer=self._defer_eligible(need_variance))
 
-    def _eager_step(self, idx, idx_y):
+    # ---- deferred status of the one-call step (round 6) -------------------------------------------------------------------------------
+    # The eager loop waited ~100 us per step at M' = 600 for the factorisation's status before it queued the optimizers' update.  Now the
+    # update is queued at once, guarded ON THE DEVICE by the status word (optim.step_together(guard=)), and the status of step t is read before
+    # step t + 1 is queued -- by then it has long arrived.  A failed factorisation (parameters untouched) is redone eagerly through
+    # psd_safe_cholesky's jitter ladder, exactly as the graph replay does it (_graph_check_previous).  OPT-IN (``loop.defer_status = True`` /
+    # DSVGP_DEFER_STATUS=1): measured at C2 / C3 / C4 on one box, alternating, the step time does not move (0.505-0.528 against 0.505-0.511 /
+    # 6.28-6.30 / 11.96-12.01 against 11.95-11.98 ms: the device, not the host, bounds those steps) -- it takes the host's jitter out of the
+    # small-problem step, nothing more.
+    def _defer_eligible(self, need_variance):
+        mode = getattr(self, "defer_status", None)
+        if mode is None:
+            mode = os.environ.get("DSVGP_DEFER_STATUS", "0") == "1"
+        if not mode or need_variance or self.dp is not None or self.autograd_protocol:
+            return False
+        eng = self.model.engine
+        return (eng.whitening == "cholesky" and not eng.shared_directions and self.mll.mll_type == "ELBO" and eng.collective is None
+                and getattr(eng, "c_step", True) and not getattr(eng, "deterministic", False) and not getattr(eng, "host_trace", None)
+                and _optim.can_step_together([self.variational_optimizer, self.hyperparameter_optimizer])
+                and self.X.dtype == torch.float32)
+
+    def _deferred_check_previous(self):
+        pend, self._deferred_pending = getattr(self, "_deferred_pending", None), None
+        if pend is None:
+            return
+        if self.model.engine.deferred_check() == 0:
+            return
+        # K_ZZ + 1e-3 I was not positive definite in fp64: the guarded update did nothing; redo the step with the learning rates and step
+        # counts it was issued with (jitter ladder of psd_safe_cholesky, NotPSDError after three tries)
+        idx, idx_y, lrs_then = pend
+        opts = (self.variational_optimizer, self.hyperparameter_optimizer)
+        lrs_now = [[g["lr"] for g in o.param_groups] for o in opts]
+        for o, ls in zip(opts, lrs_then):
+            for g, lr in zip(o.param_groups, ls):
+                g["lr"] = lr
+                for prm in g["params"]:
+                    if o.state.get(prm):
+                        o.state[prm]["step"] -= 1
+        try:
+            cols = torch.tensor(idx_y, dtype=torch.int32, device=self.device)
+            self._device_step(idx.contiguous(), cols, len(idx_y) - 1)
+            if not _optim.step_together(list(opts)):
+                for o in opts:
+                    o.step()
+        finally:
+            for o, ls in zip(opts, lrs_now):
+                for g, lr in zip(o.param_groups, ls):
+                    g["lr"] = lr
+
+    def _eager_step(self, idx, idx_y, defer=False):
         dp = self.dp
+        eng = self.model.engine
+        eng.defer_status = bool(defer)
         # host -> device without a stream sync: pinned staging ring + non_blocking copy (a pageable torch.tensor(...,
         # device=) blocks the host until the stream has drained, i.e. until the previous step has finished)
         slot = self._cols_slot = (getattr(self, "_cols_slot", -1) + 1) % 8
@@ -194,7 +248,16 @@ class TrainLoop:
         output._value_stride = len(idx_y)
         if self._values_only and getattr(self.model.engine, "_last_fast", None) is not None:
             output._value_varn = self.model.engine.value_variances(self.model._param_dict(self.likelihood))
-        if _optim.step_together([self.variational_optimizer, self.hyperparameter_optimizer]):      # both Adam: one multi-tensor launch
+        eng.defer_status = False
+        guard = eng.deferred_guard() if defer else None          # (None: the step took a path that read its status itself)
+        if guard is not None:
+            lrs = [[g["lr"] for g in o.param_groups] for o in (self.variational_optimizer, self.hyperparameter_optimizer)]
+            ok = _optim.step_together([self.variational_optimizer, self.hyperparameter_optimizer], guard=guard)
+            assert ok                                            # (_defer_eligible: both are FusedAdam; hooks would have made it False)
+            self._deferred_pending = (idx, list(idx_y), lrs)
+            self.variational_scheduler.step()
+            self.hyperparameter_scheduler.step()
+        elif _optim.step_together([self.variational_optimizer, self.hyperparameter_optimizer]):      # both Adam: one multi-tensor launch
             self.variational_scheduler.step()
             self.hyperparameter_scheduler.step()
         else:
@@ -380,8 +443,9 @@ class TrainLoop:
                     g["lr"] = lr
 
     def finish(self):
-        """drain the replay pipeline (the status of the last replayed step is checked here)"""
+        """drain the replay pipeline (the status of the last replayed / deferred step is checked here)"""
         self._graph_check_previous()
+        self._deferred_check_previous()
 
 
 def setup_training(train_dataset, num_inducing=128, num_directions=1, minibatch_size=1, minibatch_dim=1,

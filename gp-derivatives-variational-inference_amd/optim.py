@@ -110,25 +110,34 @@ class FusedAdam(torch.optim.Optimizer):
                 batch.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"], bool(getattr(p, "_dsvgp_tril", False))))
 
 
-def _launch_batches(batch):
+def _launch_batches(batch, guard=None):
     for (step, dev, lr, b1, b2, eps, dt), items in batch.items():
         ctx = _ops.Context.get(dev)
         for i in range(0, len(items), _ops.ADAM_MAX_TENSORS):
             ps, gs, ms, vs, tr = zip(*items[i:i + _ops.ADAM_MAX_TENSORS])
-            if len(ps) == 1 and dt == torch.float32 and not tr[0]:
+            if len(ps) == 1 and dt == torch.float32 and not tr[0] and guard is None:
                 _ops.adam_step_(ctx, ps[0], gs[0], ms[0], vs[0], lr, b1, b2, eps, step)
             else:
-                # (float32 or float64 tensors; a lower-triangular parameter -- chol_variational_covar -- is walked below its diagonal only)
-                _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step, tril=tr)
+                # (float32 or float64 tensors; a lower-triangular parameter -- chol_variational_covar -- is walked below its diagonal only;
+                #  ``guard``: the update is skipped on the device while guard[0] != 0)
+                _ops.adam_step_multi_(ctx, ps, gs, ms, vs, lr, b1, b2, eps, step, tril=tr, guard=guard)
+
+
+def can_step_together(optimizers):
+    """whether step_together would take these optimizers (all FusedAdam, no step hooks registered)"""
+    return bool(optimizers) and all(isinstance(o, FusedAdam) for o in optimizers) and not any(
+        getattr(o, "_optimizer_step_pre_hooks", None) or getattr(o, "_optimizer_step_post_hooks", None) for o in optimizers)
 
 
 @torch.no_grad()
-def step_together(optimizers):
+def step_together(optimizers, guard=None):
     """``opt.step()`` of several FusedAdam instances as ONE set of launches: the reference steps two ``torch.optim.Adam`` per iteration
     (variational parameters, then hyper-parameters: directional_vi.py:251-254) whose settings and step counts coincide, so their
     tensors share a multi-tensor launch (one ~4 us launch fewer per step: visible at BASELINE config 2).  The two updates touch
     disjoint parameters and each reads its own learning rate, so the order against the schedulers' steps does not matter.
-    Returns False (and does nothing) unless every optimizer is a FusedAdam without registered step hooks."""
+    Returns False (and does nothing) unless every optimizer is a FusedAdam without registered step hooks.
+    ``guard`` (int32 device tensor; round 6): the launches are skipped ON THE DEVICE while guard[0] != 0 -- the status word of the step that
+    made the gradients, for a loop that does not wait for that status before it queues the update (TrainLoop's deferred check)."""
     if not optimizers or not all(isinstance(o, FusedAdam) for o in optimizers):
         return False
     # Optimizer.step() is bypassed here: an optimizer that carries step hooks (``register_step_pre_hook`` / ``_post_hook``) keeps the
@@ -140,7 +149,9 @@ def step_together(optimizers):
         o._collect(batch)
         o._opt_called = True             # (what the LR schedulers' step-order check looks at ...
         o._step_count = getattr(o, "_step_count", 0) + 1      # ... and the wrapped step counter older schedulers read)
-    _launch_batches(batch)
+    if guard is not None and any(k[6] != torch.float32 for k in batch):
+        raise ValueError("a guarded update takes float32 parameters")
+    _launch_batches(batch, guard)
     return True
 
 

@@ -327,6 +327,12 @@ int dsvgp_adam_step_multi(dsvgp_ctx* ctx, int count, float* const* params, const
                           float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
                           float beta1, float beta2, float eps, int step);
 /* the same update for the float64 model mode (parameters, gradients and moments in double) */
+/* dsvgp_adam_step_multi skipped ON THE DEVICE while *guard_dev != 0 (round 6): guard_dev = the status word of the one-call step that made the
+ * gradients (dsvgp_elbo_step_locate, which = 5): a host that queues the update without waiting for the factorisation's status leaves the
+ * parameters untouched when it failed, reads the status later (dsvgp_elbo_step_status) and repeats the step through the jitter ladder. */
+int dsvgp_adam_step_multi_guarded(dsvgp_ctx* ctx, int count, float* const* params, const float* const* grads,
+                                  float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* sizes, float lr,
+                                  float beta1, float beta2, float eps, int step, const int* guard_dev);
 int dsvgp_adam_step_multi_f64(dsvgp_ctx* ctx, int count, double* const* params, const double* const* grads,
                               double* const* exp_avgs, double* const* exp_avg_sqs, const int64_t* sizes, double lr,
                               double beta1, double beta2, double eps, int step);
@@ -503,7 +509,8 @@ int dsvgp_elbo_step_po_f32(dsvgp_ctx* ctx, dsvgp_step_plan* plan, const dsvgp_el
                            size_t workspace_bytes, int flags);
 /* Where an intermediate of the step queued last lies inside the caller's workspace (valid until the next step on it): which = 0:
  * [A ; mu_bar^T], A = L^-1 K_ZX (float [M'+1, B']); 1: K_ZX (float [M', B']); 2: the Cholesky factor L (double [M', M'], lower);
- * 3: L^-1 (double [M', M'], lower); 4: the constrained {lengthscale, outputscale, noise, 0} (float [1, 4]).  The reference's every-50th-step nll print (directional_vi.py:255-260) reads the predictive
+ * 3: L^-1 (double [M', M'], lower); 4: the constrained {lengthscale, outputscale, noise, 0} (float [1, 4]); 5: the factorisation's status word
+ * (int32 [1], 0 = positive definite; valid from the step's factorisation until the next step on the workspace clears it).  The reference's every-50th-step nll print (directional_vi.py:255-260) reads the predictive
  * variance of the function-value rows of the forward pass it has just differentiated: W = L_S^T A[:, ::p+1] is all it takes.  */
 int dsvgp_elbo_step_locate(const dsvgp_step_plan* plan, int which, size_t* offset_bytes, int* rows, int* cols, int64_t* ld);
 /* ---- one RANK of a data-parallel job (the reference is single-process): the same step in five pieces with

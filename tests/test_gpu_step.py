@@ -758,6 +758,79 @@ def test_graph_replay_failed_factorisation_leaves_parameters_untouched(dsvgp, gp
             assert torch.equal(before[k], after[k]), k
 
 
+@pytest.mark.parametrize("lr_sched", [None, "step_lr"])
+def test_deferred_status_loop_matches_the_waiting_loop(dsvgp, gpu_device, lr_sched):
+    """the eager loop with the factorisation's status read one step late (the optimizers' update queued at once, guarded on the device by the
+    status word: TrainLoop._eager_step, optim.step_together(guard=)) against the loop that waits for the status before the update: same losses,
+    parameters, optimizer state and learning rates, as between graph replay and eager steps"""
+    out = {}
+    for defer in (False, True):
+        loop = _graph_loop(dsvgp, gpu_device, False, lr_sched, M=40)
+        loop.defer_status = defer
+        losses, deferred = [], 0
+        for epoch in range(3):
+            perm = loop.epoch_permutation()
+            for k in range(7):
+                loss, _, _ = loop.step(perm[k * 128:(k + 1) * 128])
+                deferred += loop._deferred_pending is not None
+                losses.append(loss.item())
+        loop.finish()
+        assert loop._deferred_pending is None and loop.model.engine._deferred is None
+        assert deferred == (21 if defer else 0) and loop.model.engine.c_step_used
+        P = {k: v.detach().clone() for k, v in loop.model._param_dict(loop.likelihood).items()}
+        steps = [loop.variational_optimizer.state[q]["step"] for q in loop.variational_optimizer.param_groups[0]["params"]]
+        out[defer] = (losses, P, steps, [g["lr"] for g in loop.hyperparameter_optimizer.param_groups])
+    (le, Pe, se, lre), (lg, Pg, sg, lrg) = out[False], out[True]
+    assert se == sg == [21, 21] and lre == lrg
+    for a, b in zip(le, lg):
+        assert abs(a - b) < 2e-5 * abs(a), (a, b)
+    for k in Pe:
+        assert (Pe[k] - Pg[k]).abs().max().item() < 2e-3 * max(Pe[k].abs().max().item(), 1e-2), k
+
+
+def test_deferred_status_failed_factorisation_leaves_parameters_untouched(dsvgp, gpu_device):
+    """a deferred step whose K_ZZ is not positive definite: the guarded update does nothing, the status is read before the next step (here:
+    finish()), the step is redone through the jitter ladder and raises NotPSDError like the reference's psd_safe_cholesky -- parameters and
+    step counts as before the step"""
+    loop = _graph_loop(dsvgp, gpu_device, False, M=40)
+    loop.defer_status = True
+    perm = loop.epoch_permutation()
+    for k in range(4):
+        loop.step(perm[k * 128:(k + 1) * 128])
+    loop.finish()
+    before = {k: v.detach().clone() for k, v in loop.model._param_dict(loop.likelihood).items()}
+    with torch.no_grad():
+        loop.model.covar_module.raw_outputscale.fill_(float("nan"))
+    loop.step(perm[4 * 128:5 * 128])                          # every gradient is NaN; the guard holds the update back
+    assert loop._deferred_pending is not None
+    with pytest.raises(dsvgp.NotPSDError):
+        loop.finish()
+    after = loop.model._param_dict(loop.likelihood)
+    for k in before:
+        if k != "raw_outputscale":
+            assert torch.equal(before[k], after[k]), k
+
+
+def test_guarded_adam_launch_is_held_back_by_a_non_zero_guard_word(dsvgp, gpu_device):
+    dev = gpu_device
+    w0 = torch.randn(300, 7)
+    pa, pb = [torch.nn.Parameter(w0.clone().to(dev)), torch.nn.Parameter(torch.randn(5).to(dev))], None
+    oa = dsvgp.FusedAdam(pa, lr=0.05)
+    for q in pa:
+        q.grad = torch.randn_like(q)
+    guard = torch.ones(1, dtype=torch.int32, device=dev)
+    assert dsvgp.optim.step_together([oa], guard=guard)
+    assert torch.equal(pa[0].detach().cpu(), w0)             # held back
+    guard.zero_()
+    for q in pa:
+        oa.state[q]["step"] -= 1
+    assert dsvgp.optim.step_together([oa], guard=guard)
+    ref = torch.optim.Adam([w0.clone().requires_grad_(True)], lr=0.05)
+    ref.param_groups[0]["params"][0].grad = pa[0].grad.cpu()
+    ref.step()
+    assert relmax(pa[0].detach(), ref.param_groups[0]["params"][0].detach()) < 2e-6
+
+
 def test_legacy_unwhitened_checkpoint_is_converted_on_first_call(dsvgp, gpu_device):
     """reference DGVS.py:210-240: a checkpoint whose q(u) = N(m_u, L_u L_u^T) is NOT whitened (no ``updated_strategy`` key) is
     re-parameterised on the first call, m_w = L^-1 (m_u - c), L_w = chol(L^-1 S_u L^-T) with L = chol(K_ZZ + 1e-3 I); afterwards
