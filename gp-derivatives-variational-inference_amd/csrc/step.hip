@@ -54,6 +54,8 @@ struct dsvgp_step_plan {
     size_t o_info, o_sums, o_klbuf, o_scal, o_hyp, o_center;
     size_t o_PZ, o_sZ, o_vZ, o_PX, o_sX, o_vX;
     size_t o_phi32 = 0; bool phi32_own = false;
+    bool precleared_ge = false;
+    bool precleared = false;                  // this step's targets of the main stream's split-K / OUT_LOWER products were cleared on the side stream (step_front)
     size_t o_L, o_trsm, o_potrf, o_Kzx, o_A32e, o_S32e, o_var0, o_stats, o_Ge, o_Qe64, o_S64e, o_Qe32, o_Kb32, o_G1, o_Yt, o_Kbar, o_kbwd, o_kbwd2;
     size_t o_arena, arena_bytes;     // contiguous region of everything a launcher would clear (see step_layout)
     int ldS, ldQ32;
@@ -109,8 +111,9 @@ static size_t step_layout(int M, int d, int p, int B, dsvgp_step_plan* pl, int w
     // small problems: the fp32 argument of Phi (tril([S - I | m'] [G ; b^T]), a split-K / OUT_LOWER target) gets its own place INSIDE the arena
     // -- cleared by the step's one memset -- instead of the [Q' | a] scratch, which would need a clearing launch between the dense product
     // that reads it and this product (round 6: 5 us of the M' = 600 step)
-    pl->phi32_own = (size_t)Mp * pl->ldQ32 * 4 <= ((size_t)8 << 20);
-    pl->o_phi32 = pl->phi32_own ? c.take((size_t)Mp * pl->ldQ32 * 4) : 0;
+    // (round 6, second half: at every size -- large problems clear it on the side stream under the chain, `preclear` below)
+    pl->phi32_own = true;
+    pl->o_phi32 = c.take((size_t)Mp * pl->ldQ32 * 4);
     // head: hyp[4] | info[4 ints] | sums[4] | kl_buf[2 M' + 1]   (cleared every step; hyp + info go to the host in ONE copy).
     // It closes the arena, so that the small-problem mode clears both with one memset.
     pl->o_zero = c.off;
@@ -407,7 +410,17 @@ static int step_validate(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_s
 
 // Everything up to and including the Gram product [tril(G) ; b^T] = tril([A ; mu_bar^T] A^T) of this rank's rows (shared by the
 // one-GPU step and by phase 0 of a data-parallel rank)
-static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace, int flags) {
+struct ZeroedScope {                          // ctx->prezeroed = true around a call whose target the step has cleared already
+    dsvgp_ctx* c; bool prev;
+    ZeroedScope(dsvgp_ctx* c_, bool on) : c(c_), prev(c_->prezeroed) { if (on) c->prezeroed = true; }
+    ~ZeroedScope() { c->prezeroed = prev; }
+};
+// preclear (the one-GPU step): problems too large for the one-memset mode clear the four split-K / OUT_LOWER targets of the MAIN stream's later
+// products -- [tril(G) ; b^T], the Phi argument, the two products of the Cholesky backward: 216 MB at M' = 3000 -- on the SIDE stream at
+// the start of the step, ahead of K_ZX's assembly: the main stream's wait for that assembly (in front of the forward solve) orders them, no
+// new join, and the launchers of those products are told so (ZeroedScope).  Before, four fill launches sat on the main stream between those
+// products: 23 + 8 + 40 + 12 us and their launch gaps at M' = 3000 (profiles/r06_f_preclear.txt).
+static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step_io* io, void* workspace, int flags, bool preclear = false) {
     STEP_LOCALS
     const bool overlap = (flags & 1) && !ctx->det_slab;           // (deterministic mode: the scratch serves one stream)
     const bool include_kl = flags & 2, timed = flags & 4;
@@ -421,6 +434,9 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     // and tell the launchers so (ctx->prezeroed): a dozen ~5 us fill launches fewer per step.  Large problems keep the launchers'
     // own clears (only the products that actually split K clear anything there).
     const bool prezero = pl->arena_bytes <= ((size_t)48 << 20) && !ctx->det_slab;
+    static const bool preclear_env = !getenv("DSVGP_PRECLEAR") || atoi(getenv("DSVGP_PRECLEAR")) != 0;
+    pl->precleared = preclear && preclear_env && overlap && !prezero && !ctx->det_slab && !(flags & (16 | 32 | 64));
+    pl->precleared_ge = false;
     STEP_HIP(hipMemsetAsync(io->flat, 0, io->flat_floats * sizeof(float), main));
     if (prezero) STEP_HIP(hipMemsetAsync(w + pl->o_arena, 0, pl->arena_bytes, main));
     else STEP_HIP(hipMemsetAsync(w + pl->o_zero, 0, pl->zero_bytes, main));
@@ -508,9 +524,20 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
     // and the main stream -- the step's critical path from here to the end of the chain -- sat idle for that long at M' = 600; behind the
     // chain's launches the host is ahead of the device and the prologue still starts under the chain's first launches
     STEP_CALL(zz_fwd(ctx, io, PZ, sZ, M, d, p, hyp, L, Mp));
+    auto clear_tail_targets = [&]() -> int {        // the Cholesky backward's two products and the Phi argument (read behind step_front's end only)
+        STEP_HIP(hipMemsetAsync(Yt, 0, (size_t)Mp * Mp * sizeof(double), side));
+        STEP_HIP(hipMemsetAsync(Kbar, 0, (size_t)Mp * Mp * sizeof(double), side));
+        STEP_HIP(hipMemsetAsync(w + pl->o_phi32, 0, (size_t)Mp * ldQ32 * sizeof(float), side));
+        return 0;
+    };
     auto side_prologue = [&]() -> int {      // (queued BEHIND the chain's launches on the host, see above; it only waits for ev_fork on the device)
         if (!overlap) return 0;
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork, 0));
+        if (pl->precleared && !s_late) {       // (under the chain: measured level at M' = 3000 -- the fills cost the chain what they save later)
+            STEP_CALL(clear_tail_targets());
+            STEP_HIP(hipMemsetAsync(Ge, 0, (size_t)(Mp + 1) * Mp * sizeof(float), side));
+            pl->precleared_ge = true;
+        }
         ctx->stream = side;
         const int rc = prologue(true);
         ctx->stream = main;
@@ -550,8 +577,9 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         STEP_HIP(hipStreamWaitEvent(side, pl->ev_fork2, 0));
         STEP_HIP(hipMemcpyAsync(pl->host_status, hyp, 5 * sizeof(float), hipMemcpyDeviceToHost, side));     // hyp[4] | info: contiguous
         STEP_HIP(hipEventRecord(pl->ev_status, side));
-        if (s_late) {           // [S - I | m'] beside the forward solve (see prologue_s above)
-            ctx->stream = side;
+        if (s_late) {           // [S - I | m'] beside the forward solve (see prologue_s above); in front of it the fills of `preclear`
+            if (pl->precleared) STEP_CALL(clear_tail_targets());     // (ordered by the wait for ev_s at the end of this function; [tril(G) ; b^T]
+            ctx->stream = side;                                      //  is needed before that: its launcher keeps its own fill)
             const int rc = prologue_s(s_late == 1);
             ctx->stream = main;
             if (rc) return rc;
@@ -582,9 +610,11 @@ static int step_front(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const dsvgp_elbo_step
         }
         STEP_CALL(dsvgp_split3_bf16(ctx, A32e, Bp, Mp + 1, Bp, 0, io->split_ws));
         STEP_CALL(dsvgp_gemm3b(ctx, DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.f, io->split_ws, Mp + 1, io->split_ws, Mp + 1, Ge, Mp));
-    } else
-    STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
-                         Mp, nullptr, 0, nullptr));
+    } else {
+        ZeroedScope zs(ctx, pl->precleared_ge);
+        STEP_CALL(dsvgp_gemm(ctx, 0, DSVGP_GEMM_TRANS_B | DSVGP_GEMM_OUT_LOWER, Mp + 1, Mp, Bp, 1.0, A32e, Bp, A32, Bp, 0.0, nullptr, 0, Ge,
+                             Mp, nullptr, 0, nullptr));
+    }
     STEP_TIME(7);
     if (s_late) STEP_HIP(hipStreamWaitEvent(main, pl->ev_s, 0));       // ([S - I | m'] is final: every later reader is behind this point)
     return 0;
@@ -603,7 +633,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
         PrezeroGuard(dsvgp_ctx* c_, bool on) : c(c_), prev(c_->prezeroed) { c->prezeroed = on; }
         ~PrezeroGuard() { c->prezeroed = prev; }
     } prezero_guard(ctx, pl->arena_bytes <= ((size_t)48 << 20) && !ctx->det_slab);
-    STEP_CALL(step_front(ctx, pl, io, workspace, flags));
+    STEP_CALL(step_front(ctx, pl, io, workspace, flags, true));
     float* A32 = A32e;
     STEP_CALL(dsvgp_mirror_lower_f32(ctx, Ge, Mp, Mp));
     // ---- variational block (needs only G): L_S-bar = 2 vbar tril(G L_S) + KL gradient, m-bar = b + KL gradient, trace terms, scalars
@@ -670,7 +700,7 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     // Cholesky backward.  STEP_PHI64 / flag 64 / shapes gemm32 does not take: the fp64-accumulated form.
     auto phi_arg = [&](bool qe32_free) -> int {
 #if !STEP_PHI64
-        const bool own = ctx->prezeroed && pl->phi32_own;          // (its own, already cleared place in the arena: step_layout)
+        const bool own = (ctx->prezeroed || pl->precleared) && pl->phi32_own;          // (its own, already cleared place: step_layout / preclear)
         if ((qe32_free || own) && !(flags & 64)) {
             GemmArgs g{};
             float* P32 = own ? (float*)(w + pl->o_phi32) : Qe32;
@@ -692,12 +722,15 @@ extern "C" int dsvgp_elbo_step_f32(dsvgp_ctx* ctx, dsvgp_step_plan* pl, const ds
     auto chol_tail = [&](bool qe32_free) -> int {
         int rc = phi_arg(qe32_free);                                // S = Phi(P) + Phi(P)^T of P = tril(L^T L-bar), fp64, full
         if (rc) return rc;
-        rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
-                        nullptr, 0, Yt, Mp, nullptr, 0, nullptr);
-        if (rc) return rc;
-        rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0,
-                        nullptr, 0, Kbar, Mp, nullptr, 0, nullptr);
-        if (rc) return rc;
+        {
+            ZeroedScope zs(ctx, pl->precleared);
+            rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_B_LOWER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 1.0, G1, Mp, Linv, Mp, 0.0,
+                            nullptr, 0, Yt, Mp, nullptr, 0, nullptr);
+            if (rc) return rc;
+            rc = dsvgp_gemm(ctx, 1, DSVGP_GEMM_TRANS_A | DSVGP_GEMM_A_UPPER | DSVGP_GEMM_OUT_LOWER, Mp, Mp, Mp, 0.5, Linv, Mp, Yt, Mp, 0.0,
+                            nullptr, 0, Kbar, Mp, nullptr, 0, nullptr);
+            if (rc) return rc;
+        }
         return dsvgp_phi_symmetrize(ctx, Kbar, Mp, Mp);
     };
     // tail_side: the whole M'^3 tail (L-bar, Cholesky backward) follows the variational block on the side stream, under the dense
