@@ -2184,6 +2184,13 @@ constexpr int CAN_LDT = 52;            // row stride of the 48 x 48 output / ups
 #ifndef CAN_BWD_DMA
 #define CAN_BWD_DMA 1                  // 0: the backward kernel reads the upstream micro-blocks straight into registers (tools: the A/B)
 #endif
+#ifndef CAN_FWD_NT
+#define CAN_FWD_NT 1                   // a result larger than the memory-side cache leaves as NON-TEMPORAL stores (ovec bit 2, set by the launcher from 192 MB up): written
+                                       // once, read by the forward solve a millisecond later, whatever of it is cached by then (cold result buffer: 77 -> 69 us at C4)
+#endif
+#ifndef CAN_BWD_NT
+#define CAN_BWD_NT 0                   // 1: the upstream tile's LDS-DMA loads with the nt bit (probe)
+#endif
 #ifndef CAN_FWD_STRIDED
 #define CAN_FWD_STRIDED 1
 #endif
@@ -2395,7 +2402,9 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
                 const int id = lane + 64 * u, r = id / 12, c4 = (id - 12 * r) * 4;
                 const f4 x = *reinterpret_cast<const f4*>(TT + r * CAN_LDT + c4);
                 if ((CAN_ABL & 4) && ((ct & 1) ? c4 < 16 : c4 >= 32)) continue;   // (tools: only the whole 128-byte line of each row piece)
-                if (!(CAN_ABL & 1)) *reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4) = x;
+                if (CAN_ABL & 1) continue;
+                if (CAN_FWD_NT && (ovec & 4)) __builtin_nontemporal_store(x, reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4));
+                else *reinterpret_cast<f4*>(orow + (int64_t)r * ld + c4) = x;
             }
         } else {
 #pragma unroll
@@ -2421,8 +2430,13 @@ __global__ __launch_bounds__(64, CAN_FWD_MINW) void kernel_fwd_canon_kernel(cons
 // set and restored inside the statement.
 __device__ __forceinline__ void can_dma16(const float* gsrc, unsigned lds_byte_addr) {
     unsigned keep;
+#if CAN_BWD_NT
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+#endif
 }
 
 // backward: upstream micro-blocks HBM -> registers, the pair kernel's transform with (w_b, -u_a, G_ab) from the canonical sources;
@@ -2793,7 +2807,8 @@ extern "C" int dsvgp_kernel_fwd_canon(dsvgp_ctx* ctx, const float* P1, const flo
     if (ns < 1) ns = 1;
     if (ns > ctiles) ns = ctiles;
     const size_t lds = sizeof(float) * (((16 * (size_t)(g.K4 + 5) + 3) & ~(size_t)3) + 48 * (size_t)CAN_LDT);
-    const int ovec = (ld % 4 == 0 && (uintptr_t)out % 16 == 0) ? 2 : 0;
+    const int ovec = ((ld % 4 == 0 && (uintptr_t)out % 16 == 0) ? 2 : 0) |
+                     ((size_t)n1q * (size_t)n2 * g.q * sizeof(float) >= ((size_t)192 << 20) ? 4 : 0);      // (bit 2: non-temporal stores, CAN_FWD_NT)
     dim3 grid(ns, rt);
     if (g.q == 6)
         hipLaunchKernelGGL((kernel_fwd_canon_kernel<6>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, n2, g.K4, g.DP, dir_idx,
