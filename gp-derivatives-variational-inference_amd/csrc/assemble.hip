@@ -411,12 +411,15 @@ __global__ __launch_bounds__(64, FWDP_MINW) void kernel_fwd_pair_kernel(const fl
         }
         pselfv = (lane < T && c0_ + lane < n2q) ? -self2[c0_ + lane] : 0.f;
     };
+    // ovec bit 3 (the one-call steps' K_ZZ: ctx->fwd_lower_only): only the column tiles that reach into the 64 x 64 blocks on or below the block
+    // diagonal of this row tile's rows -- what the blocked Cholesky factorisation reads
+    const int ct_end = (ovec & 8) ? min(ncoltiles, (64 * ((row0 + T - 1) / 64) + 63) / T + 1) : ncoltiles;
 #if FWDP_CHUNK
     // consecutive column tiles per wave: the 192-byte row pieces of neighbouring tiles complete each other's 128-byte lines in ONE L2
-    const int cper = (ncoltiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int ct_lo = blockIdx.x * cper, ct_hi = min(ct_lo + cper, ncoltiles), ct_step = 1;
+    const int cper = (ct_end + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ct_lo = blockIdx.x * cper, ct_hi = min(ct_lo + cper, ct_end), ct_step = 1;
 #else
-    const int ct_lo = blockIdx.x, ct_hi = ncoltiles, ct_step = gridDim.x;
+    const int ct_lo = blockIdx.x, ct_hi = ct_end, ct_step = gridDim.x;
 #endif
     if (FWDP_OVERLAY && ct_lo < ct_hi) prefetch(ct_lo);
     for (int ct = ct_lo; ct < ct_hi; ct += ct_step) {
@@ -2887,6 +2890,9 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon2_kernel(const float* __re
     float* X2s = X1s + RP * DP;             // [CP][DP]
     const int lane = threadIdx.x, i = lane >> 4, j = lane & 15;
     const int p0 = blockIdx.y * RP, j0 = blockIdx.x * CP;
+    // ovec bit 3 (ctx->fwd_lower_only, K_ZZ of the one-call steps): tiles entirely to the right of the 64 x 64 blocks on the block diagonal
+    // of these rows are not read by the Cholesky factorisation
+    if ((ovec & 8) && (int64_t)j0 * Q > 64 * (((int64_t)p0 * Q + H - 1) / 64) + 63) return;
     for (int e = lane; e < RP * DP; e += 64) {
         const int r = e / DP, k = e - r * DP;
         X1s[e] = (p0 + r < n1) ? P1[(int64_t)(p0 + r) * Q * DP + k] : 0.f;
@@ -2929,7 +2935,7 @@ __global__ __launch_bounds__(64) void kernel_fwd_canon2_kernel(const float* __re
     WAVE_SYNC();
     const int64_t row0 = (int64_t)p0 * Q, col0 = (int64_t)j0 * Q;
     const int64_t n1q = (int64_t)n1 * Q, n2q = (int64_t)n2 * Q;
-    const bool full = ovec && row0 + H <= n1q && col0 + W <= n2q;
+    const bool full = (ovec & 1) && row0 + H <= n1q && col0 + W <= n2q;
     OT* obase = out + row0 * ld + col0;
     for (int id = lane; id < NCH; id += 64) {
         const int r = id / CPR, c4 = (id - r * CPR) * 4;
@@ -3117,7 +3123,8 @@ extern "C" int dsvgp_kernel_fwd_canon2(dsvgp_ctx* ctx, const float* P1, int n1, 
     if (!canon2_ok(g)) return DSVGP_EINVAL;
     if (n1 == 0 || n2 == 0) return 0;
     if (ld < (int64_t)n2 * g.q) return DSVGP_EINVAL;
-    const int ovec = out_is_double ? (ld % 2 == 0 && (uintptr_t)out % 16 == 0) : (ld % 4 == 0 && (uintptr_t)out % 16 == 0);
+    const int ovec = ((out_is_double ? (ld % 2 == 0 && (uintptr_t)out % 16 == 0) : (ld % 4 == 0 && (uintptr_t)out % 16 == 0)) ? 1 : 0) |
+                     ((ctx->fwd_lower_only && P1 == P2 && n1 == n2) ? 8 : 0);
     const size_t lds = sizeof(float) * (64 * (size_t)g.q * g.q + 20 * (size_t)g.DP);
     dim3 grid(cdiv(n2, 16), cdiv(n1, 4));
     if (out_is_double)
@@ -3321,7 +3328,8 @@ extern "C" int dsvgp_kernel_fwd(dsvgp_ctx* ctx, const float* P1, const float* se
         const int esz = out_is_double ? 8 : 4;
         // bit 0: 2-wide stores of the micro-block rows; bit 1: 16-byte stores of lane pairs (float output, 16-byte aligned rows)
         const int ovec = (((ld % 2 == 0) && ((uintptr_t)out % (2 * esz) == 0)) ? 1 : 0) |
-                         ((!out_is_double && ld % 4 == 0 && (uintptr_t)out % 16 == 0 && FWDP_ST16) ? 2 : 0);
+                         ((!out_is_double && ld % 4 == 0 && (uintptr_t)out % 16 == 0 && FWDP_ST16) ? 2 : 0) |
+                         ((ctx->fwd_lower_only && P1 == P2 && n1 == n2) ? 8 : 0);       // (bit 3: the block triangle the Cholesky factorisation reads)
         dim3 grid(ns, rt);
 #define DSVGP_FWD_PAIR(OT_, Q_, KSM_)                                                                                \
         hipLaunchKernelGGL((kernel_fwd_pair_kernel<OT_, Q_, KSM_>), grid, dim3(64), lds, ctx->stream, P1, self1, n1q, P2, self2, \

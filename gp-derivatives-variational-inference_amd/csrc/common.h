@@ -25,6 +25,10 @@ struct dsvgp_ctx {
     // set by dsvgp_elbo_step_f32 around its two kernel backwards (K_ZX-bar, K_ZZ-bar): their last launch -- kernel_bwd_points_kernel,
     // which adds the tile kernels' slabs into d_x1 / d_v1 / d_hyp -- is not queued but noted here, and dsvgp_kernel_bwd_points_flush runs
     // ONE such launch over both slab sets, with the step's scalar tail folded in (round 6: three ~5 us launches fewer at M' = 600)
+    // set by the one-call steps around K_ZZ's assembly: the result goes straight into the blocked Cholesky factorisation, which reads the
+    // 64 x 64 blocks on and below the block diagonal only -- the assembly kernels that know the switch skip the column tiles that lie
+    // entirely to the right of them (round 6: 47 -> ~25 us on the step's critical path at M' = 3000)
+    bool fwd_lower_only = false;
     struct PointsJob { const float* slab; int ns; const float* partials; int nparts; float sym; };
     bool defer_points = false;
     int n_deferred = 0;

@@ -73,6 +73,9 @@ struct dsvgp_step_plan {
 };
 
 // workspace layout of one (M, d, p, B); returns the total byte count (0: unsupported shape)
+#ifndef STEP_KZZ_LOWER
+#define STEP_KZZ_LOWER 1            // K_ZZ assembled on and below its 64-wide block diagonal only (what potrf.hip reads)
+#endif
 #ifndef STEP_S_LATE
 #define STEP_S_LATE 2               // [S - I | m'] behind the chain, beside the forward solve: 1 as a one-workgroup-per-CU filler, 2 at full grid
 #define STEP_S_LATE_MP 1024         // ... from this M' up (below: under the chain, as in rounds 2-5)
@@ -335,6 +338,13 @@ static inline bool zz_canon2(const dsvgp_elbo_step_io* io, int d, int p) {
 static inline bool rows_in_16_byte_pieces(const void* G, int64_t ldg, int esz) { return ldg % (16 / esz) == 0 && (uintptr_t)G % 16 == 0; }
 static int zz_fwd(dsvgp_ctx* ctx, const dsvgp_elbo_step_io* io, const float* PZ, const float* sZ, int M, int d, int p, const float* hyp,
                   double* L, int64_t ld) {
+    // (the result is factored in place by the blocked Cholesky chain, which reads the 64 x 64 blocks on and below the block diagonal only:
+    //  the assembly skips the rest -- common.h: fwd_lower_only)
+    struct LowerOnly {
+        dsvgp_ctx* c; bool prev;
+        LowerOnly(dsvgp_ctx* c_) : c(c_), prev(c_->fwd_lower_only) { c->fwd_lower_only = STEP_KZZ_LOWER != 0; }
+        ~LowerOnly() { c->fwd_lower_only = prev; }
+    } lower_only(ctx);
     if (zz_canon2(io, d, p))
         return dsvgp_kernel_fwd_canon2(ctx, PZ, M, PZ, M, d, p, io->dir_idx, io->dir_idx_base, hyp, io->kzz_jitter, L, ld, 1);
     return dsvgp_kernel_fwd(ctx, PZ, sZ, M, PZ, sZ, M, d, p, hyp, io->kzz_jitter, L, ld, 1);
